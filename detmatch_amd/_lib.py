@@ -1,0 +1,110 @@
+"""ctypes binding of libdetmatch_hip.so (include/detmatch_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  Loading
+fails loudly when the .so is missing, and every op raises when handed a tensor
+that is not on a HIP device.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdetmatch_hip.so')
+_lib = None
+
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_i32_p = ctypes.POINTER(ctypes.c_int32)
+c_f32_p = ctypes.POINTER(ctypes.c_float)
+vp = ctypes.c_void_p
+ci = ctypes.c_int
+sz = ctypes.c_size_t
+cf = ctypes.c_float
+
+# name -> (restype, argtypes); must list EVERY symbol include/detmatch_hip.h declares
+SIGNATURES = {
+    'dm_version': (ctypes.c_char_p, []),
+    'dm_error_string': (ctypes.c_char_p, [ci]),
+    'dm_hard_voxelize_workspace_bytes': (sz, [ci, ci]),
+    'dm_hard_voxelize': (ci, [vp, ci, ci, c_i32_p, ci, c_f32_p, c_f32_p, ci, ci, ci, vp, vp, vp,
+                              vp, vp, vp, sz, vp]),
+    'dm_rulebook_workspace_bytes': (sz, [ci, ci]),
+    'dm_rulebook_subm': (ci, [vp, ci, ci, c_int_p, c_int_p, vp, vp, vp, vp, sz, vp]),
+    'dm_rulebook_conv_count': (ci, [vp, ci, ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, vp,
+                                    vp, sz, vp]),
+    'dm_rulebook_conv_fill': (ci, [vp, ci, ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, ci,
+                                   vp, vp, vp, vp, vp, vp, sz, vp]),
+    'dm_pairs_to_table': (ci, [vp, vp, ci, ci, ci, vp, ci, vp]),
+    'dm_spconv_workspace_bytes': (sz, [ci, ci, ci]),
+    'dm_spconv_gather_gemm': (ci, [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, sz, vp]),
+    'dm_spconv_wgrad_workspace_bytes': (sz, [ci, ci, ci, ci]),
+    'dm_spconv_wgrad': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
+}
+
+
+class DetMatchHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the C-ABI library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DetMatchHipError(
+                '%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950). There is no fallback path.' % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().dm_error_string(int(code)).decode()
+        raise DetMatchHipError('%s failed: %s (code %d)' % (what, msg, code))
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise DetMatchHipError(
+                'detmatch_amd ops run on the MI355X only (got a %s tensor); there is no CPU path'
+                % t.device)
+        if not t.is_contiguous():
+            raise DetMatchHipError('tensor must be contiguous')
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ints(v):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])
+
+
+def floats(v):
+    return (ctypes.c_float * len(v))(*[float(x) for x in v])
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag='default'):
+    """A reusable byte workspace per (device, tag); grows geometrically."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,175 @@
+"""mmdet3d/ops/spconv/ops.py — same function names / argument meaning; compute in
+libdetmatch_hip.so (rulebook.hip, spconv.hip) through the C-ABI."""
+import torch
+
+from .. import _lib
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """ops.py:20-31"""
+    output_size = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) \
+            // stride[i] + 1
+        output_size.append(1 if kernel_size[i] == -1 else size)
+    return output_size
+
+
+class Rulebook(object):
+    """Native rulebook of one indice_key: gather tables + reference-format pair lists."""
+    __slots__ = ('outids', 'indice_pairs', 'indice_num', 'nbr_out', 'nbr_in', 'subm', 'kvol',
+                 'n_in', 'n_out', 'out_shape')
+
+    def as_reference_tuple(self):
+        return self.outids, self.indice_pairs, self.indice_num
+
+
+def _norm(v, ndim):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                   subm=False, with_pairs=True):
+    """Native rulebook build.  indices (N,4) int32 [b,z,y,x] on the GPU."""
+    ndim = indices.shape[1] - 1
+    if ndim != 3:
+        raise NotImplementedError('only 3-D sparse convolution is on the DetMatch path')
+    ksize, stride, padding, dilation = (_norm(v, 3) for v in (ksize, stride, padding, dilation))
+    if any(d != 1 for d in dilation):
+        raise NotImplementedError('dilation != 1 is not used by VoxelBackBone8x')
+    if indices.dtype != torch.int32:
+        indices = indices.int()
+    indices = indices.contiguous()
+    _lib.require_device(indices)
+    L = _lib.lib()
+    dev = indices.device
+    n = indices.shape[0]
+    kvol = ksize[0] * ksize[1] * ksize[2]
+    rb = Rulebook()
+    rb.subm, rb.kvol, rb.n_in = bool(subm), kvol, n
+    wsb = L.dm_rulebook_workspace_bytes(n, kvol)
+    ws = _lib.workspace(wsb, dev, 'rulebook')
+    rb.indice_num = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    rb.indice_pairs = (torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
+                       if with_pairs else None)
+    spatial = [int(s) for s in spatial_shape]
+    if subm:
+        rb.out_shape = spatial
+        rb.nbr_out = torch.empty((kvol, n), dtype=torch.int32, device=dev)
+        rb.nbr_in = None
+        rc = L.dm_rulebook_subm(_lib.ptr(indices), n, int(batch_size), _lib.ints(spatial),
+                                _lib.ints(ksize), _lib.ptr(rb.nbr_out), _lib.ptr(rb.indice_pairs),
+                                _lib.ptr(rb.indice_num), _lib.ptr(ws), ws.numel(), _lib.stream())
+        _lib.check(rc, 'dm_rulebook_subm')
+        rb.outids = indices
+        rb.n_out = n
+        return rb
+    out_shape = get_conv_output_size(spatial, ksize, stride, padding, dilation)
+    rb.out_shape = out_shape
+    n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+    args = (_lib.ptr(indices), n, int(batch_size), _lib.ints(spatial), _lib.ints(out_shape),
+            _lib.ints(ksize), _lib.ints(stride), _lib.ints(padding))
+    rc = L.dm_rulebook_conv_count(*args, _lib.ptr(n_out_dev), _lib.ptr(ws), ws.numel(),
+                                  _lib.stream())
+    _lib.check(rc, 'dm_rulebook_conv_count')
+    # the one data-dependent size of the layer (reference: outInds.slice(0, 0, numActOut),
+    # spconv_ops.h:139, which also costs a device->host read)
+    n_out = int(n_out_dev.item())
+    rb.n_out = n_out
+    rb.outids = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+    rb.nbr_out = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
+    rb.nbr_in = torch.empty((kvol, n), dtype=torch.int32, device=dev)
+    rc = L.dm_rulebook_conv_fill(*args, n_out, _lib.ptr(rb.outids), _lib.ptr(rb.nbr_out),
+                                 _lib.ptr(rb.nbr_in), _lib.ptr(rb.indice_pairs),
+                                 _lib.ptr(rb.indice_num), _lib.ptr(ws), ws.numel(), _lib.stream())
+    _lib.check(rc, 'dm_rulebook_conv_fill')
+    return rb
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                     out_padding=0, subm=False, transpose=False, grid=None):
+    """ops.py:46-105 -> (outids, indice_pairs (K,2,N), indice_pair_num (K)).
+
+    The native gather tables ride along on the returned `indice_pairs` tensor
+    (attribute `dm_tables`) so that indice_conv can use them without rebuilding."""
+    if transpose:
+        raise NotImplementedError('transposed sparse conv is off the DetMatch hot path')
+    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+    # (nbr_out, nbr_in, subm) — a plain tuple, so no reference cycle through the tensor
+    rb.indice_pairs.dm_tables = (rb.nbr_out, rb.nbr_in, rb.subm)
+    return rb.outids, rb.indice_pairs, rb.indice_num
+
+
+def _tables_for(indice_pairs, indice_pair_num, n_in, n_out, subm):
+    tabs = getattr(indice_pairs, 'dm_tables', None)
+    if tabs is not None:
+        return tabs[0], (tabs[0] if tabs[2] else tabs[1])
+    # foreign (reference-format) rulebook: rebuild the gather tables from the pair lists
+    L = _lib.lib()
+    kvol, _, stride = indice_pairs.shape
+    dev = indice_pairs.device
+    nbr_out = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
+    _lib.check(L.dm_pairs_to_table(_lib.ptr(indice_pairs), _lib.ptr(indice_pair_num), kvol, stride,
+                                   1, _lib.ptr(nbr_out), n_out, _lib.stream()), 'dm_pairs_to_table')
+    if subm:
+        return nbr_out, nbr_out
+    nbr_in = torch.empty((kvol, n_in), dtype=torch.int32, device=dev)
+    _lib.check(L.dm_pairs_to_table(_lib.ptr(indice_pairs), _lib.ptr(indice_pair_num), kvol, stride,
+                                   0, _lib.ptr(nbr_in), n_in, _lib.stream()), 'dm_pairs_to_table')
+    return nbr_out, nbr_in
+
+
+def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k):
+    L = _lib.lib()
+    kvol = nbr.shape[0]
+    dev = feat.device
+    out = torch.empty((n_rows_out, cin if transpose_w else cout), dtype=torch.float32, device=dev)
+    ws = _lib.workspace(L.dm_spconv_workspace_bytes(kvol, cin, cout), dev, 'spconv')
+    rc = L.dm_spconv_gather_gemm(_lib.ptr(feat), feat.shape[0], _lib.ptr(filters), _lib.ptr(nbr),
+                                 n_rows_out, kvol, cin, cout, int(transpose_w), int(flip_k),
+                                 _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream())
+    _lib.check(rc, 'dm_spconv_gather_gemm')
+    return out
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
+                inverse=False, subm=False):
+    """ops.py:108-126 / spconv_ops.h:260-360 (fp32)."""
+    if inverse:
+        raise NotImplementedError('inverse sparse conv is off the DetMatch hot path')
+    if filters.dtype != torch.float32 or features.dtype != torch.float32:
+        raise NotImplementedError('fp32 only (no DetMatch config sets fp16)')
+    features = features.contiguous()
+    filters = filters.contiguous()
+    _lib.require_device(features, filters, indice_pairs)
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    nbr_out, _ = _tables_for(indice_pairs, indice_pair_num, features.shape[0],
+                             int(num_activate_out), subm)
+    return _gather_gemm(features, filters, nbr_out, int(num_activate_out), cin, cout, 0, 0)
+
+
+def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num,
+                         inverse=False, subm=False, need_input_grad=True):
+    """ops.py:142-158 / spconv_ops.h:363-456 -> [input_bp, filters_bp]."""
+    if inverse:
+        raise NotImplementedError('inverse sparse conv is off the DetMatch hot path')
+    features = features.contiguous()
+    filters = filters.contiguous()
+    out_bp = out_bp.contiguous()
+    _lib.require_device(features, filters, out_bp, indice_pairs)
+    L = _lib.lib()
+    dev = features.device
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    kvol, _, stride = indice_pairs.shape
+    n_in, n_out = features.shape[0], out_bp.shape[0]
+    input_bp = None
+    if need_input_grad:
+        _, nbr_in = _tables_for(indice_pairs, indice_pair_num, n_in, n_out, subm)
+        input_bp = _gather_gemm(out_bp, filters, nbr_in, n_in, cin, cout, 1, 1 if subm else 0)
+    filters_bp = torch.empty_like(filters)
+    ws = _lib.workspace(L.dm_spconv_wgrad_workspace_bytes(stride, kvol, cin, cout), dev, 'wgrad')
+    rc = L.dm_spconv_wgrad(_lib.ptr(features), _lib.ptr(out_bp), _lib.ptr(indice_pairs),
+                           _lib.ptr(indice_pair_num), stride, kvol, cin, cout,
+                           _lib.ptr(filters_bp), _lib.ptr(ws), ws.numel(), _lib.stream())
+    _lib.check(rc, 'dm_spconv_wgrad')
+    return input_bp, filters_bp

@@ -1,0 +1,148 @@
+"""Seeded synthetic KITTI-/Waymo-shaped frames (SURVEY.md §8(d) "Synthetic inputs").
+
+A tiny ray-cast LiDAR simulator: sensor at the origin, ground plane, two facade
+planes and a handful of oriented cuboids (Car / Pedestrian / Cyclist sizes).
+Uniform-random points are NOT acceptable for this path (they give ~1 rulebook
+pair per voxel); ray-cast surfaces reproduce the sub-manifold neighbour counts
+of real scans (≈4 / 8.6 / 10.5 / 10.5 pairs per voxel at strides 1/2/4/8).
+
+Everything here is numpy on the host; it is data generation, not the hot path.
+"""
+import numpy as np
+
+KITTI_RANGE = (0.0, -40.0, -3.0, 70.4, 40.0, 1.0)
+KITTI_VOXEL = (0.05, 0.05, 0.1)
+WAYMO_RANGE = (-75.2, -75.2, -2.0, 75.2, 75.2, 4.0)
+WAYMO_VOXEL = (0.1, 0.1, 0.15)
+
+# (l, w, h) along the box's own x / y / z
+CLASS_SIZES = np.array([[3.9, 1.6, 1.56],    # Car
+                        [0.8, 0.6, 1.73],    # Pedestrian
+                        [1.76, 0.6, 1.73]],  # Cyclist
+                       dtype=np.float64)
+
+# fixed KITTI-like projection P2 @ R0_rect @ Tr_velo_to_cam (4x4)
+_P2 = np.array([[721.5377, 0.0, 609.5593, 44.85728],
+                [0.0, 721.5377, 172.854, 0.2163791],
+                [0.0, 0.0, 1.0, 0.002745884],
+                [0.0, 0.0, 0.0, 1.0]])
+_R0 = np.array([[0.9999239, 0.00983776, -0.00744505, 0.0],
+                [-0.0098698, 0.9999421, -0.00427846, 0.0],
+                [0.00740253, 0.00435161, 0.9999631, 0.0],
+                [0.0, 0.0, 0.0, 1.0]])
+_TR = np.array([[0.00753374, -0.9999714, -0.00061660, -0.00406977],
+                [0.01480249, 0.00072807, -0.9998902, -0.07631618],
+                [0.9998621, 0.00752379, 0.01480755, -0.2717806],
+                [0.0, 0.0, 0.0, 1.0]])
+KITTI_LIDAR2IMG = (_P2 @ _R0 @ _TR).astype(np.float32)
+
+
+def _ray_obb(dirs, center, size, yaw):
+    """Slab-method ray / oriented-box intersection; rays start at the origin.
+
+    Returns the entry distance t (inf where the ray misses)."""
+    c, s = np.cos(yaw), np.sin(yaw)
+    # world -> box frame (rotation by -yaw about z)
+    ox = -(center[0] * c + center[1] * s)
+    oy = -(-center[0] * s + center[1] * c)
+    oz = -center[2]
+    dx = dirs[:, 0] * c + dirs[:, 1] * s
+    dy = -dirs[:, 0] * s + dirs[:, 1] * c
+    dz = dirs[:, 2]
+    tmin = np.full(dirs.shape[0], -np.inf)
+    tmax = np.full(dirs.shape[0], np.inf)
+    for o, d, h in ((ox, dx, size[0] / 2), (oy, dy, size[1] / 2),
+                    (oz, dz, size[2] / 2)):
+        with np.errstate(divide='ignore', invalid='ignore'):
+            inv = 1.0 / d
+            t0 = (-h - o) * inv
+            t1 = (h - o) * inv
+        lo = np.minimum(t0, t1)
+        hi = np.maximum(t0, t1)
+        par = np.abs(d) < 1e-12
+        lo = np.where(par, np.where(np.abs(o) <= h, -np.inf, np.inf), lo)
+        hi = np.where(par, np.where(np.abs(o) <= h, np.inf, -np.inf), hi)
+        tmin = np.maximum(tmin, lo)
+        tmax = np.minimum(tmax, hi)
+    hit = (tmax >= tmin) & (tmax > 0) & (tmin > 0)
+    return np.where(hit, tmin, np.inf)
+
+
+def lidar_frame(seed=0, full360=False, az_step_deg=None, n_boxes=None,
+                pc_range=None):
+    """One synthetic frame.
+
+    Returns dict(points (N,4) f32 [x,y,z,intensity], gt_boxes (G,7) f32 in the
+    mmdet3d LiDAR convention [x,y,z_bottom... no: gravity-centre x,y,z,l,w,h,yaw],
+    gt_labels (G,) i64)."""
+    rng = np.random.default_rng(seed)
+    if pc_range is None:
+        pc_range = WAYMO_RANGE if full360 else KITTI_RANGE
+    if az_step_deg is None:
+        az_step_deg = 0.113 if full360 else 0.28
+    if n_boxes is None:
+        n_boxes = 40 if full360 else 12
+    ground_z = -1.73
+    elev = np.deg2rad(np.linspace(2.0, -24.8, 64))
+    if full360:
+        az = np.deg2rad(np.arange(-180.0, 180.0, az_step_deg))
+    else:
+        az = np.deg2rad(np.arange(-45.0, 45.0, az_step_deg))
+    ee, aa = np.meshgrid(elev, az, indexing='ij')
+    dirs = np.stack([np.cos(ee) * np.cos(aa), np.cos(ee) * np.sin(aa),
+                     np.sin(ee)], axis=-1).reshape(-1, 3)
+    n_rays = dirs.shape[0]
+    t = np.full(n_rays, np.inf)
+    # ground
+    with np.errstate(divide='ignore'):
+        tg = ground_z / dirs[:, 2]
+    tg = np.where((dirs[:, 2] < 0) & (tg > 0), tg, np.inf)
+    t = np.minimum(t, tg)
+    # two facades y = +a, y = -b, kept for ground_z < z < 3
+    for sign in (1.0, -1.0):
+        yw = sign * rng.uniform(9.0, 16.0)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            tf = yw / dirs[:, 1]
+        z = tf * dirs[:, 2]
+        ok = (tf > 0) & np.isfinite(tf) & (z > ground_z) & (z < 3.0)
+        t = np.minimum(t, np.where(ok, tf, np.inf))
+    # cuboids
+    labels = rng.integers(0, 3, size=n_boxes)
+    rmax = 55.0
+    rr = rng.uniform(6.0, rmax, size=n_boxes)
+    if full360:
+        bearing = rng.uniform(-np.pi, np.pi, size=n_boxes)
+    else:
+        bearing = rng.uniform(-0.6, 0.6, size=n_boxes)
+    yaw = rng.uniform(-np.pi, np.pi, size=n_boxes)
+    boxes = np.zeros((n_boxes, 7), dtype=np.float64)
+    for b in range(n_boxes):
+        size = CLASS_SIZES[labels[b]]
+        ctr = np.array([rr[b] * np.cos(bearing[b]), rr[b] * np.sin(bearing[b]),
+                        ground_z + size[2] / 2])
+        boxes[b] = [ctr[0], ctr[1], ctr[2], size[0], size[1], size[2], yaw[b]]
+        t = np.minimum(t, _ray_obb(dirs, ctr, size, yaw[b]))
+    hit = np.isfinite(t) & (t < 75.0 * (1.5 if full360 else 1.0))
+    pts = dirs[hit] * t[hit, None]
+    pts = pts + rng.normal(0.0, 0.01, size=pts.shape)
+    keep = ((pts[:, 0] >= pc_range[0]) & (pts[:, 0] < pc_range[3]) &
+            (pts[:, 1] >= pc_range[1]) & (pts[:, 1] < pc_range[4]) &
+            (pts[:, 2] >= pc_range[2]) & (pts[:, 2] < pc_range[5]))
+    pts = pts[keep]
+    inten = rng.uniform(0.0, 1.0, size=(pts.shape[0], 1))
+    pts = np.concatenate([pts, inten], axis=1).astype(np.float32)
+    perm = rng.permutation(pts.shape[0])
+    pts = np.ascontiguousarray(pts[perm])
+    return dict(points=pts, gt_boxes=boxes.astype(np.float32),
+                gt_labels=labels.astype(np.int64))
+
+
+def kitti_batch(batch_size, seed=0):
+    """`batch_size` KITTI-shaped frames with seeds seed, seed+1, …"""
+    return [lidar_frame(seed + i) for i in range(batch_size)]
+
+
+def kitti_image(seed=0, shape=(384, 1280)):
+    """Seeded uint8 noise image already resized/padded to a /32 shape."""
+    rng = np.random.default_rng(10_000 + seed)
+    return rng.integers(0, 256, size=(shape[0], shape[1], 3), dtype=np.uint8)

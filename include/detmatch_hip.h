@@ -1,0 +1,192 @@
+/*
+ * detmatch_hip.h — C-ABI of libdetmatch_hip.so, the MI355X (gfx950) native
+ * operator library behind the DetMatch training step.
+ *
+ * This is the drop-in boundary "B2" of SURVEY.md §8(b): every entry point
+ * replaces one pybind11/at::Tensor function of the reference's compiled
+ * extensions (file:line cited per function).  Signatures use plain pointers
+ * and sizes only — no torch types — so the same library binds from ctypes,
+ * pybind, cgo or JNI alike.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - tensors are dense row-major ("contiguous"), fp32 / int32 unless noted;
+ *   - `stream` is a hipStream_t (passed as void*); all work is stream-ordered,
+ *     nothing here calls hipMalloc / hipFree / hipDeviceSynchronize;
+ *   - scratch memory is caller-provided: ask `dm_*_workspace_bytes` first;
+ *   - return value: 0 = DM_OK, otherwise a DM_ERR_* code (never exit()):
+ *     see dm_error_string().  The reference reports errors by TORCH_CHECK /
+ *     TV_ASSERT_RT_ERR exceptions or fprintf+exit(-1) (iou3d_nms.cpp:14-25,
+ *     ball_query_gpu.cu:85-89); the Python host layer turns a non-zero code
+ *     into RuntimeError.
+ *   - ops whose OUTPUT SIZE is data dependent write the size to a device int32
+ *     and never sync; the caller decides when to read it back.
+ *
+ * Reference paths below are relative to the reference tree; `pcdet/` stands
+ * for thirdparty/Spconv-OpenPCDet/pcdet/ and `spconv/` for mmdet3d/ops/spconv/.
+ */
+#ifndef DETMATCH_HIP_H_
+#define DETMATCH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *dm_stream_t; /* hipStream_t */
+
+enum {
+  DM_OK = 0,
+  DM_ERR_INVALID_ARG = 1,   /* bad size / null pointer / unsupported shape   */
+  DM_ERR_WORKSPACE = 2,     /* workspace smaller than dm_*_workspace_bytes   */
+  DM_ERR_INT32_RANGE = 3,   /* batch * volume does not fit the int32 cell id */
+  DM_ERR_UNSUPPORTED = 4,   /* channel count / kernel volume not compiled in */
+  DM_ERR_LAUNCH = 5         /* hipGetLastError() != hipSuccess after launch  */
+};
+
+const char *dm_version(void);
+const char *dm_error_string(int code);
+
+/* ------------------------------------------------------------------------ */
+/* A. Hard voxelization  (+ fused MeanVFE)                                    */
+/* ------------------------------------------------------------------------ */
+/* Replaces voxel_layer.hard_voxelize
+ *   mmdet3d/ops/voxel/src/voxelization.h:51-69 (dispatch),
+ *   voxelization_cuda.cu:184-326 (hard_voxelize_gpu), semantics ==
+ *   voxelization_cpu.cpp:44-141,
+ * for a whole batch at once (the reference loops samples in Python,
+ * mmdet3d/models/detectors/openpcdet.py:61-76) and MeanVFE.forward
+ * (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-28).
+ *
+ * points          (n_total, c) all samples stacked; sample b owns rows
+ *                 [offsets_host[b], offsets_host[b+1])
+ * voxels          (batch*max_voxels, max_points, c)  zero-filled by the callee
+ * coors           (batch*max_voxels, coor_dim): coor_dim 3 -> [z,y,x]
+ *                 (reference layout), 4 -> [b,z,y,x] (already batch-padded as
+ *                 openpcdet.py:69-72 does)
+ * num_points      (batch*max_voxels)
+ * mean_feats      (batch*max_voxels, c) or NULL: sum over the voxel's points /
+ *                 max(num,1)
+ * voxel_counts    (batch+1) int32: [0..batch) = voxels kept per sample,
+ *                 [batch] = total.  Rows of all outputs are compacted: sample
+ *                 b's voxels start at sum(voxel_counts[0..b)).
+ * Voxel order = order of each voxel's first point; points beyond max_points in
+ * a voxel, and every point of a voxel first seen after max_voxels voxels of its
+ * sample exist, are dropped (bit-exact with the reference CPU path).
+ */
+size_t dm_hard_voxelize_workspace_bytes(int n_total, int batch);
+int dm_hard_voxelize(const float *points, int n_total, int c,
+                     const int32_t *offsets_host, int batch,
+                     const float *voxel_size_host /*[3] x,y,z*/,
+                     const float *coors_range_host /*[6]*/, int max_points,
+                     int max_voxels, int coor_dim, float *voxels, int32_t *coors,
+                     int32_t *num_points, float *mean_feats, int32_t *voxel_counts,
+                     void *workspace, size_t workspace_bytes, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* B. Sparse convolution: rulebook                                            */
+/* ------------------------------------------------------------------------ */
+/* Replaces sparse_conv_ext.get_indice_pairs_3d
+ *   spconv/src/all.cc:24, spconv/include/spconv/spconv_ops.h:28-141,
+ *   kernels spconv/include/spconv/indice.cu.h:24-204, geometry.h:25-86.
+ *
+ * The native rulebook is a pair of dense GATHER TABLES instead of 27
+ * atomically-filled pair lists:
+ *   nbr_out (kvol, n_out): nbr_out[k][o] = input row feeding output row o
+ *                          through kernel offset k, or -1
+ *   nbr_in  (kvol, n_in) : nbr_in[k][i]  = output row fed by input row i
+ *                          through offset k, or -1  (strided conv only; for a
+ *                          sub-manifold conv nbr_in[k] == nbr_out[kvol-1-k])
+ * plus, for API parity and for the weight-gradient kernel, the reference's
+ *   indice_pairs (kvol, 2, n_in) int32, -1 padded; [k][0][s] = in, [k][1][s] = out
+ *   indice_num   (kvol)
+ * Pair slots are filled in ascending OUTPUT row order (deterministic; the
+ * reference GPU order is an atomicAdd race, indice.cu.h:46-52).
+ * Kernel offset index k = kz*ky_size*kx_size + ky*kx_size + kx with
+ * k_axis = in - out*stride + pad  (geometry.h:62-71).
+ * Output rows of a strided conv are sorted by ascending flat cell id
+ * (b*vol + (z*Y + y)*X + x) — the reference GPU order (torch::_unique,
+ * spconv_ops.h:130).  dilation is 1 (the only value VoxelBackBone8x uses).
+ *
+ * Strided convs are two-phase because n_out is data dependent:
+ *   dm_rulebook_conv_count  -> n_out_dev (device int32), sorted cell ids kept
+ *                              in the workspace
+ *   (caller reads n_out, allocates exact-size outputs)
+ *   dm_rulebook_conv_fill   -> out_ids, tables, pair lists
+ * The same workspace must be passed, untouched, to both phases.
+ */
+size_t dm_rulebook_workspace_bytes(int n_in, int kvol);
+
+int dm_rulebook_subm(const int32_t *indices /*(n,4) b,z,y,x*/, int n, int batch,
+                     const int *spatial_shape_host /*[3] z,y,x*/,
+                     const int *ksize_host /*[3]*/, int32_t *nbr_out /*(kvol,n)*/,
+                     int32_t *indice_pairs /*(kvol,2,n) or NULL*/,
+                     int32_t *indice_num /*(kvol)*/, void *workspace,
+                     size_t workspace_bytes, dm_stream_t stream);
+
+int dm_rulebook_conv_count(const int32_t *indices, int n, int batch,
+                           const int *spatial_shape_host, const int *out_shape_host,
+                           const int *ksize_host, const int *stride_host,
+                           const int *padding_host, int32_t *n_out_dev,
+                           void *workspace, size_t workspace_bytes,
+                           dm_stream_t stream);
+
+int dm_rulebook_conv_fill(const int32_t *indices, int n, int batch,
+                          const int *spatial_shape_host, const int *out_shape_host,
+                          const int *ksize_host, const int *stride_host,
+                          const int *padding_host, int n_out,
+                          int32_t *out_ids /*(n_out,4)*/, int32_t *nbr_out /*(kvol,n_out)*/,
+                          int32_t *nbr_in /*(kvol,n)*/,
+                          int32_t *indice_pairs /*(kvol,2,n) or NULL*/,
+                          int32_t *indice_num /*(kvol)*/, void *workspace,
+                          size_t workspace_bytes, dm_stream_t stream);
+
+/* Rebuild a gather table from reference-format pair lists (for callers that
+ * hold a rulebook produced elsewhere).  side = 1: table[k][pairs[k][1][s]] =
+ * pairs[k][0][s] (n_rows = n_out, forward); side = 0: the transpose. */
+int dm_pairs_to_table(const int32_t *indice_pairs, const int32_t *indice_num,
+                      int kvol, int pair_stride, int side, int32_t *table,
+                      int n_rows, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* B. Sparse convolution: fused gather-GEMM-scatter                           */
+/* ------------------------------------------------------------------------ */
+/* Replaces sparse_conv_ext.indice_conv_fp32 / indice_conv_backward_fp32
+ *   spconv/src/all.cc:32-33, spconv_ops.h:260-360 (fwd), :363-456 (bwd),
+ *   kernels spconv/include/spconv/reordering.cu.h:22-160.
+ *
+ * out[o,:] = sum_k feat[nbr[k][o],:] @ W[k]          (output stationary, no
+ * atomics, no intermediate buffers, one launch per layer; fp32 MFMA
+ * v_mfma_f32_16x16x4_f32, exact fp32 fma chains).
+ * filters (kvol, cin, cout) = the reference's (kz,ky,kx,cin,cout) viewed flat.
+ *
+ * transpose_w = 0: forward.      B_k = W[k]            (cin -> cout)
+ * transpose_w = 1: input-gradient. feat := out_grad (n_rows_in x cout), the
+ *                  table is nbr_in, B_k = W[k]^T (cout -> cin); for a
+ *                  sub-manifold conv pass nbr_out and flip_k = 1 (B_k =
+ *                  W[kvol-1-k]^T).
+ * Supported channel counts: cin, cout in {4(in only),16,32,64,128}.
+ */
+size_t dm_spconv_workspace_bytes(int kvol, int cin, int cout);
+int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const float *filters,
+                          const int32_t *nbr /*(kvol, n_rows_out)*/, int n_rows_out,
+                          int kvol, int cin, int cout, int transpose_w, int flip_k,
+                          float *out /*(n_rows_out, transpose_w ? cin : cout)*/,
+                          void *workspace, size_t workspace_bytes, dm_stream_t stream);
+
+/* filt_grad[k] = sum_s feat[pairs[k][0][s],:]^T (x) out_grad[pairs[k][1][s],:]
+ * (spconv_ops.h:436-441).  Deterministic two-stage reduction (partial slabs in
+ * the workspace, then a fixed-order sum) — no float atomics. */
+size_t dm_spconv_wgrad_workspace_bytes(int n_in, int kvol, int cin, int cout);
+int dm_spconv_wgrad(const float *feat, const float *out_grad,
+                    const int32_t *indice_pairs /*(kvol,2,pair_stride)*/,
+                    const int32_t *indice_num /*(kvol) device*/, int pair_stride,
+                    int kvol, int cin, int cout, float *filt_grad /*(kvol,cin,cout)*/,
+                    void *workspace, size_t workspace_bytes, dm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETMATCH_HIP_H_ */
