@@ -1,0 +1,241 @@
+"""HIP sparse conv (rulebook + fused gather-GEMM + backward) vs the oracle, through the
+C-ABI.  Integer outputs bit-exact (output voxel list, pair SETS — the reference's GPU slot
+order is an atomicAdd race, so order inside a pair list is not part of the contract);
+fp32 features within rtol 1e-4 / atol 1e-5 (summation order differs: the oracle adds
+offset by offset like the reference, the kernel accumulates fma chains in MFMA order)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = [41, 1600, 1408]
+IDX = np.array([[0, 5, 5, 5], [0, 5, 5, 6], [0, 6, 5, 5], [0, 9, 9, 9]], np.int32)
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _pair_set(pairs, num, k):
+    return set(map(tuple, pairs[k, :, :num[k]].T.tolist()))
+
+
+def _build(dev, idx, batch, shape, ks, st, pd, subm):
+    from detmatch_amd.spconv import ops
+    t = torch.from_numpy(np.ascontiguousarray(idx)).to(dev)
+    return ops.build_rulebook(t, batch, shape, ks, st, pd, 1, subm)
+
+
+def _check_rulebook(orc, dev, idx, batch, shape, ks, st, pd, subm):
+    rb = _build(dev, idx, batch, shape, ks, st, pd, subm)
+    o, p, n, osh = orc.get_indice_pairs(idx, batch, shape, ks, st, pd, subm=subm, sort_out=True)
+    assert rb.out_shape == osh
+    assert np.array_equal(rb.outids.cpu().numpy(), o)            # output voxels + order: bit-exact
+    gn = rb.indice_num.cpu().numpy()
+    assert np.array_equal(gn, n)
+    gp = rb.indice_pairs.cpu().numpy()
+    kvol = len(n)
+    for k in range(kvol):
+        assert _pair_set(gp, gn, k) == _pair_set(p, n, k)
+        assert np.all(gp[k, :, gn[k]:] == -1)
+    # gather tables are consistent with the pair lists
+    no = rb.nbr_out.cpu().numpy()
+    for k in range(kvol):
+        rows = np.nonzero(no[k] >= 0)[0]
+        assert set(zip(no[k][rows].tolist(), rows.tolist())) == _pair_set(p, n, k)
+    if not subm:
+        ni = rb.nbr_in.cpu().numpy()
+        for k in range(kvol):
+            rows = np.nonzero(ni[k] >= 0)[0]
+            assert set(zip(rows.tolist(), ni[k][rows].tolist())) == _pair_set(p, n, k)
+    return rb, (o, p, n)
+
+
+def test_survey_k2_kats(orc, dev):
+    from detmatch_amd.spconv import ops
+    W = np.stack([(k + 1) * np.ones((4, 16), np.float32) for k in range(27)])
+    rb, _ = _check_rulebook(orc, dev, IDX, 1, SHAPE, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    feats = torch.eye(4, device=dev)
+    out = ops.indice_conv(feats, torch.from_numpy(W).to(dev), rb.indice_pairs, rb.indice_num, 4,
+                          False, True)
+    assert out[:, 0].cpu().tolist() == [52, 49, 25, 14]
+    rb, (o, p, n) = _check_rulebook(orc, dev, IDX, 1, SHAPE, [3, 3, 3], [2, 2, 2], [1, 1, 1],
+                                    False)
+    out = ops.indice_conv(feats, torch.from_numpy(W).to(dev), rb.indice_pairs, rb.indice_num, 16)
+    want = orc.indice_conv(np.eye(4, dtype=np.float32), W, p, n, 16)
+    assert np.array_equal(out.cpu().numpy(), want)   # small integers: exact
+    assert sorted(want[:, 0].tolist()) == sorted(
+        [13, 15, 31, 27, 39, 21, 51, 27, 1, 3, 7, 9, 19, 21, 25, 27])
+
+
+def _rand_indices(rng, n, batch, shape):
+    vol = shape[0] * shape[1] * shape[2]
+    cells = np.sort(rng.choice(batch * vol, size=n, replace=False))
+    b, rem = np.divmod(cells, vol)
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    return np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(ks=[3, 3, 3], st=[1, 1, 1], pd=[1, 1, 1], subm=True),
+    dict(ks=[3, 3, 3], st=[2, 2, 2], pd=[1, 1, 1], subm=False),
+    dict(ks=[3, 3, 3], st=[2, 2, 2], pd=[0, 1, 1], subm=False),
+    dict(ks=[3, 1, 1], st=[2, 1, 1], pd=[0, 0, 0], subm=False),
+])
+@pytest.mark.parametrize('n', [1, 37, 700])
+def test_rulebook_random(orc, dev, cfg, n):
+    rng = np.random.default_rng(n)
+    shape = [9, 14, 11]
+    idx = _rand_indices(rng, n, 3, shape)
+    idx = idx[rng.permutation(n)]   # arbitrary (non-sorted) input order, like voxel order
+    # keep each sample's rows contiguous as the stacked layout requires
+    idx = idx[np.argsort(idx[:, 0], kind='stable')]
+    _check_rulebook(orc, dev, idx, 3, shape, cfg['ks'], cfg['st'], cfg['pd'], cfg['subm'])
+
+
+@pytest.mark.parametrize('cin,cout', [(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64),
+                                      (64, 128)])
+@pytest.mark.parametrize('subm', [True, False])
+def test_conv_forward_backward(orc, dev, cin, cout, subm):
+    from detmatch_amd.spconv import ops
+    rng = np.random.default_rng(cin * 1000 + cout)
+    shape = [12, 40, 40]
+    n = 3000
+    idx = _rand_indices(rng, n, 2, shape)
+    ks, st, pd = ([3, 3, 3], [1, 1, 1], [1, 1, 1]) if subm else ([3, 3, 3], [2, 2, 2], [1, 1, 1])
+    rb, (o, p, nn) = _check_rulebook(orc, dev, idx, 2, shape, ks, st, pd, subm)
+    feats = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) * 0.1).astype(np.float32)
+    tf = torch.from_numpy(feats).to(dev)
+    tw = torch.from_numpy(w).to(dev).view(3, 3, 3, cin, cout)
+    out = ops.indice_conv(tf, tw, rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
+    want = orc.indice_conv(feats, w, p, nn, len(o), subm=subm)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    dy = rng.standard_normal(want.shape).astype(np.float32)
+    need_dx = cin >= 16
+    dx, dw = ops.indice_conv_backward(tf, tw, torch.from_numpy(dy).to(dev), rb.indice_pairs,
+                                      rb.indice_num, False, subm, need_input_grad=need_dx)
+    odx, odw = orc.indice_conv_backward(feats, w, dy, p, nn, subm=subm)
+    np.testing.assert_allclose(dw.cpu().numpy().reshape(27, cin, cout), odw, rtol=1e-3, atol=1e-3)
+    if need_dx:
+        np.testing.assert_allclose(dx.cpu().numpy(), odx, rtol=RTOL, atol=ATOL)
+
+
+def test_foreign_rulebook_compat_path(orc, dev):
+    """indice_conv on reference-format pair lists that did NOT come from our builder."""
+    from detmatch_amd.spconv import ops
+    rng = np.random.default_rng(3)
+    shape = [12, 40, 40]
+    idx = _rand_indices(rng, 2000, 1, shape)
+    o, p, nn, _ = orc.get_indice_pairs(idx, 1, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], subm=False)
+    feats = rng.standard_normal((2000, 16)).astype(np.float32)
+    w = (rng.standard_normal((27, 16, 32)) * 0.1).astype(np.float32)
+    tp = torch.from_numpy(p).to(dev)
+    tn = torch.from_numpy(nn).to(dev)
+    out = ops.indice_conv(torch.from_numpy(feats).to(dev), torch.from_numpy(w).to(dev), tp, tn,
+                          len(o))
+    np.testing.assert_allclose(out.cpu().numpy(), orc.indice_conv(feats, w, p, nn, len(o)),
+                               rtol=RTOL, atol=ATOL)
+    dy = rng.standard_normal((len(o), 32)).astype(np.float32)
+    dx, dw = ops.indice_conv_backward(torch.from_numpy(feats).to(dev), torch.from_numpy(w).to(dev),
+                                      torch.from_numpy(dy).to(dev), tp, tn)
+    odx, odw = orc.indice_conv_backward(feats, w, dy, p, nn)
+    np.testing.assert_allclose(dx.cpu().numpy(), odx, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(dw.cpu().numpy(), odw, rtol=1e-3, atol=1e-3)
+
+
+def test_empty_input(dev):
+    from detmatch_amd.spconv import ops
+    idx = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    rb = ops.build_rulebook(idx, 1, SHAPE, 3, 1, 1, 1, True)
+    assert rb.n_out == 0 and int(rb.indice_num.sum().item()) == 0
+    rb = ops.build_rulebook(idx, 1, SHAPE, 3, 2, 1, 1, False)
+    assert rb.n_out == 0 and rb.outids.shape == (0, 4)
+    out = ops.indice_conv(torch.zeros((0, 16), device=dev), torch.zeros((3, 3, 3, 16, 32), device=dev),
+                          rb.indice_pairs, rb.indice_num, 0)
+    assert out.shape == (0, 32)
+
+
+def test_int32_limit_is_an_error(dev):
+    from detmatch_amd import _lib
+    from detmatch_amd.spconv import ops
+    with pytest.raises(_lib.DetMatchHipError):
+        ops.build_rulebook(torch.from_numpy(IDX).to(dev), 24, SHAPE, 3, 1, 1, 1, True)
+
+
+def test_backbone_chain_kitti_shape(orc, dev):
+    """The 12 sparse convs of VoxelBackBone8x (spconv_backbone.py:80-120) chained on two
+    KITTI-shaped frames, module API + autograd, against the oracle layer by layer."""
+    from detmatch_amd import synth, voxel
+    from detmatch_amd import spconv
+    frames = [synth.lidar_frame(s)['points'] for s in (0, 1)]
+    t = [torch.from_numpy(p).to(dev) for p in frames]
+    _, coors, _, mean, _ = voxel.voxelize_batch(t, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    layers = [('subm1', True, 4, 16, 3, 1, 1), ('subm1', True, 16, 16, 3, 1, 1),
+              ('spconv2', False, 16, 32, 3, 2, 1), ('subm2', True, 32, 32, 3, 1, 1),
+              ('subm2', True, 32, 32, 3, 1, 1), ('spconv3', False, 32, 64, 3, 2, 1),
+              ('subm3', True, 64, 64, 3, 1, 1), ('subm3', True, 64, 64, 3, 1, 1),
+              ('spconv4', False, 64, 64, 3, 2, (0, 1, 1)), ('subm4', True, 64, 64, 3, 1, 1),
+              ('subm4', True, 64, 64, 3, 1, 1),
+              ('spconv_down2', False, 64, 128, (3, 1, 1), (2, 1, 1), 0)]
+    torch.manual_seed(0)
+    x = spconv.SparseConvTensor(mean.clone().requires_grad_(False), coors, SHAPE, 2)
+    ox_idx, ox_feat, oshape = coors.cpu().numpy(), mean.cpu().numpy(), SHAPE
+    books = {}
+    total_pairs = 0
+    for key, subm, cin, cout, ks, st, pd in layers:
+        cls = spconv.SubMConv3d if subm else spconv.SparseConv3d
+        m = cls(cin, cout, ks, stride=st, padding=pd, bias=False, indice_key=key).to(dev)
+        with torch.no_grad():
+            m.weight.mul_(3.0)   # keep activations O(1) through 12 layers
+        y = m(x)
+        as3 = lambda v: list(v) if isinstance(v, (tuple, list)) else [v] * 3
+        if key not in books:
+            books[key] = orc.get_indice_pairs(ox_idx, 2, oshape, as3(ks), as3(st), as3(pd),
+                                              subm=subm, sort_out=True)
+        o, p, n, osh = books[key]
+        total_pairs += int(n.sum())
+        w = m.weight.detach().cpu().numpy().reshape(-1, cin, cout)
+        want = orc.indice_conv(ox_feat, w, p, n, len(o), subm=subm)
+        assert np.array_equal(y.indices.cpu().numpy(), o)
+        got = y.features.detach().cpu().numpy()
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL * scale)
+        # next layer input: ReLU of the ORACLE output on both sides (no drift accumulation)
+        ox_idx, oshape = o, osh
+        ox_feat = np.maximum(want, 0)
+        x = spconv.SparseConvTensor(torch.from_numpy(ox_feat).to(dev), y.indices, osh, 2)
+        x.indice_dict = y.indice_dict
+    assert total_pairs > 1_000_000   # realistic sub-manifold neighbour counts
+
+
+def test_autograd_through_modules(orc, dev):
+    from detmatch_amd import spconv
+    rng = np.random.default_rng(11)
+    shape = [12, 40, 40]
+    idx = _rand_indices(rng, 2500, 2, shape)
+    feats = rng.standard_normal((2500, 16)).astype(np.float32)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(16, 16, 3, padding=1, bias=False, indice_key='s1'),
+        torch.nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key='c2'),
+    ).to(dev)
+    tf = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    x = spconv.SparseConvTensor(tf, torch.from_numpy(idx).to(dev), shape, 2)
+    y = net(x)
+    dy = rng.standard_normal(tuple(y.features.shape)).astype(np.float32)
+    y.features.backward(torch.from_numpy(dy).to(dev))
+    # oracle chain
+    w1 = net[0].weight.detach().cpu().numpy().reshape(27, 16, 16)
+    w2 = net[2].weight.detach().cpu().numpy().reshape(27, 16, 32)
+    o1, p1, n1, _ = orc.get_indice_pairs(idx, 2, shape, [3] * 3, [1] * 3, [1] * 3, subm=True)
+    h = orc.indice_conv(feats, w1, p1, n1, len(o1), subm=True)
+    hr = np.maximum(h, 0)
+    o2, p2, n2, _ = orc.get_indice_pairs(o1, 2, shape, [3] * 3, [2] * 3, [1] * 3, subm=False)
+    dh, dw2 = orc.indice_conv_backward(hr, w2, dy, p2, n2)
+    dh = dh * (h > 0)
+    dx, dw1 = orc.indice_conv_backward(feats, w1, dh, p1, n1, subm=True)
+    np.testing.assert_allclose(tf.grad.cpu().numpy(), dx, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(net[0].weight.grad.cpu().numpy().reshape(27, 16, 16), dw1,
+                               rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(net[2].weight.grad.cpu().numpy().reshape(27, 16, 32), dw2,
+                               rtol=1e-3, atol=1e-3)
