@@ -1,0 +1,172 @@
+"""bench.py — train iters/sec of the DetMatch 3D hot path on synthetic KITTI-shaped data.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One JSON line on rank 0 (contract in the task description): metric/value/unit, roofline
+(dominant kernel, HIP events recorded by the library on the launch stream during the timed
+steps) and cpu_baseline (the oracle timed on the host cores, rank 0, N=1 only).
+
+The step is whatever stage of BASELINE.json configs[1] (PV-RCNN 3D supervised, KITTI 1 %,
+bs=2/GPU) is implemented natively so far — `config.workload` names it exactly.  Inputs
+(raw point clouds, GT boxes) are resident in HBM before the timed region.  Multi-GPU: the
+path shards by sample (pure data parallel): every rank draws its own frames,
+the only collective is the gradient all-reduce (RCCL) — weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+BATCH_PER_GPU = 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def gg_bytes(P, ci, co, kvol, rows_out):
+    """Algorithmic bytes of one gather-GEMM launch (per-kernel form):
+    P*(ci+co)*4 gathered + accumulated rows, 8 B per rulebook pair, weights once,
+    final output write."""
+    return P * (ci + co) * 4 + P * 8 + kvol * ci * co * 4 + rows_out * co * 4
+
+
+def build_workload(dev, rank):
+    from detmatch_amd import synth
+    from detmatch_amd.pcdet.workload import Stage3DWorkload
+    frames = [synth.lidar_frame(1000 * rank + i) for i in range(BATCH_PER_GPU)]
+    return Stage3DWorkload(frames, dev)
+
+
+def cpu_baseline(frames):
+    """The oracle (C restatement of the reference CPU path) on ONE step of the same
+    sparse-conv workload, one host core."""
+    import oracle
+    from detmatch_amd import synth
+    from detmatch_amd.pcdet.workload import BACKBONE_LAYERS
+    oracle.build()
+    rng = np.random.default_rng(0)
+    t0 = time.perf_counter()
+    feats, coors = [], []
+    for b, f in enumerate(frames):
+        v, c, n = oracle.hard_voxelize(f['points'], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+        feats.append(v.sum(1) / np.maximum(n, 1)[:, None].astype(np.float32))
+        coors.append(np.concatenate([np.full((len(n), 1), b, np.int32), c], 1))
+    x = np.concatenate(feats)
+    idx = np.concatenate(coors)
+    shape = [41, 1600, 1408]
+    books, acts = {}, []
+    for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
+        if key not in books:
+            books[key] = oracle.get_indice_pairs(idx, len(frames), shape, ks, st, pd, subm=subm)
+        o, p, n, osh = books[key]
+        w = (rng.standard_normal((int(np.prod(ks)), cin, cout)) * 0.05).astype(np.float32)
+        y = oracle.indice_conv(x, w, p, n, len(o), subm=subm)
+        acts.append((x, w, p, n, subm))
+        x, idx, shape = np.maximum(y, 0), o, osh
+    g = np.ones_like(x)
+    for (xi, w, p, n, subm) in reversed(acts):
+        g, _ = oracle.indice_conv_backward(xi, w, g, p, n, subm=subm)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit='iters/sec', cores=1, kind='port',
+                sample='1 step of the sparse-conv stage only (voxelize + 8 rulebooks + 12 sparse '
+                       'convs fwd+bwd, bs=%d, no BN/optimizer), oracle/dm_oracle.c, %.1f s'
+                       % (len(frames), dt))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    from detmatch_amd import _lib
+    wl = build_workload(dev, rank)
+    if world > 1:
+        wl.enable_ddp()
+
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.lib().dm_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    recs = _lib.profile_records()
+    _lib.lib().dm_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (HIP events from the timed region) ----
+        per_step = wl.trace_gather_gemm()   # [(ci, co, rows, kvol, P)] in launch order
+        gg = [r for r in recs if r[0] == 0]
+        roof = None
+        if per_step and len(gg) == len(per_step) * args.steps:
+            groups = {}
+            for j, r in enumerate(gg):
+                ci, co, rows, kvol, P = per_step[j % len(per_step)]
+                assert (r[1], r[2], r[4], r[5]) == (ci, co, rows, kvol)
+                name = ('spconv_gg<%d,%d,%d>' % (r[1], r[2], r[3]) if r[3] else
+                        'spconv_gr<%d,%d>' % (r[1], r[2]))
+                g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, launches=0))
+                g['ms'] += r[7]
+                g['bytes'] += gg_bytes(P, ci, co, kvol, rows)
+                g['launches'] += 1
+            name, g = max(groups.items(), key=lambda kv: kv[1]['ms'])
+            achieved = g['bytes'] / (g['ms'] * 1e-3) / 1e9
+            tot_ms = sum(v['ms'] for v in groups.values())
+            tot_b = sum(v['bytes'] for v in groups.values())
+            roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel=name,
+                        avg_us=round(g['ms'] / g['launches'] * 1e3, 2), launches=g['launches'],
+                        bytes_per_launch=int(g['bytes'] / g['launches']),
+                        all_spconv_gg=dict(achieved=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
+                                           us_per_step=round(tot_ms / args.steps * 1e3, 1)))
+        out = dict(metric='train iters/sec', value=round(args.steps * 1.0 / dt, 3), unit='iters/sec',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
+                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload=wl.describe(), batch_per_gpu=BATCH_PER_GPU,
+                               global_batch=BATCH_PER_GPU * world,
+                               parallelism='dp%d' % world),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(wl.frames)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -39,6 +39,12 @@ SIGNATURES = {
     'dm_spconv_gather_gemm': (ci, [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, sz, vp]),
     'dm_spconv_wgrad_workspace_bytes': (sz, [ci, ci, ci, ci]),
     'dm_spconv_wgrad': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
+    'dm_profile_enable': (ci, [ci]),
+    'dm_spconv_debug_stamps': (ci, [vp]),
+    'dm_spconv_set_variant': (ci, [ci]),
+    'dm_profile_count': (ci, []),
+    'dm_profile_get': (ci, [ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
+                            ctypes.POINTER(ctypes.c_ulonglong), c_f32_p]),
 }
 
 
@@ -108,3 +114,17 @@ def workspace(nbytes, device, tag='default'):
         buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def profile_records():
+    """[(kind, a, b, c, rows, kvol, table_ptr, ms)] of the launches recorded since
+    dm_profile_enable(1) (synchronises on each record's stop event)."""
+    L = lib()
+    out = []
+    k, a, b, c, rows, kv = (ctypes.c_int() for _ in range(6))
+    tab = ctypes.c_ulonglong()
+    ms = ctypes.c_float()
+    for i in range(L.dm_profile_count()):
+        check(L.dm_profile_get(i, k, a, b, c, rows, kv, tab, ms), 'dm_profile_get')
+        out.append((k.value, a.value, b.value, c.value, rows.value, kv.value, tab.value, ms.value))
+    return out

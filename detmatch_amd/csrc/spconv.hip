@@ -23,6 +23,11 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// mask a gathered value with an all-ones / all-zeros word (no branch, no NaN leak)
+__device__ __forceinline__ float mask_bits(float a, unsigned int m) {
+  return __uint_as_float(__float_as_uint(a) & m);
+}
+
 // ---- weight packing -------------------------------------------------------
 // Packed layout per kernel offset k (cin x cout floats):
 //   wp[k][t][nb][kq][n][j] = B_k[16t + 4kq + j][16nb + n]
@@ -55,17 +60,29 @@ __global__ __launch_bounds__(256) void pack_weights(const float *w, float *wp, i
 }
 
 // ---- main kernel ----------------------------------------------------------
-template <int CIN, int COUT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void spconv_gg(const float *__restrict__ feat,
-                                                        const float *__restrict__ wpack,
-                                                        const int32_t *__restrict__ nbr,
-                                                        int n_out, int kvol,
-                                                        float *__restrict__ out) {
-  constexpr int ROWS = 16 * WAVES;
-  constexpr int NB = COUT / 16;
+// Workgroup = 4 waves = RT row tiles of 16 output rows x NS column splits
+// (RT * NS = 4).  Wave w owns row tile w / NS and output channels
+// [ (w % NS) * COUT/NS, +COUT/NS ).  Splitting the channels rather than giving a
+// wave more rows keeps the per-wave MFMA chain short (the layer has only ~1-2 k
+// row tiles for 1024 SIMDs, so work-unit granularity decides the tail) while all
+// four waves still share one LDS copy of W[k].
+// `perm` (optional): processing order -> output row; `nbr` is indexed in
+// processing order.  Lets the rulebook group rows with equal neighbour masks
+// into the same tile without changing the row order of `out`.
+template <int CIN, int COUT, int NS>
+__global__ __launch_bounds__(256) void spconv_gg(const float *__restrict__ feat,
+                                                 const float *__restrict__ wpack,
+                                                 const int32_t *__restrict__ nbr,
+                                                 const int32_t *__restrict__ perm, int n_out,
+                                                 int kvol, float *__restrict__ out,
+                                                 unsigned long long *__restrict__ stamps) {
+  constexpr int RT = 4 / NS;
+  constexpr int ROWS = 16 * RT;
+  constexpr int NB = COUT / 16;            // 16-col blocks of the whole B operand
+  constexpr int NBW = NB / NS;             // ... owned by one wave
   constexpr int CT = CIN >= 16 ? CIN / 16 : 1;
   constexpr int WSZ = CIN * COUT;          // floats per kernel offset
-  constexpr int NT = WAVES * 64;
+  constexpr int NT = 256;
   constexpr int W4 = WSZ / 4;              // float4 per offset
   constexpr int W4_PER_T = (W4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,18 +93,39 @@ __global__ __launch_bounds__(WAVES * 64) void spconv_gg(const float *__restrict_
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
+  const int rt = wave / NS, ns = wave % NS;
   const int row0 = blockIdx.x * ROWS;
 
+  unsigned long long st0 = 0, st1 = 0, rt0 = 0;
+  if (stamps) {  // diagnostic only (dm_spconv_debug_stamps); never set in production
+    st0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
   if (tid == 0) *active_mask_p = 0u;
   __syncthreads();
-  // stage this tile's slice of the gather table; build the active-offset mask
+  // stage this tile's slice of the gather table (4 independent loads in flight per
+  // thread); build the active-offset mask
   unsigned int my_mask = 0u;
-  for (int e = tid; e < kvol * ROWS; e += NT) {
-    int k = e / ROWS, rr = e % ROWS;
-    int row = row0 + rr;
-    int v = row < n_out ? nbr[(size_t)k * n_out + row] : -1;
-    nb_l[e] = v;
-    if (v >= 0) my_mask |= 1u << k;
+  const int n_ent = kvol * ROWS;
+  for (int base = 0; base < n_ent; base += NT * 4) {
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int e = base + u * NT + tid;
+      int k = e / ROWS, rr = e % ROWS;
+      int row = row0 + rr;
+      bool ok = (e < n_ent) && (row < n_out);
+      v[u] = nbr[ok ? (size_t)k * n_out + row : 0];
+      if (!ok) v[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int e = base + u * NT + tid;
+      if (e < n_ent) {
+        nb_l[e] = v[u];
+        if (v[u] >= 0) my_mask |= 1u << (e / ROWS);
+      }
+    }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) my_mask |= __shfl_xor(my_mask, d);
@@ -95,143 +133,336 @@ __global__ __launch_bounds__(WAVES * 64) void spconv_gg(const float *__restrict_
   __syncthreads();
   unsigned int active = *active_mask_p;
 
-  f32x4 acc[NB];
+  f32x4 acc[NBW];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NBW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (active != 0u) {
-    // prologue: first active offset -> LDS buffer 0
-    int k = __ffs(active) - 1;
-    unsigned int rest = active & (active - 1u);
-    {
-      const f32x4 *src = (const f32x4 *)(wpack + (size_t)k * WSZ);
-      f32x4 *dst = (f32x4 *)wl;
+  // branch-free gather of this lane's slice of the 16 input rows feeding offset k
+  // (rows without a neighbour read row 0 and are zeroed by a select)
+  // Gather of this lane's slice of the 16 input rows feeding offset k.  The load is
+  // unconditional (rows without a neighbour read row 0) and is masked only when it is
+  // consumed, by an AND with an all-ones / all-zeros word: no exec-masked
+  // branch around the loads, so the compiler can keep them in flight across the MFMA
+  // block of the previous offset with exact vmcnt counts.
+  auto load_a = [&](int k, f32x4 *dst, unsigned int *okf) {
+    int idx = nb_l[k * ROWS + rt * 16 + r];
+    *okf = idx >= 0 ? 0xFFFFFFFFu : 0u;
+    size_t base = (size_t)(idx >= 0 ? idx : 0) * CIN;
+    if (CIN >= 16) {
 #pragma unroll
-      for (int i = 0; i < W4_PER_T; ++i) {
-        int e = tid + i * NT;
-        if (e < W4) dst[e] = src[e];
+      for (int t = 0; t < CT; ++t) dst[t] = *(const f32x4 *)(feat + base + 16 * t + 4 * kq);
+    } else {
+      dst[0] = (f32x4){feat[base + kq], 0.f, 0.f, 0.f};
+    }
+  };
+  static_assert(W4 % NT == 0 || W4 < NT, "weight slice must tile the workgroup");
+  auto load_w = [&](int k, f32x4 *dst) {
+    const f32x4 *src = (const f32x4 *)(wpack + (size_t)k * WSZ);
+#pragma unroll
+    for (int i = 0; i < W4_PER_T; ++i) {
+      int e = tid + i * NT;
+      dst[i] = src[W4 % NT == 0 ? e : (e < W4 ? e : 0)];
+    }
+  };
+  auto store_w = [&](int b, const f32x4 *srcv) {
+    f32x4 *dst = (f32x4 *)(wl + b * WSZ);
+#pragma unroll
+    for (int i = 0; i < W4_PER_T; ++i) {
+      int e = tid + i * NT;
+      if (W4 % NT == 0 || e < W4) dst[e] = srcv[i];
+    }
+  };
+
+  auto compute = [&](int k, const f32x4 *a, unsigned int okf, int buf) {
+    // skip if none of this wave's 16 rows has a neighbour through offset k
+    int idx = nb_l[k * ROWS + rt * 16 + r];
+    if (__ballot(idx >= 0) == 0ull) return;
+    const float *wb = wl + buf * WSZ;
+    if (CIN >= 16) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        f32x4 b[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+          b[nb] = *(const f32x4 *)(wb + (((t * NB + ns * NBW + nb) * 4 + kq) * 16 + r) * 4);
+        float av[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = mask_bits(a[t][j], okf);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b[nb][j], acc[nb], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        float b = wb[((ns * NBW + nb) * 4 + kq) * 16 + r];
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(mask_bits(a[0][0], okf), b, acc[nb], 0, 0, 0);
       }
     }
+  };
+
+  if (stamps) st1 = __builtin_amdgcn_s_memtime();
+  if (active != 0u && n_out > 0) {
+    // Software pipeline, prefetch distance 2: in iteration i the loads for offset
+    // k_{i+2} are issued, offset k_i is computed from LDS[buf] and registers loaded two
+    // iterations ago, and W[k_{i+1}] (loaded one iteration ago) moves from registers to
+    // LDS[buf^1].  A global-load latency is thus covered by a full iteration, and the
+    // per-offset chain is barrier + MFMA block + LDS write.
+    const int n_act = __popc(active);
+    unsigned int rest = active;
+    auto pop = [&]() {  // next active offset; repeats the last one when exhausted
+      int k = __ffs(rest) - 1;
+      if (rest & (rest - 1u)) rest &= rest - 1u;
+      return k;
+    };
+    int kc = pop();
+    int k1 = pop();
+    f32x4 wr0[W4_PER_T], wr1[W4_PER_T];
+    f32x4 a0[CT], a1[CT], a2[CT];
+    unsigned int ok0, ok1, ok2;
+    load_w(kc, wr0);
+    load_a(kc, a0, &ok0);
+    load_w(k1, wr1);
+    load_a(k1, a1, &ok1);
+    store_w(0, wr0);
     int buf = 0;
-    // A rows of the current offset
-    f32x4 a[CT];
-    {
-      int idx = nb_l[k * ROWS + wave * 16 + r];
+    int i = 0;
+    auto iter = [&](f32x4 *w_new, f32x4 *w_old) {
+      __syncthreads();  // LDS[buf] holds W[k_i]; nobody still reads LDS[buf^1]
+      int k2 = pop();
+      load_w(k2, w_new);
+      load_a(k2, a2, &ok2);
+      compute(kc, a0, ok0, buf);
+      if (i + 1 < n_act) store_w(buf ^ 1, w_old);
 #pragma unroll
-      for (int t = 0; t < CT; ++t) a[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (idx >= 0) {
-        if (CIN >= 16) {
-#pragma unroll
-          for (int t = 0; t < CT; ++t)
-            a[t] = *(const f32x4 *)(feat + (size_t)idx * CIN + 16 * t + 4 * kq);
-        } else {
-          a[0][0] = feat[(size_t)idx * CIN + kq];
-        }
+      for (int t = 0; t < CT; ++t) {
+        a0[t] = a1[t];
+        a1[t] = a2[t];
       }
-    }
-    while (true) {
-      __syncthreads();  // LDS[buf] holds W[k]; nobody still reads LDS[buf^1]
-      // prefetch next active offset: weights -> registers, A rows -> registers
-      int kn = rest ? __ffs(rest) - 1 : -1;
-      f32x4 wreg[W4_PER_T];
-      f32x4 an[CT];
-      if (kn >= 0) {
-        const f32x4 *src = (const f32x4 *)(wpack + (size_t)kn * WSZ);
-#pragma unroll
-        for (int i = 0; i < W4_PER_T; ++i) {
-          int e = tid + i * NT;
-          if (e < W4) wreg[i] = src[e];
-        }
-        int idx = nb_l[kn * ROWS + wave * 16 + r];
-#pragma unroll
-        for (int t = 0; t < CT; ++t) an[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (idx >= 0) {
-          if (CIN >= 16) {
-#pragma unroll
-            for (int t = 0; t < CT; ++t)
-              an[t] = *(const f32x4 *)(feat + (size_t)idx * CIN + 16 * t + 4 * kq);
-          } else {
-            an[0][0] = feat[(size_t)idx * CIN + kq];
-          }
-        }
-      }
-      // compute offset k (skip if none of this wave's 16 rows has a neighbour)
-      {
-        int idx = nb_l[k * ROWS + wave * 16 + r];
-        if (__ballot(idx >= 0) != 0ull) {
-          const float *wb = wl + buf * WSZ;
-          if (CIN >= 16) {
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-              f32x4 b[NB];
-#pragma unroll
-              for (int nb = 0; nb < NB; ++nb)
-                b[nb] = *(const f32x4 *)(wb + (((t * NB + nb) * 4 + kq) * 16 + r) * 4);
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                  acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[nb][j], acc[nb], 0, 0, 0);
-            }
-          } else {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-              float b = wb[(nb * 4 + kq) * 16 + r];
-              acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][0], b, acc[nb], 0, 0, 0);
-            }
-          }
-        }
-      }
-      if (kn < 0) break;
-      // stash next weights into the other LDS buffer
-      {
-        f32x4 *dst = (f32x4 *)(wl + (buf ^ 1) * WSZ);
-#pragma unroll
-        for (int i = 0; i < W4_PER_T; ++i) {
-          int e = tid + i * NT;
-          if (e < W4) dst[e] = wreg[i];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < CT; ++t) a[t] = an[t];
-      k = kn;
-      rest &= rest - 1u;
+      ok0 = ok1;
+      ok1 = ok2;
+      kc = k1;
+      k1 = k2;
       buf ^= 1;
+      ++i;
+    };
+    while (true) {
+      iter(wr0, wr1);
+      if (i >= n_act) break;
+      iter(wr1, wr0);
+      if (i >= n_act) break;
     }
+  }
+  if (stamps && tid == 0) {
+    unsigned long long st2 = __builtin_amdgcn_s_memtime();
+    unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long *o = stamps + (size_t)blockIdx.x * 6;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = rt0; o[4] = rt1; o[5] = __popc(active);
   }
   // epilogue: D layout col = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
-    int row = row0 + wave * 16 + kq * 4 + reg;
-    if (row < n_out) {
+    int prow = row0 + rt * 16 + kq * 4 + reg;
+    if (prow < n_out) {
+      int row = perm ? perm[prow] : prow;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) out[(size_t)row * COUT + 16 * nb + r] = acc[nb][reg];
+      for (int nb = 0; nb < NBW; ++nb)
+        out[(size_t)row * COUT + 16 * (ns * NBW + nb) + r] = acc[nb][reg];
     }
   }
 }
 
-template <int CIN, int COUT, int WAVES>
-int launch_gg_w(const float *feat, const float *wpack, const int32_t *nbr, int n_out, int kvol,
-                float *out, hipStream_t st) {
-  size_t smem = 2ull * CIN * COUT * sizeof(float) + (size_t)kvol * 16 * WAVES * sizeof(int32_t) + 16;
-  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in
-  if (!attr_set) {
-    DM_HIP(hipFuncSetAttribute((const void *)spconv_gg<CIN, COUT, WAVES>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
+unsigned long long *g_debug_stamps = nullptr;
+int g_gg_variant = -1;  // -1 auto, 0 LDS-staged weights (spconv_gg), 1 register weights (spconv_gr)
+
+// ---- main kernel, register-resident weights ----------------------------------
+// Workgroup = 4 waves = ONE tile of 16 output rows; the tile's active kernel
+// offsets are dealt round-robin to the four waves.  A wave keeps the whole
+// (cin x cout) B operand of its current offset in registers (loaded straight from
+// the packed weights, 1 KiB per wave-instruction) next to the gathered A rows, so
+// the main loop has no LDS traffic and no barrier; the four partial accumulators
+// meet once, in LDS, are summed in a fixed order (bitwise reproducible) and leave
+// as whole 16-byte-per-lane row segments.  Work units are a quarter of a tile's
+// offsets, which is what lets ~1-2 k tiles balance over 1024 SIMDs.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
+                                                 const float *__restrict__ wpack,
+                                                 const int32_t *__restrict__ nbr,
+                                                 const int32_t *__restrict__ perm, int n_out,
+                                                 int kvol, int cout_full,
+                                                 float *__restrict__ out,
+                                                 unsigned long long *__restrict__ stamps) {
+  constexpr int NB = COUT / 16;
+  constexpr int CT = CIN / 16;
+  constexpr int CTS = CT < 4 ? CT : 4;     // k-chunks of <= 64 input channels per step
+  constexpr int S = CT / CTS;              // steps per kernel offset
+  constexpr int LDP = COUT + 4;            // padded row stride of the partial tiles
+  __shared__ int32_t tbl[4][32][16];
+  __shared__ __attribute__((aligned(16))) float part[4][16][LDP];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  const int nb_full = cout_full / 16;
+  const int nb0 = blockIdx.y * NB;
+  unsigned long long st0 = 0, rt0 = 0, st1 = 0;
+  if (stamps) {
+    st0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
   }
-  spconv_gg<CIN, COUT, WAVES><<<dm_ceil_div(n_out, 16 * WAVES), WAVES * 64, smem, st>>>(
-      feat, wpack, nbr, n_out, kvol, out);
+
+  // this wave's private copy of the tile's gather table + the active-offset mask
+  unsigned int active = 0u;
+  {
+    int v[8];
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {  // all eight loads in flight before the first use
+      int k = 4 * k4 + kq;
+      bool in = (k < kvol) && (row0 + r < n_out);
+      v[k4] = nbr[in ? (size_t)k * n_out + row0 + r : 0];
+      if (!in) v[k4] = -1;
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      tbl[wave][4 * k4 + kq][r] = v[k4];
+      unsigned long long m = __ballot(v[k4] >= 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((m >> (16 * q)) & 0xFFFFull) active |= 1u << (4 * k4 + q);
+    }
+  }
+  // deal the active offsets round-robin to the four waves
+  unsigned int mine = 0u;
+  {
+    int rank = 0;
+    for (unsigned int a = active; a; a &= a - 1u) {
+      if ((rank & 3) == wave) mine |= a & (0u - a);
+      ++rank;
+    }
+  }
+  f32x4 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto load_step = [&](int k, int s, f32x4 *w, f32x4 *a, unsigned int *ok) {
+    int idx = tbl[wave][k][r];
+    *ok = idx >= 0 ? 0xFFFFFFFFu : 0u;
+    const float *src = feat + (size_t)(idx >= 0 ? idx : 0) * CIN + 16 * (s * CTS) + 4 * kq;
+#pragma unroll
+    for (int t = 0; t < CTS; ++t) a[t] = *(const f32x4 *)(src + 16 * t);
+    const f32x4 *wk = (const f32x4 *)wpack + (size_t)k * (CIN * (size_t)cout_full / 4);
+#pragma unroll
+    for (int t = 0; t < CTS; ++t)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        w[t * NB + nb] = wk[((s * CTS + t) * nb_full + nb0 + nb) * 64 + lane];
+  };
+  auto compute = [&](const f32x4 *w, const f32x4 *a, unsigned int ok) {
+#pragma unroll
+    for (int t = 0; t < CTS; ++t) {
+      float av[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[j] = mask_bits(a[t][j], ok);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[t * NB + nb][j], acc[nb], 0, 0, 0);
+    }
+  };
+
+  if (stamps) st1 = __builtin_amdgcn_s_memtime();
+  if (mine != 0u) {
+    const int n_steps = __popc(mine) * S;
+    unsigned int rest = mine;
+    int k = __ffs(rest) - 1, s = 0;
+    auto advance = [&]() {  // next (offset, k-chunk); sticks at the last one
+      if (s + 1 < S) {
+        ++s;
+      } else if (rest & (rest - 1u)) {
+        rest &= rest - 1u;
+        k = __ffs(rest) - 1;
+        s = 0;
+      }
+    };
+    f32x4 w0[CTS * NB], w1[CTS * NB], a0[CTS], a1[CTS];
+    unsigned int ok0, ok1;
+    load_step(k, s, w0, a0, &ok0);
+    int i = 0;
+    while (true) {
+      advance();
+      load_step(k, s, w1, a1, &ok1);
+      compute(w0, a0, ok0);
+      if (++i >= n_steps) break;
+      advance();
+      load_step(k, s, w0, a0, &ok0);
+      compute(w1, a1, ok1);
+      if (++i >= n_steps) break;
+    }
+  }
+  // meet in LDS: D layout col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) part[wave][4 * kq + reg][16 * nb + r] = acc[nb][reg];
+  __syncthreads();
+  if (stamps && tid == 0) {
+    unsigned long long *o = stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
+    o[0] = st0; o[1] = st1; o[2] = __builtin_amdgcn_s_memtime(); o[3] = rt0;
+    o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = __popc(active);
+  }
+  constexpr int F4_PER_ROW = COUT / 4;
+  if (tid < 16 * F4_PER_ROW) {
+    int rr = tid / F4_PER_ROW, c4 = tid % F4_PER_ROW;
+    int prow = row0 + rr;
+    if (prow < n_out) {
+      f32x4 v0 = *(const f32x4 *)&part[0][rr][4 * c4];
+      f32x4 v1 = *(const f32x4 *)&part[1][rr][4 * c4];
+      f32x4 v2 = *(const f32x4 *)&part[2][rr][4 * c4];
+      f32x4 v3 = *(const f32x4 *)&part[3][rr][4 * c4];
+      f32x4 sum = (v0 + v1) + (v2 + v3);
+      int row = perm ? perm[prow] : prow;
+      *(f32x4 *)(out + (size_t)row * cout_full + blockIdx.y * COUT + 4 * c4) = sum;
+    }
+  }
+}
+
+template <int CIN, int COUT_FULL>
+int launch_gr(const float *feat, const float *wpack, const int32_t *nbr, const int32_t *perm,
+              int n_out, int kvol, float *out, hipStream_t st) {
+  constexpr int COUT = COUT_FULL > 64 ? 64 : COUT_FULL;  // columns per workgroup
+  dim3 grid(dm_ceil_div(n_out, 16), COUT_FULL / COUT);
+  int pi = dm_prof_begin(st, DM_PROF_SPCONV_GG, CIN, COUT_FULL, 0, n_out, kvol, nbr);
+  spconv_gr<CIN, COUT><<<grid, 256, 0, st>>>(feat, wpack, nbr, perm, n_out, kvol, COUT_FULL, out,
+                                             g_debug_stamps);
+  dm_prof_end(pi, st);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
 
+
 template <int CIN, int COUT>
-int launch_gg(const float *feat, const float *wpack, const int32_t *nbr, int n_out, int kvol,
-              float *out, hipStream_t st) {
-  // 64-row tiles when they still fill the chip (256 CUs), else 32-row tiles
-  if (n_out >= 64 * 512) return launch_gg_w<CIN, COUT, 4>(feat, wpack, nbr, n_out, kvol, out, st);
-  return launch_gg_w<CIN, COUT, 2>(feat, wpack, nbr, n_out, kvol, out, st);
+int launch_gg(const float *feat, const float *wpack, const int32_t *nbr, const int32_t *perm,
+              int n_out, int kvol, float *out, hipStream_t st) {
+  // column splits per row tile: keep >= 16 channels per wave
+  constexpr int NS = COUT >= 128 ? 4 : (COUT >= 32 ? 2 : 1);
+  constexpr int ROWS = 16 * (4 / NS);
+  size_t smem = 2ull * CIN * COUT * sizeof(float) + (size_t)kvol * ROWS * sizeof(int32_t) + 16;
+  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in
+  if (!attr_set) {
+    DM_HIP(hipFuncSetAttribute((const void *)spconv_gg<CIN, COUT, NS>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  int pi = dm_prof_begin(st, DM_PROF_SPCONV_GG, CIN, COUT, NS, n_out, kvol, nbr);
+  spconv_gg<CIN, COUT, NS><<<dm_ceil_div(n_out, ROWS), 256, smem, st>>>(
+      feat, wpack, nbr, perm, n_out, kvol, out, g_debug_stamps);
+  dm_prof_end(pi, st);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
 }
 
 // ---- weight gradient --------------------------------------------------------
@@ -317,13 +548,32 @@ bool chan_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 128; }
 
 }  // namespace
 
+// diagnostic: when set, every workgroup of spconv_gg writes 6 u64 stamps
+// {t_start, t_after_prologue, t_end (s_memtime), rt_start, rt_end (s_memrealtime), n_active}
+extern "C" int dm_spconv_debug_stamps(void *buf) {
+  g_debug_stamps = (unsigned long long *)buf;
+  return DM_OK;
+}
+
+// tuning aid: -1 auto, 0 force the LDS-staged kernel, 1 force the register-weights kernel
+extern "C" int dm_spconv_set_variant(int v) {
+  g_gg_variant = v;
+  return DM_OK;
+}
+
 extern "C" size_t dm_spconv_workspace_bytes(int kvol, int cin, int cout) {
   if (kvol <= 0 || cin <= 0 || cout <= 0) return 0;
   return dm_align((size_t)kvol * cin * cout * sizeof(float));
 }
 
 #define DM_GG_CASE(CI, CO)                                                              \
-  if (ci == CI && co == CO) return launch_gg<CI, CO>(feat, wp, nbr, n_rows_out, kvol, out, st);
+  if (ci == CI && co == CO) {                                                           \
+    bool use_gr = g_gg_variant < 0 ? (CI >= 32) : (g_gg_variant == 1);                  \
+    if constexpr (CI >= 16) {                                                           \
+      if (use_gr) return launch_gr<CI, CO>(feat, wp, nbr, nullptr, n_rows_out, kvol, out, st); \
+    }                                                                                   \
+    return launch_gg<CI, CO>(feat, wp, nbr, nullptr, n_rows_out, kvol, out, st);         \
+  }
 
 extern "C" int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const float *filters,
                                      const int32_t *nbr, int n_rows_out, int kvol, int cin,
@@ -386,6 +636,7 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
     return DM_ERR_WORKSPACE;
   float *slab = (float *)workspace;
   dim3 grid(nchunks, dm_ceil_div(cin, 16), kvol);
+  int pi = dm_prof_begin(st, DM_PROF_SPCONV_WGRAD, cin, cout, 1, pair_stride, kvol, indice_pairs);
   switch (cout) {
     case 16:
       spconv_wgrad_partial<16><<<grid, 64, 0, st>>>(feat, out_grad, indice_pairs, indice_num,
@@ -407,6 +658,7 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
   DM_CHECK_LAUNCH();
   spconv_wgrad_reduce<<<dm_ceil_div((long long)per_chunk, 256), 256, 0, st>>>(slab, nchunks,
                                                                               per_chunk, filt_grad);
+  dm_prof_end(pi, st);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -1,0 +1,139 @@
+"""MeanVFE, VoxelBackBone8x, HeightCompression.
+
+Reference: pcdet/models/backbones_3d/vfe/mean_vfe.py:14-28,
+pcdet/models/backbones_3d/spconv_backbone.py:9-28,68-175,
+pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-25.
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import spconv
+
+
+class MeanVFE(nn.Module):
+    """mean of the points in a voxel.  When the batch dict already carries
+    `voxel_features` (the fused mean written by dm_hard_voxelize) it is kept."""
+
+    def __init__(self, model_cfg=None, num_point_features=4, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_point_features = num_point_features
+
+    def get_output_feature_dim(self):
+        return self.num_point_features
+
+    def forward(self, batch_dict, **kwargs):
+        if batch_dict.get('voxel_features', None) is not None:
+            return batch_dict
+        voxel_features, voxel_num_points = batch_dict['voxels'], batch_dict['voxel_num_points']
+        points_mean = voxel_features.sum(dim=1, keepdim=False)
+        normalizer = torch.clamp_min(voxel_num_points.view(-1, 1), min=1.0).type_as(voxel_features)
+        batch_dict['voxel_features'] = (points_mean / normalizer).contiguous()
+        return batch_dict
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0,
+                   conv_type='subm', norm_fn=None):
+    """spconv_backbone.py:9-28: conv -> BatchNorm1d -> ReLU."""
+    if conv_type == 'subm':
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False,
+                                 indice_key=indice_key)
+    elif conv_type == 'spconv':
+        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride,
+                                   padding=padding, bias=False, indice_key=indice_key)
+    else:
+        raise NotImplementedError(conv_type)
+    return spconv.SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
+
+
+class VoxelBackBone8x(nn.Module):
+    """12 sparse convs / 8 rulebooks (spconv_backbone.py:80-120)."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg if model_cfg is not None else {}
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.frozen_stages = self.model_cfg.get('FROZEN_STAGES', -1)
+        gs = [int(v) for v in grid_size]
+        self.sparse_shape = [gs[2] + 1, gs[1], gs[0]]  # grid_size[::-1] + [1, 0, 0]
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'),
+            norm_fn(16), nn.ReLU())
+        block = post_act_block
+        self.conv1 = spconv.SparseSequential(
+            block(16, 16, 3, norm_fn=norm_fn, padding=1, indice_key='subm1'))
+        self.conv2 = spconv.SparseSequential(
+            block(16, 32, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv2',
+                  conv_type='spconv'),
+            block(32, 32, 3, norm_fn=norm_fn, padding=1, indice_key='subm2'),
+            block(32, 32, 3, norm_fn=norm_fn, padding=1, indice_key='subm2'))
+        self.conv3 = spconv.SparseSequential(
+            block(32, 64, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv3',
+                  conv_type='spconv'),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm3'),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm3'))
+        self.conv4 = spconv.SparseSequential(
+            block(64, 64, 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key='spconv4',
+                  conv_type='spconv'),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm4'),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm4'))
+        last_pad = self.model_cfg.get('last_pad', 0)
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key='spconv_down2'),
+            norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+        self.backbone_channels = {'x_conv1': 16, 'x_conv2': 32, 'x_conv3': 64, 'x_conv4': 64}
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.conv_input.eval()
+            for p in self.conv_input.parameters():
+                p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, 'conv%d' % i)
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        return self
+
+    def forward(self, batch_dict):
+        voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+        x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(),
+                                    spatial_shape=self.sparse_shape,
+                                    batch_size=batch_dict['batch_size'])
+        x = self.conv_input(x)
+        x_conv1 = self.conv1(x)
+        x_conv2 = self.conv2(x_conv1)
+        x_conv3 = self.conv3(x_conv2)
+        x_conv4 = self.conv4(x_conv3)
+        out = self.conv_out(x_conv4)
+        batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
+        batch_dict.update({'multi_scale_3d_features': {
+            'x_conv1': x_conv1, 'x_conv2': x_conv2, 'x_conv3': x_conv3, 'x_conv4': x_conv4}})
+        batch_dict.update({'multi_scale_3d_strides': {
+            'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
+        return batch_dict
+
+
+class HeightCompression(nn.Module):
+    """(B, C, D, H, W) dense scatter viewed as (B, C*D, H, W)."""
+
+    def __init__(self, model_cfg=None, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg if model_cfg is not None else {}
+        self.num_bev_features = self.model_cfg.get('NUM_BEV_FEATURES', 256)
+
+    def forward(self, batch_dict):
+        sp = batch_dict['encoded_spconv_tensor']
+        spatial_features = sp.dense()
+        n, c, d, h, w = spatial_features.shape
+        batch_dict['spatial_features'] = spatial_features.view(n, c * d, h, w)
+        batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
+        return batch_dict

@@ -1,0 +1,108 @@
+"""Benchmark / smoke workloads assembled from the native path (used by bench.py).
+
+`Stage3DWorkload` is the part of the PV-RCNN supervised training step
+(BASELINE.json configs[1]) that is implemented so far; `describe()` says exactly
+which stages run inside a step.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .. import synth, voxel
+from ..spconv import ops as sp_ops
+from .backbones_3d import HeightCompression, MeanVFE, VoxelBackBone8x
+
+# (indice_key, subm, cin, cout, ksize, stride, padding) — spconv_backbone.py:80-120
+BACKBONE_LAYERS = [
+    ('subm1', True, 4, 16, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('subm1', True, 16, 16, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('spconv2', False, 16, 32, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+    ('subm2', True, 32, 32, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('subm2', True, 32, 32, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('spconv3', False, 32, 64, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+    ('subm3', True, 64, 64, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('subm3', True, 64, 64, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('spconv4', False, 64, 64, [3, 3, 3], [2, 2, 2], [0, 1, 1]),
+    ('subm4', True, 64, 64, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('subm4', True, 64, 64, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('spconv_down2', False, 64, 128, [3, 1, 1], [2, 1, 1], [0, 0, 0]),
+]
+
+
+class Stage3DWorkload(object):
+    """voxelize(+MeanVFE) -> VoxelBackBone8x -> HeightCompression, fwd + bwd + AdamW."""
+
+    def __init__(self, frames, device, lr=1e-3):
+        self.frames = frames
+        self.device = device
+        self.points = [torch.from_numpy(f['points']).to(device) for f in frames]
+        self.voxel_size = list(synth.KITTI_VOXEL)
+        self.pc_range = list(synth.KITTI_RANGE)
+        grid = [1408, 1600, 40]
+        torch.manual_seed(0)
+        self.vfe = MeanVFE(None, 4)
+        self.backbone = VoxelBackBone8x({}, 4, grid).to(device)
+        self.to_bev = HeightCompression({'NUM_BEV_FEATURES': 256})
+        self.params = [p for p in self.backbone.parameters() if p.requires_grad]
+        self.opt = torch.optim.AdamW(self.params, lr=lr, betas=(0.95, 0.99), weight_decay=0.01)
+        self.world = 1
+        self._trace = None
+
+    def describe(self):
+        return ('PV-RCNN 3D supervised (configs[1]) — stages A+B only: batched hard-voxelize+MeanVFE '
+                '(max_voxels 16000, max_points 5) -> VoxelBackBone8x (12 sparse convs, 8 rulebooks, '
+                'BN1d+ReLU) -> HeightCompression, L2 surrogate loss on the BEV map, backward, AdamW; '
+                'KITTI-shaped synthetic, bs=%d/GPU' % len(self.frames))
+
+    def enable_ddp(self):
+        self.world = dist.get_world_size()
+        flat = torch.cat([p.data.view(-1) for p in self.params])
+        dist.broadcast(flat, 0)
+        off = 0
+        for p in self.params:
+            p.data.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def forward(self):
+        _, coors, _, mean, _ = voxel.voxelize_batch(self.points, self.voxel_size, self.pc_range,
+                                                    5, 16000)
+        bd = dict(batch_size=len(self.points), voxel_features=mean, voxel_coords=coors)
+        bd = self.vfe(bd)
+        bd = self.backbone(bd)
+        bd = self.to_bev(bd)
+        return bd
+
+    def step(self):
+        self.backbone.train()
+        bd = self.forward()
+        loss = bd['spatial_features'].square().mean()
+        self.opt.zero_grad(set_to_none=False)
+        loss.backward()
+        if self.world > 1:  # gradients only, one flat bucket
+            flat = torch.cat([p.grad.view(-1) for p in self.params])
+            dist.all_reduce(flat)
+            flat.div_(self.world)
+            off = 0
+            for p in self.params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        self.opt.step()
+        return loss
+
+    def trace_gather_gemm(self):
+        """Launch-order list [(ci, co, rows, kvol, P)] of the gather-GEMM launches of one
+        step (forward convs in order, then input-gradient launches in reverse order)."""
+        self.backbone.train()
+        bd = self.forward()
+        x = bd['multi_scale_3d_features']['x_conv1']
+        idict = x.indice_dict
+        P = {k: int(v[3].sum().item()) for k, v in idict.items()}
+        n_in = {k: int(v[1].shape[0]) for k, v in idict.items()}
+        n_out = {k: int(v[0].shape[0]) for k, v in idict.items()}
+        fwd, bwd = [], []
+        for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
+            kvol = ks[0] * ks[1] * ks[2]
+            fwd.append((cin, cout, n_out[key], kvol, P[key]))
+            if cin >= 16:  # the first layer's input needs no gradient
+                bwd.append((cout, cin, n_in[key], kvol, P[key]))
+        return fwd + bwd[::-1]

@@ -186,6 +186,23 @@ int dm_spconv_wgrad(const float *feat, const float *out_grad,
                     int kvol, int cin, int cout, float *filt_grad /*(kvol,cin,cout)*/,
                     void *workspace, size_t workspace_bytes, dm_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* Measurement hook (bench.py roofline leg; not part of the reference ABI)    */
+/* ------------------------------------------------------------------------ */
+/* When enabled, every main sparse-conv kernel launch is bracketed by a pair of
+ * HIP events recorded on the launch stream.  dm_profile_get synchronises on the
+ * record's stop event and returns the elapsed milliseconds.
+ * kind 0 = spconv_gg (a = B-operand rows "ci", b = B-operand cols "co",
+ * c = column splits per row tile), kind 1 = wgrad partial+reduce (a = cin, b = cout). */
+int dm_profile_enable(int on); /* clears all records */
+/* diagnostic build aid: buf (device, 6 u64 per workgroup) or NULL to switch off */
+int dm_spconv_debug_stamps(void *buf);
+/* tuning aid: -1 auto, 0 LDS-staged-weights kernel, 1 register-weights kernel */
+int dm_spconv_set_variant(int v);
+int dm_profile_count(void);
+int dm_profile_get(int i, int *kind, int *a, int *b, int *c, int *rows, int *kvol,
+                   unsigned long long *table, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

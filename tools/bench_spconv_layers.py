@@ -1,0 +1,99 @@
+"""Per-layer timing of the sparse-conv kernels on the KITTI-shaped B=2 workload
+(developer tool; GPU only).  Prints us / algorithmic GB/s per layer for forward,
+input-gradient and weight-gradient launches.
+
+    python tools/bench_spconv_layers.py [--reps 50] [--only subm3]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from detmatch_amd import synth, voxel  # noqa: E402
+from detmatch_amd.pcdet.workload import BACKBONE_LAYERS  # noqa: E402
+from detmatch_amd.spconv import ops  # noqa: E402
+
+
+def timed(fn, reps, kind=None):
+    """kind None: wall time per call (torch events around the loop, includes host launch
+    overhead); kind 0/1: mean in-library HIP-event time of the gather-GEMM / wgrad kernel."""
+    from detmatch_amd import _lib
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    if kind is not None:
+        _lib.lib().dm_profile_enable(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    if kind is not None:
+        recs = [r for r in _lib.profile_records() if r[0] == kind]
+        _lib.lib().dm_profile_enable(0)
+        return sum(r[7] for r in recs) / max(len(recs), 1) * 1e3
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=50)
+    ap.add_argument('--only', default=None)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=-1)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    from detmatch_amd import _lib
+    _lib.lib().dm_spconv_set_variant(args.variant)
+    pts = [torch.from_numpy(synth.lidar_frame(s)['points']).to(dev) for s in range(args.batch)]
+    _, coors, _, mean, _ = voxel.voxelize_batch(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    idx, shape = coors, [41, 1600, 1408]
+    books = {}
+    tot = dict(f=0.0, d=0.0, w=0.0, rb=0.0, bf=0.0, bb=0.0)
+    print('%-13s %7s %7s %8s | %8s %7s | %8s %7s | %8s' % ('layer', 'N_in', 'N_out', 'P', 'fwd us',
+                                                          'GB/s', 'dgrad us', 'GB/s', 'wgrad us'))
+    for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
+        if key not in books:
+            t_rb = timed(lambda: ops.build_rulebook(idx, args.batch, shape, ks, st, pd, 1, subm), 10)
+            books[key] = ops.build_rulebook(idx, args.batch, shape, ks, st, pd, 1, subm)
+            tot['rb'] += t_rb
+            print('  rulebook %-12s %.1f us' % (key, t_rb))
+        rb = books[key]
+        P = int(rb.indice_num.sum().item())
+        kvol = rb.kvol
+        x = torch.randn(rb.n_in, cin, device=dev)
+        w = torch.randn(*ks, cin, cout, device=dev) * 0.05
+        dy = torch.randn(rb.n_out, cout, device=dev)
+        rb.indice_pairs.dm_tables = (rb.nbr_out, rb.nbr_in, rb.subm)
+        if args.only is None or args.only == key:
+            tf = timed(lambda: ops.indice_conv(x, w, rb.indice_pairs, rb.indice_num, rb.n_out,
+                                               False, subm), args.reps, 0)
+            bf = P * (cin + cout) * 4 + P * 8 + kvol * cin * cout * 4 + rb.n_out * cout * 4
+            td = tb = 0.0
+            if cin >= 16:
+                nbr = rb.nbr_out if subm else rb.nbr_in
+                td = timed(lambda: ops._gather_gemm(dy, w, nbr, rb.n_in, cin, cout, 1,
+                                                    1 if subm else 0), args.reps, 0)
+                tb = P * (cin + cout) * 4 + P * 8 + kvol * cin * cout * 4 + rb.n_in * cin * 4
+            tw = timed(lambda: ops.indice_conv_backward(x, w, dy, rb.indice_pairs, rb.indice_num,
+                                                        False, subm, need_input_grad=False),
+                       args.reps, 1)
+            print('%-13s %7d %7d %8d | %8.1f %7.0f | %8.1f %7.0f | %8.1f' % (
+                '%s %d>%d' % (key, cin, cout), rb.n_in, rb.n_out, P, tf, bf / tf / 1e3, td,
+                (tb / td / 1e3) if td else 0, tw))
+            tot['f'] += tf
+            tot['d'] += td
+            tot['w'] += tw
+            tot['bf'] += bf
+            tot['bb'] += tb
+        idx, shape = rb.outids, rb.out_shape
+    print('TOTAL fwd %.1f us (%.0f GB/s)  dgrad %.1f us (%.0f GB/s)  wgrad %.1f us  rulebooks %.1f us'
+          % (tot['f'], tot['bf'] / max(tot['f'], 1e-9) / 1e3, tot['d'],
+             tot['bb'] / max(tot['d'], 1e-9) / 1e3, tot['w'], tot['rb']))
+
+
+if __name__ == '__main__':
+    main()
