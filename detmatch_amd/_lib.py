@@ -39,6 +39,17 @@ SIGNATURES = {
     'dm_spconv_gather_gemm': (ci, [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, sz, vp]),
     'dm_spconv_wgrad_workspace_bytes': (sz, [ci, ci, ci, ci]),
     'dm_spconv_wgrad': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
+    'dm_iou3d_workspace_bytes': (sz, [ci, ci]),
+    'dm_boxes_overlap_bev': (ci, [vp, ci, vp, ci, vp, vp, sz, vp]),
+    'dm_boxes_iou_bev': (ci, [vp, ci, vp, ci, vp, vp, sz, vp]),
+    'dm_nms_workspace_bytes': (sz, [ci]),
+    'dm_nms': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
+    'dm_nms_normal': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
+    'dm_ball_query_stack': (ci, [ci, ci, cf, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
+    'dm_group_points_stack': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
+    'dm_group_points_grad_stack': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
+    'dm_furthest_point_sampling': (ci, [ci, ci, ci, vp, vp, vp, vp]),
+    'dm_points_in_boxes': (ci, [ci, ci, ci, vp, vp, vp, vp]),
     'dm_profile_enable': (ci, [ci]),
     'dm_spconv_debug_stamps': (ci, [vp]),
     'dm_spconv_set_variant': (ci, [ci]),

@@ -1,0 +1,354 @@
+// Rotated BEV overlap / IoU matrices and device-resident rotated NMS for gfx950.
+//
+// Replaces pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:236-359 and the host side of
+// pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:50-185 (cudaMalloc + whole-mask D2H + serial
+// host greedy).  Differences that are design, not semantics:
+//   * cos/sin of every box heading are evaluated ONCE per box (a pre-pass) instead of
+//     up to 20 times per pair; the values are identical because they are the same
+//     function of the same input.  Transcendentals are "double libm rounded to float"
+//     — the rule the CPU oracle uses too (oracle/dm_oracle.c) — so that keep masks
+//     agree bit for bit; the fp32 op order of box_overlap is kept as written
+//     (compiled with -ffp-contract=off).
+//   * only the upper-triangular 64x64 tiles of the suppression mask are computed (the
+//     greedy pass never reads the others, iou3d_nms.cpp:122-133);
+//   * the greedy pass runs on the device (one wave, remv[] words spread over lanes);
+//     nothing is copied to the host, num_keep stays in device memory.
+#include "dm_common.h"
+
+namespace {
+
+struct Pt {
+  float x, y;
+};
+
+constexpr float kEps = 1e-8f;
+
+__device__ __forceinline__ float cross2(Pt a, Pt b) { return a.x * b.y - a.y * b.x; }
+__device__ __forceinline__ float cross3(Pt p1, Pt p2, Pt p0) {
+  return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+__device__ __forceinline__ float fmin2(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float fmax2(float a, float b) { return a > b ? a : b; }
+
+__device__ __forceinline__ bool check_rect_cross(Pt p1, Pt p2, Pt q1, Pt q2) {
+  return fmin2(p1.x, p2.x) <= fmax2(q1.x, q2.x) && fmin2(q1.x, q2.x) <= fmax2(p1.x, p2.x) &&
+         fmin2(p1.y, p2.y) <= fmax2(q1.y, q2.y) && fmin2(q1.y, q2.y) <= fmax2(p1.y, p2.y);
+}
+
+// iou3d_nms_kernel.cu:51-62 with cos(-h) = cs.x, sin(-h) = -cs.y precomputed
+__device__ __forceinline__ bool check_in_box2d(const float *box, float2 cs, Pt p) {
+  const float MARGIN = 1e-2f;
+  float center_x = box[0], center_y = box[1];
+  float angle_cos = cs.x, angle_sin = -cs.y;
+  float rot_x = (p.x - center_x) * angle_cos + (p.y - center_y) * (-angle_sin);
+  float rot_y = (p.x - center_x) * angle_sin + (p.y - center_y) * angle_cos;
+  return fabsf(rot_x) < box[3] / 2 + MARGIN && fabsf(rot_y) < box[4] / 2 + MARGIN;
+}
+
+__device__ __forceinline__ bool intersection(Pt p1, Pt p0, Pt q1, Pt q0, Pt *ans) {
+  if (!check_rect_cross(p0, p1, q0, q1)) return false;
+  float s1 = cross3(q0, p1, p0);
+  float s2 = cross3(p1, q1, p0);
+  float s3 = cross3(p0, q1, q0);
+  float s4 = cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+  float s5 = cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > kEps) {
+    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    float D = a0 * b1 - a1 * b0;
+    ans->x = (b0 * c1 - b1 * c0) / D;
+    ans->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return true;
+}
+
+__device__ __forceinline__ Pt rotate_around_center(Pt c, float acos_, float asin_, Pt p) {
+  Pt r;
+  r.x = (p.x - c.x) * acos_ + (p.y - c.y) * (-asin_) + c.x;
+  r.y = (p.x - c.x) * asin_ + (p.y - c.y) * acos_ + c.y;
+  return r;
+}
+
+__device__ __forceinline__ float atan2f_d(float y, float x) {
+  return (float)atan2((double)y, (double)x);
+}
+
+// iou3d_nms_kernel.cu:104-224; csa / csb = (cos, sin) of the two headings
+__device__ float box_overlap(const float *box_a, float2 csa, const float *box_b, float2 csb) {
+  float a_dx_half = box_a[3] / 2, b_dx_half = box_b[3] / 2;
+  float a_dy_half = box_a[4] / 2, b_dy_half = box_b[4] / 2;
+  float a_x1 = box_a[0] - a_dx_half, a_y1 = box_a[1] - a_dy_half;
+  float a_x2 = box_a[0] + a_dx_half, a_y2 = box_a[1] + a_dy_half;
+  float b_x1 = box_b[0] - b_dx_half, b_y1 = box_b[1] - b_dy_half;
+  float b_x2 = box_b[0] + b_dx_half, b_y2 = box_b[1] + b_dy_half;
+  Pt center_a = {box_a[0], box_a[1]}, center_b = {box_b[0], box_b[1]};
+  Pt ca[5] = {{a_x1, a_y1}, {a_x2, a_y1}, {a_x2, a_y2}, {a_x1, a_y2}, {0, 0}};
+  Pt cb[5] = {{b_x1, b_y1}, {b_x2, b_y1}, {b_x2, b_y2}, {b_x1, b_y2}, {0, 0}};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    ca[k] = rotate_around_center(center_a, csa.x, csa.y, ca[k]);
+    cb[k] = rotate_around_center(center_b, csb.x, csb.y, cb[k]);
+  }
+  ca[4] = ca[0];
+  cb[4] = cb[0];
+  Pt cross_points[16];
+  Pt poly_center = {0.f, 0.f};
+  int cnt = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      Pt ans;
+      if (intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &ans)) {
+        poly_center.x = poly_center.x + ans.x;
+        poly_center.y = poly_center.y + ans.y;
+        cross_points[cnt++] = ans;
+      }
+    }
+  for (int k = 0; k < 4; k++) {
+    if (check_in_box2d(box_a, csa, cb[k])) {
+      poly_center.x = poly_center.x + cb[k].x;
+      poly_center.y = poly_center.y + cb[k].y;
+      cross_points[cnt++] = cb[k];
+    }
+    if (check_in_box2d(box_b, csb, ca[k])) {
+      poly_center.x = poly_center.x + ca[k].x;
+      poly_center.y = poly_center.y + ca[k].y;
+      cross_points[cnt++] = ca[k];
+    }
+  }
+  if (cnt == 0) return 0.f;
+  poly_center.x /= cnt;
+  poly_center.y /= cnt;
+  // bubble sort by angle about the centroid (:200-209); angles evaluated once per point
+  float ang[16];
+  for (int i = 0; i < cnt; ++i)
+    ang[i] = atan2f_d(cross_points[i].y - poly_center.y, cross_points[i].x - poly_center.x);
+  for (int j = 0; j < cnt - 1; j++)
+    for (int i = 0; i < cnt - j - 1; i++)
+      if (ang[i] > ang[i + 1]) {
+        Pt t = cross_points[i];
+        cross_points[i] = cross_points[i + 1];
+        cross_points[i + 1] = t;
+        float ta = ang[i];
+        ang[i] = ang[i + 1];
+        ang[i + 1] = ta;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; k++) {
+    Pt u = {cross_points[k].x - cross_points[0].x, cross_points[k].y - cross_points[0].y};
+    Pt v = {cross_points[k + 1].x - cross_points[0].x, cross_points[k + 1].y - cross_points[0].y};
+    area += cross2(u, v);
+  }
+  return fabsf(area) / 2.0f;
+}
+
+__device__ __forceinline__ float iou_bev(const float *a, float2 csa, const float *b, float2 csb) {
+  float sa = a[3] * a[4];
+  float sb = b[3] * b[4];
+  float s_overlap = box_overlap(a, csa, b, csb);
+  return s_overlap / fmaxf(sa + sb - s_overlap, kEps);
+}
+
+__device__ __forceinline__ float iou_normal(const float *a, const float *b) {
+  float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+  float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+  float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+  float interS = width * height;
+  float Sa = a[3] * a[4];
+  float Sb = b[3] * b[4];
+  return interS / fmaxf(Sa + Sb - interS, kEps);
+}
+
+__global__ __launch_bounds__(256) void heading_cos_sin(const float *boxes, int n, float2 *cs) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double h = (double)boxes[(size_t)i * 7 + 6];
+  cs[i] = make_float2((float)cos(h), (float)sin(h));
+}
+
+// one 16x16 tile of the (na, nb) matrix per 256-thread block, boxes staged in LDS
+template <bool IOU>
+__global__ __launch_bounds__(256) void pair_matrix(const float *boxes_a, const float2 *cs_a, int na,
+                                                   const float *boxes_b, const float2 *cs_b, int nb,
+                                                   float *out) {
+  __shared__ float sa[16 * 7], sb[16 * 7];
+  __shared__ float2 ca[16], cb[16];
+  int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
+  if (threadIdx.x < 112) {
+    int i = threadIdx.x / 7;
+    if (a0 + i < na) sa[threadIdx.x] = boxes_a[(size_t)a0 * 7 + threadIdx.x];
+    if (b0 + i < nb) sb[threadIdx.x] = boxes_b[(size_t)b0 * 7 + threadIdx.x];
+  } else if (threadIdx.x < 128) {
+    int i = threadIdx.x - 112;
+    if (a0 + i < na) ca[i] = cs_a[a0 + i];
+    if (b0 + i < nb) cb[i] = cs_b[b0 + i];
+  }
+  __syncthreads();
+  int ai = a0 + ty, bi = b0 + tx;
+  if (ai >= na || bi >= nb) return;
+  float v = IOU ? iou_bev(sa + ty * 7, ca[ty], sb + tx * 7, cb[tx])
+                : box_overlap(sa + ty * 7, ca[ty], sb + tx * 7, cb[tx]);
+  out[(size_t)ai * nb + bi] = v;
+}
+
+// mask[r][c] bit i = iou(box_r, box_{64c+i}) > thresh; upper-triangular tiles only
+template <bool NORMAL>
+__global__ __launch_bounds__(64) void nms_mask(const float *boxes, const float2 *cs, int n,
+                                               float thresh, unsigned long long *mask) {
+  const int row_start = blockIdx.y, col_start = blockIdx.x;
+  if (col_start < row_start) return;
+  const int col_blocks = (n + 63) / 64;
+  const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+  __shared__ float bb[64 * 7];
+  __shared__ float2 bcs[64];
+  int t = threadIdx.x;
+  if (t < col_size) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) bb[t * 7 + j] = boxes[(size_t)(64 * col_start + t) * 7 + j];
+    if (!NORMAL) bcs[t] = cs[64 * col_start + t];
+  }
+  __syncthreads();
+  if (t < row_size) {
+    const int cur = 64 * row_start + t;
+    float cb[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) cb[j] = boxes[(size_t)cur * 7 + j];
+    float2 ccs = NORMAL ? make_float2(1.f, 0.f) : cs[cur];
+    unsigned long long bits = 0;
+    int start = (row_start == col_start) ? t + 1 : 0;
+    for (int i = start; i < col_size; i++) {
+      float v = NORMAL ? iou_normal(cb, bb + i * 7) : iou_bev(cb, ccs, bb + i * 7, bcs[i]);
+      if (v > thresh) bits |= 1ULL << i;
+    }
+    mask[(size_t)cur * col_blocks + col_start] = bits;
+  }
+}
+
+// Greedy pass (iou3d_nms.cpp:117-133) by ONE wave: lane l owns remv words l, l+64, ...
+// Stops after max_keep survivors (callers slice keep[:post_max] anyway).
+__global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *mask, int n,
+                                                 int max_keep, long long *keep, int *num_keep) {
+  const int col_blocks = (n + 63) / 64;
+  const int lane = threadIdx.x;
+  constexpr int MAXW = 16;  // up to 64*16 words = 65536 boxes
+  unsigned long long remv[MAXW];
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) remv[w] = 0ull;
+  int kept = 0;
+  for (int blk = 0; blk < col_blocks && kept < max_keep; ++blk) {
+    // the word that decides boxes [64*blk, 64*blk+64) lives on lane blk%64, slot blk/64
+    int slot = blk >> 6, owner = blk & 63;
+    unsigned long long word = 0;
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w)
+      if (w == slot) word = remv[w];
+    word = __shfl(word, owner);
+    int lim = min(64, n - blk * 64);
+    for (int b = 0; b < lim && kept < max_keep; ++b) {
+      if (word & (1ULL << b)) continue;
+      int i = blk * 64 + b;
+      if (lane == 0) keep[kept] = i;
+      ++kept;
+      const unsigned long long *p = mask + (size_t)i * col_blocks;
+#pragma unroll
+      for (int w = 0; w < MAXW; ++w) {
+        int j = w * 64 + lane;
+        if (j >= blk && j < col_blocks) remv[w] |= p[j];
+      }
+      unsigned long long mine = 0;
+#pragma unroll
+      for (int w = 0; w < MAXW; ++w)
+        if (w == slot) mine = remv[w];
+      word = __shfl(mine, owner);
+    }
+  }
+  if (lane == 0) *num_keep = kept;
+}
+
+}  // namespace
+
+extern "C" size_t dm_iou3d_workspace_bytes(int na, int nb) {
+  size_t n = (size_t)(na > 0 ? na : 0) + (nb > 0 ? nb : 0);
+  return dm_align(n * sizeof(float2)) + 256;
+}
+
+static int pair_launch(bool iou, const float *a, int na, const float *b, int nb, float *out,
+                       void *ws, size_t ws_bytes, hipStream_t st) {
+  if (na < 0 || nb < 0) return DM_ERR_INVALID_ARG;
+  if (na == 0 || nb == 0) return DM_OK;
+  if (!a || !b || !out || !ws) return DM_ERR_INVALID_ARG;
+  if (ws_bytes < dm_iou3d_workspace_bytes(na, nb)) return DM_ERR_WORKSPACE;
+  float2 *csa = (float2 *)ws, *csb = csa + na;
+  heading_cos_sin<<<dm_ceil_div(na, 256), 256, 0, st>>>(a, na, csa);
+  heading_cos_sin<<<dm_ceil_div(nb, 256), 256, 0, st>>>(b, nb, csb);
+  DM_CHECK_LAUNCH();
+  dim3 grid(dm_ceil_div(nb, 16), dm_ceil_div(na, 16));
+  if (iou) pair_matrix<true><<<grid, 256, 0, st>>>(a, csa, na, b, csb, nb, out);
+  else pair_matrix<false><<<grid, 256, 0, st>>>(a, csa, na, b, csb, nb, out);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_boxes_overlap_bev(const float *boxes_a, int na, const float *boxes_b, int nb,
+                                    float *ans_overlap, void *workspace, size_t workspace_bytes,
+                                    dm_stream_t stream) {
+  return pair_launch(false, boxes_a, na, boxes_b, nb, ans_overlap, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}
+
+extern "C" int dm_boxes_iou_bev(const float *boxes_a, int na, const float *boxes_b, int nb,
+                                float *ans_iou, void *workspace, size_t workspace_bytes,
+                                dm_stream_t stream) {
+  return pair_launch(true, boxes_a, na, boxes_b, nb, ans_iou, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}
+
+extern "C" size_t dm_nms_workspace_bytes(int n) {
+  if (n <= 0) return 256;
+  size_t col_blocks = ((size_t)n + 63) / 64;
+  return dm_align((size_t)n * col_blocks * 8) + dm_align((size_t)n * sizeof(float2)) + 256;
+}
+
+static int nms_launch(bool normal, const float *boxes, int n, float thresh, int max_keep,
+                      long long *keep, int *num_keep, void *ws, size_t ws_bytes, hipStream_t st) {
+  if (n < 0 || !num_keep) return DM_ERR_INVALID_ARG;
+  if (n == 0) {
+    DM_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), st));
+    return DM_OK;
+  }
+  if (n > 64 * 64 * 16) return DM_ERR_UNSUPPORTED;
+  if (!boxes || !keep || !ws) return DM_ERR_INVALID_ARG;
+  if (ws_bytes < dm_nms_workspace_bytes(n)) return DM_ERR_WORKSPACE;
+  if (max_keep <= 0 || max_keep > n) max_keep = n;
+  int col_blocks = (n + 63) / 64;
+  unsigned long long *mask = (unsigned long long *)ws;
+  float2 *cs = (float2 *)((char *)ws + dm_align((size_t)n * col_blocks * 8));
+  if (!normal) {
+    heading_cos_sin<<<dm_ceil_div(n, 256), 256, 0, st>>>(boxes, n, cs);
+    DM_CHECK_LAUNCH();
+  }
+  dim3 grid(col_blocks, col_blocks);
+  if (normal) nms_mask<true><<<grid, 64, 0, st>>>(boxes, cs, n, thresh, mask);
+  else nms_mask<false><<<grid, 64, 0, st>>>(boxes, cs, n, thresh, mask);
+  DM_CHECK_LAUNCH();
+  nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_nms(const float *boxes, int n, float thresh, int max_keep, long long *keep,
+                      int *num_keep, void *workspace, size_t workspace_bytes, dm_stream_t stream) {
+  return nms_launch(false, boxes, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes,
+                    (hipStream_t)stream);
+}
+
+extern "C" int dm_nms_normal(const float *boxes, int n, float thresh, int max_keep,
+                             long long *keep, int *num_keep, void *workspace,
+                             size_t workspace_bytes, dm_stream_t stream) {
+  return nms_launch(true, boxes, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes,
+                    (hipStream_t)stream);
+}

@@ -1,0 +1,447 @@
+// Stacked-batch PointNet++ operators for gfx950: ball query, grouping (fwd / grad),
+// furthest point sampling.
+//
+// Replaces pcdet/ops/pointnet2/pointnet2_stack/src/{ball_query,group_points,sampling}_gpu.cu.
+// Index semantics are the reference's, bit for bit:
+//   ball query  first `nsample` points of the query's sample with d2 < r^2 in STORAGE
+//               order, remaining slots padded with the first hit (ball_query_gpu.cu:48-65)
+//   FPS         start at index 0; next = argmax of the running min distance; ties go to
+//               the point that the reference's block reduction would pick for its block
+//               size min(2^floor(log2 n), 1024): smallest bit-reversed (k mod bs), then
+//               smallest k
+//               (sampling_gpu.cu:9-21,55-70)
+// Distances are the FMA chain the device compiler makes of a*a+b*b+c*c, written out with
+// fmaf() (the file is compiled with -ffp-contract=off, as is the CPU oracle).
+#include "dm_common.h"
+
+namespace {
+
+__device__ __forceinline__ float dist2_fma(float dx, float dy, float dz) {
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+struct BatchCnt {
+  int n[DM_MAX_BATCH];
+};
+
+// ---- ball query ---------------------------------------------------------------
+// grid (query chunks, samples); a block stages 1024-point tiles of its sample's xyz in
+// LDS and every thread scans them for its own query until it has nsample hits.
+constexpr int BQ_TILE = 1024;
+
+__global__ __launch_bounds__(256) void ball_query_kernel(int batch, float radius2, int nsample,
+                                                         const float *__restrict__ new_xyz,
+                                                         const int *__restrict__ new_cnt,
+                                                         const float *__restrict__ xyz,
+                                                         const int *__restrict__ xyz_cnt,
+                                                         int *__restrict__ idx,
+                                                         unsigned char *__restrict__ empty_mask) {
+  __shared__ float tile[BQ_TILE * 3];
+  __shared__ int alive_s;
+  const int b = blockIdx.y;
+  int q_start = 0, p_start = 0;
+  for (int k = 0; k < b; ++k) {
+    q_start += new_cnt[k];
+    p_start += xyz_cnt[k];
+  }
+  const int mq = new_cnt[b], n = xyz_cnt[b];
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= mq) return;
+  const bool has_q = q < mq;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  int *out = idx;
+  if (has_q) {
+    const float *p = new_xyz + (size_t)(q_start + q) * 3;
+    qx = p[0];
+    qy = p[1];
+    qz = p[2];
+    out = idx + (size_t)(q_start + q) * nsample;
+  }
+  int cnt = 0;
+  bool done = !has_q;
+  const float *base = xyz + (size_t)p_start * 3;
+  for (int t0 = 0; t0 < n; t0 += BQ_TILE) {
+    int tn = min(BQ_TILE, n - t0);
+    __syncthreads();
+    if (threadIdx.x == 0) alive_s = 0;
+    for (int e = threadIdx.x; e < tn * 3; e += 256) tile[e] = base[(size_t)t0 * 3 + e];
+    __syncthreads();
+    if (!done) {
+      for (int k = 0; k < tn; ++k) {
+        float d2 = dist2_fma(qx - tile[k * 3 + 0], qy - tile[k * 3 + 1], qz - tile[k * 3 + 2]);
+        if (d2 < radius2) {
+          int pk = t0 + k;
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) out[l] = pk;
+          out[cnt] = pk;
+          ++cnt;
+          if (cnt >= nsample) {
+            done = true;
+            break;
+          }
+        }
+      }
+      if (!done) alive_s = 1;  // benign race: any writer stores 1
+    }
+    __syncthreads();
+    if (alive_s == 0) break;
+  }
+  if (has_q) {
+    if (empty_mask) {  // fused post-processing of pointnet2_utils.py:36-37
+      empty_mask[q_start + q] = cnt == 0;
+      if (cnt == 0)
+        for (int l = 0; l < nsample; ++l) out[l] = 0;
+    } else if (cnt == 0) {
+      out[0] = -1;  // ball_query_gpu.cu:65
+    }
+  }
+}
+
+// ---- grouping -------------------------------------------------------------------
+// One wave per query point: rows are read coalesced (lanes over channels), transposed
+// through a wave-private LDS tile and written as contiguous (C, nsample) blocks.
+constexpr int GP_MAX_ELEMS = 4352;  // (C+1)*nsample floats of LDS per wave, e.g. C=135, ns=32
+
+__global__ __launch_bounds__(256) void group_points_kernel(int batch, int m, int c, int nsample,
+                                                           const float *__restrict__ feats,
+                                                           const int *__restrict__ feats_cnt,
+                                                           const int *__restrict__ idx,
+                                                           const int *__restrict__ idx_cnt,
+                                                           const unsigned char *__restrict__ empty,
+                                                           float *__restrict__ out) {
+  extern __shared__ float gp_lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pt = blockIdx.x * 4 + wave;
+  if (pt >= m) return;
+  float *tile = gp_lds + (size_t)wave * (c + 1) * nsample;
+  int bs = 0, acc = idx_cnt[0];
+  for (int k = 1; k < batch; ++k) {
+    if (pt < acc) break;
+    acc += idx_cnt[k];
+    bs = k;
+  }
+  int start = 0;
+  for (int k = 0; k < bs; ++k) start += feats_cnt[k];
+  const bool zero = empty && empty[pt];
+  for (int s = 0; s < nsample; ++s) {
+    const float *row = feats + (size_t)(start + idx[(size_t)pt * nsample + s]) * c;
+    for (int ci = lane; ci < c; ci += 64) tile[s * (c + 1) + ci] = zero ? 0.f : row[ci];
+  }
+  // wave-private tile: LDS ops of one wave complete in order; the fence only pins the
+  // compiler's ordering of the cross-lane hand-off
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float *o = out + (size_t)pt * c * nsample;
+  for (int e = lane; e < c * nsample; e += 64) {
+    int ci = e / nsample, s = e % nsample;
+    o[e] = tile[s * (c + 1) + ci];
+  }
+}
+
+__global__ __launch_bounds__(256) void group_points_grad_kernel(int batch, int m, int c,
+                                                                int nsample,
+                                                                const float *__restrict__ grad_out,
+                                                                const int *__restrict__ idx,
+                                                                const int *__restrict__ idx_cnt,
+                                                                const int *__restrict__ feats_cnt,
+                                                                float *__restrict__ grad_feats) {
+  extern __shared__ float gp_lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pt = blockIdx.x * 4 + wave;
+  if (pt >= m) return;
+  float *tile = gp_lds + (size_t)wave * (c + 1) * nsample;
+  int bs = 0, acc = idx_cnt[0];
+  for (int k = 1; k < batch; ++k) {
+    if (pt < acc) break;
+    acc += idx_cnt[k];
+    bs = k;
+  }
+  int start = 0;
+  for (int k = 0; k < bs; ++k) start += feats_cnt[k];
+  const float *g = grad_out + (size_t)pt * c * nsample;
+  for (int e = lane; e < c * nsample; e += 64) {
+    int ci = e / nsample, s = e % nsample;
+    tile[s * (c + 1) + ci] = g[e];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // one 256-byte-contiguous atomic wave-instruction per (sample slot, 64 channels)
+  for (int s = 0; s < nsample; ++s) {
+    float *row = grad_feats + (size_t)(start + idx[(size_t)pt * nsample + s]) * c;
+    for (int ci = lane; ci < c; ci += 64) atomicAdd(row + ci, tile[s * (c + 1) + ci]);
+  }
+}
+
+// ---- furthest point sampling ----------------------------------------------------
+// One 1024-thread workgroup per sample; each thread keeps its points (xyz + running min
+// distance) in registers for all m-1 rounds, so a round is pure VALU + one cross-wave
+// reduction — no global traffic inside the loop.
+struct FpsBest {
+  float d;
+  int k;
+};
+
+__device__ __forceinline__ bool fps_better(float d2, int k2, float d1, int k1, int bs_mask) {
+  // reference tie rule: larger distance; then the stride class (k mod block_size) that the
+  // shared-memory tree keeps — at the level where two classes first meet the one in the
+  // lower half survives, i.e. the smaller BIT-REVERSED class index; then smaller k
+  if (d2 != d1) return d2 > d1;
+  unsigned int c2 = __brev((unsigned int)(k2 & bs_mask)), c1 = __brev((unsigned int)(k1 & bs_mask));
+  if (c2 != c1) return c2 < c1;
+  return k2 < k1;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs_mask,
+                                                   const float *__restrict__ xyz,
+                                                   float *__restrict__ temp,
+                                                   int *__restrict__ idxs) {
+  __shared__ float s_d[16];
+  __shared__ int s_k[16];
+  __shared__ float s_pt[3];
+  __shared__ int s_old;
+  const int b = blockIdx.x;
+  const float *data = xyz + (size_t)b * n * 3;
+  float *tmp = temp + (size_t)b * n;
+  int *out = idxs + (size_t)b * m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float px[PPT], py[PPT], pz[PPT], pt[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    int k = tid + i * 1024;
+    bool ok = k < n;
+    px[i] = ok ? data[(size_t)k * 3 + 0] : 0.f;
+    py[i] = ok ? data[(size_t)k * 3 + 1] : 0.f;
+    pz[i] = ok ? data[(size_t)k * 3 + 2] : 0.f;
+    pt[i] = ok ? tmp[k] : -1.f;  // padding can never win (every real d2 is >= 0 > -1)
+  }
+  if (tid == 0) {
+    out[0] = 0;
+    s_old = 0;
+    s_pt[0] = data[0];
+    s_pt[1] = data[1];
+    s_pt[2] = data[2];
+  }
+  __syncthreads();
+  for (int j = 1; j < m; ++j) {
+    const float x1 = s_pt[0], y1 = s_pt[1], z1 = s_pt[2];
+    float best = -1.f;
+    int besti = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      int k = tid + i * 1024;
+      if (k < n) {
+        float d = dist2_fma(px[i] - x1, py[i] - y1, pz[i] - z1);
+        float d2 = fminf(d, pt[i]);
+        pt[i] = d2;
+        if (fps_better(d2, k, best, besti, bs_mask) || best < 0.f) {
+          best = d2;
+          besti = k;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      float od = __shfl_xor(best, off);
+      int ok = __shfl_xor(besti, off);
+      if (od >= 0.f && (best < 0.f || fps_better(od, ok, best, besti, bs_mask))) {
+        best = od;
+        besti = ok;
+      }
+    }
+    __syncthreads();  // previous round's s_pt / s_d readers are done
+    if (lane == 0) {
+      s_d[wave] = best;
+      s_k[wave] = besti;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float d = lane < 16 ? s_d[lane] : -1.f;
+      int k = lane < 16 ? s_k[lane] : 0;
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        float od = __shfl_xor(d, off);
+        int ok = __shfl_xor(k, off);
+        if (od >= 0.f && (d < 0.f || fps_better(od, ok, d, k, bs_mask))) {
+          d = od;
+          k = ok;
+        }
+      }
+      if (lane == 0) {
+        out[j] = k;
+        s_old = k;
+        s_pt[0] = data[(size_t)k * 3 + 0];
+        s_pt[1] = data[(size_t)k * 3 + 1];
+        s_pt[2] = data[(size_t)k * 3 + 2];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    int k = tid + i * 1024;
+    if (k < n) tmp[k] = pt[i];
+  }
+}
+
+// fallback for point counts whose per-thread share does not fit the register file:
+// the running minima live in `temp` (global), as in the reference
+__global__ __launch_bounds__(1024) void fps_kernel_global(int n, int m, int bs_mask,
+                                                          const float *__restrict__ xyz,
+                                                          float *__restrict__ temp,
+                                                          int *__restrict__ idxs) {
+  __shared__ float s_d[16];
+  __shared__ int s_k[16];
+  __shared__ int s_old;
+  const int b = blockIdx.x;
+  const float *data = xyz + (size_t)b * n * 3;
+  float *tmp = temp + (size_t)b * n;
+  int *out = idxs + (size_t)b * m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    out[0] = 0;
+    s_old = 0;
+  }
+  __syncthreads();
+  for (int j = 1; j < m; ++j) {
+    int old = s_old;
+    const float x1 = data[(size_t)old * 3], y1 = data[(size_t)old * 3 + 1],
+                z1 = data[(size_t)old * 3 + 2];
+    float best = -1.f;
+    int besti = 0;
+    for (int k = tid; k < n; k += 1024) {
+      float d = dist2_fma(data[(size_t)k * 3] - x1, data[(size_t)k * 3 + 1] - y1,
+                          data[(size_t)k * 3 + 2] - z1);
+      float d2 = fminf(d, tmp[k]);
+      tmp[k] = d2;
+      if (best < 0.f || fps_better(d2, k, best, besti, bs_mask)) {
+        best = d2;
+        besti = k;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      float od = __shfl_xor(best, off);
+      int ok = __shfl_xor(besti, off);
+      if (od >= 0.f && (best < 0.f || fps_better(od, ok, best, besti, bs_mask))) {
+        best = od;
+        besti = ok;
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      s_d[wave] = best;
+      s_k[wave] = besti;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float d = lane < 16 ? s_d[lane] : -1.f;
+      int k = lane < 16 ? s_k[lane] : 0;
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        float od = __shfl_xor(d, off);
+        int ok = __shfl_xor(k, off);
+        if (od >= 0.f && (d < 0.f || fps_better(od, ok, d, k, bs_mask))) {
+          d = od;
+          k = ok;
+        }
+      }
+      if (lane == 0) {
+        out[j] = k;
+        s_old = k;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int dm_ball_query_stack(int batch, int m, float radius, int nsample,
+                                   const float *new_xyz, const int *new_xyz_batch_cnt,
+                                   const float *xyz, const int *xyz_batch_cnt, int max_m_per_sample,
+                                   int *idx, unsigned char *empty_mask, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (batch <= 0 || batch > DM_MAX_BATCH || m < 0 || nsample <= 0 || max_m_per_sample < 0)
+    return DM_ERR_INVALID_ARG;
+  if (m == 0) return DM_OK;
+  if (!new_xyz || !new_xyz_batch_cnt || !xyz_batch_cnt || !idx) return DM_ERR_INVALID_ARG;
+  float radius2 = radius * radius;  // ball_query_gpu.cu:43
+  dim3 grid(dm_ceil_div(max_m_per_sample > 0 ? max_m_per_sample : m, 256), batch);
+  ball_query_kernel<<<grid, 256, 0, st>>>(batch, radius2, nsample, new_xyz, new_xyz_batch_cnt, xyz,
+                                          xyz_batch_cnt, idx, empty_mask);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_group_points_stack(int batch, int m, int c, int nsample, const float *features,
+                                     const int *features_batch_cnt, const int *idx,
+                                     const int *idx_batch_cnt, const unsigned char *empty_mask,
+                                     float *out, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (batch <= 0 || m < 0 || c <= 0 || nsample <= 0) return DM_ERR_INVALID_ARG;
+  if (m == 0) return DM_OK;
+  if ((c + 1) * nsample > GP_MAX_ELEMS) return DM_ERR_UNSUPPORTED;
+  if (!features || !features_batch_cnt || !idx || !idx_batch_cnt || !out) return DM_ERR_INVALID_ARG;
+  size_t smem = 4ull * (c + 1) * nsample * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    DM_HIP(hipFuncSetAttribute((const void *)group_points_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    DM_HIP(hipFuncSetAttribute((const void *)group_points_grad_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr = true;
+  }
+  group_points_kernel<<<dm_ceil_div(m, 4), 256, smem, st>>>(batch, m, c, nsample, features,
+                                                            features_batch_cnt, idx, idx_batch_cnt,
+                                                            empty_mask, out);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_group_points_grad_stack(int batch, int m, int c, int n, int nsample,
+                                          const float *grad_out, const int *idx,
+                                          const int *idx_batch_cnt, const int *features_batch_cnt,
+                                          float *grad_features, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (batch <= 0 || m < 0 || c <= 0 || nsample <= 0 || n < 0) return DM_ERR_INVALID_ARG;
+  if (n > 0) {
+    if (!grad_features) return DM_ERR_INVALID_ARG;
+    DM_HIP(hipMemsetAsync(grad_features, 0, (size_t)n * c * sizeof(float), st));
+  }
+  if (m == 0 || n == 0) return DM_OK;
+  if ((c + 1) * nsample > GP_MAX_ELEMS) return DM_ERR_UNSUPPORTED;
+  if (!grad_out || !idx || !idx_batch_cnt || !features_batch_cnt) return DM_ERR_INVALID_ARG;
+  size_t smem = 4ull * (c + 1) * nsample * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    DM_HIP(hipFuncSetAttribute((const void *)group_points_grad_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr = true;
+  }
+  group_points_grad_kernel<<<dm_ceil_div(m, 4), 256, smem, st>>>(
+      batch, m, c, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float *temp,
+                                          int *idxs, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (batch < 0 || n <= 0 || m < 0) return DM_ERR_INVALID_ARG;
+  if (batch == 0 || m == 0) return DM_OK;
+  if (!xyz || !temp || !idxs) return DM_ERR_INVALID_ARG;
+  // the reference's block size for this n (sampling_gpu.cu:9-13) fixes the tie rule
+  int bs = 1;
+  while (bs * 2 <= n && bs < 1024) bs *= 2;
+  int bs_mask = bs - 1;
+  int ppt = dm_ceil_div(n, 1024);
+  if (ppt <= 4) fps_kernel<4><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
+  else if (ppt <= 8) fps_kernel<8><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
+  else if (ppt <= 16) fps_kernel<16><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
+  else if (ppt <= 24) fps_kernel<24><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
+  else if (ppt <= 32) fps_kernel<32><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
+  else fps_kernel_global<<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}

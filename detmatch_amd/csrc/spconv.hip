@@ -334,6 +334,8 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
         if ((m >> (16 * q)) & 0xFFFFull) active |= 1u << (4 * k4 + q);
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // tbl[wave] is read across lanes
+  __builtin_amdgcn_wave_barrier();
   // deal the active offsets round-robin to the four waves
   unsigned int mine = 0u;
   {

@@ -1,0 +1,198 @@
+"""Stacked-batch PointNet++ ops and modules — host-side mirror of
+pcdet/ops/pointnet2/pointnet2_stack/{pointnet2_utils,pointnet2_modules}.py.
+
+Same names / argument meaning (`ball_query`, `grouping_operation`,
+`furthest_point_sample`, `QueryAndGroup`, `StackSAModuleMSG`); compute in
+libdetmatch_hip.so (pointnet2_stack.hip).
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 else t.int()
+
+
+class BallQuery(Function):
+    """pointnet2_utils.py:8-44"""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
+                max_m_per_sample=0):
+        xyz = xyz.contiguous()
+        new_xyz = new_xyz.contiguous()
+        xyz_batch_cnt = _i32(xyz_batch_cnt).contiguous()
+        new_xyz_batch_cnt = _i32(new_xyz_batch_cnt).contiguous()
+        _lib.require_device(xyz, new_xyz, xyz_batch_cnt, new_xyz_batch_cnt)
+        B = xyz_batch_cnt.shape[0]
+        M = new_xyz.shape[0]
+        idx = torch.zeros((M, nsample), dtype=torch.int32, device=xyz.device)
+        empty = torch.zeros((M,), dtype=torch.uint8, device=xyz.device)
+        rc = _lib.lib().dm_ball_query_stack(B, M, float(radius), int(nsample), _lib.ptr(new_xyz),
+                                            _lib.ptr(new_xyz_batch_cnt), _lib.ptr(xyz),
+                                            _lib.ptr(xyz_batch_cnt), int(max_m_per_sample),
+                                            _lib.ptr(idx), _lib.ptr(empty), _lib.stream())
+        _lib.check(rc, 'dm_ball_query_stack')
+        ctx.mark_non_differentiable(idx)
+        return idx, empty.bool()
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class GroupingOperation(Function):
+    """pointnet2_utils.py:48-113.  `empty_mask` (extension): rows of empty balls are
+    written as zeros by the kernel instead of a separate masked assignment."""
+
+    @staticmethod
+    def forward(ctx, features, features_batch_cnt, idx, idx_batch_cnt, empty_mask=None):
+        features = features.contiguous()
+        features_batch_cnt = _i32(features_batch_cnt).contiguous()
+        idx_batch_cnt = _i32(idx_batch_cnt).contiguous()
+        idx = idx.contiguous()
+        _lib.require_device(features, features_batch_cnt, idx, idx_batch_cnt)
+        M, nsample = idx.size()
+        N, C = features.size()
+        B = idx_batch_cnt.shape[0]
+        output = torch.empty((M, C, nsample), dtype=torch.float32, device=features.device)
+        em = None
+        if empty_mask is not None:
+            em = empty_mask.to(torch.uint8).contiguous()
+        rc = _lib.lib().dm_group_points_stack(B, M, C, nsample, _lib.ptr(features),
+                                              _lib.ptr(features_batch_cnt), _lib.ptr(idx),
+                                              _lib.ptr(idx_batch_cnt), _lib.ptr(em),
+                                              _lib.ptr(output), _lib.stream())
+        _lib.check(rc, 'dm_group_points_stack')
+        ctx.for_backwards = (B, N, idx, features_batch_cnt, idx_batch_cnt, em)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        B, N, idx, features_batch_cnt, idx_batch_cnt, em = ctx.for_backwards
+        M, C, nsample = grad_out.size()
+        grad_out = grad_out.contiguous()
+        if em is not None:  # zeroed rows carry no gradient
+            grad_out = grad_out * (em == 0).view(-1, 1, 1).to(grad_out.dtype)
+        grad_features = torch.empty((N, C), dtype=torch.float32, device=grad_out.device)
+        rc = _lib.lib().dm_group_points_grad_stack(B, M, C, N, nsample, _lib.ptr(grad_out),
+                                                   _lib.ptr(idx), _lib.ptr(idx_batch_cnt),
+                                                   _lib.ptr(features_batch_cnt),
+                                                   _lib.ptr(grad_features), _lib.stream())
+        _lib.check(rc, 'dm_group_points_grad_stack')
+        return grad_features, None, None, None, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class QueryAndGroup(nn.Module):
+    """pointnet2_utils.py:116-156"""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None):
+        idx, empty_ball_mask = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz,
+                                          new_xyz_batch_cnt)
+        grouped_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)
+        grouped_xyz = grouped_xyz - new_xyz.unsqueeze(-1)
+        grouped_xyz = grouped_xyz * (~empty_ball_mask).view(-1, 1, 1).to(grouped_xyz.dtype)
+        if features is not None:
+            grouped_features = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt,
+                                                  empty_ball_mask)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            assert self.use_xyz, 'Cannot have not features and not use xyz as a feature!'
+            new_features = grouped_xyz
+        return new_features, idx
+
+
+class FurthestPointSampling(Function):
+    """pointnet2_utils.py:158-180"""
+
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        xyz = xyz.contiguous()
+        _lib.require_device(xyz)
+        B, N, _ = xyz.size()
+        output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        rc = _lib.lib().dm_furthest_point_sampling(B, N, int(npoint), _lib.ptr(xyz), _lib.ptr(temp),
+                                                   _lib.ptr(output), _lib.stream())
+        _lib.check(rc, 'dm_furthest_point_sampling')
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class StackSAModuleMSG(nn.Module):
+    """pointnet2_modules.py:10-92: multi-scale grouping + shared MLP + max over samples."""
+
+    def __init__(self, *, radii: List[float], nsamples: List[int], mlps: List[List[int]],
+                 use_xyz: bool = True, pool_method='max_pool'):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for i in range(len(radii)):
+            self.groupers.append(QueryAndGroup(radii[i], nsamples[i], use_xyz=use_xyz))
+            mlp_spec = mlps[i]
+            if use_xyz:
+                mlp_spec[0] += 3
+            shared_mlps = []
+            for k in range(len(mlp_spec) - 1):
+                shared_mlps.extend([nn.Conv2d(mlp_spec[k], mlp_spec[k + 1], kernel_size=1,
+                                              bias=False),
+                                    nn.BatchNorm2d(mlp_spec[k + 1]), nn.ReLU()])
+            self.mlps.append(nn.Sequential(*shared_mlps))
+        self.pool_method = pool_method
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            if isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None,
+                empty_voxel_set_zeros=True):
+        new_features_list = []
+        for k in range(len(self.groupers)):
+            new_features, _ = self.groupers[k](xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
+                                               features)  # (M, C, nsample)
+            new_features = new_features.permute(1, 0, 2).unsqueeze(dim=0)  # (1, C, M, nsample)
+            new_features = self.mlps[k](new_features)
+            if self.pool_method == 'max_pool':
+                new_features = F.max_pool2d(new_features,
+                                            kernel_size=[1, new_features.size(3)]).squeeze(dim=-1)
+            elif self.pool_method == 'avg_pool':
+                new_features = F.avg_pool2d(new_features,
+                                            kernel_size=[1, new_features.size(3)]).squeeze(dim=-1)
+            else:
+                raise NotImplementedError
+            new_features_list.append(new_features.squeeze(dim=0).permute(1, 0))  # (M, C)
+        return new_xyz, torch.cat(new_features_list, dim=1)

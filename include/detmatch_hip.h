@@ -187,6 +187,63 @@ int dm_spconv_wgrad(const float *feat, const float *out_grad,
                     void *workspace, size_t workspace_bytes, dm_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
+/* E. Rotated BEV overlap / IoU, rotated NMS                                  */
+/* ------------------------------------------------------------------------ */
+/* Replaces iou3d_nms_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu
+ *   pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:50-88, iou3d_nms_kernel.cu:236-264.
+ * boxes (N,7) [x,y,z,dx,dy,dz,heading]; ans (na, nb). */
+size_t dm_iou3d_workspace_bytes(int na, int nb);
+int dm_boxes_overlap_bev(const float *boxes_a, int na, const float *boxes_b, int nb,
+                         float *ans_overlap, void *workspace, size_t workspace_bytes,
+                         dm_stream_t stream);
+int dm_boxes_iou_bev(const float *boxes_a, int na, const float *boxes_b, int nb, float *ans_iou,
+                     void *workspace, size_t workspace_bytes, dm_stream_t stream);
+/* Replaces iou3d_nms_cuda.nms_gpu / nms_normal_gpu
+ *   pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:91-185, iou3d_nms_kernel.cu:267-359.
+ * boxes must be sorted by descending score.  keep (n) int64 DEVICE (the reference's is a
+ * host tensor filled after a D2H copy of the whole mask); num_keep device int32.  The
+ * greedy pass stops after max_keep survivors (<= 0: no limit) — callers slice
+ * keep[:post_max_size] anyway (model_nms_utils.py:19-20). */
+size_t dm_nms_workspace_bytes(int n);
+int dm_nms(const float *boxes, int n, float thresh, int max_keep, long long *keep, int *num_keep,
+           void *workspace, size_t workspace_bytes, dm_stream_t stream);
+int dm_nms_normal(const float *boxes, int n, float thresh, int max_keep, long long *keep,
+                  int *num_keep, void *workspace, size_t workspace_bytes, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* D. Stacked PointNet++ operators, points-in-boxes                           */
+/* ------------------------------------------------------------------------ */
+/* Replaces pointnet2_stack_cuda.ball_query_wrapper
+ *   pcdet/ops/pointnet2/pointnet2_stack/src/ball_query.cpp, ball_query_gpu.cu:16-89.
+ * max_m_per_sample: upper bound of new_xyz_batch_cnt[] known to the host (0: use m).
+ * empty_mask NULL: reference output (idx[m][0] = -1 for an empty ball);
+ * empty_mask != NULL: fused post-processing of pointnet2_utils.py:36-37 (mask written,
+ * empty rows zeroed). */
+int dm_ball_query_stack(int batch, int m, float radius, int nsample, const float *new_xyz,
+                        const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt,
+                        int max_m_per_sample, int *idx, unsigned char *empty_mask,
+                        dm_stream_t stream);
+/* Replaces group_points_wrapper / group_points_grad_wrapper (group_points_gpu.cu:15-131).
+ * out (m, c, nsample).  empty_mask (optional): rows of empty balls are written as zeros
+ * (pointnet2_utils.py:145,150). grad_features (n, c) is zeroed by the callee. */
+int dm_group_points_stack(int batch, int m, int c, int nsample, const float *features,
+                          const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt,
+                          const unsigned char *empty_mask, float *out, dm_stream_t stream);
+int dm_group_points_grad_stack(int batch, int m, int c, int n, int nsample, const float *grad_out,
+                               const int *idx, const int *idx_batch_cnt,
+                               const int *features_batch_cnt, float *grad_features,
+                               dm_stream_t stream);
+/* Replaces furthest_point_sampling_wrapper (sampling_gpu.cu:25-189).  xyz (b,n,3),
+ * temp (b,n) pre-filled with 1e10 by the caller, idxs (b,m). */
+int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float *temp, int *idxs,
+                               dm_stream_t stream);
+/* Replaces roiaware_pool3d_cuda.points_in_boxes_gpu (roiaware_pool3d.cpp:98-129,
+ * roiaware_pool3d_kernel.cu:313-360).  box_idx (batch, pts_num): first containing box or -1
+ * (the callee writes every element; no pre-fill needed). */
+int dm_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts,
+                       int *box_idx_of_points, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* Measurement hook (bench.py roofline leg; not part of the reference ABI)    */
 /* ------------------------------------------------------------------------ */
 /* When enabled, every main sparse-conv kernel launch is bracketed by a pair of

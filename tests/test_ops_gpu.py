@@ -1,0 +1,175 @@
+"""HIP rotated IoU / NMS, stacked PointNet++ ops and points-in-boxes vs the oracle,
+through the C-ABI.  Index outputs (NMS keep lists, ball-query indices, FPS indices,
+box ids) are compared bit for bit; IoU values too (same fp32 op sequence, transcendentals
+"double libm rounded to float" on both sides)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(rng, n, spread=30.0):
+    return np.concatenate([rng.uniform(0, spread, (n, 2)), rng.uniform(-1, 1, (n, 1)),
+                           rng.uniform(0.5, 5, (n, 3)), rng.uniform(-3.2, 3.2, (n, 1))],
+                          1).astype(np.float32)
+
+
+def test_iou_matrices(orc, dev):
+    from detmatch_amd import iou3d_nms
+    rng = np.random.default_rng(0)
+    a, b = _boxes(rng, 150), _boxes(rng, 97)
+    a[3] = b[5]                      # an identical pair
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    assert np.array_equal(iou3d_nms.boxes_iou_bev(ta, tb).cpu().numpy(), orc.boxes_iou_bev(a, b))
+    assert np.array_equal(iou3d_nms.boxes_overlap_bev(ta, tb).cpu().numpy(),
+                          orc.boxes_overlap_bev(a, b))
+    np.testing.assert_allclose(iou3d_nms.boxes_iou3d_gpu(ta, tb).cpu().numpy(),
+                               orc.boxes_iou3d(a, b), rtol=1e-6, atol=1e-7)
+    # SURVEY K4 KAT
+    A = torch.tensor([[0, 0, 0, 2, 2, 1, 0], [0, 0, 0, 2, 2, 1, np.pi / 4],
+                      [10, 10, 0, 4, 2, 1.5, 0.3]], dtype=torch.float32, device=dev)
+    B = torch.tensor([[1, 0, 0, 2, 2, 1, 0], [0, 0, 0, 2, 2, 1, 0], [10.5, 10.2, 0, 4, 2, 1.5, -0.2],
+                      [5, 5, 0, 1, 1, 1, 0]], dtype=torch.float32, device=dev)
+    want = np.array([[0.3333333, 1.0, 0, 0], [0.2962660, 0.7071069, 0, 0], [0, 0, 0.5505211, 0]],
+                    np.float32)
+    np.testing.assert_allclose(iou3d_nms.boxes_iou_bev(A, B).cpu().numpy(), want, atol=6e-8)
+    assert iou3d_nms.boxes_iou_bev(A[:0], B).shape == (0, 4)
+
+
+@pytest.mark.parametrize('n,thresh,spread', [(1, 0.5, 30), (63, 0.1, 10), (64, 0.7, 10),
+                                             (65, 0.01, 10), (1000, 0.7, 40), (4096, 0.8, 60),
+                                             (9000, 0.8, 120)])
+def test_nms_keep_lists(orc, dev, n, thresh, spread):
+    from detmatch_amd import iou3d_nms
+    rng = np.random.default_rng(n)
+    b = _boxes(rng, n, spread)
+    scores = rng.permutation(n).astype(np.float32)    # distinct scores: no tie ambiguity
+    order = np.argsort(-scores, kind='stable')
+    want = order[orc.nms(b[order], thresh)]
+    got, _ = iou3d_nms.nms_gpu(torch.from_numpy(b).to(dev), torch.from_numpy(scores).to(dev),
+                               thresh)
+    assert np.array_equal(got.cpu().numpy(), want)      # keep mask: bit-exact
+    got2, _ = iou3d_nms.nms_gpu(torch.from_numpy(b).to(dev), torch.from_numpy(scores).to(dev),
+                                thresh, pre_maxsize=min(n, 512), post_max_size=100)
+    w2 = order[:512][orc.nms(b[order[:512]], thresh)][:100]
+    assert np.array_equal(got2.cpu().numpy(), w2)
+    want_n = order[orc.nms(b[order], thresh, normal=True)]
+    got_n, _ = iou3d_nms.nms_normal_gpu(torch.from_numpy(b).to(dev),
+                                        torch.from_numpy(scores).to(dev), thresh)
+    assert np.array_equal(got_n.cpu().numpy(), want_n)
+
+
+def test_nms_empty(dev):
+    from detmatch_amd import iou3d_nms
+    k, _ = iou3d_nms.nms_gpu(torch.zeros((0, 7), device=dev), torch.zeros((0,), device=dev), 0.5)
+    assert k.shape == (0,)
+
+
+def _stacked(rng, counts, lo, hi):
+    return np.concatenate([rng.uniform(lo, hi, (c, 3)) for c in counts]).astype(np.float32)
+
+
+@pytest.mark.parametrize('radius,nsample', [(0.4, 16), (0.8, 16), (1.2, 32), (4.0, 16)])
+def test_ball_query_and_group(orc, dev, radius, nsample):
+    from detmatch_amd import pointnet2_stack as pn
+    rng = np.random.default_rng(int(radius * 10))
+    xyz_cnt, new_cnt = [3000, 0, 1700], [256, 0, 300]
+    xyz = _stacked(rng, xyz_cnt, 0, 12)
+    new_xyz = _stacked(rng, new_cnt, -1, 13)
+    feats = rng.standard_normal((xyz.shape[0], 19)).astype(np.float32)
+    t = lambda a, dt=None: torch.from_numpy(np.asarray(a, dtype=dt)).to(dev)
+    idx, empty = pn.ball_query(radius, nsample, t(xyz), t(xyz_cnt, np.int32), t(new_xyz),
+                               t(new_cnt, np.int32))
+    oidx, oempty = orc.ball_query(radius, nsample, xyz, xyz_cnt, new_xyz, new_cnt)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert np.array_equal(empty.cpu().numpy(), oempty)
+    tf = t(feats).requires_grad_(True)
+    g = pn.grouping_operation(tf, t(xyz_cnt, np.int32), idx, t(new_cnt, np.int32))
+    og = orc.group_points(feats, xyz_cnt, oidx, new_cnt)
+    assert np.array_equal(g.detach().cpu().numpy(), og)
+    gz = pn.grouping_operation(tf, t(xyz_cnt, np.int32), idx, t(new_cnt, np.int32), empty)
+    og[oempty] = 0
+    assert np.array_equal(gz.detach().cpu().numpy(), og)
+    dy = rng.standard_normal(og.shape).astype(np.float32)
+    g.backward(t(dy))
+    want = orc.group_points_grad(dy, oidx, new_cnt, xyz_cnt, xyz.shape[0])
+    np.testing.assert_allclose(tf.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_reference_ball_query_kat(dev):
+    from detmatch_amd import pointnet2_stack as pn
+    from test_oracle_ops import NEW_XYZ, XYZ
+    cnt = torch.tensor([10, 10], dtype=torch.int32, device=dev)
+    ncnt = torch.tensor([5, 5], dtype=torch.int32, device=dev)
+    idx, empty = pn.ball_query(0.2, 5, torch.from_numpy(XYZ.reshape(-1, 3)).to(dev), cnt,
+                               torch.from_numpy(NEW_XYZ.reshape(-1, 3)).to(dev), ncnt)
+    want = [[0] * 5, [6] * 5, [2] * 5, [0] * 5, [0] * 5, [0] * 5, [2] * 5, [7] * 5, [0] * 5,
+            [0] * 5]
+    assert idx.cpu().tolist() == want and not bool(empty.any())
+
+
+def test_group_large_channels(orc, dev):
+    """RoI-grid shape: C = 128, nsample = 16."""
+    from detmatch_amd import pointnet2_stack as pn
+    rng = np.random.default_rng(5)
+    feats = rng.standard_normal((4096, 128)).astype(np.float32)
+    idx = rng.integers(0, 2048, (3000, 16)).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    cnt = torch.tensor([2048, 2048], dtype=torch.int32, device=dev)
+    icnt = torch.tensor([1000, 2000], dtype=torch.int32, device=dev)
+    g = pn.grouping_operation(t(feats), cnt, t(idx), icnt)
+    assert np.array_equal(g.cpu().numpy(), orc.group_points(feats, [2048, 2048], idx, [1000, 2000]))
+
+
+@pytest.mark.parametrize('n,m', [(5, 3), (100, 37), (1024, 512), (3000, 2048), (19940, 2048)])
+def test_fps(orc, dev, n, m):
+    from detmatch_amd import pointnet2_stack as pn
+    from detmatch_amd import synth
+    if n == 19940:
+        fr = [synth.lidar_frame(s)['points'][:, :3] for s in (0, 1)]
+        n = min(len(f) for f in fr)
+        xyz = np.stack([f[:n] for f in fr])
+    else:
+        xyz = np.random.default_rng(n).uniform(-20, 20, (3, n, 3)).astype(np.float32)
+    got = pn.furthest_point_sample(torch.from_numpy(np.ascontiguousarray(xyz)).to(dev), m)
+    assert np.array_equal(got.cpu().numpy(), orc.furthest_point_sample(xyz, m))
+
+
+def test_fps_reference_kat_and_ties(orc, dev):
+    from detmatch_amd import pointnet2_stack as pn
+    xyz = np.array([[[-0.2748, 1.0020, -1.1674], [0.1015, 1.3952, -1.2681],
+                     [-0.8070, 2.4137, -0.5845], [-1.0001, 2.1982, -0.5859],
+                     [0.3841, 1.8983, -0.7431]],
+                    [[-1.0696, 3.0758, -0.1899], [-0.2559, 3.5521, -0.1402],
+                     [0.8164, 4.0081, -0.1839], [-1.1000, 3.0213, -0.8205],
+                     [-0.0518, 3.7251, -0.3950]]], np.float32)
+    assert pn.furthest_point_sample(torch.from_numpy(xyz).to(dev), 3).cpu().tolist() == \
+        [[0, 2, 4], [0, 2, 1]]
+    # duplicated points -> exact distance ties; the block-size dependent tie rule must match
+    rng = np.random.default_rng(9)
+    base = rng.uniform(-5, 5, (1, 700, 3)).astype(np.float32)
+    dup = np.concatenate([base, base, base[:, :300]], 1)
+    got = pn.furthest_point_sample(torch.from_numpy(dup).to(dev), 64)
+    assert np.array_equal(got.cpu().numpy(), orc.furthest_point_sample(dup, 64))
+
+
+def test_points_in_boxes(orc, dev):
+    from detmatch_amd import roiaware_pool3d
+    rng = np.random.default_rng(2)
+    boxes = np.stack([_boxes(rng, 30, 20.0) for _ in range(2)])
+    boxes[1, 20:] = 0          # zero-padded GT rows
+    pts = rng.uniform(-2, 22, (2, 2048, 3)).astype(np.float32)
+    pts[..., 2] = rng.uniform(-2, 2, (2, 2048))
+    got = roiaware_pool3d.points_in_boxes_gpu(torch.from_numpy(pts).to(dev),
+                                              torch.from_numpy(boxes).to(dev))
+    want = orc.points_in_boxes(pts, boxes)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert (want >= 0).sum() > 50
+    b2 = np.array([[[0, 0, 0, 4, 2, 2, 0.0], [0, 0, 0, 8, 8, 8, 0.0],
+                    [10, 0, 0, 4, 2, 2, np.pi / 2]]], np.float32)
+    p2 = np.array([[[0, 0, 0], [1.9, 0.9, 0.9], [2.5, 0, 0], [0, 0, 1.0], [0, 0, 1.01],
+                    [10, 1.9, 0], [10, 2.1, 0], [11.5, 0, 0], [50, 0, 0]]], np.float32)
+    got = roiaware_pool3d.points_in_boxes_gpu(torch.from_numpy(p2).to(dev),
+                                              torch.from_numpy(b2).to(dev))
+    assert got.cpu().tolist() == [[0, 0, 1, 0, 1, 2, -1, -1, -1]]
