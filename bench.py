@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 BATCH_PER_GPU = 2
+WORKLOAD = os.environ.get("DM_BENCH_WORKLOAD", "pvrcnn")  # "pvrcnn" (configs[1]) | "stage3d"
 
 
 def parse():
@@ -49,9 +50,10 @@ def gg_bytes(P, ci, co, kvol, rows_out):
 
 def build_workload(dev, rank):
     from detmatch_amd import synth
-    from detmatch_amd.pcdet.workload import Stage3DWorkload
+    from detmatch_amd.pcdet.workload import PVRCNNTrainWorkload, Stage3DWorkload
     frames = [synth.lidar_frame(1000 * rank + i) for i in range(BATCH_PER_GPU)]
-    return Stage3DWorkload(frames, dev)
+    cls = PVRCNNTrainWorkload if WORKLOAD == 'pvrcnn' else Stage3DWorkload
+    return cls(frames, dev)
 
 
 def cpu_baseline(frames):

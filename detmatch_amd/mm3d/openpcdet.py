@@ -1,0 +1,122 @@
+"""OpenPCDetDetector — mmdet3d/models/detectors/openpcdet.py:24-235.
+
+mm3d <-> pcdet box conventions, batched hard voxelization (+ fused MeanVFE) and the
+forward_train / simple_test surface.  The reference's GT `.cpu().float()` -> `.cuda()`
+round trip (:132-145) and `coors[-1, 0].item()` (:92) are gone: batch size is len(points),
+GT stays on the device.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from .. import voxel
+from ..pcdet.config import ConfigDict
+from ..pcdet.detector import build_network
+from .box3d import LiDARInstance3DBoxes, limit_period
+
+
+def bbox3d2result(bboxes, scores, labels):
+    """mmdet3d/core/bbox/transforms.py bbox3d2result: results moved to the CPU."""
+    return dict(boxes_3d=bboxes.to('cpu'), scores_3d=scores.cpu(), labels_3d=labels.cpu())
+
+
+def mm3d_to_pcdet_boxes(boxes):
+    """openpcdet.py:100-122: bottom-centre (x,y,z,w,l,h,yaw) -> gravity-centre
+    (x,y,z,dx,dy,dz,heading): heading = limit_period(-(yaw + pi/2) + 2 pi, 0.5, 2 pi), dims 3<->4."""
+    t = boxes.tensor
+    gc = boxes.gravity_center
+    heading = limit_period(-(t[:, 6] + np.pi / 2) + (4 * np.pi / 2), offset=0.5, period=2 * np.pi)
+    return torch.cat([gc, t[:, 4:5], t[:, 3:4], t[:, 5:6], heading[:, None]], dim=1)
+
+
+def pcdet_to_mm3d_boxes(pred_boxes):
+    """openpcdet.py:211-224: swap dims 3<->4, yaw = -heading - pi/2, origin (.5,.5,.5)."""
+    b = torch.cat([pred_boxes[:, :3], pred_boxes[:, 4:5], pred_boxes[:, 3:4], pred_boxes[:, 5:6],
+                   (-pred_boxes[:, 6] - np.pi / 2)[:, None]], dim=1)
+    return LiDARInstance3DBoxes(b, origin=(0.5, 0.5, 0.5))
+
+
+class OpenPCDetDetector(nn.Module):
+
+    def __init__(self, dataset_fields, voxel_layer, pcdet_model, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__()
+        dataset_fields = ConfigDict(copy.deepcopy(dict(dataset_fields)))
+        pcr = np.array(dataset_fields['point_cloud_range'])
+        dataset_fields['point_cloud_range'] = pcr
+        grid = (pcr[3:6] - pcr[0:3]) / np.array(dataset_fields.voxel_size)
+        dataset_fields['grid_size'] = np.round(grid).astype(np.int64)
+        self.voxel_layer = voxel.Voxelization(**voxel_layer)
+        self.model = build_network(model_cfg=ConfigDict(copy.deepcopy(dict(pcdet_model))),
+                                   num_class=len(dataset_fields.class_names),
+                                   dataset=dataset_fields)
+        self.num_classes = len(dataset_fields.class_names)
+
+    @torch.no_grad()
+    def voxelize(self, points, with_mean=False):
+        """openpcdet.py:61-76 for the whole batch at once -> voxels, num_points, coors (b,z,y,x)."""
+        max_voxels = self.voxel_layer.max_voxels[0 if self.training else 1]
+        pts = [p.float().contiguous() for p in points]
+        v, c, n, mean, _ = voxel.voxelize_batch(pts, self.voxel_layer.voxel_size,
+                                                self.voxel_layer.point_cloud_range,
+                                                self.voxel_layer.max_num_points, max_voxels,
+                                                with_mean=with_mean)
+        if with_mean:
+            return v, n, c, mean
+        return v, n, c
+
+    def _base_batch(self, points, img_metas):
+        voxels, num_points, coors, mean = self.voxelize(points, with_mean=True)
+        res = dict(batch_size=len(points), voxels=voxels, voxel_num_points=num_points,
+                   voxel_coords=coors, voxel_features=mean)
+        res['points'] = torch.cat([F.pad(p.float(), (1, 0), mode='constant', value=k)
+                                   for k, p in enumerate(points)], dim=0)
+        res['points_batch_cnt_host'] = [int(p.shape[0]) for p in points]
+        if img_metas is not None:
+            res['frame_id'] = np.array([m.get('sample_idx', i) for i, m in enumerate(img_metas)])
+        return res
+
+    @torch.no_grad()
+    def train_to_openpcdet(self, points, img_metas, gt_bboxes_3d, gt_labels_3d,
+                           gt_bboxes_ignore=None):
+        """openpcdet.py:79-160"""
+        assert gt_bboxes_ignore is None
+        res = self._base_batch(points, img_metas)
+        dev = points[0].device
+        trans = []
+        for boxes, labels in zip(gt_bboxes_3d, gt_labels_3d):
+            b = mm3d_to_pcdet_boxes(boxes).to(dev).float()
+            labels = labels.to(dev)
+            mask = (0 <= labels) & (labels < self.num_classes)
+            # kept dense: out-of-range classes become all-zero rows (== padding) and are
+            # moved behind the valid rows, like the boolean filter of :125-128
+            order = torch.sort((~mask).long(), stable=True)[1]
+            row = torch.cat([b, labels[:, None].float() + 1], dim=1) * mask[:, None].float()
+            trans.append(row[order])
+        # at least one (all-zero == padding) row: the dense target assigners treat it exactly
+        # like the reference treats an empty GT list (SURVEY §3.1 'zero pseudo-labels')
+        max_gt = max([len(x) for x in trans] + [1])
+        batch_gt = torch.zeros((len(points), max_gt, 8), dtype=torch.float32, device=dev)
+        for k, t in enumerate(trans):
+            batch_gt[k, :len(t), :] = t
+        res['gt_boxes'] = batch_gt
+        return res
+
+    def forward_train(self, points, img_metas, gt_bboxes_3d, gt_labels_3d, gt_bboxes_ignore=None):
+        batch = self.train_to_openpcdet(points, img_metas, gt_bboxes_3d, gt_labels_3d,
+                                        gt_bboxes_ignore)
+        ret_dict, tb_dict, disp_dict = self.model(batch)
+        return dict(loss=ret_dict['loss'].mean())
+
+    def simple_test(self, points, img_metas, imgs=None, rescale=False):
+        """openpcdet.py:185-235"""
+        batch = self._base_batch(points, img_metas)
+        pred_dicts, _ = self.model(batch)
+        results = []
+        for pd in pred_dicts:
+            boxes = pcdet_to_mm3d_boxes(pd['pred_boxes'])
+            results.append(bbox3d2result(boxes, pd['pred_scores'], pd['pred_labels'] - 1))
+        return results

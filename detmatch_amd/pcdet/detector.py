@@ -1,0 +1,206 @@
+"""PVRCNN detector — pcdet/models/detectors/{detector3d_template,pv_rcnn}.py and
+pcdet/models/__init__.py:16 (build_network).
+
+Module names (vfe, backbone_3d, map_to_bev_module, pfe, backbone_2d, dense_head,
+point_head, roi_head) and the `global_step` buffer follow the reference so that state
+dicts are interchangeable.
+"""
+import torch
+import torch.nn as nn
+
+from .. import iou3d_nms
+from .backbones_2d import BaseBEVBackbone
+from .backbones_3d import HeightCompression, MeanVFE, VoxelBackBone8x
+from .config import ConfigDict
+from .dense_heads import AnchorHeadSingle, PointHeadSimple, valid_gt_mask
+from .pfe import VoxelSetAbstraction
+from .roi_heads import PVRCNNHead, class_agnostic_nms_fixed
+
+_MODULES = {
+    'MeanVFE': MeanVFE, 'VoxelBackBone8x': VoxelBackBone8x, 'HeightCompression': HeightCompression,
+    'BaseBEVBackbone': BaseBEVBackbone, 'VoxelSetAbstraction': VoxelSetAbstraction,
+    'AnchorHeadSingle': AnchorHeadSingle, 'PointHeadSimple': PointHeadSimple,
+    'PVRCNNHead': PVRCNNHead,
+}
+
+
+class PVRCNN(nn.Module):
+    """forward(batch_dict): vfe -> backbone_3d -> map_to_bev -> pfe -> backbone_2d ->
+    dense_head -> point_head -> roi_head (detector3d_template.py:22-25, pv_rcnn.py:9-22)."""
+
+    module_topology = ['vfe', 'backbone_3d', 'map_to_bev_module', 'pfe', 'backbone_2d',
+                       'dense_head', 'point_head', 'roi_head']
+
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__()
+        self.model_cfg = model_cfg if isinstance(model_cfg, ConfigDict) else ConfigDict(model_cfg)
+        self.num_class = num_class
+        self.dataset = dataset if isinstance(dataset, ConfigDict) else ConfigDict(dataset)
+        self.class_names = self.dataset.class_names
+        self.register_buffer('global_step', torch.LongTensor(1).zero_())
+        self.record_recall = False
+        self.module_list = self.build_networks()
+
+    @property
+    def mode(self):
+        return 'TRAIN' if self.training else 'TEST'
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def build_networks(self):
+        ds = self.dataset
+        cfg = self.model_cfg
+        info = dict(num_rawpoint_features=ds.point_feature_encoder.num_point_features,
+                    num_point_features=ds.point_feature_encoder.num_point_features,
+                    grid_size=ds.grid_size, point_cloud_range=ds.point_cloud_range,
+                    voxel_size=ds.voxel_size)
+        mods = []
+        self.vfe = _MODULES[cfg.VFE.NAME](model_cfg=cfg.VFE,
+                                          num_point_features=info['num_rawpoint_features'])
+        info['num_point_features'] = self.vfe.get_output_feature_dim()
+        mods.append(self.vfe)
+        self.backbone_3d = _MODULES[cfg.BACKBONE_3D.NAME](
+            model_cfg=cfg.BACKBONE_3D, input_channels=info['num_point_features'],
+            grid_size=info['grid_size'])
+        info['num_point_features'] = self.backbone_3d.num_point_features
+        mods.append(self.backbone_3d)
+        self.map_to_bev_module = _MODULES[cfg.MAP_TO_BEV.NAME](model_cfg=cfg.MAP_TO_BEV)
+        info['num_bev_features'] = self.map_to_bev_module.num_bev_features
+        mods.append(self.map_to_bev_module)
+        self.pfe = _MODULES[cfg.PFE.NAME](
+            model_cfg=cfg.PFE, voxel_size=info['voxel_size'],
+            point_cloud_range=info['point_cloud_range'],
+            num_bev_features=info['num_bev_features'],
+            num_rawpoint_features=info['num_rawpoint_features'])
+        info['num_point_features'] = self.pfe.num_point_features
+        info['num_point_features_before_fusion'] = self.pfe.num_point_features_before_fusion
+        mods.append(self.pfe)
+        self.backbone_2d = _MODULES[cfg.BACKBONE_2D.NAME](model_cfg=cfg.BACKBONE_2D,
+                                                          input_channels=info['num_bev_features'])
+        info['num_bev_features'] = self.backbone_2d.num_bev_features
+        mods.append(self.backbone_2d)
+        self.dense_head = _MODULES[cfg.DENSE_HEAD.NAME](
+            model_cfg=cfg.DENSE_HEAD, input_channels=info['num_bev_features'],
+            num_class=self.num_class if not cfg.DENSE_HEAD.CLASS_AGNOSTIC else 1,
+            class_names=self.class_names, grid_size=info['grid_size'],
+            point_cloud_range=info['point_cloud_range'],
+            predict_boxes_when_training=cfg.get('ROI_HEAD', False))
+        mods.append(self.dense_head)
+        use_before = cfg.POINT_HEAD.get('USE_POINT_FEATURES_BEFORE_FUSION', False)
+        self.point_head = _MODULES[cfg.POINT_HEAD.NAME](
+            model_cfg=cfg.POINT_HEAD,
+            input_channels=info['num_point_features_before_fusion'] if use_before
+            else info['num_point_features'],
+            num_class=self.num_class if not cfg.POINT_HEAD.CLASS_AGNOSTIC else 1)
+        mods.append(self.point_head)
+        self.roi_head = _MODULES[cfg.ROI_HEAD.NAME](
+            model_cfg=cfg.ROI_HEAD, input_channels=info['num_point_features'],
+            num_class=self.num_class if not cfg.ROI_HEAD.CLASS_AGNOSTIC else 1)
+        mods.append(self.roi_head)
+        return mods
+
+    def forward(self, batch_dict):
+        for cur_module in self.module_list:
+            batch_dict = cur_module(batch_dict)
+        if self.training:
+            loss, tb_dict, disp_dict = self.get_training_loss()
+            return {'loss': loss}, tb_dict, disp_dict
+        return self.post_processing(batch_dict)
+
+    def get_training_loss(self):
+        """pv_rcnn.py:24-32"""
+        loss_rpn, tb_dict = self.dense_head.get_loss()
+        loss_point, tb_dict = self.point_head.get_loss(tb_dict)
+        loss_rcnn, tb_dict = self.roi_head.get_loss(tb_dict)
+        return loss_rpn + loss_point + loss_rcnn, tb_dict, {}
+
+    def post_processing(self, batch_dict, no_nms=False):
+        """detector3d_template.py:176-309 (MULTI_CLASSES_NMS False branch)."""
+        cfg = self.model_cfg.POST_PROCESSING
+        assert not cfg.NMS_CONFIG.MULTI_CLASSES_NMS
+        batch_size = batch_dict['batch_size']
+        recall_dict = {}
+        pred_dicts = []
+        for index in range(batch_size):
+            box_preds = batch_dict['batch_box_preds'][index]
+            src_box_preds = box_preds
+            cls_preds = batch_dict['batch_cls_preds'][index]
+            src_cls_preds = cls_preds
+            assert cls_preds.shape[1] in [1, self.num_class]
+            if not batch_dict['cls_preds_normalized']:
+                cls_preds = torch.sigmoid(cls_preds)
+            cls_preds, label_preds = torch.max(cls_preds, dim=-1)
+            if batch_dict.get('has_class_labels', False):
+                label_key = 'roi_labels' if 'roi_labels' in batch_dict else 'batch_pred_labels'
+                label_preds = batch_dict[label_key][index]
+                sem_scores = batch_dict['roi_scores'][index]
+                sem_scores_full = batch_dict['roi_scores_full'][index]
+            else:
+                label_preds = label_preds + 1
+                sem_scores = cls_preds
+                sem_scores_full = src_cls_preds
+            if no_nms:
+                selected = torch.arange(len(cls_preds), device=cls_preds.device)
+                selected_scores = cls_preds
+            else:
+                sel, valid = class_agnostic_nms_fixed(cls_preds.detach(), box_preds.detach(),
+                                                      cfg.NMS_CONFIG, score_thresh=cfg.SCORE_THRESH)
+                # the one read-back of this sample: how many boxes survive (the reference
+                # returns variable-length tensors too, model_nms_utils.py:20)
+                n_keep = int(valid.sum().item())
+                selected = sel[:n_keep]
+                selected_scores = cls_preds[selected]
+            if cfg.OUTPUT_RAW_SCORE:
+                selected_scores = torch.max(src_cls_preds, dim=-1)[0][selected]
+            record = {'pred_boxes': box_preds[selected], 'pred_scores': selected_scores,
+                      'pred_labels': label_preds[selected],
+                      'pred_sem_scores': torch.sigmoid(sem_scores[selected]),
+                      'pred_sem_scores_full': torch.sigmoid(sem_scores_full[selected])}
+            pred_dicts.append(record)
+            if self.record_recall:
+                recall_dict = self.generate_recall_record(
+                    record['pred_boxes'] if 'rois' not in batch_dict else src_box_preds,
+                    recall_dict, index, batch_dict, cfg.RECALL_THRESH_LIST)
+        return pred_dicts, recall_dict
+
+    @staticmethod
+    def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None,
+                               thresh_list=None):
+        """detector3d_template.py:312-354; counters are 0-d device tensors (no .item())."""
+        if 'gt_boxes' not in data_dict:
+            return recall_dict
+        rois = data_dict['rois'][batch_index] if 'rois' in data_dict else None
+        gt_boxes = data_dict['gt_boxes'][batch_index]
+        if len(recall_dict) == 0:
+            recall_dict = {'gt': 0}
+            for t in thresh_list:
+                recall_dict['roi_%s' % str(t)] = 0
+                recall_dict['rcnn_%s' % str(t)] = 0
+        valid = valid_gt_mask(gt_boxes[None])[0]
+        if box_preds.shape[0] > 0:
+            iou_rcnn = iou3d_nms.boxes_iou3d_gpu(box_preds[:, 0:7], gt_boxes[:, 0:7])
+        else:
+            iou_rcnn = None
+        iou_roi = iou3d_nms.boxes_iou3d_gpu(rois[:, 0:7], gt_boxes[:, 0:7]) if rois is not None \
+            else None
+        for t in thresh_list:
+            if iou_rcnn is not None:
+                recall_dict['rcnn_%s' % str(t)] = recall_dict['rcnn_%s' % str(t)] + \
+                    ((iou_rcnn.max(dim=0)[0] > t) & valid).sum()
+            if iou_roi is not None:
+                recall_dict['roi_%s' % str(t)] = recall_dict['roi_%s' % str(t)] + \
+                    ((iou_roi.max(dim=0)[0] > t) & valid).sum()
+        recall_dict['gt'] = recall_dict['gt'] + valid.sum()
+        return recall_dict
+
+
+_DETECTORS = {'PVRCNN': PVRCNN}
+
+
+def build_network(model_cfg, num_class, dataset):
+    """pcdet/models/__init__.py:16-20 / detectors/__init__.py build_detector."""
+    model_cfg = model_cfg if isinstance(model_cfg, ConfigDict) else ConfigDict(model_cfg)
+    if model_cfg.NAME not in _DETECTORS:
+        raise NotImplementedError('%s: only PVRCNN is on the DetMatch hot path' % model_cfg.NAME)
+    return _DETECTORS[model_cfg.NAME](model_cfg=model_cfg, num_class=num_class, dataset=dataset)

@@ -1,0 +1,149 @@
+"""VoxelSetAbstraction — pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:9-238.
+
+Keypoint FPS, bilinear BEV sampling, multi-scale set abstraction over raw points and the
+four sparse-conv stages, 640 -> 128 fusion.  Feature column order is
+[bev(256), raw_points(32), x_conv1(32), x_conv2(64), x_conv3(128), x_conv4(128)]
+(:181-230), which fixes the layout of vsa_point_feature_fusion.0.weight for checkpoints.
+
+Host syncs of the reference removed: per-sample point counts come from the caller
+(`batch_dict['points_batch_cnt_host']`), voxel counts per sample are device bincounts.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from .. import pointnet2_stack as pn2
+from .utils import get_voxel_centers
+
+
+def bilinear_interpolate_torch(im, x, y):
+    """voxel_set_abstraction.py:9-40: im (H, W, C), x / y (N) in pixel units, clamped."""
+    x0 = torch.floor(x).long()
+    x1 = x0 + 1
+    y0 = torch.floor(y).long()
+    y1 = y0 + 1
+    x0 = torch.clamp(x0, 0, im.shape[1] - 1)
+    x1 = torch.clamp(x1, 0, im.shape[1] - 1)
+    y0 = torch.clamp(y0, 0, im.shape[0] - 1)
+    y1 = torch.clamp(y1, 0, im.shape[0] - 1)
+    Ia, Ib, Ic, Id = im[y0, x0], im[y1, x0], im[y0, x1], im[y1, x1]
+    wa = (x1.type_as(x) - x) * (y1.type_as(y) - y)
+    wb = (x1.type_as(x) - x) * (y - y0.type_as(y))
+    wc = (x - x0.type_as(x)) * (y1.type_as(y) - y)
+    wd = (x - x0.type_as(x)) * (y - y0.type_as(y))
+    return Ia * wa[:, None] + Ib * wb[:, None] + Ic * wc[:, None] + Id * wd[:, None]
+
+
+class VoxelSetAbstraction(nn.Module):
+
+    def __init__(self, model_cfg, voxel_size, point_cloud_range, num_bev_features=None,
+                 num_rawpoint_features=None, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.voxel_size = voxel_size
+        self.point_cloud_range = point_cloud_range
+        SA_cfg = copy.deepcopy(self.model_cfg.SA_LAYER)  # the reference mutates MLPS in place
+        self.SA_layers = nn.ModuleList()
+        self.SA_layer_names = []
+        self.downsample_times_map = {}
+        c_in = 0
+        for src_name in self.model_cfg.FEATURES_SOURCE:
+            if src_name in ['bev', 'raw_points']:
+                continue
+            self.downsample_times_map[src_name] = SA_cfg[src_name].DOWNSAMPLE_FACTOR
+            mlps = [list(m) for m in SA_cfg[src_name].MLPS]
+            for k in range(len(mlps)):
+                mlps[k] = [mlps[k][0]] + mlps[k]
+            self.SA_layers.append(pn2.StackSAModuleMSG(
+                radii=SA_cfg[src_name].POOL_RADIUS, nsamples=SA_cfg[src_name].NSAMPLE, mlps=mlps,
+                use_xyz=True, pool_method='max_pool'))
+            self.SA_layer_names.append(src_name)
+            c_in += sum([x[-1] for x in mlps])
+        if 'bev' in self.model_cfg.FEATURES_SOURCE:
+            c_in += num_bev_features
+        if 'raw_points' in self.model_cfg.FEATURES_SOURCE:
+            mlps = [list(m) for m in SA_cfg['raw_points'].MLPS]
+            for k in range(len(mlps)):
+                mlps[k] = [num_rawpoint_features - 3] + mlps[k]
+            self.SA_rawpoints = pn2.StackSAModuleMSG(
+                radii=SA_cfg['raw_points'].POOL_RADIUS, nsamples=SA_cfg['raw_points'].NSAMPLE,
+                mlps=mlps, use_xyz=True, pool_method='max_pool')
+            c_in += sum([x[-1] for x in mlps])
+        self.vsa_point_feature_fusion = nn.Sequential(
+            nn.Linear(c_in, self.model_cfg.NUM_OUTPUT_FEATURES, bias=False),
+            nn.BatchNorm1d(self.model_cfg.NUM_OUTPUT_FEATURES), nn.ReLU())
+        self.num_point_features = self.model_cfg.NUM_OUTPUT_FEATURES
+        self.num_point_features_before_fusion = c_in
+
+    def interpolate_from_bev_features(self, keypoints, bev_features, batch_size, bev_stride):
+        x_idxs = (keypoints[:, :, 0] - self.point_cloud_range[0]) / self.voxel_size[0] / bev_stride
+        y_idxs = (keypoints[:, :, 1] - self.point_cloud_range[1]) / self.voxel_size[1] / bev_stride
+        out = []
+        for k in range(batch_size):
+            cur_bev = bev_features[k].permute(1, 2, 0)  # (H, W, C)
+            out.append(bilinear_interpolate_torch(cur_bev, x_idxs[k], y_idxs[k]).unsqueeze(0))
+        return torch.cat(out, dim=0)
+
+    def get_sampled_points(self, batch_dict):
+        """:119-158 — FPS of each sample's raw points (repeat-padded when N < NUM_KEYPOINTS)."""
+        assert self.model_cfg.POINT_SOURCE == 'raw_points' and self.model_cfg.SAMPLE_METHOD == 'FPS'
+        batch_size = batch_dict['batch_size']
+        points = batch_dict['points']
+        cnt = batch_dict['points_batch_cnt_host']
+        num_kp = self.model_cfg.NUM_KEYPOINTS
+        keypoints_list = []
+        start = 0
+        for bs_idx in range(batch_size):
+            n = int(cnt[bs_idx])
+            sampled_points = points[start:start + n, 1:4].unsqueeze(dim=0).contiguous()
+            start += n
+            cur_pt_idxs = pn2.furthest_point_sample(sampled_points, num_kp).long()
+            if n < num_kp:
+                times = int(num_kp / n) + 1
+                non_empty = cur_pt_idxs[0, :n]
+                cur_pt_idxs = non_empty.repeat(times)[:num_kp].unsqueeze(0)
+            keypoints_list.append(sampled_points[0][cur_pt_idxs[0]].unsqueeze(dim=0))
+        return torch.cat(keypoints_list, dim=0)
+
+    def forward(self, batch_dict):
+        keypoints = self.get_sampled_points(batch_dict)
+        batch_size, num_keypoints, _ = keypoints.shape
+        dev = keypoints.device
+        point_features_list = []
+        if 'bev' in self.model_cfg.FEATURES_SOURCE:
+            point_features_list.append(self.interpolate_from_bev_features(
+                keypoints, batch_dict['spatial_features'], batch_size,
+                bev_stride=batch_dict['spatial_features_stride']))
+        new_xyz = keypoints.view(-1, 3).contiguous()
+        new_xyz_batch_cnt = torch.full((batch_size,), num_keypoints, dtype=torch.int32, device=dev)
+        if 'raw_points' in self.model_cfg.FEATURES_SOURCE:
+            raw_points = batch_dict['points']
+            xyz_batch_cnt = torch.tensor([int(c) for c in batch_dict['points_batch_cnt_host']],
+                                         dtype=torch.int32, device=dev)
+            point_features = raw_points[:, 4:].contiguous() if raw_points.shape[1] > 4 else None
+            _, pooled = self.SA_rawpoints(xyz=raw_points[:, 1:4].contiguous(),
+                                          xyz_batch_cnt=xyz_batch_cnt, new_xyz=new_xyz,
+                                          new_xyz_batch_cnt=new_xyz_batch_cnt,
+                                          features=point_features)
+            point_features_list.append(pooled.view(batch_size, num_keypoints, -1))
+        for k, src_name in enumerate(self.SA_layer_names):
+            sp = batch_dict['multi_scale_3d_features'][src_name]
+            cur_coords = sp.indices
+            xyz = get_voxel_centers(cur_coords[:, 1:4],
+                                    downsample_times=self.downsample_times_map[src_name],
+                                    voxel_size=self.voxel_size,
+                                    point_cloud_range=self.point_cloud_range)
+            xyz_batch_cnt = torch.bincount(cur_coords[:, 0].long(), minlength=batch_size).int()
+            _, pooled = self.SA_layers[k](xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt,
+                                          new_xyz=new_xyz, new_xyz_batch_cnt=new_xyz_batch_cnt,
+                                          features=sp.features.contiguous())
+            point_features_list.append(pooled.view(batch_size, num_keypoints, -1))
+        point_features = torch.cat(point_features_list, dim=2)
+        batch_idx = torch.arange(batch_size, device=dev).view(-1, 1).repeat(1, num_keypoints).view(-1)
+        point_coords = torch.cat((batch_idx.view(-1, 1).float(), keypoints.view(-1, 3)), dim=1)
+        batch_dict['point_features_before_fusion'] = point_features.view(-1, point_features.shape[-1])
+        batch_dict['point_features'] = self.vsa_point_feature_fusion(
+            point_features.view(-1, point_features.shape[-1]))
+        batch_dict['point_coords'] = point_coords
+        return batch_dict

@@ -1,0 +1,412 @@
+"""PVRCNNHead: proposal layer (rotated NMS), proposal-target sampling, RoI-grid pooling,
+box refinement, losses.
+
+Reference: pcdet/models/roi_heads/{roi_head_template,pvrcnn_head}.py,
+roi_heads/target_assigner/proposal_target_layer.py, model_utils/model_nms_utils.py.
+
+Restated without the reference's host round-trips: NMS keeps its survivor list on the
+device (fixed-size, masked), same-class max-IoU is a dense masked max instead of a
+`.item()` class loop (:237), RoI sub-sampling draws its random numbers on the device
+(same distribution as the numpy/torch-CPU draws at :153,:164,:193-197 — a different
+stream, as any two seeds are), `tb_dict` entries are detached tensors.
+`roi_scores_full` stays attached to the graph (roi_head_template.py:98).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib, iou3d_nms
+from .. import pointnet2_stack as pn2
+from . import utils as U
+from .dense_heads import valid_gt_mask
+
+
+def class_agnostic_nms_fixed(box_scores, box_preds, nms_config, score_thresh=None):
+    """model_nms_utils.py:6-26 with a fixed-size result: (selected (POST,) int64 padded with 0,
+    valid (POST,) bool).  No device->host copy."""
+    post = int(nms_config.NMS_POST_MAXSIZE)
+    n = box_scores.shape[0]
+    dev = box_scores.device
+    if n == 0:
+        return (torch.zeros((post,), dtype=torch.int64, device=dev),
+                torch.zeros((post,), dtype=torch.bool, device=dev))
+    scores = box_scores
+    if score_thresh is not None:  # below-threshold boxes sort last and are masked out
+        scores = torch.where(box_scores >= score_thresh, box_scores,
+                             box_scores.new_full((), -float('inf')))
+    k = min(int(nms_config.NMS_PRE_MAXSIZE), n)
+    top_scores, indices = torch.topk(scores, k=k)
+    boxes = box_preds[indices][:, 0:7].contiguous().float()
+    order = torch.sort(top_scores, dim=0, descending=True, stable=True)[1]
+    boxes = boxes[order].contiguous()
+    L = _lib.lib()
+    keep = torch.zeros((max(k, post),), dtype=torch.int64, device=dev)
+    num = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = _lib.workspace(L.dm_nms_workspace_bytes(k), dev, 'nms')
+    fn = L.dm_nms if nms_config.NMS_TYPE == 'nms_gpu' else L.dm_nms_normal
+    _lib.check(fn(_lib.ptr(boxes), k, float(nms_config.NMS_THRESH), post, _lib.ptr(keep),
+                  _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms')
+    slot = torch.arange(post, device=dev)
+    valid = slot < num.long()
+    sel = indices[order[keep[:post].clamp(0, k - 1)]]
+    if score_thresh is not None:
+        valid = valid & (box_scores[sel] >= score_thresh)
+    return torch.where(valid, sel, torch.zeros_like(sel)), valid
+
+
+class ProposalTargetLayer(nn.Module):
+    """proposal_target_layer.py:8-259"""
+
+    def __init__(self, roi_sampler_cfg):
+        super().__init__()
+        self.roi_sampler_cfg = roi_sampler_cfg
+
+    def forward(self, batch_dict):
+        cfg = self.roi_sampler_cfg
+        (batch_rois, batch_gt_of_rois, batch_roi_ious, batch_roi_scores, batch_roi_labels,
+         batch_roi_scores_full) = self.sample_rois_for_rcnn(batch_dict)
+        reg_valid_mask = (batch_roi_ious > cfg.REG_FG_THRESH).long()
+        assert cfg.CLS_SCORE_TYPE == 'roi_iou'
+        iou_bg, iou_fg = cfg.CLS_BG_THRESH, cfg.CLS_FG_THRESH
+        fg_mask = batch_roi_ious > iou_fg
+        bg_mask = batch_roi_ious < iou_bg
+        interval = (~fg_mask) & (~bg_mask)
+        cls_labels = torch.where(interval, (batch_roi_ious - iou_bg) / (iou_fg - iou_bg),
+                                 fg_mask.float())
+        return {'rois': batch_rois.detach(), 'gt_of_rois': batch_gt_of_rois.detach(),
+                'gt_iou_of_rois': batch_roi_ious.detach(), 'roi_scores': batch_roi_scores.detach(),
+                'roi_labels': batch_roi_labels.detach(), 'roi_scores_full': batch_roi_scores_full,
+                'reg_valid_mask': reg_valid_mask.detach(), 'rcnn_cls_labels': cls_labels.detach()}
+
+    def sample_rois_for_rcnn(self, batch_dict):
+        """:69-134, batched over the samples."""
+        rois = batch_dict['rois']
+        roi_scores = batch_dict['roi_scores']
+        roi_labels = batch_dict['roi_labels']
+        gt_boxes = batch_dict['gt_boxes']
+        roi_scores_full = batch_dict['roi_scores_full']
+        rois = torch.where(torch.isnan(rois), torch.zeros_like(rois), rois)     # :109-112
+        gt_valid = valid_gt_mask(gt_boxes)                                       # :101-104
+        max_overlaps, gt_assignment = self.get_max_iou_with_same_class(
+            rois, roi_labels, gt_boxes[:, :, 0:7], gt_boxes[:, :, -1].long(), gt_valid)
+        sampled, ok = self.subsample_rois(max_overlaps)                          # (B, S), (B,)
+        okf = ok.view(-1, 1)
+        g = lambda t: torch.gather(t, 1, sampled)
+        batch_rois = torch.gather(rois, 1, sampled[..., None].expand(-1, -1, rois.shape[-1]))
+        batch_rois = batch_rois * okf[..., None].to(rois.dtype)
+        batch_roi_labels = g(roi_labels) * okf.long()
+        batch_roi_ious = g(max_overlaps) * okf.to(rois.dtype)
+        batch_roi_scores = g(roi_scores) * okf.to(rois.dtype)
+        batch_roi_scores_full = torch.gather(
+            roi_scores_full, 1, sampled[..., None].expand(-1, -1, roi_scores_full.shape[-1])
+        ) * okf[..., None].to(rois.dtype)
+        ga = g(gt_assignment)
+        batch_gt_of_rois = torch.gather(gt_boxes, 1, ga[..., None].expand(-1, -1, gt_boxes.shape[-1]))
+        batch_gt_of_rois = batch_gt_of_rois * okf[..., None].to(rois.dtype)
+        return (batch_rois, batch_gt_of_rois, batch_roi_ious, batch_roi_scores, batch_roi_labels,
+                batch_roi_scores_full)
+
+    @staticmethod
+    def get_max_iou_with_same_class(rois, roi_labels, gt_boxes, gt_labels, gt_valid):
+        """:217-259 as a dense masked max: rois (B,R,7), gt (B,G,7)."""
+        B = rois.shape[0]
+        mo, ga = [], []
+        for b in range(B):
+            iou3d = iou3d_nms.boxes_iou3d_gpu(rois[b], gt_boxes[b])              # (R, G)
+            same = (roi_labels[b][:, None] == gt_labels[b][None, :]) & gt_valid[b][None, :]
+            iou_m = torch.where(same, iou3d, iou3d.new_full((), -1.0))
+            m, a = iou_m.max(dim=1)
+            has = m >= 0
+            mo.append(torch.where(has, m, torch.zeros_like(m)))
+            ga.append(torch.where(has, a, torch.zeros_like(a)))
+        return torch.stack(mo), torch.stack(ga)
+
+    def subsample_rois(self, max_overlaps):
+        """:136-215 for all samples at once.  Returns indices (B, ROI_PER_IMAGE) and a
+        per-sample flag that is False only in the reference's 'no fg and no bg' error case."""
+        cfg = self.roi_sampler_cfg
+        B, R = max_overlaps.shape
+        S = int(cfg.ROI_PER_IMAGE)
+        dev = max_overlaps.device
+        fg_per_image = int(np.round(cfg.FG_RATIO * S))
+        fg_thresh = min(cfg.REG_FG_THRESH, cfg.CLS_FG_THRESH)
+        fg = max_overlaps >= fg_thresh
+        easy = max_overlaps < cfg.CLS_BG_THRESH_LO
+        hard = (max_overlaps < cfg.REG_FG_THRESH) & (max_overlaps >= cfg.CLS_BG_THRESH_LO)
+        n_fg, n_easy, n_hard = fg.sum(1), easy.sum(1), hard.sum(1)
+        n_bg = n_easy + n_hard
+        # members of each set in ascending index order come first
+        ar = torch.arange(R, device=dev)[None, :].expand(B, -1)
+        rank_of = lambda m: torch.sort(torch.where(m, ar, ar + R), dim=1)[1]
+        fg_sorted, easy_sorted, hard_sorted = rank_of(fg), rank_of(easy), rank_of(hard)
+        # random permutation of the fg members (np.random.permutation, :153)
+        key = torch.where(fg, torch.rand((B, R), device=dev), torch.full((B, R), 2.0, device=dev))
+        fg_perm = torch.sort(key, dim=1)[1]
+        slot = torch.arange(S, device=dev)[None, :].expand(B, -1)
+        u = torch.rand((B, S), device=dev)
+        pick = lambda srt, n: torch.gather(
+            srt, 1, torch.minimum((u * n[:, None]).long(), (n[:, None] - 1).clamp(min=0)))
+        fg_this = torch.minimum(n_fg, torch.full_like(n_fg, fg_per_image))
+        fg_this = torch.where(n_bg > 0, fg_this, torch.full_like(n_fg, S))       # :167-172
+        fg_this = torch.where(n_fg > 0, fg_this, torch.zeros_like(n_fg))         # :174-179
+        bg_this = S - fg_this
+        hard_num = torch.minimum((bg_this.float() * cfg.HARD_BG_RATIO).long(), n_hard)
+        hard_num = torch.where(n_easy > 0, hard_num, bg_this)                    # :203-207
+        hard_num = torch.where(n_hard > 0, hard_num, torch.zeros_like(hard_num))  # :208-212
+        fg_wo_replace = torch.gather(fg_perm, 1, slot.clamp(max=R - 1))
+        fg_choice = torch.where((n_bg > 0)[:, None], fg_wo_replace, pick(fg_sorted, n_fg))
+        j = slot - fg_this[:, None]
+        bg_choice = torch.where(j < hard_num[:, None], pick(hard_sorted, n_hard),
+                                pick(easy_sorted, n_easy))
+        sampled = torch.where(slot < fg_this[:, None], fg_choice, bg_choice)
+        ok = (n_fg + n_bg) > 0
+        return sampled, ok
+
+
+class PVRCNNHead(nn.Module):
+    """roi_head_template.py:11-263 + pvrcnn_head.py:8-201."""
+
+    def __init__(self, input_channels, model_cfg, num_class=1, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        assert model_cfg.TARGET_CONFIG.BOX_CODER == 'ResidualCoder'
+        self.box_coder = U.ResidualCoder(**model_cfg.TARGET_CONFIG.get('BOX_CODER_CONFIG', {}))
+        self.proposal_target_layer = ProposalTargetLayer(roi_sampler_cfg=model_cfg.TARGET_CONFIG)
+        self.reg_loss_func = U.WeightedSmoothL1Loss(
+            code_weights=model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['code_weights'])
+        self.forward_ret_dict = None
+        mlps = [[input_channels] + list(m) for m in model_cfg.ROI_GRID_POOL.MLPS]
+        self.roi_grid_pool_layer = pn2.StackSAModuleMSG(
+            radii=model_cfg.ROI_GRID_POOL.POOL_RADIUS, nsamples=model_cfg.ROI_GRID_POOL.NSAMPLE,
+            mlps=mlps, use_xyz=True, pool_method=model_cfg.ROI_GRID_POOL.POOL_METHOD)
+        gs = model_cfg.ROI_GRID_POOL.GRID_SIZE
+        pre_channel = gs * gs * gs * sum([x[-1] for x in mlps])
+        shared = []
+        for k in range(len(model_cfg.SHARED_FC)):
+            shared.extend([nn.Conv1d(pre_channel, model_cfg.SHARED_FC[k], kernel_size=1, bias=False),
+                           nn.BatchNorm1d(model_cfg.SHARED_FC[k]), nn.ReLU()])
+            pre_channel = model_cfg.SHARED_FC[k]
+            if k != len(model_cfg.SHARED_FC) - 1 and model_cfg.DP_RATIO > 0:
+                shared.append(nn.Dropout(model_cfg.DP_RATIO))
+        self.shared_fc_layer = nn.Sequential(*shared)
+        self.cls_layers = self.make_fc_layers(pre_channel, self.num_class, model_cfg.CLS_FC)
+        self.reg_layers = self.make_fc_layers(pre_channel, self.box_coder.code_size * self.num_class,
+                                              model_cfg.REG_FC)
+        for m in self.modules():  # init_weights('xavier'), pvrcnn_head.py:54-71
+            if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+                nn.init.xavier_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.reg_layers[-1].weight, mean=0, std=0.001)
+
+    def make_fc_layers(self, input_channels, output_channels, fc_list):
+        layers = []
+        pre = input_channels
+        for k in range(len(fc_list)):
+            layers.extend([nn.Conv1d(pre, fc_list[k], kernel_size=1, bias=False),
+                           nn.BatchNorm1d(fc_list[k]), nn.ReLU()])
+            pre = fc_list[k]
+            if self.model_cfg.DP_RATIO >= 0 and k == 0:
+                layers.append(nn.Dropout(self.model_cfg.DP_RATIO))
+        layers.append(nn.Conv1d(pre, output_channels, kernel_size=1, bias=True))
+        return nn.Sequential(*layers)
+
+    # ---- proposals ------------------------------------------------------------
+    def proposal_layer(self, batch_dict, nms_config):
+        """roi_head_template.py:46-102"""
+        batch_size = batch_dict['batch_size']
+        batch_box_preds = batch_dict['batch_box_preds']
+        batch_cls_preds = batch_dict['batch_cls_preds']
+        assert batch_cls_preds.dim() == 3 and not nms_config.MULTI_CLASSES_NMS
+        rois, roi_scores, roi_scores_full, roi_labels = [], [], [], []
+        for index in range(batch_size):
+            box_preds = batch_box_preds[index]
+            cls_preds = batch_cls_preds[index]
+            cur_roi_scores, cur_roi_labels = torch.max(cls_preds, dim=1)
+            selected, valid = class_agnostic_nms_fixed(cur_roi_scores.detach(), box_preds.detach(),
+                                                       nms_config)
+            vf = valid.to(box_preds.dtype)
+            rois.append(box_preds[selected] * vf[:, None])
+            roi_scores.append(cur_roi_scores[selected] * vf)
+            roi_labels.append(cur_roi_labels[selected] * valid.long())
+            roi_scores_full.append(cls_preds[selected] * vf[:, None])
+        batch_dict['rois'] = torch.stack(rois).detach()
+        batch_dict['roi_scores'] = torch.stack(roi_scores).detach()
+        batch_dict['roi_scores_full'] = torch.stack(roi_scores_full)   # not detached (:98)
+        batch_dict['roi_labels'] = (torch.stack(roi_labels) + 1).detach()
+        batch_dict['has_class_labels'] = batch_cls_preds.shape[-1] > 1
+        batch_dict.pop('batch_index', None)
+        return batch_dict
+
+    def assign_targets(self, batch_dict):
+        """roi_head_template.py:104-134: sample + canonical transform of the GT."""
+        batch_size = batch_dict['batch_size']
+        targets_dict = self.proposal_target_layer(batch_dict)
+        rois = targets_dict['rois']
+        gt_of_rois = targets_dict['gt_of_rois']
+        targets_dict['gt_of_rois_src'] = gt_of_rois.clone().detach()
+        roi_center = rois[:, :, 0:3]
+        roi_ry = rois[:, :, 6] % (2 * np.pi)
+        gt_of_rois = torch.cat([gt_of_rois[:, :, 0:3] - roi_center, gt_of_rois[:, :, 3:6],
+                                (gt_of_rois[:, :, 6] - roi_ry).unsqueeze(-1), gt_of_rois[:, :, 7:]],
+                               dim=-1)
+        gt_of_rois = U.rotate_points_along_z(gt_of_rois.view(-1, 1, gt_of_rois.shape[-1]),
+                                             -roi_ry.view(-1)).view(batch_size, -1,
+                                                                    gt_of_rois.shape[-1])
+        heading = gt_of_rois[:, :, 6] % (2 * np.pi)
+        opposite = (heading > np.pi * 0.5) & (heading < np.pi * 1.5)
+        heading = torch.where(opposite, (heading + np.pi) % (2 * np.pi), heading)
+        heading = torch.where(heading > np.pi, heading - np.pi * 2, heading)
+        heading = torch.clamp(heading, min=-np.pi / 2, max=np.pi / 2)
+        targets_dict['gt_of_rois'] = torch.cat([gt_of_rois[:, :, :6], heading.unsqueeze(-1),
+                                                gt_of_rois[:, :, 7:]], dim=-1)
+        return targets_dict
+
+    # ---- RoI grid pooling -------------------------------------------------------
+    @staticmethod
+    def get_dense_grid_points(rois, batch_size_rcnn, grid_size):
+        """pvrcnn_head.py:140-149"""
+        faked = rois.new_ones((grid_size, grid_size, grid_size))
+        dense_idx = faked.nonzero().repeat(batch_size_rcnn, 1, 1).float()
+        local_roi_size = rois.view(batch_size_rcnn, -1)[:, 3:6]
+        return (dense_idx + 0.5) / grid_size * local_roi_size.unsqueeze(dim=1) \
+            - (local_roi_size.unsqueeze(dim=1) / 2)
+
+    def get_global_grid_points_of_roi(self, rois, grid_size):
+        rois = rois.view(-1, rois.shape[-1])
+        local = self.get_dense_grid_points(rois, rois.shape[0], grid_size)
+        glob = U.rotate_points_along_z(local.clone(), rois[:, 6]).squeeze(dim=1)
+        return glob + rois[:, 0:3].clone().unsqueeze(dim=1), local
+
+    def roi_grid_pool(self, batch_dict):
+        """pvrcnn_head.py:73-125"""
+        batch_size = batch_dict['batch_size']
+        rois = batch_dict['rois']
+        point_coords = batch_dict['point_coords']
+        point_features = batch_dict['point_features'] * batch_dict['point_cls_scores'].view(-1, 1)
+        gs = self.model_cfg.ROI_GRID_POOL.GRID_SIZE
+        global_pts, _ = self.get_global_grid_points_of_roi(rois, grid_size=gs)
+        global_pts = global_pts.view(batch_size, -1, 3)
+        xyz = point_coords[:, 1:4]
+        xyz_batch_cnt = torch.bincount(point_coords[:, 0].long(), minlength=batch_size).int()
+        new_xyz = global_pts.view(-1, 3)
+        new_xyz_batch_cnt = torch.full((batch_size,), global_pts.shape[1], dtype=torch.int32,
+                                       device=xyz.device)
+        _, pooled = self.roi_grid_pool_layer(xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt,
+                                             new_xyz=new_xyz.contiguous(),
+                                             new_xyz_batch_cnt=new_xyz_batch_cnt,
+                                             features=point_features.contiguous())
+        return pooled.view(-1, gs ** 3, pooled.shape[-1])
+
+    def forward(self, batch_dict):
+        """pvrcnn_head.py:151-201"""
+        self.proposal_layer(batch_dict,
+                            nms_config=self.model_cfg.NMS_CONFIG['TRAIN' if self.training else 'TEST'])
+        targets_dict = None
+        if self.training:
+            targets_dict = self.assign_targets(batch_dict)
+            batch_dict['rois'] = targets_dict['rois']
+            batch_dict['roi_labels'] = targets_dict['roi_labels']
+            batch_dict['roi_scores'] = targets_dict['roi_scores']
+            batch_dict['roi_scores_full'] = targets_dict['roi_scores_full']
+        pooled = self.roi_grid_pool(batch_dict)                           # (B*N, 216, C)
+        n_rcnn = pooled.shape[0]
+        pooled = pooled.permute(0, 2, 1).contiguous()                    # (B*N, C, 216)
+        shared = self.shared_fc_layer(pooled.view(n_rcnn, -1, 1))
+        rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        batch_cls_preds, batch_box_preds = self.generate_predicted_boxes(
+            batch_dict['batch_size'], batch_dict['rois'], rcnn_cls, rcnn_reg)
+        batch_dict['batch_cls_preds'] = batch_cls_preds
+        batch_dict['batch_box_preds'] = batch_box_preds
+        batch_dict['cls_preds_normalized'] = False
+        if self.training:
+            targets_dict['rcnn_cls'] = rcnn_cls
+            targets_dict['rcnn_reg'] = rcnn_reg
+            self.forward_ret_dict = targets_dict
+        return batch_dict
+
+    def generate_predicted_boxes(self, batch_size, rois, cls_preds, box_preds):
+        """roi_head_template.py:233-263"""
+        code_size = self.box_coder.code_size
+        batch_cls_preds = cls_preds.view(batch_size, -1, cls_preds.shape[-1])
+        batch_box_preds = box_preds.view(batch_size, -1, code_size)
+        roi_ry = rois[:, :, 6].view(-1)
+        roi_xyz = rois[:, :, 0:3].view(-1, 3)
+        local_rois = rois.clone().detach()
+        local_rois[:, :, 0:3] = 0
+        decoded = self.box_coder.decode_torch(batch_box_preds, local_rois).view(-1, code_size)
+        decoded = U.rotate_points_along_z(decoded.unsqueeze(dim=1), roi_ry).squeeze(dim=1)
+        decoded = torch.cat([decoded[:, 0:3] + roi_xyz, decoded[:, 3:]], dim=-1)
+        return batch_cls_preds, decoded.view(batch_size, -1, code_size)
+
+    # ---- losses ---------------------------------------------------------------
+    def get_box_reg_layer_loss(self, d):
+        """roi_head_template.py:136-198 (smooth-l1 + corner regularisation), with the fg
+        subset expressed as a mask instead of a data-dependent gather."""
+        loss_cfgs = self.model_cfg.LOSS_CONFIG
+        assert loss_cfgs.REG_LOSS == 'smooth-l1'
+        code_size = self.box_coder.code_size
+        reg_valid_mask = d['reg_valid_mask'].view(-1)
+        gt_boxes3d_ct = d['gt_of_rois'][..., 0:code_size]
+        gt_of_rois_src = d['gt_of_rois_src'][..., 0:code_size].view(-1, code_size)
+        rcnn_reg = d['rcnn_reg']
+        roi_boxes3d = d['rois']
+        n = gt_boxes3d_ct.view(-1, code_size).shape[0]
+        fg_mask = reg_valid_mask > 0
+        fgf = fg_mask.float()
+        fg_sum = fgf.sum()
+        rois_anchor = roi_boxes3d.clone().detach().view(-1, code_size)
+        rois_anchor[:, 0:3] = 0
+        rois_anchor[:, 6] = 0
+        reg_targets = self.box_coder.encode_torch(gt_boxes3d_ct.view(n, code_size), rois_anchor)
+        loss_reg = self.reg_loss_func(rcnn_reg.view(n, -1).unsqueeze(dim=0),
+                                      reg_targets.unsqueeze(dim=0))
+        # rows that are not fg may hold inf/nan targets (zero-size boxes): mask, don't multiply
+        loss_reg = torch.where(fg_mask[:, None], loss_reg.view(n, -1),
+                               torch.zeros_like(loss_reg.view(n, -1))).sum() \
+            / torch.clamp(fg_sum, min=1.0)
+        loss_reg = loss_reg * loss_cfgs.LOSS_WEIGHTS['rcnn_reg_weight']
+        tb_dict = {'rcnn_loss_reg': loss_reg.detach()}
+        if loss_cfgs.CORNER_LOSS_REGULARIZATION:
+            rois_flat = roi_boxes3d.view(-1, code_size)
+            batch_anchors = rois_flat.clone().detach().view(1, -1, code_size)
+            roi_ry = rois_flat[:, 6]
+            roi_xyz = rois_flat[:, 0:3]
+            batch_anchors[:, :, 0:3] = 0
+            rcnn_boxes3d = self.box_coder.decode_torch(rcnn_reg.view(1, -1, code_size),
+                                                       batch_anchors).view(-1, code_size)
+            rcnn_boxes3d = U.rotate_points_along_z(rcnn_boxes3d.unsqueeze(dim=1), roi_ry).squeeze(dim=1)
+            rcnn_boxes3d = torch.cat([rcnn_boxes3d[:, 0:3] + roi_xyz, rcnn_boxes3d[:, 3:]], dim=-1)
+            corner = U.get_corner_loss_lidar(rcnn_boxes3d[:, 0:7], gt_of_rois_src[:, 0:7])
+            corner = torch.where(fg_mask, corner, torch.zeros_like(corner)).sum() \
+                / torch.clamp(fg_sum, min=1.0)     # == mean over the fg rows; 0 when there are none
+            corner = corner * loss_cfgs.LOSS_WEIGHTS['rcnn_corner_weight']
+            loss_reg = loss_reg + corner
+            tb_dict['rcnn_loss_corner'] = corner.detach()
+        return loss_reg, tb_dict
+
+    def get_box_cls_layer_loss(self, d):
+        """roi_head_template.py:200-218"""
+        loss_cfgs = self.model_cfg.LOSS_CONFIG
+        assert loss_cfgs.CLS_LOSS == 'BinaryCrossEntropy'
+        rcnn_cls_flat = d['rcnn_cls'].view(-1)
+        labels = d['rcnn_cls_labels'].view(-1)
+        batch_loss_cls = F.binary_cross_entropy(torch.sigmoid(rcnn_cls_flat), labels.float(),
+                                                reduction='none')
+        valid = (labels >= 0).float()
+        loss = (batch_loss_cls * valid).sum() / torch.clamp(valid.sum(), min=1.0)
+        loss = loss * loss_cfgs.LOSS_WEIGHTS['rcnn_cls_weight']
+        return loss, {'rcnn_loss_cls': loss.detach()}
+
+    def get_loss(self, tb_dict=None):
+        tb_dict = {} if tb_dict is None else tb_dict
+        loss_cls, cls_tb = self.get_box_cls_layer_loss(self.forward_ret_dict)
+        loss_reg, reg_tb = self.get_box_reg_layer_loss(self.forward_ret_dict)
+        tb_dict.update(cls_tb)
+        tb_dict.update(reg_tb)
+        rcnn_loss = loss_cls + loss_reg
+        tb_dict['rcnn_loss'] = rcnn_loss.detach()
+        return rcnn_loss, tb_dict

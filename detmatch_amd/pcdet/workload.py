@@ -106,3 +106,89 @@ class Stage3DWorkload(object):
             if cin >= 16:  # the first layer's input needs no gradient
                 bwd.append((cout, cin, n_in[key], kvol, P[key]))
         return fwd + bwd[::-1]
+
+
+class PVRCNNTrainWorkload(object):
+    """BASELINE.json configs[1]: PV-RCNN 3D-only supervised training step, bs=2/GPU, on
+    KITTI-shaped synthetic frames: OpenPCDetDetector.forward_train (batched voxelize+MeanVFE,
+    VoxelBackBone8x, HeightCompression, VoxelSetAbstraction, BaseBEVBackbone,
+    AnchorHeadSingle + target assignment, PointHeadSimple, PVRCNNHead with rotated NMS,
+    proposal-target sampling and RoI-grid pooling, all losses) + backward + grad clip (L2 10)
+    + AdamW (lr 1e-3, betas (0.95, 0.99), wd 0.01 — configs/detmatch/001/pretrain_pvrcnn)."""
+
+    def __init__(self, frames, device, lr=1e-3):
+        from .. import configs
+        from ..mm3d.box3d import LiDARInstance3DBoxes
+        from ..mm3d.openpcdet import OpenPCDetDetector
+        self.frames = frames
+        self.device = device
+        self.points = [torch.from_numpy(f['points']).to(device) for f in frames]
+        self.gt_boxes, self.gt_labels = [], []
+        for f in frames:
+            b, l = synth.frame_to_mm3d_gt(f)
+            self.gt_boxes.append(LiDARInstance3DBoxes(torch.from_numpy(b).to(device)))
+            self.gt_labels.append(torch.from_numpy(l).to(device))
+        self.img_metas = [dict(sample_idx=i) for i in range(len(frames))]
+        torch.manual_seed(0)
+        cfg = configs.pvrcnn_kitti_model()
+        cfg.pop('type')
+        self.model = OpenPCDetDetector(**cfg).to(device)
+        self.backbone = self.model.model.backbone_3d
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self.opt = torch.optim.AdamW(self.params, lr=lr, betas=(0.95, 0.99), weight_decay=0.01)
+        self.world = 1
+        self.last_loss = None
+
+    def describe(self):
+        return ('PV-RCNN 3D supervised train step (BASELINE configs[1]): full OpenPCDetDetector.'
+                'forward_train (voxelize+MeanVFE, VoxelBackBone8x, HeightCompression, VSA, BEV '
+                'backbone, anchor head + targets, point head, PV-RCNN RoI head: rotated NMS 9000->512, '
+                'proposal targets, RoI-grid pooling, all losses) + backward + grad-clip + AdamW; '
+                'KITTI-shaped synthetic, bs=%d/GPU, 13.1 M params' % len(self.frames))
+
+    def enable_ddp(self):
+        self.world = dist.get_world_size()
+        flat = torch.cat([p.data.view(-1) for p in self.params])
+        dist.broadcast(flat, 0)
+        off = 0
+        for p in self.params:
+            p.data.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def step(self):
+        self.model.train()
+        out = self.model.forward_train(self.points, self.img_metas, self.gt_boxes, self.gt_labels)
+        loss = out['loss']
+        self.opt.zero_grad(set_to_none=False)
+        loss.backward()
+        if self.world > 1:  # gradients only, one flat bucket (SURVEY 8e)
+            flat = torch.cat([p.grad.view(-1) for p in self.params])
+            dist.all_reduce(flat)
+            flat.div_(self.world)
+            off = 0
+            for p in self.params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        torch.nn.utils.clip_grad_norm_(self.params, 10.0)
+        self.opt.step()
+        self.last_loss = loss.detach()
+        return loss
+
+    def trace_gather_gemm(self):
+        """[(ci, co, rows, kvol, P)] of one step's gather-GEMM launches, in launch order."""
+        self.model.train()
+        batch = self.model.train_to_openpcdet(self.points, self.img_metas, self.gt_boxes,
+                                              self.gt_labels)
+        batch = self.model.model.vfe(batch)
+        batch = self.backbone(batch)
+        idict = batch['multi_scale_3d_features']['x_conv1'].indice_dict
+        P = {k: int(v[3].sum().item()) for k, v in idict.items()}
+        n_in = {k: int(v[1].shape[0]) for k, v in idict.items()}
+        n_out = {k: int(v[0].shape[0]) for k, v in idict.items()}
+        fwd, bwd = [], []
+        for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
+            kvol = ks[0] * ks[1] * ks[2]
+            fwd.append((cin, cout, n_out[key], kvol, P[key]))
+            if cin >= 16:
+                bwd.append((cout, cin, n_in[key], kvol, P[key]))
+        return fwd + bwd[::-1]

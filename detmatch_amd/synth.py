@@ -146,3 +146,17 @@ def kitti_image(seed=0, shape=(384, 1280)):
     """Seeded uint8 noise image already resized/padded to a /32 shape."""
     rng = np.random.default_rng(10_000 + seed)
     return rng.integers(0, 256, size=(shape[0], shape[1], 3), dtype=np.uint8)
+
+
+# class order of configs/detmatch: ['Pedestrian', 'Cyclist', 'Car']; simulator: Car, Ped, Cyc
+_SIM_TO_CFG_LABEL = np.array([2, 0, 1], dtype=np.int64)
+
+
+def frame_to_mm3d_gt(frame):
+    """Simulator GT (pcdet convention: gravity centre, dx along heading) -> the mmdet3d LiDAR
+    convention the detectors take (bottom centre, (x, y, z, w, l, h, yaw), the inverse of
+    mmdet3d/models/detectors/openpcdet.py:100-122) and config-order labels."""
+    b = frame['gt_boxes'].astype(np.float32)
+    out = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 5] / 2, b[:, 4], b[:, 3], b[:, 5],
+                    -b[:, 6] - np.pi / 2], axis=1).astype(np.float32)
+    return out, _SIM_TO_CFG_LABEL[frame['gt_labels']]
