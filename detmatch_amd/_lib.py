@@ -49,6 +49,7 @@ SIGNATURES = {
     'dm_group_points_stack': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     'dm_group_points_grad_stack': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     'dm_furthest_point_sampling': (ci, [ci, ci, ci, vp, vp, vp, vp]),
+    'dm_furthest_point_sampling_stack': (ci, [ci, c_i32_p, ci, vp, vp, vp, vp]),
     'dm_points_in_boxes': (ci, [ci, ci, ci, vp, vp, vp, vp]),
     'dm_profile_enable': (ci, [ci]),
     'dm_spconv_debug_stamps': (ci, [vp]),

@@ -97,6 +97,102 @@ __global__ __launch_bounds__(256) void ball_query_kernel(int batch, float radius
   }
 }
 
+// Wave-parallel ball query: one wave scans the sample's points 64 at a time for Q queries
+// (hits are ranked with a ballot + prefix popcount, so "first nsample in storage order" is
+// kept exactly) — M/Q waves instead of M/256 blocks, which is what fills 256 CUs when
+// M = 4096 keypoints.
+template <int Q>
+__global__ __launch_bounds__(256) void ball_query_wave(int batch, int m, float radius2,
+                                                       int nsample,
+                                                       const float *__restrict__ new_xyz,
+                                                       const int *__restrict__ new_cnt,
+                                                       const float *__restrict__ xyz,
+                                                       const int *__restrict__ xyz_cnt,
+                                                       int *__restrict__ idx,
+                                                       unsigned char *__restrict__ empty_mask) {
+  const int lane = threadIdx.x & 63;
+  const int wq = (blockIdx.x * 4 + (threadIdx.x >> 6)) * Q;  // first query of this wave
+  if (wq >= m) return;
+  // all Q queries of a wave must belong to one sample: the host pads nothing, so fall back
+  // to per-query sample lookup (B is tiny)
+  float qx[Q], qy[Q], qz[Q];
+  int cnt[Q], first[Q], pstart[Q], pn[Q];
+  bool live[Q];
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    int q = wq + u;
+    live[u] = q < m;
+    int qq = live[u] ? q : m - 1;
+    int b = 0, acc = new_cnt[0];
+    for (int k = 1; k < batch; ++k) {
+      if (qq < acc) break;
+      acc += new_cnt[k];
+      b = k;
+    }
+    int ps = 0;
+    for (int k = 0; k < b; ++k) ps += xyz_cnt[k];
+    pstart[u] = ps;
+    pn[u] = xyz_cnt[b];
+    qx[u] = new_xyz[(size_t)qq * 3 + 0];
+    qy[u] = new_xyz[(size_t)qq * 3 + 1];
+    qz[u] = new_xyz[(size_t)qq * 3 + 2];
+    cnt[u] = 0;
+    first[u] = 0;
+  }
+  // queries are stacked by sample, so the Q queries of a wave share a sample except at a
+  // sample boundary; handle the general case by scanning per distinct (pstart, pn)
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int u0 = 0; u0 < Q; ++u0) {
+    bool leader = true;
+#pragma unroll
+    for (int v = 0; v < u0; ++v)
+      if (pstart[v] == pstart[u0] && pn[v] == pn[u0]) leader = false;
+    if (!leader) continue;
+    const float *base = xyz + (size_t)pstart[u0] * 3;
+    const int n = pn[u0];
+    for (int k0 = 0; k0 < n; k0 += 64) {
+      bool any_open = false;
+#pragma unroll
+      for (int u = 0; u < Q; ++u)
+        if (live[u] && pstart[u] == pstart[u0] && pn[u] == n && cnt[u] < nsample) any_open = true;
+      if (!any_open) break;
+      int k = k0 + lane;
+      bool in = k < n;
+      float x = in ? base[(size_t)k * 3 + 0] : 0.f;
+      float y = in ? base[(size_t)k * 3 + 1] : 0.f;
+      float z = in ? base[(size_t)k * 3 + 2] : 0.f;
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        if (!(live[u] && pstart[u] == pstart[u0] && pn[u] == n) || cnt[u] >= nsample) continue;
+        float d2 = dist2_fma(qx[u] - x, qy[u] - y, qz[u] - z);
+        bool hit = in && d2 < radius2;
+        unsigned long long mk = __ballot(hit);
+        if (mk == 0ull) continue;
+        if (cnt[u] == 0) first[u] = k0 + __ffsll((long long)mk) - 1;
+        int pos = cnt[u] + __popcll(mk & lt);
+        if (hit && pos < nsample) idx[(size_t)(wq + u) * nsample + pos] = k;
+        cnt[u] += __popcll(mk);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    if (!live[u]) continue;
+    int *out = idx + (size_t)(wq + u) * nsample;
+    int c = cnt[u] < nsample ? cnt[u] : nsample;
+    if (c > 0) {
+      for (int l = c + lane; l < nsample; l += 64) out[l] = first[u];  // pad with first hit
+      if (empty_mask && lane == 0) empty_mask[wq + u] = 0;
+    } else if (empty_mask) {
+      for (int l = lane; l < nsample; l += 64) out[l] = 0;
+      if (lane == 0) empty_mask[wq + u] = 1;
+    } else if (lane == 0) {
+      out[0] = -1;  // ball_query_gpu.cu:65
+    }
+  }
+}
+
 // ---- grouping -------------------------------------------------------------------
 // One wave per query point: rows are read coalesced (lanes over channels), transposed
 // through a wave-private LDS tile and written as contiguous (C, nsample) blocks.
@@ -191,33 +287,45 @@ __device__ __forceinline__ bool fps_better(float d2, int k2, float d1, int k1, i
   return k2 < k1;
 }
 
+struct FpsSamples {
+  int off[DM_MAX_BATCH + 1];  // sample b owns points [off[b], off[b+1]) of the stacked xyz
+};
+
+// 512 threads = 2 waves per SIMD = 256 registers per lane: up to 48 points per thread
+// (n <= 24576) stay in registers without spilling.
+constexpr int FPS_T = 512;
+
 template <int PPT>
-__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs_mask,
-                                                   const float *__restrict__ xyz,
-                                                   float *__restrict__ temp,
-                                                   int *__restrict__ idxs) {
-  __shared__ float s_d[16];
-  __shared__ int s_k[16];
+__global__ __launch_bounds__(FPS_T) void fps_kernel(FpsSamples smp, int m,
+                                                    const float *__restrict__ xyz,
+                                                    float *__restrict__ temp,
+                                                    int *__restrict__ idxs) {
+  __shared__ float s_d[8];
+  __shared__ int s_k[8];
   __shared__ float s_pt[3];
-  __shared__ int s_old;
   const int b = blockIdx.x;
-  const float *data = xyz + (size_t)b * n * 3;
-  float *tmp = temp + (size_t)b * n;
+  const int n = smp.off[b + 1] - smp.off[b];
+  const float *data = xyz + (size_t)smp.off[b] * 3;
+  float *tmp = temp + (size_t)smp.off[b];
   int *out = idxs + (size_t)b * m;
+  if (n <= 0) return;
+  // the reference's block size for this n (sampling_gpu.cu:9-13) fixes the tie rule
+  int bs = 1;
+  while (bs * 2 <= n && bs < 1024) bs *= 2;
+  const int bs_mask = bs - 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float px[PPT], py[PPT], pz[PPT], pt[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    int k = tid + i * 1024;
+    int k = tid + i * FPS_T;
     bool ok = k < n;
     px[i] = ok ? data[(size_t)k * 3 + 0] : 0.f;
     py[i] = ok ? data[(size_t)k * 3 + 1] : 0.f;
     pz[i] = ok ? data[(size_t)k * 3 + 2] : 0.f;
-    pt[i] = ok ? tmp[k] : -1.f;  // padding can never win (every real d2 is >= 0 > -1)
+    pt[i] = ok ? tmp[k] : -1.f;  // padding: min(d, -1) = -1 can never win (real d2 >= 0)
   }
   if (tid == 0) {
     out[0] = 0;
-    s_old = 0;
     s_pt[0] = data[0];
     s_pt[1] = data[1];
     s_pt[2] = data[2];
@@ -226,20 +334,20 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs_mask,
   for (int j = 1; j < m; ++j) {
     const float x1 = s_pt[0], y1 = s_pt[1], z1 = s_pt[2];
     float best = -1.f;
-    int besti = 0;
+    int bslot = 0;  // slot i of the running best; its point index is tid + bslot * FPS_T
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      int k = tid + i * 1024;
-      if (k < n) {
-        float d = dist2_fma(px[i] - x1, py[i] - y1, pz[i] - z1);
-        float d2 = fminf(d, pt[i]);
-        pt[i] = d2;
-        if (fps_better(d2, k, best, besti, bs_mask) || best < 0.f) {
-          best = d2;
-          besti = k;
-        }
-      }
+      float d = dist2_fma(px[i] - x1, py[i] - y1, pz[i] - z1);
+      float d2 = fminf(d, pt[i]);
+      pt[i] = d2;
+      // strict '>' is the common path; exact ties (duplicated points) take the full rule
+      bool take = d2 > best;
+      if (d2 == best && d2 >= 0.f)
+        take = fps_better(d2, tid + i * FPS_T, best, tid + bslot * FPS_T, bs_mask);
+      best = take ? d2 : best;
+      bslot = take ? i : bslot;
     }
+    int besti = tid + bslot * FPS_T;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       float od = __shfl_xor(best, off);
@@ -256,10 +364,10 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs_mask,
     }
     __syncthreads();
     if (wave == 0) {
-      float d = lane < 16 ? s_d[lane] : -1.f;
-      int k = lane < 16 ? s_k[lane] : 0;
+      float d = lane < FPS_T / 64 ? s_d[lane] : -1.f;
+      int k = lane < FPS_T / 64 ? s_k[lane] : 0;
 #pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) {
+      for (int off = 4; off >= 1; off >>= 1) {
         float od = __shfl_xor(d, off);
         int ok = __shfl_xor(k, off);
         if (od >= 0.f && (d < 0.f || fps_better(od, ok, d, k, bs_mask))) {
@@ -269,7 +377,6 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs_mask,
       }
       if (lane == 0) {
         out[j] = k;
-        s_old = k;
         s_pt[0] = data[(size_t)k * 3 + 0];
         s_pt[1] = data[(size_t)k * 3 + 1];
         s_pt[2] = data[(size_t)k * 3 + 2];
@@ -279,14 +386,14 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs_mask,
   }
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    int k = tid + i * 1024;
+    int k = tid + i * FPS_T;
     if (k < n) tmp[k] = pt[i];
   }
 }
 
 // fallback for point counts whose per-thread share does not fit the register file:
 // the running minima live in `temp` (global), as in the reference
-__global__ __launch_bounds__(1024) void fps_kernel_global(int n, int m, int bs_mask,
+__global__ __launch_bounds__(1024) void fps_kernel_global(FpsSamples smp, int m,
                                                           const float *__restrict__ xyz,
                                                           float *__restrict__ temp,
                                                           int *__restrict__ idxs) {
@@ -294,9 +401,14 @@ __global__ __launch_bounds__(1024) void fps_kernel_global(int n, int m, int bs_m
   __shared__ int s_k[16];
   __shared__ int s_old;
   const int b = blockIdx.x;
-  const float *data = xyz + (size_t)b * n * 3;
-  float *tmp = temp + (size_t)b * n;
+  const int n = smp.off[b + 1] - smp.off[b];
+  const float *data = xyz + (size_t)smp.off[b] * 3;
+  float *tmp = temp + (size_t)smp.off[b];
   int *out = idxs + (size_t)b * m;
+  if (n <= 0) return;
+  int bs = 1;
+  while (bs * 2 <= n && bs < 1024) bs *= 2;
+  const int bs_mask = bs - 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) {
     out[0] = 0;
@@ -367,9 +479,15 @@ extern "C" int dm_ball_query_stack(int batch, int m, float radius, int nsample,
   if (m == 0) return DM_OK;
   if (!new_xyz || !new_xyz_batch_cnt || !xyz_batch_cnt || !idx) return DM_ERR_INVALID_ARG;
   float radius2 = radius * radius;  // ball_query_gpu.cu:43
-  dim3 grid(dm_ceil_div(max_m_per_sample > 0 ? max_m_per_sample : m, 256), batch);
-  ball_query_kernel<<<grid, 256, 0, st>>>(batch, radius2, nsample, new_xyz, new_xyz_batch_cnt, xyz,
-                                          xyz_batch_cnt, idx, empty_mask);
+  (void)max_m_per_sample;
+  if (m >= 16384)
+    ball_query_wave<4><<<dm_ceil_div(m, 16), 256, 0, st>>>(batch, m, radius2, nsample, new_xyz,
+                                                           new_xyz_batch_cnt, xyz, xyz_batch_cnt,
+                                                           idx, empty_mask);
+  else
+    ball_query_wave<2><<<dm_ceil_div(m, 8), 256, 0, st>>>(batch, m, radius2, nsample, new_xyz,
+                                                          new_xyz_batch_cnt, xyz, xyz_batch_cnt,
+                                                          idx, empty_mask);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -425,23 +543,48 @@ extern "C" int dm_group_points_grad_stack(int batch, int m, int c, int n, int ns
   return DM_OK;
 }
 
+static int fps_launch(const FpsSamples &smp, int batch, int max_n, int m, const float *xyz,
+                      float *temp, int *idxs, hipStream_t st) {
+  int ppt = dm_ceil_div(max_n, FPS_T);
+  if (ppt <= 4) fps_kernel<4><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
+  else if (ppt <= 8) fps_kernel<8><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
+  else if (ppt <= 16) fps_kernel<16><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
+  else if (ppt <= 24) fps_kernel<24><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
+  else if (ppt <= 32) fps_kernel<32><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
+  else if (ppt <= 40) fps_kernel<40><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
+  else if (ppt <= 48) fps_kernel<48><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
+  else fps_kernel_global<<<batch, 1024, 0, st>>>(smp, m, xyz, temp, idxs);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
 extern "C" int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float *temp,
                                           int *idxs, dm_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (batch < 0 || n <= 0 || m < 0) return DM_ERR_INVALID_ARG;
+  if (batch < 0 || batch > DM_MAX_BATCH || n <= 0 || m < 0) return DM_ERR_INVALID_ARG;
   if (batch == 0 || m == 0) return DM_OK;
   if (!xyz || !temp || !idxs) return DM_ERR_INVALID_ARG;
-  // the reference's block size for this n (sampling_gpu.cu:9-13) fixes the tie rule
-  int bs = 1;
-  while (bs * 2 <= n && bs < 1024) bs *= 2;
-  int bs_mask = bs - 1;
-  int ppt = dm_ceil_div(n, 1024);
-  if (ppt <= 4) fps_kernel<4><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
-  else if (ppt <= 8) fps_kernel<8><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
-  else if (ppt <= 16) fps_kernel<16><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
-  else if (ppt <= 24) fps_kernel<24><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
-  else if (ppt <= 32) fps_kernel<32><<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
-  else fps_kernel_global<<<batch, 1024, 0, st>>>(n, m, bs_mask, xyz, temp, idxs);
-  DM_CHECK_LAUNCH();
-  return DM_OK;
+  FpsSamples smp;
+  for (int b = 0; b <= batch; ++b) smp.off[b] = b * n;
+  return fps_launch(smp, batch, n, m, xyz, temp, idxs, st);
+}
+
+extern "C" int dm_furthest_point_sampling_stack(int batch, const int *offsets_host, int m,
+                                                const float *xyz, float *temp, int *idxs,
+                                                dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (batch < 0 || batch > DM_MAX_BATCH || m < 0 || !offsets_host) return DM_ERR_INVALID_ARG;
+  if (batch == 0 || m == 0) return DM_OK;
+  if (!xyz || !temp || !idxs) return DM_ERR_INVALID_ARG;
+  FpsSamples smp;
+  int max_n = 0;
+  for (int b = 0; b <= batch; ++b) {
+    smp.off[b] = offsets_host[b];
+    if (b > 0) {
+      int nb = offsets_host[b] - offsets_host[b - 1];
+      if (nb <= 0) return DM_ERR_INVALID_ARG;
+      if (nb > max_n) max_n = nb;
+    }
+  }
+  return fps_launch(smp, batch, max_n, m, xyz, temp, idxs, st);
 }

@@ -92,18 +92,18 @@ class VoxelSetAbstraction(nn.Module):
         points = batch_dict['points']
         cnt = batch_dict['points_batch_cnt_host']
         num_kp = self.model_cfg.NUM_KEYPOINTS
+        xyz = points[:, 1:4].contiguous()
+        idx = pn2.furthest_point_sample_stack(xyz, cnt, num_kp).long()      # (B, num_kp)
         keypoints_list = []
         start = 0
         for bs_idx in range(batch_size):
             n = int(cnt[bs_idx])
-            sampled_points = points[start:start + n, 1:4].unsqueeze(dim=0).contiguous()
-            start += n
-            cur_pt_idxs = pn2.furthest_point_sample(sampled_points, num_kp).long()
-            if n < num_kp:
+            cur = idx[bs_idx]
+            if n < num_kp:  # :143-146 repeat-pad the n distinct picks
                 times = int(num_kp / n) + 1
-                non_empty = cur_pt_idxs[0, :n]
-                cur_pt_idxs = non_empty.repeat(times)[:num_kp].unsqueeze(0)
-            keypoints_list.append(sampled_points[0][cur_pt_idxs[0]].unsqueeze(dim=0))
+                cur = cur[:n].repeat(times)[:num_kp]
+            keypoints_list.append(xyz[start:start + n][cur].unsqueeze(dim=0))
+            start += n
         return torch.cat(keypoints_list, dim=0)
 
     def forward(self, batch_dict):

@@ -145,6 +145,27 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
+def furthest_point_sample_stack(xyz, batch_cnt_host, npoint):
+    """Ragged FPS: xyz (sum N, 3) stacked, batch_cnt_host the per-sample point counts (host
+    ints) -> (B, npoint) int32 indices local to each sample.  All samples run concurrently
+    (the reference loops samples in Python, voxel_set_abstraction.py:135-151)."""
+    import ctypes
+    xyz = xyz.contiguous()
+    _lib.require_device(xyz)
+    B = len(batch_cnt_host)
+    offs = [0]
+    for c in batch_cnt_host:
+        offs.append(offs[-1] + int(c))
+    assert offs[-1] == xyz.shape[0]
+    output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    temp = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32, device=xyz.device)
+    rc = _lib.lib().dm_furthest_point_sampling_stack(
+        B, (ctypes.c_int32 * (B + 1))(*offs), int(npoint), _lib.ptr(xyz), _lib.ptr(temp),
+        _lib.ptr(output), _lib.stream())
+    _lib.check(rc, 'dm_furthest_point_sampling_stack')
+    return output
+
+
 class StackSAModuleMSG(nn.Module):
     """pointnet2_modules.py:10-92: multi-scale grouping + shared MLP + max over samples."""
 

@@ -237,6 +237,11 @@ int dm_group_points_grad_stack(int batch, int m, int c, int n, int nsample, cons
  * temp (b,n) pre-filled with 1e10 by the caller, idxs (b,m). */
 int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float *temp, int *idxs,
                                dm_stream_t stream);
+/* Same, ragged: sample b owns points [offsets_host[b], offsets_host[b+1]) of the stacked
+ * xyz (sum N, 3) / temp (sum N); all samples run concurrently (the reference loops samples
+ * in Python, voxel_set_abstraction.py:135-151). */
+int dm_furthest_point_sampling_stack(int batch, const int *offsets_host, int m, const float *xyz,
+                                     float *temp, int *idxs, dm_stream_t stream);
 /* Replaces roiaware_pool3d_cuda.points_in_boxes_gpu (roiaware_pool3d.cpp:98-129,
  * roiaware_pool3d_kernel.cu:313-360).  box_idx (batch, pts_num): first containing box or -1
  * (the callee writes every element; no pre-fill needed). */
