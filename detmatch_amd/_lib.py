@@ -45,6 +45,10 @@ SIGNATURES = {
     'dm_nms_workspace_bytes': (sz, [ci]),
     'dm_nms': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
     'dm_nms_normal': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
+    'dm_nms_2d': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
+    'dm_ema_update_f32': (ci, [vp, vp, sz, ctypes.c_double, vp]),
+    'dm_ema_update_i64': (ci, [vp, vp, sz, ctypes.c_double, vp]),
+    'dm_lap_host': (ci, [c_f32_p, ci, ci, c_int_p, c_int_p]),
     'dm_ball_query_stack': (ci, [ci, ci, cf, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
     'dm_group_points_stack': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     'dm_group_points_grad_stack': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),

@@ -195,6 +195,42 @@ __global__ __launch_bounds__(256) void pair_matrix(const float *boxes_a, const f
   out[(size_t)ai * nb + bi] = v;
 }
 
+// mmcv.ops.nms IoU on (x1, y1, x2, y2) boxes: inter / (area_a + area_b - inter), offset 0
+__device__ __forceinline__ float iou_xyxy(const float *a, const float *b) {
+  float w = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]), 0.f);
+  float h = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]), 0.f);
+  float inter = w * h;
+  float sa = (a[2] - a[0]) * (a[3] - a[1]);
+  float sb = (b[2] - b[0]) * (b[3] - b[1]);
+  return inter / (sa + sb - inter);
+}
+
+__global__ __launch_bounds__(64) void nms_mask_2d(const float *boxes, int n, float thresh,
+                                                  unsigned long long *mask) {
+  const int row_start = blockIdx.y, col_start = blockIdx.x;
+  if (col_start < row_start) return;
+  const int col_blocks = (n + 63) / 64;
+  const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+  __shared__ float bb[64 * 4];
+  int t = threadIdx.x;
+  if (t < col_size) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bb[t * 4 + j] = boxes[(size_t)(64 * col_start + t) * 4 + j];
+  }
+  __syncthreads();
+  if (t < row_size) {
+    const int cur = 64 * row_start + t;
+    float cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = boxes[(size_t)cur * 4 + j];
+    unsigned long long bits = 0;
+    int start = (row_start == col_start) ? t + 1 : 0;
+    for (int i = start; i < col_size; i++)
+      if (iou_xyxy(cb, bb + i * 4) > thresh) bits |= 1ULL << i;
+    mask[(size_t)cur * col_blocks + col_start] = bits;
+  }
+}
+
 // mask[r][c] bit i = iou(box_r, box_{64c+i}) > thresh; upper-triangular tiles only
 template <bool NORMAL>
 __global__ __launch_bounds__(64) void nms_mask(const float *boxes, const float2 *cs, int n,
@@ -351,4 +387,29 @@ extern "C" int dm_nms_normal(const float *boxes, int n, float thresh, int max_ke
                              size_t workspace_bytes, dm_stream_t stream) {
   return nms_launch(true, boxes, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes,
                     (hipStream_t)stream);
+}
+
+// 2-D axis-aligned NMS on (n, 4) xyxy boxes sorted by descending score — replaces
+// mmcv.ops.nms (mmcv-full 1.3.16) as called through batched_nms at
+// mmdet3d/models/ssl_modules/bbox_utils.py:97 and by the Faster R-CNN RPN / bbox head.
+extern "C" int dm_nms_2d(const float *boxes_xyxy, int n, float thresh, int max_keep,
+                         long long *keep, int *num_keep, void *workspace,
+                         size_t workspace_bytes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n < 0 || !num_keep) return DM_ERR_INVALID_ARG;
+  if (n == 0) {
+    DM_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), st));
+    return DM_OK;
+  }
+  if (n > 64 * 64 * 16) return DM_ERR_UNSUPPORTED;
+  if (!boxes_xyxy || !keep || !workspace) return DM_ERR_INVALID_ARG;
+  if (workspace_bytes < dm_nms_workspace_bytes(n)) return DM_ERR_WORKSPACE;
+  if (max_keep <= 0 || max_keep > n) max_keep = n;
+  int col_blocks = (n + 63) / 64;
+  unsigned long long *mask = (unsigned long long *)workspace;
+  nms_mask_2d<<<dim3(col_blocks, col_blocks), 64, 0, st>>>(boxes_xyxy, n, thresh, mask);
+  DM_CHECK_LAUNCH();
+  nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
 }

@@ -1,0 +1,220 @@
+"""SSL bbox utilities — mmdet3d/models/ssl_modules/bbox_utils.py (apply_3d_transformation_bboxes
+:110, filter_by_nms_2d :282, modified_multiclass_nms :14, bbox_3d_to_bbox_2d :372),
+mmdet3d/models/fusion_layers/coord_transform.py (extract_2d_info :91, bbox_2d_transform :121)
+and mmdet3d/models/ssl_modules/utils.py (mlvl_get / mlvl_set / mlvl_getattr)."""
+from functools import partial
+
+import torch
+
+from .. import _lib
+from .box3d import LiDARInstance3DBoxes
+
+
+# ------------------------------------------------------------------ dotted-key access
+def mlvl_get(d, key, default=None):
+    key_split = key.split('.', maxsplit=1)
+    if len(key_split) == 1:
+        return d.get(key, default)
+    cur, rest = key_split
+    return mlvl_get(d[cur], rest, default) if cur in d else default
+
+
+def mlvl_set(d, key, val):
+    key_split = key.split('.', maxsplit=1)
+    if len(key_split) == 1:
+        if key in d:
+            raise Exception('Key already exists')
+        d[key] = val
+        return
+    cur, rest = key_split
+    if cur not in d:
+        d[cur] = dict()
+    mlvl_set(d[cur], rest, val)
+
+
+def mlvl_getattr(c, key, default=None):
+    key_split = key.split('.', maxsplit=1)
+    if len(key_split) == 1:
+        return getattr(c, key)
+    cur, rest = key_split
+    return mlvl_getattr(getattr(c, cur), rest, default) if hasattr(c, cur) else default
+
+
+# ------------------------------------------------------------------ 3D augmentation replay
+def apply_3d_transformation_bboxes(bbox, img_meta, reverse=False):
+    """bbox_utils.py:110-200: replay (or undo) transformation_3d_flow in {T,S,R,HF,VF}.
+    The reverse rotation uses torch.inverse(M) in fp32 (:176), not M^T."""
+    assert isinstance(img_meta, dict)
+    dtype, device = bbox.tensor.dtype, bbox.tensor.device
+    rot = (torch.as_tensor(img_meta['pcd_rotation'], dtype=dtype, device=device)
+           if 'pcd_rotation' in img_meta else torch.eye(3, dtype=dtype, device=device))
+    scale = img_meta['pcd_scale_factor'] if 'pcd_scale_factor' in img_meta else 1.
+    trans = (torch.as_tensor(img_meta['pcd_trans'], dtype=dtype, device=device)
+             if 'pcd_trans' in img_meta else torch.zeros((3), dtype=dtype, device=device))
+    hflip = img_meta.get('pcd_horizontal_flip', False)
+    vflip = img_meta.get('pcd_vertical_flip', False)
+    flow = img_meta.get('transformation_3d_flow', [])
+    bbox = bbox.clone()
+    h_func = partial(bbox.flip, bev_direction='horizontal') if hflip else (lambda: None)
+    v_func = partial(bbox.flip, bev_direction='vertical') if vflip else (lambda: None)
+    if reverse:
+        scale_func = partial(bbox.scale, scale_factor=1.0 / scale)
+        translate_func = partial(bbox.translate, trans_vector=-trans)
+        rotate_func = partial(bbox.rotate, angle=rot.inverse())
+        flow = flow[::-1]
+    else:
+        scale_func = partial(bbox.scale, scale_factor=scale)
+        translate_func = partial(bbox.translate, trans_vector=trans)
+        rotate_func = partial(bbox.rotate, angle=rot)
+    mapping = {'T': translate_func, 'S': scale_func, 'R': rotate_func, 'HF': h_func, 'VF': v_func}
+    for op in flow:
+        assert op in mapping, 'This 3D data transformation op (%s) is not supported' % op
+        mapping[op]()
+    return bbox
+
+
+# ------------------------------------------------------------------ 3D -> 2D projection
+def bbox_3d_to_bbox_2d(bboxes_3d, lidar2img, img_shape):
+    """bbox_utils.py:372-441 (autograd preserving).  Returns xyxy (N,4) for ALL boxes and the
+    validity mask: >= 3 corners inside the image and mean (clamped) depth >= 0.5."""
+    assert isinstance(bboxes_3d, LiDARInstance3DBoxes)
+    lidar2img = torch.as_tensor(lidar2img, dtype=bboxes_3d.tensor.dtype,
+                                device=bboxes_3d.tensor.device)
+    assert lidar2img.shape == (4, 4)
+    n = len(bboxes_3d.tensor)
+    img_v, img_h = img_shape[0], img_shape[1]
+    if n == 0:
+        return (torch.empty((0, 4), dtype=bboxes_3d.tensor.dtype, device=bboxes_3d.tensor.device),
+                torch.empty((0,), dtype=torch.bool, device=bboxes_3d.tensor.device))
+    corners = bboxes_3d.corners.reshape(-1, 3)
+    hom = torch.cat([corners, corners.new_ones(size=(n * 8, 1))], dim=-1)
+    p = hom @ lidar2img.t()
+    depth = torch.clamp(p[:, 2], min=1e-5)     # clamp BEFORE the divide and the tests (:408)
+    x = p[:, 0] / depth
+    y = p[:, 1] / depth
+    valid = (x >= 0) & (x < img_h) & (y >= 0) & (y < img_v) & (depth > 0)
+    x, y, depth, valid = x.reshape(-1, 8), y.reshape(-1, 8), depth.reshape(-1, 8), valid.reshape(-1, 8)
+    final_valid = (valid.sum(dim=1) >= 3) & (depth.mean(dim=1) >= 0.5)
+    xmin = torch.clip(x.min(dim=1)[0], 0, img_h)
+    ymin = torch.clip(y.min(dim=1)[0], 0, img_v)
+    xmax = torch.clip(x.max(dim=1)[0], 0, img_h)
+    ymax = torch.clip(y.max(dim=1)[0], 0, img_v)
+    return torch.stack([xmin, ymin, xmax, ymax], dim=1), final_valid
+
+
+# ------------------------------------------------------------------ 2D augmentation replay
+def extract_2d_info(img_meta, tensor):
+    """coord_transform.py:91-118"""
+    img_h, img_w, _ = img_meta['img_shape']
+    ori_h, ori_w, _ = img_meta['ori_shape']
+    scale = (tensor.new_tensor(img_meta['scale_factor'][:2]) if 'scale_factor' in img_meta
+             else tensor.new_tensor([1.0, 1.0]))
+    flip = img_meta['flip'] if 'flip' in img_meta else False
+    crop = (tensor.new_tensor(img_meta['img_crop_offset']) if 'img_crop_offset' in img_meta
+            else tensor.new_tensor([0.0, 0.0]))
+    return img_h, img_w, ori_h, ori_w, scale, flip, crop
+
+
+def bbox_2d_transform(img_meta, bbox_2d, ori2new):
+    """coord_transform.py:121-175 (scale -> crop offset -> h-flip, or the reverse)."""
+    img_h, img_w, ori_h, ori_w, scale, flip, crop = extract_2d_info(img_meta, bbox_2d)
+    x1, y1, x2, y2 = bbox_2d[:, 0], bbox_2d[:, 1], bbox_2d[:, 2], bbox_2d[:, 3]
+    if ori2new:
+        x1, x2 = x1 * scale[0] + crop[0], x2 * scale[0] + crop[0]
+        y1, y2 = y1 * scale[1] + crop[1], y2 * scale[1] + crop[1]
+        if flip:
+            x1, x2 = img_w - x2, img_w - x1
+    else:
+        if flip:
+            x1, x2 = img_w - x2, img_w - x1
+        x1, x2 = (x1 - crop[0]) / scale[0], (x2 - crop[0]) / scale[0]
+        y1, y2 = (y1 - crop[1]) / scale[1], (y2 - crop[1]) / scale[1]
+    return torch.cat([torch.stack([x1, y1, x2, y2], dim=1), bbox_2d[:, 4:]], dim=1)
+
+
+# ------------------------------------------------------------------ 2D NMS
+def nms_2d(boxes, scores, iou_threshold, max_num=-1):
+    """mmcv.ops.nms on the device: -> (dets (k,5) sorted by score, keep indices (k,))."""
+    if boxes.shape[0] == 0:
+        return torch.cat([boxes, scores[:, None]], -1), boxes.new_zeros((0,), dtype=torch.long)
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    b = boxes[order].contiguous().float()
+    _lib.require_device(b)
+    n = b.shape[0]
+    L = _lib.lib()
+    keep = torch.empty((n,), dtype=torch.int64, device=b.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=b.device)
+    ws = _lib.workspace(L.dm_nms_workspace_bytes(n), b.device, 'nms')
+    _lib.check(L.dm_nms_2d(_lib.ptr(b), n, float(iou_threshold), int(max_num) if max_num > 0 else 0,
+                           _lib.ptr(keep), _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream()),
+               'dm_nms_2d')
+    k = int(num.item())
+    inds = order[keep[:k]]
+    return torch.cat([boxes[inds], scores[inds][:, None]], -1), inds
+
+
+def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+    """mmcv.ops.nms.batched_nms (mmcv-full 1.3.16): offset boxes by idx * (max_coord + 1) so
+    that classes never overlap, then plain NMS.  Extra keys of nms_cfg (e.g. max_num) ride
+    along ignored, as in the reference call (bbox_utils.py:326-334)."""
+    cfg = dict(nms_cfg)
+    thr = cfg.get('iou_threshold', cfg.get('iou_thr', 0.5))
+    if class_agnostic or boxes.shape[0] == 0:
+        boxes_for_nms = boxes
+    else:
+        max_coordinate = boxes.max()
+        offsets = idxs.to(boxes) * (max_coordinate + boxes.new_tensor(1))
+        boxes_for_nms = boxes + offsets[:, None]
+    dets, keep = nms_2d(boxes_for_nms, scores, thr)
+    return torch.cat([boxes[keep], dets[:, -1:]], -1), keep
+
+
+def modified_multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1):
+    """bbox_utils.py:14-108 with fixed_return_inds=True: -> (dets (k,5), labels (k), flat
+    (box x class) indices w.r.t. the tensors BEFORE the score threshold)."""
+    num_classes = multi_scores.size(1) - 1
+    if multi_bboxes.shape[1] > 4:
+        bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
+    else:
+        bboxes = multi_bboxes[:, None].expand(multi_scores.size(0), num_classes, 4)
+    scores = multi_scores[:, :-1]
+    labels = torch.arange(num_classes, dtype=torch.long, device=scores.device)
+    labels = labels.view(1, -1).expand_as(scores)
+    bboxes = bboxes.reshape(-1, 4)
+    scores = scores.reshape(-1)
+    labels = labels.reshape(-1)
+    valid_mask = scores > score_thr
+    inds = valid_mask.nonzero(as_tuple=False).squeeze(1)
+    bboxes, scores, labels = bboxes[inds], scores[inds], labels[inds]
+    if bboxes.numel() == 0:
+        return torch.cat([bboxes, scores[:, None]], -1), labels, inds
+    dets, keep = batched_nms(bboxes, scores, labels, nms_cfg)
+    if max_num > 0:
+        dets = dets[:max_num]
+        keep = keep[:max_num]
+    return dets, labels[keep], inds[keep]
+
+
+def filter_by_nms_2d(bbox_list, nms_cfg, use_sigmoid_cls, return_indices=False):
+    """bbox_utils.py:282-369: per-class 2D NMS keeping each survivor's full score vector."""
+    assert not return_indices
+    res = []
+    for bboxes, scores in bbox_list:
+        assert bboxes.shape[0] == scores.shape[0] and len(scores.shape) == 2
+        nms_pre = nms_cfg.get('nms_pre', -1)
+        if nms_pre > 0 and scores.shape[0] > nms_pre:
+            max_scores = scores.max(dim=1)[0] if use_sigmoid_cls else scores[:, :-1].max(dim=1)[0]
+            _, topk_inds = max_scores.topk(nms_pre)
+            bboxes, scores = bboxes[topk_inds, :], scores[topk_inds, :]
+        if use_sigmoid_cls:
+            scores_for_nms = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
+        else:
+            scores_for_nms = scores
+        cfg = {k: v for k, v in dict(nms_cfg).items() if k not in ('score_thr', 'nms_pre')}
+        score_thr = nms_cfg.get('score_thr', None)
+        dets, _, selected = modified_multiclass_nms(bboxes, scores_for_nms,
+                                                    score_thr if score_thr is not None else 0, cfg,
+                                                    nms_cfg.get('max_num', -1))
+        sel_box = selected.long() // (scores_for_nms.shape[1] - 1)
+        res.append((dets[:, :4], scores[sel_box]))
+    return res

@@ -1,0 +1,319 @@
+"""SSL teacher-student detector and the 2D+3D MMDetector wrapper —
+mmdet3d/models/detectors/ssl.py:20-380 and mmdetector.py:17-94.
+
+Teacher and student share one parameter LAYOUT in two flat, 16-byte aligned arenas, so the
+EMA of SSL._update_teacher (ssl.py:146-163: ~600 state-dict entries x 3 launches per
+iteration in the reference) is one dm_ema_update_f32 launch plus one dm_ema_update_i64
+launch for the integer buffers.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .. import _lib
+from .registry import DETECTORS, build_detector, build_ssl_module
+
+
+def add_prefix(inputs, prefix):
+    """mmseg.core.add_prefix"""
+    return {'%s.%s' % (prefix, k): v for k, v in inputs.items()}
+
+
+class _Arena(object):
+    """Re-homes every tensor of a state_dict in two flat buffers (fp32 / int64)."""
+
+    def __init__(self, module):
+        sd = module.state_dict(keep_vars=True)
+        self.keys = list(sd.keys())
+        f_items = [(k, v) for k, v in sd.items() if v.dtype == torch.float32]
+        i_items = [(k, v) for k, v in sd.items() if v.dtype == torch.int64]
+        other = [k for k, v in sd.items() if v.dtype not in (torch.float32, torch.int64)]
+        assert not other, 'unsupported state dtypes: %s' % other
+        self.f_keys = [k for k, _ in f_items]
+        self.i_keys = [k for k, _ in i_items]
+        dev = f_items[0][1].device if f_items else torch.device('cpu')
+        # each tensor starts on a 4-element boundary so the float4 kernel never straddles
+        self.f_sizes = [v.numel() for _, v in f_items]
+        pad = lambda n: (n + 3) // 4 * 4
+        self.flat_f = torch.zeros(sum(pad(n) for n in self.f_sizes), dtype=torch.float32, device=dev)
+        self.flat_i = torch.zeros(sum(v.numel() for _, v in i_items), dtype=torch.int64, device=dev)
+        off = 0
+        with torch.no_grad():
+            for (k, v), n in zip(f_items, self.f_sizes):
+                view = self.flat_f[off:off + n].view(v.shape)
+                view.copy_(v.data)
+                v.data = view
+                off += pad(n)
+            off = 0
+            for k, v in i_items:
+                n = v.numel()
+                view = self.flat_i[off:off + n].view(v.shape)
+                view.copy_(v.data)
+                v.data = view
+                off += n
+
+
+@DETECTORS.register_module()
+class MMDetector(nn.Module):
+    """mmdetector.py:17-94: holds detector_2d and detector_3d, used independently."""
+
+    def __init__(self, detector_2d, detector_3d, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        detector_2d = dict(detector_2d)
+        detector_3d = dict(detector_3d)
+        detector_2d['train_cfg'] = train_cfg['detector_2d'] if train_cfg is not None else None
+        detector_2d['test_cfg'] = test_cfg['detector_2d']
+        self.detector_2d = build_detector(detector_2d)
+        detector_3d['train_cfg'] = train_cfg['detector_3d'] if train_cfg is not None else None
+        detector_3d['test_cfg'] = test_cfg['detector_3d']
+        self.detector_3d = build_detector(detector_3d)
+        self._load_pretrained(pretrained)
+
+    def _load_pretrained(self, pretrained):
+        if pretrained is not None:
+            assert isinstance(pretrained, dict)
+            self.detector_2d.load_state_dict(
+                torch.load(pretrained['detector_2d'], map_location='cpu')['state_dict'])
+            self.detector_3d.load_state_dict(
+                torch.load(pretrained['detector_3d'], map_location='cpu')['state_dict'])
+
+    def simple_test(self, **kwargs):
+        do_2d = 'img' in kwargs
+        points = kwargs.pop('points')
+        if do_2d:
+            results_2d = self.detector_2d.simple_test(**kwargs)
+            kwargs.pop('img')
+        kwargs['points'] = points
+        results_3d = self.detector_3d.simple_test(**kwargs)
+        if do_2d:
+            return [dict(results_2d=r2, results_3d=r3) for r2, r3 in zip(results_2d, results_3d)]
+        return results_3d
+
+
+@DETECTORS.register_module()
+class SSL(nn.Module):
+
+    def __init__(self, model_cfg, ssl_cfg, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        if self.train_cfg is not None:
+            self.ema_params = self.train_cfg['ssl']['ema_params']
+            self.ema_decay = self.ema_params['ema_decay']
+            self.true_avg_rampup = self.ema_params.get('true_avg_rampup', False)
+            self.rampup_start_decay = self.ema_params.get('rampup_start_decay', 0.5)
+            self.use_student_bn_stats_for_teacher = self.ema_params.get(
+                'use_student_bn_stats_for_teacher', False)
+            self.ssl_weight_params = self.train_cfg['ssl']['weight_params']
+            self.ssl_weight = self.ssl_weight_params['weight']
+            self.ssl_weight_rampup_start_iter = self.ssl_weight_params.get(
+                'weight_rampup_start_iter', 0)
+            self.ssl_weight_rampup_num_iter = self.ssl_weight_params.get('weight_rampup_num_iter', 0)
+            self.set_teacher_eval = self.train_cfg['ssl'].get('set_teacher_eval', False)
+            self.epoch, self.iter = None, None   # filled in by ModelIterEpochHook
+        teacher_cfg = copy.deepcopy(dict(model_cfg))
+        teacher_cfg['train_cfg'] = train_cfg['teacher'] if train_cfg is not None else None
+        teacher_cfg['test_cfg'] = test_cfg['teacher']
+        teacher_cfg['pretrained'] = pretrained
+        self.teacher = build_detector(teacher_cfg)
+        for p in self.teacher.parameters():
+            p.requires_grad = False
+        student_cfg = copy.deepcopy(dict(model_cfg))
+        student_cfg['train_cfg'] = train_cfg['student'] if train_cfg is not None else None
+        student_cfg['test_cfg'] = test_cfg['student']
+        student_cfg['pretrained'] = pretrained
+        self.student = build_detector(student_cfg)
+        ssl_cfg = dict(ssl_cfg)
+        self.lab_ssl_modules, self.unlab_ssl_modules = [], []
+        for name, target in (('labeled', self.lab_ssl_modules), ('unlabeled', self.unlab_ssl_modules)):
+            if name in ssl_cfg:
+                lst = ssl_cfg[name] if isinstance(ssl_cfg[name], (list, tuple)) else [ssl_cfg[name]]
+                target.extend(build_ssl_module(c) for c in lst)
+        self._arenas = None
+
+    # ---- state-dict fan-out (ssl.py:102-127) ------------------------------------
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
+                              unexpected_keys, error_msgs):
+        loading_pretrained = not any('teacher' in k for k in state_dict.keys())
+        if loading_pretrained:
+            self.teacher.load_state_dict(state_dict)
+            self.student.load_state_dict(copy.deepcopy(state_dict))
+            for k in list(state_dict.keys()):
+                v = state_dict.pop(k)
+                state_dict['teacher.' + k] = v
+                state_dict['student.' + k] = copy.deepcopy(v)
+        else:
+            super()._load_from_state_dict(state_dict, prefix, local_metadata, strict,
+                                          missing_keys, unexpected_keys, error_msgs)
+
+    # ---- EMA ------------------------------------------------------------------------
+    def _get_curr_ema_decay(self):
+        """ssl.py:129-144"""
+        if self.ema_params.get('true_avg_rampup', False):
+            ema_start_iter = max(round(1 / (1 - self.rampup_start_decay)), 2)
+            return min(1 - 1 / (self.iter + ema_start_iter), self.ema_params['ema_decay'])
+        return self.ema_params['ema_decay']
+
+    def build_arenas(self):
+        """Call once the model sits on its device (and after any checkpoint load)."""
+        self._arenas = (_Arena(self.teacher), _Arena(self.student))
+        t, s = self._arenas
+        assert t.keys == s.keys, 'teacher / student state dicts differ'
+        return self._arenas
+
+    def _update_teacher(self):
+        """ssl.py:146-163: new_t = s * (1 - d) + t * d for EVERY state-dict entry (BN running
+        stats and integer buffers included)."""
+        d = float(self._get_curr_ema_decay())
+        if self._arenas is None:
+            self.build_arenas()
+        t, s = self._arenas
+        L = _lib.lib()
+        if t.flat_f.is_cuda:
+            _lib.check(L.dm_ema_update_f32(_lib.ptr(t.flat_f), _lib.ptr(s.flat_f), t.flat_f.numel(),
+                                           d, _lib.stream()), 'dm_ema_update_f32')
+            _lib.check(L.dm_ema_update_i64(_lib.ptr(t.flat_i), _lib.ptr(s.flat_i), t.flat_i.numel(),
+                                           d, _lib.stream()), 'dm_ema_update_i64')
+        else:
+            raise _lib.DetMatchHipError('EMA runs on the MI355X only')
+        if self.use_student_bn_stats_for_teacher:
+            tsd, ssd = self.teacher.state_dict(), self.student.state_dict()
+            for k in tsd:
+                if 'running' in k:
+                    tsd[k].copy_(ssd[k])
+
+    # ---- loss bookkeeping -------------------------------------------------------------
+    def _get_curr_ssl_weight(self):
+        """ssl.py:165-181"""
+        if self.ssl_weight_rampup_num_iter == 0:
+            return self.ssl_weight
+        if self.iter < self.ssl_weight_rampup_start_iter:
+            return 0.0
+        current = np.clip(self.iter - self.ssl_weight_rampup_start_iter, 0,
+                          self.ssl_weight_rampup_num_iter)
+        phase = 1.0 - current / self.ssl_weight_rampup_num_iter
+        return self.ssl_weight * np.exp(-5.0 * phase * phase)
+
+    def _collapse_losses(self, losses):
+        for name, value in list(losses.items()):
+            if isinstance(value, torch.Tensor):
+                losses[name] = value.mean()
+            elif isinstance(value, list):
+                losses[name] = sum(_l.mean() for _l in value)
+            else:
+                raise TypeError('%s is not a tensor or list of tensors' % name)
+        return losses
+
+    def _sum_update_losses(self, losses, new_losses):
+        losses = self._collapse_losses(losses)
+        new_losses = self._collapse_losses(new_losses)
+        for k in new_losses:
+            if k in losses:
+                losses[k] = losses[k] + new_losses[k]
+            else:
+                losses[k] = new_losses[k]
+        return losses
+
+    def _parse_losses(self, losses):
+        """mmdet BaseDetector._parse_losses: loss = sum of the entries whose key contains
+        'loss'.  The reference all-reduces every logged scalar separately (C2 in SURVEY §2.2);
+        here all of them travel in ONE packed all-reduce."""
+        log_vars = {}
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(_l.mean() for _l in value)
+            else:
+                raise TypeError('%s is not a tensor or list of tensors' % name)
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        keys = list(log_vars.keys())
+        packed = torch.stack([log_vars[k].detach().float() for k in keys])
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(packed)
+            packed = packed / dist.get_world_size()
+        # kept on the device: the logger calls .item() when (and if) it prints
+        return loss, {k: packed[i] for i, k in enumerate(keys)}
+
+    # ---- step ------------------------------------------------------------------------------
+    def train_step(self, data, optimizer=None):
+        """ssl.py:214-253"""
+        if self.set_teacher_eval:
+            self.teacher.eval()
+        losses = self(**data)
+        vis = losses.pop('vis', dict())
+        log_vars = losses.pop('log_vars', dict())
+        loss, log_vars_ = self._parse_losses(losses)
+        log_vars.update(log_vars_)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']), vis=vis)
+
+    def forward(self, return_loss=True, **kwargs):
+        if return_loss:
+            kwargs.pop('img_metas', None)
+            return self.forward_train(**kwargs)
+        return self.forward_test(**kwargs)
+
+    def forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
+        """ssl.py:255-350"""
+        if isinstance(unlab_stu, list):
+            unlab_stu = self._collate(unlab_stu)
+            unlab_tea = self._collate(unlab_tea)
+        assert lab_stu.get('gt_bboxes_ignore', None) is None and \
+            lab_tea.get('gt_bboxes_ignore', None) is None
+        lab_dict = dict(stu=lab_stu, tea=lab_tea, sup_losses=dict(), ssl_losses=dict())
+        for m in self.lab_ssl_modules:
+            lab_dict = m.forward(self, lab_dict)
+        unlab_dict = dict(stu=unlab_stu, tea=unlab_tea, ssl_losses=dict())
+        for m in self.unlab_ssl_modules:
+            unlab_dict = m.forward(self, unlab_dict)
+        losses = dict()
+        losses.update(add_prefix(lab_dict['sup_losses'], 'sup'))
+        ssl_losses = dict()
+        ssl_losses.update(add_prefix(lab_dict['ssl_losses'], 'lab'))
+        ssl_losses.update(add_prefix(unlab_dict['ssl_losses'], 'unlab'))
+        vis_dict, log_vars_dict = dict(), dict()
+        for tag, d in (('lab', lab_dict), ('unlab', unlab_dict)):
+            vis_dict.update({'%s/%s' % (tag, k): v for k, v in d.get('vis', {}).items()})
+            log_vars_dict.update({'%s/%s' % (tag, k): v for k, v in d.get('log_vars', {}).items()})
+        curr_ssl_weight = self._get_curr_ssl_weight()
+        ref = list(losses.values())[0] if len(losses) else list(ssl_losses.values())[0]
+        losses['ssl.weight'] = ref.new_tensor(curr_ssl_weight)
+        ssl_losses = self._collapse_losses(ssl_losses)
+        for k in ssl_losses.keys():
+            if '.metrics' not in k and '.acc' not in k:
+                ssl_losses[k] = ssl_losses[k] * curr_ssl_weight
+        losses.update(add_prefix(ssl_losses, 'ssl'))
+        losses['vis'] = vis_dict
+        losses['log_vars'] = log_vars_dict
+        losses['ssl.ema_decay'] = ref.new_tensor(self._get_curr_ema_decay())
+        # the EMA runs INSIDE forward_train, before this iteration's backward / step
+        # (ssl.py:348): teacher_t = d teacher_{t-1} + (1-d) student_{t-1, post-step}
+        with torch.no_grad():
+            self._update_teacher()
+        return losses
+
+    @staticmethod
+    def _collate(batches):
+        out = dict()
+        for k in batches[0].keys():
+            out[k] = [sample for batch in batches for sample in batch[k]]
+            if k in ['img']:
+                out[k] = torch.stack(out[k], dim=0)
+        return out
+
+    def forward_test(self, **kwargs):
+        for name in ['img', 'points', 'img_metas']:
+            if name in kwargs:
+                assert isinstance(kwargs[name], list)
+                kwargs[name] = kwargs[name][0]
+        return self.simple_test(**kwargs)
+
+    def simple_test(self, **kwargs):
+        """ssl.py:361-371"""
+        teacher_res = self.teacher.simple_test(**dict(kwargs))
+        student_res = self.student.simple_test(**dict(kwargs))
+        return [dict(teacher=t, student=s) for t, s in zip(teacher_res, student_res)]

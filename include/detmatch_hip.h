@@ -210,6 +210,30 @@ int dm_nms(const float *boxes, int n, float thresh, int max_keep, long long *kee
 int dm_nms_normal(const float *boxes, int n, float thresh, int max_keep, long long *keep,
                   int *num_keep, void *workspace, size_t workspace_bytes, dm_stream_t stream);
 
+/* 2-D axis-aligned NMS on (n,4) xyxy boxes sorted by descending score: IoU =
+ * inter / (area_a + area_b - inter), suppress when IoU > thresh.  Replaces mmcv.ops.nms
+ * (mmcv-full 1.3.16, un-vendored) as used through batched_nms at
+ * mmdet3d/models/ssl_modules/bbox_utils.py:97 and inside the 2D detector. */
+int dm_nms_2d(const float *boxes_xyxy, int n, float thresh, int max_keep, long long *keep,
+              int *num_keep, void *workspace, size_t workspace_bytes, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* H. Teacher-student support: fused EMA, host LAP                            */
+/* ------------------------------------------------------------------------ */
+/* Replaces SSL._update_teacher (mmdet3d/models/detectors/ssl.py:146-163) over flat,
+ * identically laid-out, 16-byte aligned arenas: t = s * f32(1-d) + t * f32(d). */
+int dm_ema_update_f32(float *teacher, const float *student, size_t n, double decay,
+                      dm_stream_t stream);
+/* integer buffers: fp32 math, truncated back (Tensor.copy_ float -> long) */
+int dm_ema_update_i64(long long *teacher, const long long *student, size_t n, double decay,
+                      dm_stream_t stream);
+/* Replaces scipy.optimize.linear_sum_assignment at
+ * mmdet3d/core/bbox/assigners/modified_hungarian_assigner.py:132.  HOST function: cost
+ * (n_rows, n_cols) row-major host floats -> min(n_rows, n_cols) pairs sorted by row.
+ * Returns the number of pairs, -1 on NaN / infeasible input. */
+int dm_lap_host(const float *cost_host, int n_rows, int n_cols, int *row_ind_host,
+                int *col_ind_host);
+
 /* ------------------------------------------------------------------------ */
 /* D. Stacked PointNet++ operators, points-in-boxes                           */
 /* ------------------------------------------------------------------------ */

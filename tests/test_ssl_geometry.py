@@ -1,0 +1,82 @@
+"""Host-side SSL geometry vs goldens produced by the reference's own files
+(tests/golden/gen_ssl_geometry_golden.py): LiDARInstance3DBoxes, 3D aug replay / reverse,
+3D->2D projection + validity mask, 2D scale/flip transform.  fp32, tolerance 1e-5 abs."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+
+G = np.load(os.path.join(GOLDEN, 'ssl_geometry.npz'))
+TOL = dict(rtol=1e-5, atol=1e-4)
+
+
+def test_box_structure():
+    from detmatch_amd.mm3d.box3d import LiDARInstance3DBoxes
+    b = LiDARInstance3DBoxes(torch.from_numpy(G['boxes']))
+    np.testing.assert_allclose(b.corners.numpy(), G['corners'], **TOL)
+    np.testing.assert_allclose(b.gravity_center.numpy(), G['gravity_center'], **TOL)
+    g = LiDARInstance3DBoxes(torch.from_numpy(G['boxes']), origin=(0.5, 0.5, 0.5))
+    np.testing.assert_allclose(g.tensor.numpy(), G['from_gravity_origin'], **TOL)
+    assert len(b[2:5]) == 3 and len(b[3]) == 1 and len(b[torch.tensor([True] * 24)]) == 24
+
+
+def test_projection_and_validity():
+    from detmatch_amd.mm3d.bbox_utils import bbox_3d_to_bbox_2d
+    from detmatch_amd.mm3d.box3d import LiDARInstance3DBoxes
+    b = LiDARInstance3DBoxes(torch.from_numpy(G['boxes']))
+    xyxy, valid = bbox_3d_to_bbox_2d(b, G['lidar2img'], (375, 1242, 3))
+    assert np.array_equal(valid.numpy(), G['proj_valid'])          # mask: exact
+    np.testing.assert_allclose(xyxy.numpy(), G['proj_xyxy'], rtol=1e-5, atol=2e-3)
+    e, v = bbox_3d_to_bbox_2d(LiDARInstance3DBoxes(torch.zeros((0, 7))), G['lidar2img'], (375, 1242, 3))
+    assert e.shape == (0, 4) and v.shape == (0,)
+    # autograd flows through the projection (Bboxes3DTo2D is differentiable)
+    t = torch.from_numpy(G['boxes']).clone().requires_grad_(True)
+    xy, _ = bbox_3d_to_bbox_2d(LiDARInstance3DBoxes(t) if False else _wrap(t), G['lidar2img'],
+                               (375, 1242, 3))
+    xy.sum().backward()
+    assert t.grad is not None and torch.isfinite(t.grad).all()
+
+
+def _wrap(t):
+    from detmatch_amd.mm3d.box3d import LiDARInstance3DBoxes
+    b = LiDARInstance3DBoxes(t.detach())
+    b.tensor = t
+    return b
+
+
+def test_3d_augmentation_replay():
+    from detmatch_amd.mm3d.bbox_utils import apply_3d_transformation_bboxes
+    from detmatch_amd.mm3d.box3d import LiDARInstance3DBoxes
+    meta = dict(pcd_rotation=torch.from_numpy(G['meta_rotation']),
+                pcd_scale_factor=float(G['meta_scale']), pcd_trans=G['meta_trans'],
+                pcd_horizontal_flip=True, pcd_vertical_flip=False,
+                transformation_3d_flow=['HF', 'R', 'S', 'T'])
+    b = LiDARInstance3DBoxes(torch.from_numpy(G['boxes']))
+    fwd = apply_3d_transformation_bboxes(b, meta, reverse=False)
+    np.testing.assert_allclose(fwd.tensor.numpy(), G['aug_forward'], **TOL)
+    back = apply_3d_transformation_bboxes(fwd, meta, reverse=True)
+    np.testing.assert_allclose(back.tensor.numpy(), G['aug_roundtrip'], **TOL)
+    np.testing.assert_allclose(b.tensor.numpy(), G['boxes'])       # input untouched
+
+
+def test_2d_transform():
+    from detmatch_amd.mm3d.bbox_utils import bbox_2d_transform
+    meta = dict(img_shape=(384, 1272, 3), ori_shape=(375, 1242, 3), scale_factor=G['meta2_scale'],
+                flip=True)
+    o2n = bbox_2d_transform(meta, torch.from_numpy(G['boxes2d']), True)
+    np.testing.assert_allclose(o2n.numpy(), G['boxes2d_ori2new'], **TOL)
+    back = bbox_2d_transform(meta, o2n, False)
+    np.testing.assert_allclose(back.numpy(), G['boxes2d_back'], **TOL)
+    np.testing.assert_allclose(back.numpy(), G['boxes2d'], rtol=1e-4, atol=1e-2)
+
+
+def test_mlvl_helpers():
+    from detmatch_amd.mm3d.bbox_utils import mlvl_get, mlvl_set
+    import pytest
+    d = {}
+    mlvl_set(d, 'a.b.c', 1)
+    assert mlvl_get(d, 'a.b.c') == 1 and mlvl_get(d, 'a.x.c', 5) == 5
+    with pytest.raises(Exception):
+        mlvl_set(d, 'a.b.c', 2)
