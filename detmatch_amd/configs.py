@@ -90,3 +90,205 @@ def pvrcnn_kitti_model(class_names=CLASS_NAMES, point_cloud_range=POINT_CLOUD_RA
                                  NMS_CONFIG=dict(MULTI_CLASSES_NMS=False, NMS_TYPE='nms_gpu',
                                                  NMS_THRESH=0.1, NMS_PRE_MAXSIZE=4096,
                                                  NMS_POST_MAXSIZE=500))))
+
+
+# ---------------------------------------------------------------------------------------------
+# configs/detmatch/001/detmatch/split_0.py as builders (values only)
+# ---------------------------------------------------------------------------------------------
+def frcnn_kitti_model(num_classes=3):
+    """detector_2d of split_0.py:39-99."""
+    coder = lambda stds: dict(type='DeltaXYWHBBoxCoder', target_means=[0.0] * 4, target_stds=stds)
+    return dict(
+        type='FasterRCNN',
+        backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                      norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='caffe',
+                      init_cfg=dict(type='Pretrained',
+                                    checkpoint='open-mmlab://detectron2/resnet50_caffe')),
+        neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5),
+        rpn_head=dict(type='RPNHead', in_channels=256, feat_channels=256,
+                      anchor_generator=dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0],
+                                            strides=[4, 8, 16, 32, 64]),
+                      bbox_coder=coder([1.0, 1.0, 1.0, 1.0]),
+                      loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                      loss_bbox=dict(type='L1Loss', loss_weight=1.0)),
+        roi_head=dict(type='StandardRoIHead',
+                      bbox_roi_extractor=dict(type='SingleRoIExtractor',
+                                              roi_layer=dict(type='RoIAlign', output_size=7,
+                                                             sampling_ratio=0),
+                                              out_channels=256, featmap_strides=[4, 8, 16, 32]),
+                      bbox_head=dict(type='Shared2FCBBoxHead', in_channels=256, fc_out_channels=1024,
+                                     roi_feat_size=7, num_classes=num_classes,
+                                     bbox_coder=coder([0.1, 0.1, 0.2, 0.2]), reg_class_agnostic=False,
+                                     loss_cls=dict(type='FocalLoss', use_sigmoid=True, loss_weight=1.0,
+                                                   gamma=2.0, alpha=0.5, reduction='mean'),
+                                     loss_bbox=dict(type='L1Loss', loss_weight=1.0))))
+
+
+def _max_iou(pos, neg, min_pos, low_quality=None, nearest3d=False):
+    d = dict(type='MaxIoUAssigner', pos_iou_thr=pos, neg_iou_thr=neg, min_pos_iou=min_pos,
+             ignore_iof_thr=-1)
+    if low_quality is not None:
+        d['match_low_quality'] = low_quality
+    if nearest3d:
+        d['iou_calculator'] = dict(type='BboxOverlapsNearest3D')
+    return d
+
+
+def frcnn_train_cfg():
+    """split_0.py:440-478 (student.detector_2d)."""
+    sampler = lambda num, frac, add_gt: dict(type='RandomSampler', num=num, pos_fraction=frac,
+                                             neg_pos_ub=-1, add_gt_as_proposals=add_gt)
+    return dict(
+        rpn=dict(assigner=_max_iou(0.7, 0.3, 0.3, True), sampler=sampler(256, 0.5, False),
+                 allowed_border=-1, pos_weight=-1, debug=False),
+        rpn_proposal=dict(nms_pre=2000, max_per_img=1000, nms=dict(type='nms', iou_threshold=0.7),
+                          min_bbox_size=0),
+        rcnn=dict(assigner=_max_iou(0.5, 0.5, 0.5, False), sampler=sampler(512, 0.25, True),
+                  pos_weight=-1, debug=False))
+
+
+def frcnn_test_cfg():
+    """split_0.py:507-529"""
+    return dict(rpn=dict(nms_pre=1000, max_per_img=1000, nms=dict(type='nms', iou_threshold=0.7),
+                         min_bbox_size=0),
+                rcnn=dict(score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100))
+
+
+def _hung_assigner():
+    return dict(type='ModHungarianAssigner',
+                cls_cost=dict(type='DoubleSidedFocalLossCost', weight=2.0),
+                reg_cost=dict(type='BBoxL1Cost', weight=5.0),
+                iou_cost=dict(type='IoUCost', iou_mode='giou', weight=2.0))
+
+
+def _xf(kind, reverse, metas, src, dst):
+    return dict(type='BboxesTransform_%s' % kind, reverse=reverse, img_metas=metas, in_bboxes_key=src,
+                out_bboxes_key=dst)
+
+
+def detmatch_ssl_cfg(class_names=CLASS_NAMES, with_vis=True):
+    """ssl_cfg of split_0.py:200-437: the labeled chain (2 modules) and the unlabeled chain."""
+    nms2d = lambda thr: dict(score_thr=thr, nms_pre=-1, max_num=100, iou_thr=0.5)
+    T3, T2 = 'tea.3d_bboxes_nms', 'tea.2d_bboxes_nms'
+    unl = [
+        dict(type='Opd_SimpleTest_3D', ssl_obj_attr='teacher.detector_3d', batch_dict_key='tea',
+             out_bboxes_key='3d_bboxes_nms'),
+        _xf('3D', True, 'tea.img_metas', T3, T3 + '_no_aug'),
+        _xf('3D', False, 'stu.img_metas', T3 + '_no_aug', T3 + '_stu_aug'),
+        dict(type='MaxScoreFilter', cls_includes_bg_pred=False, score_thr=0.1,
+             in_bboxes_key=T3 + '_no_aug', out_bboxes_key=T3 + '_no_aug_sc_filt'),
+        dict(type='SimpleTest_2D', ssl_obj_attr='teacher.detector_2d', batch_dict_key='tea',
+             out_bboxes_key='2d_bboxes'),
+        dict(type='BboxesNMS_2D', nms_cfg=nms2d(0.05), cls_includes_bg_pred=True, batch_dict_key='tea',
+             in_bboxes_key='2d_bboxes', out_bboxes_key='2d_bboxes_nms'),
+        _xf('2D', True, 'tea.img_metas', T2, T2 + '_no_aug'),
+        dict(type='MaxScoreFilter', cls_includes_bg_pred=True, score_thr=0.1,
+             in_bboxes_key=T2 + '_no_aug', out_bboxes_key=T2 + '_no_aug_sc_filt'),
+        dict(type='FusionHungarianMatching', assigner_cfg=_hung_assigner(), cost_thr=-1.5,
+             img_metas='stu.img_metas', cls_includes_bg_pred_3d=False, cls_includes_bg_pred_2d=True,
+             in_bboxes_3d_key=T3 + '_no_aug_sc_filt', in_bboxes_2d_key=T2 + '_no_aug_sc_filt',
+             out_bboxes_3d_key=T3 + '_no_aug_hung', out_bboxes_2d_key=T2 + '_no_aug_hung'),
+        _xf('3D', False, 'stu.img_metas', T3 + '_no_aug_hung', T3 + '_stu_aug_hung'),
+        _xf('2D', False, 'stu.img_metas', T2 + '_no_aug_hung', T2 + '_stu_aug_hung'),
+        dict(type='DetachBboxes', in_bboxes_key=T3 + '_stu_aug_hung', out_bboxes_key=T3 + '_stu_aug_hung_dtch'),
+        dict(type='DetachBboxes', in_bboxes_key=T2 + '_stu_aug_hung', out_bboxes_key=T2 + '_stu_aug_hung_dtch'),
+        dict(type='Opd_HardPseudoLabel_3D', score_thr=0.1, ssl_obj_attr='student.detector_3d',
+             target_bboxes_key=T3 + '_stu_aug_hung_dtch', target_batch_dict_key='stu',
+             out_bboxes_key='3d_bboxes_nms', no_nms=False),
+        dict(type='HardPseudoLabel_2D', score_thr=0.1, cls_includes_bg_pred=True,
+             loss_detach_keys=['loss_rpn_bbox', 'loss_bbox'], ssl_obj_attr='student.detector_2d',
+             target_bboxes_key=T2 + '_stu_aug_hung_dtch', target_img_key='stu.img',
+             target_img_metas_key='stu.img_metas', name='hard_pseudo_2d', weight=4),
+        dict(type='Bboxes3DTo2D', img_metas='stu.img_metas', in_bboxes_key='stu.3d_bboxes_nms',
+             out_bboxes_key='stu.3d_bboxes_nms_2d_proj'),
+        dict(type='BboxesNMS_2D', nms_cfg=nms2d(0.1), cls_includes_bg_pred=False, batch_dict_key='stu',
+             in_bboxes_key='3d_bboxes_nms_2d_proj', out_bboxes_key='3d_bboxes_nms_2d_proj_2d_nms'),
+        dict(type='DetachBboxes', in_bboxes_key=T2 + '_no_aug_hung', out_bboxes_key=T2 + '_no_aug_hung_dtch'),
+        dict(type='FusionHungarianMatching', assigner_cfg=_hung_assigner(), cost_thr=-1.5,
+             img_metas='stu.img_metas', cls_includes_bg_pred_3d=False, cls_includes_bg_pred_2d=True,
+             in_bboxes_3d_key='stu.3d_bboxes_nms_2d_proj_2d_nms',
+             in_bboxes_2d_key=T2 + '_no_aug_hung_dtch',
+             out_bboxes_3d_key='stu.3d_bboxes_nms_2d_proj_2d_nms_hung',
+             out_bboxes_2d_key=T2 + '_no_aug_hung_dtch_hung', project_3d_to_2d=False),
+        _xf('2D', False, 'stu.img_metas', 'stu.3d_bboxes_nms_2d_proj_2d_nms_hung',
+            'stu.3d_bboxes_nms_2d_proj_2d_nms_hung_stu_aug'),
+        _xf('2D', False, 'stu.img_metas', T2 + '_no_aug_hung_dtch_hung',
+            T2 + '_no_aug_hung_dtch_hung_stu_aug'),
+        dict(type='HungarianConsistency',
+             loss_cls_cfg=dict(type='FocalLoss', reduction='mean', loss_weight=1.0),
+             loss_iou_cfg=dict(type='GIoULoss', reduction='mean', loss_weight=1.0),
+             loss_l1_cfg=dict(type='L1Loss', reduction='mean', loss_weight=1.0),
+             loss_weights_cfg=dict(cls_loss=2, l1_loss=20, iou_loss=2),
+             in_bboxes_key='stu.3d_bboxes_nms_2d_proj_2d_nms_hung_stu_aug',
+             target_bboxes_key=T2 + '_no_aug_hung_dtch_hung_stu_aug',
+             cls_includes_bg_pred_in=False, cls_includes_bg_pred_target=True,
+             target_img_metas_key='stu.img_metas', name='2D_to_3D_hung'),
+        dict(type='NumPreds', bboxes_key=T3 + '_stu_aug_hung_dtch', out_name='num_tea_hung'),
+        dict(type='NumPreds', bboxes_key=T2 + '_no_aug_hung_dtch_hung', out_name='2D_to_3D_hung'),
+    ]
+    if with_vis:
+        unl.append(dict(type='Vis3D', vis_idxs='data/kitti/ssl_splits/kitti_infos_train_unlab_0.01_0.pkl',
+                        vis_idxs_interval=50, batch_dict_key='stu', stu_bboxes_key='stu.3d_bboxes_nms',
+                        tea_bboxes_key=T3 + '_stu_aug_hung_dtch', out_name_prefix='tea',
+                        class_names=class_names))
+    lab = [dict(type='Opd_Supervised_3D', ssl_obj_attr='student.detector_3d', batch_dict_key='stu'),
+           dict(type='TwoStageSupervised_2D', loss_detach_keys=[], ssl_obj_attr='student.detector_2d',
+                batch_dict_key='stu')]
+    return dict(labeled=lab, unlabeled=unl)
+
+
+def confthr_pvrcnn_ssl_cfg():
+    """ssl_cfg of configs/detmatch/001/confthr_pvrcnn/split_0.py: 3D-only confidence thresholding."""
+    T3 = 'tea.3d_bboxes_nms'
+    return dict(
+        labeled=[dict(type='Opd_Supervised_3D', ssl_obj_attr='student.detector_3d', batch_dict_key='stu')],
+        unlabeled=[
+            dict(type='Opd_SimpleTest_3D', ssl_obj_attr='teacher.detector_3d', batch_dict_key='tea',
+                 out_bboxes_key='3d_bboxes_nms'),
+            _xf('3D', True, 'tea.img_metas', T3, T3 + '_no_aug'),
+            _xf('3D', False, 'stu.img_metas', T3 + '_no_aug', T3 + '_stu_aug'),
+            dict(type='Opd_HardPseudoLabel_3D', score_thr=0.3, ssl_obj_attr='student.detector_3d',
+                 target_bboxes_key=T3 + '_stu_aug', target_batch_dict_key='stu'),
+            dict(type='NumPreds', bboxes_key=T3 + '_stu_aug', out_name='tea')])
+
+
+def _pcdet_3d_train_cfg():
+    """train_cfg.student.detector_3d of split_0.py:480-504 (mm3d-style; unused by OpenPCDetDetector)."""
+    n3 = lambda pos, neg: _max_iou(pos, neg, neg, nearest3d=True)
+    return dict(assigner=[n3(0.35, 0.2), n3(0.35, 0.2), n3(0.6, 0.45)], allowed_border=0, pos_weight=-1,
+                debug=False)
+
+
+def detmatch_kitti_model(ssl_cfg=None, pretrained=None):
+    """model = dict(type='SSL', ...) of configs/detmatch/001/detmatch/split_0.py:34-531."""
+    det3d = pvrcnn_kitti_model()
+    test = dict(detector_2d=frcnn_test_cfg(), detector_3d=dict())
+    import copy
+    return dict(
+        type='SSL', pretrained=pretrained,
+        model_cfg=dict(type='MMDetector', detector_2d=frcnn_kitti_model(), detector_3d=det3d),
+        ssl_cfg=ssl_cfg if ssl_cfg is not None else detmatch_ssl_cfg(),
+        train_cfg=dict(
+            ssl=dict(ema_params=dict(ema_decay=0.999, true_avg_rampup=True, rampup_start_decay=0.99),
+                     weight_params=dict(weight=1), set_teacher_eval=True),
+            teacher=None,
+            student=dict(detector_2d=frcnn_train_cfg(), detector_3d=_pcdet_3d_train_cfg())),
+        test_cfg=dict(teacher=copy.deepcopy(test), student=copy.deepcopy(test)))
+
+
+def detmatch_schedule(batch_size=4, num_unlabeled_samples=1, max_iters=5000):
+    """optimizer / optimizer_config / lr_config / runner / custom_hooks of split_0.py:827-868."""
+    lr_3d = 0.001 / 2 * batch_size * (1 + num_unlabeled_samples) * 10
+    lr_2d = 0.02 / 2 * batch_size * (1 + num_unlabeled_samples)
+    return dict(
+        optimizer={'constructor': 'HybridOptimizerConstructor',
+                   'student.detector_3d': dict(type='AdamW', lr=lr_3d, betas=(0.95, 0.99),
+                                               weight_decay=0.01, step_interval=1),
+                   'student.detector_2d': dict(type='SGD', lr=lr_2d, momentum=0.9, weight_decay=0.0001,
+                                               step_interval=1),
+                   'teacher': dict(type='SGD', lr=1e-9, momentum=0.9, weight_decay=0.0001,
+                                   step_interval=1)},
+        optimizer_config=dict(grad_clip=dict(max_norm=10, norm_type=2)),
+        lr_config=dict(policy='step', warmup='linear', warmup_iters=500, warmup_ratio=0.001, step=[]),
+        runner=dict(type='IterBasedSSLRunner', max_iters=max_iters),
+        custom_hooks=[dict(type='ModelIterEpochHook'), dict(type='WandbVisHook')])

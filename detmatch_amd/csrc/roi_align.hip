@@ -1,0 +1,232 @@
+// RoIAlign (avg pool, aligned / legacy, fixed or adaptive sampling grid) over an FPN pyramid.
+//
+// Replaces mmcv.ops.RoIAlign (mmcv-full 1.3.16, un-vendored; restated from its published
+// algorithm == Detectron2 ROIAlign) as used by SingleRoIExtractor in
+// configs/detmatch/001/detmatch/split_0.py:76-80 and processors_2d.py:52-54.  mmcv issues one
+// launch per pyramid level on a boolean-masked RoI subset (nonzero() -> host sync, 4 launches
+// + index_put per call); here every RoI carries its level and ONE launch serves the pyramid,
+// writing rows in RoI order.
+//
+// Work split: one workgroup per RoI.  The per-RoI sampling geometry (<= 7x7 bins x gh x gw
+// samples: 4 corner offsets + 4 bilinear weights) depends only on the RoI, not on the channel,
+// so it is computed once into LDS and reused by all C channels; the channel loop then only does
+// loads + FMAs.  HBM-bound: algorithmic bytes = R*C*49*4 (out) + the touched feature pixels.
+#include <hip/hip_runtime.h>
+
+#include "../../include/detmatch_hip.h"
+#include "dm_common.h"
+
+namespace {
+
+constexpr int kMaxLevels = 8;
+
+struct Pyramid {
+  const float *feat[kMaxLevels];
+  float *grad[kMaxLevels];
+  int h[kMaxLevels], w[kMaxLevels];
+  float scale[kMaxLevels];
+};
+
+struct RoiGeom {
+  float start_w, start_h, bin_w, bin_h;
+  int gw, gh, level, batch;
+};
+
+__device__ inline RoiGeom roi_geom(const float *roi, int level, float scale, int ph, int pw,
+                                   int sampling_ratio, int aligned) {
+  RoiGeom g;
+  g.level = level;
+  g.batch = (int)roi[0];
+  const float off = aligned ? 0.5f : 0.0f;
+  g.start_w = roi[1] * scale - off;
+  g.start_h = roi[2] * scale - off;
+  const float end_w = roi[3] * scale - off;
+  const float end_h = roi[4] * scale - off;
+  float rw = end_w - g.start_w, rh = end_h - g.start_h;
+  if (!aligned) {  // legacy: force >= 1x1
+    rw = fmaxf(rw, 1.0f);
+    rh = fmaxf(rh, 1.0f);
+  }
+  g.bin_h = rh / (float)ph;
+  g.bin_w = rw / (float)pw;
+  g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph);
+  g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw);
+  return g;
+}
+
+// 1-D bilinear tap: position -> (low index, high index, low weight, high weight), valid flag
+__device__ inline bool tap(float p, int size, int &lo, int &hi, float &wl, float &wh) {
+  if (p < -1.0f || p > (float)size) return false;
+  if (p <= 0.0f) p = 0.0f;
+  lo = (int)p;
+  if (lo >= size - 1) {
+    hi = lo = size - 1;
+    p = (float)lo;
+  } else {
+    hi = lo + 1;
+  }
+  const float l = p - (float)lo;
+  wl = 1.0f - l;
+  wh = l;
+  return true;
+}
+
+// Each RoI: y taps for ph*gh sample rows, x taps for pw*gw sample columns (separable).
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void roi_align_kernel(Pyramid pyr, const float *__restrict__ rois,
+                                                        const int *__restrict__ levels, int C,
+                                                        int ph, int pw, int sampling_ratio,
+                                                        int aligned, int gmax,
+                                                        float *__restrict__ out,
+                                                        const float *__restrict__ gout) {
+  extern __shared__ unsigned char smem[];
+  const int r = blockIdx.x;
+  const int level = levels ? levels[r] : 0;
+  const int H = pyr.h[level], W = pyr.w[level];
+  const RoiGeom g = roi_geom(rois + (size_t)r * 5, level, pyr.scale[level], ph, pw, sampling_ratio,
+                             aligned);
+  const float inv_count = 1.0f / (float)max(g.gh * g.gw, 1);
+  const int bins = ph * pw;
+  const size_t plane = (size_t)H * W;
+  const float *fbase = BACKWARD ? nullptr : pyr.feat[level] + (size_t)g.batch * C * plane;
+  float *gbase = BACKWARD ? pyr.grad[level] + (size_t)g.batch * C * plane : nullptr;
+  if (g.gh > gmax || g.gw > gmax) {
+    // RoI far larger than its pyramid level was sized for: taps computed on the fly (rare)
+    for (int o = threadIdx.x; o < C * bins; o += blockDim.x) {
+      const int c = o / bins, b = o % bins, by = b / pw, bx = b % pw;
+      const size_t oidx = ((size_t)r * C + c) * bins + b;
+      const float gv = BACKWARD ? gout[oidx] * inv_count : 0.0f;
+      float acc = 0.0f;
+      for (int sy = 0; sy < g.gh; ++sy) {
+        const float y = g.start_h + (float)by * g.bin_h + ((float)sy + 0.5f) * g.bin_h / (float)g.gh;
+        int yl, yh;
+        float wyl, wyh;
+        if (!tap(y, H, yl, yh, wyl, wyh)) continue;
+        for (int sx = 0; sx < g.gw; ++sx) {
+          const float x = g.start_w + (float)bx * g.bin_w + ((float)sx + 0.5f) * g.bin_w / (float)g.gw;
+          int xl, xh;
+          float wxl, wxh;
+          if (!tap(x, W, xl, xh, wxl, wxh)) continue;
+          if (BACKWARD) {
+            float *gp = gbase + (size_t)c * plane;
+            unsafeAtomicAdd(gp + (size_t)yl * W + xl, gv * (wyl * wxl));
+            unsafeAtomicAdd(gp + (size_t)yl * W + xh, gv * (wyl * wxh));
+            unsafeAtomicAdd(gp + (size_t)yh * W + xl, gv * (wyh * wxl));
+            unsafeAtomicAdd(gp + (size_t)yh * W + xh, gv * (wyh * wxh));
+          } else {
+            const float *fp = fbase + (size_t)c * plane;
+            acc += (wyl * wxl) * fp[(size_t)yl * W + xl] + (wyl * wxh) * fp[(size_t)yl * W + xh] +
+                   (wyh * wxl) * fp[(size_t)yh * W + xl] + (wyh * wxh) * fp[(size_t)yh * W + xh];
+          }
+        }
+      }
+      if (!BACKWARD) out[oidx] = acc * inv_count;
+    }
+    return;
+  }
+  const int ny = ph * g.gh, nx = pw * g.gw;
+  // LDS layout: ylo[ny] yhi[ny] xlo[nx] xhi[nx] (int) | ywl[ny] ywh[ny] xwl[nx] xwh[nx] (float)
+  int *ylo = (int *)smem, *yhi = ylo + ny, *xlo = yhi + ny, *xhi = xlo + nx;
+  float *ywl = (float *)(xhi + nx), *ywh = ywl + ny, *xwl = ywh + ny, *xwh = xwl + nx;
+  for (int i = threadIdx.x; i < ny + nx; i += blockDim.x) {
+    if (i < ny) {
+      const int b = i / g.gh, s = i % g.gh;
+      const float y = g.start_h + (float)b * g.bin_h + ((float)s + 0.5f) * g.bin_h / (float)g.gh;
+      int lo = 0, hi = 0;
+      float wl = 0.f, wh = 0.f;
+      if (!tap(y, H, lo, hi, wl, wh)) lo = -1;
+      ylo[i] = lo, yhi[i] = hi, ywl[i] = wl, ywh[i] = wh;
+    } else {
+      const int j = i - ny, b = j / g.gw, s = j % g.gw;
+      const float x = g.start_w + (float)b * g.bin_w + ((float)s + 0.5f) * g.bin_w / (float)g.gw;
+      int lo = 0, hi = 0;
+      float wl = 0.f, wh = 0.f;
+      if (!tap(x, W, lo, hi, wl, wh)) lo = -1;
+      xlo[j] = lo, xhi[j] = hi, xwl[j] = wl, xwh[j] = wh;
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C * bins; o += blockDim.x) {
+    const int c = o / bins, b = o % bins, by = b / pw, bx = b % pw;
+    const size_t oidx = ((size_t)r * C + c) * bins + b;
+    if (BACKWARD) {
+      const float gv = gout[oidx] * inv_count;
+      float *gp = gbase + (size_t)c * plane;
+      for (int iy = by * g.gh; iy < (by + 1) * g.gh; ++iy) {
+        if (ylo[iy] < 0) continue;
+        for (int ix = bx * g.gw; ix < (bx + 1) * g.gw; ++ix) {
+          if (xlo[ix] < 0) continue;
+          unsafeAtomicAdd(gp + (size_t)ylo[iy] * W + xlo[ix], gv * (ywl[iy] * xwl[ix]));
+          unsafeAtomicAdd(gp + (size_t)ylo[iy] * W + xhi[ix], gv * (ywl[iy] * xwh[ix]));
+          unsafeAtomicAdd(gp + (size_t)yhi[iy] * W + xlo[ix], gv * (ywh[iy] * xwl[ix]));
+          unsafeAtomicAdd(gp + (size_t)yhi[iy] * W + xhi[ix], gv * (ywh[iy] * xwh[ix]));
+        }
+      }
+    } else {
+      const float *fp = fbase + (size_t)c * plane;
+      float acc = 0.0f;
+      for (int iy = by * g.gh; iy < (by + 1) * g.gh; ++iy) {
+        if (ylo[iy] < 0) continue;
+        const float *r0 = fp + (size_t)ylo[iy] * W, *r1 = fp + (size_t)yhi[iy] * W;
+        for (int ix = bx * g.gw; ix < (bx + 1) * g.gw; ++ix) {
+          if (xlo[ix] < 0) continue;
+          // same association as the published kernel: w1*v1 + w2*v2 + w3*v3 + w4*v4
+          const float w1 = ywl[iy] * xwl[ix], w2 = ywl[iy] * xwh[ix];
+          const float w3 = ywh[iy] * xwl[ix], w4 = ywh[iy] * xwh[ix];
+          acc += w1 * r0[xlo[ix]] + w2 * r0[xhi[ix]] + w3 * r1[xlo[ix]] + w4 * r1[xhi[ix]];
+        }
+      }
+      out[oidx] = acc * inv_count;
+    }
+  }
+}
+
+// The adaptive sampling grid (ceil(roi / pooled)) is data dependent: LDS is sized for `max_grid`
+// samples per bin per axis (caller's estimate; 0 -> 8) and RoIs beyond it take the on-the-fly path.
+int launch(bool backward, const float *const *feats, float *const *grads, const int *hs,
+           const int *ws, const float *scales, int n_levels, int C, const float *rois,
+           const int *levels, int R, int ph, int pw, int sampling_ratio, int aligned, float *out,
+           const float *gout, int max_grid, hipStream_t stream) {
+  if (n_levels < 1 || n_levels > kMaxLevels || R < 0 || C < 1 || ph < 1 || pw < 1) return DM_ERR_INVALID_ARG;
+  if (R == 0) return DM_OK;
+  Pyramid p;
+  for (int l = 0; l < n_levels; ++l) {
+    p.feat[l] = feats ? feats[l] : nullptr;
+    p.grad[l] = grads ? grads[l] : nullptr;
+    p.h[l] = hs[l], p.w[l] = ws[l], p.scale[l] = scales[l];
+  }
+  int gmax = sampling_ratio > 0 ? sampling_ratio : (max_grid > 0 ? max_grid : 8);
+  while ((size_t)(ph + pw) * gmax * 16 > 48 * 1024 && gmax > 1) gmax /= 2;
+  const size_t shm = (size_t)(ph + pw) * gmax * 16;
+  if (backward)
+    hipLaunchKernelGGL(roi_align_kernel<true>, dim3(R), dim3(256), shm, stream, p, rois, levels, C,
+                       ph, pw, sampling_ratio, aligned, gmax, nullptr, gout);
+  else
+    hipLaunchKernelGGL(roi_align_kernel<false>, dim3(R), dim3(256), shm, stream, p, rois, levels,
+                       C, ph, pw, sampling_ratio, aligned, gmax, out, nullptr);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" int dm_roi_align_forward(const float *const *feats_host, const int *heights_host,
+                                    const int *widths_host, const float *scales_host, int n_levels,
+                                    int channels, const float *rois, const int *roi_levels,
+                                    int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
+                                    int aligned, int max_grid, float *out, dm_stream_t stream) {
+  return launch(false, feats_host, nullptr, heights_host, widths_host, scales_host, n_levels,
+                channels, rois, roi_levels, n_rois, pooled_h, pooled_w, sampling_ratio, aligned, out,
+                nullptr, max_grid, (hipStream_t)stream);
+}
+
+extern "C" int dm_roi_align_backward(float *const *grads_host, const int *heights_host,
+                                     const int *widths_host, const float *scales_host, int n_levels,
+                                     int channels, const float *rois, const int *roi_levels,
+                                     int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
+                                     int aligned, int max_grid, const float *grad_out,
+                                     dm_stream_t stream) {
+  return launch(true, nullptr, grads_host, heights_host, widths_host, scales_host, n_levels, channels,
+                rois, roi_levels, n_rois, pooled_h, pooled_w, sampling_ratio, aligned, nullptr,
+                grad_out, max_grid, (hipStream_t)stream);
+}

@@ -1,0 +1,149 @@
+"""ResNet-50 (caffe style) + FPN, mmdet 2.14 layouts and parameter names (parity unpinned).
+
+Config: depth 50, out_indices (0,1,2,3), frozen_stages 1, norm_cfg BN requires_grad False,
+norm_eval True, style 'caffe' (the stride-2 sits in the first 1x1 conv of a bottleneck).
+
+With norm_eval + requires_grad False every BatchNorm of the backbone is a constant per-channel
+affine map, so `FrozenBNConv` keeps the reference parameters (conv.weight, bn.weight, bn.bias,
+bn.running_mean, bn.running_var — same state-dict keys) but runs conv(x, w * s) + b with
+s = gamma / sqrt(var + eps), b = beta - mean * s: the BN kernel and its HBM round trip disappear
+while gradients w.r.t. conv.weight stay exact (d/dw of conv(x, w*s) = s * d/dw' ).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class FrozenBN(nn.Module):
+    """State-dict compatible with nn.BatchNorm2d (weight, bias, running_mean, running_var,
+    num_batches_tracked); never updates."""
+
+    def __init__(self, c, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(c), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(c), requires_grad=False)
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def scale_shift(self):
+        s = self.weight * torch.rsqrt(self.running_var + self.eps)
+        return s, self.bias - self.running_mean * s
+
+
+def conv_frozen_bn(x, conv, bn, relu):
+    s, b = bn.scale_shift()
+    w = conv.weight * s.view(-1, 1, 1, 1) if conv.weight.requires_grad else \
+        (conv.weight * s.view(-1, 1, 1, 1)).detach()
+    y = F.conv2d(x, w, b, conv.stride, conv.padding)
+    return F.relu_(y) if relu else y
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        # caffe style: stride on conv1
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False)
+        self.bn1 = FrozenBN(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=1, bias=False)
+        self.bn2 = FrozenBN(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = FrozenBN(planes * 4)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                            FrozenBN(planes * 4))
+
+    def forward(self, x):
+        out = conv_frozen_bn(x, self.conv1, self.bn1, True)
+        out = conv_frozen_bn(out, self.conv2, self.bn2, True)
+        out = conv_frozen_bn(out, self.conv3, self.bn3, False)
+        idt = x if self.downsample is None else conv_frozen_bn(x, self.downsample[0],
+                                                               self.downsample[1], False)
+        return F.relu_(out + idt)
+
+
+class ResNet(nn.Module):
+    arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+    def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1,
+                 norm_cfg=None, norm_eval=True, style='pytorch', init_cfg=None, **kwargs):
+        super().__init__()
+        assert style == 'caffe' and norm_eval and norm_cfg is not None and \
+            not norm_cfg.get('requires_grad', True), \
+            'only the DetMatch configuration (caffe style, frozen eval-mode BN) is built'
+        self.out_indices = out_indices
+        self.frozen_stages = frozen_stages
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBN(64)
+        inplanes = 64
+        self.res_layers = []
+        for i, nblocks in enumerate(self.arch[depth][:num_stages]):
+            planes, stride = 64 * 2 ** i, (1 if i == 0 else 2)
+            blocks = [Bottleneck(inplanes, planes, stride, downsample=True)]
+            inplanes = planes * 4
+            blocks += [Bottleneck(inplanes, planes) for _ in range(1, nblocks)]
+            name = 'layer%d' % (i + 1)
+            setattr(self, name, nn.Sequential(*blocks))
+            self.res_layers.append(name)
+        self._freeze_stages()
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.conv1.weight.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            for p in getattr(self, 'layer%d' % i).parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        x = conv_frozen_bn(x, self.conv1, self.bn1, True)
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class ConvModule(nn.Module):
+    """mmcv ConvModule without norm/activation: holds `.conv` so keys read `x.conv.weight`."""
+
+    def __init__(self, cin, cout, k, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding)
+        nn.init.xavier_uniform_(self.conv.weight)
+        nn.init.zeros_(self.conv.bias)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class FPN(nn.Module):
+    """mmdet FPN (add_extra_convs False): laterals 1x1, top-down nearest x2 upsampling adds,
+    3x3 output convs, extra levels by max_pool2d(1, stride=2)."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, **kwargs):
+        super().__init__()
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.lateral_convs = nn.ModuleList([ConvModule(c, out_channels, 1) for c in in_channels])
+        self.fpn_convs = nn.ModuleList([ConvModule(out_channels, out_channels, 3, padding=1)
+                                        for _ in in_channels])
+
+    def forward(self, inputs):
+        lat = [l(x) for l, x in zip(self.lateral_convs, inputs)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode='nearest')
+        outs = [c(x) for c, x in zip(self.fpn_convs, lat)]
+        for _ in range(self.num_outs - len(outs)):
+            outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+        return tuple(outs)

@@ -1,0 +1,454 @@
+"""Faster R-CNN (two-stage) for the DetMatch 2D branch — mmdet 2.14.0 TwoStageDetector / RPNHead /
+StandardRoIHead / Shared2FCBBoxHead / MaxIoUAssigner / RandomSampler / DeltaXYWHBBoxCoder /
+AnchorGenerator restated (un-vendored third party: PARITY UNPINNED) for
+configs/detmatch/001/detmatch/split_0.py:39-99 (model), :440-478 (train_cfg), :507-529 (test_cfg).
+
+Differences in HOW (not what) it computes:
+  * target assignment + random sampling are dense (masks, top-k over random keys): no nonzero(),
+    no randperm over data-dependent index sets, no host synchronisation in the training step;
+  * RPN proposals are fixed-size (max_per_img rows + validity mask), NMS on the device
+    (dm_nms_2d), one RoIAlign launch for the whole pyramid (dm_roi_align_forward);
+  * the per-level loss lists of mmdet (5 entries per RPN loss) are returned already summed — the
+    value `_parse_losses` would log and back-propagate is identical.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from ..mm3d.losses import bbox_overlaps
+from ..mm3d.registry import DETECTORS, LOSSES, build_from_cfg
+from ..roi_align import roi_align_fpn
+from .backbone import FPN, ResNet
+
+
+# ------------------------------------------------------------------ anchors / coder
+class AnchorGenerator(object):
+    """mmdet AnchorGenerator (scale_major, center_offset 0): anchors ordered (H, W, A)."""
+
+    def __init__(self, strides, ratios, scales, **kwargs):
+        self.strides = [(s, s) if isinstance(s, int) else tuple(s) for s in strides]
+        self.ratios = torch.tensor(ratios, dtype=torch.float32)
+        self.scales = torch.tensor(scales, dtype=torch.float32)
+        self.base_anchors = [self._base(s[0]) for s in self.strides]
+        self._cache = {}
+
+    @property
+    def num_base_anchors(self):
+        return [b.shape[0] for b in self.base_anchors]
+
+    def _base(self, base_size):
+        w = h = float(base_size)
+        h_ratios = torch.sqrt(self.ratios)
+        w_ratios = 1 / h_ratios
+        ws = (w * w_ratios[:, None] * self.scales[None, :]).view(-1)
+        hs = (h * h_ratios[:, None] * self.scales[None, :]).view(-1)
+        return torch.stack([-0.5 * ws, -0.5 * hs, 0.5 * ws, 0.5 * hs], dim=-1)
+
+    def grid_anchors(self, featmap_sizes, device):
+        key = (tuple(tuple(int(v) for v in s) for s in featmap_sizes), str(device))
+        if key not in self._cache:
+            out = []
+            for (h, w), (sw, sh), base in zip(featmap_sizes, self.strides, self.base_anchors):
+                sx = torch.arange(0, w, device=device, dtype=torch.float32) * sw
+                sy = torch.arange(0, h, device=device, dtype=torch.float32) * sh
+                xx = sx.repeat(h)
+                yy = sy.view(-1, 1).repeat(1, w).view(-1)
+                shifts = torch.stack([xx, yy, xx, yy], dim=-1)
+                out.append((base.to(device)[None, :, :] + shifts[:, None, :]).view(-1, 4))
+            self._cache[key] = out
+        return self._cache[key]
+
+
+class DeltaXYWHBBoxCoder(object):
+
+    def __init__(self, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.), clip_border=True,
+                 **kwargs):
+        self.means, self.stds, self.clip_border = list(target_means), list(target_stds), clip_border
+
+    def encode(self, proposals, gt):
+        p, g = proposals.float(), gt.float()
+        px, py = (p[..., 0] + p[..., 2]) * 0.5, (p[..., 1] + p[..., 3]) * 0.5
+        pw, ph = p[..., 2] - p[..., 0], p[..., 3] - p[..., 1]
+        gx, gy = (g[..., 0] + g[..., 2]) * 0.5, (g[..., 1] + g[..., 3]) * 0.5
+        gw, gh = g[..., 2] - g[..., 0], g[..., 3] - g[..., 1]
+        d = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
+        return (d - d.new_tensor(self.means)) / d.new_tensor(self.stds)
+
+    def decode(self, rois, deltas, max_shape=None, wh_ratio_clip=16 / 1000):
+        n = deltas.size(-1) // 4
+        means = deltas.new_tensor(self.means).repeat(n)
+        stds = deltas.new_tensor(self.stds).repeat(n)
+        d = deltas * stds + means
+        dx, dy, dw, dh = d[..., 0::4], d[..., 1::4], d[..., 2::4], d[..., 3::4]
+        max_ratio = abs(np.log(wh_ratio_clip))
+        dw, dh = dw.clamp(-max_ratio, max_ratio), dh.clamp(-max_ratio, max_ratio)
+        px = ((rois[..., 0] + rois[..., 2]) * 0.5).unsqueeze(-1)
+        py = ((rois[..., 1] + rois[..., 3]) * 0.5).unsqueeze(-1)
+        pw = (rois[..., 2] - rois[..., 0]).unsqueeze(-1)
+        ph = (rois[..., 3] - rois[..., 1]).unsqueeze(-1)
+        gw, gh = pw * dw.exp(), ph * dh.exp()
+        gx, gy = px + pw * dx, py + ph * dy
+        x1, y1, x2, y2 = gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5
+        if self.clip_border and max_shape is not None:
+            x1, x2 = x1.clamp(0, max_shape[1]), x2.clamp(0, max_shape[1])
+            y1, y2 = y1.clamp(0, max_shape[0]), y2.clamp(0, max_shape[0])
+        return torch.stack([x1, y1, x2, y2], dim=-1).view(deltas.size())
+
+
+# ------------------------------------------------------------------ assigner / sampler (dense)
+def max_iou_assign(boxes, gt_boxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality,
+                   box_valid=None):
+    """mmdet MaxIoUAssigner.assign_wrt_overlaps (gt_max_assign_all True, no ignore):
+    -> assigned_gt_inds (N) long: -1 ignore, 0 negative, k>0 = GT k (1-based)."""
+    n, k = boxes.shape[0], gt_boxes.shape[0]
+    if k == 0:
+        assigned = boxes.new_zeros((n,), dtype=torch.long)
+    else:
+        ov = bbox_overlaps(gt_boxes, boxes)                       # (K, N)
+        max_ov, argmax_ov = ov.max(dim=0)
+        assigned = boxes.new_full((n,), -1, dtype=torch.long)
+        assigned = torch.where((max_ov >= 0) & (max_ov < neg_iou_thr), torch.zeros_like(assigned), assigned)
+        assigned = torch.where(max_ov >= pos_iou_thr, argmax_ov + 1, assigned)
+        if match_low_quality:
+            gt_max = ov.max(dim=1)[0]
+            hit = (ov == gt_max[:, None]) & (gt_max >= min_pos_iou)[:, None]
+            # the reference loops over GTs in order, later GTs overwrite: take the largest index
+            gid = torch.arange(1, k + 1, device=boxes.device)[:, None]
+            low = (hit.long() * gid).max(dim=0)[0]
+            assigned = torch.where(low > 0, low, assigned)
+    if box_valid is not None:
+        assigned = torch.where(box_valid, assigned, torch.full_like(assigned, -1))
+    return assigned
+
+
+def random_sample(assigned, num, pos_fraction, generator=None):
+    """mmdet RandomSampler (neg_pos_ub -1): up to int(num*pos_fraction) positives, the rest
+    negatives, uniformly at random.  -> (pos_idx (P), pos_ok (P) bool, neg_idx (num), neg_ok)."""
+    n = assigned.shape[0]
+    n_pos = min(int(num * pos_fraction), n)
+    n_neg = min(num, n)
+    key = torch.rand((n,), device=assigned.device, generator=generator)
+    two = key.new_full((), 2.0)
+    vp, ip = torch.topk(torch.where(assigned > 0, key, two), n_pos, largest=False)
+    pos_ok = vp < 1.5
+    vn, ineg = torch.topk(torch.where(assigned == 0, key, two), n_neg, largest=False)
+    budget = num - pos_ok.sum()
+    neg_ok = (vn < 1.5) & (torch.arange(n_neg, device=assigned.device) < budget)
+    return ip, pos_ok, ineg, neg_ok
+
+
+def nms_fixed(boxes, scores, iou_thr, max_num):
+    """Greedy NMS on the device -> (idx (max_num) into boxes, ok (max_num) bool), score order."""
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    b = boxes[order].contiguous().float()
+    _lib.require_device(b, 'nms_2d')
+    n = b.shape[0]
+    L = _lib.lib()
+    keep = torch.zeros((max(n, max_num),), dtype=torch.int64, device=b.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=b.device)
+    ws = _lib.workspace(L.dm_nms_workspace_bytes(n), b.device, 'nms')
+    _lib.check(L.dm_nms_2d(_lib.ptr(b), n, float(iou_thr), int(max_num), _lib.ptr(keep), _lib.ptr(num),
+                           _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms_2d')
+    ok = torch.arange(max_num, device=b.device) < num
+    idx = torch.where(ok, keep[:max_num], torch.zeros_like(keep[:max_num]))
+    return order[idx], ok
+
+
+# ------------------------------------------------------------------ RPN
+class RPNHead(nn.Module):
+
+    def __init__(self, in_channels, feat_channels, anchor_generator, bbox_coder, loss_cls=None,
+                 loss_bbox=None, train_cfg=None, test_cfg=None, **kwargs):
+        super().__init__()
+        ag = dict(anchor_generator)
+        ag.pop('type', None)
+        self.anchor_generator = AnchorGenerator(**ag)
+        bc = dict(bbox_coder)
+        bc.pop('type', None)
+        self.bbox_coder = DeltaXYWHBBoxCoder(**bc)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self.loss_cls_weight = (loss_cls or {}).get('loss_weight', 1.0)
+        self.loss_bbox_weight = (loss_bbox or {}).get('loss_weight', 1.0)
+        assert (loss_cls or {}).get('use_sigmoid', True)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.rpn_conv = nn.Conv2d(in_channels, feat_channels, 3, padding=1)
+        self.rpn_cls = nn.Conv2d(feat_channels, self.num_anchors, 1)
+        self.rpn_reg = nn.Conv2d(feat_channels, self.num_anchors * 4, 1)
+        for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):
+            nn.init.normal_(m.weight, std=0.01)
+            nn.init.zeros_(m.bias)
+
+    def forward(self, feats):
+        cls, reg = [], []
+        for x in feats:
+            x = F.relu(self.rpn_conv(x), inplace=True)
+            cls.append(self.rpn_cls(x))
+            reg.append(self.rpn_reg(x))
+        return cls, reg
+
+    @staticmethod
+    def _flatten(cls, reg):
+        """-> scores (B, N_total) logits, deltas (B, N_total, 4), level sizes; anchor order (H,W,A)."""
+        b = cls[0].shape[0]
+        s = torch.cat([c.permute(0, 2, 3, 1).reshape(b, -1) for c in cls], dim=1)
+        d = torch.cat([r.permute(0, 2, 3, 1).reshape(b, -1, 4) for r in reg], dim=1)
+        return s, d
+
+    def loss(self, cls, reg, gt_bboxes, img_metas):
+        """mmdet AnchorHead.loss with sampling: BCE over the 256 sampled anchors, L1 over encoded
+        deltas of the sampled positives, both / num_total_samples (summed over the batch)."""
+        cfg = self.train_cfg
+        a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
+        sizes = [c.shape[-2:] for c in cls]
+        anchors = torch.cat(self.anchor_generator.grid_anchors(sizes, cls[0].device), dim=0)
+        scores, deltas = self._flatten(cls, reg)
+        tot_cls, tot_box, tot_n = 0., 0., 0.
+        for i in range(scores.shape[0]):
+            gt = gt_bboxes[i]
+            with torch.no_grad():
+                assigned = max_iou_assign(anchors, gt, a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'],
+                                          a_cfg['min_pos_iou'], a_cfg.get('match_low_quality', True))
+                ip, pos_ok, ineg, neg_ok = random_sample(assigned, s_cfg['num'], s_cfg['pos_fraction'])
+                if gt.shape[0] > 0:
+                    tgt = self.bbox_coder.encode(anchors[ip], gt[(assigned[ip] - 1).clamp(min=0)])
+                    tgt = torch.where(pos_ok[:, None], tgt, torch.zeros_like(tgt))
+                else:
+                    tgt = anchors.new_zeros((ip.shape[0], 4))
+            idx = torch.cat([ip, ineg])
+            w = torch.cat([pos_ok, neg_ok]).float()
+            label = torch.cat([torch.ones_like(pos_ok, dtype=torch.float32),
+                               torch.zeros_like(neg_ok, dtype=torch.float32)])
+            bce = F.binary_cross_entropy_with_logits(scores[i, idx], label, reduction='none')
+            tot_cls = tot_cls + (bce * w).sum()
+            tot_box = tot_box + ((deltas[i, ip] - tgt).abs() * pos_ok[:, None].float()).sum()
+            tot_n = tot_n + w.sum()
+        tot_n = tot_n.clamp(min=1.0) if torch.is_tensor(tot_n) else max(tot_n, 1.0)
+        return dict(loss_rpn_cls=self.loss_cls_weight * tot_cls / tot_n,
+                    loss_rpn_bbox=self.loss_bbox_weight * tot_box / tot_n)
+
+    @torch.no_grad()
+    def get_bboxes(self, cls, reg, img_metas, cfg):
+        """mmdet RPNHead._get_bboxes_single per image: per-level top nms_pre, decode, drop empty
+        boxes, NMS across levels (boxes of different levels never suppress each other), keep
+        max_per_img.  -> list of (proposals (max_per_img, 5) [x1,y1,x2,y2,score], ok (max_per_img))."""
+        sizes = [c.shape[-2:] for c in cls]
+        mlvl_anchors = self.anchor_generator.grid_anchors(sizes, cls[0].device)
+        nms_thr = cfg['nms'].get('iou_threshold', cfg['nms'].get('iou_thr', 0.7))
+        out = []
+        for i in range(cls[0].shape[0]):
+            ss, dd, aa, ll = [], [], [], []
+            for lvl, (c, r, a) in enumerate(zip(cls, reg, mlvl_anchors)):
+                s = c[i].permute(1, 2, 0).reshape(-1).sigmoid()
+                d = r[i].permute(1, 2, 0).reshape(-1, 4)
+                if cfg['nms_pre'] > 0 and s.shape[0] > cfg['nms_pre']:
+                    s, top = torch.topk(s, cfg['nms_pre'])
+                    d, a = d[top], a[top]
+                ss.append(s), dd.append(d), aa.append(a)
+                ll.append(s.new_full((s.shape[0],), lvl))
+            s, d, a, l = torch.cat(ss), torch.cat(dd), torch.cat(aa), torch.cat(ll)
+            boxes = self.bbox_coder.decode(a, d, max_shape=img_metas[i]['img_shape'])
+            live = torch.ones_like(s, dtype=torch.bool)
+            if cfg.get('min_bbox_size', 0) >= 0:
+                mn = cfg.get('min_bbox_size', 0)
+                live = ((boxes[:, 2] - boxes[:, 0]) > mn) & ((boxes[:, 3] - boxes[:, 1]) > mn)
+            # dropped boxes: pushed to the end of the score order and far away from everything
+            s_nms = torch.where(live, s, s.new_full((), -1.0))
+            off = l * (boxes.max() + 1)
+            b_nms = torch.where(live[:, None], boxes + off[:, None], boxes.new_full((), -1e6))
+            idx, ok = nms_fixed(b_nms, s_nms, nms_thr, cfg['max_per_img'])
+            ok = ok & live[idx]
+            props = torch.cat([boxes[idx], s[idx, None]], dim=1) * ok[:, None].float()
+            out.append((props, ok))
+        return out
+
+
+# ------------------------------------------------------------------ RoI head
+class Shared2FCBBoxHead(nn.Module):
+
+    def __init__(self, in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=80,
+                 bbox_coder=None, reg_class_agnostic=False, loss_cls=None, loss_bbox=None, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.reg_class_agnostic = reg_class_agnostic
+        bc = dict(bbox_coder)
+        bc.pop('type', None)
+        self.bbox_coder = DeltaXYWHBBoxCoder(**bc)
+        self.loss_cls = build_from_cfg(loss_cls, LOSSES)
+        self.loss_bbox = build_from_cfg(loss_bbox, LOSSES)
+        self.shared_fcs = nn.ModuleList([nn.Linear(in_channels * roi_feat_size ** 2, fc_out_channels),
+                                         nn.Linear(fc_out_channels, fc_out_channels)])
+        self.fc_cls = nn.Linear(fc_out_channels, num_classes + 1)
+        self.fc_reg = nn.Linear(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
+        for m in self.shared_fcs:
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.zeros_(m.bias)
+        nn.init.normal_(self.fc_cls.weight, std=0.01)
+        nn.init.zeros_(self.fc_cls.bias)
+        nn.init.normal_(self.fc_reg.weight, std=0.001)
+        nn.init.zeros_(self.fc_reg.bias)
+
+    def forward(self, x):
+        x = x.flatten(1)
+        for fc in self.shared_fcs:
+            x = F.relu(fc(x), inplace=True)
+        return self.fc_cls(x), self.fc_reg(x)
+
+    def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights):
+        """mmdet BBoxHead.loss: cls avg_factor = #(label_weights > 0); box loss over positives of
+        the class-specific prediction, averaged over ALL sampled RoIs (bbox_targets.size(0))."""
+        n_valid = (label_weights > 0).sum().clamp(min=1).float()
+        losses = dict()
+        losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=n_valid)
+        correct = (cls_score.argmax(dim=1) == labels).float() * (label_weights > 0).float()
+        losses['acc'] = correct.sum() * 100.0 / n_valid
+        pos = ((labels >= 0) & (labels < self.num_classes)).float() * (label_weights > 0).float()
+        if self.reg_class_agnostic:
+            pred = bbox_pred
+        else:
+            sel = labels.clamp(max=self.num_classes - 1)[:, None, None].expand(-1, 1, 4)
+            pred = bbox_pred.view(bbox_pred.size(0), -1, 4).gather(1, sel).squeeze(1)
+        losses['loss_bbox'] = self.loss_bbox(pred, bbox_targets, bbox_weights * pos[:, None],
+                                             avg_factor=n_valid)
+        return losses
+
+
+class StandardRoIHead(nn.Module):
+
+    def __init__(self, bbox_roi_extractor, bbox_head, train_cfg=None, test_cfg=None, **kwargs):
+        super().__init__()
+        rl = bbox_roi_extractor['roi_layer']
+        self.out_size = rl.get('output_size', 7)
+        self.sampling_ratio = rl.get('sampling_ratio', 0)
+        self.aligned = rl.get('aligned', True)
+        self.featmap_strides = list(bbox_roi_extractor['featmap_strides'])
+        self.finest_scale = bbox_roi_extractor.get('finest_scale', 56)
+        bh = dict(bbox_head)
+        assert bh.pop('type') == 'Shared2FCBBoxHead'
+        self.bbox_head = Shared2FCBBoxHead(**bh)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    def extract(self, feats, rois):
+        return roi_align_fpn(feats, rois, self.featmap_strides, self.out_size, self.sampling_ratio,
+                             self.aligned, self.finest_scale)
+
+    def forward_train(self, feats, img_metas, proposals, gt_bboxes, gt_labels):
+        cfg = self.train_cfg
+        a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
+        num = s_cfg['num']
+        nc = self.bbox_head.num_classes
+        rois, labels, lw, tgts, bw = [], [], [], [], []
+        with torch.no_grad():
+            for i, ((props, ok), gt, gl) in enumerate(zip(proposals, gt_bboxes, gt_labels)):
+                boxes, valid = props[:, :4], ok
+                if s_cfg.get('add_gt_as_proposals', True) and gt.shape[0] > 0:
+                    boxes = torch.cat([gt.float(), boxes], dim=0)
+                    valid = torch.cat([torch.ones_like(gt[:, 0], dtype=torch.bool), valid])
+                assigned = max_iou_assign(boxes, gt.float(), a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'],
+                                          a_cfg['min_pos_iou'], a_cfg.get('match_low_quality', False),
+                                          box_valid=valid)
+                ip, pos_ok, ineg, neg_ok = random_sample(assigned, num, s_cfg['pos_fraction'])
+                idx = torch.cat([ip, ineg])
+                okk = torch.cat([pos_ok, neg_ok])
+                is_pos = torch.cat([pos_ok, torch.zeros_like(neg_ok)])
+                # compact to `num` rows, sampled ones first (positives before negatives)
+                front = torch.sort((~okk).long(), stable=True)[1][:num]
+                idx, okk, is_pos = idx[front], okk[front], is_pos[front]
+                b = boxes[idx]
+                if gt.shape[0] > 0:
+                    g = (assigned[idx] - 1).clamp(min=0)
+                    t = self.bbox_head.bbox_coder.encode(b, gt.float()[g])
+                    lab = torch.where(is_pos, gl[g], torch.full_like(gl[g], nc))
+                else:
+                    t = b.new_zeros((b.shape[0], 4))
+                    lab = torch.full((b.shape[0],), nc, dtype=torch.long, device=b.device)
+                t = torch.where(is_pos[:, None], t, torch.zeros_like(t))
+                rois.append(torch.cat([b.new_full((b.shape[0], 1), float(i)), b], dim=1)
+                            * okk[:, None].float())
+                labels.append(lab), lw.append(okk.float()), tgts.append(t)
+                bw.append(is_pos.float()[:, None].expand(-1, 4))
+            rois = torch.cat(rois)
+        feats_roi = self.extract(feats, rois)
+        cls_score, bbox_pred = self.bbox_head(feats_roi)
+        return self.bbox_head.loss(cls_score, bbox_pred, torch.cat(labels), torch.cat(lw),
+                                   torch.cat(tgts), torch.cat(bw))
+
+    def simple_test_pre_nms(self, feats, proposals, img_metas):
+        """test_mixins.simple_test_bboxes up to (not including) NMS: per image
+        (decoded boxes (P, 4*C), scores (P, C+1)); rows of invalid proposals carry zero scores."""
+        rois = torch.cat([torch.cat([p.new_full((p.shape[0], 1), float(i)), p[:, :4]], dim=1)
+                          for i, (p, _) in enumerate(proposals)])
+        cls_score, bbox_pred = self.bbox_head(self.extract(feats, rois))
+        use_sigmoid = getattr(self.bbox_head.loss_cls, 'use_sigmoid', False)
+        score = torch.sigmoid(cls_score) if use_sigmoid else F.softmax(cls_score, dim=-1)
+        out, off = [], 0
+        for i, (p, ok) in enumerate(proposals):
+            n = p.shape[0]
+            boxes = self.bbox_head.bbox_coder.decode(rois[off:off + n, 1:], bbox_pred[off:off + n],
+                                                     max_shape=img_metas[i]['img_shape'])
+            out.append((boxes, score[off:off + n] * ok[:, None].float()))
+            off += n
+        return out
+
+
+# ------------------------------------------------------------------ detector
+@DETECTORS.register_module()
+class FasterRCNN(nn.Module):
+
+    def __init__(self, backbone, neck, rpn_head, roi_head, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None):
+        super().__init__()
+        bb = dict(backbone)
+        assert bb.pop('type') == 'ResNet'
+        self.backbone = ResNet(**bb)
+        nk = dict(neck)
+        assert nk.pop('type') == 'FPN'
+        self.neck = FPN(**nk)
+        rp = dict(rpn_head)
+        assert rp.pop('type') == 'RPNHead'
+        self.rpn_head = RPNHead(train_cfg=train_cfg['rpn'] if train_cfg else None,
+                                test_cfg=test_cfg['rpn'] if test_cfg else None, **rp)
+        rh = dict(roi_head)
+        assert rh.pop('type') == 'StandardRoIHead'
+        self.roi_head = StandardRoIHead(train_cfg=train_cfg['rcnn'] if train_cfg else None,
+                                        test_cfg=test_cfg['rcnn'] if test_cfg else None, **rh)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    def extract_feat(self, img):
+        return self.neck(self.backbone(img))
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, **kwargs):
+        """mmdet TwoStageDetector.forward_train -> loss_rpn_cls, loss_rpn_bbox, loss_cls, acc, loss_bbox."""
+        assert gt_bboxes_ignore is None
+        x = self.extract_feat(img)
+        cls, reg = self.rpn_head(x)
+        losses = self.rpn_head.loss(cls, reg, gt_bboxes, img_metas)
+        proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg['rpn'] if self.test_cfg else None)
+        proposals = self.rpn_head.get_bboxes([c.detach() for c in cls], [r.detach() for r in reg],
+                                             img_metas, proposal_cfg)
+        losses.update(self.roi_head.forward_train(x, img_metas, proposals, gt_bboxes, gt_labels))
+        return losses
+
+    def simple_test_pre_nms(self, img, img_metas):
+        """The body of SimpleTest_2D.forward (processors_2d.py:36-84)."""
+        x = self.extract_feat(img)
+        cls, reg = self.rpn_head(x)
+        proposals = self.rpn_head.get_bboxes(cls, reg, img_metas, self.test_cfg['rpn'])
+        return self.roi_head.simple_test_pre_nms(x, proposals, img_metas)
+
+    @torch.no_grad()
+    def simple_test(self, img, img_metas, proposals=None, rescale=False, **kwargs):
+        """mmdet TwoStageDetector.simple_test -> per image, per class (k, 5) numpy arrays."""
+        from ..mm3d.bbox_utils import modified_multiclass_nms
+        rc = self.test_cfg['rcnn']
+        nc = self.roi_head.bbox_head.num_classes
+        results = []
+        for (boxes, scores), meta in zip(self.simple_test_pre_nms(img, img_metas), img_metas):
+            if rescale:
+                sf = boxes.new_tensor(meta['scale_factor'])
+                boxes = (boxes.view(boxes.size(0), -1, 4) / sf).view(boxes.size(0), -1)
+            dets, labels, _ = modified_multiclass_nms(boxes, scores, rc['score_thr'], rc['nms'],
+                                                      rc['max_per_img'])
+            results.append([dets[labels == c].cpu().numpy() for c in range(nc)])
+        return results

@@ -1,3 +1,8 @@
-"""Host-side mirror of the DetMatch-specific mmdet3d layer (SSL detector, 2D+3D wrapper,
-OpenPCDet adapter, SSL modules, assigner, runner, optimizer, hooks, box structures) —
-the reference's registry/config surface for the hot path."""
+"""mmdet3d-side host layer of the DetMatch hot path: box structures, the
+OpenPCDet adapter, registries/config, SSL detector + modules, step driver."""
+
+
+def register_all():
+    """Import every module that registers a config-addressable type."""
+    from . import losses, openpcdet, runner, ssl, ssl_modules  # noqa: F401
+    from .. import mm2d  # noqa: F401

@@ -16,6 +16,7 @@ from .. import voxel
 from ..pcdet.config import ConfigDict
 from ..pcdet.detector import build_network
 from .box3d import LiDARInstance3DBoxes, limit_period
+from .registry import DETECTORS
 
 
 def bbox3d2result(bboxes, scores, labels):
@@ -39,6 +40,7 @@ def pcdet_to_mm3d_boxes(pred_boxes):
     return LiDARInstance3DBoxes(b, origin=(0.5, 0.5, 0.5))
 
 
+@DETECTORS.register_module()
 class OpenPCDetDetector(nn.Module):
 
     def __init__(self, dataset_fields, voxel_layer, pcdet_model, train_cfg=None, test_cfg=None,

@@ -1,0 +1,131 @@
+"""Data-parallel gradient exchange for the DetMatch step.
+
+One process per GPU; the ONLY data-path collective of an iteration is the average of the
+student's gradients.  The reference wraps the model in MMDistributedDataParallel with
+find_unused_parameters=True (mmdet3d/apis/ssl_train.py:73-80): 25 MB buckets and a graph walk
+per iteration to find parameters that got no gradient.
+
+Here the gradients of all trainable parameters live in ONE flat fp32 arena (`p.grad` are views),
+zeroed at the start of each step, so a parameter that gets no gradient contributes zeros by
+construction — no graph walk.  The arena is cut into a few large buckets (default 64 MiB: xGMI is
+point-to-point, ring steps are per-link bound, so fewer/larger messages win) in reverse
+registration order; a bucket's all-reduce is issued asynchronously as soon as autograd has
+produced its last gradient, overlapping the rest of backward; `finish()` issues whatever is left
+(buckets holding unused parameters) and waits.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class FlatGradDDP(nn.Module):
+
+    def __init__(self, module, params=None, bucket_bytes=64 << 20, process_group=None,
+                 broadcast=True):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in (params if params is not None else module.parameters())
+                       if p.requires_grad]
+        # True when the arena holds every trainable parameter: its norm IS the global norm
+        self.covers_all_clipped = params is None
+        assert self.params, 'nothing to train'
+        dev = self.params[0].device
+        assert all(p.dtype == torch.float32 and p.device == dev for p in self.params)
+        # reverse order ~ the order in which backward produces gradients
+        order = list(range(len(self.params)))[::-1]
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.buckets = []          # (start, end) element ranges of self.flat
+        self._bucket_of = {}
+        self._pending = []
+        off, b_start, cap = 0, 0, max(1, bucket_bytes // 4)
+        for i in order:
+            p = self.params[i]
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self._bucket_of[id(p)] = len(self.buckets)
+            off += p.numel()
+            if off - b_start >= cap:
+                self.buckets.append((b_start, off))
+                b_start = off
+        if off > b_start:
+            self.buckets.append((b_start, off))
+        self._need = [0] * len(self.buckets)
+        for p in self.params:
+            self._need[self._bucket_of[id(p)]] += 1
+        self._left = list(self._need)
+        self._sent = [False] * len(self.buckets)
+        self._armed = False
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+        if broadcast and self.world > 1:
+            self.broadcast_parameters()
+
+    # ---- state sync ------------------------------------------------------------------
+    @torch.no_grad()
+    def broadcast_parameters(self, src=0):
+        """Rank `src`'s parameters AND buffers to everyone, two flat messages."""
+        for tensors in ([p.data for p in self.module.parameters()],
+                        [b.data for b in self.module.buffers()]):
+            for dtype in (torch.float32, torch.int64):
+                ts = [t for t in tensors if t.dtype == dtype]
+                if not ts:
+                    continue
+                flat = torch.cat([t.reshape(-1) for t in ts])
+                dist.broadcast(flat, src, group=self.group)
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+
+    # ---- step protocol: zero_grad() -> backward -> finish() -------------------------------
+    def zero_grad(self):
+        self.flat.zero_()
+        for p in self.params:      # optimizers / user code may have replaced .grad
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4:
+                raise RuntimeError('a gradient left the flat arena (zero_grad(set_to_none=True)?)')
+        self._left = list(self._need)
+        self._sent = [False] * len(self.buckets)
+        self._pending = []
+        self._armed = True
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        self._sent[b] = True
+        if self.world > 1:
+            self._pending.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b = self._bucket_of[id(p)]
+        self._left[b] -= 1
+        if self._left[b] == 0 and not self._sent[b]:
+            self._launch(b)
+
+    def finish(self):
+        """Issue the remaining buckets, wait for all, average."""
+        self._armed = False
+        for b in range(len(self.buckets)):
+            if not self._sent[b]:
+                self._launch(b)
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if self.world > 1:
+            self.flat.div_(self.world)
+
+    def clip_grad_norm_(self, max_norm, norm_type=2):
+        """Global clip over the arena: one norm kernel + one scale kernel."""
+        assert norm_type == 2
+        total = torch.linalg.vector_norm(self.flat)
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        self.flat.mul_(coef)
+        return total
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def train_step(self, *args, **kwargs):
+        return self.module.train_step(*args, **kwargs)

@@ -1,0 +1,349 @@
+"""Step driver: IterBasedSSLRunner, HybridOptimizer(+Constructor), ModelIterEpochHook, the
+optimizer hook (grad clip) and the warm-up LR schedule — mmdet3d/core/runner/
+iter_based_ssl_runner.py:11-110, core/optimizer/hybrid_{constructor,optimizer}.py,
+core/utils/model_iter_epoch.py:18-28, configs/detmatch/001/detmatch/split_0.py:829-862.
+
+mmcv's IterBasedRunner / hook machinery (un-vendored, mmcv-full 1.3.16) is restated only as far
+as the training iteration needs it: parity unpinned for the mmcv parts.
+"""
+import copy
+import time
+
+import torch
+import torch.nn as nn
+
+from .parallel import FlatGradDDP
+from .registry import HOOKS, OPTIMIZER_BUILDERS, OPTIMIZERS, RUNNERS, build_from_cfg
+
+OPTIMIZERS.register_module(torch.optim.AdamW, name='AdamW')
+OPTIMIZERS.register_module(torch.optim.SGD, name='SGD')
+OPTIMIZERS.register_module(torch.optim.Adam, name='Adam')
+
+
+@OPTIMIZERS.register_module()
+class HybridOptimizer(torch.optim.Optimizer):
+    """hybrid_optimizer.py:5-101: several optimizers, each stepped every step_interval calls."""
+
+    def __init__(self, optimizers, step_intervals=None):
+        self.optimizers = optimizers
+        self.param_groups = []
+        for o in optimizers:
+            self.param_groups += o.param_groups
+        if not isinstance(step_intervals, list):
+            step_intervals = [1] * len(optimizers)
+        self.step_intervals = step_intervals
+        self.num_step_updated = 0
+
+    def __repr__(self):
+        s = self.__class__.__name__ + ' (\n'
+        for o, k in zip(self.optimizers, self.step_intervals):
+            s += 'Update interval: %d\n' % k + repr(o).replace('\n', '\n  ') + ',\n'
+        return s + ')'
+
+    def state_dict(self):
+        sds = [o.state_dict() for o in self.optimizers]
+        return dict(num_step_updated=self.num_step_updated, state=[s['state'] for s in sds],
+                    param_groups=[s['param_groups'] for s in sds])
+
+    def load_state_dict(self, state_dict):
+        assert len(state_dict['state']) == len(self.optimizers)
+        assert len(state_dict['param_groups']) == len(self.optimizers)
+        for o, st, pg in zip(self.optimizers, state_dict['state'], state_dict['param_groups']):
+            o.load_state_dict(dict(state=st, param_groups=pg))
+        self.param_groups = []
+        for o in self.optimizers:
+            self.param_groups += o.param_groups
+        self.num_step_updated = state_dict['num_step_updated']
+
+    def zero_grad(self, set_to_none=False):
+        for o in self.optimizers:
+            o.zero_grad(set_to_none=set_to_none)
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self.num_step_updated += 1
+        for k, o in zip(self.step_intervals, self.optimizers):
+            if self.num_step_updated % k == 0:
+                o.step()
+        return loss
+
+    def add_param_group(self, param_group):
+        raise NotImplementedError
+
+
+@OPTIMIZER_BUILDERS.register_module()
+class HybridOptimizerConstructor(object):
+    """hybrid_constructor.py:8-130: each top-level key of optimizer_cfg is a SUBSTRING of the
+    parameter names it owns (first match in key order wins); every parameter must match."""
+
+    def __init__(self, optimizer_cfg, paramwise_cfg=None):
+        if not isinstance(optimizer_cfg, dict):
+            raise TypeError('optimizer_cfg should be a dict', 'but got %s' % type(optimizer_cfg))
+        self.paramwise_cfg = {} if paramwise_cfg is None else paramwise_cfg
+        self.optimizer_cfg = optimizer_cfg
+        self.base_lr = {k: optimizer_cfg[k].get('lr', None) for k in optimizer_cfg}
+
+    def __call__(self, model):
+        if hasattr(model, 'module'):
+            model = model.module
+        custom = self.paramwise_cfg.get('custom_keys', {})
+        custom_sorted = sorted(sorted(custom.keys()), key=len, reverse=True)
+        cfg = copy.deepcopy(dict(self.optimizer_cfg))
+        groups = {k: [] for k in cfg}
+        for name, p in model.named_parameters():
+            owner = next((k for k in cfg if k in name), None)
+            assert owner is not None, 'key %s is not matched to any optimizer' % name
+            g = {'params': [p]}
+            ck = next((c for c in custom_sorted if c in name), None)
+            if ck is not None:
+                g['lr'] = self.base_lr[owner] * custom[ck].get('lr_mult', 1.)
+            groups[owner].append(g)
+        opts, intervals = [], []
+        for k, single in cfg.items():
+            single = dict(single)
+            intervals.append(single.pop('step_interval', 1))
+            if not groups[k]:       # e.g. no 2D branch built: keep the slot, nothing to step
+                groups[k] = [{'params': [nn.Parameter(torch.zeros(()), requires_grad=False)]}]
+            single['params'] = groups[k]
+            if single.get('type') in ('AdamW', 'Adam') and 'betas' in single:
+                single['betas'] = tuple(single['betas'])
+            opts.append(build_from_cfg(single, OPTIMIZERS))
+        return HybridOptimizer(opts, intervals)
+
+
+def build_optimizer(model, cfg):
+    """mmcv build_optimizer: optional 'constructor' / 'paramwise_cfg' keys."""
+    cfg = copy.deepcopy(dict(cfg))
+    ctor = cfg.pop('constructor', None)
+    paramwise = cfg.pop('paramwise_cfg', None)
+    if ctor is None:
+        cfg['params'] = [p for p in model.parameters() if p.requires_grad]
+        return build_from_cfg(cfg, OPTIMIZERS)
+    return build_from_cfg(dict(type=ctor, optimizer_cfg=cfg, paramwise_cfg=paramwise),
+                          OPTIMIZER_BUILDERS)(model)
+
+
+# ------------------------------------------------------------------ hooks
+class Hook(object):
+    def before_run(self, runner): pass
+    def after_run(self, runner): pass
+    def before_epoch(self, runner): pass
+    def after_epoch(self, runner): pass
+    def before_train_iter(self, runner): pass
+    def after_train_iter(self, runner): pass
+    def after_train_epoch(self, runner): pass
+
+
+def _inner(model):
+    return model.module if hasattr(model, 'module') else model
+
+
+@HOOKS.register_module()
+class ModelIterEpochHook(Hook):
+    """model_iter_epoch.py:18-28: model.iter = runner.iter in before_run and in after_train_iter,
+    which fires BEFORE the runner increments its counter — iterations 0 and 1 both see 0, then
+    iteration k sees k - 1 (the EMA / ssl-weight schedules inherit this lag); epoch - 1 at start."""
+
+    def before_run(self, runner):
+        m = _inner(runner.model)
+        m.iter = runner.iter
+        m.epoch = runner.epoch - 1
+
+    def after_train_iter(self, runner):
+        _inner(runner.model).iter = runner.iter
+
+    def after_train_epoch(self, runner):
+        _inner(runner.model).epoch = runner.epoch
+
+
+@HOOKS.register_module()
+class OptimizerHook(Hook):
+    """mmcv OptimizerHook(grad_clip=dict(max_norm, norm_type)): zero_grad, backward, clip, step.
+    With a FlatGradDDP-wrapped model the gradient exchange is finished between backward and clip."""
+
+    def __init__(self, grad_clip=None):
+        self.grad_clip = grad_clip
+
+    def after_train_iter(self, runner):
+        ddp = runner.model if isinstance(runner.model, FlatGradDDP) else None
+        if ddp is not None:
+            ddp.zero_grad()
+        else:
+            runner.optimizer.zero_grad()
+        runner.outputs['loss'].backward()
+        if ddp is not None:
+            ddp.finish()
+        if self.grad_clip is not None:
+            if ddp is not None and ddp.covers_all_clipped:
+                norm = ddp.clip_grad_norm_(**self.grad_clip)
+            else:
+                params = [p for g in runner.optimizer.param_groups for p in g['params']
+                          if p.requires_grad and p.grad is not None]
+                norm = torch.nn.utils.clip_grad_norm_(params, **self.grad_clip) if params else None
+            if norm is not None:
+                runner.log_buffer.setdefault('grad_norm', []).append(norm.detach())
+        runner.optimizer.step()
+
+
+@HOOKS.register_module()
+class StepLrUpdaterHook(Hook):
+    """mmcv LrUpdaterHook, policy='step' (by_epoch False) with warmup: regular lr =
+    base * gamma^(#steps passed); during the first warmup_iters iterations
+    linear: lr * (1 - (1 - it/warmup_iters) (1 - warmup_ratio)); constant: lr * ratio;
+    exp: lr * ratio^(1 - it/warmup_iters)."""
+
+    def __init__(self, step=(), gamma=0.1, warmup=None, warmup_iters=0, warmup_ratio=0.1,
+                 by_epoch=False, **kwargs):
+        self.step = [step] if isinstance(step, int) else list(step)
+        self.gamma = gamma
+        self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
+        self.base_lr = None
+
+    def before_run(self, runner):
+        for g in runner.optimizer.param_groups:
+            g.setdefault('initial_lr', g['lr'])
+        self.base_lr = [g['initial_lr'] for g in runner.optimizer.param_groups]
+
+    def get_lr(self, it):
+        exp = sum(1 for s in self.step if it >= s)
+        regular = [lr * self.gamma ** exp for lr in self.base_lr]
+        if self.warmup is None or it >= self.warmup_iters:
+            return regular
+        if self.warmup == 'constant':
+            return [lr * self.warmup_ratio for lr in regular]
+        if self.warmup == 'linear':
+            k = (1 - it / self.warmup_iters) * (1 - self.warmup_ratio)
+            return [lr * (1 - k) for lr in regular]
+        if self.warmup == 'exp':
+            k = self.warmup_ratio ** (1 - it / self.warmup_iters)
+            return [lr * k for lr in regular]
+        raise ValueError(self.warmup)
+
+    def before_train_iter(self, runner):
+        for g, lr in zip(runner.optimizer.param_groups, self.get_lr(runner.iter)):
+            g['lr'] = lr
+
+
+class _PassThroughHook(Hook):
+    def __init__(self, **kwargs):
+        pass
+
+
+for _n in ('WandbVisHook', 'TextLoggerHook', 'TensorboardLoggerHook', 'WandbLoggerHook'):
+    # logging back-ends are outside the hot path: registered so configs build
+    HOOKS.register_module(type(_n, (_PassThroughHook,), {}))
+
+
+class IterLoader(object):
+    """mmcv IterLoader: endless iterator over a loader, counting epochs."""
+
+    def __init__(self, dataloader):
+        self._dataloader = dataloader
+        self.iter_loader = iter(dataloader)
+        self._epoch = 0
+
+    @property
+    def epoch(self):
+        return self._epoch
+
+    def __next__(self):
+        try:
+            data = next(self.iter_loader)
+        except StopIteration:
+            self._epoch += 1
+            if hasattr(getattr(self._dataloader, 'sampler', None), 'set_epoch'):
+                self._dataloader.sampler.set_epoch(self._epoch)
+            self.iter_loader = iter(self._dataloader)
+            data = next(self.iter_loader)
+        return data
+
+    def __len__(self):
+        return len(self._dataloader)
+
+
+@RUNNERS.register_module()
+class IterBasedSSLRunner(object):
+    """iter_based_ssl_runner.py:11-110: one labeled + one unlabeled batch per iteration, keys
+    prefixed 'lab_' / 'unlab_'; data_batch['img_metas'] is the labeled metas (only used for
+    num_samples)."""
+
+    def __init__(self, model, optimizer=None, max_iters=None, work_dir=None, logger=None,
+                 meta=None, batch_processor=None, **kwargs):
+        self.model = model
+        self.optimizer = optimizer
+        self._max_iters = max_iters
+        self.work_dir = work_dir
+        self.logger = logger
+        self._hooks = []
+        self._iter = 0
+        self._inner_iter = 0
+        self._epoch = 0
+        self.mode = None
+        self.outputs = None
+        self.log_buffer = dict()
+
+    iter = property(lambda self: self._iter)
+    epoch = property(lambda self: self._epoch)
+    inner_iter = property(lambda self: self._inner_iter)
+    max_iters = property(lambda self: self._max_iters)
+
+    def register_hook(self, hook):
+        if isinstance(hook, dict):
+            hook = build_from_cfg(hook, HOOKS)
+        self._hooks.append(hook)
+
+    def register_training_hooks(self, lr_config=None, optimizer_config=None, custom_hooks=None):
+        """Order = mmcv priorities for this set: LR (VERY_HIGH) < optimizer (ABOVE_NORMAL)
+        < custom (NORMAL)."""
+        if lr_config is not None:
+            cfg = dict(lr_config)
+            policy = cfg.pop('policy', 'step')
+            assert policy == 'step', 'only the step policy is on the DetMatch path'
+            self.register_hook(StepLrUpdaterHook(**cfg))
+        if optimizer_config is not None:
+            self.register_hook(OptimizerHook(**dict(optimizer_config)))
+        for h in (custom_hooks or []):
+            self.register_hook(h)
+
+    def call_hook(self, name):
+        for h in self._hooks:
+            getattr(h, name, lambda r: None)(self)
+
+    def train(self, lab_data_loader, unlab_data_loader, **kwargs):
+        self.model.train()
+        self.mode = 'train'
+        self._epoch = getattr(lab_data_loader, 'epoch', 0)
+        lab = next(lab_data_loader)
+        unlab = next(unlab_data_loader)
+        data_batch = {'lab_%s' % k: v for k, v in lab.items()}
+        data_batch.update({'unlab_%s' % k: v for k, v in unlab.items()})
+        data_batch['img_metas'] = lab['img_metas']
+        self.call_hook('before_train_iter')
+        outputs = self.model.train_step(data_batch, self.optimizer, **kwargs)
+        if not isinstance(outputs, dict):
+            raise TypeError('model.train_step() must return a dict')
+        if 'log_vars' in outputs:
+            for k, v in outputs['log_vars'].items():
+                self.log_buffer.setdefault(k, []).append(v)
+        self.outputs = outputs
+        self.call_hook('after_train_iter')
+        self._inner_iter += 1
+        self._iter += 1
+
+    def run(self, data_loaders, workflow=(('train', 1),), max_iters=None, **kwargs):
+        assert isinstance(data_loaders, list) and len(data_loaders) == 2  # labeled & unlabeled
+        assert len(workflow) == 1 and workflow[0][0] == 'train'
+        if max_iters is not None:
+            self._max_iters = max_iters
+        assert self._max_iters is not None, 'max_iters must be specified during instantiation'
+        lab, unlab = IterLoader(data_loaders[0]), IterLoader(data_loaders[1])
+        self.call_hook('before_run')
+        self.call_hook('before_epoch')
+        while self.iter < self._max_iters:
+            self._inner_iter = 0
+            for _ in range(workflow[0][1]):
+                if self.iter >= self._max_iters:
+                    break
+                self.train(lab, unlab, **kwargs)
+        self.call_hook('after_epoch')
+        self.call_hook('after_run')

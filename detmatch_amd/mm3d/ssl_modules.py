@@ -1,0 +1,527 @@
+"""SSL modules — the processors and consumers that configs/detmatch/*/detmatch/*.py chain
+inside SSL.forward_train (mmdet3d/models/ssl_modules/{processors,consumers}/*.py).
+
+Every module is `forward(ssl_obj, batch_dict) -> batch_dict`; dotted keys address nested
+dicts ("tea.3d_simple_test").  Box lists are list[tuple(boxes, scores, *extras)], one tuple
+per sample.  Names, constructor arguments and key semantics follow the reference so its config
+files load unchanged (tests/test_ssl_config.py).
+"""
+import torch
+from torch.nn import functional as F
+
+from .bbox_utils import (apply_3d_transformation_bboxes, bbox_2d_transform, bbox_3d_to_bbox_2d,
+                         filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set)
+from .box3d import LiDARInstance3DBoxes
+from .losses import FocalLoss, MSELoss, bbox_xyxy_to_cxcywh
+from .openpcdet import pcdet_to_mm3d_boxes
+from .registry import SSL_MODULES, build_assigner, build_loss
+from .ssl import add_prefix
+
+
+# ------------------------------------------------------------------ helpers
+def _split(entry):
+    """entry is a tuple (boxes, *rest) or a bare box tensor/object."""
+    if isinstance(entry, tuple):
+        return entry[0], entry[1:], True
+    return entry, (), False
+
+
+def _join(boxes, rest, was_tuple):
+    return (boxes,) + tuple(rest) if was_tuple else boxes
+
+
+def _fg_scores(scores, includes_bg):
+    return scores[:, :-1] if includes_bg else scores
+
+
+def _accumulate(ssl_obj, batch_dict, losses, prefer_sup):
+    tgt = 'sup_losses' if (prefer_sup and 'sup_losses' in batch_dict) else 'ssl_losses'
+    batch_dict[tgt] = ssl_obj._sum_update_losses(batch_dict[tgt], losses)
+    return batch_dict
+
+
+def _pred_dicts_to_tuples(pred_dicts):
+    """pcdet predictions -> list[(LiDARInstance3DBoxes, per-class sigmoid scores)]
+    (consumers/openpcdet.py:74-93)."""
+    res = []
+    for pd in pred_dicts:
+        boxes = pcdet_to_mm3d_boxes(pd['pred_boxes'])
+        assert len(boxes.tensor) == len(pd['pred_sem_scores_full'])
+        res.append((boxes, pd['pred_sem_scores_full']))
+    return res
+
+
+def _threshold_pseudo(entries, score_thr, includes_bg, empty_boxes):
+    """Hard pseudo labels: boxes whose max foreground score exceeds score_thr, label = argmax
+    (consumers/openpcdet.py:139-158, consumers_2d.py:84-103).  Boolean indexing is the one
+    place the teacher path produces data-dependent shapes."""
+    labels, boxes = [], []
+    for cur_boxes, cur_scores in entries:
+        if len(cur_scores) == 0:
+            labels.append(cur_scores.new_zeros((0,), dtype=torch.long))
+            boxes.append(empty_boxes(cur_scores))
+            continue
+        top, lab = _fg_scores(cur_scores, includes_bg).max(dim=1)
+        keep = top > score_thr
+        labels.append(lab[keep])
+        boxes.append(cur_boxes[keep])
+    return boxes, labels
+
+
+# ------------------------------------------------------------------ 3D (OpenPCDet) modules
+@SSL_MODULES.register_module()
+class Opd_SimpleTest_3D(object):
+    """consumers/openpcdet.py:15-95: run the detector in its CURRENT mode on [key]['points']
+    and store un-thresholded (boxes, sigmoid class scores)."""
+
+    def __init__(self, ssl_obj_attr='teacher', batch_dict_key='tea',
+                 out_bboxes_key='3d_simple_test'):
+        self.ssl_obj_attr = ssl_obj_attr
+        self.batch_dict_key = batch_dict_key
+        self.out_bboxes_key = out_bboxes_key
+
+    def forward(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        batch = detector._base_batch(cur['points'], cur['img_metas'])
+        pred_dicts, _ = detector.model(batch)
+        cur[self.out_bboxes_key] = _pred_dicts_to_tuples(pred_dicts)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class Opd_HardPseudoLabel_3D(object):
+    """consumers/openpcdet.py:97-213: threshold teacher boxes into pseudo GT, run the student's
+    training forward on them, and optionally keep the student's (no-NMS) boxes."""
+
+    def __init__(self, score_thr, cls_includes_bg_pred=False, loss_detach_keys=[],
+                 ssl_obj_attr='student', target_bboxes_key='tea.placeholder',
+                 target_batch_dict_key='stu', name='hard_pseudo_3d', weight=1,
+                 out_bboxes_key=None, no_nms=True, box_dim=7):
+        assert len(loss_detach_keys) == 0, 'Not supported yet, requires changes elsewhere.'
+        self.score_thr = score_thr
+        self.cls_includes_bg_pred = cls_includes_bg_pred
+        self.loss_detach_keys = loss_detach_keys
+        self.ssl_obj_attr = ssl_obj_attr
+        self.target_bboxes_key = target_bboxes_key
+        self.target_batch_dict_key = target_batch_dict_key
+        self.name = name
+        self.weight = weight
+        self.out_bboxes_key = out_bboxes_key
+        self.no_nms = no_nms
+        self.box_dim = box_dim
+
+    def forward(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.target_batch_dict_key)
+        boxes, labels = _threshold_pseudo(
+            mlvl_get(batch_dict, self.target_bboxes_key), self.score_thr,
+            self.cls_includes_bg_pred,
+            lambda s: LiDARInstance3DBoxes(s.new_zeros((0, self.box_dim))))
+        batch = detector.train_to_openpcdet(cur['points'], cur['img_metas'], boxes, labels)
+        for module in detector.model.module_list:
+            batch = module(batch)
+        loss, _, _ = detector.model.get_training_loss()
+        batch_dict = _accumulate(ssl_obj, batch_dict, add_prefix(dict(loss=loss.mean()), self.name),
+                                 prefer_sup=False)
+        if self.out_bboxes_key is not None:
+            pred_dicts, _ = detector.model.post_processing(batch, no_nms=self.no_nms)
+            cur[self.out_bboxes_key] = _pred_dicts_to_tuples(pred_dicts)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class Opd_Supervised_3D(object):
+    """consumers/openpcdet.py:215-253"""
+
+    def __init__(self, ssl_obj_attr='student', batch_dict_key='stu', name='sup_3d', weight=1):
+        self.ssl_obj_attr = ssl_obj_attr
+        self.batch_dict_key = batch_dict_key
+        self.name = name
+        self.weight = weight
+
+    def forward(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        losses = detector.forward_train(cur['points'], cur['img_metas'], cur['gt_bboxes_3d'],
+                                        cur['gt_labels_3d'], cur.get('gt_bboxes_ignore', None))
+        if self.weight != 1:
+            losses = {k: v * self.weight for k, v in losses.items()}
+        return _accumulate(ssl_obj, batch_dict, add_prefix(losses, self.name), prefer_sup=True)
+
+
+# ------------------------------------------------------------------ box-list processors
+class _MapBoxes(object):
+    """in_bboxes_key -> out_bboxes_key, one sample at a time."""
+
+    def _map(self, boxes, img_meta):
+        raise NotImplementedError
+
+    def forward(self, ssl_obj, batch_dict):
+        metas = mlvl_get(batch_dict, self.img_metas)
+        out = []
+        for entry, meta in zip(mlvl_get(batch_dict, self.in_bboxes_key), metas):
+            boxes, rest, tup = _split(entry)
+            assert tup or isinstance(boxes, torch.Tensor)
+            out.append(_join(self._map(boxes, meta), rest, tup))
+        mlvl_set(batch_dict, self.out_bboxes_key, out)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class BboxesTransform_3D(_MapBoxes):
+    """processors_3d.py:12-56: apply (reverse=False) or undo (reverse=True) the 3D augmentations
+    recorded in img_metas (flip / rot / scale / trans, in transformation_3d_flow order)."""
+
+    def __init__(self, reverse, img_metas, in_bboxes_key, out_bboxes_key):
+        self.reverse, self.img_metas = reverse, img_metas
+        self.in_bboxes_key, self.out_bboxes_key = in_bboxes_key, out_bboxes_key
+
+    def _map(self, boxes, img_meta):
+        return apply_3d_transformation_bboxes(boxes, img_meta, reverse=self.reverse)
+
+
+@SSL_MODULES.register_module()
+class BboxesTransform_2D(_MapBoxes):
+    """processors_2d.py:128-187: 'forward' (reverse=False) maps original-image boxes into the
+    augmented image (ori2new), reverse maps back."""
+
+    def __init__(self, reverse, img_metas, in_bboxes_key, out_bboxes_key):
+        self.reverse, self.img_metas = reverse, img_metas
+        self.in_bboxes_key, self.out_bboxes_key = in_bboxes_key, out_bboxes_key
+
+    def _map(self, boxes, img_meta):
+        assert boxes.shape[1] >= 4
+        return bbox_2d_transform(img_meta, boxes, not self.reverse)
+
+
+@SSL_MODULES.register_module()
+class DetachBboxes(object):
+    """processors_3d.py:59-78"""
+
+    def __init__(self, in_bboxes_key, out_bboxes_key):
+        self.in_bboxes_key, self.out_bboxes_key = in_bboxes_key, out_bboxes_key
+
+    def forward(self, ssl_obj, batch_dict):
+        out = [tuple(t.detach() for t in entry) for entry in mlvl_get(batch_dict, self.in_bboxes_key)]
+        mlvl_set(batch_dict, self.out_bboxes_key, out)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class Bboxes3DTo2D(object):
+    """processors_3d.py:81-155: undo the 3D augs, project the 8 corners with lidar2img, take the
+    clipped min/max box; optionally drop boxes that are invalid (behind the camera / empty)."""
+
+    def __init__(self, img_metas='stu.img_metas', in_bboxes_key='stu.3d_bboxes_nms',
+                 out_bboxes_key='stu.3d_bboxes_nms_2d_proj', filter_invalid=True):
+        self.img_metas = img_metas
+        self.in_bboxes_key, self.out_bboxes_key = in_bboxes_key, out_bboxes_key
+        self.filter_invalid = filter_invalid
+
+    def forward(self, ssl_obj, batch_dict):
+        metas = mlvl_get(batch_dict, self.img_metas)
+        out = []
+        for entry, meta in zip(mlvl_get(batch_dict, self.in_bboxes_key), metas):
+            boxes3d, rest, tup = _split(entry)
+            boxes3d = apply_3d_transformation_bboxes(boxes3d, meta, reverse=True)
+            boxes2d, valid = bbox_3d_to_bbox_2d(boxes3d, meta['lidar2img'], meta['ori_shape'])
+            if self.filter_invalid:
+                boxes2d, rest = boxes2d[valid], [t[valid] for t in rest]
+            out.append(_join(boxes2d, rest, tup))
+        mlvl_set(batch_dict, self.out_bboxes_key, out)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class MaxScoreFilter(object):
+    """processors_fusion.py:9-47"""
+
+    def __init__(self, cls_includes_bg_pred, score_thr, in_bboxes_key, out_bboxes_key):
+        self.cls_includes_bg_pred = cls_includes_bg_pred
+        self.score_thr = score_thr
+        self.in_bboxes_key, self.out_bboxes_key = in_bboxes_key, out_bboxes_key
+
+    def forward(self, ssl_obj, batch_dict):
+        out = []
+        for entry in mlvl_get(batch_dict, self.in_bboxes_key):
+            scores = _fg_scores(entry[1], self.cls_includes_bg_pred)
+            if len(scores) == 0:
+                keep = torch.zeros((0,), dtype=torch.bool, device=scores.device)
+            else:
+                keep = scores.max(dim=1)[0] > self.score_thr
+            out.append(tuple(t[keep] for t in entry))
+        mlvl_set(batch_dict, self.out_bboxes_key, out)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class FusionHungarianMatching(object):
+    """processors_fusion.py:50-222: one-to-one match projected 3D boxes ('predictions') with 2D
+    boxes ('GT') by cls + L1 + GIoU cost; matches dearer than cost_thr are dropped; outputs are
+    index-aligned tuples.  Both score sets must be sigmoid probabilities."""
+
+    def __init__(self, assigner_cfg, cost_thr, img_metas, cls_includes_bg_pred_3d,
+                 cls_includes_bg_pred_2d, in_bboxes_3d_key, in_bboxes_2d_key, out_bboxes_3d_key,
+                 out_bboxes_2d_key, match_cost_key=None, project_3d_to_2d=True):
+        self.assigner = build_assigner(assigner_cfg)
+        self.cost_thr = cost_thr
+        self.img_metas = img_metas
+        self.cls_includes_bg_pred_3d = cls_includes_bg_pred_3d
+        self.cls_includes_bg_pred_2d = cls_includes_bg_pred_2d
+        self.in_bboxes_3d_key, self.in_bboxes_2d_key = in_bboxes_3d_key, in_bboxes_2d_key
+        self.out_bboxes_3d_key, self.out_bboxes_2d_key = out_bboxes_3d_key, out_bboxes_2d_key
+        self.match_cost_key = match_cost_key
+        self.project_3d_to_2d = project_3d_to_2d
+
+    def match(self, entry_3d, entry_2d, img_meta):
+        """-> (index tensor into entry_3d, index tensor into entry_2d, matched costs)"""
+        s3 = _fg_scores(entry_3d[1], self.cls_includes_bg_pred_3d)
+        s2 = _fg_scores(entry_2d[1], self.cls_includes_bg_pred_2d)
+        assert s3.shape[1] == s2.shape[1]
+        boxes2d = entry_2d[0]
+        if self.project_3d_to_2d:
+            proj, _ = bbox_3d_to_bbox_2d(entry_3d[0], img_meta['lidar2img'], img_meta['ori_shape'])
+        else:
+            proj = entry_3d[0]
+        img_h, img_w, _ = img_meta['ori_shape']
+        factor = boxes2d.new_tensor([img_w, img_h, img_w, img_h]).unsqueeze(0)
+        proj_norm = bbox_xyxy_to_cxcywh(proj) / factor
+        res = self.assigner.assign(proj_norm, torch.logit(s3, eps=1e-6), boxes2d,
+                                   torch.logit(s2, eps=1e-6), dict(img_shape=img_meta['ori_shape']))
+        gt_inds = res.gt_inds
+        if res.max_overlaps is None:
+            empty = gt_inds.new_zeros((0,))
+            return empty, empty, proj.new_zeros((0,))
+        matched = gt_inds > 0
+        if self.cost_thr is not None:
+            matched = matched & ~(res.max_overlaps > self.cost_thr)
+        idx3 = matched.nonzero(as_tuple=True)[0]
+        return idx3, gt_inds[idx3] - 1, res.max_overlaps[idx3]
+
+    def forward(self, ssl_obj, batch_dict):
+        metas = mlvl_get(batch_dict, self.img_metas)
+        out3, out2, costs = [], [], []
+        for e3, e2, meta in zip(mlvl_get(batch_dict, self.in_bboxes_3d_key),
+                                mlvl_get(batch_dict, self.in_bboxes_2d_key), metas):
+            i3, i2, c = self.match(e3, e2, meta)
+            out3.append(tuple(t[i3] for t in e3))
+            out2.append(tuple(t[i2] for t in e2))
+            costs.append(c)
+        mlvl_set(batch_dict, self.out_bboxes_3d_key, out3)
+        mlvl_set(batch_dict, self.out_bboxes_2d_key, out2)
+        if self.match_cost_key is not None:
+            mlvl_set(batch_dict, self.match_cost_key, costs)
+        return batch_dict
+
+
+# ------------------------------------------------------------------ 2D modules
+@SSL_MODULES.register_module()
+class SimpleTest_2D(object):
+    """processors_2d.py:11-86: Faster R-CNN test path up to (not including) NMS:
+    (decoded boxes N x 4, softmax/sigmoid scores N x (C+1)), in the augmented image frame."""
+
+    def __init__(self, ssl_obj_attr='teacher', batch_dict_key='tea', out_bboxes_key='2d_simple_test'):
+        self.ssl_obj_attr = ssl_obj_attr
+        self.batch_dict_key = batch_dict_key
+        self.out_bboxes_key = out_bboxes_key
+
+    def forward(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        cur[self.out_bboxes_key] = detector.simple_test_pre_nms(cur['img'], cur['img_metas'])
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class BboxesNMS_2D(object):
+    """processors_2d.py:89-125: per-class NMS that carries the FULL score vector of each kept box."""
+
+    def __init__(self, nms_cfg, cls_includes_bg_pred, batch_dict_key='stu',
+                 in_bboxes_key='3d_bboxes_nms_2d_proj',
+                 out_bboxes_key='3d_bboxes_nms_2d_proj_2d_nms'):
+        self.cls_includes_bg_pred = cls_includes_bg_pred
+        self.nms_cfg = nms_cfg
+        self.batch_dict_key = batch_dict_key
+        self.in_bboxes_key, self.out_bboxes_key = in_bboxes_key, out_bboxes_key
+
+    def forward(self, ssl_obj, batch_dict):
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        cur[self.out_bboxes_key] = filter_by_nms_2d(cur[self.in_bboxes_key], self.nms_cfg,
+                                                    not self.cls_includes_bg_pred)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class AverageBboxes_2D(object):
+    """processors_2d.py:190-241: element-wise mean of two index-aligned box lists."""
+
+    def __init__(self, cls_includes_bg_pred_1, cls_includes_bg_pred_2, in_bboxes_1_key,
+                 in_bboxes_2_key, out_bboxes_key, out_score_type='averaged'):
+        self.cls_includes_bg_pred_1 = cls_includes_bg_pred_1
+        self.cls_includes_bg_pred_2 = cls_includes_bg_pred_2
+        self.in_bboxes_1_key, self.in_bboxes_2_key = in_bboxes_1_key, in_bboxes_2_key
+        self.out_bboxes_key = out_bboxes_key
+        self.out_score_type = out_score_type
+
+    def forward(self, ssl_obj, batch_dict):
+        out = []
+        for e1, e2 in zip(mlvl_get(batch_dict, self.in_bboxes_1_key),
+                          mlvl_get(batch_dict, self.in_bboxes_2_key)):
+            boxes = (e1[0] + e2[0]) / 2
+            if self.out_score_type == 'averaged':
+                score = (_fg_scores(e1[1], self.cls_includes_bg_pred_1) +
+                         _fg_scores(e2[1], self.cls_includes_bg_pred_2)) / 2
+            elif self.out_score_type == 'pred_1':
+                score = e1[1]
+            elif self.out_score_type == 'pred_2':
+                score = e2[1]
+            else:
+                raise ValueError(self.out_score_type)
+            out.append((boxes, score))
+        mlvl_set(batch_dict, self.out_bboxes_key, out)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class TwoStageSupervised_2D(object):
+    """consumers_2d.py:8-52"""
+
+    def __init__(self, loss_detach_keys=[], ssl_obj_attr='student', batch_dict_key='stu'):
+        self.loss_detach_keys = loss_detach_keys
+        self.ssl_obj_attr = ssl_obj_attr
+        self.batch_dict_key = batch_dict_key
+
+    def forward(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        losses = detector.forward_train(cur['img'], cur['img_metas'], cur['gt_bboxes'],
+                                        cur['gt_labels'], cur.get('gt_bboxes_ignore', None))
+        for k in self.loss_detach_keys:
+            losses.pop(k)
+        return _accumulate(ssl_obj, batch_dict, add_prefix(losses, '%s' % self.batch_dict_key),
+                           prefer_sup=True)
+
+
+@SSL_MODULES.register_module()
+class HardPseudoLabel_2D(object):
+    """consumers_2d.py:55-121"""
+
+    def __init__(self, score_thr, cls_includes_bg_pred, loss_detach_keys=[], ssl_obj_attr='student',
+                 target_bboxes_key='tea.2d_bboxes_nms_stu_aug', target_img_key='stu.img',
+                 target_img_metas_key='stu.img_metas', name='hard_pseudo_2d', weight=1):
+        self.score_thr = score_thr
+        self.cls_includes_bg_pred = cls_includes_bg_pred
+        self.loss_detach_keys = loss_detach_keys
+        self.ssl_obj_attr = ssl_obj_attr
+        self.target_bboxes_key = target_bboxes_key
+        self.target_img_key = target_img_key
+        self.target_img_metas_key = target_img_metas_key
+        self.weight = weight
+        self.name = name
+
+    def forward(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        boxes, labels = _threshold_pseudo(mlvl_get(batch_dict, self.target_bboxes_key),
+                                          self.score_thr, self.cls_includes_bg_pred,
+                                          lambda s: s.new_zeros((0, 4)))
+        losses = detector.forward_train(mlvl_get(batch_dict, self.target_img_key),
+                                        mlvl_get(batch_dict, self.target_img_metas_key),
+                                        boxes, labels)
+        losses = ssl_obj._collapse_losses(losses)
+        for k in self.loss_detach_keys:
+            losses.pop(k)
+        for k in losses.keys():
+            if 'acc' not in k:
+                losses[k] = losses[k] * self.weight
+        return _accumulate(ssl_obj, batch_dict, add_prefix(losses, self.name), prefer_sup=False)
+
+
+# ------------------------------------------------------------------ consistency + metrics
+@SSL_MODULES.register_module()
+class HungarianConsistency(object):
+    """consumers_3d.py:11-117: box-level 2D<->3D consistency over index-aligned matched lists:
+    class loss (MSE on probabilities or focal on logits), L1 on image-normalised boxes, GIoU."""
+
+    def __init__(self, loss_cls_cfg=None, loss_iou_cfg=None, loss_l1_cfg=None,
+                 loss_weights_cfg=dict(), in_bboxes_key='stu.3d_bboxes_nms_2d_proj',
+                 target_bboxes_key='tea.2d_bboxes_nms_stu_aug_hung_dtch_bboxes',
+                 cls_includes_bg_pred_in=True, cls_includes_bg_pred_target=True,
+                 target_img_metas_key=None, name=None):
+        self.loss_cls_cfg = loss_cls_cfg
+        self.loss_cls = build_loss(loss_cls_cfg) if loss_cls_cfg is not None else None
+        self.loss_iou = build_loss(loss_iou_cfg) if loss_iou_cfg is not None else None
+        self.loss_l1 = build_loss(loss_l1_cfg) if loss_l1_cfg is not None else None
+        self.loss_weights_cfg = loss_weights_cfg
+        self.in_bboxes_key, self.target_bboxes_key = in_bboxes_key, target_bboxes_key
+        self.cls_includes_bg_pred_in = cls_includes_bg_pred_in
+        self.cls_includes_bg_pred_target = cls_includes_bg_pred_target
+        self.target_img_metas_key = target_img_metas_key
+        self.name = name
+
+    def forward(self, ssl_obj, batch_dict):
+        in_list = mlvl_get(batch_dict, self.in_bboxes_key)
+        tgt_list = mlvl_get(batch_dict, self.target_bboxes_key)
+        metas = mlvl_get(batch_dict, self.target_img_metas_key)
+        per_sample = dict()
+        active = [(n, l) for n, l in (('cls_loss', self.loss_cls), ('l1_loss', self.loss_l1),
+                                      ('iou_loss', self.loss_iou)) if l is not None]
+        for idx, (cur_in, cur_tgt) in enumerate(zip(in_list, tgt_list)):
+            in_boxes, tgt_boxes = cur_in[0], cur_tgt[0]
+            if len(cur_in[1]) == 0 or len(cur_tgt[1]) == 0:
+                continue
+            in_scores = _fg_scores(cur_in[1], self.cls_includes_bg_pred_in)
+            tgt_scores = _fg_scores(cur_tgt[1], self.cls_includes_bg_pred_target)
+            assert in_scores.shape[1] == tgt_scores.shape[1] == 3
+            for lname, fn in active:
+                if lname == 'cls_loss':
+                    if isinstance(fn, MSELoss):
+                        val = fn(in_scores, tgt_scores)
+                    elif isinstance(fn, FocalLoss):
+                        val = fn(torch.logit(in_scores, eps=1e-6), torch.argmax(tgt_scores, dim=1))
+                    else:
+                        raise Exception('Not Yet Implemented')
+                elif lname == 'l1_loss':
+                    img_h, img_w, _ = metas[idx]['img_shape']
+                    factor = in_boxes.new_tensor([img_w, img_h, img_w, img_h]).unsqueeze(0)
+                    val = fn(in_boxes / factor, tgt_boxes / factor)
+                else:
+                    val = fn(in_boxes, tgt_boxes)
+                per_sample.setdefault(lname, []).append(val)
+        ref = in_list[0][0]
+        losses = {k: sum(v) / len(v) for k, v in per_sample.items()}
+        losses = ssl_obj._collapse_losses(losses)
+        for k, w in self.loss_weights_cfg.items():
+            if k in losses:
+                losses[k] = losses[k] * w
+            else:
+                losses[k] = ref.new_tensor(0.0, dtype=torch.float32, requires_grad=True)
+        return _accumulate(ssl_obj, batch_dict, add_prefix(losses, self.name), prefer_sup=False)
+
+
+@SSL_MODULES.register_module()
+class NumPreds(object):
+    """consumers/metrics.py:9-24: mean number of boxes per sample, logged as a metric."""
+
+    def __init__(self, bboxes_key, out_name):
+        self.bboxes_key, self.out_name = bboxes_key, out_name
+
+    def forward(self, ssl_obj, batch_dict):
+        entries = mlvl_get(batch_dict, self.bboxes_key)
+        num = sum(e[0].shape[0] if isinstance(e, tuple) else e.shape[0] for e in entries) / len(entries)
+        first = entries[0][0] if isinstance(entries[0], tuple) else entries[0]
+        batch_dict['ssl_losses']['metrics.' + self.out_name] = torch.tensor(
+            num, device=first.device, dtype=torch.float)
+        return batch_dict
+
+
+@SSL_MODULES.register_module()
+class Vis3D(object):
+    """consumers/visualize.py: debugging output only — outside the hot path, kept
+    as a pass-through so configs that list it still build."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+
+    def forward(self, ssl_obj, batch_dict):
+        return batch_dict

@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .. import synth, voxel
+from ..mm3d.parallel import FlatGradDDP
 from ..spconv import ops as sp_ops
 from .backbones_3d import HeightCompression, MeanVFE, VoxelBackBone8x
 
@@ -46,6 +47,7 @@ class Stage3DWorkload(object):
         self.params = [p for p in self.backbone.parameters() if p.requires_grad]
         self.opt = torch.optim.AdamW(self.params, lr=lr, betas=(0.95, 0.99), weight_decay=0.01)
         self.world = 1
+        self.ddp = FlatGradDDP(self.backbone, broadcast=False)
         self._trace = None
 
     def describe(self):
@@ -55,13 +57,10 @@ class Stage3DWorkload(object):
                 'KITTI-shaped synthetic, bs=%d/GPU' % len(self.frames))
 
     def enable_ddp(self):
+        """One flat gradient arena + bucketed asynchronous all-reduce (mm3d/parallel.py)."""
         self.world = dist.get_world_size()
-        flat = torch.cat([p.data.view(-1) for p in self.params])
-        dist.broadcast(flat, 0)
-        off = 0
-        for p in self.params:
-            p.data.copy_(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        self.ddp.world = self.world
+        self.ddp.broadcast_parameters(0)
 
     def forward(self):
         _, coors, _, mean, _ = voxel.voxelize_batch(self.points, self.voxel_size, self.pc_range,
@@ -76,16 +75,9 @@ class Stage3DWorkload(object):
         self.backbone.train()
         bd = self.forward()
         loss = bd['spatial_features'].square().mean()
-        self.opt.zero_grad(set_to_none=False)
+        self.ddp.zero_grad()
         loss.backward()
-        if self.world > 1:  # gradients only, one flat bucket
-            flat = torch.cat([p.grad.view(-1) for p in self.params])
-            dist.all_reduce(flat)
-            flat.div_(self.world)
-            off = 0
-            for p in self.params:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+        self.ddp.finish()   # gradients only
         self.opt.step()
         return loss
 
@@ -137,6 +129,7 @@ class PVRCNNTrainWorkload(object):
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.opt = torch.optim.AdamW(self.params, lr=lr, betas=(0.95, 0.99), weight_decay=0.01)
         self.world = 1
+        self.ddp = FlatGradDDP(self.model, broadcast=False)
         self.last_loss = None
 
     def describe(self):
@@ -147,29 +140,19 @@ class PVRCNNTrainWorkload(object):
                 'KITTI-shaped synthetic, bs=%d/GPU, 13.1 M params' % len(self.frames))
 
     def enable_ddp(self):
+        """One flat gradient arena + bucketed asynchronous all-reduce (mm3d/parallel.py)."""
         self.world = dist.get_world_size()
-        flat = torch.cat([p.data.view(-1) for p in self.params])
-        dist.broadcast(flat, 0)
-        off = 0
-        for p in self.params:
-            p.data.copy_(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        self.ddp.world = self.world
+        self.ddp.broadcast_parameters(0)
 
     def step(self):
         self.model.train()
         out = self.model.forward_train(self.points, self.img_metas, self.gt_boxes, self.gt_labels)
         loss = out['loss']
-        self.opt.zero_grad(set_to_none=False)
+        self.ddp.zero_grad()
         loss.backward()
-        if self.world > 1:  # gradients only, one flat bucket
-            flat = torch.cat([p.grad.view(-1) for p in self.params])
-            dist.all_reduce(flat)
-            flat.div_(self.world)
-            off = 0
-            for p in self.params:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-        torch.nn.utils.clip_grad_norm_(self.params, 10.0)
+        self.ddp.finish()   # gradients only (SURVEY 8e)
+        self.ddp.clip_grad_norm_(10.0)
         self.opt.step()
         self.last_loss = loss.detach()
         return loss
@@ -192,3 +175,80 @@ class PVRCNNTrainWorkload(object):
             if cin >= 16:
                 bwd.append((cout, cin, n_in[key], kvol, P[key]))
         return fwd + bwd[::-1]
+
+
+class _RepeatLoader(object):
+    """Endless loader over one synthetic batch; every iteration gets FRESH dict shells (the SSL
+    modules add keys to the batch dicts and mlvl_set refuses to overwrite)."""
+
+    def __init__(self, samples):
+        self.samples = samples
+
+    def __iter__(self):
+        while True:
+            yield {k: (dict(v) if isinstance(v, dict) else v) for k, v in self.samples.items()}
+
+
+class DetMatchTrainWorkload(object):
+    """BASELINE.json configs[2]: one full DetMatch iteration (configs/detmatch/001/detmatch/
+    split_0.py) per step, bs labeled + bs unlabeled samples per GPU:
+      labeled:   student PV-RCNN supervised loss, student Faster R-CNN supervised loss;
+      unlabeled: teacher PV-RCNN + teacher Faster R-CNN inference (eval mode), 3D<->2D Hungarian
+                 matching, hard pseudo-label training of both students, 2D<->3D box consistency;
+      teacher EMA (fused, flat arenas), backward, gradient exchange, clip (L2 10), HybridOptimizer
+      (AdamW 3D / SGD 2D), linear LR warm-up — driven by IterBasedSSLRunner exactly as
+      mmdet3d/apis/ssl_train.py would.  `ssl_cfg='confthr_pvrcnn'` selects the 3D-only recipe."""
+
+    def __init__(self, batch_size, device, seed=0, ssl_cfg=None):
+        from .. import configs
+        from ..mm3d import register_all
+        from ..mm3d import runner as R
+        from ..mm3d.ssl import SSL
+        register_all()
+        self.batch_size, self.device = batch_size, device
+        self.recipe = ssl_cfg or 'detmatch'
+        chain = configs.confthr_pvrcnn_ssl_cfg() if ssl_cfg == 'confthr_pvrcnn' else \
+            configs.detmatch_ssl_cfg(with_vis=False)
+        cfg = configs.detmatch_kitti_model(ssl_cfg=chain)
+        cfg.pop('type')
+        torch.manual_seed(0)
+        self.model = SSL(**cfg).to(device)
+        # teacher starts as a copy of the student (SSL._load_from_state_dict fan-out, ssl.py:102-127)
+        self.model.teacher.load_state_dict(self.model.student.state_dict())
+        with_img = True
+        data = synth.ssl_batch(batch_size, seed, device, with_img)
+        lab = dict(stu=data['lab_stu'], tea=data['lab_tea'], img_metas=data['img_metas'])
+        unlab = dict(stu=data['unlab_stu'], tea=data['unlab_tea'], img_metas=data['img_metas'])
+        self.lab_iter = iter(_RepeatLoader(lab))
+        self.unlab_iter = iter(_RepeatLoader(unlab))
+        sched = configs.detmatch_schedule(batch_size, 1)
+        self.ddp = FlatGradDDP(self.model, broadcast=False)
+        self.opt = R.build_optimizer(self.model, sched['optimizer'])
+        self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)
+        self.runner.register_training_hooks(sched['lr_config'], sched['optimizer_config'],
+                                            sched['custom_hooks'])
+        self.runner.call_hook('before_run')
+        self.world = 1
+        self.params = self.ddp.params
+        self.backbone = self.model.student.detector_3d.model.backbone_3d
+
+    def describe(self):
+        n = sum(p.numel() for p in self.params)
+        return ('DetMatch iteration (BASELINE configs[2], recipe %s): teacher+student PV-RCNN and '
+                'Faster R-CNN R50-FPN, pseudo-label path, fused EMA, backward, grad exchange, clip, '
+                'HybridOptimizer; KITTI-shaped synthetic, %d labeled + %d unlabeled per GPU, '
+                '%.1f M trainable params' % (self.recipe, self.batch_size, self.batch_size, n / 1e6))
+
+    def enable_ddp(self):
+        self.world = dist.get_world_size()
+        self.ddp.world = self.world
+        self.ddp.broadcast_parameters(0)
+        self.model.teacher.load_state_dict(self.model.student.state_dict())
+
+    def step(self):
+        self.runner.train(self.lab_iter, self.unlab_iter)
+        return self.runner.outputs['loss']
+
+    @property
+    def last_log(self):
+        return self.runner.outputs['log_vars']

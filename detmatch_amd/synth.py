@@ -160,3 +160,116 @@ def frame_to_mm3d_gt(frame):
     out = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 5] / 2, b[:, 4], b[:, 3], b[:, 5],
                     -b[:, 6] - np.pi / 2], axis=1).astype(np.float32)
     return out, _SIM_TO_CFG_LABEL[frame['gt_labels']]
+
+
+# ---------------------------------------------------------------------------------------------
+# DetMatch iteration inputs (SURVEY §8(b) "img_metas semantics", §8(d) "Batches")
+# ---------------------------------------------------------------------------------------------
+KITTI_ORI_SHAPE = (375, 1242, 3)
+KITTI_IMG_SHAPE = (384, 1280, 3)       # after Resize (keep_ratio) + Pad(32) in the synthetic setup
+IMG_MEAN_BGR = np.array([103.530, 116.280, 123.675], dtype=np.float32)   # caffe-style, std 1
+
+
+def _in_range(pts, pc_range):
+    return ((pts[:, 0] > pc_range[0]) & (pts[:, 1] > pc_range[1]) & (pts[:, 2] > pc_range[2]) &
+            (pts[:, 0] < pc_range[3]) & (pts[:, 1] < pc_range[4]) & (pts[:, 2] < pc_range[5]))
+
+
+def ssl_sample(seed, labeled, device='cpu', with_img=True):
+    """One TS_SSL_Dataset item (teacher_student_ssl_dataset.py:26-33): the shared pipeline (Resize,
+    RandomFlip3D with sync_2d) runs once, then the student pipeline (GlobalRotScaleTrans,
+    range filters, shuffle) and the teacher pipeline (range filter, shuffle) on copies.
+
+    Returns (stu, tea) dicts of torch tensors / LiDARInstance3DBoxes with the img_metas keys the
+    SSL modules consume.  Image augmentations that do not move boxes (colour jitter, erasing) are
+    represented by independent noise in the student image."""
+    import torch
+    from .mm3d.bbox_utils import bbox_2d_transform, bbox_3d_to_bbox_2d
+    from .mm3d.box3d import LiDARInstance3DBoxes
+    rng = np.random.default_rng(77_000 + seed)
+    frame = lidar_frame(seed)
+    pts = frame['points'].copy()
+    boxes_np, labels_np = frame_to_mm3d_gt(frame)
+    boxes = LiDARInstance3DBoxes(torch.from_numpy(boxes_np))
+    labels = torch.from_numpy(labels_np)
+    flip = bool(rng.random() < 0.5)
+    sx, sy = KITTI_IMG_SHAPE[1] / KITTI_ORI_SHAPE[1], KITTI_IMG_SHAPE[0] / KITTI_ORI_SHAPE[0]
+    meta = dict(sample_idx=int(seed), lidar2img=KITTI_LIDAR2IMG.copy(), ori_shape=KITTI_ORI_SHAPE,
+                img_shape=KITTI_IMG_SHAPE, pad_shape=KITTI_IMG_SHAPE,
+                scale_factor=np.array([sx, sy, sx, sy], dtype=np.float32), flip=flip,
+                pcd_horizontal_flip=flip, pcd_vertical_flip=False, box_type_3d=LiDARInstance3DBoxes,
+                transformation_3d_flow=['HF'] if flip else [], pcd_trans=np.zeros(3, np.float32),
+                pcd_scale_factor=1.0, pcd_rotation=np.eye(3, dtype=np.float32))
+    # ---- 2D GT: projected 3D GT on the original image, then Resize + flip -------------------
+    gt2d = gt2d_labels = None
+    if labeled:
+        b2d, valid = bbox_3d_to_bbox_2d(boxes, KITTI_LIDAR2IMG, KITTI_ORI_SHAPE)
+        wh_ok = ((b2d[:, 2] - b2d[:, 0]) > 2) & ((b2d[:, 3] - b2d[:, 1]) > 2)
+        keep = valid & wh_ok
+        gt2d = bbox_2d_transform(meta, b2d[keep], True)
+        gt2d_labels = labels[keep]
+    # ---- shared flip -------------------------------------------------------------------------
+    if flip:
+        pts[:, 1] = -pts[:, 1]
+        boxes.flip('horizontal')
+    tea_pts = pts[_in_range(pts, KITTI_RANGE)]
+    tea_pts = tea_pts[rng.permutation(len(tea_pts))]
+    # ---- student: GlobalRotScaleTrans(rot ±pi/4, scale .95-1.05, no translation) ------------
+    ang = float(rng.uniform(-0.78539816, 0.78539816))
+    c, s = np.cos(ang), np.sin(ang)
+    if labeled and len(boxes_np):      # transforms_3d.py:611-616: the box matrix (not transposed)
+        rot = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float32)
+    else:                              # :604-607: points.rotate(angle) returns the transposed one
+        rot = np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]], dtype=np.float32)
+    scale = float(rng.uniform(0.95, 1.05))
+    stu_pts = pts.copy()
+    stu_pts[:, :3] = (stu_pts[:, :3] @ rot) * scale
+    stu_meta = dict(meta)
+    stu_meta.update(pcd_rotation=rot, pcd_scale_factor=scale,
+                    transformation_3d_flow=list(meta['transformation_3d_flow']) + ['R', 'S', 'T'])
+    stu_boxes = boxes.clone()
+    stu_boxes.rotate(torch.from_numpy(rot))
+    stu_boxes.scale(scale)
+    stu_pts = stu_pts[_in_range(stu_pts, KITTI_RANGE)]
+    stu_pts = stu_pts[rng.permutation(len(stu_pts))]
+    stu = dict(points=torch.from_numpy(stu_pts).to(device), img_metas=stu_meta)
+    tea = dict(points=torch.from_numpy(tea_pts).to(device), img_metas=dict(meta))
+    if labeled:
+        bev = stu_boxes.bev
+        inr = ((bev[:, 0] > KITTI_RANGE[0]) & (bev[:, 1] > KITTI_RANGE[1]) &
+               (bev[:, 0] < KITTI_RANGE[3]) & (bev[:, 1] < KITTI_RANGE[4]))   # ObjectRangeFilter
+        sb = stu_boxes[inr]
+        sb.limit_yaw(offset=0.5, period=2 * np.pi)
+        stu['gt_bboxes_3d'] = sb.to(device)
+        stu['gt_labels_3d'] = labels[inr].to(device)
+        stu['gt_bboxes'] = gt2d.to(device)
+        stu['gt_labels'] = gt2d_labels.to(device)
+    if with_img:
+        base = kitti_image(seed, KITTI_IMG_SHAPE[:2]).astype(np.float32)
+        if flip:
+            base = base[:, ::-1]
+        tea_img = (base - IMG_MEAN_BGR).transpose(2, 0, 1)
+        noise = rng.normal(0, 8, size=base.shape).astype(np.float32)
+        stu_img = (np.clip(base + noise, 0, 255) - IMG_MEAN_BGR).transpose(2, 0, 1)
+        tea['img'] = torch.from_numpy(np.ascontiguousarray(tea_img)).to(device)
+        stu['img'] = torch.from_numpy(np.ascontiguousarray(stu_img)).to(device)
+    return stu, tea
+
+
+def _collate(samples):
+    import torch
+    out = dict()
+    for k in samples[0].keys():
+        vals = [s[k] for s in samples]
+        out[k] = torch.stack(vals, dim=0) if k == 'img' else vals
+    return out
+
+
+def ssl_batch(batch_size, seed=0, device='cpu', with_img=True):
+    """The data_batch IterBasedSSLRunner.train assembles (iter_based_ssl_runner.py:21-27): `batch_size`
+    labeled + `batch_size` unlabeled samples, keys lab_stu / lab_tea / unlab_stu / unlab_tea."""
+    lab = [ssl_sample(seed + i, True, device, with_img) for i in range(batch_size)]
+    unlab = [ssl_sample(seed + 1000 + i, False, device, with_img) for i in range(batch_size)]
+    return dict(lab_stu=_collate([s for s, _ in lab]), lab_tea=_collate([t for _, t in lab]),
+                unlab_stu=_collate([s for s, _ in unlab]), unlab_tea=_collate([t for _, t in unlab]),
+                img_metas=[s['img_metas'] for s, _ in lab])

@@ -218,6 +218,31 @@ int dm_nms_2d(const float *boxes_xyxy, int n, float thresh, int max_keep, long l
               int *num_keep, void *workspace, size_t workspace_bytes, dm_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
+/* G. 2D branch: RoIAlign over an FPN pyramid                                 */
+/* ------------------------------------------------------------------------ */
+/* Replaces mmcv.ops.RoIAlign (mmcv-full 1.3.16, un-vendored: "parity unpinned") as driven by
+ * mmdet SingleRoIExtractor — configs/detmatch/001/detmatch/split_0.py:76-80,
+ * mmdet3d/models/ssl_modules/processors/processors_2d.py:52-54.  avg pooling;
+ * aligned != 0: pixel-centre shift -0.5, no minimum RoI size; sampling_ratio 0 = adaptive
+ * ceil(roi / pooled).  feats_host[l]: device pointers (NCHW fp32) of the n_levels (<= 8)
+ * maps; the three *_host arrays are HOST arrays of length n_levels; rois (R,5) device
+ * [batch_idx, x1, y1, x2, y2]; roi_levels (R) device int32 (NULL = all level 0);
+ * out (R, C, pooled_h, pooled_w).  max_grid: LDS sizing hint (samples per bin per axis,
+ * 0 = default); RoIs needing more still produce exact results on a slower path. */
+int dm_roi_align_forward(const float *const *feats_host, const int *heights_host,
+                         const int *widths_host, const float *scales_host, int n_levels,
+                         int channels, const float *rois, const int *roi_levels, int n_rois,
+                         int pooled_h, int pooled_w, int sampling_ratio, int aligned, int max_grid,
+                         float *out, dm_stream_t stream);
+/* grads_host[l]: device pointers of the per-level input gradients, ACCUMULATED into (float
+ * atomics; the caller zero-fills them). */
+int dm_roi_align_backward(float *const *grads_host, const int *heights_host,
+                          const int *widths_host, const float *scales_host, int n_levels,
+                          int channels, const float *rois, const int *roi_levels, int n_rois,
+                          int pooled_h, int pooled_w, int sampling_ratio, int aligned, int max_grid,
+                          const float *grad_out, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* H. Teacher-student support: fused EMA, host LAP                            */
 /* ------------------------------------------------------------------------ */
 /* Replaces SSL._update_teacher (mmdet3d/models/detectors/ssl.py:146-163) over flat,

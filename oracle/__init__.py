@@ -233,3 +233,27 @@ def points_in_boxes(points, boxes):
     lib().orc_points_in_boxes(b, boxes.shape[1], p, _p(boxes, _f32p), _p(points, _f32p),
                               _p(out, _i32p))
     return out
+
+
+def roi_align(feat, rois, spatial_scale, out_size=7, sampling_ratio=0, aligned=True):
+    """feat (N,C,H,W), rois (R,5) -> (R,C,out,out); mmcv RoIAlign avg (parity unpinned)."""
+    feat, rois = _f32(feat), _f32(rois)
+    n, c, h, w = feat.shape
+    r = rois.shape[0]
+    out = np.zeros((r, c, out_size, out_size), np.float32)
+    lib().orc_roi_align_forward(_p(feat, _f32p), c, h, w, _p(rois, _f32p), r,
+                                ctypes.c_float(spatial_scale), out_size, out_size, sampling_ratio,
+                                int(aligned), _p(out, _f32p))
+    return out
+
+
+def roi_align_grad(grad_out, feat_shape, rois, spatial_scale, sampling_ratio=0, aligned=True):
+    """-> d feat (N,C,H,W) float64"""
+    grad_out, rois = _f32(grad_out), _f32(rois)
+    n, c, h, w = feat_shape
+    r, _, ph, pw = grad_out.shape
+    g = np.zeros(feat_shape, np.float64)
+    lib().orc_roi_align_backward(_p(grad_out, _f32p), c, h, w, _p(rois, _f32p), r,
+                                 ctypes.c_float(spatial_scale), ph, pw, sampling_ratio, int(aligned),
+                                 g.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return g

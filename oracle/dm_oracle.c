@@ -699,3 +699,93 @@ void orc_points_in_boxes(int batch, int nboxes, int npts, const float *boxes,
       box_idx[(size_t)bi * npts + p] = res;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * RoIAlign (avg) — mmcv.ops.RoIAlign as configured at configs/detmatch/001/detmatch/split_0.py:78
+ * (output_size 7, sampling_ratio 0, aligned default True).  The algorithm lives in mmcv-full
+ * 1.3.16 (mmcv/ops/csrc/roi_align_cuda_kernel.cuh), absent from /root/reference: PARITY UNPINNED.
+ * ------------------------------------------------------------------------------------------ */
+static int orc_ra_tap(float p, int size, int *lo, int *hi, float *wl, float *wh) {
+  if (p < -1.0f || p > (float)size) return 0;
+  if (p <= 0.0f) p = 0.0f;
+  *lo = (int)p;
+  if (*lo >= size - 1) {
+    *hi = *lo = size - 1;
+    p = (float)*lo;
+  } else {
+    *hi = *lo + 1;
+  }
+  float l = p - (float)*lo;
+  *wl = 1.0f - l;
+  *wh = l;
+  return 1;
+}
+
+static void orc_roi_align_impl(const float *feat, const float *gout, double *gfeat, int c, int h,
+                               int w, const float *rois, int r, float scale, int ph, int pw,
+                               int sampling_ratio, int aligned, float *out) {
+  for (int n = 0; n < r; ++n) {
+    const float *roi = rois + (size_t)n * 5;
+    int batch = (int)roi[0];
+    float off = aligned ? 0.5f : 0.0f;
+    float sw = roi[1] * scale - off, sh = roi[2] * scale - off;
+    float ew = roi[3] * scale - off, eh = roi[4] * scale - off;
+    float rw = ew - sw, rh = eh - sh;
+    if (!aligned) {
+      rw = fmaxf(rw, 1.0f);
+      rh = fmaxf(rh, 1.0f);
+    }
+    float bh = rh / (float)ph, bw = rw / (float)pw;
+    int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph);
+    int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw);
+    float count = (float)(gh * gw > 1 ? gh * gw : 1);
+    for (int ch = 0; ch < c; ++ch) {
+      size_t plane = ((size_t)batch * c + ch) * h * w;
+      for (int by = 0; by < ph; ++by)
+        for (int bx = 0; bx < pw; ++bx) {
+          size_t oidx = (((size_t)n * c + ch) * ph + by) * pw + bx;
+          double acc = 0.0;
+          for (int iy = 0; iy < gh; ++iy) {
+            float y = sh + (float)by * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            int yl, yh;
+            float wyl, wyh;
+            if (!orc_ra_tap(y, h, &yl, &yh, &wyl, &wyh)) continue;
+            for (int ix = 0; ix < gw; ++ix) {
+              float x = sw + (float)bx * bw + ((float)ix + 0.5f) * bw / (float)gw;
+              int xl, xh;
+              float wxl, wxh;
+              if (!orc_ra_tap(x, w, &xl, &xh, &wxl, &wxh)) continue;
+              float w1 = wyl * wxl, w2 = wyl * wxh, w3 = wyh * wxl, w4 = wyh * wxh;
+              if (feat) {
+                acc += (double)w1 * feat[plane + (size_t)yl * w + xl] +
+                       (double)w2 * feat[plane + (size_t)yl * w + xh] +
+                       (double)w3 * feat[plane + (size_t)yh * w + xl] +
+                       (double)w4 * feat[plane + (size_t)yh * w + xh];
+              } else {
+                double g = (double)gout[oidx] / count;
+                gfeat[plane + (size_t)yl * w + xl] += g * w1;
+                gfeat[plane + (size_t)yl * w + xh] += g * w2;
+                gfeat[plane + (size_t)yh * w + xl] += g * w3;
+                gfeat[plane + (size_t)yh * w + xh] += g * w4;
+              }
+            }
+          }
+          if (feat) out[oidx] = (float)(acc / count);
+        }
+    }
+  }
+}
+
+void orc_roi_align_forward(const float *feat, int c, int h, int w, const float *rois, int r,
+                           float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
+                           float *out) {
+  orc_roi_align_impl(feat, NULL, NULL, c, h, w, rois, r, spatial_scale, ph, pw, sampling_ratio,
+                     aligned, out);
+}
+
+void orc_roi_align_backward(const float *grad_out, int c, int h, int w, const float *rois, int r,
+                            float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
+                            double *grad_feat) {
+  orc_roi_align_impl(NULL, grad_out, grad_feat, c, h, w, rois, r, spatial_scale, ph, pw,
+                     sampling_ratio, aligned, NULL);
+}

@@ -95,6 +95,17 @@ void orc_furthest_point_sampling(int b, int n, int m, const float *xyz, float *t
 void orc_points_in_boxes(int batch, int nboxes, int npts, const float *boxes,
                          const float *pts, int32_t *box_idx);
 
+/* mmcv.ops.RoIAlign, pool_mode 'avg' (mmcv-full 1.3.16 is NOT under /root/reference: restated from
+ * the published Detectron2/mmcv algorithm — PARITY UNPINNED).  One feature map (N,C,H,W);
+ * rois (R,5) [batch, x1, y1, x2, y2]; out (R,C,ph,pw).  Accumulates in double. */
+void orc_roi_align_forward(const float *feat, int c, int h, int w, const float *rois, int r,
+                           float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
+                           float *out);
+/* grad_feat (N,C,H,W) double accumulators, caller-zeroed */
+void orc_roi_align_backward(const float *grad_out, int c, int h, int w, const float *rois, int r,
+                            float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
+                            double *grad_feat);
+
 #ifdef __cplusplus
 }
 #endif

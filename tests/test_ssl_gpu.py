@@ -1,0 +1,82 @@
+"""GPU tests of the teacher-student step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_ema_matches_per_tensor_formula(dev):
+    """dm_ema_update_* over the flat arenas == ssl.py:146-163 applied entry by entry, including
+    BN running stats and integer buffers (float math, truncated back)."""
+    import torch.nn as nn
+    from detmatch_amd.mm3d.ssl import SSL, _Arena
+    torch.manual_seed(0)
+
+    def net():
+        return nn.Sequential(nn.Conv2d(3, 5, 3), nn.BatchNorm2d(5), nn.Linear(7, 3)).to(dev)
+    t, s = net(), net()
+    with torch.no_grad():
+        s[1].running_mean.normal_(); s[1].running_var.uniform_(0.5, 2)
+        s[1].num_batches_tracked.fill_(1001); t[1].num_batches_tracked.fill_(10)
+    ssl = SSL.__new__(SSL)
+    nn.Module.__init__(ssl)
+    ssl.teacher, ssl.student = t, s
+    ssl.ema_params = dict(ema_decay=0.999, true_avg_rampup=True, rampup_start_decay=0.99)
+    ssl.rampup_start_decay, ssl.use_student_bn_stats_for_teacher, ssl._arenas = 0.99, False, None
+    ssl.iter = 17
+    d = ssl._get_curr_ema_decay()
+    want = {k: (s.state_dict()[k] * (1 - d) + v * d) for k, v in t.state_dict().items()}
+    x = torch.randn(2, 3, 9, 9, device=dev)
+    ssl._update_teacher()
+    for k, v in t.state_dict().items():
+        if v.dtype == torch.int64:
+            assert int(v) == int(want[k].to(torch.int64)), k        # 10*d + 1001*(1-d) -> trunc
+        else:
+            assert torch.allclose(v, want[k], rtol=1e-6, atol=1e-7), k
+    # parameters still work as module parameters after re-homing into the arena
+    assert torch.isfinite(t[0](x)).all()
+    ssl._update_teacher()   # second call reuses the arenas
+
+
+def test_detmatch_confthr_iteration(dev):
+    """3D-only SSL recipe (configs/detmatch/001/confthr_pvrcnn): two full iterations."""
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    wl = DetMatchTrainWorkload(2, dev, ssl_cfg='confthr_pvrcnn')
+    t0 = wl.model.teacher.detector_3d.model.backbone_3d.conv_input[0].weight.detach().clone()
+    s0 = wl.model.student.detector_3d.model.backbone_3d.conv_input[0].weight.detach().clone()
+    assert torch.equal(t0, s0)
+    for _ in range(2):
+        loss = wl.step()
+        assert torch.isfinite(loss)
+    log = wl.last_log
+    for k in ('sup.sup_3d.loss', 'ssl.unlab.hard_pseudo_3d.loss', 'ssl.unlab.metrics.tea', 'ssl.weight',
+              'ssl.ema_decay', 'loss'):
+        assert k in log, (k, list(log))
+    s1 = wl.model.student.detector_3d.model.backbone_3d.conv_input[0].weight.detach()
+    t1 = wl.model.teacher.detector_3d.model.backbone_3d.conv_input[0].weight.detach()
+    assert not torch.equal(s1, s0)
+    # teacher after 2 iterations: EMA ran at the start of iteration 2 with d = 1 - 1/100 on the
+    # student of iteration 1 (iteration 1's EMA saw identical weights)
+    assert not torch.equal(t1, t0) and (t1 - t0).abs().max() < (s1 - s0).abs().max()
+    assert wl.model.iter == 1 and not wl.model.teacher.training
+
+
+def test_detmatch_full_iteration(dev):
+    """Full DetMatch recipe (2D + 3D, Hungarian matching, consistency): one iteration."""
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    wl = DetMatchTrainWorkload(2, dev)
+    loss = wl.step()
+    assert torch.isfinite(loss)
+    log = wl.last_log
+    want = ['sup.sup_3d.loss', 'sup.stu.loss_rpn_cls', 'sup.stu.loss_rpn_bbox', 'sup.stu.loss_cls',
+            'sup.stu.acc', 'sup.stu.loss_bbox', 'ssl.unlab.hard_pseudo_3d.loss',
+            'ssl.unlab.hard_pseudo_2d.loss_rpn_cls', 'ssl.unlab.hard_pseudo_2d.loss_cls',
+            'ssl.unlab.hard_pseudo_2d.acc', 'ssl.unlab.2D_to_3D_hung.cls_loss',
+            'ssl.unlab.2D_to_3D_hung.l1_loss', 'ssl.unlab.2D_to_3D_hung.iou_loss',
+            'ssl.unlab.metrics.num_tea_hung', 'ssl.unlab.metrics.2D_to_3D_hung']
+    for k in want:
+        assert k in log and torch.isfinite(log[k]), (k, sorted(log))
+    assert 'ssl.unlab.hard_pseudo_2d.loss_bbox' not in log      # detached by the recipe
+    loss2 = wl.step()
+    assert torch.isfinite(loss2)

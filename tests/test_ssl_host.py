@@ -1,0 +1,261 @@
+"""CPU tests of the teacher-student host layer: Hungarian matching against
+the reference-generated fixture, SSL scalar schedules, loss bookkeeping, SSL modules that are pure
+tensor glue, the hybrid optimizer, the LR warm-up and the iteration runner."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from detmatch_amd.mm3d import losses as L
+from detmatch_amd.mm3d import runner as R
+from detmatch_amd.mm3d import ssl_modules as M
+from detmatch_amd.mm3d.registry import build_assigner
+from detmatch_amd.mm3d.ssl import SSL
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'hungarian.npz')
+
+ASSIGNER_CFG = dict(type='ModHungarianAssigner',
+                    cls_cost=dict(type='DoubleSidedFocalLossCost', weight=2.0),
+                    reg_cost=dict(type='BBoxL1Cost', weight=5.0),
+                    iou_cost=dict(type='IoUCost', iou_mode='giou', weight=2.0))
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(GOLDEN)
+
+
+def test_lap_matches_scipy_fixture(gold):
+    """dm_lap_host == scipy.optimize.linear_sum_assignment on the stored cost matrices: the
+    assignment is bit-exact (same (row, col) pairs)."""
+    names = ['l%d' % i for i in range(int(gold['n_lap']))] + \
+            ['c%d' % i for i in range(int(gold['n_cases'])) if ('c%d_cost' % i) in gold]
+    for n in names:
+        rows, cols = L.linear_sum_assignment(torch.from_numpy(gold[n + '_cost']))
+        assert np.array_equal(rows, gold[n + '_rows']), n
+        assert np.array_equal(cols, gold[n + '_cols']), n
+
+
+def test_mod_hungarian_assigner_matches_reference(gold):
+    assigner = build_assigner(ASSIGNER_CFG)
+    meta = dict(img_shape=(375, 1242, 3))
+    for ci in range(int(gold['n_cases'])):
+        g = lambda k: torch.from_numpy(gold['c%d_%s' % (ci, k)])
+        res = assigner.assign(g('pred_norm'), g('pred_logits'), g('gt'), g('gt_logits'), meta)
+        assert np.array_equal(res.gt_inds.numpy(), gold['c%d_gt_inds' % ci]), ci
+        if bool(gold['c%d_has_cost' % ci]):
+            np.testing.assert_allclose(res.max_overlaps.numpy(), gold['c%d_max_overlaps' % ci],
+                                       rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(res.iou_cost.numpy(), gold['c%d_iou_cost' % ci],
+                                       rtol=1e-5, atol=1e-6)
+        else:
+            assert res.max_overlaps is None
+
+
+def test_lap_nan_is_an_error():
+    c = torch.tensor([[1.0, float('nan')], [0.5, 2.0]])
+    with pytest.raises(ValueError):
+        L.linear_sum_assignment(c)
+
+
+# ---------------------------------------------------------------- SSL scalar schedules
+class _Dummy(nn.Module):
+    def __init__(self, **kw):
+        super().__init__()
+        self.w = nn.Parameter(torch.ones(3))
+
+
+def _bare_ssl(ema=None, weight=None):
+    s = SSL.__new__(SSL)
+    nn.Module.__init__(s)
+    s.ema_params = ema or dict(ema_decay=0.999, true_avg_rampup=True, rampup_start_decay=0.99)
+    s.ema_decay = s.ema_params['ema_decay']
+    s.rampup_start_decay = s.ema_params.get('rampup_start_decay', 0.5)
+    wp = weight or dict(weight=1)
+    s.ssl_weight = wp['weight']
+    s.ssl_weight_rampup_start_iter = wp.get('weight_rampup_start_iter', 0)
+    s.ssl_weight_rampup_num_iter = wp.get('weight_rampup_num_iter', 0)
+    s.iter = 0
+    return s
+
+
+def test_ema_decay_sequence():
+    """ssl.py:129-144 with the DetMatch config: d_t = min(1 - 1/(t + 100), 0.999)."""
+    s = _bare_ssl()
+    for it in (0, 1, 10, 899, 900, 901, 5000):
+        s.iter = it
+        assert s._get_curr_ema_decay() == pytest.approx(min(1 - 1 / (it + 100), 0.999), abs=1e-12)
+    s = _bare_ssl(ema=dict(ema_decay=0.99))
+    s.iter = 3
+    assert s._get_curr_ema_decay() == 0.99
+    # rampup_start_decay 0.5 -> start iter max(round(2), 2) = 2
+    s = _bare_ssl(ema=dict(ema_decay=0.999, true_avg_rampup=True, rampup_start_decay=0.5))
+    s.iter = 0
+    assert s._get_curr_ema_decay() == pytest.approx(0.5)
+
+
+def test_ssl_weight_ramp():
+    """ssl.py:165-181: w * exp(-5 (1 - t)^2), 0 before the start iteration."""
+    s = _bare_ssl(weight=dict(weight=2.0, weight_rampup_start_iter=10, weight_rampup_num_iter=100))
+    s.iter = 5
+    assert s._get_curr_ssl_weight() == 0.0
+    s.iter = 10
+    assert s._get_curr_ssl_weight() == pytest.approx(2.0 * math.exp(-5.0))
+    s.iter = 60
+    assert s._get_curr_ssl_weight() == pytest.approx(2.0 * math.exp(-5.0 * 0.25))
+    s.iter = 500
+    assert s._get_curr_ssl_weight() == pytest.approx(2.0)
+    s = _bare_ssl()
+    assert s._get_curr_ssl_weight() == 1
+
+
+def test_loss_bookkeeping():
+    s = _bare_ssl()
+    a = dict(x=torch.tensor([1.0, 3.0]), y=[torch.tensor([2.0, 4.0]), torch.tensor(1.0)])
+    c = s._collapse_losses(dict(a))
+    assert float(c['x']) == 2.0 and float(c['y']) == 4.0
+    out = s._sum_update_losses(dict(x=torch.tensor(1.0)), dict(x=torch.tensor([2.0, 4.0]), z=torch.tensor(5.0)))
+    assert float(out['x']) == 4.0 and float(out['z']) == 5.0
+    with pytest.raises(TypeError):
+        s._collapse_losses(dict(bad=3.0))
+    loss, log = s._parse_losses({'sup.stu.loss_cls': torch.tensor([1.0, 2.0]),
+                                 'ssl.unlab.metrics.tea': torch.tensor(7.0),
+                                 'ssl.lab.hp.loss': [torch.tensor(2.0)], 'ssl.weight': torch.tensor(1.0)})
+    assert float(loss) == pytest.approx(3.5)
+    assert float(log['loss']) == pytest.approx(3.5) and float(log['ssl.unlab.metrics.tea']) == 7.0
+
+
+# ---------------------------------------------------------------- tensor-glue SSL modules
+def test_max_score_filter_detach_average_numpreds():
+    boxes = torch.arange(20.0).view(5, 4).requires_grad_()
+    scores = torch.tensor([[.9, .0, .0, .1], [.05, .02, .0, .95], [.0, .3, .0, .7], [.0, .0, .0, 1.],
+                           [.0, .0, .11, .0]])
+    bd = dict(tea={'in': [(boxes, scores), (boxes[:0], scores[:0])]}, ssl_losses=dict())
+    M.MaxScoreFilter(True, 0.1, 'tea.in', 'tea.out').forward(None, bd)
+    assert bd['tea']['out'][0][0].shape[0] == 3 and bd['tea']['out'][1][0].shape[0] == 0
+    with pytest.raises(Exception):   # mlvl_set refuses to overwrite
+        M.MaxScoreFilter(True, 0.1, 'tea.in', 'tea.out').forward(None, bd)
+    M.DetachBboxes('tea.out', 'tea.dt').forward(None, bd)
+    assert not bd['tea']['dt'][0][0].requires_grad and bd['tea']['out'][0][0].requires_grad
+    M.AverageBboxes_2D(True, False, 'tea.in', 'tea.in2', 'tea.avg').forward(
+        None, dict(tea=bd['tea'], **{}) if bd['tea'].update({'in2': [(boxes + 2, scores[:, :3]),
+                                                                  (boxes[:0], scores[:0, :3])]}) is None else None)
+    assert torch.allclose(bd['tea']['avg'][0][0], boxes + 1)
+    assert torch.allclose(bd['tea']['avg'][0][1], scores[:, :3])
+    M.NumPreds('tea.out', 'n').forward(None, bd)
+    assert float(bd['ssl_losses']['metrics.n']) == 1.5
+
+
+def test_fusion_hungarian_matching_2d_to_2d():
+    """project_3d_to_2d=False path: plain 2D<->2D matching, cost_thr drops bad pairs, outputs
+    index-aligned."""
+    mod = M.FusionHungarianMatching(
+        assigner_cfg=ASSIGNER_CFG, cost_thr=-1.5, img_metas='stu.img_metas',
+        cls_includes_bg_pred_3d=False, cls_includes_bg_pred_2d=True,
+        in_bboxes_3d_key='stu.a', in_bboxes_2d_key='tea.b', out_bboxes_3d_key='stu.a_m',
+        out_bboxes_2d_key='tea.b_m', match_cost_key='stu.cost', project_3d_to_2d=False)
+    a = torch.tensor([[100., 100., 200., 200.], [600., 50., 700., 300.], [900., 10., 950., 60.]])
+    sa = torch.tensor([[.9, .05, .05], [.1, .8, .1], [.3, .3, .4]])
+    b = torch.tensor([[598., 52., 702., 297.], [101., 99., 199., 202.]])
+    sb = torch.tensor([[.1, .9, .05, .0], [.95, .02, .02, .0]])
+    meta = dict(ori_shape=(375, 1242, 3))
+    bd = dict(stu=dict(a=[(a, sa), (a[:0], sa[:0])], img_metas=[meta, meta]),
+              tea=dict(b=[(b, sb), (b, sb)]))
+    mod.forward(None, bd)
+    m3, m2 = bd['stu']['a_m'][0], bd['tea']['b_m'][0]
+    assert torch.equal(m3[0], a[:2]) and torch.equal(m2[0], b[[1, 0]])
+    assert torch.equal(m2[1], sb[[1, 0]]) and (bd['stu']['cost'][0] < -1.5).all()
+    assert bd['stu']['a_m'][1][0].shape[0] == 0 and bd['tea']['b_m'][1][0].shape[0] == 0
+
+
+def test_hungarian_consistency_losses():
+    mod = M.HungarianConsistency(
+        loss_cls_cfg=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25),
+        loss_iou_cfg=dict(type='GIoULoss'), loss_l1_cfg=dict(type='L1Loss'),
+        loss_weights_cfg=dict(cls_loss=2, l1_loss=20, iou_loss=2),
+        in_bboxes_key='stu.p', target_bboxes_key='tea.t', cls_includes_bg_pred_in=False,
+        cls_includes_bg_pred_target=True, target_img_metas_key='stu.img_metas', name='cons')
+    p = torch.tensor([[100., 100., 200., 200.]], requires_grad=True)
+    ps = torch.tensor([[.8, .1, .1]], requires_grad=True)
+    t = torch.tensor([[110., 100., 200., 220.]])
+    ts = torch.tensor([[.9, .05, .05, .0]])
+    meta = dict(img_shape=(375, 1242, 3))
+    bd = dict(stu=dict(p=[(p, ps), (p[:0], ps[:0])], img_metas=[meta, meta]),
+              tea=dict(t=[(t, ts), (t[:0], ts[:0])]), ssl_losses=dict())
+    bd = mod.forward(_bare_ssl(), bd)
+    out = bd['ssl_losses']
+    l1 = (10 / 1242 + 20 / 375) / 4 * 20
+    assert float(out['cons.l1_loss'].detach()) == pytest.approx(l1, rel=1e-5)
+    inter, union, enc = 90 * 100, 100 * 100 + 90 * 120 - 90 * 100, 100 * 120
+    giou = inter / union - (enc - union) / enc
+    assert float(out['cons.iou_loss']) == pytest.approx(2 * (1 - giou), rel=1e-5)
+    assert float(out['cons.cls_loss']) > 0
+    (out['cons.cls_loss'] + out['cons.l1_loss'] + out['cons.iou_loss']).backward()
+    assert p.grad.abs().sum() > 0 and ps.grad.abs().sum() > 0
+    # no pairs at all -> zero-valued losses that still carry requires_grad
+    bd2 = dict(stu=dict(p=[(p[:0], ps[:0])], img_metas=[meta]), tea=dict(t=[(t[:0], ts[:0])]),
+               ssl_losses=dict())
+    out2 = mod.forward(_bare_ssl(), bd2)['ssl_losses']
+    assert float(out2['cons.l1_loss']) == 0.0 and out2['cons.l1_loss'].requires_grad
+
+
+# ---------------------------------------------------------------- optimizer / schedule / runner
+class _Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.student = nn.ModuleDict(dict(detector_3d=nn.Linear(2, 2), detector_2d=nn.Linear(2, 1)))
+        self.teacher = nn.ModuleDict(dict(detector_3d=nn.Linear(2, 2), detector_2d=nn.Linear(2, 1)))
+        self.iter, self.epoch, self.seen = None, None, []
+
+    def train_step(self, data, optimizer=None):
+        self.seen.append(self.iter)
+        x = data['lab_stu']
+        loss = self.student['detector_3d'](x).square().mean() + self.student['detector_2d'](x).square().mean()
+        return dict(loss=loss, log_vars=dict(loss=loss.detach()), num_samples=len(data['img_metas']))
+
+
+OPT_CFG = {'constructor': 'HybridOptimizerConstructor',
+           'student.detector_3d': dict(type='AdamW', lr=0.02, betas=(0.95, 0.99), weight_decay=0.01,
+                                       step_interval=1),
+           'student.detector_2d': dict(type='SGD', lr=0.04, momentum=0.9, weight_decay=0.0001,
+                                       step_interval=2),
+           'teacher': dict(type='SGD', lr=1e-9, momentum=0.9, weight_decay=0.0001, step_interval=1)}
+
+
+def test_hybrid_optimizer_and_runner():
+    torch.manual_seed(0)
+    model = _Toy()
+    opt = R.build_optimizer(model, OPT_CFG)
+    assert isinstance(opt, R.HybridOptimizer) and len(opt.optimizers) == 3
+    assert isinstance(opt.optimizers[0], torch.optim.AdamW) and opt.step_intervals == [1, 2, 1]
+    assert sum(len(g['params']) for g in opt.optimizers[0].param_groups) == 2
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    run = R.IterBasedSSLRunner(model, optimizer=opt, max_iters=6)
+    run.register_training_hooks(
+        lr_config=dict(policy='step', warmup='linear', warmup_iters=4, warmup_ratio=0.001, step=[]),
+        optimizer_config=dict(grad_clip=dict(max_norm=10, norm_type=2)),
+        custom_hooks=[dict(type='ModelIterEpochHook'), dict(type='WandbVisHook')])
+    lrs = []
+
+    class Spy(R.Hook):
+        def after_train_iter(self, runner):
+            lrs.append(runner.optimizer.optimizers[0].param_groups[0]['lr'])
+    run.register_hook(Spy())
+    lab = [dict(stu=torch.randn(4, 2), img_metas=[0, 1])] * 2
+    unlab = [dict(stu=torch.randn(4, 2), img_metas=[0, 1])] * 3
+    w2d = model.student['detector_2d'].weight.detach().clone()
+    run.run([lab, unlab], [('train', 2)])
+    assert run.iter == 6
+    # model.iter lags by one: after_train_iter runs BEFORE the runner increments its counter
+    # (iter_based_ssl_runner.py:37-39), so iterations 0 and 1 both see 0
+    assert model.seen == [0, 0, 1, 2, 3, 4] and model.iter == 5
+    expect = [0.02 * (1 - (1 - it / 4) * (1 - 0.001)) if it < 4 else 0.02 for it in range(6)]
+    assert lrs == pytest.approx(expect)
+    assert opt.num_step_updated == 6 and not torch.equal(w2d, model.student['detector_2d'].weight)
+    assert 'grad_norm' in run.log_buffer and len(run.log_buffer['loss']) == 6
+    with pytest.raises(AssertionError):   # a parameter no optimizer key matches
+        R.HybridOptimizerConstructor({'student': dict(type='SGD', lr=0.1)})(model)
