@@ -70,13 +70,15 @@ class ResNet(nn.Module):
     arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
     def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1,
-                 norm_cfg=None, norm_eval=True, style='pytorch', init_cfg=None, **kwargs):
+                 norm_cfg=None, norm_eval=True, style='pytorch', init_cfg=None,
+                 zero_init_residual=True, **kwargs):
         super().__init__()
         assert style == 'caffe' and norm_eval and norm_cfg is not None and \
             not norm_cfg.get('requires_grad', True), \
             'only the DetMatch configuration (caffe style, frozen eval-mode BN) is built'
         self.out_indices = out_indices
         self.frozen_stages = frozen_stages
+        self.zero_init_residual = zero_init_residual
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = FrozenBN(64)
         inplanes = 64
@@ -93,9 +95,15 @@ class ResNet(nn.Module):
         self.init_weights()
 
     def init_weights(self):
+        """mmdet ResNet.init_weights without a checkpoint: kaiming convs, unit BN, and
+        zero_init_residual (default True) zeroes the last BN scale of every bottleneck."""
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.zeros_(m.bn3.weight)
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:

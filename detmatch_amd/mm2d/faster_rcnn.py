@@ -143,7 +143,7 @@ def nms_fixed(boxes, scores, iou_thr, max_num):
     """Greedy NMS on the device -> (idx (max_num) into boxes, ok (max_num) bool), score order."""
     order = torch.sort(scores, descending=True, stable=True)[1]
     b = boxes[order].contiguous().float()
-    _lib.require_device(b, 'nms_2d')
+    _lib.require_device(b)
     n = b.shape[0]
     L = _lib.lib()
     keep = torch.zeros((max(n, max_num),), dtype=torch.int64, device=b.device)

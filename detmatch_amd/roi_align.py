@@ -24,7 +24,7 @@ class _RoIAlignFPN(Function):
 
     @staticmethod
     def forward(ctx, rois, levels, scales, out_size, sampling_ratio, aligned, *feats):
-        _lib.require_device(feats[0], 'roi_align')
+        _lib.require_device(feats[0])
         feats = [f.contiguous() for f in feats]
         assert all(f.dtype == torch.float32 and f.shape[1] == feats[0].shape[1] for f in feats)
         rois = rois.contiguous().float()
