@@ -1,4 +1,4 @@
-"""bench.py — train iters/sec of the DetMatch 3D hot path on synthetic KITTI-shaped data.
+"""bench.py — train iters/sec of the DetMatch training step on synthetic KITTI-shaped data.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -7,9 +7,12 @@ One JSON line on rank 0 (contract in the task description): metric/value/unit, r
 (dominant kernel, HIP events recorded by the library on the launch stream during the timed
 steps) and cpu_baseline (the oracle timed on the host cores, rank 0, N=1 only).
 
-The step is whatever stage of BASELINE.json configs[1] (PV-RCNN 3D supervised, KITTI 1 %,
-bs=2/GPU) is implemented natively so far — `config.workload` names it exactly.  Inputs
-(raw point clouds, GT boxes) are resident in HBM before the timed region.  Multi-GPU: the
+Workload (env DM_BENCH_WORKLOAD, named exactly in `config.workload`):
+  detmatch (default) the configuration the metric is quoted on: one full DetMatch iteration
+                     (2D+3D teacher-student, BASELINE.json configs[3] per-GPU shape, bs=2+2/GPU);
+  pvrcnn             BASELINE.json configs[1]: PV-RCNN 3D-only supervised step, bs=2;
+  confthr            configs[2]: 3D-only SSL (confthr_pvrcnn);   stage3d: voxelize+backbone only.
+Inputs (raw point clouds, images, GT boxes) are resident in HBM before the timed region.  Multi-GPU: the
 path shards by sample (pure data parallel): every rank draws its own frames,
 the only collective is the gradient all-reduce (RCCL) — weak scaling.
 """
@@ -29,7 +32,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 BATCH_PER_GPU = 2
-WORKLOAD = os.environ.get("DM_BENCH_WORKLOAD", "pvrcnn")  # "pvrcnn" (configs[1]) | "stage3d"
+WORKLOAD = os.environ.get("DM_BENCH_WORKLOAD", "detmatch")
 
 
 def parse():
@@ -50,10 +53,29 @@ def gg_bytes(P, ci, co, kvol, rows_out):
 
 def build_workload(dev, rank):
     from detmatch_amd import synth
-    from detmatch_amd.pcdet.workload import PVRCNNTrainWorkload, Stage3DWorkload
+    from detmatch_amd.pcdet.workload import (DetMatchTrainWorkload, PVRCNNTrainWorkload,
+                                              Stage3DWorkload)
+    if WORKLOAD in ('detmatch', 'confthr'):
+        wl = DetMatchTrainWorkload(BATCH_PER_GPU, dev, seed=5000 * rank,
+                                   ssl_cfg='confthr_pvrcnn' if WORKLOAD == 'confthr' else None)
+        wl.frames = [synth.lidar_frame(5000 * rank + i) for i in range(BATCH_PER_GPU)]
+        return wl
     frames = [synth.lidar_frame(1000 * rank + i) for i in range(BATCH_PER_GPU)]
     cls = PVRCNNTrainWorkload if WORKLOAD == 'pvrcnn' else Stage3DWorkload
     return cls(frames, dev)
+
+
+def trace_launches(wl):
+    """One extra (untimed) step with the launch trace on: [(ci, co, rows, kvol, P)] per
+    gather-GEMM launch, in launch order."""
+    from detmatch_amd.spconv import ops as sp_ops
+    sp_ops.LAUNCH_TRACE = []
+    try:
+        wl.step()
+        torch.cuda.synchronize()
+        return list(sp_ops.LAUNCH_TRACE)
+    finally:
+        sp_ops.LAUNCH_TRACE = None
 
 
 def cpu_baseline(frames):
@@ -131,14 +153,17 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events from the timed region) ----
-        per_step = wl.trace_gather_gemm()   # [(ci, co, rows, kvol, P)] in launch order
+        per_step = trace_launches(wl)   # [(ci, co, rows, kvol, P)] in launch order
         gg = [r for r in recs if r[0] == 0]
         roof = None
-        if per_step and len(gg) == len(per_step) * args.steps:
+        # the synthetic batch is the same every step, so launch j of a step always sees the same
+        # rulebook; data-dependent launches (pseudo-label dependent) would break the 1:1 mapping
+        sig = [(r[1], r[2], r[4], r[5]) for r in gg]
+        want = [(a, b, c, d) for a, b, c, d, _ in per_step] * args.steps
+        if per_step and sig == want:
             groups = {}
             for j, r in enumerate(gg):
                 ci, co, rows, kvol, P = per_step[j % len(per_step)]
-                assert (r[1], r[2], r[4], r[5]) == (ci, co, rows, kvol)
                 name = ('spconv_gg<%d,%d,%d>' % (r[1], r[2], r[3]) if r[3] else
                         'spconv_gr<%d,%d>' % (r[1], r[2]))
                 g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, launches=0))

@@ -119,9 +119,18 @@ def _tables_for(indice_pairs, indice_pair_num, n_in, n_out, subm):
     return nbr_out, nbr_in
 
 
+# bench.py's roofline accounting: when a list is installed here, every gather-GEMM launch appends
+# (c_in, c_out, rows_out, kvol, P) with P = number of rulebook pairs (one read-back per launch —
+# measurement only, never enabled inside a timed region).
+LAUNCH_TRACE = None
+
+
 def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k):
     L = _lib.lib()
     kvol = nbr.shape[0]
+    if LAUNCH_TRACE is not None:
+        ci, co = (cout, cin) if transpose_w else (cin, cout)
+        LAUNCH_TRACE.append((ci, co, int(n_rows_out), int(kvol), int((nbr >= 0).sum().item())))
     dev = feat.device
     out = torch.empty((n_rows_out, cin if transpose_w else cout), dtype=torch.float32, device=dev)
     ws = _lib.workspace(L.dm_spconv_workspace_bytes(kvol, cin, cout), dev, 'spconv')
