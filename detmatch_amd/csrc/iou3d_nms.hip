@@ -265,8 +265,18 @@ __global__ __launch_bounds__(64) void nms_mask(const float *boxes, const float2 
 }
 
 // Greedy pass (iou3d_nms.cpp:117-133) by ONE wave: lane l owns remv words l, l+64, ...
-// Stops after max_keep survivors (callers slice keep[:post_max] anyway).
-__global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *mask, int n,
+// Boxes are resolved 64 at a time.  Inside a block of 64 the decisions depend only on the
+// block's diagonal mask word of each box (one coalesced load, one word per lane) and are taken
+// with scalar bit operations + readlane — no memory access in the dependent chain.  The full mask
+// rows of the survivors of the block are then OR-ed into `remv` with up to 8 independent row loads
+// in flight.  Stops after max_keep survivors (callers slice keep[:post_max] anyway).
+__device__ __forceinline__ unsigned long long wave_bcast64(unsigned long long v, int src_lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, src_lane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), src_lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *__restrict__ mask, int n,
                                                  int max_keep, long long *keep, int *num_keep) {
   const int col_blocks = (n + 63) / 64;
   const int lane = threadIdx.x;
@@ -277,29 +287,48 @@ __global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *mask,
   int kept = 0;
   for (int blk = 0; blk < col_blocks && kept < max_keep; ++blk) {
     // the word that decides boxes [64*blk, 64*blk+64) lives on lane blk%64, slot blk/64
-    int slot = blk >> 6, owner = blk & 63;
+    const int slot = blk >> 6, owner = blk & 63;
     unsigned long long word = 0;
 #pragma unroll
     for (int w = 0; w < MAXW; ++w)
       if (w == slot) word = remv[w];
-    word = __shfl(word, owner);
-    int lim = min(64, n - blk * 64);
-    for (int b = 0; b < lim && kept < max_keep; ++b) {
-      if (word & (1ULL << b)) continue;
-      int i = blk * 64 + b;
-      if (lane == 0) keep[kept] = i;
+    word = wave_bcast64(word, owner);
+    const int lim = min(64, n - blk * 64);
+    const unsigned long long diag =
+        lane < lim ? mask[(size_t)(blk * 64 + lane) * col_blocks + blk] : 0ull;
+    unsigned long long alive = ~word & (lim == 64 ? ~0ull : ((1ull << lim) - 1ull));
+    unsigned long long survivors = 0ull;
+    while (alive != 0ull && kept < max_keep) {
+      const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+      survivors |= 1ull << b;
+      if (lane == 0) keep[kept] = blk * 64 + b;
       ++kept;
-      const unsigned long long *p = mask + (size_t)i * col_blocks;
+      alive &= ~(wave_bcast64(diag, b) | (1ull << b));
+    }
+    // OR the survivors' rows into the words of the blocks still to come
+    while (survivors != 0ull) {
+      const unsigned long long *rows[8];
+      int cnt = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        rows[u] = mask;
+        if (survivors != 0ull) {
+          const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(survivors));
+          survivors &= survivors - 1ull;
+          rows[u] = mask + (size_t)(blk * 64 + b) * col_blocks;
+          cnt = u + 1;
+        }
+      }
 #pragma unroll
       for (int w = 0; w < MAXW; ++w) {
-        int j = w * 64 + lane;
-        if (j >= blk && j < col_blocks) remv[w] |= p[j];
-      }
-      unsigned long long mine = 0;
+        if (w * 64 >= col_blocks) break;
+        const int j = w * 64 + lane;
+        const bool in = j > blk && j < col_blocks;
+        unsigned long long t[8];
 #pragma unroll
-      for (int w = 0; w < MAXW; ++w)
-        if (w == slot) mine = remv[w];
-      word = __shfl(mine, owner);
+        for (int u = 0; u < 8; ++u) t[u] = (in && u < cnt) ? rows[u][j] : 0ull;
+        remv[w] |= ((t[0] | t[1]) | (t[2] | t[3])) | ((t[4] | t[5]) | (t[6] | t[7]));
+      }
     }
   }
   if (lane == 0) *num_keep = kept;

@@ -268,6 +268,88 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(int batch, int m
   }
 }
 
+// Large query sets whose neighbourhoods overlap heavily (RoI-grid pooling: 216 grid points of one
+// RoI share a few dozen key-points; every RoI of a scene clusters on the same objects) make the
+// per-sample global atomics above contention-bound: float atomics execute at the memory side and
+// thousands of adders per row serialise (MI355X_MICROARCH.md "Global float atomics": one row
+// 14x slower).  This variant sums everything that shares a destination ON CHIP first: a workgroup
+// takes `chunk` consecutive queries, hashes their source rows into an LDS table (<= GPC_ACC_BYTES
+// of fp32 accumulators), adds with LDS atomics, and flushes each distinct row once.
+bool g_gp_grad_combine = true;
+constexpr int GPC_ACC_BYTES = 120 * 1024;
+constexpr int GPC_MAX_SLOTS = 512;
+
+__global__ __launch_bounds__(256) void group_points_grad_combine(int batch, int m, int c, int nsample,
+                                                                 int chunk, int n_slots,
+                                                                 const float *__restrict__ grad_out,
+                                                                 const int *__restrict__ idx,
+                                                                 const int *__restrict__ idx_cnt,
+                                                                 const int *__restrict__ feats_cnt,
+                                                                 float *__restrict__ grad_feats) {
+  extern __shared__ float gpc_lds[];
+  float *acc = gpc_lds;                                   // [n_slots][c]
+  int *keys = (int *)(acc + (size_t)n_slots * c);         // [n_slots] global source row or -1
+  unsigned short *slot_of = (unsigned short *)(keys + n_slots);   // [chunk * nsample]
+  const int q0 = blockIdx.x * chunk;
+  const int nq = min(chunk, m - q0);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < n_slots * c; i += 256) acc[i] = 0.0f;
+  for (int i = tid; i < n_slots; i += 256) keys[i] = -1;
+  __syncthreads();
+  // ---- 1. hash every reference of the chunk to a slot --------------------------------------
+  for (int r = tid; r < nq * nsample; r += 256) {
+    const int q = q0 + r / nsample;
+    int bs = 0, upto = idx_cnt[0], start = 0;
+    for (int k = 1; k < batch && q >= upto; ++k) {
+      start += feats_cnt[k - 1];
+      upto += idx_cnt[k];
+      bs = k;
+    }
+    (void)bs;
+    const int src = start + idx[(size_t)q0 * nsample + r];
+    unsigned h = ((unsigned)src * 2654435761u) % (unsigned)n_slots;
+    int slot = 0xFFFF;
+    for (int probe = 0; probe < n_slots; ++probe) {
+      const int old = atomicCAS(&keys[h], -1, src);
+      if (old == -1 || old == src) {
+        slot = (int)h;
+        break;
+      }
+      h = h + 1 == (unsigned)n_slots ? 0u : h + 1;
+    }
+    slot_of[r] = (unsigned short)slot;
+  }
+  __syncthreads();
+  // ---- 2. accumulate: one wave per query, coalesced reads of its (c, nsample) tile ----------
+  for (int ql = wave; ql < nq; ql += 4) {
+    const float *g = grad_out + (size_t)(q0 + ql) * c * nsample;
+    const unsigned short *so = slot_of + ql * nsample;
+    for (int e = lane; e < c * nsample; e += 64) {
+      const int ci = e / nsample, s = e % nsample;
+      const int slot = so[s];
+      const float v = g[e];
+      if (slot != 0xFFFF) {
+        unsafeAtomicAdd(&acc[slot * c + ci], v);
+      } else {   // table full (not expected for overlapping neighbourhoods): straight to memory
+        const int q = q0 + ql;
+        int upto = idx_cnt[0], start = 0;
+        for (int k = 1; k < batch && q >= upto; ++k) {
+          start += feats_cnt[k - 1];
+          upto += idx_cnt[k];
+        }
+        unsafeAtomicAdd(grad_feats + (size_t)(start + idx[(size_t)q * nsample + s]) * c + ci, v);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. flush each distinct row once: contiguous row segments per wave instruction ---------
+  for (int f = tid; f < n_slots * c; f += 256) {
+    const int slot = f / c, ci = f - slot * c;
+    const int key = keys[slot];
+    if (key >= 0) unsafeAtomicAdd(grad_feats + (size_t)key * c + ci, acc[f]);
+  }
+}
+
 // ---- furthest point sampling ----------------------------------------------------
 // One 1024-thread workgroup per sample; each thread keeps its points (xyz + running min
 // distance) in registers for all m-1 rounds, so a round is pure VALU + one cross-wave
@@ -530,13 +612,31 @@ extern "C" int dm_group_points_grad_stack(int batch, int m, int c, int n, int ns
   if (m == 0 || n == 0) return DM_OK;
   if ((c + 1) * nsample > GP_MAX_ELEMS) return DM_ERR_UNSUPPORTED;
   if (!grad_out || !idx || !idx_batch_cnt || !features_batch_cnt) return DM_ERR_INVALID_ARG;
-  size_t smem = 4ull * (c + 1) * nsample * sizeof(float);
   static bool attr = false;
   if (!attr) {
     DM_HIP(hipFuncSetAttribute((const void *)group_points_grad_kernel,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    DM_HIP(hipFuncSetAttribute((const void *)group_points_grad_combine,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
+  if (m >= 16384 && g_gp_grad_combine) {
+    // one chunk per CU-sized share of the queries (216 = one RoI's grid for the PV-RCNN head)
+    int chunk = dm_ceil_div(m, 256);
+    chunk = chunk < 32 ? 32 : (chunk > 256 ? 256 : chunk);
+    int n_slots = GPC_ACC_BYTES / (4 * c);
+    if (n_slots > GPC_MAX_SLOTS) n_slots = GPC_MAX_SLOTS;
+    size_t lds = (size_t)n_slots * c * 4 + (size_t)n_slots * 4 + (size_t)chunk * nsample * 2;
+    lds = (lds + 15) & ~(size_t)15;
+    if (n_slots >= 64 && lds <= 160 * 1024) {
+      group_points_grad_combine<<<dm_ceil_div(m, chunk), 256, lds, st>>>(
+          batch, m, c, nsample, chunk, n_slots, grad_out, idx, idx_batch_cnt, features_batch_cnt,
+          grad_features);
+      DM_CHECK_LAUNCH();
+      return DM_OK;
+    }
+  }
+  size_t smem = 4ull * (c + 1) * nsample * sizeof(float);
   group_points_grad_kernel<<<dm_ceil_div(m, 4), 256, smem, st>>>(
       batch, m, c, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features);
   DM_CHECK_LAUNCH();

@@ -79,6 +79,9 @@ class OpenPCDetDetector(nn.Module):
         res['points_batch_cnt_host'] = [int(p.shape[0]) for p in points]
         if img_metas is not None:
             res['frame_id'] = np.array([m.get('sample_idx', i) for i, m in enumerate(img_metas)])
+        pfe = getattr(self.model, 'pfe', None)
+        if pfe is not None and hasattr(pfe, 'sample_keypoints_async'):
+            pfe.sample_keypoints_async(res)
         return res
 
     @torch.no_grad()

@@ -106,8 +106,35 @@ class VoxelSetAbstraction(nn.Module):
             start += n
         return torch.cat(keypoints_list, dim=0)
 
+    _side_streams = {}
+
+    def sample_keypoints_async(self, batch_dict):
+        """FPS depends only on the raw points, runs 2047 dependent rounds and occupies one CU per
+        sample: launch it on a side HIP stream as soon as the batch is assembled so that it
+        overlaps voxelisation + the sparse and BEV backbones; forward() joins on the event."""
+        pts = batch_dict['points']
+        if not pts.is_cuda:
+            return
+        key = pts.device.index
+        side = VoxelSetAbstraction._side_streams.get(key)
+        if side is None:
+            side = VoxelSetAbstraction._side_streams[key] = torch.cuda.Stream(device=pts.device)
+        main = torch.cuda.current_stream(pts.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            kp = self.get_sampled_points(batch_dict)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        batch_dict['keypoints_async'] = (kp, ev)
+
     def forward(self, batch_dict):
-        keypoints = self.get_sampled_points(batch_dict)
+        if 'keypoints_async' in batch_dict:
+            keypoints, ev = batch_dict.pop('keypoints_async')
+            main = torch.cuda.current_stream(keypoints.device)
+            main.wait_event(ev)
+            keypoints.record_stream(main)
+        else:
+            keypoints = self.get_sampled_points(batch_dict)
         batch_size, num_keypoints, _ = keypoints.shape
         dev = keypoints.device
         point_features_list = []

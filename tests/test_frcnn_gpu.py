@@ -109,7 +109,7 @@ def test_faster_rcnn_train_and_test_paths(dev):
     total = sum(v for k, v in losses.items() if 'loss' in k)
     total.backward()
     assert m.backbone.conv1.weight.grad is None and m.backbone.layer1[0].conv1.weight.grad is None
-    for p in (m.backbone.layer2[0].conv1.weight, m.neck.lateral_convs[0].conv.weight,
+    for p in (m.backbone.layer2[0].downsample[0].weight, m.neck.lateral_convs[0].conv.weight,
               m.rpn_head.rpn_conv.weight, m.roi_head.bbox_head.fc_reg.weight):
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
     # zero GT (empty pseudo-label set) must train too

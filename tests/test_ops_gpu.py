@@ -122,6 +122,31 @@ def test_group_large_channels(orc, dev):
     assert np.array_equal(g.cpu().numpy(), orc.group_points(feats, [2048, 2048], idx, [1000, 2000]))
 
 
+@pytest.mark.parametrize('c,ns,n_src,local', [(128, 16, 4096, True), (128, 16, 4096, False),
+                                               (64, 32, 60000, False), (16, 16, 4096, True)])
+def test_group_grad_combining_kernel(orc, dev, c, ns, n_src, local):
+    """m >= 16384 takes the LDS-combining backward (on-chip sum of everything that shares a
+    source row, one flush per distinct row); `local` = RoI-grid-like overlap (few distinct rows
+    per chunk), not local = every reference distinct (table overflow path)."""
+    from detmatch_amd import pointnet2_stack as pn
+    rng = np.random.default_rng(c + ns)
+    m, half = 20000, n_src // 2
+    if local:
+        centre = rng.integers(0, half - 40, (m // 200 + 1,)).repeat(200)[:m]
+        idx = (centre[:, None] + rng.integers(0, 40, (m, ns))).astype(np.int32)
+    else:
+        idx = rng.integers(0, half, (m, ns)).astype(np.int32)
+    idx[::7, 3:] = idx[::7, :1]           # ball-query padding: repeats of the first neighbour
+    feats = torch.from_numpy(rng.standard_normal((n_src, c)).astype(np.float32)).to(dev).requires_grad_()
+    cnt = torch.tensor([half, n_src - half], dtype=torch.int32, device=dev)
+    icnt = torch.tensor([12000, 8000], dtype=torch.int32, device=dev)
+    out = pn.grouping_operation(feats, cnt, torch.from_numpy(idx).to(dev), icnt)
+    g = rng.standard_normal((m, c, ns)).astype(np.float32)
+    out.backward(torch.from_numpy(g).to(dev))
+    want = orc.group_points_grad(g, idx, [12000, 8000], [half, n_src - half], n_src)
+    np.testing.assert_allclose(feats.grad.cpu().numpy(), want, rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize('n,m', [(5, 3), (100, 37), (1024, 512), (3000, 2048), (19940, 2048)])
 def test_fps(orc, dev, n, m):
     from detmatch_amd import pointnet2_stack as pn
