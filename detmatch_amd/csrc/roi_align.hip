@@ -181,6 +181,110 @@ __global__ __launch_bounds__(256) void roi_align_kernel(Pyramid pyr, const float
   }
 }
 
+// ---- backward, separable form, NHWC accumulation -------------------------------------------------
+// d feat[y][x][c] = (1/count) * sum_by sum_bx Wy[by][y] * G[by][bx][c] * Wx[bx][x], where Wy / Wx
+// collect the bilinear tap weights of every sample of a bin row / column.  One workgroup per RoI:
+// the tap tables (7 x patch) and the RoI's output gradient (bins x C) sit in LDS, every pixel of
+// the RoI's patch then receives ONE atomic per channel, issued as 256-byte contiguous wave
+// instructions into an NHWC buffer — the shape float atomics need to run at the memory-side rate
+// (MI355X_MICROARCH.md "Global float atomics"); the per-sample NCHW form above issues
+// 4 * samples atomics per bin with 64 lanes in 64 different rows (~17x slower per byte).
+constexpr int RA_MAX_SPAN = 160;   // patch rows / columns kept in LDS; larger RoIs -> NCHW path
+
+__global__ __launch_bounds__(256) void roi_align_bwd_nhwc(Pyramid pyr, const float *__restrict__ rois,
+                                                          const int *__restrict__ levels, int C,
+                                                          int ph, int pw, int sampling_ratio,
+                                                          int aligned,
+                                                          const float *__restrict__ gout) {
+  extern __shared__ unsigned char smem[];
+  const int r = blockIdx.x;
+  const int level = levels ? levels[r] : 0;
+  const int H = pyr.h[level], W = pyr.w[level];
+  const RoiGeom g = roi_geom(rois + (size_t)r * 5, level, pyr.scale[level], ph, pw, sampling_ratio,
+                             aligned);
+  // pixel span touched by the RoI (taps clamp into [0, size-1])
+  const float end_h = g.start_h + g.bin_h * (float)ph, end_w = g.start_w + g.bin_w * (float)pw;
+  int y0 = max(0, min(H - 1, (int)floorf(fminf(g.start_h, end_h)))), y1 = max(0, min(H - 1, (int)floorf(fmaxf(g.start_h, end_h)) + 1));
+  int x0 = max(0, min(W - 1, (int)floorf(fminf(g.start_w, end_w)))), x1 = max(0, min(W - 1, (int)floorf(fmaxf(g.start_w, end_w)) + 1));
+  const int py = y1 - y0 + 1, px = x1 - x0 + 1;
+  if (g.gh <= 0 || g.gw <= 0) return;   // empty RoI: no samples
+  const int bins = ph * pw;
+  const float inv_count = 1.0f / (float)max(g.gh * g.gw, 1);
+  float *dst = pyr.grad[level] + (size_t)g.batch * H * W * C;
+  if (py > RA_MAX_SPAN || px > RA_MAX_SPAN) {
+    // RoI wider than the LDS tap tables: per-sample form (still channel-contiguous atomics)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      for (int b = 0; b < bins; ++b) {
+        const int by = b / pw, bx = b - by * pw;
+        const float gv = gout[((size_t)r * C + c) * bins + b] * inv_count;
+        for (int sy = 0; sy < g.gh; ++sy) {
+          const float y = g.start_h + (float)by * g.bin_h + ((float)sy + 0.5f) * g.bin_h / (float)g.gh;
+          int yl, yh;
+          float wyl, wyh;
+          if (!tap(y, H, yl, yh, wyl, wyh)) continue;
+          for (int sx = 0; sx < g.gw; ++sx) {
+            const float x = g.start_w + (float)bx * g.bin_w + ((float)sx + 0.5f) * g.bin_w / (float)g.gw;
+            int xl, xh;
+            float wxl, wxh;
+            if (!tap(x, W, xl, xh, wxl, wxh)) continue;
+            unsafeAtomicAdd(dst + ((size_t)yl * W + xl) * C + c, gv * (wyl * wxl));
+            unsafeAtomicAdd(dst + ((size_t)yl * W + xh) * C + c, gv * (wyl * wxh));
+            unsafeAtomicAdd(dst + ((size_t)yh * W + xl) * C + c, gv * (wyh * wxl));
+            unsafeAtomicAdd(dst + ((size_t)yh * W + xh) * C + c, gv * (wyh * wxh));
+          }
+        }
+      }
+    }
+    return;
+  }
+  float *wy = (float *)smem;                 // [ph][RA_MAX_SPAN]
+  float *wx = wy + ph * RA_MAX_SPAN;         // [pw][RA_MAX_SPAN]
+  float *gt = wx + pw * RA_MAX_SPAN;         // [ph*pw][C]
+  for (int i = threadIdx.x; i < (ph + pw) * RA_MAX_SPAN; i += 256) wy[i] = 0.0f;
+  __syncthreads();
+  // one thread per bin row / bin column accumulates its samples' taps (sequential -> no atomics)
+  if (threadIdx.x < ph + pw) {
+    const bool is_y = threadIdx.x < ph;
+    const int b = is_y ? threadIdx.x : threadIdx.x - ph;
+    const int gn = is_y ? g.gh : g.gw, size = is_y ? H : W, base = is_y ? y0 : x0;
+    const float start = is_y ? g.start_h : g.start_w, bin = is_y ? g.bin_h : g.bin_w;
+    float *row = (is_y ? wy : wx) + b * RA_MAX_SPAN;
+    for (int s = 0; s < gn; ++s) {
+      const float p = start + (float)b * bin + ((float)s + 0.5f) * bin / (float)gn;
+      int lo, hi;
+      float wl, wh;
+      if (!tap(p, size, lo, hi, wl, wh)) continue;
+      row[lo - base] += wl;
+      row[hi - base] += wh;
+    }
+  }
+  const float *gsrc = gout + (size_t)r * C * bins;
+  for (int e = threadIdx.x; e < C * bins; e += 256) {   // coalesced read, transposed LDS write
+    const int c = e / bins, b = e - c * bins;
+    gt[b * C + c] = gsrc[e] * inv_count;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    for (int yy = 0; yy < py; ++yy) {
+      for (int xx = 0; xx < px; ++xx) {
+        float acc = 0.0f;
+        bool any = false;
+        for (int by = 0; by < ph; ++by) {
+          const float a = wy[by * RA_MAX_SPAN + yy];
+          if (a == 0.0f) continue;
+          for (int bx = 0; bx < pw; ++bx) {
+            const float w = a * wx[bx * RA_MAX_SPAN + xx];
+            if (w == 0.0f) continue;
+            acc += w * gt[(by * pw + bx) * C + c];
+            any = true;
+          }
+        }
+        if (any) unsafeAtomicAdd(dst + ((size_t)(y0 + yy) * W + (x0 + xx)) * C + c, acc);
+      }
+    }
+  }
+}
+
 // The adaptive sampling grid (ceil(roi / pooled)) is data dependent: LDS is sized for `max_grid`
 // samples per bin per axis (caller's estimate; 0 -> 8) and RoIs beyond it take the on-the-fly path.
 int launch(bool backward, const float *const *feats, float *const *grads, const int *hs,
@@ -209,6 +313,38 @@ int launch(bool backward, const float *const *feats, float *const *grads, const 
 }
 
 }  // namespace
+
+extern "C" int dm_roi_align_backward_nhwc(float *const *grads_nhwc_host, const int *heights_host,
+                                          const int *widths_host, const float *scales_host,
+                                          int n_levels, int channels, const float *rois,
+                                          const int *roi_levels, int n_rois, int pooled_h,
+                                          int pooled_w, int sampling_ratio, int aligned,
+                                          const float *grad_out, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_levels < 1 || n_levels > kMaxLevels || n_rois < 0 || channels < 1 || pooled_h < 1 ||
+      pooled_w < 1)
+    return DM_ERR_INVALID_ARG;
+  if (n_rois == 0) return DM_OK;
+  Pyramid p;
+  for (int l = 0; l < n_levels; ++l) {
+    p.feat[l] = nullptr;
+    p.grad[l] = grads_nhwc_host[l];
+    p.h[l] = heights_host[l], p.w[l] = widths_host[l], p.scale[l] = scales_host[l];
+  }
+  const size_t shm = (size_t)(pooled_h + pooled_w) * RA_MAX_SPAN * 4 +
+                     (size_t)pooled_h * pooled_w * channels * 4;
+  if (shm > 150 * 1024) return DM_ERR_UNSUPPORTED;
+  static bool attr = false;
+  if (!attr) {
+    DM_HIP(hipFuncSetAttribute((const void *)roi_align_bwd_nhwc,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(roi_align_bwd_nhwc, dim3(n_rois), dim3(256), shm, st, p, rois, roi_levels,
+                     channels, pooled_h, pooled_w, sampling_ratio, aligned, grad_out);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
 
 extern "C" int dm_roi_align_forward(const float *const *feats_host, const int *heights_host,
                                     const int *widths_host, const float *scales_host, int n_levels,

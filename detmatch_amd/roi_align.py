@@ -48,13 +48,17 @@ class _RoIAlignFPN(Function):
         rois, levels = ctx.saved_tensors
         scales, out_size, sampling_ratio, aligned, shapes = ctx.meta
         gout = gout.contiguous()
-        grads = [gout.new_zeros(s) for s in shapes]
-        ptrs, hs, ws = _pyramid_args(grads)
+        # accumulate in NHWC (channel-contiguous float atomics), hand back NCHW-shaped views
+        grads = [gout.new_zeros((s[0], s[2], s[3], s[1])) for s in shapes]
+        ptrs = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
+        hs = (ctypes.c_int32 * len(grads))(*[int(s[2]) for s in shapes])
+        ws = (ctypes.c_int32 * len(grads))(*[int(s[3]) for s in shapes])
         sc = (ctypes.c_float * len(grads))(*[float(s) for s in scales])
-        _lib.check(_lib.lib().dm_roi_align_backward(
+        _lib.check(_lib.lib().dm_roi_align_backward_nhwc(
             ptrs, hs, ws, sc, len(grads), shapes[0][1], _lib.ptr(rois),
             _lib.ptr(levels) if levels is not None else None, rois.shape[0], out_size, out_size,
-            sampling_ratio, int(aligned), 8, _lib.ptr(gout), _lib.stream()), 'dm_roi_align_backward')
+            sampling_ratio, int(aligned), _lib.ptr(gout), _lib.stream()), 'dm_roi_align_backward_nhwc')
+        grads = [t.permute(0, 3, 1, 2) for t in grads]
         return (None, None, None, None, None, None) + tuple(grads)
 
 

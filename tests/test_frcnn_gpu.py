@@ -59,6 +59,34 @@ def test_roi_align_fpn_matches_per_level_oracle(dev, orc):
         np.testing.assert_allclose(tf[l].grad.cpu().numpy(), gw, rtol=1e-4, atol=1e-4)
 
 
+def test_roi_align_backward_wide_roi_and_nchw_entry(dev, orc):
+    """RoIs wider than the LDS tap tables (> 160 px span) take the in-kernel per-sample path; the
+    NCHW entry point dm_roi_align_backward stays available to C callers."""
+    import ctypes
+    from detmatch_amd import _lib
+    from detmatch_amd.roi_align import roi_align
+    rng = np.random.default_rng(9)
+    feat = rng.normal(size=(1, 8, 170, 180)).astype(np.float32)
+    rois = np.array([[0, 2, 3, 178, 168], [0, 20, 30, 60, 90], [0, -5, -5, 400, 400]], np.float32)
+    f = torch.from_numpy(feat).to(dev).requires_grad_()
+    tr = torch.from_numpy(rois).to(dev)
+    out = roi_align(f, tr, 7, 1.0, 0, True)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), orc.roi_align(feat, rois, 1.0, 7, 0, True),
+                               rtol=1e-5, atol=1e-5)
+    g = rng.normal(size=(3, 8, 7, 7)).astype(np.float32)
+    out.backward(torch.from_numpy(g).to(dev))
+    want = orc.roi_align_grad(g, feat.shape, rois, 1.0, 0, True)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    # NCHW C entry
+    gn = torch.zeros(feat.shape, device=dev)
+    tg = torch.from_numpy(g).to(dev)
+    ptrs = (ctypes.c_void_p * 1)(gn.data_ptr())
+    hs, ws, sc = (ctypes.c_int32 * 1)(170), (ctypes.c_int32 * 1)(180), (ctypes.c_float * 1)(1.0)
+    _lib.check(_lib.lib().dm_roi_align_backward(ptrs, hs, ws, sc, 1, 8, _lib.ptr(tr), None, 3, 7, 7, 0, 1,
+                                                8, _lib.ptr(tg), _lib.stream()), 'dm_roi_align_backward')
+    np.testing.assert_allclose(gn.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
 def test_nms_2d_matches_numpy(dev):
     from detmatch_amd.mm2d.faster_rcnn import nms_fixed
     rng = np.random.default_rng(11)
