@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libdetmatch_hip.so')
 _lib = None
 
+cd = ctypes.c_double
 c_int_p = ctypes.POINTER(ctypes.c_int)
 c_i32_p = ctypes.POINTER(ctypes.c_int32)
 c_f32_p = ctypes.POINTER(ctypes.c_float)
@@ -54,6 +55,8 @@ SIGNATURES = {
                                         vp, vp]),
     'dm_ema_update_f32': (ci, [vp, vp, sz, ctypes.c_double, vp]),
     'dm_ema_update_i64': (ci, [vp, vp, sz, ctypes.c_double, vp]),
+    'dm_adamw_step_f32': (ci, [vp, vp, vp, vp, sz, cd, cd, cd, cd, cd, ctypes.c_longlong, vp, vp]),
+    'dm_sgd_step_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp]),
     'dm_lap_host': (ci, [c_f32_p, ci, ci, c_int_p, c_int_p]),
     'dm_ball_query_stack': (ci, [ci, ci, cf, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
     'dm_group_points_stack': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),

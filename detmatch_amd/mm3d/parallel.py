@@ -33,18 +33,25 @@ class FlatGradDDP(nn.Module):
         assert self.params, 'nothing to train'
         dev = self.params[0].device
         assert all(p.dtype == torch.float32 and p.device == dev for p in self.params)
-        # reverse order ~ the order in which backward produces gradients
+        # reverse order ~ the order in which backward produces gradients; every tensor starts on a
+        # 4-element (16-byte) boundary so that the parameter arena, the optimizer state and this
+        # arena can be walked index-aligned by float4 kernels
         order = list(range(len(self.params)))[::-1]
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        pad = lambda n: (n + 3) // 4 * 4
+        self.flat = torch.zeros(sum(pad(p.numel()) for p in self.params), dtype=torch.float32,
+                                device=dev)
+        self.order = [self.params[i] for i in order]     # arena order
+        self.offset = {}                                 # id(param) -> first element
+        self.flat_params = None                          # set by build_param_arena / SSL.build_arenas
         self.buckets = []          # (start, end) element ranges of self.flat
         self._bucket_of = {}
         self._pending = []
         off, b_start, cap = 0, 0, max(1, bucket_bytes // 4)
-        for i in order:
-            p = self.params[i]
+        for p in self.order:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.offset[id(p)] = off
             self._bucket_of[id(p)] = len(self.buckets)
-            off += p.numel()
+            off += pad(p.numel())
             if off - b_start >= cap:
                 self.buckets.append((b_start, off))
                 b_start = off
@@ -60,6 +67,26 @@ class FlatGradDDP(nn.Module):
             p.register_post_accumulate_grad_hook(self._on_grad)
         if broadcast and self.world > 1:
             self.broadcast_parameters()
+
+    @torch.no_grad()
+    def build_param_arena(self):
+        """Re-home the trainable parameters in a flat arena laid out exactly like the gradient
+        arena (fused optimizer kernels walk both index-aligned)."""
+        flat = torch.zeros_like(self.flat)
+        for p in self.order:
+            off = self.offset[id(p)]
+            view = flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        self.flat_params = flat
+        return flat
+
+    def check_param_arena(self):
+        base = self.flat_params.data_ptr()
+        for p in self.order:
+            if p.data_ptr() != base + 4 * self.offset[id(p)]:
+                return False
+        return True
 
     # ---- state sync ------------------------------------------------------------------
     @torch.no_grad()
@@ -116,11 +143,16 @@ class FlatGradDDP(nn.Module):
         if self.world > 1:
             self.flat.div_(self.world)
 
-    def clip_grad_norm_(self, max_norm, norm_type=2):
-        """Global clip over the arena: one norm kernel + one scale kernel."""
+    def clip_coef(self, max_norm, norm_type=2):
+        """-> (total_norm, coef) device scalars of clip_grad_norm_; nothing is scaled (the fused
+        optimizer kernels apply coef while they read the gradients)."""
         assert norm_type == 2
         total = torch.linalg.vector_norm(self.flat)
-        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        return total, torch.clamp(max_norm / (total + 1e-6), max=1.0)
+
+    def clip_grad_norm_(self, max_norm, norm_type=2):
+        """Global clip over the arena: one norm kernel + one scale kernel."""
+        total, coef = self.clip_coef(max_norm, norm_type)
         self.flat.mul_(coef)
         return total
 

@@ -62,13 +62,97 @@ class HybridOptimizer(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         self.num_step_updated += 1
-        for k, o in zip(self.step_intervals, self.optimizers):
+        fused = getattr(self, '_fused', None)
+        for i, (k, o) in enumerate(zip(self.step_intervals, self.optimizers)):
             if self.num_step_updated % k == 0:
-                o.step()
+                if fused is not None and fused[i] is not None:
+                    fused[i].step(getattr(self, 'grad_scale', None))
+                else:
+                    o.step()
+        self.grad_scale = None
         return loss
+
+    def enable_fused(self, ddp):
+        """Route AdamW / SGD members whose parameters form one contiguous range of `ddp`'s flat
+        arenas through the fused kernels (dm_adamw_step_f32 / dm_sgd_step_f32).  Optimizer state
+        stays visible through `optimizer.state[p]` as views of the flat state.  Returns the number
+        of fused members."""
+        self._fused = [FusedRange.try_build(o, ddp) for o in self.optimizers]
+        return sum(f is not None for f in self._fused)
 
     def add_param_group(self, param_group):
         raise NotImplementedError
+
+
+class FusedRange(object):
+    """One torch optimizer (AdamW or SGD, uniform hyper-parameters) over one contiguous range of a
+    FlatGradDDP's parameter / gradient arenas."""
+
+    def __init__(self, opt, ddp, lo, hi, params):
+        self.opt, self.ddp, self.lo, self.hi = opt, ddp, lo, hi
+        self.kind = 'adamw' if isinstance(opt, torch.optim.AdamW) else 'sgd'
+        dev = ddp.flat.device
+        self.t = 0
+        n = hi - lo
+        if self.kind == 'adamw':
+            self.m = torch.zeros(n, device=dev)
+            self.v = torch.zeros(n, device=dev)
+        else:
+            self.buf = torch.zeros(n, device=dev)
+        self.step_t = torch.zeros((), dtype=torch.float32)
+        for p in params:   # torch-compatible view of the state (state_dict / resume parity)
+            o = ddp.offset[id(p)] - lo
+            if self.kind == 'adamw':
+                opt.state[p] = dict(step=self.step_t, exp_avg=self.m[o:o + p.numel()].view_as(p),
+                                    exp_avg_sq=self.v[o:o + p.numel()].view_as(p))
+            else:
+                opt.state[p] = dict(momentum_buffer=self.buf[o:o + p.numel()].view_as(p))
+
+    @staticmethod
+    def try_build(opt, ddp):
+        if ddp.flat_params is None or not ddp.flat.is_cuda or not ddp.check_param_arena():
+            return None
+        if not isinstance(opt, (torch.optim.AdamW, torch.optim.SGD)):
+            return None
+        params = [p for g in opt.param_groups for p in g['params'] if id(p) in ddp.offset]
+        rest = [p for g in opt.param_groups for p in g['params'] if id(p) not in ddp.offset]
+        if not params or any(p.requires_grad for p in rest):
+            return None
+        pad = lambda n: (n + 3) // 4 * 4
+        lo = min(ddp.offset[id(p)] for p in params)
+        hi = max(ddp.offset[id(p)] + pad(p.numel()) for p in params)
+        if sum(pad(p.numel()) for p in params) != hi - lo:
+            return None          # not one contiguous range
+        keys = ('lr', 'weight_decay', 'betas', 'eps', 'momentum', 'dampening', 'nesterov', 'amsgrad',
+                'maximize')
+        g0 = opt.param_groups[0]
+        for g in opt.param_groups:
+            if any(g.get(k) != g0.get(k) for k in keys):
+                return None      # per-parameter options (lr_mult ...): keep the torch path
+        if g0.get('amsgrad') or g0.get('nesterov') or g0.get('maximize'):
+            return None
+        return FusedRange(opt, ddp, lo, hi, params)
+
+    def step(self, grad_scale=None):
+        from .. import _lib
+        L = _lib.lib()
+        g0 = self.opt.param_groups[0]
+        d = self.ddp
+        p = d.flat_params[self.lo:self.hi]
+        g = d.flat[self.lo:self.hi]
+        gs = _lib.ptr(grad_scale) if grad_scale is not None else None
+        self.t += 1
+        self.step_t.fill_(self.t)
+        n = self.hi - self.lo
+        if self.kind == 'adamw':
+            _lib.check(L.dm_adamw_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(self.m), _lib.ptr(self.v),
+                                           n, g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
+                                           g0['weight_decay'], self.t, gs, _lib.stream()),
+                       'dm_adamw_step_f32')
+        else:
+            _lib.check(L.dm_sgd_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(self.buf), n, g0['lr'],
+                                         g0['momentum'], g0['dampening'], g0['weight_decay'],
+                                         int(self.t == 1), gs, _lib.stream()), 'dm_sgd_step_f32')
 
 
 @OPTIMIZER_BUILDERS.register_module()
@@ -174,7 +258,14 @@ class OptimizerHook(Hook):
         if ddp is not None:
             ddp.finish()
         if self.grad_clip is not None:
-            if ddp is not None and ddp.covers_all_clipped:
+            fused = getattr(runner.optimizer, '_fused', None)
+            if ddp is not None and ddp.covers_all_clipped and fused and all(
+                    f is not None or not any(p.requires_grad for g in o.param_groups for p in g['params'])
+                    for f, o in zip(fused, runner.optimizer.optimizers)):
+                # every trainable parameter is stepped by a fused kernel: hand the clip
+                # coefficient to the kernels instead of rescaling the arena
+                norm, runner.optimizer.grad_scale = ddp.clip_coef(**self.grad_clip)
+            elif ddp is not None and ddp.covers_all_clipped:
                 norm = ddp.clip_grad_norm_(**self.grad_clip)
             else:
                 params = [p for g in runner.optimizer.param_groups for p in g['params']

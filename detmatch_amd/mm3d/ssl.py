@@ -23,29 +23,36 @@ def add_prefix(inputs, prefix):
 
 
 class _Arena(object):
-    """Re-homes every tensor of a state_dict in two flat buffers (fp32 / int64)."""
+    """Re-homes every tensor of a state_dict in two flat buffers (fp32 / int64).  `first_keys`
+    (state-dict keys) are laid out first, in that order — the student's trainable parameters in the
+    order of the gradient arena, so optimizer, gradient and EMA kernels share one layout."""
 
-    def __init__(self, module):
+    def __init__(self, module, first_keys=None):
         sd = module.state_dict(keep_vars=True)
         self.keys = list(sd.keys())
-        f_items = [(k, v) for k, v in sd.items() if v.dtype == torch.float32]
-        i_items = [(k, v) for k, v in sd.items() if v.dtype == torch.int64]
         other = [k for k, v in sd.items() if v.dtype not in (torch.float32, torch.int64)]
         assert not other, 'unsupported state dtypes: %s' % other
-        self.f_keys = [k for k, _ in f_items]
-        self.i_keys = [k for k, _ in i_items]
+        first_keys = list(first_keys or [])
+        seen = set(first_keys)
+        self.f_keys = first_keys + [k for k, v in sd.items()
+                                    if v.dtype == torch.float32 and k not in seen]
+        self.i_keys = [k for k, v in sd.items() if v.dtype == torch.int64]
+        f_items = [(k, sd[k]) for k in self.f_keys]
+        i_items = [(k, sd[k]) for k in self.i_keys]
         dev = f_items[0][1].device if f_items else torch.device('cpu')
-        # each tensor starts on a 4-element boundary so the float4 kernel never straddles
-        self.f_sizes = [v.numel() for _, v in f_items]
+        # each tensor starts on a 4-element boundary so the float4 kernels never straddle
         pad = lambda n: (n + 3) // 4 * 4
-        self.flat_f = torch.zeros(sum(pad(n) for n in self.f_sizes), dtype=torch.float32, device=dev)
+        self.flat_f = torch.zeros(sum(pad(v.numel()) for _, v in f_items), dtype=torch.float32, device=dev)
         self.flat_i = torch.zeros(sum(v.numel() for _, v in i_items), dtype=torch.int64, device=dev)
+        self.f_offset = {}
         off = 0
         with torch.no_grad():
-            for (k, v), n in zip(f_items, self.f_sizes):
+            for k, v in f_items:
+                n = v.numel()
                 view = self.flat_f[off:off + n].view(v.shape)
                 view.copy_(v.data)
                 v.data = view
+                self.f_offset[k] = off
                 off += pad(n)
             off = 0
             for k, v in i_items:
@@ -157,11 +164,20 @@ class SSL(nn.Module):
             return min(1 - 1 / (self.iter + ema_start_iter), self.ema_params['ema_decay'])
         return self.ema_params['ema_decay']
 
-    def build_arenas(self):
-        """Call once the model sits on its device (and after any checkpoint load)."""
-        self._arenas = (_Arena(self.teacher), _Arena(self.student))
+    def build_arenas(self, ddp=None):
+        """Call once the model sits on its device (and after any checkpoint load).  With a
+        FlatGradDDP the student's trainable parameters come first, in gradient-arena order, and
+        `ddp.flat_params` becomes that prefix of the student arena."""
+        first = None
+        if ddp is not None:
+            name_of = {id(p): n for n, p in self.student.named_parameters()}
+            first = [name_of[id(p)] for p in ddp.order]
+        self._arenas = (_Arena(self.teacher, first), _Arena(self.student, first))
         t, s = self._arenas
-        assert t.keys == s.keys, 'teacher / student state dicts differ'
+        assert t.f_keys == s.f_keys and t.i_keys == s.i_keys, 'teacher / student state dicts differ'
+        if ddp is not None:
+            ddp.flat_params = s.flat_f[:ddp.flat.numel()]
+            assert ddp.check_param_arena(), 'student arena prefix does not match the gradient arena'
         return self._arenas
 
     def _update_teacher(self):

@@ -130,6 +130,9 @@ class PVRCNNTrainWorkload(object):
         self.opt = torch.optim.AdamW(self.params, lr=lr, betas=(0.95, 0.99), weight_decay=0.01)
         self.world = 1
         self.ddp = FlatGradDDP(self.model, broadcast=False)
+        self.ddp.build_param_arena()
+        from ..mm3d.runner import FusedRange
+        self.fused = FusedRange.try_build(self.opt, self.ddp)   # one AdamW launch over the arena
         self.last_loss = None
 
     def describe(self):
@@ -152,8 +155,12 @@ class PVRCNNTrainWorkload(object):
         self.ddp.zero_grad()
         loss.backward()
         self.ddp.finish()   # gradients only
-        self.ddp.clip_grad_norm_(10.0)
-        self.opt.step()
+        if self.fused is not None:
+            _, coef = self.ddp.clip_coef(10.0)
+            self.fused.step(coef)
+        else:
+            self.ddp.clip_grad_norm_(10.0)
+            self.opt.step()
         self.last_loss = loss.detach()
         return loss
 
@@ -224,6 +231,8 @@ class DetMatchTrainWorkload(object):
         sched = configs.detmatch_schedule(batch_size, 1)
         self.ddp = FlatGradDDP(self.model, broadcast=False)
         self.opt = R.build_optimizer(self.model, sched['optimizer'])
+        self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
+        self.n_fused = self.opt.enable_fused(self.ddp)
         self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)
         self.runner.register_training_hooks(sched['lr_config'], sched['optimizer_config'],
                                             sched['custom_hooks'])

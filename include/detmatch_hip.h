@@ -261,6 +261,18 @@ int dm_ema_update_f32(float *teacher, const float *student, size_t n, double dec
 /* integer buffers: fp32 math, truncated back (Tensor.copy_ float -> long) */
 int dm_ema_update_i64(long long *teacher, const long long *student, size_t n, double decay,
                       dm_stream_t stream);
+/* I. Step driver: fused optimizer steps over flat, 16-byte aligned arenas (params, grads and
+ * state index-aligned).  Replace the per-tensor torch.optim loops behind HybridOptimizer.step
+ * (mmdet3d/core/optimizer/hybrid_optimizer.py:82-101) for the optimizers named at
+ * configs/detmatch/001/detmatch/split_0.py:832-851.  grad_scale_dev: optional device scalar that
+ * multiplies every gradient (the clip_grad_norm_ coefficient).  `step` is 1-based. */
+int dm_adamw_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                      size_t n, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, long long step, const float *grad_scale_dev,
+                      dm_stream_t stream);
+int dm_sgd_step_f32(float *params, const float *grads, float *momentum_buf, size_t n, double lr,
+                    double momentum, double dampening, double weight_decay, int first_step,
+                    const float *grad_scale_dev, dm_stream_t stream);
 /* Replaces scipy.optimize.linear_sum_assignment at
  * mmdet3d/core/bbox/assigners/modified_hungarian_assigner.py:132.  HOST function: cost
  * (n_rows, n_cols) row-major host floats -> min(n_rows, n_cols) pairs sorted by row.

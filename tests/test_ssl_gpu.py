@@ -80,3 +80,50 @@ def test_detmatch_full_iteration(dev):
     assert 'ssl.unlab.hard_pseudo_2d.loss_bbox' not in log      # detached by the recipe
     loss2 = wl.step()
     assert torch.isfinite(loss2)
+
+
+def test_fused_optimizer_matches_torch(dev):
+    """dm_adamw_step_f32 / dm_sgd_step_f32 over the flat arenas (with the clip coefficient folded in)
+    == torch.optim.AdamW / SGD after clip_grad_norm_, over several steps."""
+    import copy
+    import torch.nn as nn
+    from detmatch_amd.mm3d import runner as R
+    from detmatch_amd.mm3d.parallel import FlatGradDDP
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.student = nn.ModuleDict(dict(
+                detector_3d=nn.Sequential(nn.Linear(37, 53), nn.ReLU(), nn.Linear(53, 7)),
+                detector_2d=nn.Sequential(nn.Linear(37, 29), nn.ReLU(), nn.Linear(29, 3))))
+
+        def forward(self, x):
+            return self.student['detector_3d'](x).square().mean() + self.student['detector_2d'](x).abs().mean()
+
+    cfg = {'constructor': 'HybridOptimizerConstructor',
+           'student.detector_3d': dict(type='AdamW', lr=0.01, betas=(0.95, 0.99), weight_decay=0.01),
+           'student.detector_2d': dict(type='SGD', lr=0.02, momentum=0.9, weight_decay=0.0001)}
+    torch.manual_seed(0)
+    a = Toy().to(dev)
+    b = copy.deepcopy(a)
+    ddp = FlatGradDDP(a, broadcast=False)
+    ddp.build_param_arena()
+    opt_a = R.build_optimizer(a, cfg)
+    assert opt_a.enable_fused(ddp) == 2
+    opt_b = R.build_optimizer(b, cfg)
+    for it in range(5):
+        x = torch.randn(16, 37, device=dev) * (30.0 if it % 2 else 1.0)   # clip active on odd steps
+        ddp.zero_grad()
+        a(x).backward()
+        ddp.finish()
+        norm_a, opt_a.grad_scale = ddp.clip_coef(max_norm=1.0)
+        opt_a.step()
+        opt_b.zero_grad()
+        b(x).backward()
+        norm_b = torch.nn.utils.clip_grad_norm_(list(b.parameters()), 1.0)
+        opt_b.step()
+        assert torch.allclose(norm_a, norm_b, rtol=1e-5)
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-6), (it, n)
+    sd = opt_a.state_dict()     # torch-compatible state view
+    assert len(sd['state'][0]) == 4 and 'exp_avg' in sd['state'][0][0] and 'momentum_buffer' in sd['state'][1][0]
