@@ -1,0 +1,41 @@
+"""Host -> device scalars/small arrays without stalling the queue.
+
+`torch.tensor(python_list, device='cuda')`, `x.new_tensor([...])`, `torch.as_tensor(numpy, device=...)`
+and indexing with Python lists copy from pageable host memory and then synchronise the stream: every
+such call drains the whole GPU queue, so the host can never run ahead of the device.  The hot path
+uses these two helpers instead:
+
+  const(values, device, dtype)   cached per (values, dtype, device): for true constants
+                                 (box-coder means/stds, voxel size, corner templates ...)
+  upload(values, device, dtype)  per-call data (img_meta matrices, per-sample counts): staged in
+                                 pinned memory, copied with non_blocking=True — no synchronisation.
+"""
+import numpy as np
+import torch
+
+_CACHE = {}
+
+
+def _key(values):
+    a = np.asarray(values)
+    return (a.shape, a.dtype.str, a.tobytes())
+
+
+def const(values, device, dtype=torch.float32):
+    device = torch.device(device)
+    k = (_key(values), dtype, device.type, device.index)
+    t = _CACHE.get(k)
+    if t is None:
+        t = _CACHE[k] = upload(values, device, dtype)
+    return t
+
+
+def upload(values, device, dtype=torch.float32):
+    device = torch.device(device)
+    if isinstance(values, torch.Tensor):
+        host = values.detach().to('cpu', dtype)
+    else:
+        host = torch.as_tensor(np.asarray(values)).to(dtype)
+    if device.type != 'cuda':
+        return host.to(device)
+    return host.pin_memory().to(device, non_blocking=True)

@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
+from ..devconst import const
 from ..mm3d.losses import bbox_overlaps
 from ..mm3d.registry import DETECTORS, LOSSES, build_from_cfg
 from ..roi_align import roi_align_fpn
@@ -74,12 +75,12 @@ class DeltaXYWHBBoxCoder(object):
         gx, gy = (g[..., 0] + g[..., 2]) * 0.5, (g[..., 1] + g[..., 3]) * 0.5
         gw, gh = g[..., 2] - g[..., 0], g[..., 3] - g[..., 1]
         d = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
-        return (d - d.new_tensor(self.means)) / d.new_tensor(self.stds)
+        return (d - const(self.means, d.device, d.dtype)) / const(self.stds, d.device, d.dtype)
 
     def decode(self, rois, deltas, max_shape=None, wh_ratio_clip=16 / 1000):
         n = deltas.size(-1) // 4
-        means = deltas.new_tensor(self.means).repeat(n)
-        stds = deltas.new_tensor(self.stds).repeat(n)
+        means = const(self.means * n, deltas.device, deltas.dtype)
+        stds = const(self.stds * n, deltas.device, deltas.dtype)
         d = deltas * stds + means
         dx, dy, dw, dh = d[..., 0::4], d[..., 1::4], d[..., 2::4], d[..., 3::4]
         max_ratio = abs(np.log(wh_ratio_clip))

@@ -4,7 +4,10 @@ mmdet3d/models/fusion_layers/coord_transform.py (extract_2d_info :91, bbox_2d_tr
 and mmdet3d/models/ssl_modules/utils.py (mlvl_get / mlvl_set / mlvl_getattr)."""
 from functools import partial
 
+import numpy as np
 import torch
+
+from ..devconst import const, upload
 
 from .. import _lib
 from .box3d import LiDARInstance3DBoxes
@@ -46,11 +49,15 @@ def apply_3d_transformation_bboxes(bbox, img_meta, reverse=False):
     The reverse rotation uses torch.inverse(M) in fp32 (:176), not M^T."""
     assert isinstance(img_meta, dict)
     dtype, device = bbox.tensor.dtype, bbox.tensor.device
-    rot = (torch.as_tensor(img_meta['pcd_rotation'], dtype=dtype, device=device)
-           if 'pcd_rotation' in img_meta else torch.eye(3, dtype=dtype, device=device))
+    # the record of the augmentation is host data: invert / negate it on the host (torch CPU, fp32,
+    # the same LAPACK path the reference takes on CPU tensors) and upload without a stream sync
+    rot_h = (torch.as_tensor(np.asarray(img_meta['pcd_rotation']), dtype=dtype)
+             if 'pcd_rotation' in img_meta else torch.eye(3, dtype=dtype))
     scale = img_meta['pcd_scale_factor'] if 'pcd_scale_factor' in img_meta else 1.
-    trans = (torch.as_tensor(img_meta['pcd_trans'], dtype=dtype, device=device)
-             if 'pcd_trans' in img_meta else torch.zeros((3), dtype=dtype, device=device))
+    trans_h = (torch.as_tensor(np.asarray(img_meta['pcd_trans']), dtype=dtype)
+               if 'pcd_trans' in img_meta else torch.zeros((3), dtype=dtype))
+    if isinstance(rot_h, torch.Tensor) and rot_h.is_cuda:
+        rot_h, trans_h = rot_h.cpu(), trans_h.cpu()
     hflip = img_meta.get('pcd_horizontal_flip', False)
     vflip = img_meta.get('pcd_vertical_flip', False)
     flow = img_meta.get('transformation_3d_flow', [])
@@ -59,13 +66,13 @@ def apply_3d_transformation_bboxes(bbox, img_meta, reverse=False):
     v_func = partial(bbox.flip, bev_direction='vertical') if vflip else (lambda: None)
     if reverse:
         scale_func = partial(bbox.scale, scale_factor=1.0 / scale)
-        translate_func = partial(bbox.translate, trans_vector=-trans)
-        rotate_func = partial(bbox.rotate, angle=rot.inverse())
+        translate_func = partial(bbox.translate, trans_vector=upload(-trans_h, device, dtype))
+        rotate_func = partial(bbox.rotate, angle=upload(rot_h.inverse(), device, dtype))
         flow = flow[::-1]
     else:
         scale_func = partial(bbox.scale, scale_factor=scale)
-        translate_func = partial(bbox.translate, trans_vector=trans)
-        rotate_func = partial(bbox.rotate, angle=rot)
+        translate_func = partial(bbox.translate, trans_vector=upload(trans_h, device, dtype))
+        rotate_func = partial(bbox.rotate, angle=upload(rot_h, device, dtype))
     mapping = {'T': translate_func, 'S': scale_func, 'R': rotate_func, 'HF': h_func, 'VF': v_func}
     for op in flow:
         assert op in mapping, 'This 3D data transformation op (%s) is not supported' % op
@@ -78,8 +85,9 @@ def bbox_3d_to_bbox_2d(bboxes_3d, lidar2img, img_shape):
     """bbox_utils.py:372-441 (autograd preserving).  Returns xyxy (N,4) for ALL boxes and the
     validity mask: >= 3 corners inside the image and mean (clamped) depth >= 0.5."""
     assert isinstance(bboxes_3d, LiDARInstance3DBoxes)
-    lidar2img = torch.as_tensor(lidar2img, dtype=bboxes_3d.tensor.dtype,
-                                device=bboxes_3d.tensor.device)
+    if not (isinstance(lidar2img, torch.Tensor) and lidar2img.is_cuda):
+        lidar2img = upload(lidar2img, bboxes_3d.tensor.device, bboxes_3d.tensor.dtype)
+    lidar2img = lidar2img.to(bboxes_3d.tensor)
     assert lidar2img.shape == (4, 4)
     n = len(bboxes_3d.tensor)
     img_v, img_h = img_shape[0], img_shape[1]
@@ -107,11 +115,11 @@ def extract_2d_info(img_meta, tensor):
     """coord_transform.py:91-118"""
     img_h, img_w, _ = img_meta['img_shape']
     ori_h, ori_w, _ = img_meta['ori_shape']
-    scale = (tensor.new_tensor(img_meta['scale_factor'][:2]) if 'scale_factor' in img_meta
-             else tensor.new_tensor([1.0, 1.0]))
+    scale = (upload(np.asarray(img_meta['scale_factor'][:2]), tensor.device, tensor.dtype)
+             if 'scale_factor' in img_meta else const([1.0, 1.0], tensor.device, tensor.dtype))
     flip = img_meta['flip'] if 'flip' in img_meta else False
-    crop = (tensor.new_tensor(img_meta['img_crop_offset']) if 'img_crop_offset' in img_meta
-            else tensor.new_tensor([0.0, 0.0]))
+    crop = (upload(np.asarray(img_meta['img_crop_offset']), tensor.device, tensor.dtype)
+            if 'img_crop_offset' in img_meta else const([0.0, 0.0], tensor.device, tensor.dtype))
     return img_h, img_w, ori_h, ori_w, scale, flip, crop
 
 
@@ -163,7 +171,7 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
         boxes_for_nms = boxes
     else:
         max_coordinate = boxes.max()
-        offsets = idxs.to(boxes) * (max_coordinate + boxes.new_tensor(1))
+        offsets = idxs.to(boxes) * (max_coordinate + 1)
         boxes_for_nms = boxes + offsets[:, None]
     dets, keep = nms_2d(boxes_for_nms, scores, thr)
     return torch.cat([boxes[keep], dets[:, -1:]], -1), keep

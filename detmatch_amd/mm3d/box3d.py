@@ -4,6 +4,8 @@ z_size, yaw); the origin argument re-anchors on construction (base_box3d.py:36-6
 import numpy as np
 import torch
 
+from ..devconst import const
+
 
 def limit_period(val, offset=0.5, period=np.pi):
     """structures/utils.py:5-21"""
@@ -45,9 +47,8 @@ class LiDARInstance3DBoxes(object):
         self.with_yaw = with_yaw
         self.tensor = tensor.clone()
         if tuple(origin) != (0.5, 0.5, 0):
-            dst = self.tensor.new_tensor((0.5, 0.5, 0))
-            src = self.tensor.new_tensor(origin)
-            self.tensor[:, :3] += self.tensor[:, 3:6] * (dst - src)
+            shift = const([0.5 - origin[0], 0.5 - origin[1], 0.0 - origin[2]], self.tensor.device)
+            self.tensor[:, :3] += self.tensor[:, 3:6] * shift
 
     # ---- views (base_box3d.py:68-147) ----------------------------------------
     @property
@@ -86,18 +87,17 @@ class LiDARInstance3DBoxes(object):
         """lidar_box3d.py:48-87: (N, 8, 3), order (x0y0z0, x0y0z1, x0y1z1, x0y1z0, x1y0z0, ...)."""
         assert len(self.tensor) != 0
         dims = self.dims
-        corners_norm = torch.from_numpy(
-            np.stack(np.unravel_index(np.arange(8), [2] * 3), axis=1)).to(device=dims.device,
-                                                                          dtype=dims.dtype)
-        corners_norm = corners_norm[[0, 1, 3, 2, 4, 5, 7, 6]]
-        corners_norm = corners_norm - dims.new_tensor([0.5, 0.5, 0])
+        cn = np.stack(np.unravel_index(np.arange(8), [2] * 3), axis=1).astype(np.float32)
+        cn = cn[[0, 1, 3, 2, 4, 5, 7, 6]] - np.array([0.5, 0.5, 0], np.float32)
+        corners_norm = const(cn, dims.device, dims.dtype)
         corners = dims.view([-1, 1, 3]) * corners_norm.reshape([1, 8, 3])
         corners = rotation_3d_in_axis(corners, self.tensor[:, 6], axis=2)
         return corners + self.tensor[:, :3].view(-1, 1, 3)
 
     @property
     def bev(self):
-        return self.tensor[:, [0, 1, 3, 4, 6]]
+        t = self.tensor
+        return torch.cat([t[:, 0:2], t[:, 3:5], t[:, 6:7]], dim=1)
 
     # ---- in-place transforms -----------------------------------------------------
     def rotate(self, angle, points=None):

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
+from ..devconst import const
 from .registry import BBOX_ASSIGNERS, LOSSES, MATCH_COST, build_match_cost
 
 
@@ -57,13 +58,12 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
         if mode == 'giou':
             e_lt = torch.min(bboxes1[..., :, None, :2], bboxes2[..., None, :, :2])
             e_rb = torch.max(bboxes1[..., :, None, 2:], bboxes2[..., None, :, 2:])
-    eps_t = union.new_tensor([eps])
-    union = torch.max(union, eps_t)
+    union = torch.clamp(union, min=eps)
     ious = overlap / union
     if mode == 'iou':
         return ious
     e_wh = (e_rb - e_lt).clamp(min=0)
-    enclose = torch.max(e_wh[..., 0] * e_wh[..., 1], eps_t)
+    enclose = torch.clamp(e_wh[..., 0] * e_wh[..., 1], min=eps)
     return ious - (enclose - union) / enclose
 
 
@@ -251,7 +251,7 @@ class ModHungarianAssigner(object):
                 assigned_gt_inds[:] = 0
             return AssignResult(num_gts, assigned_gt_inds, None, labels=assigned_labels)
         img_h, img_w, _ = img_meta['img_shape']
-        factor = gt_bboxes.new_tensor([img_w, img_h, img_w, img_h]).unsqueeze(0)
+        factor = const([img_w, img_h, img_w, img_h], gt_bboxes.device, gt_bboxes.dtype).unsqueeze(0)
         cls_cost = self.cls_cost(cls_pred, gt_labels)
         reg_cost = self.reg_cost(bbox_pred, gt_bboxes / factor)
         bboxes = bbox_cxcywh_to_xyxy(bbox_pred) * factor

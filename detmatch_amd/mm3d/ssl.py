@@ -297,7 +297,7 @@ class SSL(nn.Module):
             log_vars_dict.update({'%s/%s' % (tag, k): v for k, v in d.get('log_vars', {}).items()})
         curr_ssl_weight = self._get_curr_ssl_weight()
         ref = list(losses.values())[0] if len(losses) else list(ssl_losses.values())[0]
-        losses['ssl.weight'] = ref.new_tensor(curr_ssl_weight)
+        losses['ssl.weight'] = torch.full((), float(curr_ssl_weight), dtype=ref.dtype, device=ref.device)
         ssl_losses = self._collapse_losses(ssl_losses)
         for k in ssl_losses.keys():
             if '.metrics' not in k and '.acc' not in k:
@@ -305,7 +305,8 @@ class SSL(nn.Module):
         losses.update(add_prefix(ssl_losses, 'ssl'))
         losses['vis'] = vis_dict
         losses['log_vars'] = log_vars_dict
-        losses['ssl.ema_decay'] = ref.new_tensor(self._get_curr_ema_decay())
+        losses['ssl.ema_decay'] = torch.full((), float(self._get_curr_ema_decay()), dtype=ref.dtype,
+                                             device=ref.device)
         # the EMA runs INSIDE forward_train, before this iteration's backward / step
         # (ssl.py:348): teacher_t = d teacher_{t-1} + (1-d) student_{t-1, post-step}
         with torch.no_grad():

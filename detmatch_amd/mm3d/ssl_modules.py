@@ -11,6 +11,7 @@ from torch.nn import functional as F
 
 from .bbox_utils import (apply_3d_transformation_bboxes, bbox_2d_transform, bbox_3d_to_bbox_2d,
                          filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set)
+from ..devconst import const
 from .box3d import LiDARInstance3DBoxes
 from .losses import FocalLoss, MSELoss, bbox_xyxy_to_cxcywh
 from .openpcdet import pcdet_to_mm3d_boxes
@@ -285,7 +286,7 @@ class FusionHungarianMatching(object):
         else:
             proj = entry_3d[0]
         img_h, img_w, _ = img_meta['ori_shape']
-        factor = boxes2d.new_tensor([img_w, img_h, img_w, img_h]).unsqueeze(0)
+        factor = const([img_w, img_h, img_w, img_h], boxes2d.device, boxes2d.dtype).unsqueeze(0)
         proj_norm = bbox_xyxy_to_cxcywh(proj) / factor
         res = self.assigner.assign(proj_norm, torch.logit(s3, eps=1e-6), boxes2d,
                                    torch.logit(s2, eps=1e-6), dict(img_shape=img_meta['ori_shape']))
@@ -483,7 +484,7 @@ class HungarianConsistency(object):
                         raise Exception('Not Yet Implemented')
                 elif lname == 'l1_loss':
                     img_h, img_w, _ = metas[idx]['img_shape']
-                    factor = in_boxes.new_tensor([img_w, img_h, img_w, img_h]).unsqueeze(0)
+                    factor = const([img_w, img_h, img_w, img_h], in_boxes.device, in_boxes.dtype).unsqueeze(0)
                     val = fn(in_boxes / factor, tgt_boxes / factor)
                 else:
                     val = fn(in_boxes, tgt_boxes)
@@ -495,7 +496,7 @@ class HungarianConsistency(object):
             if k in losses:
                 losses[k] = losses[k] * w
             else:
-                losses[k] = ref.new_tensor(0.0, dtype=torch.float32, requires_grad=True)
+                losses[k] = torch.zeros((), dtype=torch.float32, device=ref.device, requires_grad=True)
         return _accumulate(ssl_obj, batch_dict, add_prefix(losses, self.name), prefer_sup=False)
 
 
@@ -510,8 +511,8 @@ class NumPreds(object):
         entries = mlvl_get(batch_dict, self.bboxes_key)
         num = sum(e[0].shape[0] if isinstance(e, tuple) else e.shape[0] for e in entries) / len(entries)
         first = entries[0][0] if isinstance(entries[0], tuple) else entries[0]
-        batch_dict['ssl_losses']['metrics.' + self.out_name] = torch.tensor(
-            num, device=first.device, dtype=torch.float)
+        batch_dict['ssl_losses']['metrics.' + self.out_name] = torch.full(
+            (), float(num), device=first.device, dtype=torch.float)
         return batch_dict
 
 

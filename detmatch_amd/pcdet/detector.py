@@ -122,6 +122,8 @@ class PVRCNN(nn.Module):
         batch_size = batch_dict['batch_size']
         recall_dict = {}
         pred_dicts = []
+        staged = []
+        # pass 1: everything that stays on the device (scores, labels, fixed-size NMS)
         for index in range(batch_size):
             box_preds = batch_dict['batch_box_preds'][index]
             src_box_preds = box_preds
@@ -140,16 +142,24 @@ class PVRCNN(nn.Module):
                 label_preds = label_preds + 1
                 sem_scores = cls_preds
                 sem_scores_full = src_cls_preds
+            sel = valid = None
+            if not no_nms:
+                sel, valid = class_agnostic_nms_fixed(cls_preds.detach(), box_preds.detach(),
+                                                      cfg.NMS_CONFIG, score_thresh=cfg.SCORE_THRESH)
+            staged.append((box_preds, src_box_preds, cls_preds, src_cls_preds, label_preds, sem_scores,
+                           sem_scores_full, sel, valid))
+        # the ONE read-back of the call: how many boxes survive per sample (the reference returns
+        # variable-length tensors too, model_nms_utils.py:20)
+        if not no_nms:
+            keep_counts = torch.stack([st[8].sum() for st in staged]).tolist()
+        # pass 2: variable-length records
+        for index, (box_preds, src_box_preds, cls_preds, src_cls_preds, label_preds, sem_scores,
+                    sem_scores_full, sel, valid) in enumerate(staged):
             if no_nms:
                 selected = torch.arange(len(cls_preds), device=cls_preds.device)
                 selected_scores = cls_preds
             else:
-                sel, valid = class_agnostic_nms_fixed(cls_preds.detach(), box_preds.detach(),
-                                                      cfg.NMS_CONFIG, score_thresh=cfg.SCORE_THRESH)
-                # the one read-back of this sample: how many boxes survive (the reference
-                # returns variable-length tensors too, model_nms_utils.py:20)
-                n_keep = int(valid.sum().item())
-                selected = sel[:n_keep]
+                selected = sel[:int(keep_counts[index])]
                 selected_scores = cls_preds[selected]
             if cfg.OUTPUT_RAW_SCORE:
                 selected_scores = torch.max(src_cls_preds, dim=-1)[0][selected]

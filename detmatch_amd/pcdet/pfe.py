@@ -14,7 +14,14 @@ import torch
 import torch.nn as nn
 
 from .. import pointnet2_stack as pn2
+from ..devconst import upload
 from .utils import get_voxel_centers
+
+
+def batch_row_counts(batch_idx, batch_size):
+    """Rows per sample of a batch-index column (torch.bincount reads its output size back: sync)."""
+    ar = torch.arange(batch_size, device=batch_idx.device, dtype=batch_idx.dtype)
+    return (batch_idx.view(-1, 1) == ar.view(1, -1)).sum(dim=0).int()
 
 
 def bilinear_interpolate_torch(im, x, y):
@@ -146,8 +153,8 @@ class VoxelSetAbstraction(nn.Module):
         new_xyz_batch_cnt = torch.full((batch_size,), num_keypoints, dtype=torch.int32, device=dev)
         if 'raw_points' in self.model_cfg.FEATURES_SOURCE:
             raw_points = batch_dict['points']
-            xyz_batch_cnt = torch.tensor([int(c) for c in batch_dict['points_batch_cnt_host']],
-                                         dtype=torch.int32, device=dev)
+            xyz_batch_cnt = upload([int(c) for c in batch_dict['points_batch_cnt_host']], dev,
+                                   torch.int32)
             point_features = raw_points[:, 4:].contiguous() if raw_points.shape[1] > 4 else None
             _, pooled = self.SA_rawpoints(xyz=raw_points[:, 1:4].contiguous(),
                                           xyz_batch_cnt=xyz_batch_cnt, new_xyz=new_xyz,
@@ -161,7 +168,7 @@ class VoxelSetAbstraction(nn.Module):
                                     downsample_times=self.downsample_times_map[src_name],
                                     voxel_size=self.voxel_size,
                                     point_cloud_range=self.point_cloud_range)
-            xyz_batch_cnt = torch.bincount(cur_coords[:, 0].long(), minlength=batch_size).int()
+            xyz_batch_cnt = batch_row_counts(cur_coords[:, 0], batch_size)
             _, pooled = self.SA_layers[k](xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt,
                                           new_xyz=new_xyz, new_xyz_batch_cnt=new_xyz_batch_cnt,
                                           features=sp.features.contiguous())

@@ -17,9 +17,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, iou3d_nms
+from ..devconst import const
 from .. import pointnet2_stack as pn2
 from . import utils as U
 from .dense_heads import valid_gt_mask
+from .pfe import batch_row_counts
 
 
 def class_agnostic_nms_fixed(box_scores, box_preds, nms_config, score_thresh=None):
@@ -268,8 +270,9 @@ class PVRCNNHead(nn.Module):
     @staticmethod
     def get_dense_grid_points(rois, batch_size_rcnn, grid_size):
         """pvrcnn_head.py:140-149"""
-        faked = rois.new_ones((grid_size, grid_size, grid_size))
-        dense_idx = faked.nonzero().repeat(batch_size_rcnn, 1, 1).float()
+        g = np.arange(grid_size)
+        idx = np.stack(np.meshgrid(g, g, g, indexing='ij'), axis=-1).reshape(-1, 3)   # == ones.nonzero()
+        dense_idx = const(idx.astype(np.float32), rois.device).repeat(batch_size_rcnn, 1, 1)
         local_roi_size = rois.view(batch_size_rcnn, -1)[:, 3:6]
         return (dense_idx + 0.5) / grid_size * local_roi_size.unsqueeze(dim=1) \
             - (local_roi_size.unsqueeze(dim=1) / 2)
@@ -290,7 +293,7 @@ class PVRCNNHead(nn.Module):
         global_pts, _ = self.get_global_grid_points_of_roi(rois, grid_size=gs)
         global_pts = global_pts.view(batch_size, -1, 3)
         xyz = point_coords[:, 1:4]
-        xyz_batch_cnt = torch.bincount(point_coords[:, 0].long(), minlength=batch_size).int()
+        xyz_batch_cnt = batch_row_counts(point_coords[:, 0], batch_size)
         new_xyz = global_pts.view(-1, 3)
         new_xyz_batch_cnt = torch.full((batch_size,), global_pts.shape[1], dtype=torch.int32,
                                        device=xyz.device)

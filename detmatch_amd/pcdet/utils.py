@@ -6,6 +6,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..devconst import const
+
 
 # ---------------------------------------------------------------- common_utils
 def limit_period(val, offset=0.5, period=np.pi):
@@ -28,9 +30,9 @@ def rotate_points_along_z(points, angle):
 def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):
     """common_utils.py:65-82: (idx[x,y,z] + 0.5) * voxel * stride + range_min."""
     assert voxel_coords.shape[1] == 3
-    voxel_centers = voxel_coords[:, [2, 1, 0]].float()
-    voxel_size = torch.tensor(voxel_size, device=voxel_centers.device).float() * downsample_times
-    pc_range = torch.tensor(point_cloud_range[0:3], device=voxel_centers.device).float()
+    voxel_centers = voxel_coords.flip(-1).float()      # (z, y, x) -> (x, y, z)
+    voxel_size = const([float(v) * downsample_times for v in voxel_size], voxel_centers.device)
+    pc_range = const([float(v) for v in point_cloud_range[0:3]], voxel_centers.device)
     return (voxel_centers + 0.5) * voxel_size + pc_range
 
 
@@ -41,7 +43,7 @@ _CORNER_TEMPLATE = ([1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1],
 
 def boxes_to_corners_3d(boxes3d):
     """box_utils.py:28-56 (corner order of the docstring there)."""
-    template = boxes3d.new_tensor(_CORNER_TEMPLATE) / 2
+    template = const(_CORNER_TEMPLATE, boxes3d.device, boxes3d.dtype) / 2
     corners3d = boxes3d[:, None, 3:6].repeat(1, 8, 1) * template[None, :, :]
     corners3d = rotate_points_along_z(corners3d.view(-1, 8, 3), boxes3d[:, 6]).view(-1, 8, 3)
     return corners3d + boxes3d[:, None, 0:3]
@@ -50,7 +52,7 @@ def boxes_to_corners_3d(boxes3d):
 def enlarge_box3d(boxes3d, extra_width=(0, 0, 0)):
     """box_utils.py:145-158"""
     large = boxes3d.clone()
-    large[:, 3:6] += boxes3d.new_tensor(extra_width)[None, :]
+    large[:, 3:6] += const([float(v) for v in extra_width], boxes3d.device, boxes3d.dtype)[None, :]
     return large
 
 

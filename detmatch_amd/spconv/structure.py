@@ -10,7 +10,7 @@ def scatter_nd(indices, updates, shape):
     output_shape = list(indices.shape[:-1]) + shape[indices.shape[-1]:]
     flat = indices.view(-1, ndim)
     slices = [flat[:, i] for i in range(ndim)] + [Ellipsis]
-    ret[slices] = updates.view(*output_shape)
+    ret[tuple(slices)] = updates.view(*output_shape)
     return ret
 
 
