@@ -56,6 +56,7 @@ class OpenPCDetDetector(nn.Module):
                                    num_class=len(dataset_fields.class_names),
                                    dataset=dataset_fields)
         self.num_classes = len(dataset_fields.class_names)
+        self._geom_cache = {}
 
     @torch.no_grad()
     def voxelize(self, points, with_mean=False):
@@ -70,7 +71,26 @@ class OpenPCDetDetector(nn.Module):
             return v, n, c, mean
         return v, n, c
 
+    def prepare_geometry(self, points, img_metas=None):
+        """Everything of a forward pass that depends on the points only, not on the weights:
+        voxels (+ fused MeanVFE), all rulebooks of the sparse backbone and the FPS key-points (side
+        stream).  SSL.forward_train issues this for every pass of the iteration up front, so that the
+        data-dependent size read-backs (voxel count, N_out of the 4 strided rulebooks) happen at
+        the step boundary and the passes themselves enqueue without stalling.  Must be called in
+        the mode (train / eval) the pass will run in."""
+        res = self._base_batch(points, img_metas)
+        bb = getattr(self.model, 'backbone_3d', None)
+        if bb is not None and hasattr(bb, 'build_rulebooks'):
+            res['indice_dict_prefetch'] = bb.build_rulebooks(res['voxel_coords'], res['batch_size'])
+        self._geom_cache[id(points)] = (points, self.training, res)
+
     def _base_batch(self, points, img_metas):
+        hit = self._geom_cache.pop(id(points), None)
+        if hit is not None and hit[0] is points and hit[1] == self.training:
+            res = hit[2]
+            if img_metas is not None:
+                res['frame_id'] = np.array([m.get('sample_idx', i) for i, m in enumerate(img_metas)])
+            return res
         voxels, num_points, coors, mean = self.voxelize(points, with_mean=True)
         res = dict(batch_size=len(points), voxels=voxels, voxel_num_points=num_points,
                    voxel_coords=coors, voxel_features=mean)

@@ -106,7 +106,9 @@ class FlatGradDDP(nn.Module):
                     off += t.numel()
 
     # ---- step protocol: zero_grad() -> backward -> finish() -------------------------------
-    def zero_grad(self):
+    def zero_grad(self, arm=True):
+        """arm=False: zero only; the bucket hooks stay quiet until arm() (several backward passes
+        accumulate into the arena, only the last one may trigger the exchange)."""
         self.flat.zero_()
         for p in self.params:      # optimizers / user code may have replaced .grad
             if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
@@ -115,6 +117,10 @@ class FlatGradDDP(nn.Module):
         self._left = list(self._need)
         self._sent = [False] * len(self.buckets)
         self._pending = []
+        self._armed = arm
+
+    def arm(self):
+        self._left = list(self._need)
         self._armed = True
 
     def _launch(self, b):

@@ -248,9 +248,19 @@ class OptimizerHook(Hook):
     def __init__(self, grad_clip=None):
         self.grad_clip = grad_clip
 
+    @staticmethod
+    def _early(runner):
+        return isinstance(runner.model, FlatGradDDP) and getattr(_inner(runner.model), 'early_backward', False)
+
+    def before_train_iter(self, runner):
+        if self._early(runner):      # the model back-propagates part of the loss inside train_step
+            runner.model.zero_grad(arm=False)
+
     def after_train_iter(self, runner):
         ddp = runner.model if isinstance(runner.model, FlatGradDDP) else None
-        if ddp is not None:
+        if ddp is not None and self._early(runner):
+            ddp.arm()
+        elif ddp is not None:
             ddp.zero_grad()
         else:
             runner.optimizer.zero_grad()

@@ -281,9 +281,24 @@ class SSL(nn.Module):
         assert lab_stu.get('gt_bboxes_ignore', None) is None and \
             lab_tea.get('gt_bboxes_ignore', None) is None
         lab_dict = dict(stu=lab_stu, tea=lab_tea, sup_losses=dict(), ssl_losses=dict())
+        unlab_dict = dict(stu=unlab_stu, tea=unlab_tea, ssl_losses=dict())
+        # weight-independent geometry of every pass of the iteration, issued up front
+        for chain, d in ((self.lab_ssl_modules, lab_dict), (self.unlab_ssl_modules, unlab_dict)):
+            for m in chain:
+                if hasattr(m, 'prefetch'):
+                    m.prefetch(self, d)
         for m in self.lab_ssl_modules:
             lab_dict = m.forward(self, lab_dict)
-        unlab_dict = dict(stu=unlab_stu, tea=unlab_tea, ssl_losses=dict())
+        if getattr(self, 'early_backward', False) and torch.is_grad_enabled():
+            # Scheduling only: d(sum of losses) = sum of d(losses), so the supervised part can be
+            # back-propagated now.  Its (GPU-bound) backward then runs underneath the host-bound
+            # teacher / pseudo-label phase instead of after it, and its graph is freed early.
+            # Gradients accumulate in the flat arena (zeroed at the start of the iteration).
+            sup = self._collapse_losses(dict(lab_dict['sup_losses']))
+            terms = [v for k, v in sup.items() if 'loss' in k and v.requires_grad]
+            if terms:
+                sum(terms).backward()
+            lab_dict['sup_losses'] = {k: v.detach() for k, v in sup.items()}
         for m in self.unlab_ssl_modules:
             unlab_dict = m.forward(self, unlab_dict)
         losses = dict()

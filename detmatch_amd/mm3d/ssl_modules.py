@@ -81,6 +81,12 @@ class Opd_SimpleTest_3D(object):
         self.batch_dict_key = batch_dict_key
         self.out_bboxes_key = out_bboxes_key
 
+    def prefetch(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        if hasattr(detector, 'prepare_geometry'):
+            detector.prepare_geometry(cur['points'], cur['img_metas'])
+
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
         cur = mlvl_get(batch_dict, self.batch_dict_key)
@@ -112,6 +118,12 @@ class Opd_HardPseudoLabel_3D(object):
         self.no_nms = no_nms
         self.box_dim = box_dim
 
+    def prefetch(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.target_batch_dict_key)
+        if hasattr(detector, 'prepare_geometry'):
+            detector.prepare_geometry(cur['points'], cur['img_metas'])
+
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
         cur = mlvl_get(batch_dict, self.target_batch_dict_key)
@@ -140,6 +152,12 @@ class Opd_Supervised_3D(object):
         self.batch_dict_key = batch_dict_key
         self.name = name
         self.weight = weight
+
+    def prefetch(self, ssl_obj, batch_dict):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        if hasattr(detector, 'prepare_geometry'):
+            detector.prepare_geometry(cur['points'], cur['img_metas'])
 
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)

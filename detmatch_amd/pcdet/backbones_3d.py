@@ -103,11 +103,34 @@ class VoxelBackBone8x(nn.Module):
         self._freeze_stages()
         return self
 
+    @torch.no_grad()
+    def build_rulebooks(self, voxel_coords, batch_size):
+        """The 8 rulebooks of the 12 convolutions, from the voxel coordinates alone (they do not
+        depend on the weights): {indice_key: (outids, in_indices, indice_pairs, indice_num, shape)},
+        the cache format of SparseConvolution.forward (spconv/conv.py:146-172)."""
+        from ..spconv import ops as sp_ops
+        from ..spconv.conv import SparseConvolution
+        indice_dict = {}
+        indices, shape = voxel_coords.int(), list(self.sparse_shape)
+        for m in self.modules():
+            if not isinstance(m, SparseConvolution) or m.conv1x1:
+                continue
+            out_shape = shape if m.subm else sp_ops.get_conv_output_size(
+                shape, m.kernel_size, m.stride, m.padding, m.dilation)
+            if m.indice_key not in indice_dict:
+                outids, pairs, num = sp_ops.get_indice_pairs(
+                    indices, batch_size, shape, m.kernel_size, m.stride, m.padding, m.dilation,
+                    m.output_padding, m.subm, m.transposed)
+                indice_dict[m.indice_key] = (outids, indices, pairs, num, shape)
+            indices, shape = indice_dict[m.indice_key][0], out_shape
+        return indice_dict
+
     def forward(self, batch_dict):
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(),
                                     spatial_shape=self.sparse_shape,
                                     batch_size=batch_dict['batch_size'])
+        x.indice_dict.update(batch_dict.pop('indice_dict_prefetch', None) or {})
         x = self.conv_input(x)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)

@@ -73,7 +73,8 @@ def boxes_iou_normal(boxes_a, boxes_b):
 def boxes3d_lidar_to_aligned_bev_boxes(boxes3d):
     """box_utils.py:272-283"""
     rot_angle = limit_period(boxes3d[:, 6], offset=0.5, period=np.pi).abs()
-    choose_dims = torch.where(rot_angle[:, None] < np.pi / 4, boxes3d[:, [3, 4]], boxes3d[:, [4, 3]])
+    dims = boxes3d[:, 3:5]
+    choose_dims = torch.where(rot_angle[:, None] < np.pi / 4, dims, dims.flip(-1))
     return torch.cat((boxes3d[:, 0:2] - choose_dims / 2, boxes3d[:, 0:2] + choose_dims / 2), dim=1)
 
 

@@ -231,6 +231,7 @@ class DetMatchTrainWorkload(object):
         sched = configs.detmatch_schedule(batch_size, 1)
         self.ddp = FlatGradDDP(self.model, broadcast=False)
         self.opt = R.build_optimizer(self.model, sched['optimizer'])
+        self.model.early_backward = True
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
         self.n_fused = self.opt.enable_fused(self.ddp)
         self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)
