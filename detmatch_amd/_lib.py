@@ -61,6 +61,8 @@ SIGNATURES = {
     'dm_ball_query_stack': (ci, [ci, ci, cf, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
     'dm_group_points_stack': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     'dm_group_points_grad_stack': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
+    'dm_query_group_rows': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'dm_group_rows_grad': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     'dm_furthest_point_sampling': (ci, [ci, ci, ci, vp, vp, vp, vp]),
     'dm_furthest_point_sampling_stack': (ci, [ci, c_i32_p, ci, vp, vp, vp, vp]),
     'dm_points_in_boxes': (ci, [ci, ci, ci, vp, vp, vp, vp]),

@@ -350,6 +350,118 @@ __global__ __launch_bounds__(256) void group_points_grad_combine(int batch, int 
   }
 }
 
+// ---- fused QueryAndGroup in row layout ---------------------------------------------------------
+// pointnet2_utils.py:119-156 produces (M, 3+C, nsample) with three launches + cat and the shared
+// MLP then runs as 1x1 Conv2d on a (1, C, M, nsample) view (a strided copy first).  In row layout
+// out (M, nsample, 3+C) a reference is one contiguous row: the gather is a coalesced row copy, the
+// MLP a plain GEMM on (M*nsample, C) rows and BatchNorm a column reduction — no transposes, no cat.
+__device__ __forceinline__ int sample_start(int q, int batch, const int *__restrict__ q_cnt,
+                                            const int *__restrict__ src_cnt) {
+  int upto = q_cnt[0], start = 0;
+  for (int k = 1; k < batch && q >= upto; ++k) {
+    start += src_cnt[k - 1];
+    upto += q_cnt[k];
+  }
+  return start;
+}
+
+__global__ __launch_bounds__(256) void query_group_rows_kernel(
+    int batch, int m, int c, int nsample, int use_xyz, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, const float *__restrict__ feats,
+    const int *__restrict__ xyz_cnt, const int *__restrict__ new_cnt, const int *__restrict__ idx,
+    const unsigned char *__restrict__ empty, float *__restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + wave;     // reference = (query, sample)
+  if (r >= (long long)m * nsample) return;
+  const int q = (int)(r / nsample);
+  const int width = (use_xyz ? 3 : 0) + c;
+  float *o = out + r * width;
+  if (empty && empty[q]) {
+    for (int e = lane; e < width; e += 64) o[e] = 0.0f;
+    return;
+  }
+  const int src = sample_start(q, batch, new_cnt, xyz_cnt) + idx[r];
+  if (use_xyz && lane < 3) o[lane] = xyz[(size_t)src * 3 + lane] - new_xyz[(size_t)q * 3 + lane];
+  const float *f = feats + (size_t)src * c;
+  float *of = o + (use_xyz ? 3 : 0);
+  for (int e = lane; e < c; e += 64) of[e] = f[e];
+}
+
+// backward: grad_feats[src, :] += grad_out[r, col_off : col_off + c].  Small query sets: one
+// coalesced row of global atomics per reference.  Large ones (RoI-grid pooling): per-workgroup LDS
+// hash of the distinct source rows first (see group_points_grad_combine), flush once per row.
+__global__ __launch_bounds__(256) void group_rows_grad_direct(
+    int batch, int m, int c, int nsample, int width, int col_off, const float *__restrict__ gout,
+    const int *__restrict__ idx, const int *__restrict__ q_cnt, const int *__restrict__ src_cnt,
+    const unsigned char *__restrict__ empty, float *__restrict__ gfeats) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= (long long)m * nsample) return;
+  const int q = (int)(r / nsample);
+  if (empty && empty[q]) return;
+  const int src = sample_start(q, batch, q_cnt, src_cnt) + idx[r];
+  const float *g = gout + r * width + col_off;
+  float *dst = gfeats + (size_t)src * c;
+  for (int e = lane; e < c; e += 64) unsafeAtomicAdd(dst + e, g[e]);
+}
+
+__global__ __launch_bounds__(256) void group_rows_grad_combine(
+    int batch, int m, int c, int nsample, int width, int col_off, int chunk, int n_slots,
+    const float *__restrict__ gout, const int *__restrict__ idx, const int *__restrict__ q_cnt,
+    const int *__restrict__ src_cnt, const unsigned char *__restrict__ empty,
+    float *__restrict__ gfeats) {
+  extern __shared__ float gpc_lds[];
+  float *acc = gpc_lds;                                   // [n_slots][c]
+  int *keys = (int *)(acc + (size_t)n_slots * c);         // [n_slots] source row or -1
+  const int q0 = blockIdx.x * chunk;
+  const int nq = min(chunk, m - q0);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < n_slots * c; i += 256) acc[i] = 0.0f;
+  for (int i = tid; i < n_slots; i += 256) keys[i] = -1;
+  __syncthreads();
+  // 1. every thread hashes references in parallel -> slot (or -1: table full / empty ball)
+  short *slot_of = (short *)(keys + n_slots);             // [chunk * nsample]
+  for (int rl = tid; rl < nq * nsample; rl += 256) {
+    const int q = q0 + rl / nsample;
+    int slot = -2;                                        // -2: skip (empty ball)
+    if (!(empty && empty[q])) {
+      const int src = sample_start(q, batch, q_cnt, src_cnt) + idx[(long long)q0 * nsample + rl];
+      unsigned h = ((unsigned)src * 2654435761u) % (unsigned)n_slots;
+      slot = -1;
+      for (int probe = 0; probe < n_slots; ++probe) {
+        const int old = atomicCAS(&keys[h], -1, src);
+        if (old == -1 || old == src) {
+          slot = (int)h;
+          break;
+        }
+        h = h + 1 == (unsigned)n_slots ? 0u : h + 1;
+      }
+    }
+    slot_of[rl] = (short)slot;
+  }
+  __syncthreads();
+  // 2. one wave per reference row: contiguous read, conflict-free LDS adds
+  for (int rl = wave; rl < nq * nsample; rl += 4) {
+    const int slot = slot_of[rl];
+    if (slot == -2) continue;
+    const long long r = (long long)q0 * nsample + rl;
+    const float *g = gout + r * width + col_off;
+    if (slot >= 0) {
+      for (int e = lane; e < c; e += 64) unsafeAtomicAdd(&acc[slot * c + e], g[e]);
+    } else {
+      const int q = q0 + rl / nsample;
+      float *dst = gfeats + (size_t)(sample_start(q, batch, q_cnt, src_cnt) + idx[r]) * c;
+      for (int e = lane; e < c; e += 64) unsafeAtomicAdd(dst + e, g[e]);
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < n_slots * c; f += 256) {
+    const int slot = f / c, ci = f - slot * c;
+    const int key = keys[slot];
+    if (key >= 0) unsafeAtomicAdd(gfeats + (size_t)key * c + ci, acc[f]);
+  }
+}
+
 // ---- furthest point sampling ----------------------------------------------------
 // One 1024-thread workgroup per sample; each thread keeps its points (xyz + running min
 // distance) in registers for all m-1 rounds, so a round is pure VALU + one cross-wave
@@ -639,6 +751,68 @@ extern "C" int dm_group_points_grad_stack(int batch, int m, int c, int n, int ns
   size_t smem = 4ull * (c + 1) * nsample * sizeof(float);
   group_points_grad_kernel<<<dm_ceil_div(m, 4), 256, smem, st>>>(
       batch, m, c, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_query_group_rows(int batch, int m, int c, int nsample, int use_xyz,
+                                   const float *xyz, const float *new_xyz, const float *features,
+                                   const int *xyz_batch_cnt, const int *new_xyz_batch_cnt,
+                                   const int *idx, const unsigned char *empty_mask, float *out,
+                                   dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (batch <= 0 || m < 0 || c < 0 || nsample <= 0 || (!use_xyz && c == 0)) return DM_ERR_INVALID_ARG;
+  if (m == 0) return DM_OK;
+  if (!xyz || !new_xyz || !xyz_batch_cnt || !new_xyz_batch_cnt || !idx || !out || (c > 0 && !features))
+    return DM_ERR_INVALID_ARG;
+  long long refs = (long long)m * nsample;
+  query_group_rows_kernel<<<(unsigned)((refs + 3) / 4), 256, 0, st>>>(
+      batch, m, c, nsample, use_xyz, xyz, new_xyz, features, xyz_batch_cnt, new_xyz_batch_cnt, idx,
+      empty_mask, out);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_group_rows_grad(int batch, int m, int c, int n, int nsample, int row_width,
+                                  int col_offset, const float *grad_out, const int *idx,
+                                  const int *idx_batch_cnt, const int *features_batch_cnt,
+                                  const unsigned char *empty_mask, float *grad_features,
+                                  dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (batch <= 0 || m < 0 || c <= 0 || nsample <= 0 || n < 0 || col_offset < 0 ||
+      col_offset + c > row_width)
+    return DM_ERR_INVALID_ARG;
+  if (n > 0) {
+    if (!grad_features) return DM_ERR_INVALID_ARG;
+    DM_HIP(hipMemsetAsync(grad_features, 0, (size_t)n * c * sizeof(float), st));
+  }
+  if (m == 0 || n == 0) return DM_OK;
+  if (!grad_out || !idx || !idx_batch_cnt || !features_batch_cnt) return DM_ERR_INVALID_ARG;
+  static bool attr = false;
+  if (!attr) {
+    DM_HIP(hipFuncSetAttribute((const void *)group_rows_grad_combine,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  if (m >= 16384 && g_gp_grad_combine) {
+    int chunk = dm_ceil_div(m, 256);
+    chunk = chunk < 32 ? 32 : (chunk > 256 ? 256 : chunk);
+    int n_slots = GPC_ACC_BYTES / (4 * c);
+    if (n_slots > GPC_MAX_SLOTS) n_slots = GPC_MAX_SLOTS;
+    size_t lds = ((size_t)n_slots * c * 4 + (size_t)n_slots * 4 + (size_t)chunk * nsample * 2 + 15) &
+                 ~(size_t)15;
+    if (n_slots >= 64 && lds <= 160 * 1024) {
+      group_rows_grad_combine<<<dm_ceil_div(m, chunk), 256, lds, st>>>(
+          batch, m, c, nsample, row_width, col_offset, chunk, n_slots, grad_out, idx, idx_batch_cnt,
+          features_batch_cnt, empty_mask, grad_features);
+      DM_CHECK_LAUNCH();
+      return DM_OK;
+    }
+  }
+  long long refs = (long long)m * nsample;
+  group_rows_grad_direct<<<(unsigned)((refs + 3) / 4), 256, 0, st>>>(
+      batch, m, c, nsample, row_width, col_offset, grad_out, idx, idx_batch_cnt, features_batch_cnt,
+      empty_mask, grad_features);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

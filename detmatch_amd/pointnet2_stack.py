@@ -121,6 +121,87 @@ class QueryAndGroup(nn.Module):
         return new_features, idx
 
 
+class QueryGroupRows(Function):
+    """Fused QueryAndGroup gather in row layout: -> (M, nsample, [3+]C) with
+    rows[m,s,0:3] = xyz[src] - new_xyz[m], rows[m,s,3:] = features[src], zero rows for empty balls
+    (the content of pointnet2_utils.py:139-153, one launch, no cat).  Gradient: features only."""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty_mask,
+                use_xyz):
+        _lib.require_device(xyz)
+        xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
+        xyz_batch_cnt = _i32(xyz_batch_cnt).contiguous()
+        new_xyz_batch_cnt = _i32(new_xyz_batch_cnt).contiguous()
+        c = 0 if features is None else features.shape[1]
+        if features is not None:
+            features = features.contiguous()
+        m, ns = idx.shape
+        width = (3 if use_xyz else 0) + c
+        out = torch.empty((m, ns, width), dtype=torch.float32, device=xyz.device)
+        em = empty_mask.contiguous().view(torch.uint8) if empty_mask is not None else None
+        _lib.check(_lib.lib().dm_query_group_rows(
+            xyz_batch_cnt.numel(), m, c, ns, int(use_xyz), _lib.ptr(xyz), _lib.ptr(new_xyz),
+            _lib.ptr(features) if features is not None else None, _lib.ptr(xyz_batch_cnt),
+            _lib.ptr(new_xyz_batch_cnt), _lib.ptr(idx), _lib.ptr(em) if em is not None else None,
+            _lib.ptr(out), _lib.stream()), 'dm_query_group_rows')
+        ctx.save_for_backward(idx, xyz_batch_cnt, new_xyz_batch_cnt, em)
+        ctx.meta = (features.shape[0] if features is not None else 0, c, width, 3 if use_xyz else 0)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, xyz_cnt, new_cnt, em = ctx.saved_tensors
+        n, c, width, off = ctx.meta
+        gfeat = None
+        if c > 0 and ctx.needs_input_grad[4]:
+            grad_out = grad_out.contiguous()
+            m, ns = idx.shape
+            gfeat = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+            _lib.check(_lib.lib().dm_group_rows_grad(
+                xyz_cnt.numel(), m, c, n, ns, width, off, _lib.ptr(grad_out), _lib.ptr(idx),
+                _lib.ptr(new_cnt), _lib.ptr(xyz_cnt), _lib.ptr(em) if em is not None else None,
+                _lib.ptr(gfeat), _lib.stream()), 'dm_group_rows_grad')
+        return None, None, None, None, gfeat, None, None, None
+
+
+class TallSkinnyLinear(Function):
+    """y = x @ w^T for x (R, Cin) with R in the hundreds of thousands and Cin, Cout <= a few hundred
+    (the shared MLP over all grouped references).  Forward / input gradient are ordinary GEMMs; the
+    weight gradient dW = dy^T x contracts over R, a shape (64 x 131 x 884736) a single GEMM launch
+    fills the chip poorly with: it is computed split-K as one batched GEMM over row chunks + a sum."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            rows = x.shape[0]
+            split = next((s for s in (256, 128, 64, 32, 16, 8) if rows % s == 0 and rows // s >= 2048), 1)
+            if split > 1:
+                gw = torch.bmm(gy.view(split, rows // split, -1).transpose(1, 2),
+                               x.view(split, rows // split, -1)).sum(dim=0)
+            else:
+                gw = gy.t() @ x
+        return gx, gw
+
+
+def query_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None,
+                     use_xyz=True):
+    """QueryAndGroup (pointnet2_utils.py:116-156) in row layout -> (M, nsample, [3+]C), idx."""
+    idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+    assert use_xyz or features is not None, 'Cannot have not features and not use xyz as a feature!'
+    rows = QueryGroupRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty,
+                                use_xyz)
+    return rows, idx
+
+
 class FurthestPointSampling(Function):
     """pointnet2_utils.py:158-180"""
 
@@ -187,6 +268,7 @@ class StackSAModuleMSG(nn.Module):
                                     nn.BatchNorm2d(mlp_spec[k + 1]), nn.ReLU()])
             self.mlps.append(nn.Sequential(*shared_mlps))
         self.pool_method = pool_method
+        self.row_layout = True      # False: the reference's (1, C, M, nsample) Conv2d formulation
         self.init_weights()
 
     def init_weights(self):
@@ -202,6 +284,27 @@ class StackSAModuleMSG(nn.Module):
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None,
                 empty_voxel_set_zeros=True):
         new_features_list = []
+        if self.row_layout and self.pool_method == 'max_pool':
+            # Row layout: a grouped reference is one contiguous row, the shared 1x1-conv MLP a GEMM
+            # over (M*nsample, C) rows, BatchNorm2d a column reduction over the same M*nsample
+            # elements per channel — the math of :72-83 without the (1, C, M, nsample) copies.
+            for k, g in enumerate(self.groupers):
+                rows, _ = query_group_rows(g.radius, g.nsample, xyz, xyz_batch_cnt, new_xyz,
+                                           new_xyz_batch_cnt, features, g.use_xyz)
+                m, ns, width = rows.shape
+                x = rows.view(m * ns, width)
+                mods = list(self.mlps[k])
+                for conv, bn in zip(mods[0::3], mods[1::3]):
+                    x = TallSkinnyLinear.apply(x, conv.weight.view(conv.out_channels, conv.in_channels))
+                    if conv.bias is not None:
+                        x = x + conv.bias
+                    if bn.training and bn.track_running_stats:
+                        bn.num_batches_tracked.add_(1)
+                    x = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                                     bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
+                    x = F.relu(x, inplace=True)
+                new_features_list.append(x.view(m, ns, -1).max(dim=1)[0])      # (M, C)
+            return new_xyz, torch.cat(new_features_list, dim=1)
         for k in range(len(self.groupers)):
             new_features, _ = self.groupers[k](xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
                                                features)  # (M, C, nsample)

@@ -303,6 +303,21 @@ int dm_group_points_grad_stack(int batch, int m, int c, int n, int nsample, cons
                                const int *idx, const int *idx_batch_cnt,
                                const int *features_batch_cnt, float *grad_features,
                                dm_stream_t stream);
+/* Fused QueryAndGroup gather in ROW layout (pointnet2_utils.py:119-156 = group xyz, subtract the
+ * ball centre, group features, cat; then StackSAModuleMSG permutes to (1,C,M,ns) for 1x1 convs,
+ * pointnet2_modules.py:72-76).  out (M, nsample, [3+]C): out[m,s,0:3] = xyz[src] - new_xyz[m],
+ * out[m,s,3:] = features[src]; rows of empty balls (empty_mask[m] != 0) are zero.  features may be
+ * NULL with c == 0 (xyz only). */
+int dm_query_group_rows(int batch, int m, int c, int nsample, int use_xyz, const float *xyz,
+                        const float *new_xyz, const float *features, const int *xyz_batch_cnt,
+                        const int *new_xyz_batch_cnt, const int *idx,
+                        const unsigned char *empty_mask, float *out, dm_stream_t stream);
+/* Its gradient w.r.t. features: grad_features[src,:] += grad_out[m,s,col_offset:col_offset+c]
+ * (grad_out rows have row_width floats).  grad_features (n, c) is zeroed by the callee. */
+int dm_group_rows_grad(int batch, int m, int c, int n, int nsample, int row_width, int col_offset,
+                       const float *grad_out, const int *idx, const int *idx_batch_cnt,
+                       const int *features_batch_cnt, const unsigned char *empty_mask,
+                       float *grad_features, dm_stream_t stream);
 /* Replaces furthest_point_sampling_wrapper (sampling_gpu.cu:25-189).  xyz (b,n,3),
  * temp (b,n) pre-filled with 1e10 by the caller, idxs (b,m). */
 int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float *temp, int *idxs,

@@ -198,3 +198,42 @@ def test_points_in_boxes(orc, dev):
     got = roiaware_pool3d.points_in_boxes_gpu(torch.from_numpy(p2).to(dev),
                                               torch.from_numpy(b2).to(dev))
     assert got.cpu().tolist() == [[0, 0, 1, 0, 1, 2, -1, -1, -1]]
+
+
+@pytest.mark.parametrize('m_per,c,with_feats', [(300, 16, True), (9000, 32, True), (500, 0, False)])
+def test_sa_module_row_layout_equals_reference_formulation(dev, m_per, c, with_feats):
+    """StackSAModuleMSG in row layout (fused gather, GEMM MLP, column BatchNorm) == the reference's
+    (1, C, M, nsample) Conv2d formulation built from the oracle-checked group ops: outputs, input
+    gradient, weight gradients and BatchNorm running statistics."""
+    import copy
+    from detmatch_amd import pointnet2_stack as pn
+    rng = np.random.default_rng(m_per + c)
+    n = [1500, 1100]
+    xyz = torch.from_numpy(rng.uniform(-4, 4, (sum(n), 3)).astype(np.float32)).to(dev)
+    new_xyz = torch.from_numpy(rng.uniform(-5, 5, (2 * m_per, 3)).astype(np.float32)).to(dev)
+    cnt = torch.tensor(n, dtype=torch.int32, device=dev)
+    ncnt = torch.tensor([m_per, m_per], dtype=torch.int32, device=dev)
+    torch.manual_seed(0)
+    a = pn.StackSAModuleMSG(radii=[0.6, 1.5], nsamples=[8, 16], mlps=[[c, 16, 24], [c, 16, 32]],
+                            use_xyz=True).to(dev)
+    b = copy.deepcopy(a)
+    b.row_layout = False
+    outs = []
+    for mod in (a, b):
+        f = None
+        if with_feats:
+            f = torch.from_numpy(rng.standard_normal((sum(n), c)).astype(np.float32)).to(dev) \
+                if not outs else outs[0][2].detach().clone()
+            f.requires_grad_()
+        _, y = mod(xyz, cnt, new_xyz, ncnt, f)
+        y.square().sum().backward()
+        outs.append((y, mod, f))
+    (ya, ma, fa), (yb, mb, fb) = outs
+    assert ya.shape == (2 * m_per, 24 + 32)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+    if with_feats:
+        assert torch.allclose(fa.grad, fb.grad, rtol=1e-3, atol=1e-3 * float(fb.grad.abs().max()))
+    for (na, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.allclose(pa.grad, pb.grad, rtol=1e-3, atol=1e-3 * float(pb.grad.abs().max())), na
+    for (na, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-4, atol=1e-5), na
