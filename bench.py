@@ -124,6 +124,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
+    if os.environ.get('DM_CUDNN_BENCHMARK'):     # tools/miopen_tune.sh: exhaustive MIOpen find
+        torch.backends.cudnn.benchmark = True
     from detmatch_amd import _lib
     wl = build_workload(dev, rank)
     if world > 1:

@@ -9,9 +9,18 @@ Here the gradients of all trainable parameters live in ONE flat fp32 arena (`p.g
 zeroed at the start of each step, so a parameter that gets no gradient contributes zeros by
 construction — no graph walk.  The arena is cut into a few large buckets (default 64 MiB: xGMI is
 point-to-point, ring steps are per-link bound, so fewer/larger messages win) in reverse
-registration order; a bucket's all-reduce is issued asynchronously as soon as autograd has
-produced its last gradient, overlapping the rest of backward; `finish()` issues whatever is left
-(buckets holding unused parameters) and waits.
+registration order.
+
+Two ways of getting gradients into the arena:
+  mode='collect' (default)  `.grad` starts as None, autograd keeps the first gradient of a
+      parameter without any kernel, and `collect()` adds all produced gradients into the arena with
+      batched multi-tensor launches (a dozen launches instead of one accumulation kernel per
+      parameter per backward pass: ~600 parameters x 2 passes per DetMatch iteration); `finish()`
+      then all-reduces the buckets.  216 MB over xGMI is ~1 % of an iteration, so not overlapping
+      it with backward costs nothing measurable.
+  mode='hooks'   `.grad` are views of the arena, autograd accumulates in place, and a bucket's
+      all-reduce is issued asynchronously as soon as its last gradient of the (final) backward pass
+      has been produced, overlapping the rest of backward.
 """
 import torch
 import torch.distributed as dist
@@ -21,8 +30,10 @@ import torch.nn as nn
 class FlatGradDDP(nn.Module):
 
     def __init__(self, module, params=None, bucket_bytes=64 << 20, process_group=None,
-                 broadcast=True):
+                 broadcast=True, mode='collect'):
         super().__init__()
+        assert mode in ('collect', 'hooks')
+        self.mode = mode
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -47,8 +58,10 @@ class FlatGradDDP(nn.Module):
         self._bucket_of = {}
         self._pending = []
         off, b_start, cap = 0, 0, max(1, bucket_bytes // 4)
+        self._view = {}
         for p in self.order:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self._view[id(p)] = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = self._view[id(p)] if mode == 'hooks' else None
             self.offset[id(p)] = off
             self._bucket_of[id(p)] = len(self.buckets)
             off += pad(p.numel())
@@ -63,8 +76,9 @@ class FlatGradDDP(nn.Module):
         self._left = list(self._need)
         self._sent = [False] * len(self.buckets)
         self._armed = False
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
+        if mode == 'hooks':
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
         if broadcast and self.world > 1:
             self.broadcast_parameters()
 
@@ -107,21 +121,37 @@ class FlatGradDDP(nn.Module):
 
     # ---- step protocol: zero_grad() -> backward -> finish() -------------------------------
     def zero_grad(self, arm=True):
-        """arm=False: zero only; the bucket hooks stay quiet until arm() (several backward passes
-        accumulate into the arena, only the last one may trigger the exchange)."""
+        """arm=False (hooks mode): zero only; the bucket hooks stay quiet until arm() (several
+        backward passes accumulate into the arena, only the last one may trigger the exchange)."""
         self.flat.zero_()
-        for p in self.params:      # optimizers / user code may have replaced .grad
-            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4:
-                raise RuntimeError('a gradient left the flat arena (zero_grad(set_to_none=True)?)')
+        if self.mode == 'collect':
+            for p in self.params:
+                p.grad = None
+        else:
+            for p in self.params:      # optimizers / user code may have replaced .grad
+                if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
+                        p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4:
+                    raise RuntimeError('a gradient left the flat arena (zero_grad(set_to_none=True)?)')
         self._left = list(self._need)
         self._sent = [False] * len(self.buckets)
         self._pending = []
-        self._armed = arm
+        self._armed = arm and self.mode == 'hooks'
+
+    def collect(self):
+        """collect mode: add the gradients autograd has produced so far into the arena (batched
+        multi-tensor adds) and release them.  Call after every backward pass."""
+        if self.mode != 'collect':
+            return
+        ps = [p for p in self.order if p.grad is not None and p.grad.data_ptr() != self._view[id(p)].data_ptr()]
+        if ps:
+            torch._foreach_add_([self._view[id(p)] for p in ps], [p.grad for p in ps])
+        for p in ps:
+            p.grad = None
 
     def arm(self):
-        self._left = list(self._need)
-        self._armed = True
+        if self.mode == 'hooks':
+            self._left = list(self._need)
+            self._armed = True
 
     def _launch(self, b):
         s, e = self.buckets[b]
@@ -138,8 +168,13 @@ class FlatGradDDP(nn.Module):
             self._launch(b)
 
     def finish(self):
-        """Issue the remaining buckets, wait for all, average."""
+        """Issue the remaining buckets, wait for all, average; afterwards `p.grad` are the arena
+        views (what clip / optimizers that are not fused read)."""
         self._armed = False
+        if self.mode == 'collect':
+            self.collect()
+            for p in self.order:
+                p.grad = self._view[id(p)]
         for b in range(len(self.buckets)):
             if not self._sent[b]:
                 self._launch(b)

@@ -298,6 +298,9 @@ class SSL(nn.Module):
             terms = [v for k, v in sup.items() if 'loss' in k and v.requires_grad]
             if terms:
                 sum(terms).backward()
+                hook = getattr(self, 'after_partial_backward', None)
+                if hook is not None:      # e.g. FlatGradDDP.collect
+                    hook()
             lab_dict['sup_losses'] = {k: v.detach() for k, v in sup.items()}
         for m in self.unlab_ssl_modules:
             unlab_dict = m.forward(self, unlab_dict)

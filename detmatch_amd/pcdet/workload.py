@@ -112,6 +112,8 @@ class PVRCNNTrainWorkload(object):
         from .. import configs
         from ..mm3d.box3d import LiDARInstance3DBoxes
         from ..mm3d.openpcdet import OpenPCDetDetector
+        import detmatch_amd
+        detmatch_amd.enable_tuned_miopen()
         self.frames = frames
         self.device = device
         self.points = [torch.from_numpy(f['points']).to(device) for f in frames]
@@ -212,6 +214,8 @@ class DetMatchTrainWorkload(object):
         from ..mm3d import runner as R
         from ..mm3d.ssl import SSL
         register_all()
+        import detmatch_amd
+        self.tuned_miopen = detmatch_amd.enable_tuned_miopen()
         self.batch_size, self.device = batch_size, device
         self.recipe = ssl_cfg or 'detmatch'
         chain = configs.confthr_pvrcnn_ssl_cfg() if ssl_cfg == 'confthr_pvrcnn' else \
@@ -232,6 +236,7 @@ class DetMatchTrainWorkload(object):
         self.ddp = FlatGradDDP(self.model, broadcast=False)
         self.opt = R.build_optimizer(self.model, sched['optimizer'])
         self.model.early_backward = True
+        self.model.after_partial_backward = self.ddp.collect
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
         self.n_fused = self.opt.enable_fused(self.ddp)
         self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)

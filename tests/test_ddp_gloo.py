@@ -34,7 +34,7 @@ class _Net(nn.Module):
         return self.frozen(self.b(torch.relu(self.bn(self.a(x)))))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
         from detmatch_amd.mm3d.parallel import FlatGradDDP
         torch.manual_seed(100 + rank)          # ranks start DIFFERENT: broadcast must fix it
         net = _Net()
-        ddp = FlatGradDDP(net, bucket_bytes=256)   # tiny buckets -> several async all-reduces
+        ddp = FlatGradDDP(net, bucket_bytes=256, mode=mode)   # tiny buckets -> several all-reduces
         assert len(ddp.buckets) > 2
         w0 = [torch.zeros_like(net.a.weight) for _ in range(world)]
         dist.all_gather(w0, net.a.weight.data)
@@ -85,11 +85,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_flat_grad_ddp_world2():
+@pytest.mark.parametrize('mode', ['collect', 'hooks'])
+def test_flat_grad_ddp_world2(mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -110,6 +111,20 @@ def test_flat_grad_single_process():
     ddp.finish()
     g = net.a.weight.grad
     assert g.data_ptr() >= ddp.flat.data_ptr() and g.abs().sum() > 0
-    net.a.weight.grad = None
+    # two backward passes with a collect() in between accumulate
+    x = torch.randn(3, 8)
+    ddp.zero_grad()
+    ddp(x).sum().backward()
+    ddp.collect()
+    assert net.a.weight.grad is None
+    ddp(x).sum().backward()
+    ddp.finish()
+    two = net.a.weight.grad.clone()
+    ddp.zero_grad()
+    ddp(x).sum().backward()
+    ddp.finish()
+    assert torch.allclose(two, 2 * net.a.weight.grad, atol=1e-6)
+    hk = FlatGradDDP(_Net(), mode='hooks')
+    hk.module.a.weight.grad = None
     with pytest.raises(RuntimeError):
-        ddp.zero_grad()
+        hk.zero_grad()
