@@ -4,6 +4,8 @@
 (BASELINE.json configs[1]) that is implemented so far; `describe()` says exactly
 which stages run inside a step.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -233,7 +235,7 @@ class DetMatchTrainWorkload(object):
         self.lab_iter = iter(_RepeatLoader(lab))
         self.unlab_iter = iter(_RepeatLoader(unlab))
         sched = configs.detmatch_schedule(batch_size, 1)
-        self.ddp = FlatGradDDP(self.model, broadcast=False)
+        self.ddp = FlatGradDDP(self.model, broadcast=False, mode=os.environ.get('DM_GRAD_MODE', 'collect'))
         self.opt = R.build_optimizer(self.model, sched['optimizer'])
         self.model.early_backward = True
         self.model.after_partial_backward = self.ddp.collect
