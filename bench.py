@@ -51,6 +51,21 @@ def gg_bytes(P, ci, co, kvol, rows_out):
     return P * (ci + co) * 4 + P * 8 + kvol * ci * co * 4 + rows_out * co * 4
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_spconv.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of
+    this same bench command, gfx950 correction applied — tools/pmc_traffic.py); None if absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_spconv.json')
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    stem = kernel.rstrip('>')
+    for k, v in table.items():
+        if k == kernel or k.startswith(stem + ','):
+            return v['traffic_bytes_per_launch']
+    return None
+
+
 def build_workload(dev, rank):
     from detmatch_amd import synth
     from detmatch_amd.pcdet.workload import (DetMatchTrainWorkload, PVRCNNTrainWorkload,
@@ -177,7 +192,7 @@ def main():
             tot_ms = sum(v['ms'] for v in groups.values())
             tot_b = sum(v['bytes'] for v in groups.values())
             roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel=name,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name), kernel=name,
                         avg_us=round(g['ms'] / g['launches'] * 1e3, 2), launches=g['launches'],
                         bytes_per_launch=int(g['bytes'] / g['launches']),
                         all_spconv_gg=dict(achieved=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),

@@ -206,9 +206,11 @@ __device__ __forceinline__ float iou_xyxy(const float *a, const float *b) {
 }
 
 __global__ __launch_bounds__(64) void nms_mask_2d(const float *boxes, int n, float thresh,
-                                                  unsigned long long *mask) {
-  const int row_start = blockIdx.y, col_start = blockIdx.x;
+                                                  unsigned long long *mask, int col_begin,
+                                                  const int *num_keep, int max_keep) {
+  const int row_start = blockIdx.y, col_start = blockIdx.x + col_begin;
   if (col_start < row_start) return;
+  if (num_keep && *num_keep >= max_keep) return;   // second phase not needed (see nms_two_phase)
   const int col_blocks = (n + 63) / 64;
   const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
   __shared__ float bb[64 * 4];
@@ -234,9 +236,11 @@ __global__ __launch_bounds__(64) void nms_mask_2d(const float *boxes, int n, flo
 // mask[r][c] bit i = iou(box_r, box_{64c+i}) > thresh; upper-triangular tiles only
 template <bool NORMAL>
 __global__ __launch_bounds__(64) void nms_mask(const float *boxes, const float2 *cs, int n,
-                                               float thresh, unsigned long long *mask) {
-  const int row_start = blockIdx.y, col_start = blockIdx.x;
+                                               float thresh, unsigned long long *mask, int col_begin,
+                                               const int *num_keep, int max_keep) {
+  const int row_start = blockIdx.y, col_start = blockIdx.x + col_begin;
   if (col_start < row_start) return;
+  if (num_keep && *num_keep >= max_keep) return;   // second phase not needed (see nms_two_phase)
   const int col_blocks = (n + 63) / 64;
   const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
   __shared__ float bb[64 * 7];
@@ -276,8 +280,13 @@ __device__ __forceinline__ unsigned long long wave_bcast64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// The pass can be split in two (nms_two_phase): boxes arrive sorted by score and callers keep only
+// the first max_keep survivors, which are almost always found among the first few thousand
+// candidates — so the mask is first computed for the leading blk_end blocks only, and the rest of the
+// (quadratic) mask + the rest of this pass run only if the budget was not met (`resume`).
 __global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *__restrict__ mask, int n,
-                                                 int max_keep, long long *keep, int *num_keep) {
+                                                 int max_keep, long long *keep, int *num_keep,
+                                                 int blk_begin, int blk_end, int resume) {
   const int col_blocks = (n + 63) / 64;
   const int lane = threadIdx.x;
   constexpr int MAXW = 16;  // up to 64*16 words = 65536 boxes
@@ -285,7 +294,28 @@ __global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *__res
 #pragma unroll
   for (int w = 0; w < MAXW; ++w) remv[w] = 0ull;
   int kept = 0;
-  for (int blk = 0; blk < col_blocks && kept < max_keep; ++blk) {
+  if (resume) {
+    kept = *num_keep;
+    if (kept >= max_keep) return;
+    // suppression state of the remaining blocks: OR the rows of the survivors found so far
+    for (int i0 = 0; i0 < kept; i0 += 8) {
+      const unsigned long long *rows[8];
+      const int cnt = min(8, kept - i0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rows[u] = mask + (size_t)keep[i0 + (u < cnt ? u : 0)] * col_blocks;
+#pragma unroll
+      for (int w = 0; w < MAXW; ++w) {
+        if (w * 64 >= col_blocks) break;
+        const int j = w * 64 + lane;
+        const bool in = j >= blk_begin && j < col_blocks;
+        unsigned long long t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (in && u < cnt) ? rows[u][j] : 0ull;
+        remv[w] |= ((t[0] | t[1]) | (t[2] | t[3])) | ((t[4] | t[5]) | (t[6] | t[7]));
+      }
+    }
+  }
+  for (int blk = blk_begin; blk < blk_end && kept < max_keep; ++blk) {
     // the word that decides boxes [64*blk, 64*blk+64) lives on lane blk%64, slot blk/64
     const int slot = blk >> 6, owner = blk & 63;
     unsigned long long word = 0;
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *__res
       for (int w = 0; w < MAXW; ++w) {
         if (w * 64 >= col_blocks) break;
         const int j = w * 64 + lane;
-        const bool in = j > blk && j < col_blocks;
+        const bool in = j > blk && j < blk_end;
         unsigned long long t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = (in && u < cnt) ? rows[u][j] : 0ull;
@@ -378,6 +408,17 @@ extern "C" size_t dm_nms_workspace_bytes(int n) {
   return dm_align((size_t)n * col_blocks * 8) + dm_align((size_t)n * sizeof(float2)) + 256;
 }
 
+// Blocks (of 64 score-sorted boxes) whose mask is computed up front: 4x the survivor budget, at
+// least 1024 boxes.  Everything when no budget applies.
+static int nms_lead_blocks(int n, int max_keep) {
+  const int col_blocks = (n + 63) / 64;
+  if (max_keep <= 0 || max_keep >= n) return col_blocks;
+  long long lead_boxes = 4ll * max_keep;
+  if (lead_boxes < 1024) lead_boxes = 1024;
+  int lead = (int)((lead_boxes + 63) / 64);
+  return lead < col_blocks ? lead : col_blocks;
+}
+
 static int nms_launch(bool normal, const float *boxes, int n, float thresh, int max_keep,
                       long long *keep, int *num_keep, void *ws, size_t ws_bytes, hipStream_t st) {
   if (n < 0 || !num_keep) return DM_ERR_INVALID_ARG;
@@ -397,10 +438,18 @@ static int nms_launch(bool normal, const float *boxes, int n, float thresh, int 
     DM_CHECK_LAUNCH();
   }
   dim3 grid(col_blocks, col_blocks);
-  if (normal) nms_mask<true><<<grid, 64, 0, st>>>(boxes, cs, n, thresh, mask);
-  else nms_mask<false><<<grid, 64, 0, st>>>(boxes, cs, n, thresh, mask);
-  DM_CHECK_LAUNCH();
-  nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep);
+  const int lead = nms_lead_blocks(n, max_keep);
+  for (int phase = 0; phase < (lead < col_blocks ? 2 : 1); ++phase) {
+    // phase 0: tiles (r <= c < lead), greedy over the leading blocks; phase 1 (skipped on the
+    // device when the budget is already met): tiles with c >= lead, greedy over the rest
+    const int c0 = phase == 0 ? 0 : lead, c1 = phase == 0 ? lead : col_blocks;
+    dim3 g(c1 - c0, c1);
+    const int *flag = phase == 0 ? nullptr : num_keep;
+    if (normal) nms_mask<true><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
+    else nms_mask<false><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
+    DM_CHECK_LAUNCH();
+    nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep, c0, c1, phase);
+  }
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -436,9 +485,14 @@ extern "C" int dm_nms_2d(const float *boxes_xyxy, int n, float thresh, int max_k
   if (max_keep <= 0 || max_keep > n) max_keep = n;
   int col_blocks = (n + 63) / 64;
   unsigned long long *mask = (unsigned long long *)workspace;
-  nms_mask_2d<<<dim3(col_blocks, col_blocks), 64, 0, st>>>(boxes_xyxy, n, thresh, mask);
-  DM_CHECK_LAUNCH();
-  nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep);
+  const int lead = nms_lead_blocks(n, max_keep);
+  for (int phase = 0; phase < (lead < col_blocks ? 2 : 1); ++phase) {
+    const int c0 = phase == 0 ? 0 : lead, c1 = phase == 0 ? lead : col_blocks;
+    nms_mask_2d<<<dim3(c1 - c0, c1), 64, 0, st>>>(boxes_xyxy, n, thresh, mask, c0,
+                                                   phase == 0 ? nullptr : num_keep, max_keep);
+    DM_CHECK_LAUNCH();
+    nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep, c0, c1, phase);
+  }
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -60,6 +60,26 @@ def test_nms_keep_lists(orc, dev, n, thresh, spread):
     assert np.array_equal(got_n.cpu().numpy(), want_n)
 
 
+@pytest.mark.parametrize('n,budget,spread', [(3000, 300, 4.0), (5000, 400, 5.0), (9000, 512, 60.0)])
+def test_nms_two_phase_budget(orc, dev, n, budget, spread):
+    """With a survivor budget the mask is built for the leading blocks first; crowded scenes
+    (small spread: few survivors among the first 1024 boxes) force the second phase to resume."""
+    from detmatch_amd import iou3d_nms
+    rng = np.random.default_rng(n + budget)
+    b = _boxes(rng, n, spread)
+    scores = rng.permutation(n).astype(np.float32)
+    order = np.argsort(-scores, kind='stable')
+    full = order[orc.nms(b[order], 0.3)]
+    want = full[:budget]
+    got, _ = iou3d_nms.nms_gpu(torch.from_numpy(b).to(dev), torch.from_numpy(scores).to(dev), 0.3,
+                               post_max_size=budget)
+    assert np.array_equal(got.cpu().numpy(), want)
+    lead_hits = int((np.isin(order[:max(4 * budget, 1024)], full)).sum())
+    if spread <= 6.0:
+        assert lead_hits < budget < n  # the case really exercises the resume path
+        assert len(full) > lead_hits   # ... and finds more survivors there
+
+
 def test_nms_empty(dev):
     from detmatch_amd import iou3d_nms
     k, _ = iou3d_nms.nms_gpu(torch.zeros((0, 7), device=dev), torch.zeros((0,), device=dev), 0.5)
