@@ -168,9 +168,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # one extra untimed step with the launch trace on — on EVERY rank (a step contains the gradient
+    # and log all-reduces; a rank stepping alone would dead-lock the others)
+    per_step = trace_launches(wl)   # [(ci, co, rows, kvol, P)] in launch order
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events from the timed region) ----
-        per_step = trace_launches(wl)   # [(ci, co, rows, kvol, P)] in launch order
         gg = [r for r in recs if r[0] == 0]
         roof = None
         # the synthetic batch is the same every step, so launch j of a step always sees the same
