@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import roiaware_pool3d
+from ..devconst import const
 from . import utils as U
 
 
@@ -96,7 +97,67 @@ class AxisAlignedTargetAssigner(object):
 
     def assign_targets(self, all_anchors, gt_boxes_with_classes):
         """all_anchors: [(1,ny,nx,1,n_rot,7)] per class; gt (B, M, 8) -> dict of
-        box_cls_labels (B, A) int32, box_reg_targets (B, A, 7), reg_weights (B, A)."""
+        box_cls_labels (B, A) int32, box_reg_targets (B, A, 7), reg_weights (B, A).
+
+        All anchor classes and all samples in ONE set of tensor ops ((C, B, A, M) overlaps):
+        `assign_targets_single` below is the same computation for one (class, sample) and is what
+        the tests compare this against; the reference loops samples x classes in Python with
+        .cpu().numpy() argmax read-backs (axis_aligned_target_assigner.py:36-130)."""
+        shapes = {tuple(a.shape) for a in all_anchors}
+        if len(shapes) != 1:         # per-class feature maps differ: fall back to the loop
+            return self._assign_targets_loop(all_anchors, gt_boxes_with_classes)
+        gt_classes = gt_boxes_with_classes[:, :, -1].int()
+        gt_boxes = gt_boxes_with_classes[:, :, :-1]
+        B, M = gt_boxes.shape[:2]
+        C = len(all_anchors)
+        fmap = all_anchors[0].shape[:3]
+        anchors = torch.stack([a.view(-1, a.shape[-1]) for a in all_anchors])       # (C, A, 7)
+        A = anchors.shape[1]
+        valid = valid_gt_mask(gt_boxes)
+        num_class = len(self.class_names)
+        cls_eff = torch.where(gt_classes == 0, torch.full_like(gt_classes, num_class), gt_classes)
+        dev, dt = anchors.device, anchors.dtype
+        cids = const([self.class_names.index(n) + 1 for n in self.anchor_class_names], dev, torch.int32)
+        matched = const([self.matched_thresholds[n] for n in self.anchor_class_names], dev, dt)
+        unmatched = const([self.unmatched_thresholds[n] for n in self.anchor_class_names], dev, dt)
+        sel = valid[None] & (cls_eff[None] == cids[:, None, None])                  # (C, B, M)
+        # nearest-BEV IoU (box_utils.py:286-298), broadcast to (C, B, A, M)
+        ab = U.boxes3d_lidar_to_aligned_bev_boxes(anchors.view(-1, anchors.shape[-1])[:, 0:7]).view(C, 1, A, 1, 4)
+        gb = U.boxes3d_lidar_to_aligned_bev_boxes(gt_boxes.reshape(-1, gt_boxes.shape[-1])[:, 0:7]).view(1, B, 1, M, 4)
+        x_len = torch.clamp_min(torch.min(ab[..., 2], gb[..., 2]) - torch.max(ab[..., 0], gb[..., 0]), min=0)
+        y_len = torch.clamp_min(torch.min(ab[..., 3], gb[..., 3]) - torch.max(ab[..., 1], gb[..., 1]), min=0)
+        area_a = (ab[..., 2] - ab[..., 0]) * (ab[..., 3] - ab[..., 1])
+        area_b = (gb[..., 2] - gb[..., 0]) * (gb[..., 3] - gb[..., 1])
+        inter = x_len * y_len
+        overlap = inter / torch.clamp_min(area_a + area_b - inter, min=1e-6)        # (C, B, A, M)
+        overlap = torch.where(sel[:, :, None, :], overlap, overlap.new_full((), -1.0))
+        a2g_max, a2g_arg = overlap.max(dim=3)                                        # (C, B, A)
+        g2a_max = overlap.max(dim=2)[0]                                              # (C, B, M)
+        g2a_max = torch.where((g2a_max == 0) | ~sel, g2a_max.new_full((), -2.0), g2a_max)
+        force = (overlap == g2a_max[:, :, None, :]).any(dim=3)                       # :154
+        cls_of_anchor = torch.gather(gt_classes[None].expand(C, B, M), 2, a2g_arg)
+        labels = torch.full((C, B, A), -1, dtype=torch.int32, device=dev)
+        labels = torch.where(force, cls_of_anchor, labels)                           # :156
+        labels = torch.where(a2g_max >= matched[:, None, None], cls_of_anchor, labels)   # :161
+        labels = torch.where(a2g_max < unmatched[:, None, None], torch.zeros_like(labels), labels)
+        labels = torch.where(force, cls_of_anchor, labels)                           # :188
+        labels = torch.where(sel.any(dim=2)[:, :, None], labels, torch.zeros_like(labels))
+        fg = labels > 0
+        idx7 = a2g_arg[..., None].expand(C, B, A, 7)
+        matched_gt = torch.gather(gt_boxes[None, :, :, 0:7].expand(C, B, M, 7), 2, idx7)
+        enc = self.box_coder.encode_torch(matched_gt.reshape(-1, 7),
+                                          anchors[:, None, :, 0:7].expand(C, B, A, 7).reshape(-1, 7))
+        enc = enc.view(C, B, A, -1)
+        tgt = torch.where(fg[..., None], enc, torch.zeros_like(enc))
+        code = self.box_coder.code_size
+        # per location the classes are concatenated: (B, ny, nx, [z], C * n_rot)
+        per_loc = A // (fmap[0] * fmap[1] * fmap[2])
+        to_loc = lambda t, tail: t.view(C, B, *fmap, per_loc, *tail).permute(
+            1, 2, 3, 4, 0, 5, *range(6, 6 + len(tail))).reshape(B, -1, *tail)
+        return {'box_cls_labels': to_loc(labels, ()), 'box_reg_targets': to_loc(tgt, (code,)),
+                'reg_weights': to_loc(fg.to(dt), ())}
+
+    def _assign_targets_loop(self, all_anchors, gt_boxes_with_classes):
         gt_classes = gt_boxes_with_classes[:, :, -1].int()
         gt_boxes = gt_boxes_with_classes[:, :, :-1]
         B = gt_boxes.shape[0]
