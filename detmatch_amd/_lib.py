@@ -134,8 +134,11 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag='default'):
-    """A reusable byte workspace per (device, tag); grows geometrically."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    """A reusable byte workspace per (device, HIP stream, tag); grows geometrically.  Keyed by the
+    current stream: work queued on different streams (2D / 3D lanes, FPS side stream) never shares
+    scratch memory."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)

@@ -27,6 +27,8 @@ def const(values, device, dtype=torch.float32):
     t = _CACHE.get(k)
     if t is None:
         t = _CACHE[k] = upload(values, device, dtype)
+        if device.type == 'cuda':      # cached constants are read from any stream later on
+            torch.cuda.current_stream(device).synchronize()
     return t
 
 

@@ -145,6 +145,10 @@ class FlatGradDDP(nn.Module):
         ps = [p for p in self.order if p.grad is not None and p.grad.data_ptr() != self._view[id(p)].data_ptr()]
         if ps:
             torch._foreach_add_([self._view[id(p)] for p in ps], [p.grad for p in ps])
+            if self.flat.is_cuda:      # gradients may have been produced on another stream (2D lane)
+                cur = torch.cuda.current_stream(self.flat.device)
+                for p in ps:
+                    p.grad.record_stream(cur)
         for p in ps:
             p.grad = None
 

@@ -22,6 +22,99 @@ def add_prefix(inputs, prefix):
     return {'%s.%s' % (prefix, k): v for k, v in inputs.items()}
 
 
+class _LaneDict(dict):
+    """Batch-dict shell that knows on which HIP stream ("lane") each entry was produced.  Reading
+    an entry produced on the other lane makes the reading stream wait for the producer's event and
+    registers the tensors with the reading stream (caching-allocator safety) — the data-flow edges
+    between the 2D and the 3D branch become stream dependencies, everything else runs concurrently."""
+
+    def __init__(self, data, lanes):
+        super().__init__(data)
+        self._lanes = lanes
+        self._event = {}          # key -> (lane id, event or None while the producer still runs)
+
+    # loss / log dictionaries are merged entry by entry without touching the existing tensors
+    # (SSL._sum_update_losses); they are made visible to the main lane by _Lanes.join()
+    UNTRACKED = ('sup_losses', 'ssl_losses', 'vis', 'log_vars')
+
+    def __setitem__(self, k, v):
+        ln = self._lanes
+        if k in self.UNTRACKED:
+            return super().__setitem__(k, v)
+        if isinstance(v, dict) and not isinstance(v, _LaneDict):
+            v = _LaneDict(v, ln)
+        super().__setitem__(k, v)
+        tok = [ln.current, None]
+        self._event[k] = tok
+        ln.pending.append(tok)
+
+    def _sync(self, k):
+        tok = self._event.get(k)
+        ln = self._lanes
+        if tok is not None and tok[0] != ln.current and tok[1] is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(tok[1])
+            ln.record(super().get(k), cur)
+
+    def __getitem__(self, k):
+        self._sync(k)
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._sync(k)
+        return super().get(k, default)
+
+
+class _Lanes(object):
+    """Two HIP streams for SSL.forward_train: lane 0 = the caller's stream (3D branch + all light
+    glue modules), lane 1 = a side stream for the modules that run the 2D detector."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.side = _Lanes._side.get(device.index)
+        if self.side is None:
+            self.side = _Lanes._side[device.index] = torch.cuda.Stream(device=device)
+        self.current = 0
+        self.pending = []
+
+    _side = {}
+
+    def stream(self, lane):
+        return self.side if lane else self.main
+
+    @staticmethod
+    def record(value, stream):
+        if isinstance(value, torch.Tensor):
+            if value.is_cuda:
+                value.record_stream(stream)
+        elif hasattr(value, 'tensor') and isinstance(value.tensor, torch.Tensor):
+            _Lanes.record(value.tensor, stream)
+        elif isinstance(value, (list, tuple)):
+            for v in value:
+                _Lanes.record(v, stream)
+        elif isinstance(value, dict):
+            for v in value.values():
+                _Lanes.record(v, stream)
+
+    def run(self, module, ssl_obj, batch_dict):
+        lane = 1 if getattr(module, 'ssl_obj_attr', '').endswith('detector_2d') else 0
+        self.current, self.pending = lane, []
+        with torch.cuda.stream(self.stream(lane)):
+            out = module.forward(ssl_obj, batch_dict)
+            ev = torch.cuda.Event()
+            ev.record(self.stream(lane))
+        for tok in self.pending:
+            tok[1] = ev
+        self.current, self.pending = 0, []
+        return out
+
+    def join(self, *values):
+        """Everything issued on the side lane so far becomes visible to the main lane."""
+        self.main.wait_stream(self.side)
+        for v in values:
+            self.record(v, self.main)
+
+
 class _Arena(object):
     """Re-homes every tensor of a state_dict in two flat buffers (fp32 / int64).  `first_keys`
     (state-dict keys) are laid out first, in that order — the student's trainable parameters in the
@@ -216,7 +309,9 @@ class SSL(nn.Module):
     def _collapse_losses(self, losses):
         for name, value in list(losses.items()):
             if isinstance(value, torch.Tensor):
-                losses[name] = value.mean()
+                # mean() of a 0-d tensor is the identity: skipped so that merging loss dicts never
+                # touches entries another lane (HIP stream) may still be computing
+                losses[name] = value.mean() if value.dim() > 0 else value
             elif isinstance(value, list):
                 losses[name] = sum(_l.mean() for _l in value)
             else:
@@ -228,6 +323,10 @@ class SSL(nn.Module):
         new_losses = self._collapse_losses(new_losses)
         for k in new_losses:
             if k in losses:
+                lanes = getattr(self, '_lanes', None)
+                if lanes is not None:      # rare: the same key from both lanes
+                    torch.cuda.current_stream().wait_stream(lanes.stream(1 - lanes.current))
+                    lanes.record(losses[k], torch.cuda.current_stream())
                 losses[k] = losses[k] + new_losses[k]
             else:
                 losses[k] = new_losses[k]
@@ -282,13 +381,28 @@ class SSL(nn.Module):
             lab_tea.get('gt_bboxes_ignore', None) is None
         lab_dict = dict(stu=lab_stu, tea=lab_tea, sup_losses=dict(), ssl_losses=dict())
         unlab_dict = dict(stu=unlab_stu, tea=unlab_tea, ssl_losses=dict())
+        lanes = None
+        dev = next(self.student.parameters()).device
+        if getattr(self, 'two_lanes', False) and dev.type == 'cuda':
+            # 2D and 3D branches on two HIP streams; data-flow edges become event waits (_LaneDict)
+            lanes = _Lanes(dev)
+            lab_dict = _LaneDict({k: (_LaneDict(v, lanes) if isinstance(v, dict) else v)
+                                  for k, v in lab_dict.items()}, lanes)
+            unlab_dict = _LaneDict({k: (_LaneDict(v, lanes) if isinstance(v, dict) else v)
+                                    for k, v in unlab_dict.items()}, lanes)
+            lanes.side.wait_stream(lanes.main)      # the inputs were produced on the main stream
+        self._lanes = lanes
+        run = (lambda m, d: lanes.run(m, self, d)) if lanes is not None else \
+            (lambda m, d: m.forward(self, d))
         # weight-independent geometry of every pass of the iteration, issued up front
         for chain, d in ((self.lab_ssl_modules, lab_dict), (self.unlab_ssl_modules, unlab_dict)):
             for m in chain:
                 if hasattr(m, 'prefetch'):
                     m.prefetch(self, d)
         for m in self.lab_ssl_modules:
-            lab_dict = m.forward(self, lab_dict)
+            lab_dict = run(m, lab_dict)
+        if lanes is not None:
+            lanes.join(lab_dict['sup_losses'], lab_dict['ssl_losses'])
         if getattr(self, 'early_backward', False) and torch.is_grad_enabled():
             # Scheduling only: d(sum of losses) = sum of d(losses), so the supervised part can be
             # back-propagated now.  Its (GPU-bound) backward then runs underneath the host-bound
@@ -303,7 +417,9 @@ class SSL(nn.Module):
                     hook()
             lab_dict['sup_losses'] = {k: v.detach() for k, v in sup.items()}
         for m in self.unlab_ssl_modules:
-            unlab_dict = m.forward(self, unlab_dict)
+            unlab_dict = run(m, unlab_dict)
+        if lanes is not None:
+            lanes.join(unlab_dict['ssl_losses'], lab_dict['ssl_losses'])
         losses = dict()
         losses.update(add_prefix(lab_dict['sup_losses'], 'sup'))
         ssl_losses = dict()
@@ -329,6 +445,7 @@ class SSL(nn.Module):
         # (ssl.py:348): teacher_t = d teacher_{t-1} + (1-d) student_{t-1, post-step}
         with torch.no_grad():
             self._update_teacher()
+        self._lanes = None
         return losses
 
     @staticmethod

@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+import detmatch_amd  # noqa: E402,F401  (sets the MIOpen environment before the first convolution)
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
