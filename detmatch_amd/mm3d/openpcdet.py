@@ -19,6 +19,23 @@ from .box3d import LiDARInstance3DBoxes, limit_period
 from .registry import DETECTORS
 
 
+def _record_tree(value, stream):
+    """record_stream on every tensor reachable from a prefetched batch dict (incl. the gather
+    tables riding on a rulebook's indice_pairs)."""
+    if isinstance(value, torch.Tensor):
+        if value.is_cuda:
+            value.record_stream(stream)
+        tabs = getattr(value, 'dm_tables', None)
+        if tabs is not None:
+            _record_tree(tabs, stream)
+    elif isinstance(value, dict):
+        for v in value.values():
+            _record_tree(v, stream)
+    elif isinstance(value, (list, tuple)):
+        for v in value:
+            _record_tree(v, stream)
+
+
 def bbox3d2result(bboxes, scores, labels):
     """mmdet3d/core/bbox/transforms.py bbox3d2result: results moved to the CPU."""
     return dict(boxes_3d=bboxes.to('cpu'), scores_3d=scores.cpu(), labels_3d=labels.cpu())
@@ -82,12 +99,17 @@ class OpenPCDetDetector(nn.Module):
         bb = getattr(self.model, 'backbone_3d', None)
         if bb is not None and hasattr(bb, 'build_rulebooks'):
             res['indice_dict_prefetch'] = bb.build_rulebooks(res['voxel_coords'], res['batch_size'])
-        self._geom_cache[id(points)] = (points, self.training, res)
+        stream = torch.cuda.current_stream(points[0].device) if points[0].is_cuda else None
+        self._geom_cache[id(points)] = (points, self.training, res, stream)
 
     def _base_batch(self, points, img_metas):
         hit = self._geom_cache.pop(id(points), None)
         if hit is not None and hit[0] is points and hit[1] == self.training:
             res = hit[2]
+            if hit[3] is not None:
+                cur = torch.cuda.current_stream(points[0].device)
+                if cur != hit[3]:      # consumed on another lane: keep the allocator informed
+                    _record_tree(res, cur)
             if img_metas is not None:
                 res['frame_id'] = np.array([m.get('sample_idx', i) for i, m in enumerate(img_metas)])
             return res

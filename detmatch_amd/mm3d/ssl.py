@@ -66,21 +66,35 @@ class _LaneDict(dict):
 
 
 class _Lanes(object):
-    """Two HIP streams for SSL.forward_train: lane 0 = the caller's stream (3D branch + all light
-    glue modules), lane 1 = a side stream for the modules that run the 2D detector."""
+    """HIP streams for SSL.forward_train.  Lane 0 = the caller's stream: the student's 3D passes
+    (stateful modules, strictly ordered) and the final aggregation; lane 1: the modules that run a 2D
+    detector; lane 2: the teacher's 3D pass and all the light glue modules (filters, transforms,
+    Hungarian matching, consistency) — so the pseudo-label chain, including its host read-backs,
+    never queues behind the student's (early) backward on lane 0."""
+
+    N = 3
+    _side = {}
 
     def __init__(self, device):
         self.main = torch.cuda.current_stream(device)
-        self.side = _Lanes._side.get(device.index)
-        if self.side is None:
-            self.side = _Lanes._side[device.index] = torch.cuda.Stream(device=device)
+        pool = _Lanes._side.get(device.index)
+        if pool is None:
+            pool = _Lanes._side[device.index] = [torch.cuda.Stream(device=device) for _ in range(self.N - 1)]
+        self.streams = [self.main] + pool
         self.current = 0
         self.pending = []
 
-    _side = {}
-
     def stream(self, lane):
-        return self.side if lane else self.main
+        return self.streams[lane]
+
+    @staticmethod
+    def lane_of(module):
+        attr = getattr(module, 'ssl_obj_attr', None)
+        if attr is None:
+            return 2                       # glue
+        if attr.endswith('detector_2d'):
+            return 1
+        return 0 if attr.startswith('student') else 2
 
     @staticmethod
     def record(value, stream):
@@ -96,8 +110,13 @@ class _Lanes(object):
             for v in value.values():
                 _Lanes.record(v, stream)
 
+    def fork(self):
+        """The inputs (and the weights, just updated by optimizer / EMA) live on the main stream."""
+        for s in self.streams[1:]:
+            s.wait_stream(self.main)
+
     def run(self, module, ssl_obj, batch_dict):
-        lane = 1 if getattr(module, 'ssl_obj_attr', '').endswith('detector_2d') else 0
+        lane = self.lane_of(module)
         self.current, self.pending = lane, []
         with torch.cuda.stream(self.stream(lane)):
             out = module.forward(ssl_obj, batch_dict)
@@ -109,8 +128,9 @@ class _Lanes(object):
         return out
 
     def join(self, *values):
-        """Everything issued on the side lane so far becomes visible to the main lane."""
-        self.main.wait_stream(self.side)
+        """Everything issued on the other lanes so far becomes visible to the main lane."""
+        for s in self.streams[1:]:
+            self.main.wait_stream(s)
         for v in values:
             self.record(v, self.main)
 
@@ -324,9 +344,12 @@ class SSL(nn.Module):
         for k in new_losses:
             if k in losses:
                 lanes = getattr(self, '_lanes', None)
-                if lanes is not None:      # rare: the same key from both lanes
-                    torch.cuda.current_stream().wait_stream(lanes.stream(1 - lanes.current))
-                    lanes.record(losses[k], torch.cuda.current_stream())
+                if lanes is not None:      # rare: the same key from two lanes
+                    cur = torch.cuda.current_stream()
+                    for st in lanes.streams:
+                        if st != cur:
+                            cur.wait_stream(st)
+                    lanes.record(losses[k], cur)
                 losses[k] = losses[k] + new_losses[k]
             else:
                 losses[k] = new_losses[k]
@@ -390,7 +413,6 @@ class SSL(nn.Module):
                                   for k, v in lab_dict.items()}, lanes)
             unlab_dict = _LaneDict({k: (_LaneDict(v, lanes) if isinstance(v, dict) else v)
                                     for k, v in unlab_dict.items()}, lanes)
-            lanes.side.wait_stream(lanes.main)      # the inputs were produced on the main stream
         self._lanes = lanes
         run = (lambda m, d: lanes.run(m, self, d)) if lanes is not None else \
             (lambda m, d: m.forward(self, d))
@@ -399,6 +421,8 @@ class SSL(nn.Module):
             for m in chain:
                 if hasattr(m, 'prefetch'):
                     m.prefetch(self, d)
+        if lanes is not None:
+            lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
         for m in self.lab_ssl_modules:
             lab_dict = run(m, lab_dict)
         if lanes is not None:
