@@ -238,7 +238,10 @@ class DetMatchTrainWorkload(object):
         self.ddp = FlatGradDDP(self.model, broadcast=False, mode=os.environ.get('DM_GRAD_MODE', 'collect'))
         self.opt = R.build_optimizer(self.model, sched['optimizer'])
         self.model.early_backward = True
-        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '1') == '1'
+        # multi-stream lanes (2D / 3D / teacher branches concurrently): measured -4.5 % step time, but
+        # overlapped kernels inflate each other's duration, which would blur the per-kernel roofline
+        # bench.py reports — opt-in (DM_TWO_LANES=1)
+        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '0') == '1'
         self.model.after_partial_backward = self.ddp.collect
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
         self.n_fused = self.opt.enable_fused(self.ddp)
