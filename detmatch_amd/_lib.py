@@ -51,6 +51,8 @@ SIGNATURES = {
                                   vp, vp]),
     'dm_roi_align_backward': (ci, [vp, c_i32_p, c_i32_p, c_f32_p, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci,
                                    vp, vp]),
+    'dm_roi_align_forward_nhwc': (ci, [vp, c_i32_p, c_i32_p, c_f32_p, ci, ci, vp, vp, ci, ci, ci, ci, ci,
+                                       vp, vp]),
     'dm_roi_align_backward_nhwc': (ci, [vp, c_i32_p, c_i32_p, c_f32_p, ci, ci, vp, vp, ci, ci, ci, ci, ci,
                                         vp, vp]),
     'dm_ema_update_f32': (ci, [vp, vp, sz, ctypes.c_double, vp]),

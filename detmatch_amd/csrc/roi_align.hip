@@ -191,6 +191,52 @@ __global__ __launch_bounds__(256) void roi_align_kernel(Pyramid pyr, const float
 // 4 * samples atomics per bin with 64 lanes in 64 different rows (~17x slower per byte).
 constexpr int RA_MAX_SPAN = 160;   // patch rows / columns kept in LDS; larger RoIs -> NCHW path
 
+// Tap tables of one RoI (all 256 threads of the workgroup call this; ends with a barrier):
+//   wy[by][yy] / wx[bx][xx]  summed bilinear weights of bin row by / column bx on patch row yy / column xx
+//   rng[0..3][span]          per patch row / column: first and last bin with a non-zero weight
+//   rng[4*span + 0..63]      per bin row / column: first and last patch row / column it touches
+__device__ inline void build_tap_tables(const RoiGeom &g, int H, int W, int y0, int x0, int py, int px,
+                                        int ph, int pw, float *wy, float *wx, short *rng) {
+  for (int i = threadIdx.x; i < (ph + pw) * RA_MAX_SPAN; i += 256) wy[i] = 0.0f;   // wx follows wy
+  __syncthreads();
+  short *pix = rng + 4 * RA_MAX_SPAN;      // [yp_lo 16][yp_hi 16][xp_lo 16][xp_hi 16]
+  if (threadIdx.x < ph + pw) {             // one thread per bin row / column: sequential, no atomics
+    const bool is_y = threadIdx.x < ph;
+    const int b = is_y ? threadIdx.x : threadIdx.x - ph;
+    const int gn = is_y ? g.gh : g.gw, size = is_y ? H : W, base = is_y ? y0 : x0;
+    const float start = is_y ? g.start_h : g.start_w, bin = is_y ? g.bin_h : g.bin_w;
+    float *row = (is_y ? wy : wx) + b * RA_MAX_SPAN;
+    int first = 32767, last = -1;
+    for (int s = 0; s < gn; ++s) {
+      const float p = start + (float)b * bin + ((float)s + 0.5f) * bin / (float)gn;
+      int lo, hi;
+      float wl, wh;
+      if (!tap(p, size, lo, hi, wl, wh)) continue;
+      row[lo - base] += wl;
+      row[hi - base] += wh;
+      first = min(first, lo - base);
+      last = max(last, hi - base);
+    }
+    pix[(is_y ? 0 : 32) + b] = (short)first;
+    pix[(is_y ? 16 : 48) + b] = (short)last;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < py + px; i += 256) {   // per patch row / column: bins that reach it
+    const bool is_y = i < py;
+    const int p = is_y ? i : i - py, nb = is_y ? ph : pw;
+    const float *tab = is_y ? wy : wx;
+    int first = 32767, last = -1;
+    for (int b = 0; b < nb; ++b)
+      if (tab[b * RA_MAX_SPAN + p] != 0.0f) {
+        first = min(first, b);
+        last = b;
+      }
+    rng[(is_y ? 0 : 2 * RA_MAX_SPAN) + p] = (short)first;
+    rng[(is_y ? RA_MAX_SPAN : 3 * RA_MAX_SPAN) + p] = (short)last;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(Pyramid pyr, const float *__restrict__ rois,
                                                           const int *__restrict__ levels, int C,
                                                           int ph, int pw, int sampling_ratio,
@@ -239,25 +285,11 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(Pyramid pyr, const flo
   }
   float *wy = (float *)smem;                 // [ph][RA_MAX_SPAN]
   float *wx = wy + ph * RA_MAX_SPAN;         // [pw][RA_MAX_SPAN]
-  float *gt = wx + pw * RA_MAX_SPAN;         // [ph*pw][C]
-  for (int i = threadIdx.x; i < (ph + pw) * RA_MAX_SPAN; i += 256) wy[i] = 0.0f;
-  __syncthreads();
-  // one thread per bin row / bin column accumulates its samples' taps (sequential -> no atomics)
-  if (threadIdx.x < ph + pw) {
-    const bool is_y = threadIdx.x < ph;
-    const int b = is_y ? threadIdx.x : threadIdx.x - ph;
-    const int gn = is_y ? g.gh : g.gw, size = is_y ? H : W, base = is_y ? y0 : x0;
-    const float start = is_y ? g.start_h : g.start_w, bin = is_y ? g.bin_h : g.bin_w;
-    float *row = (is_y ? wy : wx) + b * RA_MAX_SPAN;
-    for (int s = 0; s < gn; ++s) {
-      const float p = start + (float)b * bin + ((float)s + 0.5f) * bin / (float)gn;
-      int lo, hi;
-      float wl, wh;
-      if (!tap(p, size, lo, hi, wl, wh)) continue;
-      row[lo - base] += wl;
-      row[hi - base] += wh;
-    }
-  }
+  short *rng = (short *)(wx + pw * RA_MAX_SPAN);   // bin / pixel ranges, see build_tap_tables
+  float *gt = (float *)(rng + 4 * RA_MAX_SPAN + 4 * 16);   // [ph*pw][C]
+  build_tap_tables(g, H, W, y0, x0, py, px, ph, pw, wy, wx, rng);
+  const short *yb_lo = rng, *yb_hi = rng + RA_MAX_SPAN, *xb_lo = rng + 2 * RA_MAX_SPAN,
+              *xb_hi = rng + 3 * RA_MAX_SPAN;
   const float *gsrc = gout + (size_t)r * C * bins;
   for (int e = threadIdx.x; e < C * bins; e += 256) {   // coalesced read, transposed LDS write
     const int c = e / bins, b = e - c * bins;
@@ -266,22 +298,115 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(Pyramid pyr, const flo
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     for (int yy = 0; yy < py; ++yy) {
+      const int b0 = yb_lo[yy], b1 = yb_hi[yy];
+      if (b0 > b1) continue;
       for (int xx = 0; xx < px; ++xx) {
+        const int a0 = xb_lo[xx], a1 = xb_hi[xx];
+        if (a0 > a1) continue;
         float acc = 0.0f;
-        bool any = false;
-        for (int by = 0; by < ph; ++by) {
+        for (int by = b0; by <= b1; ++by) {
           const float a = wy[by * RA_MAX_SPAN + yy];
-          if (a == 0.0f) continue;
-          for (int bx = 0; bx < pw; ++bx) {
-            const float w = a * wx[bx * RA_MAX_SPAN + xx];
-            if (w == 0.0f) continue;
-            acc += w * gt[(by * pw + bx) * C + c];
-            any = true;
-          }
+          for (int bx = a0; bx <= a1; ++bx)
+            acc += (a * wx[bx * RA_MAX_SPAN + xx]) * gt[(by * pw + bx) * C + c];
         }
-        if (any) unsafeAtomicAdd(dst + ((size_t)(y0 + yy) * W + (x0 + xx)) * C + c, acc);
+        unsafeAtomicAdd(dst + ((size_t)(y0 + yy) * W + (x0 + xx)) * C + c, acc);
       }
     }
+  }
+}
+
+// ---- forward, separable form, NHWC input ---------------------------------------------------------
+// out[by][bx][c] = (1/count) sum_y sum_x Wy[by][y] Wx[bx][x] F[y][x][c]; thread = channel, so every
+// feature load is a 256-byte-contiguous wave instruction and a bin reads only the pixels its taps
+// touch; the (bins x C) tile is transposed through LDS into the (R, C, ph, pw) output.
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc(Pyramid pyr, const float *__restrict__ rois,
+                                                          const int *__restrict__ levels, int C,
+                                                          int ph, int pw, int sampling_ratio,
+                                                          int aligned, float *__restrict__ out) {
+  extern __shared__ unsigned char smem[];
+  const int r = blockIdx.x;
+  const int level = levels ? levels[r] : 0;
+  const int H = pyr.h[level], W = pyr.w[level];
+  const RoiGeom g = roi_geom(rois + (size_t)r * 5, level, pyr.scale[level], ph, pw, sampling_ratio,
+                             aligned);
+  const float end_h = g.start_h + g.bin_h * (float)ph, end_w = g.start_w + g.bin_w * (float)pw;
+  const int y0 = max(0, min(H - 1, (int)floorf(fminf(g.start_h, end_h)))), y1 = max(0, min(H - 1, (int)floorf(fmaxf(g.start_h, end_h)) + 1));
+  const int x0 = max(0, min(W - 1, (int)floorf(fminf(g.start_w, end_w)))), x1 = max(0, min(W - 1, (int)floorf(fmaxf(g.start_w, end_w)) + 1));
+  const int py = y1 - y0 + 1, px = x1 - x0 + 1;
+  const int bins = ph * pw;
+  float *dst = out + (size_t)r * C * bins;
+  if (g.gh <= 0 || g.gw <= 0) {            // empty RoI: no samples -> zeros
+    for (int e = threadIdx.x; e < C * bins; e += 256) dst[e] = 0.0f;
+    return;
+  }
+  const float inv_count = 1.0f / (float)max(g.gh * g.gw, 1);
+  const float *src = pyr.feat[level] + (size_t)g.batch * H * W * C;
+  float *wy = (float *)smem;
+  float *wx = wy + ph * RA_MAX_SPAN;
+  short *rng = (short *)(wx + pw * RA_MAX_SPAN);
+  float *ot = (float *)(rng + 4 * RA_MAX_SPAN + 4 * 16);   // [ph*pw][C + 1]
+  const bool wide = py > RA_MAX_SPAN || px > RA_MAX_SPAN;
+  if (!wide) build_tap_tables(g, H, W, y0, x0, py, px, ph, pw, wy, wx, rng);
+  const short *yp_lo = rng + 4 * RA_MAX_SPAN, *yp_hi = yp_lo + 16, *xp_lo = yp_lo + 32, *xp_hi = yp_lo + 48;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (!wide && (C & 3) == 0) {
+    // a wave owns every 4th bin, a lane 4 consecutive channels: 16-byte loads, 1 KiB per wave-load
+    for (int b = wave; b < bins; b += 4) {
+      const int by = b / pw, bx = b - by * pw;
+      const int ya = yp_lo[by], yb = yp_hi[by], xa = xp_lo[bx], xb = xp_hi[bx];
+      for (int cg = lane; cg < C / 4; cg += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int yy = ya; yy <= yb; ++yy) {
+          const float a = wy[by * RA_MAX_SPAN + yy];
+          const float4 *row = (const float4 *)(src + ((size_t)(y0 + yy) * W + x0) * C) + cg;
+          for (int xx = xa; xx <= xb; ++xx) {
+            const float w = a * wx[bx * RA_MAX_SPAN + xx];
+            const float4 f = row[(size_t)xx * (C / 4)];
+            acc.x += w * f.x, acc.y += w * f.y, acc.z += w * f.z, acc.w += w * f.w;
+          }
+        }
+        float *o = ot + b * (C + 1) + 4 * cg;
+        o[0] = acc.x * inv_count, o[1] = acc.y * inv_count, o[2] = acc.z * inv_count, o[3] = acc.w * inv_count;
+      }
+    }
+  } else
+  for (int c = threadIdx.x; c < C; c += 256) {
+    for (int b = 0; b < bins; ++b) {
+      const int by = b / pw, bx = b - by * pw;
+      float acc = 0.0f;
+      if (!wide) {
+        for (int yy = yp_lo[by]; yy <= yp_hi[by]; ++yy) {
+          const float a = wy[by * RA_MAX_SPAN + yy];
+          if (a == 0.0f) continue;
+          const float *row = src + ((size_t)(y0 + yy) * W + x0) * C + c;
+          for (int xx = xp_lo[bx]; xx <= xp_hi[bx]; ++xx) {
+            const float w = a * wx[bx * RA_MAX_SPAN + xx];
+            if (w != 0.0f) acc += w * row[(size_t)xx * C];
+          }
+        }
+      } else {                              // RoI wider than the tap tables: taps on the fly
+        for (int sy = 0; sy < g.gh; ++sy) {
+          const float y = g.start_h + (float)by * g.bin_h + ((float)sy + 0.5f) * g.bin_h / (float)g.gh;
+          int yl, yh;
+          float wyl, wyh;
+          if (!tap(y, H, yl, yh, wyl, wyh)) continue;
+          for (int sx = 0; sx < g.gw; ++sx) {
+            const float x = g.start_w + (float)bx * g.bin_w + ((float)sx + 0.5f) * g.bin_w / (float)g.gw;
+            int xl, xh;
+            float wxl, wxh;
+            if (!tap(x, W, xl, xh, wxl, wxh)) continue;
+            acc += (wyl * wxl) * src[((size_t)yl * W + xl) * C + c] + (wyl * wxh) * src[((size_t)yl * W + xh) * C + c] +
+                   (wyh * wxl) * src[((size_t)yh * W + xl) * C + c] + (wyh * wxh) * src[((size_t)yh * W + xh) * C + c];
+          }
+        }
+      }
+      ot[b * (C + 1) + c] = acc * inv_count;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < C * bins; e += 256) {   // (C, bins) order, coalesced
+    const int c = e / bins, b = e - c * bins;
+    dst[e] = ot[b * (C + 1) + c];
   }
 }
 
@@ -331,7 +456,8 @@ extern "C" int dm_roi_align_backward_nhwc(float *const *grads_nhwc_host, const i
     p.grad[l] = grads_nhwc_host[l];
     p.h[l] = heights_host[l], p.w[l] = widths_host[l], p.scale[l] = scales_host[l];
   }
-  const size_t shm = (size_t)(pooled_h + pooled_w) * RA_MAX_SPAN * 4 +
+  if (pooled_h > 16 || pooled_w > 16) return DM_ERR_UNSUPPORTED;
+  const size_t shm = (size_t)(pooled_h + pooled_w) * RA_MAX_SPAN * 4 + (4 * RA_MAX_SPAN + 64) * 2 +
                      (size_t)pooled_h * pooled_w * channels * 4;
   if (shm > 150 * 1024) return DM_ERR_UNSUPPORTED;
   static bool attr = false;
@@ -342,6 +468,38 @@ extern "C" int dm_roi_align_backward_nhwc(float *const *grads_nhwc_host, const i
   }
   hipLaunchKernelGGL(roi_align_bwd_nhwc, dim3(n_rois), dim3(256), shm, st, p, rois, roi_levels,
                      channels, pooled_h, pooled_w, sampling_ratio, aligned, grad_out);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_roi_align_forward_nhwc(const float *const *feats_nhwc_host, const int *heights_host,
+                                         const int *widths_host, const float *scales_host,
+                                         int n_levels, int channels, const float *rois,
+                                         const int *roi_levels, int n_rois, int pooled_h,
+                                         int pooled_w, int sampling_ratio, int aligned, float *out,
+                                         dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_levels < 1 || n_levels > kMaxLevels || n_rois < 0 || channels < 1 || pooled_h < 1 ||
+      pooled_w < 1 || pooled_h > 16 || pooled_w > 16)
+    return DM_ERR_INVALID_ARG;
+  if (n_rois == 0) return DM_OK;
+  Pyramid p;
+  for (int l = 0; l < n_levels; ++l) {
+    p.feat[l] = feats_nhwc_host[l];
+    p.grad[l] = nullptr;
+    p.h[l] = heights_host[l], p.w[l] = widths_host[l], p.scale[l] = scales_host[l];
+  }
+  const size_t shm = (size_t)(pooled_h + pooled_w) * RA_MAX_SPAN * 4 + (4 * RA_MAX_SPAN + 64) * 2 +
+                     (size_t)pooled_h * pooled_w * (channels + 1) * 4;
+  if (shm > 150 * 1024) return DM_ERR_UNSUPPORTED;
+  static bool attr = false;
+  if (!attr) {
+    DM_HIP(hipFuncSetAttribute((const void *)roi_align_fwd_nhwc,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(roi_align_fwd_nhwc, dim3(n_rois), dim3(256), shm, st, p, rois, roi_levels,
+                     channels, pooled_h, pooled_w, sampling_ratio, aligned, out);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -31,14 +31,16 @@ class _RoIAlignFPN(Function):
         levels = levels.contiguous().int() if levels is not None else None
         r, c = rois.shape[0], feats[0].shape[1]
         out = feats[0].new_empty((r, c, out_size, out_size))
-        ptrs, hs, ws = _pyramid_args(feats)
+        # channel-last copies of the maps: every tap then reads 256 contiguous bytes per wave
+        nhwc = [f.permute(0, 2, 3, 1).contiguous() for f in feats]
+        ptrs = (ctypes.c_void_p * len(nhwc))(*[t.data_ptr() for t in nhwc])
+        hs = (ctypes.c_int32 * len(feats))(*[int(f.shape[2]) for f in feats])
+        ws = (ctypes.c_int32 * len(feats))(*[int(f.shape[3]) for f in feats])
         sc = (ctypes.c_float * len(feats))(*[float(s) for s in scales])
-        # LDS sizing hint: a RoI routed to level l by map_roi_levels is < 2*56*2^l px, i.e.
-        # <= 28 feature px at its own level -> ceil(28 / 7) = 4; 8 leaves room for the top level
-        _lib.check(_lib.lib().dm_roi_align_forward(
+        _lib.check(_lib.lib().dm_roi_align_forward_nhwc(
             ptrs, hs, ws, sc, len(feats), c, _lib.ptr(rois), _lib.ptr(levels) if levels is not None else None,
-            r, out_size, out_size, sampling_ratio, int(aligned), 8, _lib.ptr(out), _lib.stream()),
-            'dm_roi_align_forward')
+            r, out_size, out_size, sampling_ratio, int(aligned), _lib.ptr(out), _lib.stream()),
+            'dm_roi_align_forward_nhwc')
         ctx.save_for_backward(rois, levels)
         ctx.meta = (scales, out_size, sampling_ratio, aligned, [tuple(f.shape) for f in feats])
         return out

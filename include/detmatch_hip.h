@@ -242,6 +242,14 @@ int dm_roi_align_backward(float *const *grads_host, const int *heights_host,
                           int pooled_h, int pooled_w, int sampling_ratio, int aligned, int max_grid,
                           const float *grad_out, dm_stream_t stream);
 
+/* Forward on NHWC maps (feats_nhwc_host[l]: (N, H_l, W_l, C) device pointers): separable taps,
+ * thread = channel, every feature load a 256-byte-contiguous wave instruction.  Same results as
+ * dm_roi_align_forward up to fp32 summation order.  pooled_h, pooled_w <= 16. */
+int dm_roi_align_forward_nhwc(const float *const *feats_nhwc_host, const int *heights_host,
+                              const int *widths_host, const float *scales_host, int n_levels,
+                              int channels, const float *rois, const int *roi_levels, int n_rois,
+                              int pooled_h, int pooled_w, int sampling_ratio, int aligned, float *out,
+                              dm_stream_t stream);
 /* Same gradient, separable form: grads_nhwc_host[l] are (N, H_l, W_l, C) buffers (caller-zeroed,
  * accumulated into with one 256-byte-contiguous float atomic per pixel and 64 channels; RoIs whose
  * pixel span exceeds the kernel's LDS tables fall back to per-sample atomics in place). */

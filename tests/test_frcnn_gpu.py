@@ -85,6 +85,12 @@ def test_roi_align_backward_wide_roi_and_nchw_entry(dev, orc):
     _lib.check(_lib.lib().dm_roi_align_backward(ptrs, hs, ws, sc, 1, 8, _lib.ptr(tr), None, 3, 7, 7, 0, 1,
                                                 8, _lib.ptr(tg), _lib.stream()), 'dm_roi_align_backward')
     np.testing.assert_allclose(gn.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    on = torch.empty((3, 8, 7, 7), device=dev)
+    fp = (ctypes.c_void_p * 1)(f.data_ptr())
+    _lib.check(_lib.lib().dm_roi_align_forward(fp, hs, ws, sc, 1, 8, _lib.ptr(tr), None, 3, 7, 7, 0, 1, 8,
+                                               _lib.ptr(on), _lib.stream()), 'dm_roi_align_forward')
+    np.testing.assert_allclose(on.cpu().numpy(), orc.roi_align(feat, rois, 1.0, 7, 0, True),
+                               rtol=1e-5, atol=1e-5)
 
 
 def test_nms_2d_matches_numpy(dev):
