@@ -440,18 +440,32 @@ __global__ __launch_bounds__(256) void group_rows_grad_combine(
     slot_of[rl] = (short)slot;
   }
   __syncthreads();
-  // 2. one wave per reference row: contiguous read, conflict-free LDS adds
-  for (int rl = wave; rl < nq * nsample; rl += 4) {
-    const int slot = slot_of[rl];
-    if (slot == -2) continue;
-    const long long r = (long long)q0 * nsample + rl;
-    const float *g = gout + r * width + col_off;
-    if (slot >= 0) {
-      for (int e = lane; e < c; e += 64) unsafeAtomicAdd(&acc[slot * c + e], g[e]);
-    } else {
-      const int q = q0 + rl / nsample;
-      float *dst = gfeats + (size_t)(sample_start(q, batch, q_cnt, src_cnt) + idx[r]) * c;
-      for (int e = lane; e < c; e += 64) unsafeAtomicAdd(dst + e, g[e]);
+  // 2. one wave per reference row, four rows in flight per wave (the loop is latency bound: one
+  //    workgroup per CU because of the 120 KiB table): contiguous reads, conflict-free LDS adds
+  const int n_refs = nq * nsample;
+  for (int base = wave * 4; base < n_refs; base += 16) {
+    int slot[4];
+    const float *g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rl = base + u;
+      slot[u] = rl < n_refs ? (int)slot_of[rl] : -2;
+      g[u] = gout + ((long long)q0 * nsample + (rl < n_refs ? rl : 0)) * width + col_off;
+    }
+    for (int e = lane; e < c; e += 64) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = slot[u] != -2 ? g[u][e] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (slot[u] >= 0) {
+          unsafeAtomicAdd(&acc[slot[u] * c + e], v[u]);
+        } else if (slot[u] == -1) {
+          const int rl = base + u, q = q0 + rl / nsample;
+          const long long r = (long long)q0 * nsample + rl;
+          unsafeAtomicAdd(gfeats + (size_t)(sample_start(q, batch, q_cnt, src_cnt) + idx[r]) * c + e, v[u]);
+        }
+      }
     }
   }
   __syncthreads();
