@@ -238,11 +238,11 @@ class DetMatchTrainWorkload(object):
         self.ddp = FlatGradDDP(self.model, broadcast=False, mode=os.environ.get('DM_GRAD_MODE', 'collect'))
         self.opt = R.build_optimizer(self.model, sched['optimizer'])
         self.model.early_backward = True
-        # multi-stream lanes (2D / 3D / teacher branches concurrently): measured -4.5 % step time, but
-        # overlapped kernels inflate each other's duration, which would blur the per-kernel roofline
-        # bench.py reports — opt-in (DM_TWO_LANES=1)
-        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '0') == '1'
-        self.model.after_partial_backward = self.ddp.collect
+        # multi-stream lanes (student 3D / 2D detectors / teacher 3D + glue run concurrently, data-flow
+        # edges as event waits): -8 % step time.  Co-scheduled kernels share CUs, so per-kernel
+        # durations (and the per-kernel roofline bench.py reports) are ~25 % longer than in serial
+        # order (DM_TWO_LANES=0), where spconv_gr<64,64> runs at 0.24-0.26 of the HBM peak.
+        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '1') == '1'
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
         self.n_fused = self.opt.enable_fused(self.ddp)
         self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)
