@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdetmatch_hip.so')
+LIB_PATH = os.environ.get('DM_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libdetmatch_hip.so')  # env: A/B builds
 _lib = None
 
 cd = ctypes.c_double

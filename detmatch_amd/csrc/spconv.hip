@@ -19,6 +19,13 @@
 // Algorithmic bytes per pair: (cin + cout)*4 + 8.
 #include "dm_common.h"
 
+// Input channels per pipeline step of spconv_gr = 16 * DM_GR_CTS.  2 (32 channels, 8 KiB of weights
+// per step) keeps the kernel at 106 VGPRs = 4 waves/SIMD; 4 needs 166 (3 waves/SIMD) and measures
+// 8 % slower on the 64->64 layers (tools/bench_spconv_layers.py).
+#ifndef DM_GR_CTS
+#define DM_GR_CTS 2
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,10 +43,7 @@ __device__ __forceinline__ float mask_bits(float a, unsigned int m) {
 // B_k = W[k] (forward) or W[kk]^T with kk = flip ? kvol-1-k : k (input grad).
 // For cin_eff == 4 (first layer) the layout degenerates to t = 0, kq = row.
 __global__ __launch_bounds__(256) void pack_weights(const float *w, float *wp, int kvol, int ci,
-                                                    int co, int transpose_w, int flip_k,
-                                                    int *tile_counters) {
-  // the persistent main kernel pulls tiles from these counters; resetting them here costs nothing
-  if (blockIdx.x == 0 && threadIdx.x < 8) tile_counters[threadIdx.x] = 0;
+                                                    int co, int transpose_w, int flip_k) {
   // B_k is (ci x co).  forward: W is (kvol, ci, co); transposed: W is (kvol, co, ci).
   int per_k = ci * co;
   int e = blockIdx.x * 256 + threadIdx.x;
@@ -279,9 +283,6 @@ __global__ __launch_bounds__(256) void spconv_gg(const float *__restrict__ feat,
 
 unsigned long long *g_debug_stamps = nullptr;
 int g_gg_variant = -1;  // -1 auto, 0 LDS-staged weights (spconv_gg), 1 register weights (spconv_gr)
-int g_gr_tiles = 1;    // MFMA row tiles per wave in spconv_gr (dm_spconv_set_variant(10 + n))
-int g_gr_persistent = 0;   // 1: persistent workgroups pulling tiles from a counter (measured: no gain, 2x slower on the
-                           // small layers) — kept as a tuning switch: dm_spconv_set_variant(10 + tiles) / (20 + tiles)
 
 // ---- main kernel, register-resident weights ----------------------------------
 // Workgroup = 4 waves = ONE tile of 16 output rows; the tile's active kernel
@@ -292,34 +293,26 @@ int g_gr_persistent = 0;   // 1: persistent workgroups pulling tiles from a coun
 // meet once, in LDS, are summed in a fixed order (bitwise reproducible) and leave
 // as whole 16-byte-per-lane row segments.  Work units are a quarter of a tile's
 // offsets, which is what lets ~1-2 k tiles balance over 1024 SIMDs.
-template <int CIN, int COUT, int NT>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
                                                  const float *__restrict__ wpack,
                                                  const int32_t *__restrict__ nbr,
                                                  const int32_t *__restrict__ perm, int n_out,
                                                  int kvol, int cout_full,
                                                  float *__restrict__ out,
-                                                 unsigned long long *__restrict__ stamps,
-                                                 int *__restrict__ tile_counter) {
+                                                 unsigned long long *__restrict__ stamps) {
   constexpr int NB = COUT / 16;
   constexpr int CT = CIN / 16;
-  constexpr int CTS = CT < 4 ? CT : 4;     // k-chunks of <= 64 input channels per step
+  constexpr int CTS = CT < DM_GR_CTS ? CT : DM_GR_CTS;   // k-chunks of <= 16*DM_GR_CTS input channels per step
   constexpr int S = CT / CTS;              // steps per kernel offset
   constexpr int LDP = COUT + 4;            // padded row stride of the partial tiles
-  constexpr int ROWS = 16 * NT;            // output rows of the workgroup (NT MFMA row tiles)
-  __shared__ int32_t tbl[4][32][ROWS];
-  __shared__ __attribute__((aligned(16))) float part[4][ROWS][LDP];
+  __shared__ int32_t tbl[4][32][16];
+  __shared__ __attribute__((aligned(16))) float part[4][16][LDP];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
-  // persistent workgroups: tiles are pulled from a global counter (tile cost varies with the
-  // number of active offsets; static assignment leaves a ~40 % tail)
-  __shared__ int next_tile;
-  const int n_tiles = (n_out + ROWS - 1) / ROWS;
-  int tile = blockIdx.x;
-  while (tile < n_tiles) {
-  const int row0 = tile * ROWS;
+  const int row0 = blockIdx.x * 16;
   const int nb_full = cout_full / 16;
   const int nb0 = blockIdx.y * NB;
   unsigned long long st0 = 0, rt0 = 0, st1 = 0;
@@ -330,19 +323,18 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
 
   // this wave's private copy of the tile's gather table + the active-offset mask
   unsigned int active = 0u;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
+  {
     int v[8];
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {  // all eight loads in flight before the first use
       int k = 4 * k4 + kq;
-      bool in = (k < kvol) && (row0 + 16 * nt + r < n_out);
-      v[k4] = nbr[in ? (size_t)k * n_out + row0 + 16 * nt + r : 0];
+      bool in = (k < kvol) && (row0 + r < n_out);
+      v[k4] = nbr[in ? (size_t)k * n_out + row0 + r : 0];
       if (!in) v[k4] = -1;
     }
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
-      tbl[wave][4 * k4 + kq][16 * nt + r] = v[k4];
+      tbl[wave][4 * k4 + kq][r] = v[k4];
       unsigned long long m = __ballot(v[k4] >= 0);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -360,21 +352,16 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
       ++rank;
     }
   }
-  f32x4 acc[NT][NB];
+  f32x4 acc[NB];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int i = 0; i < NB; ++i) acc[nt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto load_step = [&](int k, int s, f32x4 *w, f32x4 *a, unsigned int *ok) {
+    int idx = tbl[wave][k][r];
+    *ok = idx >= 0 ? 0xFFFFFFFFu : 0u;
+    const float *src = feat + (size_t)(idx >= 0 ? idx : 0) * CIN + 16 * (s * CTS) + 4 * kq;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      int idx = tbl[wave][k][16 * nt + r];
-      ok[nt] = idx >= 0 ? 0xFFFFFFFFu : 0u;
-      const float *src = feat + (size_t)(idx >= 0 ? idx : 0) * CIN + 16 * (s * CTS) + 4 * kq;
-#pragma unroll
-      for (int t = 0; t < CTS; ++t) a[nt * CTS + t] = *(const f32x4 *)(src + 16 * t);
-    }
+    for (int t = 0; t < CTS; ++t) a[t] = *(const f32x4 *)(src + 16 * t);
     const f32x4 *wk = (const f32x4 *)wpack + (size_t)k * (CIN * (size_t)cout_full / 4);
 #pragma unroll
     for (int t = 0; t < CTS; ++t)
@@ -382,22 +369,17 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
       for (int nb = 0; nb < NB; ++nb)
         w[t * NB + nb] = wk[((s * CTS + t) * nb_full + nb0 + nb) * 64 + lane];
   };
-  auto compute = [&](const f32x4 *w, const f32x4 *a, const unsigned int *ok) {
+  auto compute = [&](const f32x4 *w, const f32x4 *a, unsigned int ok) {
 #pragma unroll
     for (int t = 0; t < CTS; ++t) {
-      float av[NT][4];
+      float av[4];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) av[nt][j] = mask_bits(a[nt * CTS + t][j], ok[nt]);
+      for (int j = 0; j < 4; ++j) av[j] = mask_bits(a[t][j], ok);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[nt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt][j], w[t * NB + nb][j],
-                                                               acc[nt][nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[t * NB + nb][j], acc[nb], 0, 0, 0);
     }
   };
 
@@ -415,29 +397,26 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
         s = 0;
       }
     };
-    f32x4 w0[CTS * NB], w1[CTS * NB], a0[NT * CTS], a1[NT * CTS];
-    unsigned int ok0[NT], ok1[NT];
-    load_step(k, s, w0, a0, ok0);
+    f32x4 w0[CTS * NB], w1[CTS * NB], a0[CTS], a1[CTS];
+    unsigned int ok0, ok1;
+    load_step(k, s, w0, a0, &ok0);
     int i = 0;
     while (true) {
       advance();
-      load_step(k, s, w1, a1, ok1);
+      load_step(k, s, w1, a1, &ok1);
       compute(w0, a0, ok0);
       if (++i >= n_steps) break;
       advance();
-      load_step(k, s, w0, a0, ok0);
+      load_step(k, s, w0, a0, &ok0);
       compute(w1, a1, ok1);
       if (++i >= n_steps) break;
     }
   }
   // meet in LDS: D layout col = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-        part[wave][16 * nt + 4 * kq + reg][16 * nb + r] = acc[nt][nb][reg];
+    for (int nb = 0; nb < NB; ++nb) part[wave][4 * kq + reg][16 * nb + r] = acc[nb][reg];
   __syncthreads();
   if (stamps && tid == 0) {
     unsigned long long *o = stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
@@ -445,8 +424,8 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
     o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = __popc(active);
   }
   constexpr int F4_PER_ROW = COUT / 4;
-  for (int e = tid; e < ROWS * F4_PER_ROW; e += 256) {
-    int rr = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
+  if (tid < 16 * F4_PER_ROW) {
+    int rr = tid / F4_PER_ROW, c4 = tid % F4_PER_ROW;
     int prow = row0 + rr;
     if (prow < n_out) {
       f32x4 v0 = *(const f32x4 *)&part[0][rr][4 * c4];
@@ -458,44 +437,16 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
       *(f32x4 *)(out + (size_t)row * cout_full + blockIdx.y * COUT + 4 * c4) = sum;
     }
   }
-  if (tile_counter == nullptr) break;
-  __syncthreads();                       // part[] / tbl[] are reused by the next tile
-  if (tid == 0) next_tile = gridDim.x + atomicAdd(tile_counter + blockIdx.y, 1);
-  __syncthreads();
-  tile = next_tile;
-  }
-}
-
-template <typename K>
-static int resident_blocks(K kernel) {   // workgroups the chip holds at once (256 CUs on MI355X)
-  int per_cu = 0, dev = 0, cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1)
-    per_cu = 2;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    cus = prop.multiProcessorCount;
-  return per_cu * cus;
 }
 
 template <int CIN, int COUT_FULL>
 int launch_gr(const float *feat, const float *wpack, const int32_t *nbr, const int32_t *perm,
-              int n_out, int kvol, float *out, int *counters, hipStream_t st) {
+              int n_out, int kvol, float *out, hipStream_t st) {
   constexpr int COUT = COUT_FULL > 64 ? 64 : COUT_FULL;  // columns per workgroup
+  dim3 grid(dm_ceil_div(n_out, 16), COUT_FULL / COUT);
   int pi = dm_prof_begin(st, DM_PROF_SPCONV_GG, CIN, COUT_FULL, 0, n_out, kvol, nbr);
-  int *ctr = g_gr_persistent ? counters : nullptr;
-  if (g_gr_tiles == 2) {
-    static const int resident = resident_blocks(spconv_gr<CIN, COUT, 2>);
-    int tiles = dm_ceil_div(n_out, 32), splits = COUT_FULL / COUT;
-    dim3 grid(ctr ? (tiles < resident / splits ? tiles : resident / splits) : tiles, splits);
-    spconv_gr<CIN, COUT, 2><<<grid, 256, 0, st>>>(feat, wpack, nbr, perm, n_out, kvol, COUT_FULL,
-                                                  out, g_debug_stamps, ctr);
-  } else {
-    static const int resident = resident_blocks(spconv_gr<CIN, COUT, 1>);
-    int tiles = dm_ceil_div(n_out, 16), splits = COUT_FULL / COUT;
-    dim3 grid(ctr ? (tiles < resident / splits ? tiles : resident / splits) : tiles, splits);
-    spconv_gr<CIN, COUT, 1><<<grid, 256, 0, st>>>(feat, wpack, nbr, perm, n_out, kvol, COUT_FULL,
-                                                  out, g_debug_stamps, ctr);
-  }
+  spconv_gr<CIN, COUT><<<grid, 256, 0, st>>>(feat, wpack, nbr, perm, n_out, kvol, COUT_FULL, out,
+                                             g_debug_stamps);
   dm_prof_end(pi, st);
   DM_CHECK_LAUNCH();
   return DM_OK;
@@ -615,30 +566,20 @@ extern "C" int dm_spconv_debug_stamps(void *buf) {
 
 // tuning aid: -1 auto, 0 force the LDS-staged kernel, 1 force the register-weights kernel
 extern "C" int dm_spconv_set_variant(int v) {
-  if (v >= 20) {        // 21 / 22: static grid (one workgroup per tile), 1 / 2 row tiles per wave
-    g_gr_tiles = v - 20;
-    g_gr_persistent = 0;
-    g_gg_variant = 1;
-  } else if (v >= 10) { // 11 / 12: persistent workgroups, 1 / 2 row tiles per wave
-    g_gr_tiles = v - 10;
-    g_gr_persistent = 1;
-    g_gg_variant = 1;
-  } else {
-    g_gg_variant = v;
-  }
+  g_gg_variant = v;
   return DM_OK;
 }
 
 extern "C" size_t dm_spconv_workspace_bytes(int kvol, int cin, int cout) {
   if (kvol <= 0 || cin <= 0 || cout <= 0) return 0;
-  return dm_align((size_t)kvol * cin * cout * sizeof(float)) + 256;   // + tile counters
+  return dm_align((size_t)kvol * cin * cout * sizeof(float));
 }
 
 #define DM_GG_CASE(CI, CO)                                                              \
   if (ci == CI && co == CO) {                                                           \
     bool use_gr = g_gg_variant < 0 ? (CI >= 32) : (g_gg_variant == 1);                  \
     if constexpr (CI >= 16) {                                                           \
-      if (use_gr) return launch_gr<CI, CO>(feat, wp, nbr, nullptr, n_rows_out, kvol, out, counters, st); \
+      if (use_gr) return launch_gr<CI, CO>(feat, wp, nbr, nullptr, n_rows_out, kvol, out, st); \
     }                                                                                   \
     return launch_gg<CI, CO>(feat, wp, nbr, nullptr, n_rows_out, kvol, out, st);         \
   }
@@ -662,9 +603,8 @@ extern "C" int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const flo
   int total = kvol * ci * co;
   // pack_weights indexes W as (kvol, ci, co) when !transpose_w and as
   // (kvol, co_w = co.., ) transposed otherwise: W is (kvol, cin, cout) = (kvol, co, ci)
-  int *counters = (int *)((char *)workspace + dm_align((size_t)total * sizeof(float)));
   pack_weights<<<dm_ceil_div(total, 256), 256, 0, st>>>(filters, wp, kvol, ci, co, transpose_w,
-                                                        flip_k, counters);
+                                                        flip_k);
   DM_CHECK_LAUNCH();
   DM_GG_CASE(4, 16)
   DM_GG_CASE(16, 16)

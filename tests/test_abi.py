@@ -32,7 +32,7 @@ def test_python_binding_covers_header():
     # host-only size queries are safe without a GPU
     assert L.dm_rulebook_workspace_bytes(1000, 27) > 0
     assert L.dm_hard_voxelize_workspace_bytes(1000, 2) > 0
-    assert L.dm_spconv_workspace_bytes(27, 64, 64) == 27 * 64 * 64 * 4 + 256   # packed weights + tile counters
+    assert L.dm_spconv_workspace_bytes(27, 64, 64) == 27 * 64 * 64 * 4
 
 
 def test_ops_refuse_cpu_tensors():
