@@ -136,10 +136,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
+    # test hooks: several ranks on ONE GPU over gloo (validates the N>1 control flow on a 1-GPU box)
+    if os.environ.get('DM_FORCE_DEVICE') is not None:
+        local_rank = int(os.environ['DM_FORCE_DEVICE'])
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('DM_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if os.environ.get('DM_CUDNN_BENCHMARK'):     # tools/miopen_tune.sh: exhaustive MIOpen find
         torch.backends.cudnn.benchmark = True
     from detmatch_amd import _lib
@@ -200,11 +207,14 @@ def main():
                         bytes_per_launch=int(g['bytes'] / g['launches']),
                         all_spconv_gg=dict(achieved=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
                                            us_per_step=round(tot_ms / args.steps * 1e3, 1)))
-        out = dict(metric='train iters/sec', value=round(args.steps * 1.0 / dt, 3), unit='iters/sec',
+        # weak scaling: every rank steps through its own (2 labeled + 2 unlabeled) batch, so the
+        # whole-job rate is world x steps / time (per-GPU-batch iterations per second, all ranks)
+        out = dict(metric='train iters/sec', value=round(world * args.steps * 1.0 / dt, 3), unit='iters/sec',
                    n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=wl.describe(), batch_per_gpu=BATCH_PER_GPU,
+                               value_is='iterations of one per-GPU batch, summed over ranks',
                                global_batch=BATCH_PER_GPU * world,
                                parallelism='dp%d' % world),
                    roofline=roof)
