@@ -27,15 +27,35 @@ class FrozenBN(nn.Module):
         self.register_buffer('running_var', torch.ones(c))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
+    # bumped by whoever rewrites these tensors behind autograd's back (raw-pointer kernels such as the
+    # fused EMA); ordinary in-place updates (load_state_dict, copy_) are caught by Tensor._version
+    GENERATION = 0
+
     def scale_shift(self):
-        s = self.weight * torch.rsqrt(self.running_var + self.eps)
-        return s, self.bias - self.running_mean * s
+        """The constant affine map of the frozen layer: (gamma / sqrt(var + eps), beta - mean * scale),
+        cached until one of the four tensors changes."""
+        key = (FrozenBN.GENERATION, self.weight._version, self.bias._version,
+               self.running_mean._version, self.running_var._version, self.weight.device)
+        cached = getattr(self, '_affine', None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                s = self.weight * torch.rsqrt(self.running_var + self.eps)
+                b = self.bias - self.running_mean * s
+            cached = self._affine = (key, s, b)
+        return cached[1], cached[2]
 
 
 def conv_frozen_bn(x, conv, bn, relu):
     s, b = bn.scale_shift()
-    w = conv.weight * s.view(-1, 1, 1, 1) if conv.weight.requires_grad else \
-        (conv.weight * s.view(-1, 1, 1, 1)).detach()
+    if conv.weight.requires_grad:
+        w = conv.weight * s.view(-1, 1, 1, 1)
+    else:   # frozen stage: the folded weight is a constant too
+        key = (FrozenBN.GENERATION, conv.weight._version, id(s))
+        cached = getattr(conv, '_folded', None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = conv._folded = (key, conv.weight * s.view(-1, 1, 1, 1))
+        w = cached[1]
     y = F.conv2d(x, w, b, conv.stride, conv.padding)
     return F.relu_(y) if relu else y
 

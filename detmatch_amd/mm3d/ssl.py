@@ -281,6 +281,7 @@ class SSL(nn.Module):
         """Call once the model sits on its device (and after any checkpoint load).  With a
         FlatGradDDP the student's trainable parameters come first, in gradient-arena order, and
         `ddp.flat_params` becomes that prefix of the student arena."""
+        self._frozen_bn_differs = None
         first = None
         if ddp is not None:
             name_of = {id(p): n for n, p in self.student.named_parameters()}
@@ -308,11 +309,30 @@ class SSL(nn.Module):
                                            d, _lib.stream()), 'dm_ema_update_i64')
         else:
             raise _lib.DetMatchHipError('EMA runs on the MI355X only')
+        self._bump_frozen_bn()
         if self.use_student_bn_stats_for_teacher:
             tsd, ssd = self.teacher.state_dict(), self.student.state_dict()
             for k in tsd:
                 if 'running' in k:
                     tsd[k].copy_(ssd[k])
+
+    def _bump_frozen_bn(self):
+        """The EMA kernel rewrites the teacher's tensors through raw pointers.  Frozen-BatchNorm
+        layers cache their affine map; it only needs refreshing if teacher and student constants
+        differ (then the EMA really moves them) — checked once."""
+        differs = getattr(self, '_frozen_bn_differs', None)
+        if differs is None:
+            from ..mm2d.backbone import FrozenBN
+            differs = False
+            for mt, ms in zip(self.teacher.modules(), self.student.modules()):
+                if isinstance(mt, FrozenBN):
+                    for a, b in ((mt.weight, ms.weight), (mt.bias, ms.bias),
+                                 (mt.running_mean, ms.running_mean), (mt.running_var, ms.running_var)):
+                        differs = differs or not torch.equal(a, b)
+            self._frozen_bn_differs = differs
+        if differs:
+            from ..mm2d.backbone import FrozenBN
+            FrozenBN.GENERATION += 1
 
     # ---- loss bookkeeping -------------------------------------------------------------
     def _get_curr_ssl_weight(self):
