@@ -47,6 +47,9 @@ SIGNATURES = {
     'dm_nms': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
     'dm_nms_normal': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
     'dm_nms_2d': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
+    'dm_bn_rows_workspace_bytes': (sz, [ctypes.c_longlong, ci]),
+    'dm_bn_rows_forward': (ci, [vp, ctypes.c_longlong, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
+    'dm_bn_rows_backward': (ci, [vp, vp, ctypes.c_longlong, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
     'dm_roi_align_forward': (ci, [vp, c_i32_p, c_i32_p, c_f32_p, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci,
                                   vp, vp]),
     'dm_roi_align_backward': (ci, [vp, c_i32_p, c_i32_p, c_f32_p, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci,

@@ -1,0 +1,70 @@
+"""Fused training-mode BatchNorm (+ReLU) over (N, C) row-major activations — host side of
+csrc/bn_relu.hip.  `bn_relu_rows(x, bn, relu)` computes exactly what `relu(bn(x))` does for an
+nn.BatchNorm1d / nn.BatchNorm2d module `bn` whose channels are the last dim of `x`, including the
+running-statistics and num_batches_tracked updates; evaluation mode and shapes the kernel does not
+take fall through to torch.nn.functional.batch_norm."""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+
+
+class _BNReLURows(Function):
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = x.contiguous()
+        n, c = x.shape
+        L = _lib.lib()
+        y = torch.empty_like(x)
+        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
+        _lib.check(L.dm_bn_rows_forward(
+            _lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
+            _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(y), _lib.ptr(mean),
+            _lib.ptr(invstd), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_bn_rows_forward')
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        n, c = x.shape
+        L = _lib.lib()
+        gx = torch.empty_like(x)
+        ggamma = torch.empty((c,), dtype=torch.float32, device=x.device)
+        gbeta = torch.empty_like(ggamma)
+        ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
+        _lib.check(L.dm_bn_rows_backward(
+            _lib.ptr(gy), _lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean),
+            _lib.ptr(invstd), int(ctx.relu), _lib.ptr(gx), _lib.ptr(ggamma), _lib.ptr(gbeta), _lib.ptr(ws),
+            ws.numel(), _lib.stream()), 'dm_bn_rows_backward')
+        return (gx, ggamma if gamma is not None else None, gbeta if beta is not None else None,
+                None, None, None, None, None)
+
+
+def _kernel_takes(x, c):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 1 and c % 4 == 0
+            and 4 <= c <= 1024 and 256 % (c // 4) == 0)
+
+
+def bn_relu_rows(x, bn, relu=True):
+    """relu(bn(x)) for x (N, C), bn an nn.BatchNorm{1,2}d over C."""
+    c = x.shape[-1]
+    training = bn.training or not bn.track_running_stats
+    if training and bn.momentum is not None and _kernel_takes(x, c) and \
+            (bn.weight is None) == (bn.bias is None):
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        rm = bn.running_mean if bn.track_running_stats else None
+        rv = bn.running_var if bn.track_running_stats else None
+        return _BNReLURows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, relu)
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
+                     bn.momentum if bn.momentum is not None else 0.0, bn.eps)
+    return F.relu(y, inplace=True) if relu else y

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib
+from .bn_relu import bn_relu_rows
 
 
 def _i32(t):
@@ -298,11 +299,7 @@ class StackSAModuleMSG(nn.Module):
                     x = TallSkinnyLinear.apply(x, conv.weight.view(conv.out_channels, conv.in_channels))
                     if conv.bias is not None:
                         x = x + conv.bias
-                    if bn.training and bn.track_running_stats:
-                        bn.num_batches_tracked.add_(1)
-                    x = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                                     bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
-                    x = F.relu(x, inplace=True)
+                    x = bn_relu_rows(x, bn, relu=True)      # fused BatchNorm + ReLU over rows
                 new_features_list.append(x.view(m, ns, -1).max(dim=1)[0])      # (M, C)
             return new_xyz, torch.cat(new_features_list, dim=1)
         for k in range(len(self.groupers)):

@@ -54,7 +54,22 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        mods = list(self._modules.items())
+        skip = False
+        for i, (k, module) in enumerate(mods):
+            if skip:            # the ReLU fused into the preceding BatchNorm
+                skip = False
+                continue
+            if isinstance(module, nn.BatchNorm1d) and isinstance(input, SparseConvTensor) and \
+                    input.features.is_cuda and input.indices.shape[0] != 0:
+                # BatchNorm1d (+ ReLU) over the (N, C) feature rows: one fused pass
+                # (modules.py:125-137 runs them as two dense modules on input.features)
+                from ..bn_relu import bn_relu_rows
+                nxt = mods[i + 1][1] if i + 1 < len(mods) else None
+                fuse = isinstance(nxt, nn.ReLU)
+                input.features = bn_relu_rows(input.features, module, relu=fuse)
+                skip = fuse
+                continue
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity

@@ -218,6 +218,27 @@ int dm_nms_2d(const float *boxes_xyxy, int n, float thresh, int max_keep, long l
               int *num_keep, void *workspace, size_t workspace_bytes, dm_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
+/* B/D. Fused training-mode BatchNorm (+ReLU) over row-major (N, C) activations */
+/* ------------------------------------------------------------------------ */
+/* Replaces the BatchNorm1d + ReLU of every sparse-conv block
+ * (pcdet/models/backbones_3d/spconv_backbone.py:9-28, spconv/modules.py:125-137) and the
+ * BatchNorm2d + ReLU of the shared set-abstraction MLPs
+ * (pcdet/ops/pointnet2/pointnet2_stack/pointnet2_modules.py:31-40) — torch.nn.functional.batch_norm
+ * semantics (biased variance for normalisation, unbiased for running_var, momentum update;
+ * running_* may be NULL).  C % 4 == 0, C/4 divides 256.  save_mean / save_invstd (C) feed the
+ * backward.  gamma / beta may be NULL (1 / 0). */
+size_t dm_bn_rows_workspace_bytes(long long n, int c);
+int dm_bn_rows_forward(const float *x, long long n, int c, const float *gamma, const float *beta,
+                       float eps, float momentum, float *running_mean, float *running_var, int relu,
+                       float *y, float *save_mean, float *save_invstd, void *workspace,
+                       size_t workspace_bytes, dm_stream_t stream);
+/* grad_x (N,C), grad_gamma (C), grad_beta (C); the ReLU mask is recomputed from x. */
+int dm_bn_rows_backward(const float *grad_out, const float *x, long long n, int c, const float *gamma,
+                        const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                        float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
+                        size_t workspace_bytes, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* G. 2D branch: RoIAlign over an FPN pyramid                                 */
 /* ------------------------------------------------------------------------ */
 /* Replaces mmcv.ops.RoIAlign (mmcv-full 1.3.16, un-vendored: "parity unpinned") as driven by

@@ -257,3 +257,47 @@ def test_sa_module_row_layout_equals_reference_formulation(dev, m_per, c, with_f
         assert torch.allclose(pa.grad, pb.grad, rtol=1e-3, atol=1e-3 * float(pb.grad.abs().max())), na
     for (na, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-4, atol=1e-5), na
+
+
+@pytest.mark.parametrize('n,c,relu', [(5000, 16, True), (30336, 32, True), (884736, 64, True), (777, 128, False),
+                                      (2, 256, True), (1025, 4, True)])
+def test_fused_bn_relu_rows_matches_torch(dev, n, c, relu):
+    """dm_bn_rows_forward/backward == relu(F.batch_norm(x)) (float64 reference): outputs, running
+    statistics, and the gradients w.r.t. x, gamma, beta."""
+    import torch.nn as nn
+    from detmatch_amd.bn_relu import bn_relu_rows
+    torch.manual_seed(n + c)
+    x = (torch.randn(n, c, device=dev) * 2.5 + torch.linspace(-40, 40, c, device=dev)).requires_grad_()
+    bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    ref = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    y = bn_relu_rows(x, bn, relu=relu)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xd = x.detach().double().requires_grad_()
+    pre = ref(xd)
+    yd = torch.relu(pre) if relu else pre
+    yd.backward(g.double())
+    pre = pre.detach()
+    scale = float(yd.abs().max()) + 1e-6
+    assert float((y.double() - yd).abs().max()) < 2e-5 * scale + 2e-5
+    assert torch.allclose(bn.running_mean.double(), ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.double(), ref.running_var, rtol=1e-4, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    gs = float(xd.grad.abs().max()) + 1e-9
+    # elements whose pre-activation sits within rounding distance of 0 may take the other ReLU branch
+    sure = (pre.abs() > 1e-4) if relu else torch.ones_like(pre, dtype=torch.bool)
+    assert float(((x.grad.double() - xd.grad).abs() * sure).max()) < 5e-4 * gs
+    assert float((~sure).double().mean()) < 1e-3
+    assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, rtol=2e-3, atol=2e-3 * float(ref.weight.grad.abs().max()))
+    assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=2e-3, atol=2e-3 * float(ref.bias.grad.abs().max()))
+    bn.eval()
+    ye = bn_relu_rows(x.detach(), bn, relu=relu)          # evaluation mode falls through to torch
+    ref.eval()
+    ze = ref(x.detach().double())
+    assert torch.allclose(ye.double(), torch.relu(ze) if relu else ze, rtol=1e-4, atol=1e-4)
