@@ -374,17 +374,23 @@ __global__ __launch_bounds__(256) void query_group_rows_kernel(
   const long long r = (long long)blockIdx.x * 4 + wave;     // reference = (query, sample)
   if (r >= (long long)m * nsample) return;
   const int q = (int)(r / nsample);
-  const int width = (use_xyz ? 3 : 0) + c;
+  const int xoff = use_xyz ? 4 : 0;        // xyz occupies a 16-byte slot: [dx, dy, dz, 0]
+  const int width = xoff + c;
   float *o = out + r * width;
   if (empty && empty[q]) {
     for (int e = lane; e < width; e += 64) o[e] = 0.0f;
     return;
   }
   const int src = sample_start(q, batch, new_cnt, xyz_cnt) + idx[r];
-  if (use_xyz && lane < 3) o[lane] = xyz[(size_t)src * 3 + lane] - new_xyz[(size_t)q * 3 + lane];
+  if (use_xyz && lane < 4)
+    o[lane] = lane < 3 ? xyz[(size_t)src * 3 + lane] - new_xyz[(size_t)q * 3 + lane] : 0.0f;
   const float *f = feats + (size_t)src * c;
-  float *of = o + (use_xyz ? 3 : 0);
-  for (int e = lane; e < c; e += 64) of[e] = f[e];
+  float *of = o + xoff;
+  if ((c & 3) == 0) {                      // rows and feature blocks are 16-byte aligned
+    for (int e = lane; e < c / 4; e += 64) ((float4 *)of)[e] = ((const float4 *)f)[e];
+  } else {
+    for (int e = lane; e < c; e += 64) of[e] = f[e];
+  }
 }
 
 // backward: grad_feats[src, :] += grad_out[r, col_off : col_off + c].  Small query sets: one
@@ -410,24 +416,29 @@ __global__ __launch_bounds__(256) void group_rows_grad_combine(
     const float *__restrict__ gout, const int *__restrict__ idx, const int *__restrict__ q_cnt,
     const int *__restrict__ src_cnt, const unsigned char *__restrict__ empty,
     float *__restrict__ gfeats) {
-  extern __shared__ float gpc_lds[];
-  float *acc = gpc_lds;                                   // [n_slots][c]
-  int *keys = (int *)(acc + (size_t)n_slots * c);         // [n_slots] source row or -1
+  // Counting sort of the chunk's references by source row (LDS hash -> slot, per-slot counts,
+  // prefix sum, scatter), then every wave sums the rows of "its" slots in REGISTERS and issues one
+  // global atomic row per distinct source.  (A first version accumulated in LDS with ds_add_f32:
+  // LDS float atomics retire lane-serially and were the bottleneck.)
+  extern __shared__ int gps_lds[];
+  int *keys = gps_lds;                       // [n_slots] source row or -1
+  int *cnt = keys + n_slots;                 // [n_slots] references per slot, then scatter cursor
+  int *first = cnt + n_slots;                // [n_slots + 1] start of the slot's run in `sorted`
+  short *slot_of = (short *)(first + n_slots + 1);          // [chunk * nsample]
+  unsigned short *sorted = (unsigned short *)(slot_of + chunk * nsample);   // [chunk * nsample]
   const int q0 = blockIdx.x * chunk;
   const int nq = min(chunk, m - q0);
+  const int n_refs = nq * nsample;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < n_slots * c; i += 256) acc[i] = 0.0f;
-  for (int i = tid; i < n_slots; i += 256) keys[i] = -1;
+  for (int i = tid; i < n_slots; i += 256) keys[i] = -1, cnt[i] = 0;
   __syncthreads();
-  // 1. every thread hashes references in parallel -> slot (or -1: table full / empty ball)
-  short *slot_of = (short *)(keys + n_slots);             // [chunk * nsample]
-  for (int rl = tid; rl < nq * nsample; rl += 256) {
+  for (int rl = tid; rl < n_refs; rl += 256) {
     const int q = q0 + rl / nsample;
     int slot = -2;                                        // -2: skip (empty ball)
     if (!(empty && empty[q])) {
       const int src = sample_start(q, batch, q_cnt, src_cnt) + idx[(long long)q0 * nsample + rl];
       unsigned h = ((unsigned)src * 2654435761u) % (unsigned)n_slots;
-      slot = -1;
+      slot = -1;                                          // -1: table full
       for (int probe = 0; probe < n_slots; ++probe) {
         const int old = atomicCAS(&keys[h], -1, src);
         if (old == -1 || old == src) {
@@ -436,43 +447,100 @@ __global__ __launch_bounds__(256) void group_rows_grad_combine(
         }
         h = h + 1 == (unsigned)n_slots ? 0u : h + 1;
       }
+      if (slot >= 0) atomicAdd(&cnt[slot], 1);
     }
     slot_of[rl] = (short)slot;
   }
   __syncthreads();
-  // 2. one wave per reference row, four rows in flight per wave (the loop is latency bound: one
-  //    workgroup per CU because of the 120 KiB table): contiguous reads, conflict-free LDS adds
-  const int n_refs = nq * nsample;
-  for (int base = wave * 4; base < n_refs; base += 16) {
-    int slot[4];
-    const float *g[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rl = base + u;
-      slot[u] = rl < n_refs ? (int)slot_of[rl] : -2;
-      g[u] = gout + ((long long)q0 * nsample + (rl < n_refs ? rl : 0)) * width + col_off;
+  if (wave == 0) {                           // exclusive prefix sum of cnt over the slots
+    const int per = (n_slots + 63) / 64;
+    int sum = 0;
+    for (int j = 0; j < per; ++j) {
+      const int sidx = lane * per + j;
+      if (sidx < n_slots) sum += cnt[sidx];
     }
-    for (int e = lane; e < c; e += 64) {
-      float v[4];
+    int incl = sum;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = slot[u] != -2 ? g[u][e] : 0.0f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (slot[u] >= 0) {
-          unsafeAtomicAdd(&acc[slot[u] * c + e], v[u]);
-        } else if (slot[u] == -1) {
-          const int rl = base + u, q = q0 + rl / nsample;
-          const long long r = (long long)q0 * nsample + rl;
-          unsafeAtomicAdd(gfeats + (size_t)(sample_start(q, batch, q_cnt, src_cnt) + idx[r]) * c + e, v[u]);
-        }
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    int run = incl - sum;
+    for (int j = 0; j < per; ++j) {
+      const int sidx = lane * per + j;
+      if (sidx < n_slots) {
+        first[sidx] = run;
+        run += cnt[sidx];
       }
+    }
+    if (lane == 63) first[n_slots] = incl;
+  }
+  __syncthreads();
+  for (int i = tid; i < n_slots; i += 256) cnt[i] = first[i];   // scatter cursors
+  __syncthreads();
+  for (int rl = tid; rl < n_refs; rl += 256) {
+    const int slot = slot_of[rl];
+    if (slot >= 0) {
+      sorted[atomicAdd(&cnt[slot], 1)] = (unsigned short)rl;
+    } else if (slot == -1) {     // table full (incoherent neighbourhoods): straight to memory
+      const int q = q0 + rl / nsample;
+      const long long r = (long long)q0 * nsample + rl;
+      float *dst = gfeats + (size_t)(sample_start(q, batch, q_cnt, src_cnt) + idx[r]) * c;
+      const float *g = gout + r * width + col_off;
+      for (int e = 0; e < c; ++e) unsafeAtomicAdd(dst + e, g[e]);
     }
   }
   __syncthreads();
-  for (int f = tid; f < n_slots * c; f += 256) {
-    const int slot = f / c, ci = f - slot * c;
-    const int key = keys[slot];
-    if (key >= 0) unsafeAtomicAdd(gfeats + (size_t)key * c + ci, acc[f]);
+  const float *gbase = gout + (long long)q0 * nsample * width + col_off;
+  for (int slot = wave; slot < n_slots; slot += 4) {
+    const int lo = first[slot], hi = first[slot + 1];
+    if (hi == lo) continue;
+    float *dst = gfeats + (size_t)keys[slot] * c;
+    if (((c | width | col_off) & 3) == 0) {
+      // 16-byte aligned rows: one float4 per lane covers 256 channels per sweep
+      for (int e0 = 0; e0 < c / 4; e0 += 64) {
+        const int e = e0 + lane;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < c / 4)
+          for (int i = lo; i < hi; i += 4) {             // four rows in flight
+            const float4 v0 = ((const float4 *)(gbase + (long long)sorted[i] * width))[e];
+            const float4 v1 = ((const float4 *)(gbase + (long long)sorted[min(i + 1, hi - 1)] * width))[e];
+            const float4 v2 = ((const float4 *)(gbase + (long long)sorted[min(i + 2, hi - 1)] * width))[e];
+            const float4 v3 = ((const float4 *)(gbase + (long long)sorted[min(i + 3, hi - 1)] * width))[e];
+            const float w1 = i + 1 < hi ? 1.f : 0.f, w2 = i + 2 < hi ? 1.f : 0.f, w3 = i + 3 < hi ? 1.f : 0.f;
+            a.x += v0.x + w1 * v1.x + (w2 * v2.x + w3 * v3.x);
+            a.y += v0.y + w1 * v1.y + (w2 * v2.y + w3 * v3.y);
+            a.z += v0.z + w1 * v1.z + (w2 * v2.z + w3 * v3.z);
+            a.w += v0.w + w1 * v1.w + (w2 * v2.w + w3 * v3.w);
+          }
+        if (e < c / 4) {
+          unsafeAtomicAdd(dst + 4 * e, a.x);
+          unsafeAtomicAdd(dst + 4 * e + 1, a.y);
+          unsafeAtomicAdd(dst + 4 * e + 2, a.z);
+          unsafeAtomicAdd(dst + 4 * e + 3, a.w);
+        }
+      }
+      continue;
+    }
+    for (int e0 = 0; e0 < c; e0 += 256) {              // <= 4 channels per lane per sweep
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const int e = e0 + lane;
+      for (int i = lo; i < hi; i += 4) {               // four rows in flight
+        const float *g0 = gbase + (long long)sorted[i] * width;
+        const float *g1 = gbase + (long long)sorted[min(i + 1, hi - 1)] * width;
+        const float *g2 = gbase + (long long)sorted[min(i + 2, hi - 1)] * width;
+        const float *g3 = gbase + (long long)sorted[min(i + 3, hi - 1)] * width;
+        const float w1 = i + 1 < hi ? 1.f : 0.f, w2 = i + 2 < hi ? 1.f : 0.f, w3 = i + 3 < hi ? 1.f : 0.f;
+        if (e < c) a0 += g0[e] + w1 * g1[e] + (w2 * g2[e] + w3 * g3[e]);
+        if (e + 64 < c) a1 += g0[e + 64] + w1 * g1[e + 64] + (w2 * g2[e + 64] + w3 * g3[e + 64]);
+        if (e + 128 < c) a2 += g0[e + 128] + w1 * g1[e + 128] + (w2 * g2[e + 128] + w3 * g3[e + 128]);
+        if (e + 192 < c) a3 += g0[e + 192] + w1 * g1[e + 192] + (w2 * g2[e + 192] + w3 * g3[e + 192]);
+      }
+      if (e < c) unsafeAtomicAdd(dst + e, a0);
+      if (e + 64 < c) unsafeAtomicAdd(dst + e + 64, a1);
+      if (e + 128 < c) unsafeAtomicAdd(dst + e + 128, a2);
+      if (e + 192 < c) unsafeAtomicAdd(dst + e + 192, a3);
+    }
   }
 }
 
@@ -811,11 +879,9 @@ extern "C" int dm_group_rows_grad(int batch, int m, int c, int n, int nsample, i
   if (m >= 16384 && g_gp_grad_combine) {
     int chunk = dm_ceil_div(m, 256);
     chunk = chunk < 32 ? 32 : (chunk > 256 ? 256 : chunk);
-    int n_slots = GPC_ACC_BYTES / (4 * c);
-    if (n_slots > GPC_MAX_SLOTS) n_slots = GPC_MAX_SLOTS;
-    size_t lds = ((size_t)n_slots * c * 4 + (size_t)n_slots * 4 + (size_t)chunk * nsample * 2 + 15) &
-                 ~(size_t)15;
-    if (n_slots >= 64 && lds <= 160 * 1024) {
+    int n_slots = 1024;                       // open-addressing table of distinct source rows
+    size_t lds = ((size_t)(3 * n_slots + 1) * 4 + (size_t)chunk * nsample * 4 + 15) & ~(size_t)15;
+    if (chunk * nsample <= 65535 && lds <= 64 * 1024) {
       group_rows_grad_combine<<<dm_ceil_div(m, chunk), 256, lds, st>>>(
           batch, m, c, nsample, row_width, col_offset, chunk, n_slots, grad_out, idx, idx_batch_cnt,
           features_batch_cnt, empty_mask, grad_features);

@@ -123,8 +123,8 @@ class QueryAndGroup(nn.Module):
 
 
 class QueryGroupRows(Function):
-    """Fused QueryAndGroup gather in row layout: -> (M, nsample, [3+]C) with
-    rows[m,s,0:3] = xyz[src] - new_xyz[m], rows[m,s,3:] = features[src], zero rows for empty balls
+    """Fused QueryAndGroup gather in row layout: -> (M, nsample, [4+]C) with
+    rows[m,s,0:4] = [xyz[src] - new_xyz[m], 0], rows[m,s,4:] = features[src], zero rows for empty balls
     (the content of pointnet2_utils.py:139-153, one launch, no cat).  Gradient: features only."""
 
     @staticmethod
@@ -138,7 +138,7 @@ class QueryGroupRows(Function):
         if features is not None:
             features = features.contiguous()
         m, ns = idx.shape
-        width = (3 if use_xyz else 0) + c
+        width = (4 if use_xyz else 0) + c      # xyz rides in a 16-byte slot [dx, dy, dz, 0]
         out = torch.empty((m, ns, width), dtype=torch.float32, device=xyz.device)
         em = empty_mask.contiguous().view(torch.uint8) if empty_mask is not None else None
         _lib.check(_lib.lib().dm_query_group_rows(
@@ -147,7 +147,7 @@ class QueryGroupRows(Function):
             _lib.ptr(new_xyz_batch_cnt), _lib.ptr(idx), _lib.ptr(em) if em is not None else None,
             _lib.ptr(out), _lib.stream()), 'dm_query_group_rows')
         ctx.save_for_backward(idx, xyz_batch_cnt, new_xyz_batch_cnt, em)
-        ctx.meta = (features.shape[0] if features is not None else 0, c, width, 3 if use_xyz else 0)
+        ctx.meta = (features.shape[0] if features is not None else 0, c, width, 4 if use_xyz else 0)
         return out
 
     @staticmethod
@@ -195,7 +195,7 @@ class TallSkinnyLinear(Function):
 
 def query_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None,
                      use_xyz=True):
-    """QueryAndGroup (pointnet2_utils.py:116-156) in row layout -> (M, nsample, [3+]C), idx."""
+    """QueryAndGroup (pointnet2_utils.py:116-156) in row layout -> (M, nsample, [4+]C), idx."""
     idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
     assert use_xyz or features is not None, 'Cannot have not features and not use xyz as a feature!'
     rows = QueryGroupRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty,
@@ -295,8 +295,11 @@ class StackSAModuleMSG(nn.Module):
                 m, ns, width = rows.shape
                 x = rows.view(m * ns, width)
                 mods = list(self.mlps[k])
-                for conv, bn in zip(mods[0::3], mods[1::3]):
-                    x = TallSkinnyLinear.apply(x, conv.weight.view(conv.out_channels, conv.in_channels))
+                for li, (conv, bn) in enumerate(zip(mods[0::3], mods[1::3])):
+                    w = conv.weight.view(conv.out_channels, conv.in_channels)
+                    if li == 0 and g.use_xyz:      # zero column for the padding float after xyz
+                        w = torch.cat([w[:, :3], w.new_zeros((w.shape[0], 1)), w[:, 3:]], dim=1)
+                    x = TallSkinnyLinear.apply(x, w)
                     if conv.bias is not None:
                         x = x + conv.bias
                     x = bn_relu_rows(x, bn, relu=True)      # fused BatchNorm + ReLU over rows

@@ -334,9 +334,10 @@ int dm_group_points_grad_stack(int batch, int m, int c, int n, int nsample, cons
                                dm_stream_t stream);
 /* Fused QueryAndGroup gather in ROW layout (pointnet2_utils.py:119-156 = group xyz, subtract the
  * ball centre, group features, cat; then StackSAModuleMSG permutes to (1,C,M,ns) for 1x1 convs,
- * pointnet2_modules.py:72-76).  out (M, nsample, [3+]C): out[m,s,0:3] = xyz[src] - new_xyz[m],
- * out[m,s,3:] = features[src]; rows of empty balls (empty_mask[m] != 0) are zero.  features may be
- * NULL with c == 0 (xyz only). */
+ * pointnet2_modules.py:72-76).  out (M, nsample, [4+]C): with use_xyz the row starts with a
+ * 16-byte slot [xyz[src] - new_xyz[m], 0], then features[src] (so rows and feature blocks stay
+ * 16-byte aligned for C % 4 == 0); rows of empty balls (empty_mask[m] != 0) are zero.  features
+ * may be NULL with c == 0 (xyz only). */
 int dm_query_group_rows(int batch, int m, int c, int nsample, int use_xyz, const float *xyz,
                         const float *new_xyz, const float *features, const int *xyz_batch_cnt,
                         const int *new_xyz_batch_cnt, const int *idx,
