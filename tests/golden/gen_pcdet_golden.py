@@ -1,0 +1,174 @@
+"""Generates tests/golden/pcdet_torch.npz by running the REFERENCE's own pure-PyTorch OpenPCDet code
+(thirdparty/Spconv-OpenPCDet/pcdet, loaded by file path; build container only) on seeded inputs:
+
+    pcdet/utils/box_coder_utils.py     ResidualCoder.encode_torch / decode_torch
+    pcdet/utils/loss_utils.py          SigmoidFocalClassificationLoss, WeightedSmoothL1Loss,
+                                       WeightedCrossEntropyLoss, get_corner_loss_lidar
+    pcdet/utils/box_utils.py           boxes_to_corners_3d, boxes3d_nearest_bev_iou, enlarge_box3d
+    pcdet/utils/common_utils.py        limit_period, rotate_points_along_z, get_voxel_centers
+    pcdet/models/dense_heads/target_assigner/anchor_generator.py          AnchorGenerator
+    pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py  assign_targets
+
+The compiled extension modules those files import (iou3d_nms_cuda, roiaware_pool3d_cuda) are not
+built here and not needed on these code paths: empty placeholder modules stand in for them, and
+Tensor.cuda() is made the identity for the two `.cuda()` calls of the anchor generator.  The fixture
+holds inputs + reference outputs only.
+
+    python tests/golden/gen_pcdet_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference/thirdparty/Spconv-OpenPCDet'
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+
+def _pkg(name):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _load(dotted, rel):
+    spec = importlib.util.spec_from_file_location(dotted, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[dotted] = mod
+    parent, _, leaf = dotted.rpartition('.')
+    if parent in sys.modules:
+        setattr(sys.modules[parent], leaf, mod)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    for n in ('pcdet', 'pcdet.ops', 'pcdet.ops.roiaware_pool3d', 'pcdet.ops.iou3d_nms', 'pcdet.utils',
+              'pcdet.models', 'pcdet.models.dense_heads', 'pcdet.models.dense_heads.target_assigner'):
+        _pkg(n)
+    sys.modules['pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda'] = types.ModuleType('roiaware_pool3d_cuda')
+    sys.modules['pcdet.ops.roiaware_pool3d'].roiaware_pool3d_cuda = sys.modules['pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda']
+    sys.modules['pcdet.ops.iou3d_nms.iou3d_nms_cuda'] = types.ModuleType('iou3d_nms_cuda')
+    sys.modules['pcdet.ops.iou3d_nms'].iou3d_nms_cuda = sys.modules['pcdet.ops.iou3d_nms.iou3d_nms_cuda']
+    common = _load('pcdet.utils.common_utils', 'pcdet/utils/common_utils.py')
+    _load('pcdet.ops.roiaware_pool3d.roiaware_pool3d_utils', 'pcdet/ops/roiaware_pool3d/roiaware_pool3d_utils.py')
+    box_utils = _load('pcdet.utils.box_utils', 'pcdet/utils/box_utils.py')
+    coder = _load('pcdet.utils.box_coder_utils', 'pcdet/utils/box_coder_utils.py')
+    loss = _load('pcdet.utils.loss_utils', 'pcdet/utils/loss_utils.py')
+    _load('pcdet.ops.iou3d_nms.iou3d_nms_utils', 'pcdet/ops/iou3d_nms/iou3d_nms_utils.py')
+    agen = _load('pcdet.models.dense_heads.target_assigner.anchor_generator',
+                 'pcdet/models/dense_heads/target_assigner/anchor_generator.py')
+    assigner = _load('pcdet.models.dense_heads.target_assigner.axis_aligned_target_assigner',
+                     'pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py')
+    return common, box_utils, coder, loss, agen, assigner
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+    def get(self, k, d=None):
+        return dict.get(self, k, d)
+
+
+def main():
+    from detmatch_amd import configs, synth
+    common, box_utils, coder_m, loss_m, agen_m, assigner_m = load_reference()
+    torch.Tensor.cuda = lambda self, *a, **k: self          # anchor_generator.py:36,39
+    rng = np.random.default_rng(11)
+    out = {}
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+
+    def boxes(n):
+        return np.concatenate([rng.uniform([0, -40, -3], [70, 40, 1], (n, 3)), rng.uniform(0.4, 5.0, (n, 3)),
+                               rng.uniform(-4, 4, (n, 1))], 1).astype(np.float32)
+    # ---- common_utils
+    ang = rng.uniform(-7, 7, 50).astype(np.float32)
+    out['lp_in'] = ang
+    out['lp_out_pi'] = common.limit_period(f32(ang), 0.5, np.pi).numpy()
+    out['lp_out_2pi'] = common.limit_period(f32(ang), 0.5, 2 * np.pi).numpy()
+    pts = rng.normal(size=(4, 9, 5)).astype(np.float32)
+    rot = rng.uniform(-3, 3, 4).astype(np.float32)
+    out['rot_pts'], out['rot_ang'] = pts, rot
+    out['rot_out'] = common.rotate_points_along_z(f32(pts), f32(rot)).numpy()
+    vc = rng.integers(0, 40, (30, 3)).astype(np.int32)
+    out['vc_in'] = vc
+    out['vc_out'] = common.get_voxel_centers(torch.from_numpy(vc), 4, [0.05, 0.05, 0.1],
+                                             [0, -40, -3, 70.4, 40, 1]).numpy()
+    # ---- box_utils
+    b = boxes(40)
+    out['bx_in'] = b
+    out['bx_corners'] = box_utils.boxes_to_corners_3d(f32(b)).numpy()
+    out['bx_enlarged'] = box_utils.enlarge_box3d(f32(b), extra_width=(0.2, 0.2, 0.2)).numpy()
+    b2 = boxes(17)
+    b2[:5] = b[:5] + rng.normal(0, 0.2, (5, 7)).astype(np.float32)
+    out['bx_in2'] = b2
+    out['bx_nearest_iou'] = box_utils.boxes3d_nearest_bev_iou(f32(b), f32(b2)).numpy()
+    # ---- ResidualCoder
+    rc = coder_m.ResidualCoder()
+    anchors = boxes(60)
+    gts = anchors + rng.normal(0, 0.3, anchors.shape).astype(np.float32)
+    gts[:, 3:6] = np.abs(gts[:, 3:6]) + 0.1
+    out['rc_anchors'], out['rc_gt'] = anchors, gts
+    enc = rc.encode_torch(f32(gts), f32(anchors))
+    out['rc_enc'] = enc.numpy()
+    out['rc_dec'] = rc.decode_torch(enc, f32(anchors)).numpy()
+    # ---- losses
+    logits = rng.normal(0, 2, (2, 500, 3)).astype(np.float32)
+    onehot = np.eye(4, dtype=np.float32)[rng.integers(0, 4, (2, 500))][..., 1:]
+    w = rng.uniform(0, 1, (2, 500)).astype(np.float32)
+    out['fl_logits'], out['fl_targets'], out['fl_w'] = logits, onehot, w
+    out['fl_out'] = loss_m.SigmoidFocalClassificationLoss(alpha=0.25, gamma=2.0)(f32(logits), f32(onehot), f32(w)).numpy()
+    pr, tg = rng.normal(0, 1, (2, 300, 7)).astype(np.float32), rng.normal(0, 1, (2, 300, 7)).astype(np.float32)
+    tg[0, :5, 2] = np.nan
+    cw = [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+    out['sl_pred'], out['sl_tgt'], out['sl_w'] = pr, tg, w[:, :300]
+    out['sl_out'] = loss_m.WeightedSmoothL1Loss(beta=1.0 / 9.0, code_weights=cw)(f32(pr), f32(tg), f32(w[:, :300])).numpy()
+    dl = rng.normal(0, 1, (2, 300, 2)).astype(np.float32)
+    dt = np.eye(2, dtype=np.float32)[rng.integers(0, 2, (2, 300))]
+    out['ce_logits'], out['ce_tgt'] = dl, dt
+    out['ce_out'] = loss_m.WeightedCrossEntropyLoss()(f32(dl), f32(dt), f32(w[:, :300])).numpy()
+    pb, gb = boxes(64), boxes(64)
+    out['cl_pred'], out['cl_gt'] = pb, gb
+    out['cl_out'] = loss_m.get_corner_loss_lidar(f32(pb), f32(gb)).numpy()
+    # ---- anchors + target assignment (KITTI PV-RCNN config)
+    cfg = configs.pvrcnn_kitti_model()['pcdet_model']['DENSE_HEAD']
+    gen_cfg = [AttrDict(c) for c in cfg['ANCHOR_GENERATOR_CONFIG']]
+    gen = agen_m.AnchorGenerator(anchor_range=np.array(configs.POINT_CLOUD_RANGE, dtype=np.float32),
+                                 anchor_generator_config=gen_cfg)
+    fmap = [np.array([176, 200]) for _ in gen_cfg]
+    anchors_list, per_loc = gen.generate_anchors(fmap)
+    out['ag_num_per_loc'] = np.array(per_loc)
+    for i, a in enumerate(anchors_list):
+        out['ag_shape_%d' % i] = np.array(a.shape)
+        out['ag_sample_%d' % i] = a.reshape(-1, 7)[::997].numpy()      # every 997th anchor
+        out['ag_sum_%d' % i] = a.double().sum(dim=(0, 1, 2, 3, 4)).numpy()
+    model_cfg = AttrDict(ANCHOR_GENERATOR_CONFIG=gen_cfg,
+                         TARGET_ASSIGNER_CONFIG=AttrDict(cfg['TARGET_ASSIGNER_CONFIG']))
+    ta = assigner_m.AxisAlignedTargetAssigner(model_cfg=model_cfg, class_names=configs.CLASS_NAMES,
+                                              box_coder=rc, match_height=False)
+    gt = np.zeros((3, 12, 8), np.float32)
+    for s in range(2):
+        f = synth.lidar_frame(s)
+        lab = synth._SIM_TO_CFG_LABEL[f['gt_labels']] + 1
+        g = np.concatenate([f['gt_boxes'], lab[:, None].astype(np.float32)], 1)
+        if s == 1:
+            g = g[:7]
+        gt[s, :len(g)] = g
+    out['ta_gt'] = gt                      # third sample: no GT at all
+    res = ta.assign_targets(anchors_list, f32(gt))
+    out['ta_labels'] = res['box_cls_labels'].numpy().astype(np.int32)
+    out['ta_weights'] = res['reg_weights'].numpy()
+    fg = out['ta_labels'] > 0
+    out['ta_fg_idx'] = np.stack(np.nonzero(fg), 1).astype(np.int32)
+    out['ta_fg_targets'] = res['box_reg_targets'].numpy()[fg]
+    np.savez_compressed(os.path.join(HERE, 'pcdet_torch.npz'), **out)
+    print('wrote pcdet_torch.npz: %d arrays, %d foreground anchors' % (len(out), int(fg.sum())))
+
+
+if __name__ == '__main__':
+    main()
