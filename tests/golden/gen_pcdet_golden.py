@@ -168,6 +168,60 @@ def main():
     out['ta_fg_targets'] = res['box_reg_targets'].numpy()[fg]
     np.savez_compressed(os.path.join(HERE, 'pcdet_torch.npz'), **out)
     print('wrote pcdet_torch.npz: %d arrays, %d foreground anchors' % (len(out), int(fg.sum())))
+    roi_head_goldens(rng, boxes)
+
+
+def roi_head_goldens(rng, boxes):
+    """RoIHeadTemplate (roi_head_template.py) with the sampling step replaced by fixed inputs: the
+    IoU -> (reg_valid_mask, soft cls label) mapping of ProposalTargetLayer.forward, the canonical
+    transform of assign_targets, generate_predicted_boxes and the two RoI losses."""
+    from detmatch_amd import configs
+    for n in ('pcdet.models.model_utils', 'pcdet.models.roi_heads', 'pcdet.models.roi_heads.target_assigner'):
+        _pkg(n)
+    _load('pcdet.models.model_utils.model_nms_utils', 'pcdet/models/model_utils/model_nms_utils.py')
+    ptl_m = _load('pcdet.models.roi_heads.target_assigner.proposal_target_layer',
+                  'pcdet/models/roi_heads/target_assigner/proposal_target_layer.py')
+    tmpl = _load('pcdet.models.roi_heads.roi_head_template', 'pcdet/models/roi_heads/roi_head_template.py')
+
+    def to_attr(d):
+        return AttrDict({k: (to_attr(v) if isinstance(v, dict) else v) for k, v in d.items()})
+    cfg = to_attr(configs.pvrcnn_kitti_model()['pcdet_model']['ROI_HEAD'])
+    head = tmpl.RoIHeadTemplate(num_class=1, model_cfg=cfg)
+    f32 = lambda a: torch.from_numpy(np.array(a, dtype=np.float32, copy=True))   # the reference edits in place
+    B, R = 2, 128
+    rois = boxes(B * R).reshape(B, R, 7)
+    gt = rois + rng.normal(0, 0.4, rois.shape).astype(np.float32)
+    gt[..., 3:6] = np.abs(gt[..., 3:6]) + 0.2
+    gt_of_rois = np.concatenate([gt, rng.integers(1, 4, (B, R, 1)).astype(np.float32)], -1)
+    ious = rng.uniform(0, 1, (B, R)).astype(np.float32)
+    scores = rng.normal(size=(B, R)).astype(np.float32)
+    labels = rng.integers(1, 4, (B, R)).astype(np.int64)
+    scores_full = rng.normal(size=(B, R, 3)).astype(np.float32)
+    head.proposal_target_layer.sample_rois_for_rcnn = lambda batch_dict: (
+        f32(rois), f32(gt_of_rois), f32(ious), f32(scores), torch.from_numpy(labels), f32(scores_full))
+    td = head.assign_targets(dict(batch_size=B))
+    out = dict(rois=rois, gt_of_rois_in=gt_of_rois, ious=ious, scores=scores, labels=labels,
+               scores_full=scores_full, reg_valid_mask=td['reg_valid_mask'].numpy(),
+               rcnn_cls_labels=td['rcnn_cls_labels'].numpy(), gt_of_rois=td['gt_of_rois'].numpy(),
+               gt_of_rois_src=td['gt_of_rois_src'].numpy())
+    rcnn_cls = rng.normal(size=(B * R, 1)).astype(np.float32)
+    rcnn_reg = rng.normal(0, 0.3, (B * R, 7)).astype(np.float32)
+    cls_p, box_p = head.generate_predicted_boxes(B, f32(rois), f32(rcnn_cls), f32(rcnn_reg))
+    out.update(rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg, pred_cls=cls_p.numpy(), pred_boxes=box_p.numpy())
+    fwd = dict(td)
+    fwd['rcnn_cls'], fwd['rcnn_reg'] = f32(rcnn_cls), f32(rcnn_reg)
+    head.forward_ret_dict = fwd
+    lc, _ = head.get_box_cls_layer_loss(fwd)
+    lr, tb = head.get_box_reg_layer_loss(fwd)
+    out.update(loss_cls=np.array(float(lc)), loss_reg=np.array(float(lr)),
+               loss_corner=np.array(float(tb['rcnn_loss_corner'])))
+    # a batch without any regression-valid RoI
+    fwd0 = dict(fwd)
+    fwd0['reg_valid_mask'] = torch.zeros_like(fwd['reg_valid_mask'])
+    lr0, _ = head.get_box_reg_layer_loss(fwd0)
+    out['loss_reg_no_fg'] = np.array(float(lr0))
+    np.savez_compressed(os.path.join(HERE, 'pcdet_roi_head.npz'), **out)
+    print('wrote pcdet_roi_head.npz: %d arrays; %d reg-valid RoIs' % (len(out), int(out['reg_valid_mask'].sum())))
 
 
 if __name__ == '__main__':
