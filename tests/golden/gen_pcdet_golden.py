@@ -169,6 +169,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'pcdet_torch.npz'), **out)
     print('wrote pcdet_torch.npz: %d arrays, %d foreground anchors' % (len(out), int(fg.sum())))
     roi_head_goldens(rng, boxes)
+    dense_goldens(rng, rc)
+    state_key_goldens()
 
 
 def roi_head_goldens(rng, boxes):
@@ -222,6 +224,180 @@ def roi_head_goldens(rng, boxes):
     out['loss_reg_no_fg'] = np.array(float(lr0))
     np.savez_compressed(os.path.join(HERE, 'pcdet_roi_head.npz'), **out)
     print('wrote pcdet_roi_head.npz: %d arrays; %d reg-valid RoIs' % (len(out), int(out['reg_valid_mask'].sum())))
+
+
+
+
+def _to_attr(d):
+    if isinstance(d, dict):
+        return AttrDict({k: _to_attr(v) for k, v in d.items()})
+    if isinstance(d, (list, tuple)):
+        return type(d)(_to_attr(v) for v in d)
+    return d
+
+
+def dense_goldens(rng, rc):
+    """Module-level goldens (state_dict + input -> output, losses) of the reference's dense modules on a
+    REDUCED geometry (16 m x 16 m range, narrow channels) so that the fixture stays small:
+    AnchorHeadSingle forward/get_loss/generate_predicted_boxes, BaseBEVBackbone.forward,
+    PointHeadSimple forward/get_loss, MeanVFE.forward, bilinear_interpolate_torch."""
+    from detmatch_amd import configs
+    for n in ('pcdet.models.backbones_2d', 'pcdet.models.backbones_3d', 'pcdet.models.backbones_3d.vfe',
+              'pcdet.models.backbones_3d.pfe', 'pcdet.ops.pointnet2', 'pcdet.ops.pointnet2.pointnet2_stack'):
+        _pkg(n)
+    for leaf in ('pointnet2_modules', 'pointnet2_utils'):     # imported by voxel_set_abstraction.py, unused here
+        m = types.ModuleType('pcdet.ops.pointnet2.pointnet2_stack.' + leaf)
+        sys.modules[m.__name__] = m
+        setattr(sys.modules['pcdet.ops.pointnet2.pointnet2_stack'], leaf, m)
+    _load('pcdet.models.dense_heads.target_assigner.atss_target_assigner',
+          'pcdet/models/dense_heads/target_assigner/atss_target_assigner.py')
+    _load('pcdet.models.dense_heads.anchor_head_template', 'pcdet/models/dense_heads/anchor_head_template.py')
+    ahs = _load('pcdet.models.dense_heads.anchor_head_single', 'pcdet/models/dense_heads/anchor_head_single.py')
+    _load('pcdet.models.dense_heads.point_head_template', 'pcdet/models/dense_heads/point_head_template.py')
+    phs = _load('pcdet.models.dense_heads.point_head_simple', 'pcdet/models/dense_heads/point_head_simple.py')
+    _load('pcdet.utils.frozen_bn', 'pcdet/utils/frozen_bn.py')      # imported, not selected (no FROZEN_BN key)
+    bev = _load('pcdet.models.backbones_2d.base_bev_backbone', 'pcdet/models/backbones_2d/base_bev_backbone.py')
+    _load('pcdet.models.backbones_3d.vfe.vfe_template', 'pcdet/models/backbones_3d/vfe/vfe_template.py')
+    vfe = _load('pcdet.models.backbones_3d.vfe.mean_vfe', 'pcdet/models/backbones_3d/vfe/mean_vfe.py')
+    vsa = _load('pcdet.models.backbones_3d.pfe.voxel_set_abstraction',
+                'pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py')
+    model = configs.pvrcnn_kitti_model()['pcdet_model']
+    out = {}
+    f32 = lambda a: torch.from_numpy(np.array(a, dtype=np.float32, copy=True))
+    sd = lambda prefix, m: out.update({prefix + '/' + k: v.detach().numpy().copy() for k, v in m.state_dict().items()})
+    torch.manual_seed(5)
+    # ---- AnchorHeadSingle on a 40 x 40 map
+    pcr = np.array([0, -8, -3, 16, 8, 1], dtype=np.float32)
+    grid = np.array([320, 320, 40])
+    C = 16
+    head = ahs.AnchorHeadSingle(model_cfg=_to_attr(model['DENSE_HEAD']), input_channels=C, num_class=3,
+                                class_names=configs.CLASS_NAMES, grid_size=grid, point_cloud_range=pcr)
+    with torch.no_grad():
+        for p in head.parameters():                      # conv_box is N(0, 0.001): make the maps non-trivial
+            p.add_(torch.randn_like(p) * 0.1)
+    sizes = np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]], np.float32)
+    z0 = np.array([-1.0, -0.6, -0.6], np.float32)
+    gt = np.zeros((2, 9, 8), np.float32)
+    for b, n in enumerate((9, 4)):
+        cls = rng.integers(0, 3, n)
+        gt[b, :n, 0] = rng.uniform(1, 15, n)
+        gt[b, :n, 1] = rng.uniform(-7, 7, n)
+        gt[b, :n, 2] = z0[cls] + rng.normal(0, 0.1, n)
+        gt[b, :n, 3:6] = sizes[cls] * rng.uniform(0.9, 1.1, (n, 3))
+        gt[b, :n, 6] = rng.uniform(-np.pi, np.pi, n)
+        gt[b, :n, 7] = cls + 1
+    x = rng.normal(size=(2, C, 40, 40)).astype(np.float32)
+    head.train()
+    dd = head(dict(spatial_features_2d=f32(x), gt_boxes=f32(gt), batch_size=2))
+    sd('ah', head)
+    out.update(ah_pcr=pcr, ah_grid=grid, ah_x=x, ah_gt=gt,
+               ah_cls_preds=head.forward_ret_dict['cls_preds'].detach().numpy(),
+               ah_box_preds=head.forward_ret_dict['box_preds'].detach().numpy(),
+               ah_dir_preds=head.forward_ret_dict['dir_cls_preds'].detach().numpy(),
+               ah_labels=head.forward_ret_dict['box_cls_labels'].numpy().astype(np.int32),
+               ah_batch_cls=dd['batch_cls_preds'].detach().numpy(),
+               ah_batch_box=dd['batch_box_preds'].detach().numpy())
+    loss, tb = head.get_loss()
+    out.update(ah_loss=np.array(float(loss)), ah_loss_cls=np.array(tb['rpn_loss_cls']),
+               ah_loss_loc=np.array(tb['rpn_loss_loc']), ah_loss_dir=np.array(tb['rpn_loss_dir']))
+    # ---- BaseBEVBackbone, narrow
+    bcfg = AttrDict(LAYER_NUMS=[2, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[8, 16], UPSAMPLE_STRIDES=[1, 2],
+                    NUM_UPSAMPLE_FILTERS=[16, 16])
+    bb = bev.BaseBEVBackbone(bcfg, input_channels=12)
+    bb.train()                                            # batch statistics: exercises eps / momentum too
+    xb = rng.normal(size=(2, 12, 24, 20)).astype(np.float32)
+    sd('bev_before', bb)
+    ob = bb(dict(spatial_features=f32(xb)))
+    sd('bev_after', bb)
+    out.update(bev_x=xb, bev_out=ob['spatial_features_2d'].detach().numpy())
+    # ---- PointHeadSimple
+    ph = phs.PointHeadSimple(num_class=1, input_channels=24, model_cfg=_to_attr(model['POINT_HEAD']))
+    ph.eval()
+    with torch.no_grad():
+        for m in ph.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    pf = rng.normal(size=(300, 24)).astype(np.float32)
+    od = ph(dict(point_features=f32(pf), point_features_before_fusion=f32(pf),
+                 point_coords=torch.zeros(300, 4), batch_size=1))
+    sd('ph', ph)
+    lab = rng.integers(-1, 2, 300).astype(np.int64)
+    ph.forward_ret_dict['point_cls_labels'] = torch.from_numpy(lab)
+    pl, ptb = ph.get_loss()
+    out.update(ph_x=pf, ph_scores=od['point_cls_scores'].detach().numpy(),
+               ph_preds=ph.forward_ret_dict['point_cls_preds'].detach().numpy(), ph_labels=lab,
+               ph_loss=np.array(float(pl)), ph_pos=np.array(ptb['point_pos_num']))
+    # ---- MeanVFE
+    mv = vfe.MeanVFE(model_cfg=AttrDict(), num_point_features=4)
+    vox = rng.normal(size=(50, 5, 4)).astype(np.float32)
+    npts = rng.integers(1, 6, 50).astype(np.int32)
+    for i, n in enumerate(npts):
+        vox[i, n:] = 0
+    out.update(vfe_voxels=vox, vfe_num=npts,
+               vfe_out=mv(dict(voxels=f32(vox), voxel_num_points=torch.from_numpy(npts)))['voxel_features'].numpy())
+    # ---- bilinear interpolation of BEV features at keypoints
+    im = rng.normal(size=(25, 22, 6)).astype(np.float32)
+    bx = rng.uniform(-1, 23, 80).astype(np.float32)      # includes out-of-map coordinates (clamped)
+    by = rng.uniform(-1, 26, 80).astype(np.float32)
+    out.update(bi_im=im, bi_x=bx, bi_y=by,
+               bi_out=vsa.bilinear_interpolate_torch(f32(im), f32(bx), f32(by)).numpy())
+    np.savez_compressed(os.path.join(HERE, 'pcdet_dense.npz'), **out)
+    print('wrote pcdet_dense.npz: %d arrays, %d positive anchors, %.0f kB' % (
+        len(out), int((out['ah_labels'] > 0).sum()), os.path.getsize(os.path.join(HERE, 'pcdet_dense.npz')) / 1e3))
+
+
+def state_key_goldens():
+    """Parameter / buffer names and shapes of the reference's PV-RCNN modules at the KITTI config
+    (modules are only constructed; the compiled ops behind them are placeholder modules): the
+    checkpoint-interoperability contract of the 3D branch."""
+    import json
+    from detmatch_amd import configs
+    for n in ('pcdet.ops.spconv',):
+        _pkg(n)
+    sys.modules['pcdet.ops.spconv.sparse_conv_ext'] = types.ModuleType('sparse_conv_ext')
+    sys.modules['pcdet.ops.spconv'].sparse_conv_ext = sys.modules['pcdet.ops.spconv.sparse_conv_ext']
+    for leaf in ('structure', 'modules', 'ops', 'functional', 'conv', 'pool'):
+        _load('pcdet.ops.spconv.' + leaf, 'pcdet/ops/spconv/%s.py' % leaf)
+    sp = _load('pcdet.ops.spconv', 'pcdet/ops/spconv/__init__.py')
+    sp.__path__ = []
+    sys.modules['pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda'] = types.ModuleType('pointnet2_stack_cuda')
+    sys.modules['pcdet.ops.pointnet2.pointnet2_stack'].pointnet2_stack_cuda = \
+        sys.modules['pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda']
+    _load('pcdet.ops.pointnet2.pointnet2_stack.pointnet2_utils', 'pcdet/ops/pointnet2/pointnet2_stack/pointnet2_utils.py')
+    _load('pcdet.ops.pointnet2.pointnet2_stack.pointnet2_modules', 'pcdet/ops/pointnet2/pointnet2_stack/pointnet2_modules.py')
+    bb3 = _load('pcdet.models.backbones_3d.spconv_backbone', 'pcdet/models/backbones_3d/spconv_backbone.py')
+    vsa = _load('pcdet.models.backbones_3d.pfe.voxel_set_abstraction',
+                'pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py')
+    pvh = _load('pcdet.models.roi_heads.pvrcnn_head', 'pcdet/models/roi_heads/pvrcnn_head.py')
+    m = sys.modules
+    model = _to_attr(configs.pvrcnn_kitti_model()['pcdet_model'])
+    grid = np.array([1408, 1600, 40])
+    pcr = np.array(configs.POINT_CLOUD_RANGE, dtype=np.float32)
+    mods = {
+        'backbone_3d': bb3.VoxelBackBone8x(model.BACKBONE_3D, input_channels=4, grid_size=grid),
+        'pfe': vsa.VoxelSetAbstraction(model.PFE, voxel_size=[0.05, 0.05, 0.1], point_cloud_range=pcr,
+                                       num_bev_features=256, num_rawpoint_features=4),
+        'backbone_2d': m['pcdet.models.backbones_2d.base_bev_backbone'].BaseBEVBackbone(model.BACKBONE_2D, 256),
+        'dense_head': m['pcdet.models.dense_heads.anchor_head_single'].AnchorHeadSingle(
+            model_cfg=model.DENSE_HEAD, input_channels=512, num_class=3, class_names=configs.CLASS_NAMES,
+            grid_size=grid, point_cloud_range=pcr),
+    }
+    mods['point_head'] = m['pcdet.models.dense_heads.point_head_simple'].PointHeadSimple(
+        num_class=1 if model.POINT_HEAD.CLASS_AGNOSTIC else 3,
+        input_channels=(mods['pfe'].num_point_features_before_fusion
+                        if model.POINT_HEAD.get('USE_POINT_FEATURES_BEFORE_FUSION', False)
+                        else mods['pfe'].num_point_features),     # detector3d_template.py:143-146
+        model_cfg=model.POINT_HEAD)
+    mods['roi_head'] = pvh.PVRCNNHead(input_channels=mods['pfe'].num_point_features, model_cfg=model.ROI_HEAD,
+                                      num_class=1 if model.ROI_HEAD.CLASS_AGNOSTIC else 3)
+    keys = {}
+    for name, mod in mods.items():
+        for k, v in mod.state_dict().items():
+            keys['%s.%s' % (name, k)] = list(v.shape)
+    with open(os.path.join(HERE, 'pcdet_state_keys.json'), 'w') as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    print('wrote pcdet_state_keys.json: %d entries' % len(keys))
 
 
 if __name__ == '__main__':
