@@ -398,6 +398,17 @@ def state_key_goldens():
     with open(os.path.join(HERE, 'pcdet_state_keys.json'), 'w') as f:
         json.dump(keys, f, indent=0, sort_keys=True)
     print('wrote pcdet_state_keys.json: %d entries' % len(keys))
+    # pure-tensor methods of the two modules that only exist as instances
+    rng = np.random.default_rng(23)
+    rois = np.concatenate([rng.uniform([0, -40, -3], [70, 40, 1], (20, 3)), rng.uniform(0.4, 5.0, (20, 3)),
+                           rng.uniform(-4, 4, (20, 1))], 1).astype(np.float32)
+    glob, local = mods['roi_head'].get_global_grid_points_of_roi(torch.from_numpy(rois.copy()), grid_size=6)
+    kp = rng.uniform([0, -40, -3], [70.4, 40, 1], (2, 50, 3)).astype(np.float32)
+    bevf = rng.normal(size=(2, 8, 200, 176)).astype(np.float16).astype(np.float32)   # stored as f16: exact
+    pb = mods['pfe'].interpolate_from_bev_features(torch.from_numpy(kp.copy()), torch.from_numpy(bevf.copy()), 2, 8)
+    np.savez_compressed(os.path.join(HERE, 'pcdet_grid.npz'), rois=rois, grid_global=glob.numpy(),
+                        grid_local=local.numpy(), kp=kp, bev=bevf.astype(np.float16), kp_bev=pb.numpy())
+    print('wrote pcdet_grid.npz')
 
 
 if __name__ == '__main__':
