@@ -54,6 +54,9 @@ class HybridOptimizer(torch.optim.Optimizer):
         for o in self.optimizers:
             self.param_groups += o.param_groups
         self.num_step_updated = state_dict['num_step_updated']
+        for f in getattr(self, '_fused', None) or []:
+            if f is not None:     # torch re-homed the loaded state: move it back into the flat state
+                f.adopt_loaded_state()
 
     def zero_grad(self, set_to_none=False):
         for o in self.optimizers:
@@ -100,13 +103,46 @@ class FusedRange(object):
         else:
             self.buf = torch.zeros(n, device=dev)
         self.step_t = torch.zeros((), dtype=torch.float32)
-        for p in params:   # torch-compatible view of the state (state_dict / resume parity)
+        self.params = list(params)
+        if any(opt.state.get(p, None) for p in self.params):
+            self.adopt_loaded_state()      # built after a resume: keep the loaded state
+        else:
+            self._publish()
+
+    def _publish(self):
+        """torch-compatible view of the state (state_dict / resume parity, hybrid_optimizer.py:41-68)."""
+        opt, ddp, lo = self.opt, self.ddp, self.lo
+        for p in self.params:
             o = ddp.offset[id(p)] - lo
             if self.kind == 'adamw':
                 opt.state[p] = dict(step=self.step_t, exp_avg=self.m[o:o + p.numel()].view_as(p),
                                     exp_avg_sq=self.v[o:o + p.numel()].view_as(p))
             else:
                 opt.state[p] = dict(momentum_buffer=self.buf[o:o + p.numel()].view_as(p))
+
+    @torch.no_grad()
+    def adopt_loaded_state(self):
+        """After optimizer.load_state_dict (which replaces the per-parameter state tensors by
+        copies of the checkpoint's): copy them into the flat state the kernels walk and publish the
+        views again.  Parameters without loaded state (never stepped) keep zeros."""
+        lo, steps = self.lo, []
+        for p in self.params:
+            st = self.opt.state.get(p, None)
+            if not st:
+                continue
+            o = self.ddp.offset[id(p)] - lo
+            if self.kind == 'adamw':
+                self.m[o:o + p.numel()].copy_(st['exp_avg'].reshape(-1))
+                self.v[o:o + p.numel()].copy_(st['exp_avg_sq'].reshape(-1))
+                steps.append(int(st['step']))
+            elif st.get('momentum_buffer', None) is not None:
+                self.buf[o:o + p.numel()].copy_(st['momentum_buffer'].reshape(-1))
+                steps.append(1)           # momentum buffer exists: not the first step any more
+        if steps:
+            assert len(set(steps)) == 1, 'parameters of one fused range must share the step count'
+            self.t = steps[0]
+            self.step_t.fill_(self.t)
+        self._publish()
 
     @staticmethod
     def try_build(opt, ddp):

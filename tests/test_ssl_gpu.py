@@ -127,6 +127,35 @@ def test_fused_optimizer_matches_torch(dev):
             assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-6), (it, n)
     sd = opt_a.state_dict()     # torch-compatible state view
     assert len(sd['state'][0]) == 4 and 'exp_avg' in sd['state'][0][0] and 'momentum_buffer' in sd['state'][1][0]
+    # resume parity (hybrid_optimizer.py:41-68): a fused optimizer restored from (i) its own and
+    # (ii) a plain torch HybridOptimizer checkpoint continues exactly like the one that never stopped
+    resumed = []
+    for ckpt, fuse_first in ((copy.deepcopy(sd), True), (copy.deepcopy(opt_b.state_dict()), False)):
+        c = copy.deepcopy(b)
+        ddp_c = FlatGradDDP(c, broadcast=False)
+        ddp_c.build_param_arena()
+        opt_c = R.build_optimizer(c, cfg)
+        if fuse_first:
+            assert opt_c.enable_fused(ddp_c) == 2
+        opt_c.load_state_dict(ckpt)
+        if not fuse_first:
+            assert opt_c.enable_fused(ddp_c) == 2
+        assert opt_c.num_step_updated == 5
+        resumed.append((c, ddp_c, opt_c))
+    for it in range(2):
+        x = torch.randn(16, 37, device=dev)
+        opt_b.zero_grad()
+        b(x).backward()
+        torch.nn.utils.clip_grad_norm_(list(b.parameters()), 1.0)
+        opt_b.step()
+        for c, ddp_c, opt_c in resumed:
+            ddp_c.zero_grad()
+            c(x).backward()
+            ddp_c.finish()
+            _, opt_c.grad_scale = ddp_c.clip_coef(max_norm=1.0)
+            opt_c.step()
+            for (n, pc), pb in zip(c.named_parameters(), b.parameters()):
+                assert torch.allclose(pc, pb, rtol=2e-5, atol=2e-6), (it, n)
 
 
 def test_early_backward_and_prefetch_do_not_change_gradients(dev):
