@@ -252,6 +252,58 @@ def confthr_pvrcnn_ssl_cfg():
             dict(type='NumPreds', bboxes_key=T3 + '_stu_aug', out_name='tea')])
 
 
+def confthr_frcnn_ssl_cfg(class_names=CLASS_NAMES, with_vis=True):
+    """ssl_cfg of configs/detmatch/001/confthr_frcnn/split_0.py: 2D-only confidence thresholding
+    (teacher Faster R-CNN boxes above 0.7 become hard pseudo labels of the student)."""
+    T2 = 'tea.2d_bboxes_nms'
+    unl = [
+        dict(type='SimpleTest_2D', ssl_obj_attr='teacher.detector_2d', batch_dict_key='tea',
+             out_bboxes_key='2d_bboxes'),
+        dict(type='BboxesNMS_2D', nms_cfg=dict(nms_pre=-1, score_thr=0.7, max_num=100, iou_thr=0.5),
+             cls_includes_bg_pred=True, batch_dict_key='tea', in_bboxes_key='2d_bboxes',
+             out_bboxes_key='2d_bboxes_nms'),
+        _xf('2D', True, 'tea.img_metas', T2, T2 + '_no_aug'),
+        _xf('2D', False, 'stu.img_metas', T2 + '_no_aug', T2 + '_stu_aug'),
+        dict(type='DetachBboxes', in_bboxes_key=T2 + '_stu_aug', out_bboxes_key=T2 + '_stu_aug_dtch'),
+        dict(type='HardPseudoLabel_2D', score_thr=0.7, cls_includes_bg_pred=True,
+             loss_detach_keys=['loss_rpn_bbox', 'loss_bbox'], ssl_obj_attr='student.detector_2d',
+             target_bboxes_key=T2 + '_stu_aug_dtch', target_img_key='stu.img',
+             target_img_metas_key='stu.img_metas', name='hard_pseudo_2d', weight=1),
+        dict(type='MaxScoreFilter', cls_includes_bg_pred=True, score_thr=0.7,
+             in_bboxes_key=T2 + '_stu_aug_dtch', out_bboxes_key=T2 + '_stu_aug_dtch_filt'),
+        dict(type='NumPreds', bboxes_key=T2 + '_stu_aug_dtch_filt', out_name='num_tea'),
+    ]
+    if with_vis:
+        unl.append(dict(type='Vis2D_Kitti', class_names=class_names, batch_dict_key='stu',
+                        tea_bboxes_key=T2 + '_stu_aug_dtch_filt', stu_bboxes_key=None,
+                        vis_idxs='data/kitti/ssl_splits/kitti_infos_train_unlab_0.01_0.pkl',
+                        vis_idxs_interval=50, out_name_prefix='Vis_2D_Tea'))
+    return dict(labeled=[dict(type='TwoStageSupervised_2D', loss_detach_keys=[],
+                              ssl_obj_attr='student.detector_2d', batch_dict_key='stu')],
+                unlabeled=unl)
+
+
+def pretrain_pvrcnn_schedule(batch_size=8, max_epochs=40):
+    """configs/detmatch/001/pretrain_pvrcnn/split_0.py:320-336 (supervised PV-RCNN pre-training)."""
+    return dict(
+        optimizer=dict(type='AdamW', lr=0.001 / 2 * batch_size, betas=(0.9, 0.99), weight_decay=0.01),
+        optimizer_config=dict(grad_clip=dict(max_norm=10, norm_type=2)),
+        lr_config=dict(policy='cyclic', target_ratio=(10, 1e-4), cyclic_times=1, step_ratio_up=0.4),
+        momentum_config=dict(policy='cyclic', target_ratio=(0.85 / 0.95, 1), cyclic_times=1,
+                             step_ratio_up=0.4),
+        runner=dict(type='EpochBasedRunner', max_epochs=max_epochs))
+
+
+def pretrain_frcnn_schedule(batch_size=8, max_epochs=12):
+    """configs/detmatch/001/pretrain_frcnn/split_0.py:185-195 (supervised Faster R-CNN pre-training)."""
+    return dict(
+        optimizer=dict(type='SGD', lr=0.02 / 2 * batch_size, momentum=0.9, weight_decay=0.0001),
+        optimizer_config=dict(grad_clip=None),
+        lr_config=dict(policy='step', warmup='linear', warmup_iters=500, warmup_ratio=0.001,
+                       step=[8, 10]),
+        runner=dict(type='EpochBasedRunner', max_epochs=max_epochs))
+
+
 def _pcdet_3d_train_cfg():
     """train_cfg.student.detector_3d of split_0.py:480-504 (mm3d-style; unused by OpenPCDetDetector)."""
     n3 = lambda pos, neg: _max_iou(pos, neg, neg, nearest3d=True)

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from ..devconst import const
+from ..mm3d.base_detector import DetectorStepMixin
 from ..mm3d.losses import bbox_overlaps
 from ..mm3d.registry import DETECTORS, LOSSES, build_from_cfg
 from ..roi_align import roi_align_fpn
@@ -395,7 +396,7 @@ class StandardRoIHead(nn.Module):
 
 # ------------------------------------------------------------------ detector
 @DETECTORS.register_module()
-class FasterRCNN(nn.Module):
+class FasterRCNN(DetectorStepMixin, nn.Module):
 
     def __init__(self, backbone, neck, rpn_head, roi_head, train_cfg=None, test_cfg=None,
                  pretrained=None, init_cfg=None):

@@ -15,6 +15,7 @@ from torch.nn import functional as F
 from .. import voxel
 from ..pcdet.config import ConfigDict
 from ..pcdet.detector import build_network
+from .base_detector import DetectorStepMixin
 from .box3d import LiDARInstance3DBoxes, limit_period
 from .registry import DETECTORS
 
@@ -58,7 +59,7 @@ def pcdet_to_mm3d_boxes(pred_boxes):
 
 
 @DETECTORS.register_module()
-class OpenPCDetDetector(nn.Module):
+class OpenPCDetDetector(DetectorStepMixin, nn.Module):
 
     def __init__(self, dataset_fields, voxel_layer, pcdet_model, train_cfg=None, test_cfg=None,
                  pretrained=None):

@@ -7,6 +7,7 @@ mmcv's IterBasedRunner / hook machinery (un-vendored, mmcv-full 1.3.16) is resta
 as the training iteration needs it: parity unpinned for the mmcv parts.
 """
 import copy
+import math
 import time
 
 import torch
@@ -334,6 +335,7 @@ class StepLrUpdaterHook(Hook):
         self.step = [step] if isinstance(step, int) else list(step)
         self.gamma = gamma
         self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
+        self.by_epoch = by_epoch       # `step` counts epochs (pretrain_frcnn: step=[8, 10]); warm-up stays per iteration
         self.base_lr = None
 
     def before_run(self, runner):
@@ -341,8 +343,9 @@ class StepLrUpdaterHook(Hook):
             g.setdefault('initial_lr', g['lr'])
         self.base_lr = [g['initial_lr'] for g in runner.optimizer.param_groups]
 
-    def get_lr(self, it):
-        exp = sum(1 for s in self.step if it >= s)
+    def get_lr(self, it, epoch=0):
+        progress = epoch if self.by_epoch else it
+        exp = sum(1 for s in self.step if progress >= s)
         regular = [lr * self.gamma ** exp for lr in self.base_lr]
         if self.warmup is None or it >= self.warmup_iters:
             return regular
@@ -357,8 +360,83 @@ class StepLrUpdaterHook(Hook):
         raise ValueError(self.warmup)
 
     def before_train_iter(self, runner):
-        for g, lr in zip(runner.optimizer.param_groups, self.get_lr(runner.iter)):
+        for g, lr in zip(runner.optimizer.param_groups, self.get_lr(runner.iter, runner.epoch)):
             g['lr'] = lr
+
+
+def annealing_cos(start, end, factor, weight=1):
+    """mmcv.runner.hooks.lr_updater.annealing_cos"""
+    return end + 0.5 * weight * (start - end) * (math.cos(math.pi * factor) + 1)
+
+
+class _CyclicHook(Hook):
+    """mmcv Cyclic{Lr,Momentum}UpdaterHook (1.3.16, by_epoch=False, anneal 'cos'; un-vendored: parity
+    unpinned): per cycle of max_iters // cyclic_times iterations the value goes base ->
+    base*target_ratio[0] over the first step_ratio_up of the cycle, then -> base*target_ratio[1]."""
+
+    def __init__(self, by_epoch=False, target_ratio=(10, 1e-4), cyclic_times=1, step_ratio_up=0.4,
+                 anneal_strategy='cos', **kwargs):
+        assert not by_epoch, 'currently only support "by_epoch" = False'
+        if isinstance(target_ratio, (int, float)):
+            target_ratio = (target_ratio, target_ratio / 1e5)
+        assert len(target_ratio) == 2 and 0 <= step_ratio_up < 1.0
+        assert anneal_strategy == 'cos'
+        self.target_ratio, self.cyclic_times, self.step_ratio_up = tuple(target_ratio), cyclic_times, step_ratio_up
+        self.phases = []
+        self.base = None
+
+    def before_run(self, runner):
+        per = runner.max_iters // self.cyclic_times
+        up = int(self.step_ratio_up * per)
+        self.phases = [(0, up, per, 1, self.target_ratio[0]),
+                       (up, per, per, self.target_ratio[0], self.target_ratio[1])]
+
+    def value(self, it, base):
+        for start, end, per, r0, r1 in self.phases:
+            it %= per
+            if start <= it < end:
+                return annealing_cos(base * r0, base * r1, (it - start) / (end - start))
+        return base
+
+
+@HOOKS.register_module()
+class CyclicLrUpdaterHook(_CyclicHook):
+
+    def before_run(self, runner):
+        super().before_run(runner)
+        for g in runner.optimizer.param_groups:
+            g.setdefault('initial_lr', g['lr'])
+        self.base = [g['initial_lr'] for g in runner.optimizer.param_groups]
+
+    def before_train_iter(self, runner):
+        for g, b in zip(runner.optimizer.param_groups, self.base):
+            g['lr'] = self.value(runner.iter, b)
+
+
+@HOOKS.register_module()
+class CyclicMomentumUpdaterHook(_CyclicHook):
+    """target_ratio default (0.85/0.95, 1); drives `momentum` (SGD) or betas[0] (Adam family)."""
+
+    def __init__(self, target_ratio=(0.85 / 0.95, 1), **kwargs):
+        super().__init__(target_ratio=target_ratio, **kwargs)
+
+    def before_run(self, runner):
+        super().before_run(runner)
+        self.base = []
+        for g in runner.optimizer.param_groups:
+            if 'momentum' in g:
+                g.setdefault('initial_momentum', g['momentum'])
+            else:
+                g.setdefault('initial_momentum', g['betas'][0])
+            self.base.append(g['initial_momentum'])
+
+    def before_train_iter(self, runner):
+        for g, b in zip(runner.optimizer.param_groups, self.base):
+            m = self.value(runner.iter, b)
+            if 'momentum' in g:
+                g['momentum'] = m
+            else:
+                g['betas'] = (m, g['betas'][1])
 
 
 class _PassThroughHook(Hook):
@@ -398,11 +476,7 @@ class IterLoader(object):
         return len(self._dataloader)
 
 
-@RUNNERS.register_module()
-class IterBasedSSLRunner(object):
-    """iter_based_ssl_runner.py:11-110: one labeled + one unlabeled batch per iteration, keys
-    prefixed 'lab_' / 'unlab_'; data_batch['img_metas'] is the labeled metas (only used for
-    num_samples)."""
+class _RunnerBase(object):
 
     def __init__(self, model, optimizer=None, max_iters=None, work_dir=None, logger=None,
                  meta=None, batch_processor=None, **kwargs):
@@ -429,14 +503,24 @@ class IterBasedSSLRunner(object):
             hook = build_from_cfg(hook, HOOKS)
         self._hooks.append(hook)
 
-    def register_training_hooks(self, lr_config=None, optimizer_config=None, custom_hooks=None):
-        """Order = mmcv priorities for this set: LR (VERY_HIGH) < optimizer (ABOVE_NORMAL)
-        < custom (NORMAL)."""
+    def register_training_hooks(self, lr_config=None, optimizer_config=None, custom_hooks=None,
+                                momentum_config=None, **ignored):
+        """Order = mmcv priorities for this set: LR (VERY_HIGH) < momentum (HIGH) < optimizer
+        (ABOVE_NORMAL) < custom (NORMAL).  checkpoint / log / evaluation configs are outside the
+        step and ignored here."""
         if lr_config is not None:
             cfg = dict(lr_config)
             policy = cfg.pop('policy', 'step')
-            assert policy == 'step', 'only the step policy is on the DetMatch path'
-            self.register_hook(StepLrUpdaterHook(**cfg))
+            assert policy in ('step', 'cyclic'), 'policies of the DetMatch recipes: step, cyclic'
+            if policy == 'step':
+                cfg.setdefault('by_epoch', isinstance(self, EpochBasedRunner))     # mmcv default: by_epoch=True
+                self.register_hook(StepLrUpdaterHook(**cfg))
+            else:
+                self.register_hook(CyclicLrUpdaterHook(**cfg))
+        if momentum_config is not None:
+            cfg = dict(momentum_config)
+            assert cfg.pop('policy') == 'cyclic'
+            self.register_hook(CyclicMomentumUpdaterHook(**cfg))
         if optimizer_config is not None:
             self.register_hook(OptimizerHook(**dict(optimizer_config)))
         for h in (custom_hooks or []):
@@ -445,6 +529,69 @@ class IterBasedSSLRunner(object):
     def call_hook(self, name):
         for h in self._hooks:
             getattr(h, name, lambda r: None)(self)
+
+    def _after_step(self, outputs):
+        if not isinstance(outputs, dict):
+            raise TypeError('model.train_step() must return a dict')
+        if 'log_vars' in outputs:
+            for k, v in outputs['log_vars'].items():
+                self.log_buffer.setdefault(k, []).append(v)
+        self.outputs = outputs
+
+
+@RUNNERS.register_module()
+class EpochBasedRunner(_RunnerBase):
+    """mmcv EpochBasedRunner (1.3.16; the pre-training recipes pretrain_pvrcnn / pretrain_frcnn):
+    run(data_loaders, workflow) sets max_iters = max_epochs * len(loader) and trains epoch by epoch,
+    one model.train_step per batch."""
+
+    def __init__(self, model, optimizer=None, max_epochs=None, max_iters=None, **kwargs):
+        super().__init__(model, optimizer=optimizer, max_iters=max_iters, **kwargs)
+        self._max_epochs = max_epochs
+
+    max_epochs = property(lambda self: self._max_epochs)
+
+    def train(self, data_loader, **kwargs):
+        self.model.train()
+        self.mode = 'train'
+        self.data_loader = data_loader
+        self._max_iters = self._max_epochs * len(data_loader)
+        self.call_hook('before_epoch')
+        for i, data_batch in enumerate(data_loader):
+            self._inner_iter = i
+            self.call_hook('before_train_iter')
+            self._after_step(self.model.train_step(data_batch, self.optimizer, **kwargs))
+            self.call_hook('after_train_iter')
+            self._iter += 1
+        self.call_hook('after_train_epoch')
+        self.call_hook('after_epoch')
+        self._epoch += 1
+
+    def run(self, data_loaders, workflow=(('train', 1),), max_epochs=None, **kwargs):
+        assert isinstance(data_loaders, list) and len(data_loaders) == len(workflow)
+        if max_epochs is not None:
+            self._max_epochs = max_epochs
+        assert self._max_epochs is not None, 'max_epochs must be specified during instantiation'
+        for i, (mode, epochs) in enumerate(workflow):
+            if mode == 'train':
+                self._max_iters = self._max_epochs * len(data_loaders[i])
+                break
+        self.call_hook('before_run')
+        while self.epoch < self._max_epochs:
+            for i, (mode, epochs) in enumerate(workflow):
+                assert mode == 'train', 'only the train workflow is on the DetMatch path'
+                for _ in range(epochs):
+                    if self.epoch >= self._max_epochs:
+                        break
+                    self.train(data_loaders[i], **kwargs)
+        self.call_hook('after_run')
+
+
+@RUNNERS.register_module()
+class IterBasedSSLRunner(_RunnerBase):
+    """iter_based_ssl_runner.py:11-110: one labeled + one unlabeled batch per iteration, keys
+    prefixed 'lab_' / 'unlab_'; data_batch['img_metas'] is the labeled metas (only used for
+    num_samples)."""
 
     def train(self, lab_data_loader, unlab_data_loader, **kwargs):
         self.model.train()
@@ -456,13 +603,7 @@ class IterBasedSSLRunner(object):
         data_batch.update({'unlab_%s' % k: v for k, v in unlab.items()})
         data_batch['img_metas'] = lab['img_metas']
         self.call_hook('before_train_iter')
-        outputs = self.model.train_step(data_batch, self.optimizer, **kwargs)
-        if not isinstance(outputs, dict):
-            raise TypeError('model.train_step() must return a dict')
-        if 'log_vars' in outputs:
-            for k, v in outputs['log_vars'].items():
-                self.log_buffer.setdefault(k, []).append(v)
-        self.outputs = outputs
+        self._after_step(self.model.train_step(data_batch, self.optimizer, **kwargs))
         self.call_hook('after_train_iter')
         self._inner_iter += 1
         self._iter += 1

@@ -544,3 +544,8 @@ class Vis3D(object):
 
     def forward(self, ssl_obj, batch_dict):
         return batch_dict
+
+
+@SSL_MODULES.register_module()
+class Vis2D_Kitti(Vis3D):
+    """consumers/visualize.py (2D variant, confthr_frcnn recipe): pass-through, as Vis3D."""

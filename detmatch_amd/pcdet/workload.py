@@ -208,7 +208,7 @@ class DetMatchTrainWorkload(object):
                  matching, hard pseudo-label training of both students, 2D<->3D box consistency;
       teacher EMA (fused, flat arenas), backward, gradient exchange, clip (L2 10), HybridOptimizer
       (AdamW 3D / SGD 2D), linear LR warm-up — driven by IterBasedSSLRunner exactly as
-      mmdet3d/apis/ssl_train.py would.  `ssl_cfg='confthr_pvrcnn'` selects the 3D-only recipe."""
+      mmdet3d/apis/ssl_train.py would.  `ssl_cfg='confthr_pvrcnn'` / `'confthr_frcnn'` select the 3D-only / 2D-only recipes."""
 
     def __init__(self, batch_size, device, seed=0, ssl_cfg=None):
         from .. import configs
@@ -220,8 +220,9 @@ class DetMatchTrainWorkload(object):
         self.tuned_miopen = detmatch_amd.enable_tuned_miopen()
         self.batch_size, self.device = batch_size, device
         self.recipe = ssl_cfg or 'detmatch'
-        chain = configs.confthr_pvrcnn_ssl_cfg() if ssl_cfg == 'confthr_pvrcnn' else \
-            configs.detmatch_ssl_cfg(with_vis=False)
+        chain = {'confthr_pvrcnn': configs.confthr_pvrcnn_ssl_cfg,
+                 'confthr_frcnn': lambda: configs.confthr_frcnn_ssl_cfg(with_vis=False),
+                 'detmatch': lambda: configs.detmatch_ssl_cfg(with_vis=False)}[self.recipe]()
         cfg = configs.detmatch_kitti_model(ssl_cfg=chain)
         cfg.pop('type')
         torch.manual_seed(0)
@@ -274,3 +275,43 @@ class DetMatchTrainWorkload(object):
     @property
     def last_log(self):
         return self.runner.outputs['log_vars']
+
+
+class PretrainWorkload(object):
+    """The supervised pre-training recipes of configs/detmatch/001 driven as
+    mmdet3d/apis/train.py would: one stand-alone detector, its `train_step`, EpochBasedRunner with the
+    recipe's optimizer / clip / LR (+momentum) schedule, gradients through the flat arena.
+      recipe='pretrain_pvrcnn'  OpenPCDetDetector (PV-RCNN), AdamW, cyclic LR + momentum, clip 10
+      recipe='pretrain_frcnn'   FasterRCNN R50-caffe-FPN (focal sigmoid head), SGD, step LR, no clip"""
+
+    def __init__(self, batch_size, device, recipe='pretrain_pvrcnn', seed=0, iters_per_epoch=4, max_epochs=2):
+        from .. import configs
+        from ..mm3d import register_all
+        from ..mm3d import runner as R
+        from ..mm3d.registry import build_detector
+        register_all()
+        import detmatch_amd
+        detmatch_amd.enable_tuned_miopen()
+        self.recipe, self.batch_size = recipe, batch_size
+        data = synth.ssl_batch(batch_size, seed, device, with_img=recipe == 'pretrain_frcnn')['lab_stu']
+        torch.manual_seed(0)
+        if recipe == 'pretrain_pvrcnn':
+            self.model = build_detector(configs.pvrcnn_kitti_model()).to(device)
+            batch = {k: data[k] for k in ('points', 'img_metas', 'gt_bboxes_3d', 'gt_labels_3d')}
+            sched = configs.pretrain_pvrcnn_schedule(batch_size, max_epochs)
+        else:
+            cfg = configs.frcnn_kitti_model()
+            cfg.update(train_cfg=configs.frcnn_train_cfg(), test_cfg=configs.frcnn_test_cfg())
+            self.model = build_detector(cfg).to(device)
+            batch = {k: data[k] for k in ('img', 'img_metas', 'gt_bboxes', 'gt_labels')}
+            sched = configs.pretrain_frcnn_schedule(batch_size, max_epochs)
+        self.loader = [batch] * iters_per_epoch
+        self.ddp = FlatGradDDP(self.model, broadcast=False)
+        self.opt = R.build_optimizer(self.model, sched['optimizer'])
+        self.runner = R.build_from_cfg(dict(sched['runner'], model=self.ddp, optimizer=self.opt), R.RUNNERS)
+        self.runner.register_training_hooks(sched['lr_config'], sched['optimizer_config'],
+                                            momentum_config=sched.get('momentum_config'))
+
+    def run(self):
+        self.runner.run([self.loader], [('train', 1)])
+        return self.runner.outputs['loss']

@@ -38,6 +38,24 @@ def test_confthr_builder_equals_reference_config():
 
 
 @needs_ref
+def test_confthr_frcnn_and_pretrain_builders_equal_reference_configs():
+    """the other recipes of configs/detmatch/001 on the same kernels."""
+    cfg = Config.fromfile(os.path.join(REF, 'confthr_frcnn/split_0.py'))
+    assert _plain(configs.confthr_frcnn_ssl_cfg()) == _plain(cfg['model']['ssl_cfg'])
+    ref_model = _plain(cfg['model'])
+    mine = _plain(configs.detmatch_kitti_model(ssl_cfg=configs.confthr_frcnn_ssl_cfg(),
+                                               pretrained=ref_model['pretrained']))
+    assert mine == ref_model
+    cfg = Config.fromfile(os.path.join(REF, 'pretrain_pvrcnn/split_0.py'))
+    assert _plain(configs.pvrcnn_kitti_model()) == _plain(cfg['model'])
+    for k, v in configs.pretrain_pvrcnn_schedule(batch_size=cfg['batch_size']).items():
+        assert _plain(v) == _plain(cfg[k]), k
+    cfg = Config.fromfile(os.path.join(REF, 'pretrain_frcnn/split_0.py'))
+    for k, v in configs.pretrain_frcnn_schedule(batch_size=cfg['batch_size']).items():
+        assert _plain(v) == _plain(cfg[k]), k
+
+
+@needs_ref
 def test_reference_config_types_resolve():
     """Every `type` named inside model / optimizer / runner / hooks resolves to a registered class."""
     import detmatch_amd.mm2d  # noqa: F401

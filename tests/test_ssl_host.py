@@ -303,3 +303,70 @@ def test_checkpoint_key_layout_and_pretrained_loading():
     model.load_state_dict(full)
     after = model.state_dict()
     assert float(after['teacher.' + k].mean()) == 0.5 and float(after['student.' + k].mean()) == 0.75
+
+
+def test_epoch_based_runner_cyclic_and_step_schedules():
+    """The pre-training recipes' driver (configs/detmatch/001/pretrain_pvrcnn, pretrain_frcnn):
+    EpochBasedRunner + cyclic LR / momentum (mmcv formulas restated; closed-form check) and the
+    by-epoch step policy with per-iteration linear warm-up."""
+    from detmatch_amd import configs
+    from detmatch_amd.mm3d.base_detector import DetectorStepMixin
+
+    class Det(DetectorStepMixin, nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = nn.Linear(3, 2)
+
+        def forward_train(self, x, img_metas):
+            return dict(loss_a=self.fc(x).square().mean(), acc=torch.tensor(1.0), loss_list=[self.fc(x).abs().sum()])
+
+    torch.manual_seed(0)
+    loader = [dict(x=torch.randn(4, 3), img_metas=[0, 1, 2, 3]) for _ in range(5)]
+    # ---- pretrain_pvrcnn: AdamW, cyclic lr (x10 up over 40 %, down to x1e-4) and momentum
+    sched = configs.pretrain_pvrcnn_schedule(batch_size=8, max_epochs=4)
+    model = Det()
+    opt = R.build_optimizer(model, sched['optimizer'])
+    run = R.build_from_cfg(dict(sched['runner'], model=model, optimizer=opt), R.RUNNERS)
+    assert isinstance(run, R.EpochBasedRunner)
+    run.register_training_hooks(sched['lr_config'], sched['optimizer_config'],
+                                momentum_config=sched['momentum_config'])
+    seen = []
+
+    class Spy(R.Hook):
+        def after_train_iter(self, runner):
+            g = runner.optimizer.param_groups[0]
+            seen.append((g['lr'], g['betas'][0] if 'betas' in g else g['momentum']))
+    run.register_hook(Spy())
+    w0 = model.fc.weight.detach().clone()
+    run.run([loader], [('train', 1)])
+    assert run.epoch == 4 and run.iter == 20 and run.max_iters == 20
+    assert not torch.equal(w0, model.fc.weight) and len(run.log_buffer['loss']) == 20
+    base, up = 0.004, 8
+    cos = lambda a, b, f: b + 0.5 * (a - b) * (math.cos(math.pi * f) + 1)
+    for it, (lr, mom) in enumerate(seen):
+        if it < up:
+            assert lr == pytest.approx(cos(base, base * 10, it / up))
+            assert mom == pytest.approx(cos(0.9, 0.9 * 0.85 / 0.95, it / up))
+        else:
+            assert lr == pytest.approx(cos(base * 10, base * 1e-4, (it - up) / (20 - up)))
+            assert mom == pytest.approx(cos(0.9 * 0.85 / 0.95, 0.9, (it - up) / (20 - up)))
+    assert seen[0][0] == pytest.approx(base) and max(s[0] for s in seen) == pytest.approx(10 * base)
+    # ---- pretrain_frcnn: SGD, step [8, 10] counted in EPOCHS, linear warm-up counted in iterations
+    sched = configs.pretrain_frcnn_schedule(batch_size=8, max_epochs=12)
+    sched['lr_config'].update(warmup_iters=7)
+    model = Det()
+    opt = R.build_optimizer(model, sched['optimizer'])
+    run = R.EpochBasedRunner(model, optimizer=opt, max_epochs=12)
+    run.register_training_hooks(sched['lr_config'], sched['optimizer_config'])
+    seen.clear()
+    run.register_hook(Spy())
+    run.run([loader], [('train', 1)])
+    assert run.iter == 60 and 'grad_norm' not in run.log_buffer            # grad_clip=None
+    for it, (lr, _) in enumerate(seen):
+        regular = 0.08 * 0.1 ** sum(it // 5 >= s for s in (8, 10))
+        warm = 1 - (1 - it / 7) * (1 - 0.001) if it < 7 else 1.0
+        assert lr == pytest.approx(regular * warm), it
+    # stand-alone detector interface: loss = sum of the 'loss' keys, lists summed, metrics excluded
+    out = model.train_step(loader[0])
+    assert out['num_samples'] == 4 and set(out['log_vars']) == {'loss_a', 'acc', 'loss_list', 'loss'}
+    assert float(out['log_vars']['loss']) == pytest.approx(float(out['log_vars']['loss_a'] + out['log_vars']['loss_list']))
