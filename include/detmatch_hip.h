@@ -309,6 +309,28 @@ int dm_sgd_step_f32(float *params, const float *grads, float *momentum_buf, size
 int dm_lap_host(const float *cost_host, int n_rows, int n_cols, int *row_ind_host,
                 int *col_ind_host);
 
+/* Fused 3D augmentation of a batch of point clouds (the point part of the
+ * TS_SSL_Dataset pipelines).  Replaces, per view (= one sample as the student or the teacher pipeline
+ * sees it), RandomFlip3D (mmdet3d/datasets/pipelines/transforms_3d.py:102-127 ->
+ * core/points/lidar_points.py:28-33), GlobalRotScaleTrans (:566-690 -> base_points.py:139-205,263-269),
+ * PointsRangeFilter (:783-797 -> base_points.py:207-229) and PointShuffle (:695-712 ->
+ * base_points.py:129-137).
+ *   points   device (*, n_feat) f32 rows [x, y, z, ...]; view v reads rows src_off[v] .. +src_len[v]
+ *            (views may share a source segment); src_off / src_len / dst_off are HOST arrays
+ *   params   device (n_views, DM_AUG_PARAMS) f32: [0] horizontal flip (y -> -y) != 0, [1] vertical flip,
+ *            [2..10] M row-major with p' = p @ M (the recorded `pcd_rotation`), [11] scale,
+ *            [12..14] translation, [15..20] range x/y/z min then max (strict), rest unused
+ *   perm     device int32 or NULL: slot j of view v reads source row perm[dst_off[v] + j] (local index)
+ *   out      device rows; view v's kept rows, in slot order, start at row dst_off[v]
+ *   out_counts device (n_views) int32: kept rows per view (the caller decides when to read them) */
+#define DM_AUG_MAX_VIEWS 128
+#define DM_AUG_PARAMS 24
+size_t dm_points_augment_workspace_bytes(int n_views, const int *src_len_host);
+int dm_points_augment(const float *points, int n_feat, int n_views, const int *src_off_host,
+                      const int *src_len_host, const int *dst_off_host, const float *params,
+                      const int *perm, float *out, int *out_counts, void *workspace,
+                      size_t workspace_bytes, dm_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* D. Stacked PointNet++ operators, points-in-boxes                           */
 /* ------------------------------------------------------------------------ */

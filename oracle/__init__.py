@@ -257,3 +257,18 @@ def roi_align_grad(grad_out, feat_shape, rois, spatial_scale, sampling_ratio=0, 
                                  ctypes.c_float(spatial_scale), ph, pw, sampling_ratio, int(aligned),
                                  g.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     return g
+
+
+def points_augment(points, params, perm=None):
+    """One view of dm_points_augment: points (N,C) f32, params (24,) f32 -> kept rows (M,C)."""
+    points, params = _f32(points), _f32(params)
+    n, c = points.shape
+    out = np.zeros((n, c), np.float32)
+    pp = None
+    if perm is not None:
+        perm = np.ascontiguousarray(perm, dtype=np.int32)
+        pp = perm.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    L = lib()
+    L.orc_points_augment.restype = ctypes.c_int
+    kept = L.orc_points_augment(_p(points, _f32p), n, c, _p(params, _f32p), pp, _p(out, _f32p))
+    return out[:kept]

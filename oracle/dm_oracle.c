@@ -789,3 +789,36 @@ void orc_roi_align_backward(const float *grad_out, int c, int h, int w, const fl
   orc_roi_align_impl(NULL, grad_out, grad_feat, c, h, w, rois, r, spatial_scale, ph, pw,
                      sampling_ratio, aligned, NULL);
 }
+
+
+/* ---- 3D augmentation of one view (transforms_3d.py RandomFlip3D / GlobalRotScaleTrans /
+ * PointsRangeFilter on LiDARPoints: lidar_points.py:28-33, base_points.py:139-229,263-269) ---- */
+int orc_points_augment(const float *points, int n, int n_feat, const float *P,
+                       const int32_t *perm, float *out) {
+  int kept = 0;
+  for (int j = 0; j < n; ++j) {
+    const float *row = points + (size_t)(perm ? perm[j] : j) * n_feat;
+    float x = row[0], y = row[1], z = row[2];
+    if (P[0] != 0.f) y = -y;
+    if (P[1] != 0.f) x = -x;
+    float rx = x * P[2];
+    rx = fmaf(y, P[5], rx);
+    rx = fmaf(z, P[8], rx);
+    float ry = x * P[3];
+    ry = fmaf(y, P[6], ry);
+    ry = fmaf(z, P[9], ry);
+    float rz = x * P[4];
+    rz = fmaf(y, P[7], rz);
+    rz = fmaf(z, P[10], rz);
+    x = rx * P[11] + P[12];      /* -ffp-contract=off: product and sum round separately */
+    y = ry * P[11] + P[13];
+    z = rz * P[11] + P[14];
+    if (x > P[15] && y > P[16] && z > P[17] && x < P[18] && y < P[19] && z < P[20]) {
+      float *dst = out + (size_t)kept * n_feat;
+      dst[0] = x, dst[1] = y, dst[2] = z;
+      for (int c = 3; c < n_feat; ++c) dst[c] = row[c];
+      ++kept;
+    }
+  }
+  return kept;
+}

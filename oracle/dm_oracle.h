@@ -106,6 +106,14 @@ void orc_roi_align_backward(const float *grad_out, int c, int h, int w, const fl
                             float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
                             double *grad_feat);
 
+/* 3D augmentation of one view of a point cloud, the reference's host chain restated:
+ * lidar_points.py:28-33 (flip), base_points.py:139-179 (rotate: p @ M, k-ordered fused multiply-adds as
+ * the BLAS behind torch's (N,3)@(3,3)), :263-269 (scale), :186-205 (translate), :207-229 (in_range_3d,
+ * strict), then the rows are kept in slot order; slot j reads source row perm[j] (or j).
+ * params: 24 floats, layout of include/detmatch_hip.h dm_points_augment.  Returns the kept count. */
+int orc_points_augment(const float *points, int n, int n_feat, const float *params,
+                       const int32_t *perm, float *out);
+
 #ifdef __cplusplus
 }
 #endif
