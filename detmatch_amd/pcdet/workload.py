@@ -230,7 +230,8 @@ class DetMatchTrainWorkload(object):
         # teacher starts as a copy of the student (SSL._load_from_state_dict fan-out, ssl.py:102-127)
         self.model.teacher.load_state_dict(self.model.student.state_dict())
         with_img = True
-        data = synth.ssl_batch(batch_size, seed, device, with_img)
+        data = synth.ssl_batch(batch_size, seed, device, with_img,
+                               device_pipeline=os.environ.get('DM_DEVICE_PIPELINE', '0') == '1')
         lab = dict(stu=data['lab_stu'], tea=data['lab_tea'], img_metas=data['img_metas'])
         unlab = dict(stu=data['unlab_stu'], tea=data['unlab_tea'], img_metas=data['img_metas'])
         self.lab_iter = iter(_RepeatLoader(lab))

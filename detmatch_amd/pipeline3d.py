@@ -51,6 +51,31 @@ class View3D(object):
         v.meta = {k: (list(x) if isinstance(x, list) else x) for k, x in self.meta.items()}
         return v
 
+    @classmethod
+    def from_meta(cls, meta, source=0, point_cloud_range=None, shuffle=False):
+        """Replay a recorded img_meta (the keys apply_3d_transformation consumes,
+        mmdet3d/models/ssl_modules/bbox_utils.py:135-160) on raw points: flow entries 'HF' / 'VF' /
+        'R' / 'S' / 'T' must appear in the fused order."""
+        v = cls(source)
+        v.meta = dict(meta)
+        stage = {'HF': 1, 'VF': 1, 'R': 2, 'S': 2, 'T': 2}
+        for op in meta.get('transformation_3d_flow', []):
+            v._advance(stage[op], op)
+            if op == 'HF':
+                v.flip_h = bool(meta['pcd_horizontal_flip'])
+            elif op == 'VF':
+                v.flip_v = bool(meta['pcd_vertical_flip'])
+            elif op == 'R':
+                v.rot = np.asarray(meta['pcd_rotation'], dtype=np.float32)
+            elif op == 'S':
+                v.scale = float(meta['pcd_scale_factor'])
+            else:
+                v.trans = np.asarray(meta['pcd_trans'], dtype=np.float32)
+        if point_cloud_range is not None:
+            v.range = np.asarray(point_cloud_range, dtype=np.float32)
+        v.shuffle = shuffle
+        return v
+
     def _advance(self, stage, what):
         if stage < self._stage:
             raise ValueError('%s after a later transform: the fused kernel applies flip, rotation, scale, '

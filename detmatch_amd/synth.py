@@ -265,11 +265,32 @@ def _collate(samples):
     return out
 
 
-def ssl_batch(batch_size, seed=0, device='cpu', with_img=True):
+def _device_points(samples, seeds, device, generator=None):
+    """Replace the host-augmented point clouds of `samples` [(stu, tea), ...] by the output of the
+    device pipeline (pipeline3d.augment_points): the raw frames go to HBM once and every student /
+    teacher view replays its recorded img_metas there (flip, rotation, scale, range filter, shuffle)."""
+    import torch
+    from .pipeline3d import View3D, augment_points
+    raw = [torch.from_numpy(lidar_frame(s)['points']).to(device) for s in seeds]
+    views = []
+    for i, (stu, tea) in enumerate(samples):
+        views += [View3D.from_meta(stu['img_metas'], i, KITTI_RANGE, shuffle=True),
+                  View3D.from_meta(tea['img_metas'], i, KITTI_RANGE, shuffle=True)]
+    outs = augment_points(raw, views, generator)
+    for i, (stu, tea) in enumerate(samples):
+        stu['points'], tea['points'] = outs[2 * i], outs[2 * i + 1]
+
+
+def ssl_batch(batch_size, seed=0, device='cpu', with_img=True, device_pipeline=False):
     """The data_batch IterBasedSSLRunner.train assembles (iter_based_ssl_runner.py:21-27): `batch_size`
-    labeled + `batch_size` unlabeled samples, keys lab_stu / lab_tea / unlab_stu / unlab_tea."""
+    labeled + `batch_size` unlabeled samples, keys lab_stu / lab_tea / unlab_stu / unlab_tea.
+    device_pipeline=True: the point clouds are augmented on the GPU (one dm_points_augment call for all
+    4 * batch_size views) instead of in numpy."""
     lab = [ssl_sample(seed + i, True, device, with_img) for i in range(batch_size)]
     unlab = [ssl_sample(seed + 1000 + i, False, device, with_img) for i in range(batch_size)]
+    if device_pipeline:
+        _device_points(lab + unlab, [seed + i for i in range(batch_size)] +
+                       [seed + 1000 + i for i in range(batch_size)], device)
     return dict(lab_stu=_collate([s for s, _ in lab]), lab_tea=_collate([t for _, t in lab]),
                 unlab_stu=_collate([s for s, _ in unlab]), unlab_tea=_collate([t for _, t in unlab]),
                 img_metas=[s['img_metas'] for s, _ in lab])

@@ -109,6 +109,35 @@ def main():
     row('fused AdamW step, 54.2 M params', us, n * 4 * 7)
     us = timed(lambda: _lib.check(L.dm_ema_update_f32(_lib.ptr(p), _lib.ptr(g2), n, 0.999, _lib.stream()), 'ema'))
     row('fused EMA, 54.2 M floats', us, n * 4 * 3)
+    # ---- data pipeline: 8 views (4 frames x student/teacher) in one call -------------
+    import ctypes
+    from detmatch_amd import pipeline3d as P3
+    for tag, reps_pts in (('KITTI', 1), ('Waymo-sized', 10)):
+        raw = [torch.from_numpy(np.tile(synth.lidar_frame(s)['points'], (reps_pts, 1))).to(dev) for s in range(4)]
+        views = []
+        rs = np.random.RandomState(0)
+        for i in range(4):
+            sv, tv = P3.View3D(i), P3.View3D(i)
+            P3.GlobalRotScaleTrans()(sv, rs)
+            for v in (sv, tv):
+                P3.PointsRangeFilter(synth.KITTI_RANGE)(v)
+            views += [sv, tv]
+        flat = torch.cat(raw)
+        lens = [len(r) for r in raw]
+        st = np.concatenate([[0], np.cumsum(lens)])
+        src_off = [int(st[v.source]) for v in views]
+        src_len = [lens[v.source] for v in views]
+        dst_off = np.concatenate([[0], np.cumsum(src_len)])
+        par = torch.from_numpy(np.stack([v.params() for v in views])).to(dev)
+        out = torch.empty((int(dst_off[-1]), 4), device=dev)
+        cnts = torch.empty(8, dtype=torch.int32, device=dev)
+        ws = _lib.workspace(L.dm_points_augment_workspace_bytes(8, _lib.ints(src_len)), dev, 'aug')
+        a = (_lib.ptr(flat), 4, 8, _lib.ints(src_off), _lib.ints(src_len), _lib.ints(dst_off[:-1]), _lib.ptr(par),
+             None, _lib.ptr(out), _lib.ptr(cnts), _lib.ptr(ws), ctypes.c_size_t(ws.numel()))
+        us = timed(lambda: _lib.check(L.dm_points_augment(*a, _lib.stream()), 'aug'))
+        tot = int(dst_off[-1])
+        row('dm_points_augment 8 views, %s (%d slots)' % (tag, tot), us, tot * 16 * 3,
+            '2 launches; rows read twice (count + scatter), written once')
 
 
 if __name__ == '__main__':
