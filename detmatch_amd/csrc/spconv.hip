@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
                                                  const int32_t *__restrict__ perm, int n_out,
                                                  int kvol, int cout_full,
                                                  float *__restrict__ out,
-                                                 unsigned long long *__restrict__ stamps) {
+                                                 unsigned long long *__restrict__ stamps,
+                                                 const int32_t *__restrict__ tile_order) {
   constexpr int NB = COUT / 16;
   constexpr int CT = CIN / 16;
   constexpr int CTS = CT < DM_GR_CTS ? CT : DM_GR_CTS;   // k-chunks of <= 16*DM_GR_CTS input channels per step
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
-  const int row0 = blockIdx.x * 16;
+  const int row0 = (tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x) * 16;
   const int nb_full = cout_full / 16;
   const int nb0 = blockIdx.y * NB;
   unsigned long long st0 = 0, rt0 = 0, st1 = 0;
@@ -441,12 +442,12 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
 
 template <int CIN, int COUT_FULL>
 int launch_gr(const float *feat, const float *wpack, const int32_t *nbr, const int32_t *perm,
-              int n_out, int kvol, float *out, hipStream_t st) {
+              const int32_t *tile_order, int n_out, int kvol, float *out, hipStream_t st) {
   constexpr int COUT = COUT_FULL > 64 ? 64 : COUT_FULL;  // columns per workgroup
   dim3 grid(dm_ceil_div(n_out, 16), COUT_FULL / COUT);
   int pi = dm_prof_begin(st, DM_PROF_SPCONV_GG, CIN, COUT_FULL, 0, n_out, kvol, nbr);
   spconv_gr<CIN, COUT><<<grid, 256, 0, st>>>(feat, wpack, nbr, perm, n_out, kvol, COUT_FULL, out,
-                                             g_debug_stamps);
+                                             g_debug_stamps, tile_order);
   dm_prof_end(pi, st);
   DM_CHECK_LAUNCH();
   return DM_OK;
@@ -564,6 +565,64 @@ extern "C" int dm_spconv_debug_stamps(void *buf) {
   return DM_OK;
 }
 
+// ---- launch order of the 16-row tiles ------------------------------------------------------
+// A gather-GEMM launch fits the chip in about one round of workgroups, so it lasts as long as the
+// compute unit that happened to receive the heaviest tiles (a tile walks 1..kvol active offsets;
+// rocprofv3 SQ counters: 63 % of the wave cycles are issue stalls behind the fp32 MFMA pipe, whose
+// busy time is 14 us per SIMD of a 34 us launch).  Handing the tiles out by descending work lets
+// the dispatcher spread the heavy ones first: -13..17 % per launch on the 32/64-channel layers.
+// The order is a property of the gather table: built once per rulebook (counting sort by active
+// offsets, two tiny launches), reused by every forward / input-gradient launch on that table.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void tile_order_kernel(const int32_t *__restrict__ nbr, int n_rows,
+                                                         int kvol, int n_tiles, int *__restrict__ hist,
+                                                         int32_t *__restrict__ order) {
+  const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;
+  const int row = tile * 16 + r;
+  unsigned int active = 0u;
+#pragma unroll
+  for (int k4 = 0; k4 < 8; ++k4) {
+    const int k = 4 * k4 + kq;
+    const bool in = (k < kvol) && (row < n_rows);
+    int v = nbr[in ? (size_t)k * n_rows + row : 0];
+    if (!in) v = -1;
+    const unsigned long long m = __ballot(v >= 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if ((m >> (16 * q)) & 0xFFFFull) active |= 1u << (4 * k4 + q);
+  }
+  if (lane != 0) return;
+  const int w = __popc(active);                    // 0..32
+  if (!SCATTER) {
+    atomicAdd(&hist[w], 1);
+  } else {
+    int base = 0;                                  // tiles with more work come first
+    for (int c = w + 1; c <= 32; ++c) base += hist[c];
+    order[base + atomicAdd(&hist[33 + w], 1)] = tile;
+  }
+}
+
+extern "C" size_t dm_spconv_tile_order_workspace_bytes(void) { return dm_align(66 * sizeof(int)); }
+
+extern "C" int dm_spconv_tile_order(const int32_t *nbr, int n_rows, int kvol, int32_t *order,
+                                    void *workspace, size_t workspace_bytes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rows < 0 || kvol <= 0 || kvol > 32) return DM_ERR_INVALID_ARG;
+  if (n_rows == 0) return DM_OK;
+  if (!nbr || !order || !workspace) return DM_ERR_INVALID_ARG;
+  if (workspace_bytes < dm_spconv_tile_order_workspace_bytes()) return DM_ERR_WORKSPACE;
+  int *hist = (int *)workspace;
+  const int n_tiles = dm_ceil_div(n_rows, 16);
+  DM_HIP(hipMemsetAsync(hist, 0, 66 * sizeof(int), st));
+  tile_order_kernel<false><<<dm_ceil_div(n_tiles, 4), 256, 0, st>>>(nbr, n_rows, kvol, n_tiles, hist, order);
+  DM_CHECK_LAUNCH();
+  tile_order_kernel<true><<<dm_ceil_div(n_tiles, 4), 256, 0, st>>>(nbr, n_rows, kvol, n_tiles, hist, order);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
 // tuning aid: -1 auto, 0 force the LDS-staged kernel, 1 force the register-weights kernel
 extern "C" int dm_spconv_set_variant(int v) {
   g_gg_variant = v;
@@ -579,7 +638,7 @@ extern "C" size_t dm_spconv_workspace_bytes(int kvol, int cin, int cout) {
   if (ci == CI && co == CO) {                                                           \
     bool use_gr = g_gg_variant < 0 ? (CI >= 32) : (g_gg_variant == 1);                  \
     if constexpr (CI >= 16) {                                                           \
-      if (use_gr) return launch_gr<CI, CO>(feat, wp, nbr, nullptr, n_rows_out, kvol, out, st); \
+      if (use_gr) return launch_gr<CI, CO>(feat, wp, nbr, nullptr, tile_order, n_rows_out, kvol, out, st); \
     }                                                                                   \
     return launch_gg<CI, CO>(feat, wp, nbr, nullptr, n_rows_out, kvol, out, st);         \
   }
@@ -587,8 +646,8 @@ extern "C" size_t dm_spconv_workspace_bytes(int kvol, int cin, int cout) {
 extern "C" int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const float *filters,
                                      const int32_t *nbr, int n_rows_out, int kvol, int cin,
                                      int cout, int transpose_w, int flip_k, float *out,
-                                     void *workspace, size_t workspace_bytes,
-                                     dm_stream_t stream) {
+                                     const int32_t *tile_order, void *workspace,
+                                     size_t workspace_bytes, dm_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n_rows_in < 0 || n_rows_out < 0 || kvol <= 0 || kvol > 32) return DM_ERR_INVALID_ARG;
   // effective B operand dims: (ci x co)

@@ -125,9 +125,30 @@ def _tables_for(indice_pairs, indice_pair_num, n_in, n_out, subm):
 LAUNCH_TRACE = None
 
 
+def tile_order(nbr):
+    """Heavy-first launch order of a gather table's 16-row tiles (dm_spconv_tile_order), cached on
+    the table tensor: one build per rulebook table, reused by every launch on it."""
+    order = getattr(nbr, 'dm_tile_order', None)
+    if order is None:
+        L = _lib.lib()
+        kvol, n = int(nbr.shape[0]), int(nbr.shape[1])
+        order = torch.empty(((n + 15) // 16,), dtype=torch.int32, device=nbr.device)
+        ws = _lib.workspace(L.dm_spconv_tile_order_workspace_bytes(), nbr.device, 'tile_order')
+        _lib.check(L.dm_spconv_tile_order(_lib.ptr(nbr), n, kvol, _lib.ptr(order), _lib.ptr(ws),
+                                          ws.numel(), _lib.stream()), 'dm_spconv_tile_order')
+        nbr.dm_tile_order = order
+    return order
+
+
+# tables with fewer tiles than this are launch-latency sized: the order would cost more than it saves
+TILE_ORDER_MIN_ROWS = 4096
+
+
 def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k):
     L = _lib.lib()
     kvol = nbr.shape[0]
+    ci = cout if transpose_w else cin
+    order = tile_order(nbr) if (ci >= 32 and n_rows_out >= TILE_ORDER_MIN_ROWS) else None
     if LAUNCH_TRACE is not None:
         ci, co = (cout, cin) if transpose_w else (cin, cout)
         LAUNCH_TRACE.append((ci, co, int(n_rows_out), int(kvol), int((nbr >= 0).sum().item())))
@@ -136,7 +157,7 @@ def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k)
     ws = _lib.workspace(L.dm_spconv_workspace_bytes(kvol, cin, cout), dev, 'spconv')
     rc = L.dm_spconv_gather_gemm(_lib.ptr(feat), feat.shape[0], _lib.ptr(filters), _lib.ptr(nbr),
                                  n_rows_out, kvol, cin, cout, int(transpose_w), int(flip_k),
-                                 _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream())
+                                 _lib.ptr(out), _lib.ptr(order), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, 'dm_spconv_gather_gemm')
     return out
 

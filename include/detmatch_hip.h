@@ -174,7 +174,17 @@ int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const float *filters
                           const int32_t *nbr /*(kvol, n_rows_out)*/, int n_rows_out,
                           int kvol, int cin, int cout, int transpose_w, int flip_k,
                           float *out /*(n_rows_out, transpose_w ? cin : cout)*/,
+                          const int32_t *tile_order /* from dm_spconv_tile_order, or NULL */,
                           void *workspace, size_t workspace_bytes, dm_stream_t stream);
+/* Launch order of the 16-row output tiles of a gather table: tiles sorted by descending number of
+ * active kernel offsets (a launch lasts as long as the compute unit that received the heaviest
+ * tiles; heavy-first dispatch balances them).  A property of the table: build once per rulebook,
+ * pass to every dm_spconv_gather_gemm on that table (same order for flip_k = 1).  Results do not
+ * depend on it.  order: device int32[ceil(n_rows/16)], a permutation of the tile indices. */
+size_t dm_spconv_tile_order_workspace_bytes(void);
+int dm_spconv_tile_order(const int32_t *nbr /*(kvol, n_rows)*/, int n_rows, int kvol,
+                         int32_t *order, void *workspace, size_t workspace_bytes,
+                         dm_stream_t stream);
 
 /* filt_grad[k] = sum_s feat[pairs[k][0][s],:]^T (x) out_grad[pairs[k][1][s],:]
  * (spconv_ops.h:436-441).  Deterministic two-stage reduction (partial slabs in

@@ -239,3 +239,49 @@ def test_autograd_through_modules(orc, dev):
                                rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(net[2].weight.grad.cpu().numpy().reshape(27, 16, 32), dw2,
                                rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize('subm', [True, False])
+def test_tile_launch_order(orc, dev, subm, monkeypatch):
+    """dm_spconv_tile_order: a permutation of the 16-row tiles by descending number of active kernel
+    offsets; the gather-GEMM result does not depend on it (bit-exact with and without) and still
+    matches the oracle."""
+    from detmatch_amd.spconv import ops
+    rng = np.random.default_rng(5)
+    shape = [12, 60, 60]
+    n = 9000
+    idx = _rand_indices(rng, n, 2, shape)
+    # plus a dense clump in sample 0 so that tiles differ in work
+    clump = np.stack([np.zeros(4000, np.int64), rng.integers(2, 8, 4000), rng.integers(10, 30, 4000),
+                      rng.integers(10, 30, 4000)], 1).astype(idx.dtype)
+    idx = np.unique(np.concatenate([idx, clump]), axis=0)        # sorted: sample rows stay contiguous
+    n = len(idx)
+    ks, st, pd = ([3, 3, 3], [1, 1, 1], [1, 1, 1]) if subm else ([3, 3, 3], [2, 2, 2], [1, 1, 1])
+    rb, (o, p, nn) = _check_rulebook(orc, dev, idx, 2, shape, ks, st, pd, subm)
+    tables = [rb.nbr_out] + ([] if subm else [rb.nbr_in])
+    for nbr in tables:
+        order = ops.tile_order(nbr)
+        rows = nbr.shape[1]
+        nt = (rows + 15) // 16
+        assert order.shape == (nt,) and torch.equal(torch.sort(order.long())[0], torch.arange(nt, device=dev))
+        act = torch.zeros(nt * 16, nbr.shape[0], dtype=torch.bool, device=dev)
+        act[:rows] = (nbr >= 0).t()
+        work = act.view(nt, 16, -1).any(dim=1).sum(dim=1)
+        w_sorted = work[order.long()]
+        assert bool((w_sorted[:-1] >= w_sorted[1:]).all()) and int(work.max()) > int(work.min())
+        assert ops.tile_order(nbr) is order               # cached on the table
+    cin = cout = 64
+    feats = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) * 0.1).astype(np.float32)
+    tf = torch.from_numpy(feats).to(dev)
+    tw = torch.from_numpy(w).to(dev).view(3, 3, 3, cin, cout)
+    dy = torch.randn(rb.n_out, cout, device=dev)
+    assert min(n, rb.n_out) >= ops.TILE_ORDER_MIN_ROWS
+    out = ops.indice_conv(tf, tw, rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
+    dx, _ = ops.indice_conv_backward(tf, tw, dy, rb.indice_pairs, rb.indice_num, False, subm)
+    monkeypatch.setattr(ops, 'TILE_ORDER_MIN_ROWS', 1 << 30)      # identity order
+    out0 = ops.indice_conv(tf, tw, rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
+    dx0, _ = ops.indice_conv_backward(tf, tw, dy, rb.indice_pairs, rb.indice_num, False, subm)
+    assert torch.equal(out, out0) and torch.equal(dx, dx0)
+    want = orc.indice_conv(feats, w, p, nn, len(o), subm=subm)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
