@@ -341,6 +341,27 @@ int dm_points_augment(const float *points, int n_feat, int n_views, const int *s
                       const int *perm, float *out, int *out_counts, void *workspace,
                       size_t workspace_bytes, dm_stream_t stream);
 
+/* KITTI AP bookkeeping.  HOST functions replacing the numba-compiled loops
+ * compute_statistics_jit / fused_compute_statistics of
+ * mmdet3d/core/evaluation/kitti_utils/eval.py:161-279,291-338 for one (class, difficulty,
+ * min_overlap) cell over all images.  Per image n: overlaps (dt_nums[n] x gt_nums[n]) row-major
+ * doubles, gt_datas rows [x1,y1,x2,y2,alpha], dt_datas rows [x1,y1,x2,y2,alpha,score], dontcares
+ * rows [x1,y1,x2,y2], ignore flags as clean_data produces them (eval.py:28-80); all arrays are the
+ * per-image pieces concatenated.  metric 0 = 2D boxes (DontCare regions absorb false positives).
+ *   dm_kitti_tp_scores_host  scores of the matched detections at threshold 0 -> count (< 0: bad input)
+ *   dm_kitti_pr_host         pr (n_thresholds, 4) += [tp, fp, fn, orientation similarity] */
+long long dm_kitti_tp_scores_host(const double *overlaps, const int64_t *gt_nums,
+                                  const int64_t *dt_nums, const int64_t *dc_nums, int n_images,
+                                  const double *gt_datas, const double *dt_datas,
+                                  const double *dontcares, const int64_t *ignored_gts,
+                                  const int64_t *ignored_dets, int metric, double min_overlap,
+                                  double *tp_scores);
+int dm_kitti_pr_host(const double *overlaps, const int64_t *gt_nums, const int64_t *dt_nums,
+                     const int64_t *dc_nums, int n_images, const double *gt_datas,
+                     const double *dt_datas, const double *dontcares, const int64_t *ignored_gts,
+                     const int64_t *ignored_dets, int metric, double min_overlap,
+                     const double *thresholds, int n_thresholds, int compute_aos, double *pr);
+
 /* ------------------------------------------------------------------------ */
 /* D. Stacked PointNet++ operators, points-in-boxes                           */
 /* ------------------------------------------------------------------------ */
