@@ -98,3 +98,38 @@ def test_evaluate(ds):
     both = ds.evaluate([dict(teacher=_result(), student=_result())], ['mAP'])
     assert set(both) == {'tea.' + k for k in ap} | {'stu.' + k for k in ap}
     assert both['stu.KITTI/Overall_BEV_hard'] == both['tea.KITTI/Overall_BEV_hard']
+
+
+@pytest.mark.gpu
+def test_inference_to_evaluation_end_to_end(ds):
+    """The reference's test loop in one piece: KITTI frame from disk -> SSL.simple_test (teacher and
+    student, 2D + 3D) -> KittiDataset.evaluate -> `tea.3d.KITTI/...` / `stu.2d.KITTI/...` keys
+    (kitti_dataset.py:320-375).  Random weights: only the plumbing is checked."""
+    from detmatch_amd import configs
+    from detmatch_amd.mm3d import register_all
+    from detmatch_amd.mm3d.registry import build_detector
+    from detmatch_amd.synth import IMG_MEAN_BGR
+    register_all()
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = build_detector(configs.detmatch_kitti_model()).to(dev).eval()
+    info = ds.get_data_info(0)
+    pts = torch.from_numpy(ds.load_points(0)).to(dev)
+    raw = ds.load_image(0).astype(np.float32) - IMG_MEAN_BGR            # Normalize(mean, std=1, to_rgb=False)
+    h, w = raw.shape[:2]
+    ph, pw = (h + 31) // 32 * 32, (w + 31) // 32 * 32                   # Pad(size_divisor=32)
+    img = np.zeros((ph, pw, 3), np.float32)
+    img[:h, :w] = raw
+    img = torch.from_numpy(img.transpose(2, 0, 1)[None]).to(dev)
+    meta = dict(sample_idx=0, lidar2img=info['lidar2img'], ori_shape=(h, w, 3), img_shape=(h, w, 3),
+                pad_shape=(ph, pw, 3), scale_factor=np.ones(4, np.float32), flip=False,
+                pcd_horizontal_flip=False, pcd_vertical_flip=False, box_type_3d=LiDARInstance3DBoxes,
+                transformation_3d_flow=[])
+    with torch.no_grad():
+        res = model.simple_test(points=[pts], img_metas=[meta], img=img, rescale=True)
+    assert set(res[0]) == {'teacher', 'student'} and set(res[0]['teacher']) == {'results_2d', 'results_3d'}
+    ap = ds.evaluate(res, ['mAP'])
+    for who in ('tea', 'stu'):
+        for k in ('2d.KITTI/Overall_2D_moderate', '3d.KITTI/Overall_3D_moderate', '3d.KITTI/Overall_BEV_easy',
+                  '3d.KITTI/Pedestrian_3D_hard_strict'):
+            assert np.isfinite(ap['%s.%s' % (who, k)]), (who, k, sorted(ap))
