@@ -11,6 +11,8 @@ indexing, `tb_dict[...] = x.item()`): target assignment is a dense masked formul
 the padded GT tensor, so a training step issues no device->host copy here.  `tb_dict`
 values are detached 0-d tensors (call .item() on them outside the step if wanted).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -216,6 +218,45 @@ class AxisAlignedTargetAssigner(object):
         return labels, bbox_targets, fg.to(anchors.dtype)
 
 
+class _FusedAnchorHeadLoss(torch.autograd.Function):
+    """dm_anchor_head_loss_forward / _backward (csrc/anchor_loss.hip): the classification, regression and
+    direction losses of the anchor head in one launch each way -> tensor [cls, loc, dir]."""
+
+    @staticmethod
+    def forward(ctx, cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, num_pos, meta):
+        from .. import _lib
+        L = _lib.lib()
+        _lib.require_device(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, num_pos)
+        b, a = int(labels.shape[0]), int(labels.shape[1])
+        n_cls, n_bins, alpha, beta, dir_offset, w3, cw7 = meta
+        out = torch.empty(3, dtype=torch.float32, device=cls_preds.device)
+        ws = _lib.workspace(L.dm_anchor_head_loss_workspace_bytes(b, a), cls_preds.device, 'anchor_loss')
+        _lib.check(L.dm_anchor_head_loss_forward(
+            _lib.ptr(cls_preds), _lib.ptr(box_preds), _lib.ptr(dir_preds), _lib.ptr(labels), _lib.ptr(reg_targets),
+            _lib.ptr(anchors), _lib.ptr(num_pos), b, a, n_cls, n_bins, alpha, beta, dir_offset, _lib.floats(w3),
+            _lib.floats(cw7), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_anchor_head_loss_forward')
+        ctx.save_for_backward(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, num_pos)
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        from .. import _lib
+        L = _lib.lib()
+        cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, num_pos = ctx.saved_tensors
+        n_cls, n_bins, alpha, beta, dir_offset, w3, cw7 = ctx.meta
+        b, a = int(labels.shape[0]), int(labels.shape[1])
+        grad = grad.contiguous().float()
+        g_cls, g_box = torch.empty_like(cls_preds), torch.empty_like(box_preds)
+        g_dir = torch.empty_like(dir_preds) if dir_preds is not None else None
+        _lib.check(L.dm_anchor_head_loss_backward(
+            _lib.ptr(cls_preds), _lib.ptr(box_preds), _lib.ptr(dir_preds), _lib.ptr(labels), _lib.ptr(reg_targets),
+            _lib.ptr(anchors), _lib.ptr(num_pos), b, a, n_cls, n_bins, alpha, beta, dir_offset, _lib.floats(w3),
+            _lib.floats(cw7), _lib.ptr(grad), _lib.ptr(g_cls), _lib.ptr(g_box), _lib.ptr(g_dir), _lib.stream()),
+            'dm_anchor_head_loss_backward')
+        return g_cls, g_box, g_dir, None, None, None, None, None
+
+
 class AnchorHeadSingle(nn.Module):
     """anchor_head_template.py:11-275 + anchor_head_single.py:7-75."""
 
@@ -390,10 +431,48 @@ class AnchorHeadSingle(nn.Module):
         return box_loss, tb_dict
 
     def get_loss(self):
+        """anchor_head_template.py:216-223.  On the GPU the three losses come from the fused kernel
+        (csrc/anchor_loss.hip); `get_loss_torch` is the element-wise restatement of the reference (the one
+        the reference-generated goldens pin, and the numerics reference of the kernel)."""
+        if self.forward_ret_dict['cls_preds'].is_cuda and os.environ.get('DM_ANCHOR_LOSS', 'fused') == 'fused':
+            return self.get_loss_fused()
+        return self.get_loss_torch()
+
+    def get_loss_torch(self):
         cls_loss, tb_dict = self.get_cls_layer_loss()
         box_loss, tb_dict_box = self.get_box_reg_layer_loss()
         tb_dict.update(tb_dict_box)
         rpn_loss = cls_loss + box_loss
+        tb_dict['rpn_loss'] = rpn_loss.detach()
+        return rpn_loss, tb_dict
+
+    def get_loss_fused(self):
+        d = self.forward_ret_dict
+        cls_preds, box_preds = d['cls_preds'], d['box_preds']
+        dir_preds = d.get('dir_cls_preds', None)
+        labels = d['box_cls_labels']
+        b = int(cls_preds.shape[0])
+        a = labels.shape[1]
+        lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        n_bins = int(self.model_cfg.NUM_DIR_BINS) if dir_preds is not None else 0
+        meta = (self.num_class, n_bins, 0.25, float(self.reg_loss_func.beta),
+                float(self.model_cfg.get('DIR_OFFSET', 0.0)),
+                [float(lw['cls_weight']), float(lw['loc_weight']), float(lw.get('dir_weight', 0.0))],
+                [float(v) for v in lw['code_weights']])
+        anchors = getattr(self, '_anchors_flat', None)
+        if anchors is None or anchors.device != cls_preds.device:
+            anchors = self._anchors_flat = self._cat_anchors().reshape(-1, 7).contiguous()
+        num_pos = (labels > 0).sum(dim=1).float()
+        parts = _FusedAnchorHeadLoss.apply(
+            cls_preds.reshape(b, a, self.num_class).contiguous(), box_preds.reshape(b, a, 7).contiguous(),
+            dir_preds.reshape(b, a, n_bins).contiguous() if dir_preds is not None else None,
+            labels.int().contiguous(), d['box_reg_targets'].contiguous(), anchors, num_pos, meta)
+        cls_loss, loc_loss = parts[0], parts[1]
+        tb_dict = {'rpn_loss_cls': cls_loss.detach(), 'rpn_loss_loc': loc_loss.detach()}
+        rpn_loss = cls_loss + loc_loss
+        if dir_preds is not None:
+            rpn_loss = rpn_loss + parts[2]
+            tb_dict['rpn_loss_dir'] = parts[2].detach()
         tb_dict['rpn_loss'] = rpn_loss.detach()
         return rpn_loss, tb_dict
 

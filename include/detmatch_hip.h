@@ -341,6 +341,30 @@ int dm_points_augment(const float *points, int n_feat, int n_views, const int *s
                       const int *perm, float *out, int *out_counts, void *workspace,
                       size_t workspace_bytes, dm_stream_t stream);
 
+/* Fused anchor-head losses.  Replaces get_cls_layer_loss / get_box_reg_layer_loss of
+ * pcdet/models/dense_heads/anchor_head_template.py:101-214 with the loss functions of
+ * pcdet/utils/loss_utils.py:9-137,181-206 (sigmoid focal gamma 2, smooth-L1 with the sin-difference
+ * heading term, direction-bin cross-entropy), ~160 element-wise launches each way in the reference.
+ *   cls_preds (B,A,n_cls)  box_preds (B,A,7)  dir_preds (B,A,n_bins) or NULL
+ *   labels (B,A) int32: -1 ignore, 0 background, c+1 class    reg_targets (B,A,7)   anchors (A,7)
+ *   num_pos (B) float: positives per sample (the normaliser; clamped to >= 1 inside)
+ *   weights3_host = {cls_weight, loc_weight, dir_weight}; code_weights7_host; all sums / B
+ *   forward : losses3 = {cls, loc, dir} (deterministic two-level reduction)
+ *   backward: grad_* = d(sum_i grad_losses3[i] * losses3[i]) / d(*_preds), dense (zeros off the positives) */
+size_t dm_anchor_head_loss_workspace_bytes(int batch, int n_anchors);
+int dm_anchor_head_loss_forward(const float *cls_preds, const float *box_preds, const float *dir_preds,
+                                const int32_t *labels, const float *reg_targets, const float *anchors,
+                                const float *num_pos, int batch, int n_anchors, int n_cls, int n_bins,
+                                float alpha, float beta, float dir_offset, const float *weights3_host,
+                                const float *code_weights7_host, float *losses3, void *workspace,
+                                size_t workspace_bytes, dm_stream_t stream);
+int dm_anchor_head_loss_backward(const float *cls_preds, const float *box_preds, const float *dir_preds,
+                                 const int32_t *labels, const float *reg_targets, const float *anchors,
+                                 const float *num_pos, int batch, int n_anchors, int n_cls, int n_bins,
+                                 float alpha, float beta, float dir_offset, const float *weights3_host,
+                                 const float *code_weights7_host, const float *grad_losses3,
+                                 float *grad_cls, float *grad_box, float *grad_dir, dm_stream_t stream);
+
 /* KITTI AP bookkeeping.  HOST functions replacing the numba-compiled loops
  * compute_statistics_jit / fused_compute_statistics of
  * mmdet3d/core/evaluation/kitti_utils/eval.py:161-279,291-338 for one (class, difficulty,
