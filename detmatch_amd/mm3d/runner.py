@@ -8,6 +8,7 @@ as the training iteration needs it: parity unpinned for the mmcv parts.
 """
 import copy
 import math
+import os
 import time
 
 import torch
@@ -476,6 +477,18 @@ class IterLoader(object):
         return len(self._dataloader)
 
 
+def _ensure_train_mode(model):
+    """`model.train()` of the reference runners.  Walking the ~1300 sub-modules of the DetMatch model
+    every iteration costs 3-6 ms of host time (hidden behind the previous step's device tail on this
+    host, not on a slower or shared one), so a model may vouch for
+    its own mode through `training_mode_ok()` (SSL does: student training, teacher eval, checked two
+    levels deep); anything else gets the plain call."""
+    inner = model.module if hasattr(model, 'module') else model
+    ok = getattr(inner, 'training_mode_ok', None)
+    if not (model.training and ok is not None and ok()):
+        model.train()
+
+
 class _RunnerBase(object):
 
     def __init__(self, model, optimizer=None, max_iters=None, work_dir=None, logger=None,
@@ -552,7 +565,7 @@ class EpochBasedRunner(_RunnerBase):
     max_epochs = property(lambda self: self._max_epochs)
 
     def train(self, data_loader, **kwargs):
-        self.model.train()
+        _ensure_train_mode(self.model)
         self.mode = 'train'
         self.data_loader = data_loader
         self._max_iters = self._max_epochs * len(data_loader)
@@ -594,7 +607,7 @@ class IterBasedSSLRunner(_RunnerBase):
     num_samples)."""
 
     def train(self, lab_data_loader, unlab_data_loader, **kwargs):
-        self.model.train()
+        _ensure_train_mode(self.model)
         self.mode = 'train'
         self._epoch = getattr(lab_data_loader, 'epoch', 0)
         lab = next(lab_data_loader)

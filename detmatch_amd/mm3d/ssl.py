@@ -398,9 +398,24 @@ class SSL(nn.Module):
         return loss, {k: packed[i] for i, k in enumerate(keys)}
 
     # ---- step ------------------------------------------------------------------------------
+    @staticmethod
+    def _subtree_mode(module, training):
+        """True when `module`, its children and grandchildren all have `.training == training` (the modes
+        are only ever switched by whole-subtree train() / eval() calls)."""
+        for m in (module,) + tuple(module.children()):
+            if m.training != training or any(c.training != training for c in m.children()):
+                return False
+        return True
+
+    def training_mode_ok(self):
+        """The state every training iteration starts from after the first one: student in training
+        mode, teacher in eval mode (set_teacher_eval) — lets the runner skip a redundant model.train()."""
+        return self.training and self._subtree_mode(self.student, True) and \
+            (self._subtree_mode(self.teacher, False) if self.set_teacher_eval else self._subtree_mode(self.teacher, True))
+
     def train_step(self, data, optimizer=None):
         """ssl.py:214-253"""
-        if self.set_teacher_eval:
+        if self.set_teacher_eval and not self._subtree_mode(self.teacher, False):
             self.teacher.eval()
         losses = self(**data)
         vis = losses.pop('vis', dict())

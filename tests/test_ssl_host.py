@@ -370,3 +370,30 @@ def test_epoch_based_runner_cyclic_and_step_schedules():
     out = model.train_step(loader[0])
     assert out['num_samples'] == 4 and set(out['log_vars']) == {'loss_a', 'acc', 'loss_list', 'loss'}
     assert float(out['log_vars']['loss']) == pytest.approx(float(out['log_vars']['loss_a'] + out['log_vars']['loss_list']))
+
+
+def test_training_mode_shortcut_is_only_taken_in_the_steady_state():
+    """The runners skip the per-iteration model.train() tree walk only when SSL.training_mode_ok():
+    student training, teacher eval — exactly the state model.train() + train_step's teacher.eval() of
+    the reference leave behind (iter_based_ssl_runner.py:16, ssl.py:219)."""
+    from detmatch_amd import configs
+    from detmatch_amd.mm3d import register_all
+    from detmatch_amd.mm3d.registry import build_detector
+    register_all()
+    model = build_detector(configs.detmatch_kitti_model())
+    calls = []
+    orig = model.train
+    model.train = lambda mode=True: (calls.append(mode), orig(mode))[1]
+    R._ensure_train_mode(model)                    # fresh model: teacher still in training mode
+    assert calls == [True] and not model.training_mode_ok()
+    model.teacher.eval()                           # what train_step does
+    assert model.training_mode_ok()
+    R._ensure_train_mode(model)
+    assert calls == [True]                         # steady state: no second walk
+    model.student.detector_2d.eval()               # any deviation -> the plain call again
+    assert not model.training_mode_ok()
+    R._ensure_train_mode(model)
+    assert calls == [True, True] and model.student.detector_2d.training
+    model.eval()
+    R._ensure_train_mode(model)
+    assert calls == [True, True, False, True] and model.training          # eval() itself is train(False)

@@ -1,0 +1,16 @@
+import cProfile, pstats, sys, os, io
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import detmatch_amd, torch
+from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+wl = DetMatchTrainWorkload(2, torch.device('cuda', 0))
+for _ in range(4): wl.step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(5): wl.step()
+torch.cuda.synchronize()
+pr.disable()
+s = io.StringIO()
+st = pstats.Stats(pr, stream=s).sort_stats('tottime')
+st.print_stats(45)
+print(s.getvalue()[:9000])
