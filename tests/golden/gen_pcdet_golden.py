@@ -342,6 +342,21 @@ def dense_goldens(rng, rc):
     by = rng.uniform(-1, 26, 80).astype(np.float32)
     out.update(bi_im=im, bi_x=bx, bi_y=by,
                bi_out=vsa.bilinear_interpolate_torch(f32(im), f32(bx), f32(by)).numpy())
+    # ---- SparseConvTensor.dense + HeightCompression (structure.py has no compiled import)
+    for n in ('pcdet.ops.spconv', 'pcdet.models.backbones_2d.map_to_bev'):
+        if n not in sys.modules:
+            _pkg(n)
+    st = _load('pcdet.ops.spconv.structure', 'pcdet/ops/spconv/structure.py')
+    hc = _load('pcdet.models.backbones_2d.map_to_bev.height_compression',
+               'pcdet/models/backbones_2d/map_to_bev/height_compression.py')
+    cells = rng.permutation(2 * 2 * 5 * 7)[:50]
+    sp_idx = np.stack(np.unravel_index(cells, (2, 2, 5, 7)), 1).astype(np.int32)
+    sp_feat = rng.normal(size=(50, 6)).astype(np.float32)
+    spt = st.SparseConvTensor(f32(sp_feat), torch.from_numpy(sp_idx.copy()), [2, 5, 7], 2)
+    hd = hc.HeightCompression(AttrDict(NUM_BEV_FEATURES=12))(dict(encoded_spconv_tensor=spt,
+                                                                 encoded_spconv_tensor_stride=8))
+    out.update(sp_idx=sp_idx, sp_feat=sp_feat, sp_dense=spt.dense().numpy(),
+               sp_bev=hd['spatial_features'].numpy())
     np.savez_compressed(os.path.join(HERE, 'pcdet_dense.npz'), **out)
     print('wrote pcdet_dense.npz: %d arrays, %d positive anchors, %.0f kB' % (
         len(out), int((out['ah_labels'] > 0).sum()), os.path.getsize(os.path.join(HERE, 'pcdet_dense.npz')) / 1e3))
