@@ -75,7 +75,12 @@ class _Lanes(object):
     N = 3
     _side = {}
 
-    def __init__(self, device):
+    def __init__(self, device, mode='branches'):
+        # mode 'branches': the three lanes above.  mode 'glue': TWO lanes — every detector pass (student
+        # and teacher, 2D and 3D) stays on the caller's stream, strictly ordered, so the heavy kernels
+        # never share the device; only the light pseudo-label glue (filters, transforms, matching, with
+        # all its host read-backs) runs on a side stream, underneath the supervised passes.
+        self.mode = mode
         self.main = torch.cuda.current_stream(device)
         pool = _Lanes._side.get(device.index)
         if pool is None:
@@ -87,9 +92,10 @@ class _Lanes(object):
     def stream(self, lane):
         return self.streams[lane]
 
-    @staticmethod
-    def lane_of(module):
+    def lane_of(self, module):
         attr = getattr(module, 'ssl_obj_attr', None)
+        if self.mode == 'glue':
+            return 1 if attr is None else 0
         if attr is None:
             return 2                       # glue
         if attr.endswith('detector_2d'):
@@ -441,9 +447,10 @@ class SSL(nn.Module):
         unlab_dict = dict(stu=unlab_stu, tea=unlab_tea, ssl_losses=dict())
         lanes = None
         dev = next(self.student.parameters()).device
-        if getattr(self, 'two_lanes', False) and dev.type == 'cuda':
-            # 2D and 3D branches on two HIP streams; data-flow edges become event waits (_LaneDict)
-            lanes = _Lanes(dev)
+        lane_mode = getattr(self, 'lane_mode', None) or ('branches' if getattr(self, 'two_lanes', False) else None)
+        if lane_mode and dev.type == 'cuda':
+            # modules on several HIP streams; data-flow edges become event waits (_LaneDict)
+            lanes = _Lanes(dev, lane_mode)
             lab_dict = _LaneDict({k: (_LaneDict(v, lanes) if isinstance(v, dict) else v)
                                   for k, v in lab_dict.items()}, lanes)
             unlab_dict = _LaneDict({k: (_LaneDict(v, lanes) if isinstance(v, dict) else v)
@@ -458,6 +465,17 @@ class SSL(nn.Module):
                     m.prefetch(self, d)
         if lanes is not None:
             lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
+        unlab_modules = list(self.unlab_ssl_modules)
+        if lanes is not None and lanes.mode == 'glue':
+            # The teacher's inference passes read nothing but the raw unlabeled batch: issue them first, so
+            # that the glue that consumes them can run (on its side stream) while the main stream works
+            # through the supervised passes and their early backward.  Values do not depend on the order:
+            # the teacher is in eval mode and draws no random numbers.
+            hoisted = [m for m in unlab_modules if getattr(m, 'hoistable', False) and
+                       str(getattr(m, 'ssl_obj_attr', '')).startswith('teacher')]
+            for m in sorted(hoisted, key=lambda m: getattr(m, 'has_readback', False)):   # read-back last
+                unlab_dict = run(m, unlab_dict)
+            unlab_modules = [m for m in unlab_modules if m not in hoisted]
         for m in self.lab_ssl_modules:
             lab_dict = run(m, lab_dict)
         if lanes is not None:
@@ -475,7 +493,7 @@ class SSL(nn.Module):
                 if hook is not None:      # e.g. FlatGradDDP.collect
                     hook()
             lab_dict['sup_losses'] = {k: v.detach() for k, v in sup.items()}
-        for m in self.unlab_ssl_modules:
+        for m in unlab_modules:
             unlab_dict = run(m, unlab_dict)
         if lanes is not None:
             lanes.join(unlab_dict['ssl_losses'], lab_dict['ssl_losses'])

@@ -75,6 +75,11 @@ class Opd_SimpleTest_3D(object):
     """consumers/openpcdet.py:15-95: run the detector in its CURRENT mode on [key]['points']
     and store un-thresholded (boxes, sigmoid class scores)."""
 
+    # scheduling hints for SSL.forward_train (lane mode 'glue'): reads only the raw batch -> may be
+    # issued ahead of the labeled chain; ends with a host read-back (post_processing)
+    hoistable = True
+    has_readback = True
+
     def __init__(self, ssl_obj_attr='teacher', batch_dict_key='tea',
                  out_bboxes_key='3d_simple_test'):
         self.ssl_obj_attr = ssl_obj_attr
@@ -339,6 +344,8 @@ class FusionHungarianMatching(object):
 class SimpleTest_2D(object):
     """processors_2d.py:11-86: Faster R-CNN test path up to (not including) NMS:
     (decoded boxes N x 4, softmax/sigmoid scores N x (C+1)), in the augmented image frame."""
+
+    hoistable = True          # reads only the raw batch (see Opd_SimpleTest_3D)
 
     def __init__(self, ssl_obj_attr='teacher', batch_dict_key='tea', out_bboxes_key='2d_simple_test'):
         self.ssl_obj_attr = ssl_obj_attr

@@ -246,6 +246,7 @@ class DetMatchTrainWorkload(object):
         # bench.py) stop agreeing with the serialised rocprofv3 kernel trace (52 vs 36 us for
         # spconv_gr<64,64>); the default keeps the measurement contract clean.
         self.model.two_lanes = os.environ.get('DM_TWO_LANES', '0') == '1'
+        self.model.lane_mode = os.environ.get('DM_LANE_MODE') or None      # 'glue': see ssl.py:_Lanes
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
         self.n_fused = self.opt.enable_fused(self.ddp)
         self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)

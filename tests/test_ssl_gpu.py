@@ -180,14 +180,17 @@ def test_early_backward_and_prefetch_do_not_change_gradients(dev):
     assert rel < 1e-3, float(rel)      # float atomics: run-to-run noise ~1e-5..1e-4
 
 
-def test_two_lanes_do_not_change_gradients(dev):
-    """Full DetMatch recipe: running the 2D-detector modules on a second HIP stream (data-flow edges
-    turned into event waits) gives the same accumulated gradient and losses as the serial order."""
+@pytest.mark.parametrize('mode', ['branches', 'glue'])
+def test_lanes_do_not_change_gradients(dev, mode):
+    """Full DetMatch recipe on several HIP streams (data-flow edges turned into event waits) gives the
+    same accumulated gradient and losses as the serial order.  'branches': student-3D / 2D detectors /
+    teacher-3D + glue lanes; 'glue': only the pseudo-label glue on a side stream, teacher inference
+    issued ahead of the supervised passes."""
     from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
     out = []
-    for lanes in (True, False):
+    for lanes in (mode, None):
         wl = DetMatchTrainWorkload(2, dev)
-        wl.model.two_lanes = lanes
+        wl.model.two_lanes, wl.model.lane_mode = False, lanes
         torch.manual_seed(321)       # one iteration: no feedback through updated weights
         wl.step()
         torch.cuda.synchronize()
