@@ -95,10 +95,15 @@ __device__ __forceinline__ int dm_hash_find(const uint32_t *keys, const int32_t 
 __device__ __forceinline__ int dm_lane_id() { return threadIdx.x & 63; }
 
 // ---- optional per-launch HIP-event timing (bench.py roofline leg) ----------
-// Events are recorded on the stream the kernel is launched on, immediately
-// before and after the launch.  Disabled (zero overhead) unless
-// dm_profile_enable(1) was called.
+// Disabled (zero overhead) unless dm_profile_enable(1) was called.  Two flavours:
+//   dm_prof_begin / dm_prof_end   events recorded on the launch stream immediately before and after
+//                                 (a multi-kernel region: the weight gradient);
+//   dm_prof_open + hipExtLaunchKernelGGL(..., e0, e1, ...)   the events carry the start / end
+//                                 timestamps of THAT dispatch (what rocprofv3's kernel trace reports),
+//                                 unaffected by work queued on other streams.
 enum { DM_PROF_SPCONV_GG = 0, DM_PROF_SPCONV_WGRAD = 1 };
 int dm_prof_begin(hipStream_t st, int kind, int a, int b, int c, int rows, int kvol,
                   const void *table);
 void dm_prof_end(int idx, hipStream_t st);
+int dm_prof_open(int kind, int a, int b, int c, int rows, int kvol, const void *table, hipEvent_t *e0,
+                 hipEvent_t *e1);

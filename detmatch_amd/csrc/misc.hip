@@ -41,6 +41,20 @@ int dm_prof_begin(hipStream_t st, int kind, int a, int b, int c, int rows, int k
   return (int)g_recs.size() - 1;
 }
 
+int dm_prof_open(int kind, int a, int b, int c, int rows, int kvol, const void *table, hipEvent_t *e0,
+                 hipEvent_t *e1) {
+  if (!g_prof_on) return -1;
+  ProfRec r;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+  r.kind = kind; r.a = a; r.b = b; r.c = c; r.rows = rows; r.kvol = kvol;
+  r.table = (unsigned long long)(uintptr_t)table;
+  r.closed = true;               // the launch itself fills both events
+  *e0 = r.e0;
+  *e1 = r.e1;
+  g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
+}
+
 void dm_prof_end(int idx, hipStream_t st) {
   if (idx < 0 || idx >= (int)g_recs.size()) return;
   (void)hipEventRecord(g_recs[idx].e1, st);

@@ -17,6 +17,8 @@
 // (no weight staging, no barrier).
 //
 // Algorithmic bytes per pair: (cin + cout)*4 + 8.
+#include <hip/hip_ext.h>
+
 #include "dm_common.h"
 
 // Input channels per pipeline step of spconv_gr = 16 * DM_GR_CTS.  2 (32 channels, 8 KiB of weights
@@ -445,10 +447,13 @@ int launch_gr(const float *feat, const float *wpack, const int32_t *nbr, const i
               const int32_t *tile_order, int n_out, int kvol, float *out, hipStream_t st) {
   constexpr int COUT = COUT_FULL > 64 ? 64 : COUT_FULL;  // columns per workgroup
   dim3 grid(dm_ceil_div(n_out, 16), COUT_FULL / COUT);
-  int pi = dm_prof_begin(st, DM_PROF_SPCONV_GG, CIN, COUT_FULL, 0, n_out, kvol, nbr);
-  spconv_gr<CIN, COUT><<<grid, 256, 0, st>>>(feat, wpack, nbr, perm, n_out, kvol, COUT_FULL, out,
-                                             g_debug_stamps, tile_order);
-  dm_prof_end(pi, st);
+  hipEvent_t e0, e1;
+  if (dm_prof_open(DM_PROF_SPCONV_GG, CIN, COUT_FULL, 0, n_out, kvol, nbr, &e0, &e1) >= 0)
+    hipExtLaunchKernelGGL((spconv_gr<CIN, COUT>), grid, dim3(256), 0, st, e0, e1, 0, feat, wpack, nbr, perm,
+                          n_out, kvol, (int)COUT_FULL, out, g_debug_stamps, tile_order);
+  else
+    spconv_gr<CIN, COUT><<<grid, 256, 0, st>>>(feat, wpack, nbr, perm, n_out, kvol, COUT_FULL, out,
+                                               g_debug_stamps, tile_order);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -467,10 +472,13 @@ int launch_gg(const float *feat, const float *wpack, const int32_t *nbr, const i
                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
-  int pi = dm_prof_begin(st, DM_PROF_SPCONV_GG, CIN, COUT, NS, n_out, kvol, nbr);
-  spconv_gg<CIN, COUT, NS><<<dm_ceil_div(n_out, ROWS), 256, smem, st>>>(
-      feat, wpack, nbr, perm, n_out, kvol, out, g_debug_stamps);
-  dm_prof_end(pi, st);
+  hipEvent_t e0, e1;
+  if (dm_prof_open(DM_PROF_SPCONV_GG, CIN, COUT, NS, n_out, kvol, nbr, &e0, &e1) >= 0)
+    hipExtLaunchKernelGGL((spconv_gg<CIN, COUT, NS>), dim3(dm_ceil_div(n_out, ROWS)), dim3(256), (uint32_t)smem,
+                          st, e0, e1, 0, feat, wpack, nbr, perm, n_out, kvol, out, g_debug_stamps);
+  else
+    spconv_gg<CIN, COUT, NS><<<dm_ceil_div(n_out, ROWS), 256, smem, st>>>(
+        feat, wpack, nbr, perm, n_out, kvol, out, g_debug_stamps);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -466,7 +466,7 @@ class SSL(nn.Module):
         if lanes is not None:
             lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
         unlab_modules = list(self.unlab_ssl_modules)
-        if lanes is not None and lanes.mode == 'glue':
+        if lanes is not None and (lanes.mode == 'glue' or getattr(self, 'lane_hoist', False)):
             # The teacher's inference passes read nothing but the raw unlabeled batch: issue them first, so
             # that the glue that consumes them can run (on its side stream) while the main stream works
             # through the supervised passes and their early backward.  Values do not depend on the order:
