@@ -1,3 +1,8 @@
+"""cProfile of the host side of 5 DetMatch iterations (top functions by own time): where the Python /
+launch overhead of the step goes (blocking read-backs show up as `tolist` / `item` / `nonzero`).
+
+    python tools/host_profile.py
+"""
 import cProfile, pstats, sys, os, io
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import detmatch_amd, torch
