@@ -1,52 +1,58 @@
-"""mmdet3d/ops/spconv/structure.py:5-69 — SparseConvTensor container."""
+"""Sparse tensor container of the spconv API surface (the reference: mmdet3d/ops/spconv/structure.py —
+`SparseConvTensor` :21-69, `scatter_nd` :5-18).  Same attributes and methods, because the modules and
+the PV-RCNN code address them by name; densification goes through one flat row copy."""
 import numpy as np
 import torch
 
 
+def _linear_rows(indices, shape):
+    """Row-major linear index of integer coordinates (N, k) in a grid of size shape[:k]."""
+    lin = indices[:, 0].long()
+    for d in range(1, indices.shape[1]):
+        lin = lin * int(shape[d]) + indices[:, d].long()
+    return lin
+
+
 def scatter_nd(indices, updates, shape):
-    """structure.py:5-18: out[indices] = updates on a zero tensor of `shape`."""
-    ret = torch.zeros(*shape, dtype=updates.dtype, device=updates.device)
-    ndim = indices.shape[-1]
-    output_shape = list(indices.shape[:-1]) + shape[indices.shape[-1]:]
-    flat = indices.view(-1, ndim)
-    slices = [flat[:, i] for i in range(ndim)] + [Ellipsis]
-    ret[tuple(slices)] = updates.view(*output_shape)
-    return ret
+    """out[tuple(indices[i])] = updates[i] on zeros(shape); duplicates are not accumulated (the last
+    writer wins, as in the reference)."""
+    k = indices.shape[-1]
+    idx = indices.reshape(-1, k)
+    rows = int(np.prod(shape[:k]))
+    tail = [int(s) for s in shape[k:]]
+    flat = torch.zeros([rows] + tail, dtype=updates.dtype, device=updates.device)
+    flat[_linear_rows(idx, shape)] = updates.reshape([idx.shape[0]] + tail)
+    return flat.view(*[int(s) for s in shape])
 
 
 class SparseConvTensor(object):
-    """features (N, C) f32, indices (N, 4) int32 [b, z, y, x]."""
+    """features (N, C) fp32 rows, indices (N, 4) int32 [batch, z, y, x] of the active cells of a
+    `spatial_shape` grid; `indice_dict` caches the rulebooks of the layers that share an indice_key."""
 
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
         self.features = features
-        self.indices = indices
-        if self.indices.dtype != torch.int32:
-            self.indices = self.indices.int()
+        self.indices = indices if indices.dtype == torch.int32 else indices.int()
         self.spatial_shape = spatial_shape
         self.batch_size = batch_size
-        self.indice_dict = {}
         self.grid = grid
+        self.indice_dict = {}
+
+    def find_indice_pair(self, key):
+        return None if key is None else self.indice_dict.get(key)
 
     @property
     def spatial_size(self):
         return np.prod(self.spatial_shape)
 
-    def find_indice_pair(self, key):
-        if key is None:
-            return None
-        return self.indice_dict.get(key, None)
-
-    def dense(self, channels_first=True):
-        """structure.py:55-64: scatter to (B, [C,] D, H, W[, C])."""
-        output_shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
-        res = scatter_nd(self.indices.long(), self.features, output_shape)
-        if not channels_first:
-            return res
-        ndim = len(self.spatial_shape)
-        perm = list(range(0, ndim + 1))
-        perm.insert(1, ndim + 1)
-        return res.permute(*perm).contiguous()
-
     @property
     def sparity(self):
-        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+        return self.indices.shape[0] / float(self.spatial_size) / self.batch_size
+
+    def dense(self, channels_first=True):
+        """(B, C, *spatial) — or (B, *spatial, C) with channels_first=False — with zeros at inactive cells."""
+        grid = [self.batch_size] + [int(s) for s in self.spatial_shape]
+        out = scatter_nd(self.indices, self.features, grid + [self.features.shape[1]])
+        if channels_first:
+            last = out.dim() - 1
+            out = out.permute(0, last, *range(1, last)).contiguous()
+        return out
