@@ -262,10 +262,12 @@ class DetMatchTrainWorkload(object):
 
     def describe(self):
         n = sum(p.numel() for p in self.params)
-        return ('DetMatch iteration (BASELINE configs[2], recipe %s): teacher+student PV-RCNN and '
+        cfg_idx = {'detmatch': 3, 'confthr_pvrcnn': 2}.get(self.recipe)
+        where = 'BASELINE configs[%d] per-GPU shape' % cfg_idx if cfg_idx is not None else 'configs/detmatch/001'
+        return ('DetMatch iteration (%s, recipe %s): teacher+student PV-RCNN and '
                 'Faster R-CNN R50-FPN, pseudo-label path, fused EMA, backward, grad exchange, clip, '
                 'HybridOptimizer; KITTI-shaped synthetic, %d labeled + %d unlabeled per GPU, '
-                '%.1f M trainable params' % (self.recipe, self.batch_size, self.batch_size, n / 1e6))
+                '%.1f M trainable params' % (where, self.recipe, self.batch_size, self.batch_size, n / 1e6))
 
     def enable_ddp(self):
         self.world = dist.get_world_size()
