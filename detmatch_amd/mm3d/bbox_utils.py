@@ -226,3 +226,78 @@ def filter_by_nms_2d(bbox_list, nms_cfg, use_sigmoid_cls, return_indices=False):
         sel_box = selected.long() // (scores_for_nms.shape[1] - 1)
         res.append((dets[:, :4], scores[sel_box]))
     return res
+
+
+# ------------------------------------------------------------------ 3D multi-class NMS
+def xywhr2xyxyr(boxes_xywhr):
+    """mmdet3d/core/bbox/structures/utils.py:62-82: BEV (cx, cy, w, h, r) -> (x1, y1, x2, y2, r)."""
+    half = boxes_xywhr[:, 2:4] / 2
+    return torch.cat([boxes_xywhr[:, 0:2] - half, boxes_xywhr[:, 0:2] + half, boxes_xywhr[:, 4:5]], dim=1)
+
+
+def _xyxyr_as_boxes7(b):
+    """(x1,y1,x2,y2,r) rotated BEV rectangles as the 7-value boxes the device NMS takes."""
+    z = torch.zeros_like(b[:, :1])
+    return torch.cat([(b[:, 0:1] + b[:, 2:3]) / 2, (b[:, 1:2] + b[:, 3:4]) / 2, z, b[:, 2:3] - b[:, 0:1],
+                      b[:, 3:4] - b[:, 1:2], z + 1, b[:, 4:5]], dim=1)
+
+
+def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg,
+                         mlvl_attr_scores=None):
+    """mmdet3d/core/post_processing/box3d_nms.py:9-120: per-class rotated (or axis-aligned) BEV NMS on
+    (x1,y1,x2,y2,r) boxes, classes concatenated, top `max_num` by score
+    -> (bboxes, scores, labels[, attr_scores])."""
+    from .. import iou3d_nms
+    num_classes = mlvl_scores.shape[1] - 1
+    get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+    nms = iou3d_nms.nms_gpu if get('use_rotate_nms') else iou3d_nms.nms_normal_gpu
+    bboxes, scores, labels, attrs = [], [], [], []
+    for i in range(num_classes):
+        cls_inds = mlvl_scores[:, i] > score_thr
+        if not bool(cls_inds.any()):
+            continue
+        _scores = mlvl_scores[cls_inds, i]
+        selected, _ = nms(_xyxyr_as_boxes7(mlvl_bboxes_for_nms[cls_inds, :]), _scores, get('nms_thr'))
+        bboxes.append(mlvl_bboxes[cls_inds, :][selected])
+        scores.append(_scores[selected])
+        labels.append(torch.full((len(selected),), i, dtype=torch.long, device=mlvl_bboxes.device))
+        if mlvl_attr_scores is not None:
+            attrs.append(mlvl_attr_scores[cls_inds][selected])
+    if bboxes:
+        bboxes, scores, labels = torch.cat(bboxes, 0), torch.cat(scores, 0), torch.cat(labels, 0)
+        attrs = torch.cat(attrs, 0) if mlvl_attr_scores is not None else None
+        if bboxes.shape[0] > max_num:
+            inds = scores.sort(descending=True)[1][:max_num]
+            bboxes, scores, labels = bboxes[inds, :], scores[inds], labels[inds]
+            attrs = attrs[inds] if attrs is not None else None
+    else:
+        bboxes = mlvl_scores.new_zeros((0, mlvl_bboxes.size(-1)))
+        scores = mlvl_scores.new_zeros((0,))
+        labels = mlvl_scores.new_zeros((0,), dtype=torch.long)
+        attrs = mlvl_scores.new_zeros((0,)) if mlvl_attr_scores is not None else None
+    return (bboxes, scores, labels) + ((attrs,) if mlvl_attr_scores is not None else ())
+
+
+def filter_by_nms(raw_bbox_list, nms_cfg, use_sigmoid_cls, return_labels=False):
+    """bbox_utils.py:203-279: multi-class 3D NMS of (boxes, (n, C) score matrix) pairs that keeps each
+    survivor's FULL score vector (a survivor's class label need not be its arg-max)."""
+    res = []
+    get = nms_cfg.get if isinstance(nms_cfg, dict) else (lambda k, d=None: getattr(nms_cfg, k, d))
+    for bboxes, scores in raw_bbox_list:
+        assert bboxes.tensor.shape[0] == scores.shape[0] and scores.dim() == 2
+        pred = bboxes.tensor
+        nms_pre = get('nms_pre', -1)
+        if nms_pre > 0 and scores.shape[0] > nms_pre:
+            max_scores = scores.max(dim=1)[0] if use_sigmoid_cls else scores[:, :-1].max(dim=1)[0]
+            topk = max_scores.topk(nms_pre)[1]
+            pred, scores = pred[topk, :], scores[topk, :]
+        for_nms = xywhr2xyxyr(type(bboxes)(pred, box_dim=pred.shape[-1]).bev)
+        scores_for_nms = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1) if use_sigmoid_cls \
+            else scores
+        idx = torch.arange(len(pred), dtype=torch.float32, device=pred.device)
+        sel_boxes, _, sel_labels, sel_idx = box3d_multiclass_nms(pred, for_nms, scores_for_nms, get('score_thr', 0),
+                                                                 get('max_num'), nms_cfg, mlvl_attr_scores=idx)
+        sel_idx = sel_idx.long()
+        out = (type(bboxes)(sel_boxes, box_dim=sel_boxes.shape[-1]), scores[sel_idx])
+        res.append(out + ((sel_labels,) if return_labels else ()))
+    return res

@@ -242,3 +242,40 @@ def test_pretrain_recipes_run_through_epoch_based_runner(dev, recipe):
         assert len(r.log_buffer['grad_norm']) == 6
         g = r.optimizer.param_groups[0]
         assert g['lr'] != g['initial_lr'] and g['betas'][0] != 0.9      # cyclic schedules are live
+
+
+def test_filter_by_nms_3d_multiclass(dev):
+    """ssl_modules/bbox_utils.py:203-279 + core/post_processing/box3d_nms.py: per-class rotated BEV NMS;
+    the kept set per class equals the oracle's greedy NMS on the same rotated rectangles, survivors keep
+    their full score vectors and the score threshold / max_num are honoured."""
+    import oracle
+    from detmatch_amd.mm3d.bbox_utils import filter_by_nms
+    from detmatch_amd.mm3d.box3d import LiDARInstance3DBoxes
+    rng = np.random.default_rng(0)
+    n = 300
+    base = np.stack([rng.uniform(5, 40, 40), rng.uniform(-15, 15, 40), rng.uniform(-1.8, -1.2, 40),
+                     rng.uniform(1.4, 2.0, 40), rng.uniform(3.2, 4.6, 40), rng.uniform(1.4, 1.8, 40),
+                     rng.uniform(-3.1, 3.1, 40)], 1)
+    b = (base[rng.integers(0, 40, n)] + rng.normal(0, 0.25, (n, 7))).astype(np.float32)
+    scores = rng.uniform(0, 1, (n, 3)).astype(np.float32) ** 2
+    boxes = LiDARInstance3DBoxes(torch.from_numpy(b).to(dev))
+    cfg = dict(nms_pre=-1, score_thr=0.3, max_num=60, use_rotate_nms=True, nms_thr=0.3)
+    (kept, kept_scores, kept_labels), = filter_by_nms([(boxes, torch.from_numpy(scores).to(dev))], cfg, True,
+                                                      return_labels=True)
+    assert len(kept) == len(kept_scores) == len(kept_labels) <= 60 and kept_scores.shape[1] == 3
+    bev = boxes.bev.cpu().numpy()                       # (cx, cy, w, h, r)
+    b7 = np.stack([bev[:, 0], bev[:, 1], 0 * bev[:, 0], bev[:, 2], bev[:, 3], 1 + 0 * bev[:, 0], bev[:, 4]], 1)
+    want = []
+    for c in range(3):
+        idx = np.nonzero(scores[:, c] > 0.3)[0]
+        order = idx[np.argsort(-scores[idx, c], kind='stable')]
+        keep = oracle.nms(b7[order].astype(np.float32), 0.3)
+        want += [(float(scores[order[k], c]), c, int(order[k])) for k in keep]
+    want.sort(key=lambda t: -t[0])
+    want = want[:60]
+    got_rows = {(int(l), tuple(np.round(x, 4))) for l, x in zip(kept_labels.cpu().numpy(), kept.tensor.cpu().numpy())}
+    want_rows = {(c, tuple(np.round(b[i], 4))) for _, c, i in want}
+    assert got_rows == want_rows
+    for l, s, x in zip(kept_labels.cpu().numpy(), kept_scores.cpu().numpy(), kept.tensor.cpu().numpy()):
+        i = int(np.argmin(np.abs(b - x).sum(1)))
+        assert np.allclose(s, scores[i]) and s[l] > 0.3          # the FULL score vector of the survivor
