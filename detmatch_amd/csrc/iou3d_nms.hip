@@ -13,6 +13,8 @@
 //     greedy pass never reads the others, iou3d_nms.cpp:122-133);
 //   * the greedy pass runs on the device (one wave, remv[] words spread over lanes);
 //     nothing is copied to the host, num_keep stays in device memory.
+#include <cstdlib>
+
 #include "dm_common.h"
 
 namespace {
@@ -268,6 +270,88 @@ __global__ __launch_bounds__(64) void nms_mask(const float *boxes, const float2 
   }
 }
 
+// Rotated variant with a load-balanced tile.  A score-sorted tile holds boxes from all over the scene:
+// of its 4096 pairs only the few whose bounding circles touch can overlap at all, but in the plain loop
+// above a wave pays for the polygon clipping of column i as soon as ONE of its 64 rows is near it.
+// Stage 1: every lane tests its row against the 64 columns by centre distance (exact: pairs farther
+// apart than r_a + r_b + 5 cm have no intersection point and no corner inside the other box even with
+// the reference's 1 cm containment margin, so their overlap is 0 and the bit is 0).  Stage 2: the
+// surviving (row, column) candidates of the whole tile are dealt out evenly to the 64 lanes.
+__device__ __forceinline__ int select_bit(unsigned long long word, int k) {   // index of the k-th set bit
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const int c = __popcll(word & (((1ull << w) - 1ull) << pos));
+    if (k >= c) {
+      k -= c;
+      pos += w;
+    }
+  }
+  return pos;
+}
+
+__global__ __launch_bounds__(64) void nms_mask_rot(const float *boxes, const float2 *cs, int n, float thresh,
+                                                   unsigned long long *mask, int col_begin,
+                                                   const int *num_keep, int max_keep) {
+  const int row_start = blockIdx.y, col_start = blockIdx.x + col_begin;
+  if (col_start < row_start) return;
+  if (num_keep && *num_keep >= max_keep) return;
+  const int col_blocks = (n + 63) / 64;
+  const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+  __shared__ float rb[64 * 7], cbx[64 * 7];
+  __shared__ float2 rcs[64], ccs[64];
+  __shared__ float rrad[64], crad[64];
+  __shared__ unsigned long long cand[64], res[64];
+  __shared__ int pre[65];
+  const int t = threadIdx.x;
+  if (t < row_size) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) rb[t * 7 + j] = boxes[(size_t)(64 * row_start + t) * 7 + j];
+    rcs[t] = cs[64 * row_start + t];
+    rrad[t] = 0.5f * sqrtf(rb[t * 7 + 3] * rb[t * 7 + 3] + rb[t * 7 + 4] * rb[t * 7 + 4]);
+  }
+  if (t < col_size) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) cbx[t * 7 + j] = boxes[(size_t)(64 * col_start + t) * 7 + j];
+    ccs[t] = cs[64 * col_start + t];
+    crad[t] = 0.5f * sqrtf(cbx[t * 7 + 3] * cbx[t * 7 + 3] + cbx[t * 7 + 4] * cbx[t * 7 + 4]);
+  }
+  res[t] = 0ull;
+  __syncthreads();
+  unsigned long long c = 0ull;
+  if (t < row_size) {
+    const float x = rb[t * 7], y = rb[t * 7 + 1], r0 = rrad[t] + 0.05f;
+    const int start = (row_start == col_start) ? t + 1 : 0;
+    for (int i = start; i < col_size; i++) {
+      const float dx = x - cbx[i * 7], dy = y - cbx[i * 7 + 1], rr = r0 + crad[i];
+      if (!(dx * dx + dy * dy > rr * rr)) c |= 1ull << i;     // NaN-safe: unordered -> candidate
+    }
+  }
+  cand[t] = c;
+  int incl = __popcll(c);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (t >= o) incl += up;
+  }
+  pre[t + 1] = incl;
+  if (t == 0) pre[0] = 0;
+  __syncthreads();
+  const int total = pre[64];
+  for (int p = t; p < total; p += 64) {
+    int lo = 0, hi = 63;                         // largest row with pre[row] <= p
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pre[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const int col = select_bit(cand[lo], p - pre[lo]);
+    const float v = iou_bev(rb + lo * 7, rcs[lo], cbx + col * 7, ccs[col]);
+    if (v > thresh) atomicOr(&res[lo], 1ull << col);
+  }
+  __syncthreads();
+  if (t < row_size) mask[(size_t)(64 * row_start + t) * col_blocks + col_start] = res[t];
+}
+
 // Greedy pass (iou3d_nms.cpp:117-133) by ONE wave: lane l owns remv words l, l+64, ...
 // Boxes are resolved 64 at a time.  Inside a block of 64 the decisions depend only on the
 // block's diagonal mask word of each box (one coalesced load, one word per lane) and are taken
@@ -419,6 +503,8 @@ static int nms_lead_blocks(int n, int max_keep) {
   return lead < col_blocks ? lead : col_blocks;
 }
 
+static bool g_nms_plain = false;   // tuning aid (DM_NMS_PLAIN=1): the one-row-per-lane mask kernel
+
 static int nms_launch(bool normal, const float *boxes, int n, float thresh, int max_keep,
                       long long *keep, int *num_keep, void *ws, size_t ws_bytes, hipStream_t st) {
   if (n < 0 || !num_keep) return DM_ERR_INVALID_ARG;
@@ -428,6 +514,10 @@ static int nms_launch(bool normal, const float *boxes, int n, float thresh, int 
   }
   if (n > 64 * 64 * 16) return DM_ERR_UNSUPPORTED;
   if (!boxes || !keep || !ws) return DM_ERR_INVALID_ARG;
+  {
+    static const bool plain = getenv("DM_NMS_PLAIN") && getenv("DM_NMS_PLAIN")[0] == '1';
+    g_nms_plain = plain;
+  }
   if (ws_bytes < dm_nms_workspace_bytes(n)) return DM_ERR_WORKSPACE;
   if (max_keep <= 0 || max_keep > n) max_keep = n;
   int col_blocks = (n + 63) / 64;
@@ -446,7 +536,8 @@ static int nms_launch(bool normal, const float *boxes, int n, float thresh, int 
     dim3 g(c1 - c0, c1);
     const int *flag = phase == 0 ? nullptr : num_keep;
     if (normal) nms_mask<true><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
-    else nms_mask<false><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
+    else if (g_nms_plain) nms_mask<false><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
+    else nms_mask_rot<<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
     DM_CHECK_LAUNCH();
     nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep, c0, c1, phase);
   }
