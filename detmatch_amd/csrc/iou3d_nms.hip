@@ -410,6 +410,16 @@ __global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *__res
     const int lim = min(64, n - blk * 64);
     const unsigned long long diag =
         lane < lim ? mask[(size_t)(blk * 64 + lane) * col_blocks + blk] : 0ull;
+    // Word `lane` (slot 0: blocks 0..63, where the survivor budget is normally met) of ALL 64 rows of
+    // this block, requested before the decisions are known: the loads do not depend on the resolve
+    // loop below and complete underneath it, instead of one gather round per 8 survivors afterwards.
+    unsigned long long t0[64];
+    {
+      const bool in0 = lane > blk && lane < blk_end && lane < col_blocks;
+#pragma unroll
+      for (int u = 0; u < 64; ++u)
+        t0[u] = (in0 && u < lim) ? mask[(size_t)(blk * 64 + u) * col_blocks + lane] : 0ull;
+    }
     unsigned long long alive = ~word & (lim == 64 ? ~0ull : ((1ull << lim) - 1ull));
     unsigned long long survivors = 0ull;
     while (alive != 0ull && kept < max_keep) {
@@ -419,29 +429,38 @@ __global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *__res
       ++kept;
       alive &= ~(wave_bcast64(diag, b) | (1ull << b));
     }
-    // OR the survivors' rows into the words of the blocks still to come
-    while (survivors != 0ull) {
-      const unsigned long long *rows[8];
-      int cnt = 0;
+    {
+      unsigned long long acc = 0ull;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        rows[u] = mask;
-        if (survivors != 0ull) {
-          const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(survivors));
-          survivors &= survivors - 1ull;
-          rows[u] = mask + (size_t)(blk * 64 + b) * col_blocks;
-          cnt = u + 1;
+      for (int u = 0; u < 64; ++u) acc |= ((survivors >> u) & 1ull) ? t0[u] : 0ull;
+      remv[0] |= acc;
+    }
+    // slots >= 1 (boxes beyond 4096: only reached when the budget was not met among the leading
+    // blocks): gather the survivors' rows, 8 at a time
+    if (col_blocks > 64 && blk_end > 64) {
+      while (survivors != 0ull) {
+        const unsigned long long *rows[8];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          rows[u] = mask;
+          if (survivors != 0ull) {
+            const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(survivors));
+            survivors &= survivors - 1ull;
+            rows[u] = mask + (size_t)(blk * 64 + b) * col_blocks;
+            cnt = u + 1;
+          }
         }
-      }
 #pragma unroll
-      for (int w = 0; w < MAXW; ++w) {
-        if (w * 64 >= col_blocks) break;
-        const int j = w * 64 + lane;
-        const bool in = j > blk && j < blk_end;
-        unsigned long long t[8];
+        for (int w = 1; w < MAXW; ++w) {
+          if (w * 64 >= col_blocks) break;
+          const int j = w * 64 + lane;
+          const bool in = j > blk && j < blk_end;
+          unsigned long long t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = (in && u < cnt) ? rows[u][j] : 0ull;
-        remv[w] |= ((t[0] | t[1]) | (t[2] | t[3])) | ((t[4] | t[5]) | (t[6] | t[7]));
+          for (int u = 0; u < 8; ++u) t[u] = (in && u < cnt) ? rows[u][j] : 0ull;
+          remv[w] |= ((t[0] | t[1]) | (t[2] | t[3])) | ((t[4] | t[5]) | (t[6] | t[7]));
+        }
       }
     }
   }
