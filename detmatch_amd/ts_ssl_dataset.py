@@ -11,10 +11,13 @@ Normalize, Pad to a multiple of 32) with torch ops on the device.
 dict(stu=..., tea=..., img_metas=...) with `points` / `gt_bboxes_3d` / `gt_labels_3d` / `gt_bboxes` /
 `gt_labels` lists, a stacked `img` tensor and the img_metas keys the SSL modules replay.
 
-Not restated (documented gaps): `ObjectSample` GT-paste (needs the db-info crops and numba collision
-tests), the student-only photometric augmentations (torchvision ColorJitter / Grayscale / GaussianBlur /
-RandomErasing — they do not move boxes), mmcv's cv2 interpolation (torch bilinear here).  mmdet / mmcv
-transform semantics are un-vendored: parity unpinned for the 2D side."""
+The student-only photometric chain of split_0.py:586-625 (torchvision ColorJitter p .8, RandomGrayscale
+p .2, SimCLR GaussianBlur p .5, three RandomErasing with random fill) is `StudentPhotometric`: the same
+parameter draws, evaluated with torch ops on the device (true Gaussian kernel instead of PIL's box
+approximation; erased patches filled with clamped noise).
+
+Not restated (documented gap): `ObjectSample` GT-paste (needs the db-info crops and numba collision
+tests).  mmdet / mmcv / torchvision transform semantics are un-vendored: parity unpinned for the 2D side."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -39,7 +42,7 @@ class ImageResizeFlipNormPad(object):
         shorts = [min(s) for s in self.img_scale]
         return (int(rng.randint(min(longs), max(longs) + 1)), int(rng.randint(min(shorts), max(shorts) + 1)))
 
-    def __call__(self, img, scale, flip):
+    def __call__(self, img, scale, flip, photometric=None):
         h, w = int(img.shape[0]), int(img.shape[1])
         k = min(max(scale) / max(h, w), min(scale) / min(h, w))            # mmcv.rescale_size
         nw, nh = int(w * float(k) + 0.5), int(h * float(k) + 0.5)
@@ -47,6 +50,8 @@ class ImageResizeFlipNormPad(object):
         x = F.interpolate(x, size=(nh, nw), mode='bilinear', align_corners=False)
         if flip:
             x = x.flip(-1)
+        if photometric is not None:        # student only: after the shared Resize / flip, before Normalize
+            x = photometric(x[0]).unsqueeze(0)
         x = (x - x.new_tensor(self.mean).view(1, 3, 1, 1)) / x.new_tensor(self.std).view(1, 3, 1, 1)
         d = self.size_divisor
         ph, pw = (nh + d - 1) // d * d, (nw + d - 1) // d * d
@@ -69,17 +74,96 @@ class ImageResizeFlipNormPad(object):
         return b
 
 
+class StudentPhotometric(object):
+    """split_0.py:586-625 on a (3, H, W) float image in [0, 255] on the device (channel order as stored:
+    the reference hands mmcv's BGR array to torchvision as if it were RGB, so the grey weights hit the
+    same stored channels here).  Formulas: torchvision.transforms.functional (adjust_brightness /
+    contrast / saturation / hue, rgb_to_grayscale, RandomErasing.get_params)."""
+
+    GREY = (0.299, 0.587, 0.114)
+
+    def __init__(self, jitter=(0.4, 0.4, 0.4, 0.1), p_jitter=0.8, p_grey=0.2, blur_sigma=(0.1, 2.0), p_blur=0.5,
+                 erasing=((0.7, (0.05, 0.2), (0.3, 3.3)), (0.5, (0.02, 0.2), (0.1, 6)), (0.3, (0.02, 0.2), (0.05, 8)))):
+        self.jitter, self.p_jitter, self.p_grey = jitter, p_jitter, p_grey
+        self.blur_sigma, self.p_blur, self.erasing = blur_sigma, p_blur, erasing
+
+    def _grey(self, x):
+        w = x.new_tensor(self.GREY).view(3, 1, 1)
+        return (x * w).sum(0, keepdim=True)
+
+    @staticmethod
+    def _hue(x, shift):
+        """adjust_hue: RGB -> HSV, h += shift (mod 1), back; x in [0, 1]."""
+        r, g, b = x[0], x[1], x[2]
+        maxc, minc = x.max(0)[0], x.min(0)[0]
+        v = maxc
+        cr = maxc - minc
+        s = cr / torch.where(maxc == 0, torch.ones_like(maxc), maxc)
+        crd = torch.where(cr == 0, torch.ones_like(cr), cr)
+        rc, gc, bc = (maxc - r) / crd, (maxc - g) / crd, (maxc - b) / crd
+        h = torch.where(maxc == r, bc - gc, torch.where(maxc == g, 2.0 + rc - bc, 4.0 + gc - rc))
+        h = torch.where(cr == 0, torch.zeros_like(h), h)
+        h = ((h / 6.0 + 1.0) % 1.0 + shift) % 1.0
+        i = torch.floor(h * 6.0)
+        f = h * 6.0 - i
+        i = i.long() % 6
+        p, q, t = v * (1 - s), v * (1 - f * s), v * (1 - (1 - f) * s)
+        sel = lambda opts: torch.stack(opts, 0).gather(0, i.unsqueeze(0)).squeeze(0)
+        return torch.stack([sel([v, q, p, p, t, v]), sel([t, v, v, q, p, p]), sel([p, p, t, v, v, q])], 0)
+
+    def __call__(self, img, rng, generator=None):
+        x = img / 255.0
+        if rng.rand() < self.p_jitter:
+            b, c, s, h = self.jitter
+            fb, fc = rng.uniform(1 - b, 1 + b), rng.uniform(1 - c, 1 + c)
+            fs, fh = rng.uniform(1 - s, 1 + s), rng.uniform(-h, h)
+            for op in rng.permutation(4):
+                if op == 0:
+                    x = (x * fb).clamp(0, 1)
+                elif op == 1:
+                    x = (fc * x + (1 - fc) * self._grey(x).mean()).clamp(0, 1)
+                elif op == 2:
+                    x = (fs * x + (1 - fs) * self._grey(x)).clamp(0, 1)
+                else:
+                    x = self._hue(x, fh)
+        if rng.rand() < self.p_grey:
+            x = self._grey(x).expand(3, -1, -1).contiguous()
+        if rng.rand() < self.p_blur:
+            sigma = rng.uniform(*self.blur_sigma)
+            r = max(int(3 * sigma + 0.5), 1)
+            k = torch.exp(-0.5 * (torch.arange(-r, r + 1, device=x.device, dtype=x.dtype) / sigma) ** 2)
+            k = k / k.sum()
+            y = F.pad(x.unsqueeze(0), (r, r, r, r), mode='replicate')
+            y = F.conv2d(y, k.view(1, 1, 1, -1).expand(3, 1, 1, -1), groups=3)
+            x = F.conv2d(y, k.view(1, 1, -1, 1).expand(3, 1, -1, 1), groups=3)[0]
+        hh, ww = x.shape[1], x.shape[2]
+        for p, scale, ratio in self.erasing:
+            if rng.rand() >= p:
+                continue
+            for _ in range(10):
+                area = hh * ww * rng.uniform(*scale)
+                aspect = float(np.exp(rng.uniform(np.log(ratio[0]), np.log(ratio[1]))))
+                eh, ew = int(round(np.sqrt(area * aspect))), int(round(np.sqrt(area / aspect)))
+                if eh < hh and ew < ww:
+                    i, j = rng.randint(0, hh - eh + 1), rng.randint(0, ww - ew + 1)
+                    noise = torch.randn((3, eh, ew), device=x.device, dtype=x.dtype, generator=generator)
+                    x[:, i:i + eh, j:j + ew] = noise.clamp(0, 1)
+                    break
+        return (x * 255.0).round().clamp(0, 255)            # TVToPILImage: back to 8-bit levels
+
+
 class TSSSLDeviceLoader(object):
     """One of the two loaders `IterBasedSSLRunner.run([labeled, unlabeled])` takes."""
 
     def __init__(self, dataset, samples_per_gpu, device, labeled, point_cloud_range, seed=0,
                  rot_range=(-0.78539816, 0.78539816), scale_ratio_range=(0.95, 1.05), flip_ratio=0.5,
-                 img_scale=((640, 192), (2560, 768)), shuffle=True, with_img=True):
+                 img_scale=((640, 192), (2560, 768)), shuffle=True, with_img=True, student_photometric=True):
         self.dataset, self.bs, self.device, self.labeled = dataset, samples_per_gpu, torch.device(device), labeled
         self.rng = np.random.RandomState(seed)
         self.shuffle, self.with_img = shuffle, with_img
         self.flip_ratio = flip_ratio
         self.image_tf = ImageResizeFlipNormPad(img_scale)
+        self.photometric = StudentPhotometric() if student_photometric else None
         self.pipe = P3.TSSSLPipeline3D(
             shared=[P3.RandomFlip3D(sync_2d=True, flip_ratio_bev_horizontal=flip_ratio)],
             student=[P3.GlobalRotScaleTrans(rot_range=list(rot_range), scale_ratio_range=list(scale_ratio_range)),
@@ -104,7 +188,7 @@ class TSSSLDeviceLoader(object):
 
     def batch(self, indices):
         dev, ds = self.device, self.dataset
-        frames, metas2d, imgs = [], [], []
+        frames, imgs, imgs_stu = [], [], []
         for i in indices:
             info = ds.get_data_info(i)
             flip = bool(self.rng.rand() < self.flip_ratio)                 # mmdet RandomFlip's draw
@@ -112,9 +196,13 @@ class TSSSLDeviceLoader(object):
                         box_type_3d=LiDARInstance3DBoxes)
             if self.with_img:
                 raw = torch.from_numpy(ds.load_image(i)).to(dev)
-                img, m2 = self.image_tf(raw, self.image_tf.draw_scale(self.rng), flip)
+                scale = self.image_tf.draw_scale(self.rng)
+                img, m2 = self.image_tf(raw, scale, flip)
                 meta.update(m2)
                 imgs.append(img)
+                if self.photometric is not None:
+                    imgs_stu.append(self.image_tf(raw, scale, flip,
+                                                  photometric=lambda x: self.photometric(x, self.rng))[0])
             f = dict(points=torch.from_numpy(ds.load_points(i)).to(dev), meta=meta)
             if self.labeled:
                 ann = info['ann_info']
@@ -134,8 +222,9 @@ class TSSSLDeviceLoader(object):
         if self.with_img:
             ph = max(int(i.shape[1]) for i in imgs)
             pw = max(int(i.shape[2]) for i in imgs)
-            batch = torch.stack([F.pad(i, (0, pw - i.shape[2], 0, ph - i.shape[1])) for i in imgs])
-            out_s['img'], out_t['img'] = batch, batch            # no photometric student augmentation (see above)
+            stack = lambda lst: torch.stack([F.pad(i, (0, pw - i.shape[2], 0, ph - i.shape[1])) for i in lst])
+            out_t['img'] = stack(imgs)
+            out_s['img'] = stack(imgs_stu) if self.photometric is not None else out_t['img']
             for s, t in zip(out_s['img_metas'], out_t['img_metas']):
                 s['pad_shape'] = t['pad_shape'] = (ph, pw, 3)
         return dict(stu=out_s, tea=out_t, img_metas=out_s['img_metas'])
