@@ -4,7 +4,8 @@
 What runs where:
   * rotated BEV / 3D overlaps: the device kernel of iou3d_nms.hip (`boxes_overlap_bev`) instead of the
     reference's numba-CUDA `rotate_iou_gpu_eval` (kitti_utils/rotate_iou.py); camera-frame boxes
-    (x, z, l, w, ry) — an overlap area does not depend on the handedness of the angle convention.
+    (x, z, l, w, ry).  rotate_iou.py turns its corners CLOCKWISE by the angle (:205-227), the device kernel
+    counter-clockwise by the heading: the boxes are handed over with heading = -ry.
     No CPU path: BEV / 3D metrics raise without the GPU;
   * the greedy per-image matching (numba `compute_statistics_jit` / `fused_compute_statistics`,
     eval.py:161-338): dm_kitti_tp_scores_host / dm_kitti_pr_host, one call per (class, difficulty,
@@ -91,7 +92,7 @@ def _bev_intersection(boxes, qboxes):
     def as7(b):
         b = torch.as_tensor(np.asarray(b, dtype=np.float32), device=dev)
         z = torch.zeros_like(b[:, :1])
-        return torch.cat([b[:, 0:2], z, b[:, 2:4], z + 1, b[:, 4:5]], dim=1).contiguous()
+        return torch.cat([b[:, 0:2], z, b[:, 2:4], z + 1, -b[:, 4:5]], dim=1).contiguous()
     if len(boxes) == 0 or len(qboxes) == 0:
         return np.zeros((len(boxes), len(qboxes)), dtype=np.float64)
     return iou3d_nms.boxes_overlap_bev(as7(boxes), as7(qboxes)).double().cpu().numpy()

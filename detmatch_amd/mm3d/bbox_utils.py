@@ -236,10 +236,12 @@ def xywhr2xyxyr(boxes_xywhr):
 
 
 def _xyxyr_as_boxes7(b):
-    """(x1,y1,x2,y2,r) rotated BEV rectangles as the 7-value boxes the device NMS takes."""
+    """(x1,y1,x2,y2,r) rotated BEV rectangles as the 7-value boxes the device NMS takes.  mmdet3d's
+    iou3d kernel turns its corners CLOCKWISE by r (mmdet3d/ops/iou3d/src/iou3d_kernel.cu:111-118), the
+    device NMS counter-clockwise by the heading: heading = -r."""
     z = torch.zeros_like(b[:, :1])
     return torch.cat([(b[:, 0:1] + b[:, 2:3]) / 2, (b[:, 1:2] + b[:, 3:4]) / 2, z, b[:, 2:3] - b[:, 0:1],
-                      b[:, 3:4] - b[:, 1:2], z + 1, b[:, 4:5]], dim=1)
+                      b[:, 3:4] - b[:, 1:2], z + 1, -b[:, 4:5]], dim=1)
 
 
 def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg,

@@ -157,13 +157,19 @@ class TSSSLDeviceLoader(object):
 
     def __init__(self, dataset, samples_per_gpu, device, labeled, point_cloud_range, seed=0,
                  rot_range=(-0.78539816, 0.78539816), scale_ratio_range=(0.95, 1.05), flip_ratio=0.5,
-                 img_scale=((640, 192), (2560, 768)), shuffle=True, with_img=True, student_photometric=True):
+                 img_scale=((640, 192), (2560, 768)), shuffle=True, with_img=True, student_photometric=True,
+                 db_sampler=None):
         self.dataset, self.bs, self.device, self.labeled = dataset, samples_per_gpu, torch.device(device), labeled
         self.rng = np.random.RandomState(seed)
         self.shuffle, self.with_img = shuffle, with_img
         self.flip_ratio = flip_ratio
         self.image_tf = ImageResizeFlipNormPad(img_scale)
         self.photometric = StudentPhotometric() if student_photometric else None
+        # ObjectSample(db_sampler) of the labeled shared pipeline (split_0.py:570): GT-paste before the flip
+        self.object_sample = None
+        if db_sampler is not None and labeled:
+            from .dbsampler import ObjectSample
+            self.object_sample = db_sampler if isinstance(db_sampler, ObjectSample) else ObjectSample(db_sampler)
         self.pipe = P3.TSSSLPipeline3D(
             shared=[P3.RandomFlip3D(sync_2d=True, flip_ratio_bev_horizontal=flip_ratio)],
             student=[P3.GlobalRotScaleTrans(rot_range=list(rot_range), scale_ratio_range=list(scale_ratio_range)),
@@ -209,6 +215,13 @@ class TSSSLDeviceLoader(object):
                 f['gt_bboxes_3d'] = ann['gt_bboxes_3d']
                 f['gt_labels_3d'] = torch.from_numpy(ann['gt_labels_3d'])
                 f['bboxes'], f['labels'] = torch.from_numpy(ann['bboxes']), torch.from_numpy(ann['labels'])
+                if self.object_sample is not None:       # pasted objects get no 2D box (sample_2d=False)
+                    calib = ds.data_infos[i].get('calib')
+                    if calib is not None:
+                        f['calib'] = calib
+                    if 'road_plane' in ds.data_infos[i]:
+                        f['road_plane'] = ds.data_infos[i]['road_plane']
+                    f = self.object_sample(f)
             frames.append(f)
         stu, tea = self.pipe(frames, self.rng)
         out_s = dict(points=[s['points'] for s in stu], img_metas=[s['img_metas'] for s in stu])
