@@ -80,3 +80,25 @@ def test_mlvl_helpers():
     assert mlvl_get(d, 'a.b.c') == 1 and mlvl_get(d, 'a.x.c', 5) == 5
     with pytest.raises(Exception):
         mlvl_set(d, 'a.b.c', 2)
+
+
+def test_mm3d_pcdet_conversion_keeps_the_box_geometry():
+    """openpcdet.py:100-122 / :211-224: the converted box covers the same eight corners.  Both corner
+    functions are pinned to the reference's outputs (LiDARInstance3DBoxes.corners in ssl_geometry.npz,
+    boxes_to_corners_3d in pcdet_torch.npz), so this pins the conversion formulas geometrically."""
+    import numpy as np
+    import torch
+    from detmatch_amd.mm3d.box3d import LiDARInstance3DBoxes
+    from detmatch_amd.mm3d.openpcdet import mm3d_to_pcdet_boxes, pcdet_to_mm3d_boxes
+    from detmatch_amd.pcdet.utils import boxes_to_corners_3d
+    rng = np.random.default_rng(0)
+    b = np.stack([rng.uniform(0, 70, 30), rng.uniform(-40, 40, 30), rng.uniform(-2, 0, 30), rng.uniform(0.5, 2, 30),
+                  rng.uniform(0.6, 5, 30), rng.uniform(1, 2, 30), rng.uniform(-6, 6, 30)], 1).astype(np.float32)
+    mm = LiDARInstance3DBoxes(torch.from_numpy(b))
+    pc = mm3d_to_pcdet_boxes(mm)
+    srt = lambda c: np.sort(np.round(c.reshape(30, 8, 3).numpy().astype(np.float64), 3).view([('', np.float64)] * 3),
+                            axis=1).view(np.float64).reshape(30, 8, 3)
+    np.testing.assert_allclose(srt(boxes_to_corners_3d(pc)), srt(mm.corners), atol=2e-3)
+    back = pcdet_to_mm3d_boxes(pc)
+    np.testing.assert_allclose(srt(back.corners), srt(mm.corners), atol=2e-3)
+    assert float(pc[:, 6].min()) >= -np.pi - 1e-5 and float(pc[:, 6].max()) < np.pi + 1e-5   # limit_period(., .5, 2 pi)
