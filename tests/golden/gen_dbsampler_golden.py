@@ -122,6 +122,16 @@ def main():
             print('call %d: pasted %d objects %s, %d points; %d scene points removed' % (
                 call, len(ret['gt_labels_3d']), ret['gt_labels_3d'].tolist(), len(out[k + 'points']),
                 int((~out[k + 'scene_keep']).sum())))
+    # road-plane placement (dbsampler.py:192-243) with the calibration of the reference's KITTI fixture frame
+    lp = sys.modules['mmdet3d.core.points.lidar_points']
+    calib = pickle.load(open('/root/reference/tests/data/kitti/kitti_infos_train.pkl', 'rb'))[0]['calib']
+    rb = out['call0_boxes'].copy()
+    pts = [lp.LiDARPoints(torch.from_numpy(out['call0_points'][i * 20:(i + 1) * 20].copy()), points_dim=4)
+           for i in range(len(rb))]
+    plane = np.array([0.01, -0.999, 0.02, 1.62], dtype=np.float32)
+    nb, npts = sampler.put_boxes_on_road_planes(rb, pts, dict(calib=calib, road_plane=plane))
+    out.update(rp_plane=plane, rp_boxes=nb, rp_points=np.concatenate([p.tensor.numpy() for p in npts]),
+               rp_R0=calib['R0_rect'], rp_Tr=calib['Tr_velo_to_cam'])
     np.savez_compressed(os.path.join(HERE, 'dbsampler.npz'), **out)
     print('database: %s objects; wrote dbsampler.npz' % {c: len(v) for c, v in infos.items()})
 
