@@ -135,6 +135,17 @@ def indice_conv_backward(features, filters, out_grad, indice_pairs, indice_num, 
 
 
 # ---------------------------------------------------------------- iou3d / nms
+class host_libm_trig(object):
+    """Context manager: evaluate cos/sin/atan2 of the box code with the FLOAT libm functions, as
+    the compiled reference (g++: cos(float) -> cosf) does; default = correctly rounded."""
+
+    def __enter__(self):
+        lib().orc_set_trig_mode(1)
+
+    def __exit__(self, *a):
+        lib().orc_set_trig_mode(0)
+
+
 def boxes_overlap_bev(a, b):
     a, b = _f32(a), _f32(b)
     out = np.empty((a.shape[0], b.shape[0]), np.float32)

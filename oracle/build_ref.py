@@ -10,9 +10,18 @@ has.
     mmdet3d/ops/voxel/src/voxelization_cpu.cpp    (hard_voxelize_cpu :105)
     mmdet3d/ops/voxel/src/scatter_points_cpu.cpp  (symbol needed by the module)
 
-The reference's spconv and iou3d_nms CPU sources are NOT buildable under the
-no-stand-in rule (every file includes <cuda_runtime_api.h> / <cuda.h>, which this
-image lacks) — see DESIGN.md §Oracle.
+Round 2: the sparse-conv and BEV-IoU CPU sources are built too.  They include
+<cuda_runtime_api.h> / <cuda.h>; the image ships the REAL headers inside the triton wheel
+(triton/backends/nvidia/include), which is put on the include path — nothing is patched and
+no stand-in header is written:
+
+    spconv_ref   oracle/ref_spconv_driver.cc (own driver) + the reference's
+                 mmdet3d/ops/spconv/include/spconv/geometry.h (getIndicePairsConv :145,
+                 getIndicePairsSubM :248) and mmdet3d/ops/spconv/src/reordering.cc (CPU
+                 gather / scatter-add functors :21-50)
+    iou3d_ref    oracle/ref_iou3d_driver.cc (own 10-line pybind stub) + the reference's
+                 thirdparty/Spconv-OpenPCDet/pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp
+                 (boxes_iou_bev_cpu :232)
 """
 import importlib.util
 import os
@@ -30,11 +39,25 @@ def ref_sources():
             ('voxelization.cpp', 'voxelization_cpu.cpp', 'scatter_points_cpu.cpp')]
 
 
-def so_path():
+SPCONV_NAME = 'spconv_ref'
+IOU3D_NAME = 'iou3d_ref'
+
+
+def _cuda_include():
+    """The real CUDA runtime headers the image ships (triton wheel); None if absent."""
+    try:
+        import triton
+    except Exception:
+        return None
+    d = os.path.join(os.path.dirname(triton.__file__), 'backends', 'nvidia', 'include')
+    return d if os.path.exists(os.path.join(d, 'cuda_runtime_api.h')) else None
+
+
+def so_path(name=NAME):
     if not os.path.isdir(OUT_DIR):
         return None
     for f in os.listdir(OUT_DIR):
-        if f.startswith(NAME) and f.endswith('.so'):
+        if f.startswith(name) and f.endswith('.so'):
             return os.path.join(OUT_DIR, f)
     return None
 
@@ -52,13 +75,72 @@ def build(verbose=False):
     return so_path()
 
 
-def load_ref():
-    """Import the compiled reference module, or None when it is not available."""
-    path = so_path()
+def build_spconv(verbose=False):
+    """oracle/_ref/spconv_ref*.so: own driver + the reference's geometry.h / reordering.cc."""
+    if so_path(SPCONV_NAME) is not None:
+        return so_path(SPCONV_NAME)
+    inc = _cuda_include()
+    if not os.path.isdir(REF_ROOT) or inc is None:
+        return None
+    from torch.utils.cpp_extension import load
+    sp = os.path.join(REF_ROOT, 'mmdet3d/ops/spconv')
+    out = os.path.join(OUT_DIR, SPCONV_NAME + '_build')
+    os.makedirs(out, exist_ok=True)
+    load(name=SPCONV_NAME, sources=[os.path.join(_HERE, 'ref_spconv_driver.cc'),
+                                    os.path.join(sp, 'src/reordering.cc')],
+         extra_include_paths=[os.path.join(sp, 'include'), inc], build_directory=out,
+         extra_cflags=['-O2', '-w', '-std=c++17'], verbose=verbose, is_python_module=True)
+    _hoist(out, SPCONV_NAME)
+    return so_path(SPCONV_NAME)
+
+
+def build_iou3d(verbose=False):
+    """oracle/_ref/iou3d_ref*.so: the reference's iou3d_cpu.cpp + an own pybind stub."""
+    if so_path(IOU3D_NAME) is not None:
+        return so_path(IOU3D_NAME)
+    inc = _cuda_include()
+    if not os.path.isdir(REF_ROOT) or inc is None:
+        return None
+    from torch.utils.cpp_extension import load
+    src = os.path.join(REF_ROOT, 'thirdparty/Spconv-OpenPCDet/pcdet/ops/iou3d_nms/src')
+    out = os.path.join(OUT_DIR, IOU3D_NAME + '_build')
+    os.makedirs(out, exist_ok=True)
+    load(name=IOU3D_NAME, sources=[os.path.join(_HERE, 'ref_iou3d_driver.cc'),
+                                   os.path.join(src, 'iou3d_cpu.cpp')],
+         extra_include_paths=[src, inc], build_directory=out,
+         extra_cflags=['-O2', '-w', '-std=c++17'], verbose=verbose, is_python_module=True)
+    _hoist(out, IOU3D_NAME)
+    return so_path(IOU3D_NAME)
+
+
+def _hoist(build_dir, name):
+    """Keep only the .so (next to the voxel one); the ninja scratch dir is not needed."""
+    import shutil
+    for f in os.listdir(build_dir):
+        if f.startswith(name) and f.endswith('.so'):
+            shutil.copy2(os.path.join(build_dir, f), os.path.join(OUT_DIR, f))
+    shutil.rmtree(build_dir, ignore_errors=True)
+
+
+def build_all(verbose=False):
+    """Every reference-compiled checker that can be built here; returns {name: path|None}."""
+    out = {}
+    for name, fn in ((NAME, build), (SPCONV_NAME, build_spconv), (IOU3D_NAME, build_iou3d)):
+        try:
+            out[name] = fn(verbose=verbose)
+        except Exception as e:      # optional test infrastructure
+            print('[oracle/_ref] %s not built: %s' % (name, e), file=sys.stderr)
+            out[name] = None
+    return out
+
+
+def load_ref(name=NAME):
+    """Import a compiled reference module, or None when it is not available."""
+    path = so_path(name)
     if path is None:
         return None
     import torch  # noqa: F401  (libtorch must be loaded first)
-    spec = importlib.util.spec_from_file_location(NAME, path)
+    spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -83,5 +165,4 @@ def ref_hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
 
 
 if __name__ == '__main__':
-    p = build(verbose='-v' in sys.argv)
-    print('oracle/_ref:', p)
+    print('oracle/_ref:', build_all(verbose='-v' in sys.argv))

@@ -344,9 +344,19 @@ void orc_indice_conv_backward(const float *features, int n_in, const float *filt
  * (iou3d_cpu.cpp, C <math.h>) evaluates them in double and rounds to float.
  * Oracle and HIP kernel both use "double libm, round to float" so that results
  * agree wherever the double result is not within 2^-29 of a float tie. */
-static float cosf_d(float x) { return (float)cos((double)x); }
-static float sinf_d(float x) { return (float)sin((double)x); }
-static float atan2f_d(float y, float x) { return (float)atan2((double)y, (double)x); }
+/* Round 2: compiling the reference's iou3d_cpu.cpp here (oracle/_ref) showed that g++ resolves
+ * its cos(float) / sin(float) / atan2(float, float) to the FLOAT libm overloads (cosf ...), which
+ * are not correctly rounded everywhere: 1 box in ~500 gets a 1-ulp different cosine and its IoUs
+ * move by up to 2e-6.  orc_set_trig_mode(1) selects the float libm calls, with which this file
+ * reproduces the compiled reference bit for bit (tests/test_oracle_ops.py); the default mode 0
+ * (correctly rounded) is what the HIP pre-pass computes. */
+static int g_trig_mode = 0;
+void orc_set_trig_mode(int m) { g_trig_mode = m; }
+static float cosf_d(float x) { return g_trig_mode ? cosf(x) : (float)cos((double)x); }
+static float sinf_d(float x) { return g_trig_mode ? sinf(x) : (float)sin((double)x); }
+static float atan2f_d(float y, float x) {
+  return g_trig_mode ? atan2f(y, x) : (float)atan2((double)y, (double)x);
+}
 
 typedef struct {
   float x, y;

@@ -69,6 +69,9 @@ void orc_indice_conv_backward(const float *features, int n_in, const float *filt
 float orc_box_overlap(const float *a, const float *b);
 float orc_iou_bev(const float *a, const float *b);
 void orc_boxes_overlap_bev(const float *a, int na, const float *b, int nb, float *out);
+/* 0 (default): cos/sin/atan2 correctly rounded (double libm -> float), as the HIP pre-pass;
+ * 1: float libm (cosf ...), what the reference's iou3d_cpu.cpp compiles to under g++. */
+void orc_set_trig_mode(int mode);
 void orc_boxes_iou_bev(const float *a, int na, const float *b, int nb, float *out);
 /* iou3d_nms_kernel.cu:267-311 (mask) + iou3d_nms.cpp:91-137 (greedy).  boxes must
  * already be sorted by descending score.  keep (n) int64.  Returns num_to_keep. */

@@ -301,3 +301,43 @@ def test_fused_bn_relu_rows_matches_torch(dev, n, c, relu):
     ref.eval()
     ze = ref(x.detach().double())
     assert torch.allclose(ye.double(), torch.relu(ze) if relu else ze, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# Reference-compiled / reference-held vectors (round 2): HIP against the goldens directly.
+def test_iou_and_nms_equal_compiled_reference(dev):
+    """tests/golden/iou3d_ref.npz (the reference's iou3d_cpu.cpp compiled here,
+    gen_iou3d_golden.py): IoU values within 3e-6 (1-ulp cosine of the heading: the reference's
+    host cosf vs the correctly rounded value of the HIP pre-pass), NMS keep lists bit-exact."""
+    import os
+    from conftest import GOLDEN
+    from detmatch_amd import iou3d_nms
+    g = np.load(os.path.join(GOLDEN, 'iou3d_ref.npz'))
+    ta, tb = torch.from_numpy(g['a']).to(dev), torch.from_numpy(g['b']).to(dev)
+    got = iou3d_nms.boxes_iou_bev(ta, tb).cpu().numpy()
+    np.testing.assert_allclose(got, g['iou'], rtol=0, atol=3e-6)
+    assert (got != g['iou']).mean() < 0.01
+    boxes = g['nms_boxes']
+    n = len(boxes)
+    scores = torch.arange(n, 0, -1, dtype=torch.float32, device=dev)   # already sorted
+    for thr in (0.01, 0.1, 0.7, 0.8):
+        keep, _ = iou3d_nms.nms_gpu(torch.from_numpy(boxes).to(dev), scores, thr)
+        assert np.array_equal(keep.cpu().numpy(), g['keep_%g' % thr]), thr
+
+
+def test_reference_points_in_boxes_kat_gpu(dev):
+    """The reference-held vector of tests/test_models/test_common_modules/test_roiaware_pool3d.py:
+    43-71, mapped to the pcdet box convention as in tests/test_oracle_ops.py."""
+    from detmatch_amd.roiaware_pool3d import points_in_boxes_gpu
+    boxes = np.array([[[1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 0.3]],
+                      [[-10.0, 23.0, 16.0, 10, 20, 20, 0.5]]], np.float32)
+    pts = np.array([[[1, 2, 3.3], [1.2, 2.5, 3.0], [0.8, 2.1, 3.5], [1.6, 2.6, 3.6],
+                     [0.8, 1.2, 3.9], [-9.2, 21.0, 18.2], [3.8, 7.9, 6.3], [4.7, 3.5, -12.2]],
+                    [[3.8, 7.6, -2], [-10.6, -12.9, -20], [-16, -18, 9], [-21.3, -52, -5],
+                     [0, 0, 0], [6, 7, 8], [-2, -3, -4], [6, 4, 9]]], np.float32)
+    pc = boxes.copy()
+    pc[..., 2] = boxes[..., 2] + boxes[..., 5] / 2
+    pc[..., 3], pc[..., 4] = boxes[..., 4], boxes[..., 3]
+    pc[..., 6] = -(boxes[..., 6] + np.float32(np.pi / 2))
+    got = points_in_boxes_gpu(torch.from_numpy(pts).to(dev), torch.from_numpy(pc).to(dev))
+    assert got.cpu().tolist() == [[0, 0, 0, 0, 0, -1, -1, -1], [-1] * 8]

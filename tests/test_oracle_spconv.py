@@ -117,3 +117,136 @@ def test_empty_input(orc):
 def test_int32_limit(orc):
     with pytest.raises(ValueError):
         orc.get_indice_pairs(IDX, 24, SHAPE, [3, 3, 3], [1, 1, 1], [1, 1, 1], subm=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# Reference-compiled goldens (tests/golden/gen_spconv_golden.py: the reference's unpatched
+# geometry.h + reordering.cc built by oracle/build_ref.py).  These pin the oracle's rulebook bit
+# for bit (first-touch order, raw indicePairs bytes) and its conv forward / backward to 1e-5.
+import hashlib  # noqa: E402
+import os  # noqa: E402
+
+from conftest import GOLDEN  # noqa: E402
+
+LAYERS = [
+    ('subm1', True, 4, 16, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('subm1', True, 16, 16, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('spconv2', False, 16, 32, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+    ('subm2', True, 32, 32, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('subm2', True, 32, 32, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('spconv3', False, 32, 64, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+    ('subm3', True, 64, 64, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('subm3', True, 64, 64, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('spconv4', False, 64, 64, [3, 3, 3], [2, 2, 2], [0, 1, 1]),
+    ('subm4', True, 64, 64, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('subm4', True, 64, 64, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+    ('spconv_down2', False, 64, 128, [3, 1, 1], [2, 1, 1], [0, 0, 0]),
+]
+
+
+def layer_weight(li, ks, cin, cout):
+    return (np.random.default_rng(1000 + li).standard_normal(list(ks) + [cin, cout]) * 0.05
+            ).astype(np.float32)
+
+
+def layer_dy(li, shape):
+    return np.random.default_rng(2000 + li).standard_normal(shape).astype(np.float32)
+
+
+def _sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _oracle_books(orc, idx, batch, sort_out=False):
+    books, shape, cur = {}, SHAPE, idx
+    for key, subm, cin, cout, ks, st, pd in LAYERS:
+        if key in books:
+            continue
+        o, p, n, osh = orc.get_indice_pairs(cur, batch, shape, ks, st, pd, subm=subm,
+                                            sort_out=sort_out)
+        if subm:
+            o = cur
+        books[key] = (o, p, n, osh)
+        cur, shape = o, osh
+    return books
+
+
+def test_rulebook_equals_reference_small(orc):
+    g = np.load(os.path.join(GOLDEN, 'spconv_ref_small.npz'))
+    books = _oracle_books(orc, g['indices'], 2)
+    for key, (o, p, n, osh) in books.items():
+        assert osh == g['rb_%s_out_shape' % key].tolist()
+        assert np.array_equal(n, g['rb_%s_num' % key]), key
+        assert np.array_equal(o, g['rb_%s_outids' % key]), key          # first-touch order
+        pin = np.concatenate([p[k, 0, :n[k]] for k in range(len(n))])
+        pout = np.concatenate([p[k, 1, :n[k]] for k in range(len(n))])
+        assert np.array_equal(pin, g['rb_%s_pairs_in' % key]), key      # pair ORDER too
+        assert np.array_equal(pout, g['rb_%s_pairs_out' % key]), key
+
+
+def test_conv_chain_equals_reference_small(orc):
+    """12-layer chain, forward + input gradient + weight gradient vs the reference's
+    gather / torch::mm / scatter-add sequence: <= 1e-5 (MKL vs plain-C summation order)."""
+    g = np.load(os.path.join(GOLDEN, 'spconv_ref_small.npz'))
+    books = _oracle_books(orc, g['indices'], 2)
+    x = g['features']
+    for li, (key, subm, cin, cout, ks, st, pd) in enumerate(LAYERS):
+        o, p, n, osh = books[key]
+        w = layer_weight(li, ks, cin, cout).reshape(-1, cin, cout)
+        y = orc.indice_conv(x, w, p, n, len(o), subm=subm)
+        np.testing.assert_allclose(y, g['l%d_y' % li], rtol=1e-5, atol=1e-5, err_msg='fwd %d' % li)
+        dx, dw = orc.indice_conv_backward(x, w, layer_dy(li, y.shape), p, n, subm=subm)
+        np.testing.assert_allclose(dx, g['l%d_dx' % li], rtol=1e-5, atol=1e-5, err_msg='dx %d' % li)
+        if 'l%d_dw_taps' % li in g:
+            dw = dw[g['l%d_dw_taps' % li]]
+        np.testing.assert_allclose(dw, g['l%d_dw' % li], rtol=1e-5, atol=2e-5, err_msg='dw %d' % li)
+        x = np.maximum(g['l%d_y' % li], 0)        # chain on the reference's activations
+
+
+def test_rulebook_digests_full_frames(orc):
+    """Full KITTI-shaped frames (B=2, 27 k voxels, all 8 rulebooks): the oracle's raw outids and
+    indicePairs arrays hash to the reference's, byte for byte."""
+    from detmatch_amd import synth
+    g = np.load(os.path.join(GOLDEN, 'spconv_ref_full.npz'))
+    feats, coors = [], []
+    for b, s in enumerate(g['seeds']):
+        v, c, n = orc.hard_voxelize(synth.lidar_frame(int(s))['points'], synth.KITTI_VOXEL,
+                                    synth.KITTI_RANGE, 5, 16000)
+        coors.append(np.concatenate([np.full((len(n), 1), b, np.int32), c], 1))
+    idx = np.concatenate(coors).astype(np.int32)
+    assert _sha(idx) == str(g['indices_sha1'])
+    for key, (o, p, n, osh) in _oracle_books(orc, idx, 2).items():
+        assert np.array_equal(n, g['%s_num' % key]), key
+        assert len(o) == int(g['%s_n_out' % key])
+        if not key.startswith('subm'):
+            assert _sha(o) == str(g['%s_outids_sha1' % key]), key
+        assert _sha(p) == str(g['%s_pairs_sha1' % key]), key
+
+
+def test_canonical_digest_is_order_free(orc):
+    """The order-free digests of the golden (what the HIP rulebook, which sorts strided outputs
+    by cell id, is held to) are reproduced by the oracle in its SORTED output mode."""
+    from detmatch_amd import synth
+    g = np.load(os.path.join(GOLDEN, 'spconv_ref_full.npz'))
+    coors = []
+    for b, s in enumerate(g['seeds']):
+        v, c, n = orc.hard_voxelize(synth.lidar_frame(int(s))['points'], synth.KITTI_VOXEL,
+                                    synth.KITTI_RANGE, 5, 16000)
+        coors.append(np.concatenate([np.full((len(n), 1), b, np.int32), c], 1))
+    idx = np.concatenate(coors).astype(np.int32)
+
+    def cells(ids, shape):
+        ids = ids.astype(np.int64)
+        return ((ids[:, 0] * shape[0] + ids[:, 1]) * shape[1] + ids[:, 2]) * shape[2] + ids[:, 3]
+
+    in_ids, in_shape = idx, SHAPE
+    for key, (o, p, n, osh) in _oracle_books(orc, idx, 2, sort_out=True).items():
+        ic, oc = cells(in_ids, in_shape), cells(o, osh)
+        assert _sha(np.sort(oc)) == str(g['%s_canon_out_sha1' % key])
+        h = hashlib.sha1()
+        for k in range(len(n)):
+            i, oo = ic[p[k, 0, :n[k]]], oc[p[k, 1, :n[k]]]
+            order = np.lexsort((oo, i))
+            h.update(np.ascontiguousarray(np.stack([i[order], oo[order]], 1)).tobytes())
+        assert h.hexdigest() == str(g['%s_canon_pairs_sha1' % key]), key
+        in_ids, in_shape = o, osh

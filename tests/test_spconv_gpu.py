@@ -285,3 +285,111 @@ def test_tile_launch_order(orc, dev, subm, monkeypatch):
     assert torch.equal(out, out0) and torch.equal(dx, dx0)
     want = orc.indice_conv(feats, w, p, nn, len(o), subm=subm)
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
+# ---------------------------------------------------------------------------------------------
+# HIP vs goldens produced by the REFERENCE sparse-conv CPU code compiled here
+# (tests/golden/gen_spconv_golden.py).  The reference lists strided outputs in first-touch order,
+# the HIP rulebook sorted by cell id (documented in DESIGN §2), so rows are matched through their
+# voxel coordinates: the pair SETS (input row, output cell) and the output cell set are bit-exact.
+import hashlib  # noqa: E402
+import os  # noqa: E402
+
+from conftest import GOLDEN  # noqa: E402
+from test_oracle_spconv import LAYERS, layer_dy, layer_weight  # noqa: E402
+
+
+def _cells(ids, shape):
+    ids = ids.astype(np.int64)
+    return ((ids[:, 0] * shape[0] + ids[:, 1]) * shape[1] + ids[:, 2]) * shape[2] + ids[:, 3]
+
+
+def _hip_books(dev, idx, batch):
+    from detmatch_amd.spconv import ops
+    books, shape, cur = {}, SHAPE, torch.from_numpy(np.ascontiguousarray(idx)).to(dev)
+    for key, subm, cin, cout, ks, st, pd in LAYERS:
+        if key in books:
+            continue
+        rb = ops.build_rulebook(cur, batch, shape, ks, st, pd, 1, subm)
+        books[key] = (rb, shape)
+        cur, shape = rb.outids, rb.out_shape
+    return books
+
+
+def test_rulebook_and_conv_equal_reference_small(dev):
+    from detmatch_amd.spconv import ops
+    g = np.load(os.path.join(GOLDEN, 'spconv_ref_small.npz'))
+    books = _hip_books(dev, g['indices'], 2)
+    perm = {}            # key -> for every reference output row, the HIP row holding the same voxel
+    prev_perm = np.arange(len(g['indices']))
+    for key, (rb, in_shape) in books.items():
+        osh = g['rb_%s_out_shape' % key].tolist()
+        assert rb.out_shape == osh
+        ref_cells = _cells(g['rb_%s_outids' % key], osh)
+        hip_cells = _cells(rb.outids.cpu().numpy(), osh)
+        assert np.array_equal(np.sort(ref_cells), np.sort(hip_cells)), key       # same voxel set
+        order = np.argsort(hip_cells)
+        perm[key] = order[np.searchsorted(hip_cells[order], ref_cells)]
+        num = g['rb_%s_num' % key]
+        assert np.array_equal(rb.indice_num.cpu().numpy(), num), key
+        gp = rb.indice_pairs.cpu().numpy()
+        s = 0
+        for k in range(len(num)):
+            ref = set(zip(prev_perm[g['rb_%s_pairs_in' % key][s:s + num[k]]].tolist(),
+                          perm[key][g['rb_%s_pairs_out' % key][s:s + num[k]]].tolist()))
+            assert _pair_set(gp, num, k) == ref, (key, k)
+            s += num[k]
+        prev_perm = perm[key]
+    # conv forward / backward of the 12 layers on the reference's activations
+    x_ref, in_perm = g['features'], np.arange(len(g['indices']))
+    for li, (key, subm, cin, cout, ks, st, pd) in enumerate(LAYERS):
+        rb, _ = books[key]
+        out_perm = perm[key]
+        x = np.empty_like(x_ref)
+        x[in_perm] = x_ref                      # reference row r lives in HIP row in_perm[r]
+        w = layer_weight(li, ks, cin, cout)
+        tx, tw = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+        y = ops.indice_conv(tx, tw, rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
+        np.testing.assert_allclose(y.cpu().numpy()[out_perm], g['l%d_y' % li], rtol=1e-5, atol=1e-5,
+                                   err_msg='fwd %d' % li)
+        dy_ref = layer_dy(li, g['l%d_y' % li].shape)
+        dy = np.empty_like(dy_ref)
+        dy[out_perm] = dy_ref
+        dx, dw = ops.indice_conv_backward(tx, tw, torch.from_numpy(dy).to(dev), rb.indice_pairs,
+                                          rb.indice_num, False, subm, need_input_grad=cin >= 16)
+        if cin >= 16:
+            np.testing.assert_allclose(dx.cpu().numpy()[in_perm], g['l%d_dx' % li], rtol=1e-5,
+                                       atol=1e-5, err_msg='dx %d' % li)
+        dw = dw.cpu().numpy().reshape(-1, cin, cout)
+        if 'l%d_dw_taps' % li in g:
+            dw = dw[g['l%d_dw_taps' % li]]
+        np.testing.assert_allclose(dw, g['l%d_dw' % li], rtol=1e-5, atol=2e-5, err_msg='dw %d' % li)
+        x_ref, in_perm = np.maximum(g['l%d_y' % li], 0), out_perm
+
+
+def test_rulebook_digests_full_frames_reference(dev):
+    """Full KITTI-shaped frames (B=2, 27 k voxels): every rulebook's canonical (order-free) form
+    hashes to the reference's."""
+    from detmatch_amd import synth, voxel
+    g = np.load(os.path.join(GOLDEN, 'spconv_ref_full.npz'))
+    t = [torch.from_numpy(synth.lidar_frame(int(s))['points']).to(dev) for s in g['seeds']]
+    _, coors, _, _, _ = voxel.voxelize_batch(t, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    idx = coors.cpu().numpy()
+    assert hashlib.sha1(np.ascontiguousarray(idx).tobytes()).hexdigest() == str(g['indices_sha1'])
+    in_ids = idx
+    for key, (rb, in_shape) in _hip_books(dev, idx, 2).items():
+        in_cells = _cells(in_ids, in_shape)
+        num = rb.indice_num.cpu().numpy()
+        assert np.array_equal(num, g['%s_num' % key]), key
+        assert rb.n_out == int(g['%s_n_out' % key])
+        cells = _cells(rb.outids.cpu().numpy(), rb.out_shape)
+        assert hashlib.sha1(np.sort(cells).tobytes()).hexdigest() == str(g['%s_canon_out_sha1' % key])
+        p = rb.indice_pairs.cpu().numpy()
+        h = hashlib.sha1()
+        for k in range(len(num)):
+            i = in_cells[p[k, 0, :num[k]]]
+            o = cells[p[k, 1, :num[k]]]
+            order = np.lexsort((o, i))
+            h.update(np.ascontiguousarray(np.stack([i[order], o[order]], 1)).tobytes())
+        assert h.hexdigest() == str(g['%s_canon_pairs_sha1' % key]), key
+        in_ids = rb.outids.cpu().numpy()
