@@ -130,11 +130,58 @@ def cpu_baseline(frames):
                        % (len(frames), dt))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (reference: tools/dist_train.sh:7-9 spawns
+    --nproc_per_node ranks): start N fresh ranks through torch.distributed.run as a CHILD process
+    (this process has not touched the GPU and never execs), relay rank 0's JSON line and exit with
+    the children's status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), '--gpus', str(args.gpus),
+           '--steps', str(args.steps), '--warmup', str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append('--no-cpu-baseline')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def joined_world(dev, backend_is_device):
+    """Number of ranks that actually joined the process group: all-reduce of ones."""
+    one = torch.ones(1, dtype=torch.float32, device=dev if backend_is_device else 'cpu')
+    dist.all_reduce(one)
+    return int(round(float(one.item())))
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks'
+                         % (args.gpus, world))
+    if os.environ.get('DM_BENCH_DRYRUN'):
+        # launcher / process-group control flow only (CPU test, gloo): no workload, no GPU
+        n = 1
+        if world > 1:
+            dist.init_process_group(os.environ.get('DM_DIST_BACKEND', 'gloo'))
+            n = joined_world(None, False)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(dict(metric='train iters/sec', value=None, n_gpus=n, dryrun=True)))
+        if n != args.gpus:
+            raise SystemExit('bench.py: %d of %d ranks joined' % (n, args.gpus))
+        return
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
     # test hooks: several ranks on ONE GPU over gloo (validates the N>1 control flow on a 1-GPU box)
     if os.environ.get('DM_FORCE_DEVICE') is not None:
@@ -147,6 +194,11 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+    joined = 1
+    if world > 1:
+        joined = joined_world(dev, os.environ.get('DM_DIST_BACKEND', 'nccl') == 'nccl')
+        if joined != args.gpus:
+            raise SystemExit('bench.py: %d of %d ranks joined the process group' % (joined, args.gpus))
     if os.environ.get('DM_CUDNN_BENCHMARK'):     # tools/miopen_tune.sh: exhaustive MIOpen find
         torch.backends.cudnn.benchmark = True
     from detmatch_amd import _lib
@@ -210,7 +262,7 @@ def main():
         # weak scaling: every rank steps through its own (2 labeled + 2 unlabeled) batch, so the
         # whole-job rate is world x steps / time (per-GPU-batch iterations per second, all ranks)
         out = dict(metric='train iters/sec', value=round(world * args.steps * 1.0 / dt, 3), unit='iters/sec',
-                   n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   n_gpus=joined, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=wl.describe(), batch_per_gpu=BATCH_PER_GPU,

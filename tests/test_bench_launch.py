@@ -1,0 +1,33 @@
+"""`python bench.py --gpus N` launches N ranks itself (reference
+tools/dist_train.sh:7-9).  CPU test of the launcher control flow: DM_BENCH_DRYRUN skips the GPU
+workload, the ranks rendezvous over gloo and rank 0 reports how many joined."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env):
+    env = dict(os.environ, DM_BENCH_DRYRUN='1', DM_DIST_BACKEND='gloo', **extra_env)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env,
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_self_launch_two_ranks():
+    r = _run(['--gpus', '2', '--steps', '1', '--warmup', '0'], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout           # exactly one JSON line, from rank 0
+    assert json.loads(lines[0])['n_gpus'] == 2
+
+
+def test_world_size_mismatch_fails():
+    env = dict(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    e = dict(os.environ, DM_BENCH_DRYRUN='1', **env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=e,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)

@@ -341,3 +341,13 @@ def test_reference_points_in_boxes_kat_gpu(dev):
     pc[..., 6] = -(boxes[..., 6] + np.float32(np.pi / 2))
     got = points_in_boxes_gpu(torch.from_numpy(pts).to(dev), torch.from_numpy(pc).to(dev))
     assert got.cpu().tolist() == [[0, 0, 0, 0, 0, -1, -1, -1], [-1] * 8]
+
+
+def test_reference_grouping_kat_gpu(dev):
+    """Reference-held grouping_operation vector (test_pointnet_ops.py:126-195), stacked layout."""
+    from detmatch_amd import pointnet2_stack as pn
+    from test_oracle_ops import reference_grouping_kat
+    feats, fc, idx, ic, want = reference_grouping_kat()
+    t = lambda a, dt=None: torch.from_numpy(np.asarray(a, dtype=dt)).to(dev)
+    got = pn.grouping_operation(t(feats), t(fc, np.int32), t(idx), t(ic, np.int32))
+    assert np.array_equal(got.cpu().numpy(), want)

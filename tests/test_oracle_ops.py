@@ -99,6 +99,40 @@ def test_reference_ball_query_kat(orc):
     assert empty.tolist() == [True] and idx.tolist() == [[0, 0, 0, 0]]
 
 
+GROUP_IDX = np.array([[[0, 0, 0], [3, 3, 3], [8, 8, 8], [0, 0, 0], [0, 0, 0], [0, 0, 0]],
+                      [[0, 0, 0], [6, 6, 6], [9, 9, 9], [0, 0, 0], [0, 0, 0], [0, 0, 0]]], np.int32)
+GROUP_FEATS = np.array(
+    [[[0.5798, -0.7981, -0.9280, -1.3311, 1.3687, 0.9277, -0.4164, -1.8274, 0.9268, 0.8414],
+      [5.4247, 1.5113, 2.3944, 1.4740, 5.0300, 5.1030, 1.9360, 2.1939, 2.1581, 3.4666],
+      [-1.6266, -1.0281, -1.0393, -1.6931, -1.3982, -0.5732, -1.0830, -1.7561, -1.6786, -1.6967]],
+     [[-0.0380, -0.1880, -1.5724, 0.6905, -0.3190, 0.7798, -0.3693, -0.9457, -0.2942, -1.8527],
+      [1.1773, 1.5009, 2.6399, 5.9242, 1.0962, 2.7346, 6.0865, 1.5555, 4.3303, 2.8229],
+      [-0.6646, -0.6870, -0.1125, -0.2224, -0.3445, -1.4049, 0.4990, -0.7037, -0.9924, 0.0386]]],
+    np.float32)
+GROUP_PICK = np.array([[[0.5798, -1.3311, 0.9268, 0.5798, 0.5798, 0.5798],
+                        [5.4247, 1.4740, 2.1581, 5.4247, 5.4247, 5.4247],
+                        [-1.6266, -1.6931, -1.6786, -1.6266, -1.6266, -1.6266]],
+                       [[-0.0380, -0.3693, -1.8527, -0.0380, -0.0380, -0.0380],
+                        [1.1773, 6.0865, 2.8229, 1.1773, 1.1773, 1.1773],
+                        [-0.6646, 0.4990, 0.0386, -0.6646, -0.6646, -0.6646]]], np.float32)
+
+
+def reference_grouping_kat():
+    """tests/test_models/test_common_modules/test_pointnet_ops.py:126-195 (batch layout
+    features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample); every expected row repeats
+    one value nsample times) re-laid-out for the stacked op: features (B*N, C), idx (B*npoint,
+    nsample) local to the sample, out (B*npoint, C, nsample)."""
+    feats = np.concatenate([GROUP_FEATS[b].T for b in range(2)])
+    idx = GROUP_IDX.reshape(-1, 3)
+    want = np.repeat(GROUP_PICK.transpose(0, 2, 1).reshape(12, 3)[:, :, None], 3, axis=2)
+    return feats, [10, 10], idx, [6, 6], want
+
+
+def test_reference_grouping_kat(orc):
+    feats, fc, idx, ic, want = reference_grouping_kat()
+    assert np.array_equal(orc.group_points(feats, fc, idx, ic), want)
+
+
 def test_group_points_roundtrip(orc):
     rng = np.random.default_rng(1)
     feats = rng.standard_normal((30, 7)).astype(np.float32)
