@@ -64,6 +64,8 @@ SIGNATURES = {
     'dm_ema_update_i64': (ci, [vp, vp, sz, ctypes.c_double, vp]),
     'dm_adamw_step_f32': (ci, [vp, vp, vp, vp, sz, cd, cd, cd, cd, cd, ctypes.c_longlong, vp, vp]),
     'dm_sgd_step_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp]),
+    'dm_adamw_step_masked_f32': (ci, [vp, vp, vp, vp, sz, cd, cd, cd, cd, cd, ctypes.c_longlong, vp, vp, vp]),
+    'dm_sgd_step_masked_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp, vp]),
     'dm_lap_host': (ci, [c_f32_p, ci, ci, c_int_p, c_int_p]),
     'dm_anchor_head_loss_workspace_bytes': (sz, [ci, ci]),
     'dm_anchor_head_loss_forward': (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cf, c_f32_p, c_f32_p, vp, vp, sz, vp]),

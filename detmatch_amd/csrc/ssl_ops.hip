@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void adamw_f32_kernel(float *__restrict__ p,
                                                         const float *__restrict__ g,
                                                         float *__restrict__ m, float *__restrict__ v,
                                                         size_t n, AdamWArgs a,
-                                                        const float *__restrict__ grad_scale) {
+                                                        const float *__restrict__ grad_scale,
+                                                        const unsigned char *__restrict__ live) {
   const float gs = grad_scale ? *grad_scale : 1.0f;
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
+  if (live && !live[i >> 2]) return;   // parameter never received a gradient: torch skips it
   const int cnt = (int)(n - i < 4 ? n - i : 4);
   float pv[4], gv[4], mv[4], vv[4];
   if (cnt == 4) {
@@ -102,10 +104,12 @@ __global__ __launch_bounds__(256) void sgd_f32_kernel(float *__restrict__ p,
                                                       const float *__restrict__ g,
                                                       float *__restrict__ buf, size_t n, float lr,
                                                       float momentum, float dampening, float wd,
-                                                      int first, const float *__restrict__ grad_scale) {
+                                                      int first, const float *__restrict__ grad_scale,
+                                                      const unsigned char *__restrict__ live) {
   const float gs = grad_scale ? *grad_scale : 1.0f;
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
+  if (live && !live[i >> 2]) return;
   const int cnt = (int)(n - i < 4 ? n - i : 4);
   for (int k = 0; k < cnt; ++k) {
     const float pk = p[i + k];
@@ -121,10 +125,11 @@ __global__ __launch_bounds__(256) void sgd_f32_kernel(float *__restrict__ p,
 
 }  // namespace
 
-extern "C" int dm_adamw_step_f32(float *params, const float *grads, float *exp_avg,
-                                 float *exp_avg_sq, size_t n, double lr, double beta1, double beta2,
-                                 double eps, double weight_decay, long long step,
-                                 const float *grad_scale_dev, dm_stream_t stream) {
+extern "C" int dm_adamw_step_masked_f32(float *params, const float *grads, float *exp_avg,
+                                        float *exp_avg_sq, size_t n, double lr, double beta1,
+                                        double beta2, double eps, double weight_decay,
+                                        long long step, const float *grad_scale_dev,
+                                        const unsigned char *block_live, dm_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) return DM_OK;
   if (!params || !grads || !exp_avg || !exp_avg_sq || step < 1) return DM_ERR_INVALID_ARG;
@@ -140,7 +145,30 @@ extern "C" int dm_adamw_step_f32(float *params, const float *grads, float *exp_a
   a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   a.eps = (float)eps;
   adamw_f32_kernel<<<dm_ceil_div((long long)((n + 3) / 4), 256), 256, 0, st>>>(
-      params, grads, exp_avg, exp_avg_sq, n, a, grad_scale_dev);
+      params, grads, exp_avg, exp_avg_sq, n, a, grad_scale_dev, block_live);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_adamw_step_f32(float *params, const float *grads, float *exp_avg,
+                                 float *exp_avg_sq, size_t n, double lr, double beta1, double beta2,
+                                 double eps, double weight_decay, long long step,
+                                 const float *grad_scale_dev, dm_stream_t stream) {
+  return dm_adamw_step_masked_f32(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                                  weight_decay, step, grad_scale_dev, nullptr, stream);
+}
+
+extern "C" int dm_sgd_step_masked_f32(float *params, const float *grads, float *momentum_buf,
+                                      size_t n, double lr, double momentum, double dampening,
+                                      double weight_decay, int first_step,
+                                      const float *grad_scale_dev, const unsigned char *block_live,
+                                      dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return DM_OK;
+  if (!params || !grads || (momentum != 0.0 && !momentum_buf)) return DM_ERR_INVALID_ARG;
+  sgd_f32_kernel<<<dm_ceil_div((long long)((n + 3) / 4), 256), 256, 0, st>>>(
+      params, grads, momentum_buf, n, (float)lr, (float)momentum, (float)dampening,
+      (float)weight_decay, first_step, grad_scale_dev, block_live);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -148,14 +176,8 @@ extern "C" int dm_adamw_step_f32(float *params, const float *grads, float *exp_a
 extern "C" int dm_sgd_step_f32(float *params, const float *grads, float *momentum_buf, size_t n,
                                double lr, double momentum, double dampening, double weight_decay,
                                int first_step, const float *grad_scale_dev, dm_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if (n == 0) return DM_OK;
-  if (!params || !grads || (momentum != 0.0 && !momentum_buf)) return DM_ERR_INVALID_ARG;
-  sgd_f32_kernel<<<dm_ceil_div((long long)((n + 3) / 4), 256), 256, 0, st>>>(
-      params, grads, momentum_buf, n, (float)lr, (float)momentum, (float)dampening,
-      (float)weight_decay, first_step, grad_scale_dev);
-  DM_CHECK_LAUNCH();
-  return DM_OK;
+  return dm_sgd_step_masked_f32(params, grads, momentum_buf, n, lr, momentum, dampening,
+                                weight_decay, first_step, grad_scale_dev, nullptr, stream);
 }
 
 extern "C" int dm_ema_update_f32(float *teacher, const float *student, size_t n, double decay,

@@ -20,8 +20,27 @@ Two ways of getting gradients into the arena:
       it with backward costs nothing measurable.
   mode='hooks'   `.grad` are views of the arena, autograd accumulates in place, and a bucket's
       all-reduce is issued asynchronously as soon as its last gradient of the (final) backward pass
-      has been produced, overlapping the rest of backward.
+      has been produced, overlapping the rest of backward.  Buckets are ALWAYS issued in index
+      order (bucket b only after 0..b-1): which parameters get a gradient depends on the data
+      (pseudo-label / match counts), so a "ready first, sent first" order would differ between
+      ranks and pair bucket i of one rank with bucket j of another.
+
+Liveness (the reference's find_unused_parameters=True + mmcv zero_grad semantics,
+mmdet3d/apis/ssl_train.py:65-69): a parameter that NO rank has ever produced a gradient for keeps
+`.grad is None` in the reference, so torch optimizers skip it (no weight decay, no state).  The
+arena ends in one float flag per parameter ("got a gradient this step on this rank"); it rides in
+the last bucket's all-reduce, so `ever` (sticky, device-resident) is the same on all ranks without
+an extra collective, and the fused optimizer kernels take it as a per-16-byte-block mask
+(`live_mask`).  Once every flag is set (probed through a pinned, event-guarded copy: no host
+sync) the mask is dropped.
+
+Exchange: `all_reduce` per bucket (default), or `exchange='rs_ag'` (env DM_GRAD_EXCHANGE=rs_ag):
+reduce_scatter_tensor + all_gather_into_tensor per bucket, the direct algorithm over the 7 xGMI
+links SURVEY §8(e) names (needs the nccl backend; buckets are padded to a multiple of the world
+size).
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -30,10 +49,12 @@ import torch.nn as nn
 class FlatGradDDP(nn.Module):
 
     def __init__(self, module, params=None, bucket_bytes=64 << 20, process_group=None,
-                 broadcast=True, mode='collect'):
+                 broadcast=True, mode='collect', exchange=None):
         super().__init__()
         assert mode in ('collect', 'hooks')
         self.mode = mode
+        self.exchange = exchange or os.environ.get('DM_GRAD_EXCHANGE', 'all_reduce')
+        assert self.exchange in ('all_reduce', 'rs_ag')
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -49,9 +70,25 @@ class FlatGradDDP(nn.Module):
         # arena can be walked index-aligned by float4 kernels
         order = list(range(len(self.params)))[::-1]
         pad = lambda n: (n + 3) // 4 * 4
-        self.flat = torch.zeros(sum(pad(p.numel()) for p in self.params), dtype=torch.float32,
-                                device=dev)
+        n_grad = sum(pad(p.numel()) for p in self.params)
+        # tail: one "got a gradient" flag per parameter, padded so that rs_ag can cut every bucket
+        # into world equal shards
+        n_all = n_grad + pad(len(self.params))
+        n_all = (n_all + 4 * self.world - 1) // (4 * self.world) * (4 * self.world)
+        self.flat_all = torch.zeros(n_all, dtype=torch.float32, device=dev)
+        self.flat = self.flat_all[:n_grad]               # the gradients (what clip / optimizers see)
+        self.used = self.flat_all[n_grad:n_grad + len(self.params)]
+        self.ever = torch.zeros(len(self.params), dtype=torch.bool, device=dev)   # sticky, all ranks
         self.order = [self.params[i] for i in order]     # arena order
+        self.index = {id(p): i for i, p in enumerate(self.order)}
+        self._blocks = torch.tensor([pad(p.numel()) // 4 for p in self.order], dtype=torch.int64,
+                                    device=dev)
+        self.n_blocks = n_grad // 4
+        self.block_live = None      # uint8 per 4-element block while some parameter is still dead
+        self._all_live = False
+        self._probe = None
+        self._mark_cache = {}
+        self._fired = set()
         self.offset = {}                                 # id(param) -> first element
         self.flat_params = None                          # set by build_param_arena / SSL.build_arenas
         self.buckets = []          # (start, end) element ranges of self.flat
@@ -65,17 +102,18 @@ class FlatGradDDP(nn.Module):
             self.offset[id(p)] = off
             self._bucket_of[id(p)] = len(self.buckets)
             off += pad(p.numel())
-            if off - b_start >= cap:
+            if off - b_start >= cap and off % (4 * self.world) == 0:
                 self.buckets.append((b_start, off))
                 b_start = off
-        if off > b_start:
-            self.buckets.append((b_start, off))
+        self.buckets.append((b_start, n_all))            # last bucket: rest + the flag tail
         self._need = [0] * len(self.buckets)
         for p in self.params:
             self._need[self._bucket_of[id(p)]] += 1
         self._left = list(self._need)
         self._sent = [False] * len(self.buckets)
+        self._next = 0
         self._armed = False
+        self._shards = None
         if mode == 'hooks':
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -123,7 +161,9 @@ class FlatGradDDP(nn.Module):
     def zero_grad(self, arm=True):
         """arm=False (hooks mode): zero only; the bucket hooks stay quiet until arm() (several
         backward passes accumulate into the arena, only the last one may trigger the exchange)."""
-        self.flat.zero_()
+        self.flat_all.zero_()
+        self._fired = set()
+        self._next = 0
         if self.mode == 'collect':
             for p in self.params:
                 p.grad = None
@@ -144,6 +184,7 @@ class FlatGradDDP(nn.Module):
             return
         ps = [p for p in self.order if p.grad is not None and p.grad.data_ptr() != self._view[id(p)].data_ptr()]
         if ps:
+            self._mark([self.index[id(p)] for p in ps])
             torch._foreach_add_([self._view[id(p)] for p in ps], [p.grad for p in ps])
             if self.flat.is_cuda:      # gradients may have been produced on another stream (2D lane)
                 cur = torch.cuda.current_stream(self.flat.device)
@@ -151,6 +192,18 @@ class FlatGradDDP(nn.Module):
                     p.grad.record_stream(cur)
         for p in ps:
             p.grad = None
+
+    def _mark(self, idxs):
+        """used[idxs] = 1 (index tensors cached per distinct set: no H2D copy in the steady state)."""
+        if not idxs:
+            return
+        key = tuple(idxs)
+        t = self._mark_cache.get(key)
+        if t is None:
+            if len(self._mark_cache) > 64:
+                self._mark_cache.clear()
+            t = self._mark_cache[key] = torch.tensor(idxs, dtype=torch.int64, device=self.flat.device)
+        self.used.index_fill_(0, t, 1.0)
 
     def arm(self):
         if self.mode == 'hooks':
@@ -160,16 +213,33 @@ class FlatGradDDP(nn.Module):
     def _launch(self, b):
         s, e = self.buckets[b]
         self._sent[b] = True
-        if self.world > 1:
-            self._pending.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
+        if self.world <= 1:
+            return
+        buf = self.flat_all[s:e]
+        if self.exchange == 'rs_ag':
+            if self._shards is None:
+                self._shards = [torch.empty((e2 - s2) // self.world, dtype=torch.float32,
+                                            device=self.flat.device) for s2, e2 in self.buckets]
+            sh = self._shards[b]
+            # same stream of the process group: the all-gather runs after the reduce-scatter
+            dist.reduce_scatter_tensor(sh, buf, group=self.group, async_op=True)
+            self._pending.append(dist.all_gather_into_tensor(buf, sh, group=self.group, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(buf, group=self.group, async_op=True))
+
+    def _launch_ready(self, limit):
+        """Issue buckets strictly in index order while the next one is complete."""
+        while self._next < limit and self._left[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _on_grad(self, p):
+        self._fired.add(self.index[id(p)])
         if not self._armed:
             return
-        b = self._bucket_of[id(p)]
-        self._left[b] -= 1
-        if self._left[b] == 0 and not self._sent[b]:
-            self._launch(b)
+        self._left[self._bucket_of[id(p)]] -= 1
+        # the last bucket carries the liveness flags, written in finish(): never from a hook
+        self._launch_ready(len(self.buckets) - 1)
 
     def finish(self):
         """Issue the remaining buckets, wait for all, average; afterwards `p.grad` are the arena
@@ -179,14 +249,57 @@ class FlatGradDDP(nn.Module):
             self.collect()
             for p in self.order:
                 p.grad = self._view[id(p)]
-        for b in range(len(self.buckets)):
-            if not self._sent[b]:
-                self._launch(b)
+        else:
+            self._mark(sorted(self._fired))
+        for b in range(self._next, len(self.buckets)):       # the rest, in index order
+            self._launch(b)
+        self._next = len(self.buckets)
         for w in self._pending:
             w.wait()
         self._pending = []
         if self.world > 1:
             self.flat.div_(self.world)
+        self._update_live()
+
+    # ---- liveness ---------------------------------------------------------------------
+    def _update_live(self):
+        if self._all_live:
+            return
+        if self._probe is not None:          # did an earlier step already see every flag set?
+            host, ev = self._probe
+            if ev is None or ev.query():
+                if bool(host.item()):
+                    self._all_live, self.block_live, self._probe = True, None, None
+                    return
+                self._probe = None
+        torch.logical_or(self.ever, self.used > 0, out=self.ever)
+        self.block_live = torch.repeat_interleave(self.ever.to(torch.uint8), self._blocks,
+                                                  output_size=self.n_blocks)
+        if self._probe is None:
+            allv = self.ever.all().reshape(1)
+            if self.flat.is_cuda:
+                host = torch.empty(1, dtype=torch.bool, pin_memory=True)
+                host.copy_(allv, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._probe = (host, ev)
+            else:
+                self._probe = (allv.clone(), None)
+
+    def live_mask(self, lo, hi):
+        """uint8 per 4-element block of arena range [lo, hi) (0 = the parameter never received a
+        gradient on any rank), or None when every parameter is live."""
+        if self.block_live is None:
+            return None
+        return self.block_live[lo // 4:(hi + 3) // 4]
+
+    def dead_params(self):
+        """Parameters no rank has produced a gradient for so far (host read-back: slow path, used
+        by non-fused optimizers and state_dict only)."""
+        if self._all_live:
+            return []
+        ever = self.ever.cpu().tolist()
+        return [p for p, e in zip(self.order, ever) if not e]
 
     def clip_coef(self, max_norm, norm_type=2):
         """-> (total_norm, coef) device scalars of clip_grad_norm_; nothing is scaled (the fused

@@ -43,6 +43,9 @@ class HybridOptimizer(torch.optim.Optimizer):
         return s + ')'
 
     def state_dict(self):
+        for f in getattr(self, '_fused', None) or []:
+            if f is not None:     # fresh per-parameter step tensors, no state for never-used params
+                f.sync_published_state()
         sds = [o.state_dict() for o in self.optimizers]
         return dict(num_step_updated=self.num_step_updated, state=[s['state'] for s in sds],
                     param_groups=[s['param_groups'] for s in sds])
@@ -73,6 +76,13 @@ class HybridOptimizer(torch.optim.Optimizer):
                 if fused is not None and fused[i] is not None:
                     fused[i].step(getattr(self, 'grad_scale', None))
                 else:
+                    ddp = getattr(self, '_ddp', None)
+                    if ddp is not None:      # never-used parameters: .grad None, as in the reference
+                        dead = set(id(p) for p in ddp.dead_params())
+                        for g in o.param_groups:
+                            for p in g['params']:
+                                if id(p) in dead:
+                                    p.grad = None
                     o.step()
         self.grad_scale = None
         return loss
@@ -82,6 +92,7 @@ class HybridOptimizer(torch.optim.Optimizer):
         arenas through the fused kernels (dm_adamw_step_f32 / dm_sgd_step_f32).  Optimizer state
         stays visible through `optimizer.state[p]` as views of the flat state.  Returns the number
         of fused members."""
+        self._ddp = ddp
         self._fused = [FusedRange.try_build(o, ddp) for o in self.optimizers]
         return sum(f is not None for f in self._fused)
 
@@ -117,10 +128,20 @@ class FusedRange(object):
         for p in self.params:
             o = ddp.offset[id(p)] - lo
             if self.kind == 'adamw':
-                opt.state[p] = dict(step=self.step_t, exp_avg=self.m[o:o + p.numel()].view_as(p),
+                opt.state[p] = dict(step=self.step_t.clone(), exp_avg=self.m[o:o + p.numel()].view_as(p),
                                     exp_avg_sq=self.v[o:o + p.numel()].view_as(p))
             else:
                 opt.state[p] = dict(momentum_buffer=self.buf[o:o + p.numel()].view_as(p))
+
+    def sync_published_state(self):
+        """Before state_dict(): every parameter gets its OWN 0-d step tensor holding the current
+        count (a shared tensor would be stepped once per parameter by a plain torch optimizer that
+        loads the checkpoint), and parameters that never received a gradient have no state at all,
+        as in torch."""
+        self.step_t.fill_(self.t)
+        self._publish()
+        for p in self.ddp.dead_params():
+            self.opt.state.pop(p, None)
 
     @torch.no_grad()
     def adopt_loaded_state(self):
@@ -182,15 +203,19 @@ class FusedRange(object):
         self.t += 1
         self.step_t.fill_(self.t)
         n = self.hi - self.lo
+        # parameters that never received a gradient are skipped, as torch.optim skips .grad None
+        mask = d.live_mask(self.lo, self.hi)
+        mk = _lib.ptr(mask) if mask is not None else None
         if self.kind == 'adamw':
-            _lib.check(L.dm_adamw_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(self.m), _lib.ptr(self.v),
-                                           n, g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
-                                           g0['weight_decay'], self.t, gs, _lib.stream()),
-                       'dm_adamw_step_f32')
+            _lib.check(L.dm_adamw_step_masked_f32(
+                _lib.ptr(p), _lib.ptr(g), _lib.ptr(self.m), _lib.ptr(self.v), n, g0['lr'],
+                g0['betas'][0], g0['betas'][1], g0['eps'], g0['weight_decay'], self.t, gs, mk,
+                _lib.stream()), 'dm_adamw_step_masked_f32')
         else:
-            _lib.check(L.dm_sgd_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(self.buf), n, g0['lr'],
-                                         g0['momentum'], g0['dampening'], g0['weight_decay'],
-                                         int(self.t == 1), gs, _lib.stream()), 'dm_sgd_step_f32')
+            _lib.check(L.dm_sgd_step_masked_f32(
+                _lib.ptr(p), _lib.ptr(g), _lib.ptr(self.buf), n, g0['lr'], g0['momentum'],
+                g0['dampening'], g0['weight_decay'], int(self.t == 1), gs, mk, _lib.stream()),
+                'dm_sgd_step_masked_f32')
 
 
 @OPTIMIZER_BUILDERS.register_module()

@@ -312,6 +312,18 @@ int dm_adamw_step_f32(float *params, const float *grads, float *exp_avg, float *
 int dm_sgd_step_f32(float *params, const float *grads, float *momentum_buf, size_t n, double lr,
                     double momentum, double dampening, double weight_decay, int first_step,
                     const float *grad_scale_dev, dm_stream_t stream);
+/* The same with a liveness mask: block_live[i / 4] == 0 leaves elements 4i..4i+3 (parameter,
+ * state) untouched — torch.optim skips parameters whose .grad is None, which is what a parameter
+ * that never received a gradient has under mmcv's zero_grad + DDP(find_unused_parameters=True)
+ * (mmdet3d/apis/ssl_train.py:65-69).  block_live may be NULL (= all live). */
+int dm_adamw_step_masked_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                             size_t n, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, long long step, const float *grad_scale_dev,
+                             const unsigned char *block_live, dm_stream_t stream);
+int dm_sgd_step_masked_f32(float *params, const float *grads, float *momentum_buf, size_t n,
+                           double lr, double momentum, double dampening, double weight_decay,
+                           int first_step, const float *grad_scale_dev,
+                           const unsigned char *block_live, dm_stream_t stream);
 /* Replaces scipy.optimize.linear_sum_assignment at
  * mmdet3d/core/bbox/assigners/modified_hungarian_assigner.py:132.  HOST function: cost
  * (n_rows, n_cols) row-major host floats -> min(n_rows, n_cols) pairs sorted by row.

@@ -128,3 +128,114 @@ def test_flat_grad_single_process():
     hk.module.a.weight.grad = None
     with pytest.raises(RuntimeError):
         hk.zero_grad()
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 2 (ADVICE): data-dependent unused sets that DIFFER between ranks, and liveness.
+class _Branchy(nn.Module):
+    """`skip_mid` on one rank only: that rank produces no gradient for `mid` this step (what a
+    batch without pseudo-labels / matches does to the SSL losses)."""
+
+    def __init__(self):
+        super().__init__()
+        self.first = nn.Linear(8, 8)
+        self.mid = nn.Linear(8, 8)
+        self.last = nn.Linear(8, 2)
+        self.never = nn.Linear(8, 2)         # no rank ever uses it
+
+    def forward(self, x, skip_mid):
+        h = torch.relu(self.first(x))
+        if not skip_mid:
+            h = h + self.mid(h)
+        return self.last(h)
+
+
+def _worker_uneven(rank, world, port, q, mode):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from detmatch_amd.mm3d.parallel import FlatGradDDP
+        torch.manual_seed(0)
+        net = _Branchy()
+        ddp = FlatGradDDP(net, bucket_bytes=64, mode=mode)      # one bucket per tensor or so
+        assert len(ddp.buckets) >= 4
+        torch.manual_seed(10 + rank)
+        x = torch.randn(4, 8)
+        for step in range(3):
+            skip = (rank == 1) if step < 2 else True            # step 2: nobody uses `mid`
+            params = dict(net.named_parameters())
+            gl = torch.autograd.grad(net(x, skip).square().mean(), list(params.values()),
+                                     allow_unused=True)
+            want = {}
+            for (n, p), g in zip(params.items(), gl):
+                g = g if g is not None else torch.zeros_like(p)
+                gs = [torch.zeros_like(g) for _ in range(world)]
+                dist.all_gather(gs, g)
+                want[n] = sum(gs) / world
+            ddp.zero_grad()
+            net(x, skip).square().mean().backward()
+            ddp.finish()                       # a rank-dependent launch order would hang / corrupt
+            for n, p in net.named_parameters():
+                assert torch.allclose(ddp._view[id(p)], want[n], atol=1e-7), (step, n)
+            live = {n: bool(ddp.ever[ddp.index[id(p)]]) for n, p in net.named_parameters()}
+            # `mid` got a gradient on rank 0 only: live on BOTH ranks; `never` stays dead
+            assert live['mid.weight'] and live['first.weight'] and not live['never.weight']
+            dead = ddp.dead_params()
+            assert {id(p) for p in dead} == {id(net.never.weight), id(net.never.bias)}
+            m = ddp.live_mask(0, ddp.flat.numel())
+            off = ddp.offset[id(net.never.weight)]
+            assert m is not None and int(m[off // 4]) == 0
+            assert int(m[ddp.offset[id(net.mid.weight)] // 4]) == 1
+        q.put((rank, 'ok'))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['collect', 'hooks'])
+def test_rank_dependent_unused_sets(mode):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', 'rank %d: %s' % (rank, msg)
+
+
+def test_never_used_parameters_are_not_stepped():
+    """confthr_pvrcnn builds a 2D student it never trains: the reference leaves those .grad None
+    (DDP find_unused_parameters + mmcv zero_grad), so SGD weight decay must not shrink them."""
+    from detmatch_amd.mm3d.parallel import FlatGradDDP
+    from detmatch_amd.mm3d.runner import HybridOptimizer
+    torch.manual_seed(0)
+    net = _Branchy()
+    ddp = FlatGradDDP(net)
+    opt = HybridOptimizer([torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=0.1)])
+    opt._ddp = ddp
+    w_never, w_mid = net.never.weight.detach().clone(), net.mid.weight.detach().clone()
+    x = torch.randn(4, 8)
+    for step in range(3):
+        ddp.zero_grad()
+        net(x, skip_mid=step > 0).square().mean().backward()     # `mid` only used at step 0
+        ddp.finish()
+        opt.step()
+    assert torch.equal(net.never.weight, w_never)                 # untouched
+    assert not torch.equal(net.mid.weight, w_mid)                 # used once: decays ever after
+    assert net.never.weight.grad is None and net.mid.weight.grad is not None
+    assert all(id(p) not in {id(q) for q in ddp.dead_params()} for p in net.mid.parameters())
+    # everything live -> the mask is dropped (no per-step cost in the steady state)
+    net2 = nn.Linear(4, 4)
+    d2 = FlatGradDDP(net2)
+    for _ in range(3):
+        d2.zero_grad()
+        net2(torch.randn(2, 4)).sum().backward()
+        d2.finish()
+    assert d2._all_live and d2.live_mask(0, d2.flat.numel()) is None

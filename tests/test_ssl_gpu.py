@@ -289,3 +289,60 @@ def test_filter_by_nms_3d_multiclass(dev):
     for l, s, x in zip(kept_labels.cpu().numpy(), kept_scores.cpu().numpy(), kept.tensor.cpu().numpy()):
         i = int(np.argmin(np.abs(b - x).sum(1)))
         assert np.allclose(s, scores[i]) and s[l] > 0.3          # the FULL score vector of the survivor
+
+
+def test_fused_optimizer_skips_never_used_parameters(dev):
+    """A branch that never receives a gradient (confthr_pvrcnn's 2D student) is left untouched by
+    the fused kernels (liveness mask), exactly like torch optimizers skip `.grad is None`; a
+    parameter used once keeps being stepped (weight decay, momentum) with zero gradients."""
+    import copy
+    import torch.nn as nn
+    from detmatch_amd.mm3d import runner as R
+    from detmatch_amd.mm3d.parallel import FlatGradDDP
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.student = nn.ModuleDict(dict(
+                detector_3d=nn.ModuleDict(dict(a=nn.Linear(37, 53), once=nn.Linear(53, 53), b=nn.Linear(53, 7))),
+                detector_2d=nn.Sequential(nn.Linear(37, 29), nn.ReLU(), nn.Linear(29, 3))))
+
+        def forward(self, x, use_once):
+            d = self.student['detector_3d']
+            h = torch.relu(d['a'](x))
+            if use_once:
+                h = h + d['once'](h)
+            return d['b'](h).square().mean()               # detector_2d: never used
+
+    cfg = {'constructor': 'HybridOptimizerConstructor',
+           'student.detector_3d': dict(type='AdamW', lr=0.01, betas=(0.95, 0.99), weight_decay=0.01),
+           'student.detector_2d': dict(type='SGD', lr=0.02, momentum=0.9, weight_decay=0.01)}
+    torch.manual_seed(0)
+    a = Toy().to(dev)
+    b = copy.deepcopy(a)
+    ddp = FlatGradDDP(a, broadcast=False)
+    ddp.build_param_arena()
+    opt_a = R.build_optimizer(a, cfg)
+    assert opt_a.enable_fused(ddp) == 2
+    opt_b = R.build_optimizer(b, cfg)
+    w2d = [p.detach().clone() for p in a.student['detector_2d'].parameters()]
+    for it in range(4):
+        x = torch.randn(16, 37, device=dev)
+        ddp.zero_grad()
+        a(x, it == 1).backward()
+        ddp.finish()
+        opt_a.step()
+        opt_b.zero_grad()            # torch default set_to_none... mmcv semantics: keep tensors
+        for p in b.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        b(x, it == 1).backward()
+        opt_b.step()
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-6), (it, n)
+    for p, w in zip(a.student['detector_2d'].parameters(), w2d):
+        assert torch.equal(p, w)
+    sd = opt_a.state_dict()
+    assert len(sd['state'][1]) == 0                         # no state for the dead branch
+    steps = [st['step'] for st in sd['state'][0].values()]
+    assert all(int(s) == 4 for s in steps) and len({s.data_ptr() for s in steps}) == len(steps)
