@@ -1,0 +1,750 @@
+// Dense 2-D convolution family for gfx950: implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+//
+// Replaces the cuDNN convolutions behind torch.nn.Conv2d / ConvTranspose2d on the DetMatch path:
+//   pcdet/models/backbones_2d/base_bev_backbone.py:38-69,94-112   (BEV backbone, 3x3 / 3x3 s2 /
+//                                                                  ConvT 1x1 / ConvT 2x2 s2)
+//   pcdet/models/dense_heads/anchor_head_single.py:20-37          (1x1 heads)
+//   mmdet ResNet-50 (caffe) + FPN + RPNHead as configured at
+//   configs/detmatch/001/detmatch/split_0.py:39-99               (7x7 s2 stem, 1x1, 3x3)
+//
+// ONE gather-GEMM kernel covers forward, input gradient (any stride) and transposed convolution
+// by describing the op as taps over an output LATTICE:
+//
+//   out[b, oy0 + i*oys, ox0 + j*oxs, n] (+bias[n]) (relu) =
+//       sum_{t < T} sum_{c < Cin} in[b, i*iys + dy[t], j*ixs + dx[t], c] * W[ws[t]][n][c]
+//
+// (reads outside the input image are zero).  Rows of the GEMM are the lattice points m = (b,i,j),
+// columns the output channels, K = T*Cin with the tap as the slow index.  Activations are NHWC, so a
+// row's K-slice of one tap is contiguous; weights are pre-packed [slice][N][K] (dm_dconv_pack).
+//   forward conv (k, stride s, pad p):  lattice = all outputs, iys = s, dy = kh - p
+//   input gradient, stride 1:           lattice = all inputs,  dy = p - kh, W = packed transpose
+//   input gradient, stride s:           s*s launches, one per residue class (oy0 = ry, oys = s), each
+//                                       with the taps whose (ry + p - kh) is divisible by s
+//   ConvTranspose2d(k = s):             s*s launches of one tap each
+//
+// Tile: BM x BN outputs per workgroup of 4 waves, K-step BK = 32, operands staged through LDS with
+// 16-byte rows of BK+4 floats (conflict-free ds_read_b128: 36*n mod 64 hits 16 distinct 4-bank
+// groups), double buffered with the next tile's global loads in flight under the MFMAs.  Each lane
+// fetches 4 consecutive k of its row with one ds_read_b128 and feeds them to 4 MFMAs: the k order
+// inside an 8-block is permuted identically for A and B (lane half h, element j -> k = 4h + j), which
+// a dot product does not care about.  The weight gradient is a second kernel (pixels are the
+// reduction index, split over workgroups, fixed-order reduce -> bitwise reproducible).
+#include "dm_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DConvGeom {
+  int B, Hin, Win, Cin;
+  int Hout, Wout, Cout;
+  int LH, LW;
+  int oy0, ox0, oys, oxs;
+  int iys, ixs;
+  int T;
+  int relu;
+  int dense_out;   // lattice == every output pixel in order: row m lives at y + m*Cout
+  int M;           // B*LH*LW
+  int Ktot;        // T*Cin
+};
+
+struct DConvTaps {   // 32-bit entries: a wave-uniform tap index then reads them with s_load_dword
+  int dy[64], dx[64], ws[64];
+};
+
+#define DCONV_MAX_TAPS 64
+#ifndef STAGGER_SLEEP
+#define STAGGER_SLEEP 70   /* x64 cycles: about half a K-tile of a 128x128 tile with the pipe shared */
+#endif
+
+// SOLO: pad the LDS allocation beyond half of the CU's 160 KB so that only ONE workgroup is resident
+// per CU — used for the tail launch (see dm_dconv_gemm), whose few tiles should spread over the
+// chip instead of piling up on the CUs that happen to be free first.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool UNI, bool SOLO>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    float *__restrict__ y, const DConvGeom g, const DConvTaps tt, int n_tiles_m, int n_tiles_n,
+    int m_lo) {
+#ifdef DCONV_STAMPS
+  const float *bias_arg = bias;
+  const long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int LDK = BK + 4;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  constexpr int KQ = BK / 4;
+  constexpr int RPP = NT / KQ;  // rows staged per pass
+  constexpr int AP = BM / RPP, BP = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && TM >= 1 && TN >= 1, "tile shape");
+  constexpr int LDS_FLOATS = 2 * (BM + BN) * LDK;
+  __shared__ __attribute__((aligned(16))) float lds[SOLO && LDS_FLOATS < 21504 ? 21504 : LDS_FLOATS];
+
+  // XCD-aware tile map: workgroups L, L+8, L+16 ... share an XCD (its L2); give them the column tiles
+  // of the SAME row tile back to back, so the activation rows are fetched from HBM once.
+  const int L = blockIdx.x;
+  const int xcd = L & 7, seq = L >> 3;
+  const int mt = (seq / n_tiles_n) * 8 + xcd;
+  const int nt = seq % n_tiles_n;
+  if (mt >= n_tiles_m) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int kq = tid % KQ, r0 = tid / KQ;
+  const int m0 = m_lo + mt * BM, n0 = nt * BN;
+
+  // per-thread row state; addresses are 32-bit BYTE offsets from the (wave-uniform) tensor base, so a
+  // load is `global_load_dwordx4 v, v_off, s[base]` and a K-tile's address math is a few 32-bit adds
+  int a_iy[AP], a_ix[AP];
+  unsigned a_off[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = m0 + r0 + p * RPP;
+    if (m < g.M) {
+      const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, b = tmp / g.LH;
+      a_iy[p] = i * g.iys;
+      a_ix[p] = j * g.ixs;
+      a_off[p] = (unsigned)(((b * g.Hin + a_iy[p]) * g.Win + a_ix[p]) * g.Cin + kq * 4) * 4u;
+    } else {
+      a_iy[p] = -(1 << 20);  // every tap lands outside the image
+      a_ix[p] = 0;
+      a_off[p] = 0;
+    }
+  }
+  // weight rows beyond Cout are clamped to row 0: their products land in accumulator columns that
+  // the epilogue never stores
+  unsigned b_off[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int n = n0 + r0 + p * RPP;
+    b_off[p] = (unsigned)((n < g.Cout ? n : 0) * g.Cin + kq * 4) * 4u;
+  }
+  const char *xb = (const char *)x, *wb = (const char *)w;
+  const unsigned slice_bytes = (unsigned)g.Cout * g.Cin * 4u;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float4 ra[AP], rb[BP];
+  bool ra_ok[AP];
+  int tU = 0, cU = 0;  // UNI: tap / first channel of the K-tile being fetched
+
+  // Loads are UNCONDITIONAL (offset clamped to a valid element; padding taps are zeroed later, in
+  // sstore, so that nothing waits for the data before the MFMAs of the current tile): a conditional
+  // load makes hipcc branch around it and drain vmcnt per element, which serialises the eight
+  // fetches of a K-tile into eight dependent L2 round trips.
+  // K-tile fetch, split into pieces (one global load each) so that the main loop can weave them
+  // between groups of MFMAs: gprep() computes the tile's wave-uniform part, gA(p) / gB(p) issue one
+  // load, sA(p) / sB(p) mask and store one piece to LDS.
+  int g_dy = 0, g_dx = 0;
+  unsigned g_shift = 0, g_wshift = 0;
+  bool g_kv = true;
+  auto gprep = [&](int kt) {
+    if (UNI) {
+      const int tr = __builtin_amdgcn_readfirstlane(tU);
+      const int t = tr < g.T ? tr : g.T - 1;   // past the last tile: a valid, unused fetch
+      const int c0 = __builtin_amdgcn_readfirstlane(cU);
+      cU += BK;
+      const int wrap = cU >= g.Cin;
+      tU += wrap;
+      cU = wrap ? 0 : cU;
+      g_dy = tt.dy[t], g_dx = tt.dx[t];
+      g_shift = (unsigned)((g_dy * g.Win + g_dx) * g.Cin + c0) * 4u;   // SALU
+      g_wshift = (unsigned)tt.ws[t] * slice_bytes + (unsigned)c0 * 4u;
+    } else {
+      const int k = kt * BK + kq * 4;
+      const int t = k / g.Cin, c = k - t * g.Cin;
+      g_kv = t < g.T;
+      const int tc = g_kv ? t : 0;
+      g_dy = tt.dy[tc], g_dx = tt.dx[tc];
+      g_shift = (unsigned)((g_dy * g.Win + g_dx) * g.Cin + c - kq * 4) * 4u;
+      g_wshift = (unsigned)tt.ws[tc] * slice_bytes + (unsigned)(c - kq * 4) * 4u;
+    }
+  };
+  auto gA = [&](int p) {
+    const int iy = a_iy[p] + g_dy, ix = a_ix[p] + g_dx;
+    const bool ok = g_kv & ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
+    ra[p] = *(const float4 *)(xb + (ok ? a_off[p] + g_shift : 0u));
+    ra_ok[p] = ok;
+  };
+  auto gB = [&](int p) {
+    rb[p] = *(const float4 *)(wb + (g_kv ? b_off[p] + g_wshift : 0u));
+  };
+  auto sA = [&](int buf, int p) {
+    float4 v = ra[p];
+    const bool ok = ra_ok[p];
+    v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
+    *(float4 *)(lds + buf * (BM + BN) * LDK + (r0 + p * RPP) * LDK + kq * 4) = v;
+  };
+  auto sB = [&](int buf, int p) {
+    float4 v = rb[p];
+    if (!UNI) {   // generic path (the 7x7 stem only): K padding must contribute zeros
+      const bool kv = g_kv;
+      v.x = kv ? v.x : 0.0f, v.y = kv ? v.y : 0.0f, v.z = kv ? v.z : 0.0f, v.w = kv ? v.w : 0.0f;
+    }
+    *(float4 *)(lds + buf * (BM + BN) * LDK + BM * LDK + (r0 + p * RPP) * LDK + kq * 4) = v;
+  };
+  auto gload = [&](int kt) {
+    gprep(kt);
+#pragma unroll
+    for (int p = 0; p < AP; ++p) gA(p);
+#pragma unroll
+    for (int p = 0; p < BP; ++p) gB(p);
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < AP; ++p) sA(buf, p);
+#pragma unroll
+    for (int p = 0; p < BP; ++p) sB(buf, p);
+  };
+
+  const int lr = lane & 31, lh = lane >> 5;
+  // Fragments of the NEXT 8-deep k-block are fetched from LDS before the MFMAs of the current one
+  // are issued, and the staging stores of the next K-tile sit in the middle of the MFMA stream: a
+  // 32x32x2 f32 MFMA occupies the matrix pipe for 64 cycles but the wave's issue slot for 8, so all
+  // of this runs in the MFMAs' shadow as long as it is in the same basic block (no branches in the
+  // steady-state loop: the last K-tile is peeled).
+  float4 af[2][TM], bf[2][TN];
+  auto frag = [&](int buf, int kb, int slot) {
+    const float *As = lds + buf * (BM + BN) * LDK + (wm * WM + lr) * LDK + lh * 4;
+    const float *Bs = lds + buf * (BM + BN) * LDK + BM * LDK + (wn * WN + lr) * LDK + lh * 4;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) af[slot][a] = *(const float4 *)(As + a * 32 * LDK + kb * 8);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bf[slot][b] = *(const float4 *)(Bs + b * 32 * LDK + kb * 8);
+  };
+  auto mma_ab = [&](int slot, int a, int b) {
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a].x, bf[slot][b].x, acc[a][b], 0, 0, 0);
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a].y, bf[slot][b].y, acc[a][b], 0, 0, 0);
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a].z, bf[slot][b].z, acc[a][b], 0, 0, 0);
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a].w, bf[slot][b].w, acc[a][b], 0, 0, 0);
+  };
+  auto mma = [&](int slot) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) mma_ab(slot, a, b);
+  };
+  constexpr int NKB = BK / 8;
+  static_assert(NKB == 4, "the K-tile schedule below is written for BK = 32");
+
+  const int KT = (g.Ktot + BK - 1) / BK;
+#ifdef DCONV_STAMPS
+  long long st_t[6] = {0, 0, 0, 0, 0, 0};
+  const long long st_real0 = __builtin_amdgcn_s_memrealtime();
+  long long st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i)                                        \
+  do {                                                  \
+    const long long now_ = __builtin_amdgcn_s_memtime(); \
+    st_t[i] += now_ - st_prev;                          \
+    st_prev = now_;                                     \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  STAMP(0);
+  // Steady state: the 4 x (TM*TN) groups of 4 MFMAs of a K-tile are issued in a fixed order
+  // (sched_barrier pins) with ONE piece of memory work in front of each group: the next tile's
+  // global loads in front of the first groups, its masked LDS stores in front of the last ones
+  // (>= half a tile of MFMAs later), so the wave never stops feeding the matrix pipe except at the
+  // barrier.
+  constexpr int G = TM * TN, NG = 4 * G, NP = AP + BP;
+  constexpr int HALF = NG / 2, PPG = (NP + HALF - 1) / HALF;   // pieces per MFMA group
+  for (int kt = 0; kt + 1 < KT; ++kt) {
+    const int buf = kt & 1;
+    frag(buf, 0, 0);
+    frag(buf, 1, 1);
+    gprep(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int kb = gi / G, ab = gi % G;
+#pragma unroll
+      for (int q = 0; q < PPG; ++q) {
+        const int p = (gi % HALF) * PPG + q;
+        if (p < NP) {
+          if (gi < HALF) {                 // first half of the groups: the next tile's loads
+            if (p < AP) gA(p); else gB(p - AP);
+          } else {                         // second half: its masked LDS stores
+            if (p < AP) sA(buf ^ 1, p); else sB(buf ^ 1, p - AP);
+          }
+        }
+      }
+      if (ab == 0 && kb >= 1 && kb + 1 < 4) frag(buf, kb + 1, (kb + 1) & 1);   // prefetch next k-block
+      __builtin_amdgcn_sched_barrier(0);
+      mma_ab(kb & 1, ab / TN, ab % TN);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
+  }
+  {
+    const int buf = (KT - 1) & 1;
+    frag(buf, 0, 0);
+    frag(buf, 1, 1);
+    mma(0);
+    frag(buf, 2, 0);
+    mma(1);
+    frag(buf, 3, 1);
+    mma(0);
+    mma(1);
+  }
+#ifdef DCONV_STAMPS
+  if (lane == 0 && g.relu == 2) {   // debug build only: relu == 2 asks for the stamp dump
+    long long *dbg = (long long *)bias_arg;   // caller passes a buffer of 6 * waves int64 as `bias`
+    const int wv_id = (blockIdx.x * (NT / 64) + wave);
+    for (int i = 0; i < 6; ++i) dbg[wv_id * 8 + i] = st_t[i];
+    dbg[wv_id * 8 + 0] = __builtin_amdgcn_s_memrealtime() - st_real0;   // 100 MHz ticks, whole loop
+    dbg[wv_id * 8 + 6] = st_real0 - st_entry;                          // entry -> loop start
+  }
+  bias = nullptr;
+  const long long st_loop_end = __builtin_amdgcn_s_memrealtime();
+  long long *dbg_end = (long long *)bias_arg;
+#endif
+
+  // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane
+  // >> 5): a lane owns single floats of 16 rows, so storing straight from the accumulators issues 64
+  // two-line stores per wave (measured: a quarter of the kernel at one round of tiles).  Instead each
+  // wave transposes its WM x WN tile through its own slice of the (now idle) LDS and writes whole
+  // rows 16 bytes per lane.
+  constexpr int LDC = WN + 4;
+  static_assert(WAVES_M * WAVES_N * WM * LDC <= 2 * (BM + BN) * LDK, "epilogue tile must fit the LDS");
+  __syncthreads();   // every wave has finished reading the operand tiles
+  float *cs = lds + wave * WM * LDC;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + wn * WN + b * 32 + lr;
+    const float bv = (bias != nullptr && n < g.Cout) ? bias[n] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[a][b][r] + bv;
+        if (g.relu == 1) v = fmaxf(v, 0.0f);
+        cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + b * 32 + lr] = v;
+      }
+  }
+  // (same wave reads what it wrote: the compiler's lgkmcnt wait orders it, no barrier)
+  constexpr int CQ = WN / 4;          // float4 per tile row
+  constexpr int RPI = 64 / CQ;        // rows per wave-instruction
+  const int cq = lane % CQ, rr = lane / CQ;
+  const int ncol = n0 + wn * WN + cq * 4;
+  const bool vec_ok = (g.Cout & 3) == 0;
+#pragma unroll 4
+  for (int it = 0; it < WM / RPI; ++it) {
+    const int rl = it * RPI + rr;
+    const int m = m0 + wm * WM + rl;
+    if (m >= g.M || ncol >= g.Cout) continue;
+    size_t row;
+    if (g.dense_out) {
+      row = (size_t)m;
+    } else {
+      const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, bb = tmp / g.LH;
+      row = ((size_t)bb * g.Hout + g.oy0 + i * g.oys) * g.Wout + g.ox0 + j * g.oxs;
+    }
+    const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
+    float *dst = y + row * g.Cout + ncol;
+    if (vec_ok && ncol + 3 < g.Cout) {
+      *(float4 *)dst = v;
+    } else {
+      dst[0] = v.x;
+      if (ncol + 1 < g.Cout) dst[1] = v.y;
+      if (ncol + 2 < g.Cout) dst[2] = v.z;
+      if (ncol + 3 < g.Cout) dst[3] = v.w;
+    }
+  }
+#ifdef DCONV_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0 && g.relu == 2)
+    dbg_end[(blockIdx.x * (NT / 64) + wave) * 8 + 7] = __builtin_amdgcn_s_memrealtime() - st_loop_end;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient:  G[t][u][v] = sum_m U[m][u] * V[b, i*vys + dy[t], j*vxs + dx[t]][v]
+// (Conv2d: U = dy, V = x, G = dW[t][cout][cin]; ConvTranspose2d: U = x, V = dy, G = dW[t][cin][cout]).
+// Grid = (tap, u-tile, v-tile) x nsplit chunks of the pixel range; partial tiles go to the workspace
+// [nsplit][T][Cu][Cv], dconv_wgrad_reduce sums them in a fixed order and writes the caller's layout.
+struct DWgradGeom {
+  int B, LH, LW;         // lattice of U rows (dense: row m at U + m*Cu)
+  int Cu, Cv;
+  int Hv, Wv;            // V image
+  int vys, vxs;
+  int T;
+  int M;                 // B*LH*LW
+  int chunk;             // rows per split (multiple of BK)
+};
+
+template <int BU, int BV, int BK, int WAVES_U, int WAVES_V>
+__global__ __launch_bounds__(WAVES_U *WAVES_V * 64) void dconv_wgrad_kernel(
+    const float *__restrict__ U, const float *__restrict__ V, float *__restrict__ part,
+    const DWgradGeom g, const DConvTaps tt, int n_tiles_u, int n_tiles_v) {
+  constexpr int NT = WAVES_U * WAVES_V * 64;
+  constexpr int LDU = BU + 4, LDV = BV + 4;
+  constexpr int WU = BU / WAVES_U, WV = BV / WAVES_V, TU = WU / 32, TV = WV / 32;
+  constexpr int UQ = BU / 4, VQ = BV / 4;           // float4 per staged row
+  constexpr int URPP = NT / UQ, VRPP = NT / VQ;     // pixel rows per pass
+  constexpr int UP = BK / URPP, VP = BK / VRPP;
+  static_assert(BK % URPP == 0 && BK % VRPP == 0 && UP >= 1 && VP >= 1, "tile shape");
+  constexpr int LDS_STAGE = 2 * BK * (LDU + LDV), LDS_EPI = WAVES_U * WAVES_V * WU * (WV + 4);
+  __shared__ __attribute__((aligned(16))) float lds[LDS_STAGE > LDS_EPI ? LDS_STAGE : LDS_EPI];
+
+  int tile = blockIdx.x;
+  const int vt = tile % n_tiles_v;
+  tile /= n_tiles_v;
+  const int ut = tile % n_tiles_u;
+  const int t = tile / n_tiles_u;
+  const int split = blockIdx.y;
+  const int m_lo = split * g.chunk;
+  const int m_hi = min(g.M, m_lo + g.chunk);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wu = wave / WAVES_V, wv = wave % WAVES_V;
+  const int u0 = ut * BU, v0 = vt * BV;
+  const int uq = tid % UQ, ur0 = tid / UQ;
+  const int vq = tid % VQ, vr0 = tid / VQ;
+  const int dy = tt.dy[t], dx = tt.dx[t];
+  const bool u_ok = u0 + uq * 4 < g.Cu, v_ok = v0 + vq * 4 < g.Cv;
+
+  f32x16 acc[TU][TV];
+#pragma unroll
+  for (int a = 0; a < TU; ++a)
+#pragma unroll
+    for (int b = 0; b < TV; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float4 ru[UP], rv[VP];
+  bool ru_ok[UP], rv_ok[VP];
+  // unconditional loads from clamped addresses, masked on the way to LDS (see dconv_gemm_kernel);
+  // one piece = one global load, woven between the MFMA groups of the main loop
+  auto gU = [&](int kt, int p) {
+    const int m = m_lo + kt * BK + ur0 + p * URPP;
+    const bool ok = (m < m_hi) & u_ok;
+    ru[p] = *(const float4 *)(U + (size_t)(ok ? m : m_lo) * g.Cu + (u_ok ? u0 + uq * 4 : 0));
+    ru_ok[p] = ok;
+  };
+  auto gV = [&](int kt, int p) {
+    const int m = m_lo + kt * BK + vr0 + p * VRPP;
+    const int mm = m < m_hi ? m : m_lo;
+    const int j = mm % g.LW, tmp = mm / g.LW, i = tmp % g.LH, b = tmp / g.LH;
+    const int iy = i * g.vys + dy, ix = j * g.vxs + dx;
+    const bool ok = (m < m_hi) & v_ok & ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
+    const int pix = ok ? (b * g.Hv + iy) * g.Wv + ix : 0;
+    rv[p] = *(const float4 *)(V + (size_t)pix * g.Cv + (v_ok ? v0 + vq * 4 : 0));
+    rv_ok[p] = ok;
+  };
+  auto sU = [&](int buf, int p) {
+    float4 v = ru[p];
+    const bool ok = ru_ok[p];
+    v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
+    *(float4 *)(lds + buf * BK * (LDU + LDV) + (ur0 + p * URPP) * LDU + uq * 4) = v;
+  };
+  auto sV = [&](int buf, int p) {
+    float4 v = rv[p];
+    const bool ok = rv_ok[p];
+    v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
+    *(float4 *)(lds + buf * BK * (LDU + LDV) + BK * LDU + (vr0 + p * VRPP) * LDV + vq * 4) = v;
+  };
+  const int lr = lane & 31, lh = lane >> 5;
+  float af[2][TU], bf[2][TV];
+  auto frag = [&](int buf, int kk, int slot) {
+    const float *Us = lds + buf * BK * (LDU + LDV) + lh * LDU + wu * WU + lr;
+    const float *Vs = lds + buf * BK * (LDU + LDV) + BK * LDU + lh * LDV + wv * WV + lr;
+#pragma unroll
+    for (int a = 0; a < TU; ++a) af[slot][a] = Us[kk * 2 * LDU + a * 32];
+#pragma unroll
+    for (int b = 0; b < TV; ++b) bf[slot][b] = Vs[kk * 2 * LDV + b * 32];
+  };
+  auto mma = [&](int slot) {
+#pragma unroll
+    for (int a = 0; a < TU; ++a)
+#pragma unroll
+      for (int b = 0; b < TV; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a], bf[slot][b], acc[a][b], 0, 0, 0);
+  };
+
+  const int KT = (m_hi - m_lo + BK - 1) / BK;
+  constexpr int NG = BK / 2, HALF = NG / 2, NP = UP + VP, PPG = (NP + HALF - 1) / HALF;
+  if (KT > 0) {
+#pragma unroll
+    for (int p = 0; p < UP; ++p) gU(0, p);
+#pragma unroll
+    for (int p = 0; p < VP; ++p) gV(0, p);
+#pragma unroll
+    for (int p = 0; p < UP; ++p) sU(0, p);
+#pragma unroll
+    for (int p = 0; p < VP; ++p) sV(0, p);
+    __syncthreads();
+    // same pinned schedule as dconv_gemm_kernel: one piece of memory work in front of each group of
+    // MFMAs (loads of the next tile first, its LDS stores in the second half), fragments one k-pair
+    // ahead
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+      const int buf = kt & 1;
+      frag(buf, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+        for (int q = 0; q < PPG; ++q) {
+          const int p = (gi % HALF) * PPG + q;
+          if (p < NP) {
+            if (gi < HALF) {
+              if (p < UP) gU(kt + 1, p); else gV(kt + 1, p - UP);
+            } else {
+              if (p < UP) sU(buf ^ 1, p); else sV(buf ^ 1, p - UP);
+            }
+          }
+        }
+        if (gi + 1 < NG) frag(buf, gi + 1, (gi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(gi & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+    {
+      const int buf = (KT - 1) & 1;
+      frag(buf, 0, 0);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) frag(buf, gi + 1, (gi + 1) & 1);
+        mma(gi & 1);
+      }
+    }
+  }
+  float *dst = part + ((size_t)split * g.T + t) * g.Cu * g.Cv;
+  // transposed through LDS and stored 16 bytes per lane (see dconv_gemm_kernel's epilogue)
+  constexpr int LDC = WV + 4;
+  __syncthreads();
+  float *cs = lds + wave * WU * LDC;
+#pragma unroll
+  for (int b = 0; b < TV; ++b)
+#pragma unroll
+    for (int a = 0; a < TU; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + b * 32 + lr] = acc[a][b][r];
+  constexpr int CQ = WV / 4, RPI = 64 / CQ;
+  const int cq = lane % CQ, rr = lane / CQ;
+  const int vcol = v0 + wv * WV + cq * 4;
+#pragma unroll 4
+  for (int it = 0; it < WU / RPI; ++it) {
+    const int rl = it * RPI + rr;
+    const int u = u0 + wu * WU + rl;
+    if (u < g.Cu && vcol < g.Cv)     // Cv % 4 == 0: whole float4 in range
+      *(float4 *)(dst + (size_t)u * g.Cv + vcol) = *(const float4 *)(cs + rl * LDC + cq * 4);
+  }
+}
+
+// out[u*su + v*sv + t*st] = scale_u[u] * sum_s part[s][t][u][v]   (v < Cv_out: drops channel padding)
+__global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(
+    const float *__restrict__ part, float *__restrict__ out, const float *__restrict__ scale_u,
+    int nsplit, int T, int Cu, int Cv, int Cv_out, long long su, long long sv, long long st,
+    int accumulate) {
+  const long long total = (long long)T * Cu * Cv;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int v = (int)(e % Cv);
+  const long long r = e / Cv;
+  const int u = (int)(r % Cu), t = (int)(r / Cu);
+  if (v >= Cv_out) return;
+  float s = 0.0f;
+  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * total + e];
+  if (scale_u) s *= scale_u[u];
+  float *o = out + u * su + v * sv + t * st;
+  *o = accumulate ? *o + s : s;
+}
+
+// dst[s][n][k] = src[n*sn + k*sk + s*st] * scale_n[n] * scale_k[k]   (k >= Ksrc, n >= Nsrc: zero)
+__global__ __launch_bounds__(256) void dconv_pack_kernel(const float *__restrict__ src,
+                                                         float *__restrict__ dst,
+                                                         const float *__restrict__ scale_n,
+                                                         const float *__restrict__ scale_k, int S,
+                                                         int N, int K, int Nsrc, int Ksrc,
+                                                         long long sn, long long sk, long long st) {
+  const long long total = (long long)S * N * K;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int k = (int)(e % K);
+  const long long r = e / K;
+  const int n = (int)(r % N), s = (int)(r / N);
+  float v = 0.0f;
+  if (k < Ksrc && n < Nsrc) {
+    v = src[n * sn + k * sk + s * st];
+    if (scale_n) v *= scale_n[n];
+    if (scale_k) v *= scale_k[k];
+  }
+  dst[e] = v;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNI, bool SOLO = false>
+int launch_gemm(const float *x, const float *w, const float *bias, float *y, DConvGeom g,
+                const DConvTaps &tt, hipStream_t st, int m_lo = 0, int m_hi = -1) {
+  if (m_hi < 0) m_hi = g.M;
+  if (m_hi <= m_lo) return DM_OK;
+  g.M = m_hi;
+  const int tm = dm_ceil_div(m_hi - m_lo, BM), tn = dm_ceil_div(g.Cout, BN);
+  const int blocks = dm_ceil_div(tm, 8) * 8 * tn;
+  dconv_gemm_kernel<BM, BN, 32, WAVES_M, WAVES_N, UNI, SOLO>
+      <<<blocks, WAVES_M * WAVES_N * 64, 0, st>>>(x, w, bias, y, g, tt, tm, tn, m_lo);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" int dm_dconv_pack(const float *src, float *dst, const float *scale_n,
+                             const float *scale_k, int S, int N, int K, int Nsrc, int Ksrc,
+                             long long sn, long long sk, long long st, dm_stream_t stream) {
+  if (S <= 0 || N <= 0 || K <= 0) return DM_OK;
+  if (!src || !dst || Ksrc > K || Nsrc > N) return DM_ERR_INVALID_ARG;
+  const long long total = (long long)S * N * K;
+  dconv_pack_kernel<<<dm_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(
+      src, dst, scale_n, scale_k, S, N, K, Nsrc, Ksrc, sn, sk, st);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+// geom_host: 17 ints {B,Hin,Win,Cin, Hout,Wout,Cout, LH,LW, oy0,ox0,oys,oxs, iys,ixs, T, relu};
+// taps_host: 3*T shorts {dy[T], dx[T], wslice[T]}.
+extern "C" int dm_dconv_gemm(const float *x, const float *w_packed, const float *bias, float *y,
+                             const int *geom_host, const short *taps_host, dm_stream_t stream) {
+  if (!x || !w_packed || !y || !geom_host || !taps_host) return DM_ERR_INVALID_ARG;
+  DConvGeom g;
+  const int *q = geom_host;
+  g.B = q[0], g.Hin = q[1], g.Win = q[2], g.Cin = q[3];
+  g.Hout = q[4], g.Wout = q[5], g.Cout = q[6];
+  g.LH = q[7], g.LW = q[8];
+  g.oy0 = q[9], g.ox0 = q[10], g.oys = q[11], g.oxs = q[12];
+  g.iys = q[13], g.ixs = q[14];
+  g.T = q[15], g.relu = q[16];
+  if (g.T < 1 || g.T > DCONV_MAX_TAPS || (g.Cin & 3) || g.Cin < 4 || g.Cout < 1)
+    return DM_ERR_UNSUPPORTED;
+  const long long M = (long long)g.B * g.LH * g.LW;
+  if (M == 0) return DM_OK;
+  int max_slice = 0;
+  for (int t = 0; t < g.T; ++t) max_slice = taps_host[2 * g.T + t] > max_slice ? taps_host[2 * g.T + t] : max_slice;
+  // the kernel addresses both operands with 32-bit byte offsets
+  if (M < 0 || M > 0x7fffffffLL || (long long)g.B * g.Hin * g.Win * g.Cin * 4 >= 0xffffffffLL ||
+      (long long)(max_slice + 1) * g.Cout * g.Cin * 4 >= 0xffffffffLL)
+    return DM_ERR_INT32_RANGE;
+  g.M = (int)M;
+  g.Ktot = g.T * g.Cin;
+  g.dense_out = (g.oy0 == 0 && g.ox0 == 0 && g.oys == 1 && g.oxs == 1 && g.LH == g.Hout &&
+                 g.LW == g.Wout);
+  DConvTaps tt;
+  for (int t = 0; t < DCONV_MAX_TAPS; ++t) tt.dy[t] = tt.dx[t] = tt.ws[t] = 0;
+  for (int t = 0; t < g.T; ++t) {
+    tt.dy[t] = taps_host[t];
+    tt.dx[t] = taps_host[g.T + t];
+    tt.ws[t] = taps_host[2 * g.T + t];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const bool uni = (g.Cin % 32) == 0;
+  if (!uni) return launch_gemm<128, 64, 2, 2, false>(x, w_packed, bias, y, g, tt, st);
+  if (g.Cout <= 32) return launch_gemm<128, 32, 4, 1, true>(x, w_packed, bias, y, g, tt, st);
+  // Tile choice is a scheduling problem: a 128x128 tile (4 waves, 64 MFMAs per wave and K-step) is
+  // the efficient one, two fit a CU, so the chip runs 512 at a time ("a round", one CU-second of
+  // MFMA work each); what is left after the full rounds would occupy a few CUs for a whole round.
+  // That tail is handed to 64x64 tiles (a quarter of the work each) in a second launch limited to
+  // one workgroup per CU, which spreads it over the chip.
+  const int SLOTS = 512;
+  const bool narrow = g.Cout <= 64 || ((g.Cout % 128) > 0 && (g.Cout % 128) <= 64 && g.Cout < 256);
+  if (narrow) {
+    const int tm = dm_ceil_div(g.M, 128), tn = dm_ceil_div(g.Cout, 64);
+    const long long tiles = (long long)tm * tn;
+    if (tiles < SLOTS) return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
+    const int rem = (int)(tiles % SLOTS);
+    if (rem == 0 || rem > (SLOTS * 3) / 4)
+      return launch_gemm<128, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
+    const int mt_main = (int)((tiles - rem) / tn) / 8 * 8;
+    int rc = launch_gemm<128, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, 0, mt_main * 128);
+    if (rc != DM_OK) return rc;
+    return launch_gemm<64, 64, 2, 2, true, true>(x, w_packed, bias, y, g, tt, st, mt_main * 128);
+  }
+  const int tm = dm_ceil_div(g.M, 128), tn = dm_ceil_div(g.Cout, 128);
+  const long long tiles = (long long)tm * tn;
+  if (tiles <= 256) return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
+  const int rem = (int)(tiles % SLOTS);
+  if (rem == 0 || rem > (SLOTS * 3) / 4)
+    return launch_gemm<128, 128, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
+  const int mt_main = (int)((tiles - rem) / tn) / 8 * 8;
+  int rc = DM_OK;
+  if (mt_main > 0)
+    rc = launch_gemm<128, 128, 2, 2, true>(x, w_packed, bias, y, g, tt, st, 0, mt_main * 128);
+  if (rc != DM_OK) return rc;
+  const long long tail_tiles = (long long)dm_ceil_div(g.M - mt_main * 128, 64) * dm_ceil_div(g.Cout, 64);
+  if (tail_tiles <= 1024)
+    return launch_gemm<64, 64, 2, 2, true, true>(x, w_packed, bias, y, g, tt, st, mt_main * 128);
+  return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, mt_main * 128);
+}
+
+static int dconv_wgrad_splits(long long M, int T, int Cu, int Cv) {
+  // one full round of workgroups: 2 per CU for the 128x128 tile, 4 per CU for the 64x64 tile
+  const bool small = Cu <= 64 || Cv <= 64;
+  const int tile = small ? 64 : 128, slots = small ? 1024 : 512;
+  const long long tiles = (long long)T * dm_ceil_div(Cu, tile) * dm_ceil_div(Cv, tile);
+  long long want = slots / tiles;
+  const long long max_split = (M + 255) / 256;         // at least 256 pixels per chunk
+  if (want > max_split) want = max_split;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+// geom_host: 10 ints {B, LH, LW, Cu, Cv, Hv, Wv, vys, vxs, T}
+extern "C" size_t dm_dconv_wgrad_workspace_bytes(const int *geom_host) {
+  const int *q = geom_host;
+  const long long M = (long long)q[0] * q[1] * q[2];
+  const int ns = dconv_wgrad_splits(M, q[9], q[3], q[4]);
+  return dm_align((size_t)ns * q[9] * q[3] * q[4] * sizeof(float));
+}
+
+extern "C" int dm_dconv_wgrad(const float *U, const float *V, float *out, const float *scale_u,
+                              const int *geom_host, const short *taps_host, int Cv_out,
+                              long long su, long long sv, long long st_, int accumulate,
+                              void *workspace, size_t workspace_bytes, dm_stream_t stream) {
+  if (!U || !V || !out || !geom_host || !taps_host) return DM_ERR_INVALID_ARG;
+  const int *q = geom_host;
+  DWgradGeom g;
+  g.B = q[0], g.LH = q[1], g.LW = q[2], g.Cu = q[3], g.Cv = q[4], g.Hv = q[5], g.Wv = q[6];
+  g.vys = q[7], g.vxs = q[8], g.T = q[9];
+  if (g.T < 1 || g.T > DCONV_MAX_TAPS || (g.Cu & 3) || (g.Cv & 3) || Cv_out > g.Cv)
+    return DM_ERR_UNSUPPORTED;
+  const long long M = (long long)g.B * g.LH * g.LW;
+  if (M > 0x7fffffffLL || (long long)g.B * g.Hv * g.Wv * g.Cv > 0x7fffffffLL)
+    return DM_ERR_INT32_RANGE;
+  g.M = (int)M;
+  if (workspace_bytes < dm_dconv_wgrad_workspace_bytes(geom_host) || !workspace)
+    return DM_ERR_WORKSPACE;
+  const int ns = dconv_wgrad_splits(M, g.T, g.Cu, g.Cv);
+  g.chunk = (int)(((M + ns - 1) / ns + 31) / 32 * 32);
+  DConvTaps tt;
+  for (int t = 0; t < DCONV_MAX_TAPS; ++t) tt.dy[t] = tt.dx[t] = tt.ws[t] = 0;
+  for (int t = 0; t < g.T; ++t) tt.dy[t] = taps_host[t], tt.dx[t] = taps_host[g.T + t];
+  hipStream_t st = (hipStream_t)stream;
+  float *part = (float *)workspace;
+  if (g.Cu <= 64 || g.Cv <= 64) {
+    const int tu = dm_ceil_div(g.Cu, 64), tv = dm_ceil_div(g.Cv, 64);
+    dconv_wgrad_kernel<64, 64, 32, 2, 2><<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g, tt,
+                                                                                 tu, tv);
+  } else {
+    const int tu = dm_ceil_div(g.Cu, 128), tv = dm_ceil_div(g.Cv, 128);
+    dconv_wgrad_kernel<128, 128, 32, 2, 2><<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g,
+                                                                                   tt, tu, tv);
+  }
+  DM_CHECK_LAUNCH();
+  const long long total = (long long)g.T * g.Cu * g.Cv;
+  dconv_wgrad_reduce_kernel<<<dm_ceil_div(total, 256), 256, 0, st>>>(
+      part, out, scale_u, ns, g.T, g.Cu, g.Cv, Cv_out, su, sv, st_, accumulate);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}

@@ -1,0 +1,276 @@
+"""Dense 2-D convolutions on the hand-written fp32-MFMA implicit-GEMM kernels (csrc/conv2d.hip).
+
+Host-side mirror of `torch.nn.functional.conv2d` / `conv_transpose2d` for the shapes of the DetMatch
+path (pcdet/models/backbones_2d/base_bev_backbone.py:38-69, anchor_head_single.py:20-37, mmdet
+ResNet-50/FPN/RPN at configs/detmatch/001/detmatch/split_0.py:39-99): same argument meaning, same
+(N, C, H, W) logical shapes; tensors are kept in `torch.channels_last` memory format (= NHWC rows),
+which is what the kernels read and write.  Forward, input gradient and weight gradient all run in
+libdetmatch_hip.so; there is no MIOpen / cuDNN call and no CPU path (`DetMatchHipError` on CPU
+tensors) — except when a TEST sets `TORCH_REFERENCE_FOR_TESTS = True`, which routes CPU tensors to
+torch's own convolution so that host logic around the convolutions can be checked without a GPU.
+"""
+import ctypes
+import weakref
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+# Set by CPU-only tests (tests/conftest.py).  Never set by the product, bench.py or smoke().
+TORCH_REFERENCE_FOR_TESTS = False
+
+# Bumped by whoever rewrites weights through raw pointers (fused optimizer / EMA kernels): the
+# packed-weight cache is keyed on it (ordinary in-place torch updates bump Tensor._version).
+_GENERATION = [0]
+_PACK_CACHE = {}
+
+
+def weights_changed():
+    _GENERATION[0] += 1
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+
+
+def _shorts(v):
+    return (ctypes.c_short * len(v))(*[int(x) for x in v])
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def _cl(x):
+    """(N,C,H,W) tensor whose memory is dense NHWC."""
+    if x.dim() != 4:
+        raise ValueError('expected a (N, C, H, W) tensor')
+    st = x.stride()
+    n, c, h, w = x.shape
+    if st == (h * w * c, 1, w * c, c):
+        return x
+    return x.contiguous(memory_format=torch.channels_last) if (c > 1 and h * w > 1) else \
+        x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def _empty_cl(n, c, h, w, like):
+    return torch.empty((n, h, w, c), dtype=torch.float32, device=like.device).permute(0, 3, 1, 2)
+
+
+def _pad_channels(x, c4):
+    """Zero-pad the channel dimension of an NHWC tensor to c4 (the RGB stem: 3 -> 4)."""
+    n, c, h, w = x.shape
+    if c == c4:
+        return x
+    out = torch.zeros((n, h, w, c4), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+    out[:, :c] = x
+    return out
+
+
+def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None):
+    """[S][N][K] packed copy of `weight` (cached until the weight or a scale changes)."""
+    cacheable = isinstance(weight, nn.Parameter)     # temporaries may recycle an address
+    key = (id(weight), weight.data_ptr(), tag, N, K)
+    ver = (_GENERATION[0], weight._version,
+           None if scale_n is None else (scale_n.data_ptr(), scale_n._version),
+           None if scale_k is None else (scale_k.data_ptr(), scale_k._version),
+           torch.cuda.current_stream().cuda_stream)
+    hit = _PACK_CACHE.get(key) if cacheable else None
+    if hit is not None and hit[0] == ver and hit[3]() is weight:
+        return hit[1]
+    dst = torch.empty((S, N, K), dtype=torch.float32, device=weight.device)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    _lib.check(_lib.lib().dm_dconv_pack(_lib.ptr(w), _lib.ptr(dst), _lib.ptr(scale_n),
+                                        _lib.ptr(scale_k), S, N, K, n_src, k_src, sn, sk, st,
+                                        _lib.stream()), 'dm_dconv_pack')
+    if cacheable:
+        _PACK_CACHE[key] = (ver, dst, w, weakref.ref(weight))
+    return dst
+
+
+def _gemm(x, wp, bias, y, geom, taps):
+    """geom: the 17 ints of dm_dconv_gemm; taps: [(dy, dx, slice)]."""
+    t = [a for a, _, _ in taps] + [b for _, b, _ in taps] + [c for _, _, c in taps]
+    _lib.check(_lib.lib().dm_dconv_gemm(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y),
+                                        _lib.ints(geom), _shorts(t), _lib.stream()), 'dm_dconv_gemm')
+
+
+def _wgrad(U, V, out, scale_u, geom, taps, cv_out, su, sv, st):
+    L = _lib.lib()
+    g = _lib.ints(geom)
+    nbytes = L.dm_dconv_wgrad_workspace_bytes(g)
+    ws = _lib.workspace(nbytes, U.device, 'dconv_wgrad')
+    t = [a for a, _ in taps] + [b for _, b in taps]
+    _lib.check(L.dm_dconv_wgrad(_lib.ptr(U), _lib.ptr(V), _lib.ptr(out), _lib.ptr(scale_u), g,
+                                _shorts(t), cv_out, su, sv, st, 0, _lib.ptr(ws), ws.numel(),
+                                _lib.stream()), 'dm_dconv_wgrad')
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def _require(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DetMatchHipError(
+                'detmatch_amd.dense_conv runs on the MI355X only (got a %s tensor); there is no '
+                'CPU path' % t.device)
+
+
+class _Conv2dFn(torch.autograd.Function):
+    """y = conv2d(x, weight * w_scale[:, None, None, None], bias, stride, padding) [+ ReLU]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_scale, stride, padding, relu):
+        cout, cin, kh, kw = weight.shape
+        (sh, sw), (ph, pw) = stride, padding
+        x = _pad_channels(_cl(x.detach()), _pad4(cin))
+        n, c4, h, w = x.shape
+        ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+        T = kh * kw
+        wp = _pack(weight, 'f', T, cout, c4, cout, cin, cin * T, T, 1, scale_n=w_scale)
+        y = _empty_cl(n, cout, ho, wo, x)
+        taps = [(a - ph, b - pw, a * kw + b) for a in range(kh) for b in range(kw)]
+        _gemm(x, wp, None if bias is None else bias.detach(), y,
+              [n, h, w, c4, ho, wo, cout, ho, wo, 0, 0, 1, 1, sh, sw, T, int(relu)], taps)
+        ctx.geom = (stride, padding, relu, (n, cin, h, w))
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, w_scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, w_scale, y = ctx.saved_tensors
+        (sh, sw), (ph, pw), relu, (n, cin, h, w) = ctx.geom
+        cout, _, kh, kw = weight.shape
+        c4 = x.shape[1]
+        T = kh * kw
+        if relu:
+            dy = dy * (y > 0)
+        if cout % 4:       # the kernels read rows of the gradient 16 bytes at a time
+            raise _lib.DetMatchHipError('dense_conv: Cout must be a multiple of 4 (pad the layer)')
+        dy = _cl(dy)
+        ho, wo = dy.shape[2], dy.shape[3]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = _pack(weight, 'b', T, c4, cout, cin, cout, T, cin * T, 1, scale_k=w_scale)
+            dxp = _empty_cl(n, c4, h, w, dy)
+            if sh == 1 and sw == 1:
+                taps = [(ph - a, pw - b, a * kw + b) for a in range(kh) for b in range(kw)]
+                _gemm(dy, wt, None, dxp, [n, ho, wo, cout, h, w, c4, h, w, 0, 0, 1, 1, 1, 1, T, 0],
+                      taps)
+            else:
+                classes = []
+                for ry in range(sh):
+                    for rx in range(sw):
+                        taps = [((ry + ph - a) // sh, (rx + pw - b) // sw, a * kw + b)
+                                for a in range(kh) for b in range(kw)
+                                if (ry + ph - a) % sh == 0 and (rx + pw - b) % sw == 0]
+                        lh, lw = (h - ry + sh - 1) // sh, (w - rx + sw - 1) // sw
+                        classes.append((ry, rx, lh, lw, taps))
+                if any(not c[4] for c in classes):
+                    dxp.zero_()
+                for ry, rx, lh, lw, taps in classes:
+                    if taps and lh > 0 and lw > 0:
+                        _gemm(dy, wt, None, dxp, [n, ho, wo, cout, h, w, c4, lh, lw, ry, rx, sh, sw,
+                                                  1, 1, len(taps), 0], taps)
+            dx = dxp if c4 == cin else dxp[:, :cin]
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            taps = [(a - ph, b - pw) for a in range(kh) for b in range(kw)]
+            _wgrad(dy, x, dw, w_scale, [n, ho, wo, cout, c4, h, w, sh, sw, T], taps, cin,
+                   cin * T, T, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 2, 3))
+        return dx, dw, db, None, None, None, None
+
+
+class _ConvTranspose2dFn(torch.autograd.Function):
+    """ConvTranspose2d with kernel == stride, no padding, no bias (the BEV backbone's deblocks,
+    base_bev_backbone.py:52-58): every output pixel has exactly one tap."""
+
+    @staticmethod
+    def forward(ctx, x, weight, k):
+        cin, cout = weight.shape[0], weight.shape[1]
+        x = _cl(x.detach())
+        n, _, h, w = x.shape
+        T = k * k
+        wp = _pack(weight, 'tf', T, cout, cin, cout, cin, T, cout * T, 1)
+        y = _empty_cl(n, cout, h * k, w * k, x)
+        for a in range(k):
+            for b in range(k):
+                _gemm(x, wp, None, y, [n, h, w, cin, h * k, w * k, cout, h, w, a, b, k, k, 1, 1, 1, 0],
+                      [(0, 0, a * k + b)])
+        ctx.k = k
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        k = ctx.k
+        cin, cout = weight.shape[0], weight.shape[1]
+        n, _, h, w = x.shape
+        T = k * k
+        dy = _cl(dy)
+        dx = dw = None
+        taps = [(a, b) for a in range(k) for b in range(k)]
+        if ctx.needs_input_grad[0]:
+            wt = _pack(weight, 'tb', T, cin, cout, cin, cout, cout * T, T, 1)
+            dx = _empty_cl(n, cin, h, w, dy)
+            _gemm(dy, wt, None, dx, [n, h * k, w * k, cout, h, w, cin, h, w, 0, 0, 1, 1, k, k, T, 0],
+                  [(a, b, a * k + b) for a, b in taps])
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            _wgrad(x, dy, dw, None, [n, h, w, cin, cout, h * k, w * k, k, k, T], taps, cout,
+                   cout * T, T, 1)
+        return dx, dw, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, w_scale=None):
+    """F.conv2d (dilation 1, groups 1) [+ fused ReLU]; `w_scale` (Cout) multiplies the weight rows
+    (frozen-BatchNorm fold).  Returns a channels_last tensor."""
+    stride, padding = _pair(stride), _pair(padding)
+    if not x.is_cuda:
+        if TORCH_REFERENCE_FOR_TESTS:
+            w = weight if w_scale is None else weight * w_scale.view(-1, 1, 1, 1)
+            y = F.conv2d(x, w, bias, stride, padding)
+            return F.relu(y) if relu else y
+        _require(x)
+    _require(weight, bias, w_scale)
+    return _Conv2dFn.apply(x, weight, bias, w_scale, stride, padding, bool(relu))
+
+
+def conv_transpose2d(x, weight, stride):
+    """F.conv_transpose2d for kernel_size == stride, no padding / bias."""
+    k = int(stride[0] if isinstance(stride, (tuple, list)) else stride)
+    if tuple(weight.shape[2:]) != (k, k):
+        raise NotImplementedError('conv_transpose2d: only kernel_size == stride is on the path')
+    if not x.is_cuda:
+        if TORCH_REFERENCE_FOR_TESTS:
+            return F.conv_transpose2d(x, weight, None, stride=k)
+        _require(x)
+    _require(weight)
+    return _ConvTranspose2dFn.apply(x, weight, k)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same constructor, parameters and state-dict keys) computed by the HIP kernels."""
+
+    def forward(self, x):
+        if self.dilation != (1, 1) or self.groups != 1 or self.padding_mode != 'zeros' or \
+                isinstance(self.padding, str):
+            raise NotImplementedError('dense_conv.Conv2d: dilation / groups / padding modes are '
+                                      'not on the DetMatch path')
+        return conv2d(x, self.weight, self.bias, self.stride, self.padding)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x):
+        if self.bias is not None or self.padding != (0, 0) or self.output_padding != (0, 0) or \
+                self.kernel_size != self.stride:
+            raise NotImplementedError('dense_conv.ConvTranspose2d: only kernel == stride, no bias')
+        return conv_transpose2d(x, self.weight, self.stride)

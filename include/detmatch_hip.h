@@ -324,6 +324,44 @@ int dm_sgd_step_masked_f32(float *params, const float *grads, float *momentum_bu
                            double lr, double momentum, double dampening, double weight_decay,
                            int first_step, const float *grad_scale_dev,
                            const unsigned char *block_live, dm_stream_t stream);
+/* ------------------------------------------------------------------------ */
+/* C / G. Dense 2-D convolutions (BEV backbone, anchor-head convs, ResNet-50 + FPN + RPN)      */
+/* ------------------------------------------------------------------------ */
+/* Replace the cuDNN convolutions behind torch.nn.Conv2d / ConvTranspose2d at
+ *   pcdet/models/backbones_2d/base_bev_backbone.py:38-69,94-112,
+ *   pcdet/models/dense_heads/anchor_head_single.py:20-37,
+ *   and mmdet's ResNet / FPN / RPNHead as configured at
+ *   configs/detmatch/001/detmatch/split_0.py:39-99
+ * (the reference has no binding of its own here: F.conv2d -> cudnn).  Activations NHWC fp32,
+ * implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).
+ *
+ * dm_dconv_pack: weights -> the [S][N][K] layout the GEMM reads (K contiguous):
+ *   dst[s][n][k] = src[n*sn + k*sk + s*st] * scale_n[n] * scale_k[k], zero for n >= Nsrc, k >= Ksrc
+ *   (scales may be NULL; the frozen-BatchNorm fold of the 2D backbone is a scale per output
+ *   channel).  Conv2d weight (Cout,Cin,KH,KW): forward N=Cout,K=Cin: sn=Cin*T, sk=T, st=1;
+ *   input gradient N=Cin,K=Cout: sn=T, sk=Cin*T, st=1.
+ *
+ * dm_dconv_gemm: the lattice convolution
+ *   out[b, oy0+i*oys, ox0+j*oxs, n] (+bias[n]) (relu) =
+ *       sum_t sum_c in[b, i*iys+dy[t], j*ixs+dx[t], c] * w_packed[ws[t]][n][c]
+ *   geom_host = 17 ints {B,Hin,Win,Cin, Hout,Wout,Cout, LH,LW, oy0,ox0,oys,oxs, iys,ixs, T, relu};
+ *   taps_host = 3*T int16 {dy[T], dx[T], ws[T]} (T <= 64).  Cin % 4 == 0.  Forward convolution,
+ *   input gradient (per residue class for stride > 1) and ConvTranspose2d are all instances.
+ *
+ * dm_dconv_wgrad: G[t][u][v] = sum_{b,i,j} U[(b,i,j)][u] * V[b, i*vys+dy[t], j*vxs+dx[t]][v],
+ *   written as out[u*su + v*sv + t*st] = scale_u[u] * G (v < Cv_out; `accumulate` adds).
+ *   geom_host = 10 ints {B, LH, LW, Cu, Cv, Hv, Wv, vys, vxs, T}.  Split over pixel chunks with a
+ *   fixed-order reduce: bitwise reproducible. */
+int dm_dconv_pack(const float *src, float *dst, const float *scale_n, const float *scale_k, int S,
+                  int N, int K, int Nsrc, int Ksrc, long long sn, long long sk, long long st,
+                  dm_stream_t stream);
+int dm_dconv_gemm(const float *x, const float *w_packed, const float *bias, float *y,
+                  const int *geom_host, const short *taps_host, dm_stream_t stream);
+size_t dm_dconv_wgrad_workspace_bytes(const int *geom_host);
+int dm_dconv_wgrad(const float *U, const float *V, float *out, const float *scale_u,
+                   const int *geom_host, const short *taps_host, int Cv_out, long long su,
+                   long long sv, long long st, int accumulate, void *workspace,
+                   size_t workspace_bytes, dm_stream_t stream);
 /* Replaces scipy.optimize.linear_sum_assignment at
  * mmdet3d/core/bbox/assigners/modified_hungarian_assigner.py:132.  HOST function: cost
  * (n_rows, n_cols) row-major host floats -> min(n_rows, n_cols) pairs sorted by row.

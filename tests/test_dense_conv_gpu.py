@@ -1,0 +1,134 @@
+"""Hand-written fp32-MFMA dense convolutions (csrc/conv2d.hip, detmatch_amd/dense_conv.py) vs
+torch's convolution evaluated in float64 on the CPU: forward, input gradient, weight gradient, bias
+gradient, for every layer TYPE of the DetMatch path (BEV backbone base_bev_backbone.py:38-69,
+anchor-head 1x1, ResNet-50 caffe / FPN / RPN at split_0.py:39-99) at reduced spatial sizes.
+Tolerance: 1e-4 relative to the largest reference magnitude (fp32 products, fp32 accumulation over
+K = 27 ... 4608 terms; VERDICT r1 item 5 asks <= 1e-4 rel)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, what, tol=1e-4):
+    want = want.to(torch.float64)
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got.detach().cpu().to(torch.float64) - want).abs().max())
+    assert err <= tol * scale, '%s: max err %.3e vs scale %.3e' % (what, err, scale)
+
+
+CASES = [
+    # name, (N, Cin, H, W), Cout, k, stride, pad, bias
+    ('bev 3x3 128->128', (2, 128, 40, 36), 128, 3, 1, 1, False),
+    ('bev first 3x3 256->128', (2, 256, 24, 20), 128, 3, 1, 1, False),
+    ('bev 3x3 s2 128->256 odd', (2, 128, 41, 37), 256, 3, 2, 1, False),
+    ('bev 3x3 256->256', (1, 256, 25, 22), 256, 3, 1, 1, False),
+    ('resnet 1x1 s2 256->512', (2, 256, 24, 40), 512, 1, 2, 0, False),
+    ('resnet 1x1 64->256', (2, 64, 24, 40), 256, 1, 1, 0, False),
+    ('resnet 3x3 64->64', (2, 64, 24, 40), 64, 3, 1, 1, False),
+    ('resnet 3x3 512->512 tiny', (2, 512, 6, 10), 512, 3, 1, 1, False),
+    ('resnet 1x1 2048->512', (1, 2048, 6, 10), 512, 1, 1, 0, False),
+    ('stem 7x7 s2 3->64', (2, 3, 64, 96), 64, 7, 2, 3, False),
+    ('fpn 3x3 256->256 bias', (2, 256, 12, 20), 256, 3, 1, 1, True),
+    ('fpn lateral 1x1 1024->256 bias', (2, 1024, 6, 10), 256, 1, 1, 0, True),
+    ('heads 1x1 512->72 bias', (2, 512, 20, 22), 72, 1, 1, 0, True),
+    ('rpn 1x1 256->16 bias', (2, 256, 12, 20), 16, 1, 1, 0, True),
+    ('ragged 3x3 s2 p0 32->36', (3, 32, 17, 13), 36, 3, 2, 0, True),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv2d_forward_backward(dev, case):
+    from detmatch_amd import dense_conv
+    name, xs, cout, k, s, p, has_bias = case
+    g = torch.Generator().manual_seed(abs(hash(name)) % 1000)
+    x = torch.randn(xs, generator=g)
+    w = torch.randn((cout, xs[1], k, k), generator=g) / np.sqrt(xs[1] * k * k)
+    b = torch.randn(cout, generator=g) if has_bias else None
+    xd = x.to(dev).requires_grad_(xs[1] >= 4)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if has_bias else None
+    y = dense_conv.conv2d(xd, wd, bd, s, p)
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True) if has_bias else None
+    y64 = F.conv2d(x64, w64, b64, s, p)
+    assert tuple(y.shape) == tuple(y64.shape)
+    _close(y, y64, 'forward')
+    dy = torch.randn(y64.shape, generator=g)
+    y.backward(dy.to(dev))
+    y64.backward(dy.double())
+    _close(wd.grad, w64.grad, 'weight grad')
+    if xs[1] >= 4:
+        _close(xd.grad, x64.grad, 'input grad')
+    if has_bias:
+        _close(bd.grad, b64.grad, 'bias grad')
+
+
+def test_frozen_bn_fold_and_fused_relu(dev):
+    """conv(x, w * s) + b with ReLU in the epilogue (the 2D backbone's frozen BatchNorm fold,
+    mm2d/backbone.py): gradients w.r.t. the UNSCALED weight."""
+    from detmatch_amd import dense_conv
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 64, 20, 28), generator=g)
+    w = torch.randn((128, 64, 3, 3), generator=g) / 24
+    s = torch.rand(128, generator=g) + 0.5
+    b = torch.randn(128, generator=g) * 0.1
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = dense_conv.conv2d(xd, wd, b.to(dev), 1, 1, relu=True, w_scale=s.to(dev))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.relu(F.conv2d(x64, w64 * s.double().view(-1, 1, 1, 1), b.double(), 1, 1))
+    _close(y, y64, 'forward')
+    dy = torch.randn(y64.shape, generator=g)
+    y.backward(dy.to(dev))
+    y64.backward(dy.double())
+    _close(wd.grad, w64.grad, 'weight grad')
+    _close(xd.grad, x64.grad, 'input grad')
+
+
+@pytest.mark.parametrize('k,cin,cout', [(1, 128, 256), (2, 256, 256)])
+def test_conv_transpose2d(dev, k, cin, cout):
+    """The BEV backbone's deblocks (base_bev_backbone.py:52-58): ConvTranspose2d k == stride."""
+    from detmatch_amd import dense_conv
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn((2, cin, 13, 11), generator=g)
+    w = torch.randn((cin, cout, k, k), generator=g) / np.sqrt(cin)
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = dense_conv.conv_transpose2d(xd, wd, k)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv_transpose2d(x64, w64, None, stride=k)
+    assert tuple(y.shape) == tuple(y64.shape)
+    _close(y, y64, 'forward')
+    dy = torch.randn(y64.shape, generator=g)
+    y.backward(dy.to(dev))
+    y64.backward(dy.double())
+    _close(wd.grad, w64.grad, 'weight grad')
+    _close(xd.grad, x64.grad, 'input grad')
+
+
+def test_weight_gradient_is_reproducible_and_cache_invalidates(dev):
+    from detmatch_amd import dense_conv
+    torch.manual_seed(0)
+    x = torch.randn(2, 128, 30, 30, device=dev)
+    conv = dense_conv.Conv2d(128, 128, 3, padding=1, bias=False).to(dev)
+    grads = []
+    for _ in range(2):
+        conv.weight.grad = None
+        conv(x).square().sum().backward()
+        grads.append(conv.weight.grad.clone())
+    assert torch.equal(grads[0], grads[1])           # split-K with a fixed-order reduce
+    y0 = conv(x)
+    with torch.no_grad():
+        conv.weight.mul_(2.0)                          # _version bump -> packed copy refreshed
+    assert torch.allclose(conv(x), 2 * y0, rtol=1e-5, atol=1e-5)
+    conv.weight.data.view(-1)[:] *= 0.5                # also bumps; raw-pointer writers call:
+    dense_conv.weights_changed()
+    assert torch.allclose(conv(x), y0, rtol=1e-5, atol=1e-5)
+
+
+def test_cpu_tensors_are_refused():
+    from detmatch_amd import _lib, dense_conv
+    with pytest.raises(_lib.DetMatchHipError):
+        dense_conv.conv2d(torch.zeros(1, 4, 8, 8), torch.zeros(4, 4, 3, 3), None, 1, 1)
