@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import dense_conv
+
 
 class FrozenBN(nn.Module):
     """State-dict compatible with nn.BatchNorm2d (weight, bias, running_mean, running_var,
@@ -46,18 +48,11 @@ class FrozenBN(nn.Module):
 
 
 def conv_frozen_bn(x, conv, bn, relu):
+    """relu?(conv(x, w * s) + b): the fold happens while the weights are packed for the kernel
+    (`w_scale`), bias and ReLU in the GEMM's epilogue; gradients come back w.r.t. the unscaled
+    conv.weight (csrc/conv2d.hip, dense_conv.conv2d)."""
     s, b = bn.scale_shift()
-    if conv.weight.requires_grad:
-        w = conv.weight * s.view(-1, 1, 1, 1)
-    else:   # frozen stage: the folded weight is a constant too
-        key = (FrozenBN.GENERATION, conv.weight._version, id(s))
-        cached = getattr(conv, '_folded', None)
-        if cached is None or cached[0] != key:
-            with torch.no_grad():
-                cached = conv._folded = (key, conv.weight * s.view(-1, 1, 1, 1))
-        w = cached[1]
-    y = F.conv2d(x, w, b, conv.stride, conv.padding)
-    return F.relu_(y) if relu else y
+    return dense_conv.conv2d(x, conv.weight, b, conv.stride, conv.padding, relu=relu, w_scale=s)
 
 
 class Bottleneck(nn.Module):
@@ -148,7 +143,7 @@ class ConvModule(nn.Module):
 
     def __init__(self, cin, cout, k, padding=0):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, padding=padding)
+        self.conv = dense_conv.Conv2d(cin, cout, k, padding=padding)
         nn.init.xavier_uniform_(self.conv.weight)
         nn.init.zeros_(self.conv.bias)
 

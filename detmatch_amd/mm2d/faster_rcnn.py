@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _lib
+from .. import _lib, dense_conv
 from ..devconst import const
 from ..mm3d.base_detector import DetectorStepMixin
 from ..mm3d.losses import bbox_overlaps
@@ -175,7 +175,7 @@ class RPNHead(nn.Module):
         self.loss_bbox_weight = (loss_bbox or {}).get('loss_weight', 1.0)
         assert (loss_cls or {}).get('use_sigmoid', True)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
-        self.rpn_conv = nn.Conv2d(in_channels, feat_channels, 3, padding=1)
+        self.rpn_conv = dense_conv.Conv2d(in_channels, feat_channels, 3, padding=1)
         self.rpn_cls = nn.Conv2d(feat_channels, self.num_anchors, 1)
         self.rpn_reg = nn.Conv2d(feat_channels, self.num_anchors * 4, 1)
         for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):
@@ -183,11 +183,21 @@ class RPNHead(nn.Module):
             nn.init.zeros_(m.bias)
 
     def forward(self, feats):
+        """3x3 conv + ReLU (fused in the GEMM epilogue), then the objectness and delta 1x1 convs as ONE
+        GEMM (A + 4A output channels, zero-padded to a multiple of 4), per pyramid level."""
+        a = self.num_anchors
+        pad = (-5 * a) % 4
+        w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight], dim=0)
+        b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], dim=0)
+        if pad:
+            w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
+            b = torch.cat([b, b.new_zeros(pad)], dim=0)
         cls, reg = [], []
         for x in feats:
-            x = F.relu(self.rpn_conv(x), inplace=True)
-            cls.append(self.rpn_cls(x))
-            reg.append(self.rpn_reg(x))
+            x = dense_conv.conv2d(x, self.rpn_conv.weight, self.rpn_conv.bias, 1, 1, relu=True)
+            y = dense_conv.conv2d(x, w, b, 1, 0)
+            cls.append(y[:, :a])
+            reg.append(y[:, a:5 * a])
         return cls, reg
 
     @staticmethod

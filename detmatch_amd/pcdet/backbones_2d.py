@@ -1,10 +1,54 @@
-"""BaseBEVBackbone — pcdet/models/backbones_2d/base_bev_backbone.py:9-117 (dense 2-D convs;
-MIOpen / hipBLASLt through torch — the legitimately MFMA-bound part of the 3D branch)."""
-from functools import partial
+"""BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py) on the hand-written kernels.
 
+Same constructor arguments (LAYER_NUMS / LAYER_STRIDES / NUM_FILTERS / UPSAMPLE_STRIDES /
+NUM_UPSAMPLE_FILTERS), same parameters and state-dict keys (`blocks.<i>.<j>.*`, `deblocks.<i>.<j>.*`
+with the reference's Sequential slot numbering, so its checkpoints load with strict=True) and the
+same outputs (`spatial_features_2d`, `spatial_features_<s>x`).  The computation is this repo's own:
+
+  * every convolution / transposed convolution is the fp32-MFMA implicit GEMM of csrc/conv2d.hip
+    (`dense_conv`), activations stay NHWC (`torch.channels_last`) end to end — no MIOpen, no layout
+    transposes;
+  * the reference's `ZeroPad2d(1)` + `Conv2d(padding=0)` pair is one convolution with padding 1 (the
+    kernel zero-fills out-of-image taps);
+  * BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU run as the fused row kernels of csrc/bn_relu.hip over
+    the (B*H*W, C) row view of the NHWC tensor.
+"""
 import numpy as np
 import torch
 import torch.nn as nn
+
+from .. import dense_conv
+from ..bn_relu import bn_relu_rows
+
+_BN = dict(eps=1e-3, momentum=0.01)
+
+
+def _conv_bn_relu_slots(conv):
+    """[conv, BatchNorm2d, ReLU]: three consecutive Sequential slots of the reference layout."""
+    return [conv, nn.BatchNorm2d(conv.out_channels, **_BN), nn.ReLU()]
+
+
+def _bn_relu_nhwc(x, bn):
+    """relu(bn(x)) for a channels_last (B, C, H, W) tensor, through its (B*H*W, C) row view."""
+    b, c, h, w = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c)
+    return bn_relu_rows(rows, bn, relu=True).view(b, h, w, c).permute(0, 3, 1, 2)
+
+
+class _Stage(object):
+    """One (convolution, BatchNorm) pair of a block, resolved from the Sequential slots once."""
+    __slots__ = ('conv', 'bn', 'padding')
+
+    def __init__(self, conv, bn, padding):
+        self.conv, self.bn, self.padding = conv, bn, padding
+
+    def __call__(self, x):
+        conv = self.conv
+        if isinstance(conv, nn.ConvTranspose2d):
+            y = dense_conv.conv_transpose2d(x, conv.weight, conv.stride)
+        else:
+            y = dense_conv.conv2d(x, conv.weight, conv.bias, conv.stride, self.padding)
+        return _bn_relu_nhwc(y, self.bn)
 
 
 class BaseBEVBackbone(nn.Module):
@@ -12,63 +56,69 @@ class BaseBEVBackbone(nn.Module):
     def __init__(self, model_cfg, input_channels):
         super().__init__()
         self.model_cfg = model_cfg
-        norm_fn = partial(nn.BatchNorm2d, eps=1e-3, momentum=0.01)
-        layer_nums = model_cfg.get('LAYER_NUMS', None) or []
-        layer_strides = model_cfg.get('LAYER_STRIDES', None) or []
-        num_filters = model_cfg.get('NUM_FILTERS', None) or []
-        upsample_strides = model_cfg.get('UPSAMPLE_STRIDES', None) or []
-        num_upsample_filters = model_cfg.get('NUM_UPSAMPLE_FILTERS', None) or []
-        assert len(layer_nums) == len(layer_strides) == len(num_filters)
-        assert len(upsample_strides) == len(num_upsample_filters)
-        num_levels = len(layer_nums)
-        c_in_list = [input_channels, *num_filters[:-1]]
+        cfg = lambda k: list(model_cfg.get(k, None) or [])
+        depth, strides, width = cfg('LAYER_NUMS'), cfg('LAYER_STRIDES'), cfg('NUM_FILTERS')
+        up_strides, up_width = cfg('UPSAMPLE_STRIDES'), cfg('NUM_UPSAMPLE_FILTERS')
+        assert len(depth) == len(strides) == len(width), 'one entry per level'
+        assert len(up_strides) == len(up_width), 'one entry per up-sampling branch'
+        fan_in = [input_channels] + width[:-1]
         self.blocks = nn.ModuleList()
         self.deblocks = nn.ModuleList()
-        for idx in range(num_levels):
-            cur_layers = [nn.ZeroPad2d(1),
-                          nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3,
-                                    stride=layer_strides[idx], padding=0, bias=False),
-                          norm_fn(num_filters[idx]), nn.ReLU()]
-            for _ in range(layer_nums[idx]):
-                cur_layers.extend([nn.Conv2d(num_filters[idx], num_filters[idx], kernel_size=3,
-                                             padding=1, bias=False),
-                                   norm_fn(num_filters[idx]), nn.ReLU()])
-            self.blocks.append(nn.Sequential(*cur_layers))
-            if len(upsample_strides) > 0:
-                stride = upsample_strides[idx]
-                if stride >= 1:
-                    self.deblocks.append(nn.Sequential(
-                        nn.ConvTranspose2d(num_filters[idx], num_upsample_filters[idx],
-                                           upsample_strides[idx], stride=upsample_strides[idx],
-                                           bias=False),
-                        norm_fn(num_upsample_filters[idx]), nn.ReLU()))
-                else:
-                    stride = int(np.round(1 / stride))
-                    self.deblocks.append(nn.Sequential(
-                        nn.Conv2d(num_filters[idx], num_upsample_filters[idx], stride,
-                                  stride=stride, bias=False),
-                        norm_fn(num_upsample_filters[idx]), nn.ReLU()))
-        c_in = sum(num_upsample_filters)
-        if len(upsample_strides) > num_levels:
-            self.deblocks.append(nn.Sequential(
-                nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1],
-                                   bias=False), norm_fn(c_in), nn.ReLU()))
-        self.num_bev_features = c_in
+        for lvl, (n_extra, stride, cout) in enumerate(zip(depth, strides, width)):
+            # slot 0 is the reference's explicit ZeroPad2d (kept so the slot numbers match; the
+            # padding itself is applied by the first convolution's kernel)
+            slots = [nn.ZeroPad2d(1)]
+            slots += _conv_bn_relu_slots(nn.Conv2d(fan_in[lvl], cout, 3, stride=stride, padding=0,
+                                                   bias=False))
+            for _ in range(n_extra):
+                slots += _conv_bn_relu_slots(nn.Conv2d(cout, cout, 3, padding=1, bias=False))
+            self.blocks.append(nn.Sequential(*slots))
+            if up_strides:
+                self.deblocks.append(nn.Sequential(*self._up_branch(cout, up_width[lvl],
+                                                                    up_strides[lvl])))
+        self.num_bev_features = sum(up_width)
+        if len(up_strides) > len(depth):      # one more transposed convolution on the concatenation
+            c = self.num_bev_features
+            self.deblocks.append(nn.Sequential(*self._up_branch(c, c, up_strides[-1])))
+
+    @staticmethod
+    def _up_branch(cin, cout, stride):
+        if stride >= 1:
+            k = int(stride)
+            return _conv_bn_relu_slots(nn.ConvTranspose2d(cin, cout, k, stride=k, bias=False))
+        k = int(np.round(1 / stride))         # fractional "up" stride: a strided convolution
+        return _conv_bn_relu_slots(nn.Conv2d(cin, cout, k, stride=k, bias=False))
+
+    def _plan(self):
+        """[[stage, ...] per block], [[stage] per deblock] — built lazily (after load_state_dict /
+        .to(), module identities are stable)."""
+        plan = getattr(self, '_stages', None)
+        if plan is None:
+            def stages(seq, first_padding):
+                mods, out, pad = list(seq), [], first_padding
+                for i, m in enumerate(mods):
+                    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                        p = pad if pad is not None else m.padding
+                        out.append(_Stage(m, mods[i + 1], p))
+                        pad = None
+                return out
+            plan = ([stages(b, (1, 1)) for b in self.blocks],
+                    [stages(d, None) for d in self.deblocks])
+            self._stages = plan
+        return plan
 
     def forward(self, data_dict):
-        spatial_features = data_dict['spatial_features']
-        ups = []
-        x = spatial_features
-        for i in range(len(self.blocks)):
-            x = self.blocks[i](x)
-            stride = int(spatial_features.shape[2] / x.shape[2])
-            data_dict['spatial_features_%dx' % stride] = x
-            ups.append(self.deblocks[i](x) if len(self.deblocks) > 0 else x)
-        if len(ups) > 1:
-            x = torch.cat(ups, dim=1)
-        elif len(ups) == 1:
-            x = ups[0]
-        if len(self.deblocks) > len(self.blocks):
-            x = self.deblocks[-1](x)
-        data_dict['spatial_features_2d'] = x
+        blocks, deblocks = self._plan()
+        x = data_dict['spatial_features']
+        full = x.shape[2]
+        branches = []
+        for lvl, block in enumerate(blocks):
+            for stage in block:
+                x = stage(x)
+            data_dict['spatial_features_%dx' % int(full / x.shape[2])] = x
+            branches.append(deblocks[lvl][0](x) if deblocks else x)
+        out = branches[0] if len(branches) == 1 else torch.cat(branches, dim=1)
+        if len(deblocks) > len(blocks):
+            out = deblocks[-1][0](out)
+        data_dict['spatial_features_2d'] = out
         return data_dict

@@ -154,9 +154,16 @@ class HeightCompression(nn.Module):
         self.num_bev_features = self.model_cfg.get('NUM_BEV_FEATURES', 256)
 
     def forward(self, batch_dict):
+        """height_compression.py:10-26: `.dense()` -> (B, C, D, H, W) -> view (B, C*D, H, W), i.e.
+        channel c*D + d.  Built here directly in NHWC memory (what the BEV convolutions read): the
+        active voxels are scattered into a zeroed (B, H, W, C, D) buffer, whose (B, H, W, C*D) view
+        permuted to (B, C*D, H, W) is the reference tensor in torch.channels_last layout."""
         sp = batch_dict['encoded_spconv_tensor']
-        spatial_features = sp.dense()
-        n, c, d, h, w = spatial_features.shape
-        batch_dict['spatial_features'] = spatial_features.view(n, c * d, h, w)
+        d, h, w = (int(v) for v in sp.spatial_shape)
+        c = sp.features.shape[1]
+        idx = sp.indices.long()
+        buf = sp.features.new_zeros((sp.batch_size, h, w, c, d))
+        buf[idx[:, 0], idx[:, 2], idx[:, 3], :, idx[:, 1]] = sp.features      # (N, C) rows
+        batch_dict['spatial_features'] = buf.view(sp.batch_size, h, w, c * d).permute(0, 3, 1, 2)
         batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
         return batch_dict

@@ -17,6 +17,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import dense_conv
+
 from .. import roiaware_pool3d
 from ..devconst import const
 from . import utils as U
@@ -310,13 +312,26 @@ class AnchorHeadSingle(nn.Module):
 
     def forward(self, data_dict):
         x = data_dict['spatial_features_2d']
-        cls_preds = self.conv_cls(x).permute(0, 2, 3, 1).contiguous()
-        box_preds = self.conv_box(x).permute(0, 2, 3, 1).contiguous()
+        # the three 1x1 heads (anchor_head_single.py:20-37) are ONE implicit GEMM over the NHWC
+        # feature map: weights / biases concatenated along the output channels (padded to a multiple
+        # of 4 for the kernel's 16-byte rows), the (B, H, W, 18 | 42 | 12) predictions are column
+        # slices of its output — the reference's permute(0, 2, 3, 1) is the layout we already have
+        heads = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
+        widths = [m.out_channels for m in heads]
+        pad = (-sum(widths)) % 4
+        w = torch.cat([m.weight for m in heads], dim=0)
+        b = torch.cat([m.bias for m in heads], dim=0)
+        if pad:
+            w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
+            b = torch.cat([b, b.new_zeros(pad)], dim=0)
+        y = dense_conv.conv2d(x, w, b, 1, 0).permute(0, 2, 3, 1)          # (B, H, W, sum) NHWC view
+        outs = [t.contiguous() for t in torch.split(y, widths + ([pad] if pad else []), dim=-1)[:len(heads)]]
+        cls_preds, box_preds = outs[0], outs[1]
         self.forward_ret_dict['cls_preds'] = cls_preds
         self.forward_ret_dict['box_preds'] = box_preds
         dir_cls_preds = None
         if self.conv_dir_cls is not None:
-            dir_cls_preds = self.conv_dir_cls(x).permute(0, 2, 3, 1).contiguous()
+            dir_cls_preds = outs[2]
             self.forward_ret_dict['dir_cls_preds'] = dir_cls_preds
         if self.training:
             self.forward_ret_dict.update(

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 import detmatch_amd  # noqa: E402,F401  (sets the MIOpen environment before the first convolution)
+from detmatch_amd import dense_conv  # noqa: E402
+
+# CPU tensors only: host logic around the convolutions is checked with torch's own convolution as the
+# stand-in; CUDA tensors always take the HIP kernels (the product never sets this flag).
+dense_conv.TORCH_REFERENCE_FOR_TESTS = True
 
 
 def pytest_configure(config):

@@ -128,7 +128,8 @@ def test_weight_gradient_is_reproducible_and_cache_invalidates(dev):
     assert torch.allclose(conv(x), y0, rtol=1e-5, atol=1e-5)
 
 
-def test_cpu_tensors_are_refused():
+def test_cpu_tensors_are_refused(monkeypatch):
     from detmatch_amd import _lib, dense_conv
+    monkeypatch.setattr(dense_conv, 'TORCH_REFERENCE_FOR_TESTS', False)   # the product's setting
     with pytest.raises(_lib.DetMatchHipError):
         dense_conv.conv2d(torch.zeros(1, 4, 8, 8), torch.zeros(4, 4, 3, 3), None, 1, 1)
