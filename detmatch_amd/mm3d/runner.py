@@ -193,7 +193,8 @@ class FusedRange(object):
         return FusedRange(opt, ddp, lo, hi, params)
 
     def step(self, grad_scale=None):
-        from .. import _lib
+        from .. import _lib, dense_conv
+        dense_conv.weights_changed()     # raw-pointer update: packed conv weights are stale now
         L = _lib.lib()
         g0 = self.opt.param_groups[0]
         d = self.ddp

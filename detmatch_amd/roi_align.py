@@ -24,14 +24,15 @@ class _RoIAlignFPN(Function):
 
     @staticmethod
     def forward(ctx, rois, levels, scales, out_size, sampling_ratio, aligned, *feats):
-        _lib.require_device(feats[0])
-        feats = [f.contiguous() for f in feats]
+        if not feats[0].is_cuda:
+            _lib.require_device(feats[0])      # raises: no CPU path
         assert all(f.dtype == torch.float32 and f.shape[1] == feats[0].shape[1] for f in feats)
         rois = rois.contiguous().float()
         levels = levels.contiguous().int() if levels is not None else None
         r, c = rois.shape[0], feats[0].shape[1]
-        out = feats[0].new_empty((r, c, out_size, out_size))
-        # channel-last copies of the maps: every tap then reads 256 contiguous bytes per wave
+        out = torch.empty((r, c, out_size, out_size), dtype=torch.float32, device=feats[0].device)
+        # channel-last maps (a no-op for the channels_last tensors the convolutions produce): every tap
+        # then reads 256 contiguous bytes per wave
         nhwc = [f.permute(0, 2, 3, 1).contiguous() for f in feats]
         ptrs = (ctypes.c_void_p * len(nhwc))(*[t.data_ptr() for t in nhwc])
         hs = (ctypes.c_int32 * len(feats))(*[int(f.shape[2]) for f in feats])
