@@ -67,7 +67,8 @@ SIGNATURES = {
     'dm_adamw_step_masked_f32': (ci, [vp, vp, vp, vp, sz, cd, cd, cd, cd, cd, ctypes.c_longlong, vp, vp, vp]),
     'dm_sgd_step_masked_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp, vp]),
     'dm_dconv_pack': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, vp]),
-    'dm_dconv_gemm': (ci, [vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), vp]),
+    'dm_dconv_gemm_workspace_bytes': (sz, [c_int_p]),
+    'dm_dconv_gemm': (ci, [vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), vp, sz, vp]),
     'dm_dconv_wgrad_workspace_bytes': (sz, [c_int_p]),
     'dm_dconv_wgrad': (ci, [vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), ci, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ci, vp, sz, vp]),
     'dm_lap_host': (ci, [c_f32_p, ci, ci, c_int_p, c_int_p]),

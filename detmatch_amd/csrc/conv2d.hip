@@ -57,14 +57,14 @@ struct DConvTaps {   // 32-bit entries: a wave-uniform tap index then reads them
 #define STAGGER_SLEEP 70   /* x64 cycles: about half a K-tile of a 128x128 tile with the pipe shared */
 #endif
 
-// SOLO: pad the LDS allocation beyond half of the CU's 160 KB so that only ONE workgroup is resident
-// per CU — used for the tail launch (see dm_dconv_gemm), whose few tiles should spread over the
-// chip instead of piling up on the CUs that happen to be free first.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool UNI, bool SOLO>
+// LIMIT (1 or 2): pad the LDS allocation so that at most that many workgroups are resident per CU —
+// used for tail launches (see dm_dconv_gemm), whose few tiles should spread over the chip instead
+// of piling up on the CUs that happen to be free first.  0 = no limit.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool UNI, int LIMIT>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     float *__restrict__ y, const DConvGeom g, const DConvTaps tt, int n_tiles_m, int n_tiles_n,
-    int m_lo) {
+    int m_lo, int kt_per_split, float *__restrict__ partial) {
 #ifdef DCONV_STAMPS
   const float *bias_arg = bias;
   const long long st_entry = __builtin_amdgcn_s_memrealtime();
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
   constexpr int AP = BM / RPP, BP = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0 && TM >= 1 && TN >= 1, "tile shape");
   constexpr int LDS_FLOATS = 2 * (BM + BN) * LDK;
-  __shared__ __attribute__((aligned(16))) float lds[SOLO && LDS_FLOATS < 21504 ? 21504 : LDS_FLOATS];
+  constexpr int LDS_MIN = LIMIT == 1 ? 21504 : (LIMIT == 2 ? 14336 : 0);   // 84 KB / 56 KB
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS < LDS_MIN ? LDS_MIN : LDS_FLOATS];
 
   // XCD-aware tile map: workgroups L, L+8, L+16 ... share an XCD (its L2); give them the column tiles
   // of the SAME row tile back to back, so the activation rows are fetched from HBM once.
@@ -131,7 +132,10 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
 
   float4 ra[AP], rb[BP];
   bool ra_ok[AP];
-  int tU = 0, cU = 0;  // UNI: tap / first channel of the K-tile being fetched
+  // split-K: this workgroup owns K-tiles [kt0, kt0 + KT) of the reduction (blockIdx.y = split)
+  const int KT_all = (g.Ktot + BK - 1) / BK;
+  const int kt0 = blockIdx.y * kt_per_split;
+  int tU = (kt0 * BK) / g.Cin, cU = (kt0 * BK) % g.Cin;  // UNI: tap / first channel of the K-tile being fetched
 
   // Loads are UNCONDITIONAL (offset clamped to a valid element; padding taps are zeroed later, in
   // sstore, so that nothing waits for the data before the MFMAs of the current tile): a conditional
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
       g_shift = (unsigned)((g_dy * g.Win + g_dx) * g.Cin + c0) * 4u;   // SALU
       g_wshift = (unsigned)tt.ws[t] * slice_bytes + (unsigned)c0 * 4u;
     } else {
-      const int k = kt * BK + kq * 4;
+      const int k = (kt0 + kt) * BK + kq * 4;
       const int t = k / g.Cin, c = k - t * g.Cin;
       g_kv = t < g.T;
       const int tc = g_kv ? t : 0;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
   constexpr int NKB = BK / 8;
   static_assert(NKB == 4, "the K-tile schedule below is written for BK = 32");
 
-  const int KT = (g.Ktot + BK - 1) / BK;
+  const int KT = min(kt_per_split, KT_all - kt0);
 #ifdef DCONV_STAMPS
   long long st_t[6] = {0, 0, 0, 0, 0, 0};
   const long long st_real0 = __builtin_amdgcn_s_memrealtime();
@@ -323,13 +327,13 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int n = n0 + wn * WN + b * 32 + lr;
-    const float bv = (bias != nullptr && n < g.Cout) ? bias[n] : 0.0f;
+    const float bv = (bias != nullptr && partial == nullptr && n < g.Cout) ? bias[n] : 0.0f;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[a][b][r] + bv;
-        if (g.relu == 1) v = fmaxf(v, 0.0f);
+        if (g.relu == 1 && partial == nullptr) v = fmaxf(v, 0.0f);
         cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + b * 32 + lr] = v;
       }
   }
@@ -345,14 +349,18 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
     const int m = m0 + wm * WM + rl;
     if (m >= g.M || ncol >= g.Cout) continue;
     size_t row;
-    if (g.dense_out) {
+    float *obase = y;
+    if (partial != nullptr) {       // split-K: raw partial sums, dense rows [split][M][Cout]
+      row = (size_t)blockIdx.y * g.M + m;
+      obase = partial;
+    } else if (g.dense_out) {
       row = (size_t)m;
     } else {
       const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, bb = tmp / g.LH;
       row = ((size_t)bb * g.Hout + g.oy0 + i * g.oys) * g.Wout + g.ox0 + j * g.oxs;
     }
     const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
-    float *dst = y + row * g.Cout + ncol;
+    float *dst = obase + row * g.Cout + ncol;
     if (vec_ok && ncol + 3 < g.Cout) {
       *(float4 *)dst = v;
     } else {
@@ -586,18 +594,68 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const float *__restrict
   dst[e] = v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNI, bool SOLO = false>
+// y[row(m)][n] = relu?(bias[n] + sum_s partial[s][m][n])   (split-K epilogue; fixed summation order)
+__global__ __launch_bounds__(256) void dconv_splitk_reduce_kernel(const float *__restrict__ partial,
+                                                                  const float *__restrict__ bias,
+                                                                  float *__restrict__ y,
+                                                                  const DConvGeom g, int nsplit) {
+  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long long total = (long long)g.M * g.Cout;
+  if (e >= total) return;
+  const int m = (int)(e / g.Cout), n = (int)(e % g.Cout);     // Cout % 4 == 0 on this path
+  float4 s = *(const float4 *)(partial + e);
+  for (int k = 1; k < nsplit; ++k) {
+    const float4 v = *(const float4 *)(partial + (size_t)k * total + e);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  if (bias) s.x += bias[n], s.y += bias[n + 1], s.z += bias[n + 2], s.w += bias[n + 3];
+  if (g.relu == 1) s.x = fmaxf(s.x, 0.f), s.y = fmaxf(s.y, 0.f), s.z = fmaxf(s.z, 0.f), s.w = fmaxf(s.w, 0.f);
+  size_t row;
+  if (g.dense_out) {
+    row = (size_t)m;
+  } else {
+    const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, bb = tmp / g.LH;
+    row = ((size_t)bb * g.Hout + g.oy0 + i * g.oys) * g.Wout + g.ox0 + j * g.oxs;
+  }
+  *(float4 *)(y + row * g.Cout + n) = s;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNI, int LIMIT = 0>
 int launch_gemm(const float *x, const float *w, const float *bias, float *y, DConvGeom g,
-                const DConvTaps &tt, hipStream_t st, int m_lo = 0, int m_hi = -1) {
+                const DConvTaps &tt, hipStream_t st, int m_lo = 0, int m_hi = -1, int nsplit = 1,
+                float *partial = nullptr) {
   if (m_hi < 0) m_hi = g.M;
   if (m_hi <= m_lo) return DM_OK;
   g.M = m_hi;
   const int tm = dm_ceil_div(m_hi - m_lo, BM), tn = dm_ceil_div(g.Cout, BN);
   const int blocks = dm_ceil_div(tm, 8) * 8 * tn;
-  dconv_gemm_kernel<BM, BN, 32, WAVES_M, WAVES_N, UNI, SOLO>
-      <<<blocks, WAVES_M * WAVES_N * 64, 0, st>>>(x, w, bias, y, g, tt, tm, tn, m_lo);
+  const int KT = dm_ceil_div(g.Ktot, 32);
+  const int per = dm_ceil_div(KT, nsplit);
+  nsplit = dm_ceil_div(KT, per);
+  dconv_gemm_kernel<BM, BN, 32, WAVES_M, WAVES_N, UNI, LIMIT>
+      <<<dim3(blocks, nsplit), WAVES_M * WAVES_N * 64, 0, st>>>(x, w, bias, y, g, tt, tm, tn, m_lo, per,
+                                                               nsplit > 1 ? partial : nullptr);
   DM_CHECK_LAUNCH();
+  if (nsplit > 1) {
+    dconv_splitk_reduce_kernel<<<dm_ceil_div((long long)g.M * g.Cout / 4, 256), 256, 0, st>>>(
+        partial, bias, y, g, nsplit);
+    DM_CHECK_LAUNCH();
+  }
   return DM_OK;
+}
+
+// How many ways the reduction of a SMALL problem (fewer 64x64 tiles than half a round) is split.
+static int dconv_gemm_splits(const int *q) {
+  const long long M = (long long)q[0] * q[7] * q[8];
+  const int Cin = q[3], Cout = q[6], T = q[15];
+  if ((Cin % 32) != 0 || Cout <= 32 || (Cout & 3)) return 1;
+  const long long tiles = (long long)dm_ceil_div(M, 64) * dm_ceil_div(Cout, 64);
+  const int KT = dm_ceil_div((long long)T * Cin, 32);
+  if (tiles >= 512 || KT < 16) return 1;
+  long long s = 1024 / tiles;
+  if (s > KT / 8) s = KT / 8;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int)s;
 }
 
 }  // namespace
@@ -616,8 +674,15 @@ extern "C" int dm_dconv_pack(const float *src, float *dst, const float *scale_n,
 
 // geom_host: 17 ints {B,Hin,Win,Cin, Hout,Wout,Cout, LH,LW, oy0,ox0,oys,oxs, iys,ixs, T, relu};
 // taps_host: 3*T shorts {dy[T], dx[T], wslice[T]}.
+extern "C" size_t dm_dconv_gemm_workspace_bytes(const int *geom_host) {
+  const int ns = dconv_gemm_splits(geom_host);
+  if (ns <= 1) return 0;
+  return dm_align((size_t)ns * geom_host[0] * geom_host[7] * geom_host[8] * geom_host[6] * sizeof(float));
+}
+
 extern "C" int dm_dconv_gemm(const float *x, const float *w_packed, const float *bias, float *y,
-                             const int *geom_host, const short *taps_host, dm_stream_t stream) {
+                             const int *geom_host, const short *taps_host, void *workspace,
+                             size_t workspace_bytes, dm_stream_t stream) {
   if (!x || !w_packed || !y || !geom_host || !taps_host) return DM_ERR_INVALID_ARG;
   DConvGeom g;
   const int *q = geom_host;
@@ -652,40 +717,48 @@ extern "C" int dm_dconv_gemm(const float *x, const float *w_packed, const float 
   const bool uni = (g.Cin % 32) == 0;
   if (!uni) return launch_gemm<128, 64, 2, 2, false>(x, w_packed, bias, y, g, tt, st);
   if (g.Cout <= 32) return launch_gemm<128, 32, 4, 1, true>(x, w_packed, bias, y, g, tt, st);
-  // Tile choice is a scheduling problem: a 128x128 tile (4 waves, 64 MFMAs per wave and K-step) is
-  // the efficient one, two fit a CU, so the chip runs 512 at a time ("a round", one CU-second of
-  // MFMA work each); what is left after the full rounds would occupy a few CUs for a whole round.
-  // That tail is handed to 64x64 tiles (a quarter of the work each) in a second launch limited to
-  // one workgroup per CU, which spreads it over the chip.
-  const int SLOTS = 512;
-  const bool narrow = g.Cout <= 64 || ((g.Cout % 128) > 0 && (g.Cout % 128) <= 64 && g.Cout < 256);
-  if (narrow) {
-    const int tm = dm_ceil_div(g.M, 128), tn = dm_ceil_div(g.Cout, 64);
-    const long long tiles = (long long)tm * tn;
-    if (tiles < SLOTS) return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
-    const int rem = (int)(tiles % SLOTS);
-    if (rem == 0 || rem > (SLOTS * 3) / 4)
-      return launch_gemm<128, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
-    const int mt_main = (int)((tiles - rem) / tn) / 8 * 8;
-    int rc = launch_gemm<128, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, 0, mt_main * 128);
-    if (rc != DM_OK) return rc;
-    return launch_gemm<64, 64, 2, 2, true, true>(x, w_packed, bias, y, g, tt, st, mt_main * 128);
+  // Tile choice is a scheduling problem.  128x128 tiles: 2 workgroups per CU, 512 per "round";
+  // 64x64 tiles: 4 per CU, 1024 per round, a quarter of the work each (and measured ~10 % more
+  // efficient per round: 4 waves per SIMD cover each other's barrier windows).  Whatever is left
+  // after the full rounds would occupy a few CUs for a whole round, so it goes to a second launch
+  // of 64x64 tiles limited to 1 (2) workgroups per CU, which spreads <= 256 (512) tiles over the
+  // chip.  Problems of less than half a 64x64 round split the reduction over workgroups instead
+  // (partial sums in the workspace, fixed-order reduce).
+  const int nsplit = dconv_gemm_splits(geom_host);
+  if (nsplit > 1) {
+    if (!workspace || workspace_bytes < (size_t)nsplit * g.M * g.Cout * sizeof(float))
+      return DM_ERR_WORKSPACE;
+    return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, 0, -1, nsplit,
+                                           (float *)workspace);
   }
-  const int tm = dm_ceil_div(g.M, 128), tn = dm_ceil_div(g.Cout, 128);
-  const long long tiles = (long long)tm * tn;
-  if (tiles <= 256) return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
-  const int rem = (int)(tiles % SLOTS);
-  if (rem == 0 || rem > (SLOTS * 3) / 4)
-    return launch_gemm<128, 128, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
-  const int mt_main = (int)((tiles - rem) / tn) / 8 * 8;
-  int rc = DM_OK;
-  if (mt_main > 0)
-    rc = launch_gemm<128, 128, 2, 2, true>(x, w_packed, bias, y, g, tt, st, 0, mt_main * 128);
-  if (rc != DM_OK) return rc;
-  const long long tail_tiles = (long long)dm_ceil_div(g.M - mt_main * 128, 64) * dm_ceil_div(g.Cout, 64);
-  if (tail_tiles <= 1024)
-    return launch_gemm<64, 64, 2, 2, true, true>(x, w_packed, bias, y, g, tt, st, mt_main * 128);
-  return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, mt_main * 128);
+  const int tm128 = dm_ceil_div(g.M, 128), tn128 = dm_ceil_div(g.Cout, 128);
+  const long long tiles128 = (long long)tm128 * tn128;
+  int m_done = 0;
+  if (tiles128 >= 512 && g.Cout > 64) {          // at least one full round of the big tile
+    const int rem = (int)(tiles128 % 512);
+    if (rem == 0 || rem > 384) return launch_gemm<128, 128, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
+    const int mt_main = (int)((tiles128 - rem) / tn128) / 8 * 8;
+    const int rc = launch_gemm<128, 128, 2, 2, true>(x, w_packed, bias, y, g, tt, st, 0, mt_main * 128);
+    if (rc != DM_OK) return rc;
+    m_done = mt_main * 128;
+  }
+  // the rest (or everything) in 64x64 tiles: full rounds, then a spread-out tail
+  const int tn64 = dm_ceil_div(g.Cout, 64);
+  const long long tiles64 = (long long)dm_ceil_div(g.M - m_done, 64) * tn64;
+  const long long full = tiles64 / 1024 * 1024;
+  const int rem64 = (int)(tiles64 - full);
+  int m_main = m_done;
+  if (full > 0 && rem64 > 0 && rem64 <= 512) m_main = m_done + (int)(full / tn64) / 8 * 8 * 64;
+  else if (rem64 == 0 || rem64 > 512) m_main = g.M;
+  if (m_main > m_done) {
+    const int rc = launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, m_done, m_main);
+    if (rc != DM_OK) return rc;
+  }
+  if (m_main >= g.M) return DM_OK;
+  const long long tail = (long long)dm_ceil_div(g.M - m_main, 64) * tn64;
+  if (tail <= 256) return launch_gemm<64, 64, 2, 2, true, 1>(x, w_packed, bias, y, g, tt, st, m_main);
+  if (tail <= 512) return launch_gemm<64, 64, 2, 2, true, 2>(x, w_packed, bias, y, g, tt, st, m_main);
+  return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, m_main);
 }
 
 static int dconv_wgrad_splits(long long M, int T, int Cu, int Cv) {

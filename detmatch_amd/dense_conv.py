@@ -93,8 +93,13 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
 def _gemm(x, wp, bias, y, geom, taps):
     """geom: the 17 ints of dm_dconv_gemm; taps: [(dy, dx, slice)]."""
     t = [a for a, _, _ in taps] + [b for _, b, _ in taps] + [c for _, _, c in taps]
-    _lib.check(_lib.lib().dm_dconv_gemm(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y),
-                                        _lib.ints(geom), _shorts(t), _lib.stream()), 'dm_dconv_gemm')
+    L = _lib.lib()
+    g = _lib.ints(geom)
+    nbytes = L.dm_dconv_gemm_workspace_bytes(g)
+    ws = _lib.workspace(nbytes, x.device, 'dconv_gemm') if nbytes else None
+    _lib.check(L.dm_dconv_gemm(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y), g, _shorts(t),
+                               _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
+               'dm_dconv_gemm')
 
 
 def _wgrad(U, V, out, scale_u, geom, taps, cv_out, su, sv, st):

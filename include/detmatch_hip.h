@@ -347,6 +347,9 @@ int dm_sgd_step_masked_f32(float *params, const float *grads, float *momentum_bu
  *   geom_host = 17 ints {B,Hin,Win,Cin, Hout,Wout,Cout, LH,LW, oy0,ox0,oys,oxs, iys,ixs, T, relu};
  *   taps_host = 3*T int16 {dy[T], dx[T], ws[T]} (T <= 64).  Cin % 4 == 0.  Forward convolution,
  *   input gradient (per residue class for stride > 1) and ConvTranspose2d are all instances.
+ *   Small problems split the reduction over workgroups (partial sums in the workspace, summed in a
+ *   fixed order: bitwise reproducible); large ones run full rounds of 128x128 / 64x64 tiles plus a
+ *   spread-out tail launch.
  *
  * dm_dconv_wgrad: G[t][u][v] = sum_{b,i,j} U[(b,i,j)][u] * V[b, i*vys+dy[t], j*vxs+dx[t]][v],
  *   written as out[u*su + v*sv + t*st] = scale_u[u] * G (v < Cv_out; `accumulate` adds).
@@ -355,8 +358,10 @@ int dm_sgd_step_masked_f32(float *params, const float *grads, float *momentum_bu
 int dm_dconv_pack(const float *src, float *dst, const float *scale_n, const float *scale_k, int S,
                   int N, int K, int Nsrc, int Ksrc, long long sn, long long sk, long long st,
                   dm_stream_t stream);
+size_t dm_dconv_gemm_workspace_bytes(const int *geom_host);   /* 0 unless the reduction is split */
 int dm_dconv_gemm(const float *x, const float *w_packed, const float *bias, float *y,
-                  const int *geom_host, const short *taps_host, dm_stream_t stream);
+                  const int *geom_host, const short *taps_host, void *workspace,
+                  size_t workspace_bytes, dm_stream_t stream);
 size_t dm_dconv_wgrad_workspace_bytes(const int *geom_host);
 int dm_dconv_wgrad(const float *U, const float *V, float *out, const float *scale_u,
                    const int *geom_host, const short *taps_host, int Cv_out, long long su,

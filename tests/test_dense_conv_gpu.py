@@ -133,3 +133,26 @@ def test_cpu_tensors_are_refused(monkeypatch):
     monkeypatch.setattr(dense_conv, 'TORCH_REFERENCE_FOR_TESTS', False)   # the product's setting
     with pytest.raises(_lib.DetMatchHipError):
         dense_conv.conv2d(torch.zeros(1, 4, 8, 8), torch.zeros(4, 4, 3, 3), None, 1, 1)
+
+
+@pytest.mark.parametrize('shape', [
+    ((2, 512, 12, 40), 512, 3, 1, 1),      # ResNet layer4 3x3: 120 tiles of 64x64 -> split-K
+    ((2, 1024, 24, 80), 256, 1, 1, 0),     # layer3 1x1
+    ((2, 256, 6, 20), 256, 3, 1, 1),       # FPN P5 3x3: 8 tiles
+    ((2, 256, 100, 88), 256, 3, 1, 1),     # BEV block2: 1100 tiles of 64x64 = one round + tail
+    ((1, 64, 200, 176), 128, 3, 1, 1),     # 550 x 2 tiles
+], ids=['splitk l4', 'splitk l3 1x1', 'splitk P5', 'round+tail', 'round+tail 2'])
+def test_scheduling_paths_agree_with_reference(dev, shape):
+    """Every launch plan of dm_dconv_gemm (split-K with reduce, full rounds + limited tail) against
+    the float64 convolution, plus bitwise run-to-run reproducibility."""
+    from detmatch_amd import dense_conv
+    xs, cout, k, s, p = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(xs, generator=g)
+    w = torch.randn((cout, xs[1], k, k), generator=g) / np.sqrt(xs[1] * k * k)
+    b = torch.randn(cout, generator=g)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    y = dense_conv.conv2d(xd, wd, bd, s, p, relu=True)
+    y64 = F.relu(F.conv2d(x.double(), w.double(), b.double(), s, p))
+    _close(y, y64, 'forward')
+    assert torch.equal(y, dense_conv.conv2d(xd, wd, bd, s, p, relu=True))

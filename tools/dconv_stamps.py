@@ -10,7 +10,7 @@ import torch
 
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_alt', 'libdconv_stamps.so'))
 vp = ctypes.c_void_p
-lib.dm_dconv_gemm.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_short), vp]
+lib.dm_dconv_gemm.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_short), vp, ctypes.c_size_t, vp]
 dev = torch.device('cuda:0')
 B, C, H, W, N = 2, 128, 200, 176, 128
 x = torch.randn(B, H, W, C, device=dev)
@@ -22,7 +22,7 @@ geom = (ctypes.c_int * 17)(B, H, W, C, H, W, N, H, W, 0, 0, 1, 1, 1, 1, 9, 2)
 taps = [a - 1 for a in range(3) for b in range(3)] + [b - 1 for a in range(3) for b in range(3)] + list(range(9))
 taps = (ctypes.c_short * 27)(*taps)
 for _ in range(3):
-    rc = lib.dm_dconv_gemm(vp(x.data_ptr()), vp(wp.data_ptr()), vp(dbg.data_ptr()), vp(y.data_ptr()), geom, taps, None)
+    rc = lib.dm_dconv_gemm(vp(x.data_ptr()), vp(wp.data_ptr()), vp(dbg.data_ptr()), vp(y.data_ptr()), geom, taps, None, 0, None)
 torch.cuda.synchronize()
 assert rc == 0
 d = dbg.view(-1, 8).cpu().double()
