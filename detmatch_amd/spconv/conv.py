@@ -1,10 +1,16 @@
-"""mmdet3d/ops/spconv/conv.py:47-300 — SparseConvolution / SubMConv3d / SparseConv3d."""
+"""Sparse convolution modules with the reference's public surface (mmdet3d/ops/spconv/conv.py:
+`SparseConvolution`, `SparseConv3d`, `SubMConv3d` — same constructor arguments, attribute names,
+parameter names and the (kz, ky, kx, Cin, Cout) weight layout of conv.py:98-99, so released
+checkpoints load unchanged) computed by this repo's kernels: rulebook.hip builds the gather tables
+once per `indice_key`, spconv.hip runs the fused gather-GEMM.
+
+Only what VoxelBackBone8x uses is implemented (3-D, groups 1, dilation 1, no transposed / inverse /
+fused-BN variants); everything else raises instead of silently computing something different.
+"""
 import math
 
-import numpy as np
 import torch
-from torch.nn import init
-from torch.nn.parameter import Parameter
+from torch import nn
 
 from . import functional as Fsp
 from . import ops
@@ -12,105 +18,89 @@ from .modules import SparseModule
 from .structure import SparseConvTensor
 
 
-def _calculate_fan_in_and_fan_out_hwio(tensor):
-    """conv.py:27-44: fans of a (k..., Cin, Cout) filter."""
-    if tensor.ndimension() < 2:
-        raise ValueError('fan in and fan out can not be computed for tensor with fewer than 2 '
-                         'dimensions')
-    if tensor.ndimension() == 2:
-        return tensor.size(-2), tensor.size(-1)
-    rf = tensor[..., 0, 0].numel()
-    return tensor.size(-2) * rf, tensor.size(-1) * rf
+def _per_dim(value, ndim):
+    return [int(v) for v in value] if isinstance(value, (list, tuple)) else [int(value)] * ndim
+
+
+def _fans_hwio(weight):
+    """(fan_in, fan_out) of a (k..., Cin, Cout) filter bank: receptive field x channels."""
+    if weight.dim() < 2:
+        raise ValueError('a filter bank needs at least (Cin, Cout)')
+    field = 1
+    for k in weight.shape[:-2]:
+        field *= int(k)
+    return weight.shape[-2] * field, weight.shape[-1] * field
 
 
 class SparseConvolution(SparseModule):
-    """Weight layout (kz, ky, kx, Cin, Cout) as in the reference (conv.py:98-99), so
-    released checkpoints load unchanged."""
+
+    _UNSUPPORTED = ('transposed', 'inverse', 'fused_bn')
 
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
                  dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
                  inverse=False, indice_key=None, fused_bn=False):
         super().__init__()
-        assert groups == 1
-        if transposed or inverse or fused_bn:
-            raise NotImplementedError('transposed / inverse / fused-BN sparse conv are off the '
-                                      'DetMatch hot path (SURVEY §2.1)')
-        as_list = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
-        kernel_size, stride, padding, dilation, output_padding = (
-            as_list(v) for v in (kernel_size, stride, padding, dilation, output_padding))
-        for d, s in zip(dilation, stride):
-            assert any([s == 1, d == 1]), "don't support this."
-        self.ndim = ndim
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = kernel_size
-        self.conv1x1 = np.prod(kernel_size) == 1
-        self.stride = stride
-        self.padding = padding
-        self.dilation = dilation
-        self.transposed = transposed
-        self.inverse = inverse
-        self.output_padding = output_padding
-        self.groups = groups
-        self.subm = subm
-        self.indice_key = indice_key
-        self.fused_bn = fused_bn
-        self.weight = Parameter(torch.Tensor(*kernel_size, in_channels, out_channels))
-        if bias:
-            self.bias = Parameter(torch.Tensor(out_channels))
-        else:
-            self.register_parameter('bias', None)
+        flags = dict(transposed=transposed, inverse=inverse, fused_bn=fused_bn)
+        bad = [k for k in self._UNSUPPORTED if flags[k]]
+        if bad or groups != 1:
+            raise NotImplementedError('sparse conv variant off the DetMatch path: %s'
+                                      % (bad or 'groups=%d' % groups))
+        self.ndim, self.groups = ndim, groups
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _per_dim(kernel_size, ndim)
+        self.stride = _per_dim(stride, ndim)
+        self.padding = _per_dim(padding, ndim)
+        self.dilation = _per_dim(dilation, ndim)
+        self.output_padding = _per_dim(output_padding, ndim)
+        if any(d != 1 and s != 1 for d, s in zip(self.dilation, self.stride)):
+            raise ValueError('dilation and stride cannot both differ from 1')
+        self.subm, self.indice_key = subm, indice_key
+        self.transposed, self.inverse, self.fused_bn = transposed, inverse, fused_bn
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
 
     def reset_parameters(self):
-        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        """As the reference (conv.py:103-108): torch's kaiming_uniform_(a = sqrt(5)) applied to the
+        (k..., Cin, Cout) tensor AS IS — torch derives its fan from dim 1, not from Cin, and that
+        (smaller) scale is what released models were initialised with — and bias ~ U(+-1/sqrt(fan_in))
+        with the true fan of the channels-last layout."""
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:
-            fan_in, _ = _calculate_fan_in_and_fan_out_hwio(self.weight)
-            bound = 1 / math.sqrt(fan_in)
-            init.uniform_(self.bias, -bound, bound)
+            bound = 1.0 / math.sqrt(_fans_hwio(self.weight)[0])
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    # ------------------------------------------------------------------ forward
+    def _rulebook(self, x):
+        """(outids, indice_pairs, indice_pair_num) of this layer, shared through the tensor's
+        `indice_dict` by every layer with the same `indice_key`."""
+        hit = x.find_indice_pair(self.indice_key)
+        if hit is not None:
+            return hit[0], hit[2], hit[3]
+        outids, pairs, num = ops.get_indice_pairs(
+            x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
+            self.dilation, self.output_padding, self.subm, self.transposed, grid=x.grid)
+        x.indice_dict[self.indice_key] = (outids, x.indices, pairs, num, x.spatial_shape)
+        return outids, pairs, num
 
     def forward(self, input):
-        assert isinstance(input, SparseConvTensor)
-        features = input.features
-        indices = input.indices
-        spatial_shape = input.spatial_shape
-        batch_size = input.batch_size
-        if not self.subm:
-            out_spatial_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size,
-                                                         self.stride, self.padding, self.dilation)
+        if not isinstance(input, SparseConvTensor):
+            raise TypeError('SparseConvolution expects a SparseConvTensor')
+        if self.conv1x1:       # a pointwise layer touches no neighbours: one dense GEMM on the rows
+            rows = input.features @ self.weight.view(self.in_channels, self.out_channels)
+            ids, shape = input.indices, input.spatial_shape
         else:
-            out_spatial_shape = spatial_shape
-        if self.conv1x1:
-            features = torch.mm(input.features,
-                                self.weight.view(self.in_channels, self.out_channels))
-            if self.bias is not None:
-                features += self.bias
-            out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape,
-                                          input.batch_size)
-            out_tensor.indice_dict = input.indice_dict
-            out_tensor.grid = input.grid
-            return out_tensor
-        datas = input.find_indice_pair(self.indice_key)
-        if self.indice_key is not None and datas is not None:
-            outids, _, indice_pairs, indice_pair_num, _ = datas
-        else:
-            outids, indice_pairs, indice_pair_num = ops.get_indice_pairs(
-                indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,
-                self.dilation, self.output_padding, self.subm, self.transposed, grid=input.grid)
-            input.indice_dict[self.indice_key] = (outids, indices, indice_pairs, indice_pair_num,
-                                                  spatial_shape)
-        if self.subm:
-            out_features = Fsp.indice_subm_conv(features, self.weight, indice_pairs,
-                                                indice_pair_num, outids.shape[0])
-        else:
-            out_features = Fsp.indice_conv(features, self.weight, indice_pairs, indice_pair_num,
-                                           outids.shape[0])
+            ids, pairs, num = self._rulebook(input)
+            conv = Fsp.indice_subm_conv if self.subm else Fsp.indice_conv
+            rows = conv(input.features, self.weight, pairs, num, ids.shape[0])
+            shape = input.spatial_shape if self.subm else ops.get_conv_output_size(
+                input.spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation)
         if self.bias is not None:
-            out_features += self.bias
-        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
-        out_tensor.indice_dict = input.indice_dict
-        out_tensor.grid = input.grid
-        return out_tensor
+            rows = rows + self.bias
+        out = SparseConvTensor(rows, ids, shape, input.batch_size)
+        out.indice_dict, out.grid = input.indice_dict, input.grid
+        return out
 
 
 class SparseConv3d(SparseConvolution):
@@ -126,4 +116,4 @@ class SubMConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
                  groups=1, bias=True, indice_key=None):
         super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
-                         groups, bias, True, indice_key=indice_key)
+                         groups, bias, subm=True, indice_key=indice_key)
