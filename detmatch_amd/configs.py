@@ -344,3 +344,99 @@ def detmatch_schedule(batch_size=4, num_unlabeled_samples=1, max_iters=5000):
         lr_config=dict(policy='step', warmup='linear', warmup_iters=500, warmup_ratio=0.001, step=[]),
         runner=dict(type='IterBasedSSLRunner', max_iters=max_iters),
         custom_hooks=[dict(type='ModelIterEpochHook'), dict(type='WandbVisHook')])
+
+
+# --------------------------------------------------------------------------------------------
+# data section (configs/detmatch/001/detmatch/split_0.py:534-824), value for value
+def _photometric_chain():
+    erase = lambda p, scale, ratio: dict(type='TVRandomErasing', p=p, scale=scale, ratio=ratio, value='random')
+    return [
+        dict(type='TVToPILImage'),
+        dict(type='RandomAppliedTrans',
+             transforms=[dict(type='TVColorJitter', brightness=0.4, contrast=0.4, saturation=0.4, hue=0.1)],
+             p=0.8),
+        dict(type='TVRandomGrayscale', p=0.2),
+        dict(type='RandomAppliedTrans', transforms=[dict(type='GaussianBlur', sigma_min=0.1, sigma_max=2.0)],
+             p=0.5),
+        dict(type='TVToTensor'),
+        erase(0.7, (0.05, 0.2), (0.3, 3.3)), erase(0.5, (0.02, 0.2), (0.1, 6)), erase(0.3, (0.02, 0.2), (0.05, 8)),
+        dict(type='TVToPILImage'),
+        dict(type='ToNumpy'),
+    ]
+
+
+def detmatch_pipelines(data_root='data/kitti/', db_info_path=None, class_names=CLASS_NAMES,
+                       point_cloud_range=POINT_CLOUD_RANGE):
+    """The seven pipeline lists of the DetMatch recipe, keyed as in the reference config."""
+    file_client_args = dict(backend='disk')
+    norm = dict(mean=[103.530, 116.280, 123.675], std=[1.0, 1.0, 1.0], to_rgb=False)
+    db_sampler = dict(data_root=data_root, info_path=db_info_path, rate=1.0,
+                      prepare=dict(filter_by_difficulty=[-1],
+                                   filter_by_min_points=dict(Car=5, Pedestrian=5, Cyclist=5)),
+                      classes=class_names, use_road_plane=True, limit_whole_scene=False,
+                      sample_groups=dict(Car=15, Pedestrian=10, Cyclist=10))
+    load_img = dict(type='LoadImageFromFile')
+    load_pts = dict(type='LoadPointsFromFile', coord_type='LIDAR', load_dim=4, use_dim=4,
+                    file_client_args=file_client_args)
+    resize = dict(type='Resize', img_scale=[(640, 192), (2560, 768)], multiscale_mode='range', keep_ratio=True)
+    flip = dict(type='RandomFlip3D', flip_ratio_bev_horizontal=0.5)
+    grst = dict(type='GlobalRotScaleTrans', rot_range=[-0.78539816, 0.78539816], scale_ratio_range=[0.95, 1.05])
+    prf = dict(type='PointsRangeFilter', point_cloud_range=point_cloud_range)
+    tail = lambda keys: [dict(type='Normalize', **norm), dict(type='Pad', size_divisor=32),
+                         dict(type='DefaultFormatBundle3D', class_names=class_names),
+                         dict(type='Collect3D', keys=keys)]
+    teacher = [prf, dict(type='PointShuffle')] + tail(['points', 'img'])
+    return dict(
+        labeled_shared_pipeline=[
+            load_img, load_pts,
+            dict(type='LoadAnnotations3D', with_bbox_3d=True, with_label_3d=True, with_bbox=True,
+                 with_label=True, file_client_args=file_client_args),
+            dict(type='ObjectSample', db_sampler=db_sampler), resize, flip],
+        labeled_student_pipeline=[grst, prf, dict(type='ObjectRangeFilter', point_cloud_range=point_cloud_range),
+                                  dict(type='PointShuffle')] + _photometric_chain() +
+        tail(['points', 'gt_bboxes_3d', 'gt_labels_3d', 'img', 'gt_bboxes', 'gt_labels']),
+        labeled_teacher_pipeline=teacher,
+        unlabeled_shared_pipeline=[load_img, load_pts, resize, flip],
+        unlabeled_student_pipeline=[grst, prf, dict(type='PointShuffle')] + _photometric_chain() +
+        tail(['points', 'img']),
+        unlabeled_teacher_pipeline=teacher,
+        test_pipeline=[
+            load_img, load_pts,
+            dict(type='MultiScaleFlipAug3D', img_scale=(1280, 384), pts_scale_ratio=1, flip=False,
+                 transforms=[dict(type='GlobalRotScaleTrans', rot_range=[0, 0], scale_ratio_range=[1., 1.],
+                                  translation_std=[0, 0, 0]),
+                             dict(type='Resize', keep_ratio=True), dict(type='RandomFlip3D'), prf,
+                             dict(type='Normalize', **norm), dict(type='Pad', size_divisor=32),
+                             dict(type='DefaultFormatBundle3D', class_names=class_names, with_label=False),
+                             dict(type='Collect3D', keys=['points', 'img'])])])
+
+
+def detmatch_data(data_root='data/kitti/', split_folder='ssl_splits', split_frac=0.01, split_num=0, batch_size=4,
+                  class_names=CLASS_NAMES, point_cloud_range=POINT_CLOUD_RANGE, lab_info=None, unlab_info=None,
+                  db_info=None, val_info=None):
+    """`data = dict(...)` of split_0.py:764-824."""
+    fmt = lambda stem: data_root + '%s/%s_%s_%s.pkl' % (split_folder, stem, split_frac, split_num)
+    lab_info = lab_info or fmt('kitti_infos_train_proj_3d_lab')
+    unlab_info = unlab_info or fmt('kitti_infos_train_unlab')
+    db_info = db_info or fmt('kitti_dbinfos_train_lab')
+    val_info = val_info or data_root + 'kitti_infos_val.pkl'
+    pipes = detmatch_pipelines(data_root, db_info, class_names, point_cloud_range)
+    modality = dict(use_lidar=True, use_camera=True)
+    kitti = lambda ann, pipe, **kw: dict(type='KittiDataset', data_root=data_root, ann_file=ann, split='training',
+                                         pts_prefix='velodyne_reduced', pipeline=pipe, modality=modality,
+                                         classes=class_names, box_type_3d='LiDAR', **kw)
+    test = kitti(val_info, pipes['test_pipeline'], test_mode=True)
+    return dict(
+        samples_per_gpu=batch_size, workers_per_gpu=1,
+        train_lab=dict(type='TS_SSL_Dataset',
+                       dataset=dict(type='RepeatDataset', times=100,
+                                    dataset=kitti(lab_info, pipes['labeled_shared_pipeline'], test_mode=False,
+                                                  completely_remove_other_classes=True)),
+                       student_pipeline=pipes['labeled_student_pipeline'],
+                       teacher_pipeline=pipes['labeled_teacher_pipeline']),
+        train_unlab=dict(type='TS_SSL_Dataset',
+                         dataset=kitti(unlab_info, pipes['unlabeled_shared_pipeline'], test_mode=False,
+                                       filter_empty_gt=False, completely_remove_other_classes=True),
+                         student_pipeline=pipes['unlabeled_student_pipeline'],
+                         teacher_pipeline=pipes['unlabeled_teacher_pipeline']),
+        val=test, test=dict(test))

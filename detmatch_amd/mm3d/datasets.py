@@ -1,0 +1,371 @@
+"""B1, data section: `DATASETS` / `PIPELINES` registries that resolve every `type` of the `data=` and
+`*_pipeline` sections of configs/detmatch/* (mmdet3d/datasets/builder.py, mmdet3d/datasets/
+teacher_student_ssl_dataset.py:26-33, configs/detmatch/001/detmatch/split_0.py:552-824) and the
+`train_ssl_detector(model, datasets, cfg)` entry of mmdet3d/apis/ssl_train.py:15-150, so that
+
+    cfg = Config.fromfile('<reference>/configs/detmatch/001/detmatch/split_0.py')
+    model = build_detector(cfg.model); datasets = [build_dataset(cfg.data.train_lab),
+                                                   build_dataset(cfg.data.train_unlab)]
+    train_ssl_detector(model, datasets, cfg)
+
+runs the reference's config file unchanged.
+
+HOW differs from the reference: the reference executes the transform objects one
+sample at a time in CPU loader workers; here a pipeline entry is a *declaration* (its config kwargs,
+validated at build time) and `TS_SSL_Dataset.device_loader()` compiles the shared / student / teacher
+lists into ONE per-batch device program — `TSSSLDeviceLoader` (raw frame uploaded once, fused point
+augmentation kernel `dm_points_augment`, image resize / flip / photometric chain / normalise / pad as
+device tensor ops, GT-paste through `dbsampler.ObjectSample`).  A pipeline the compiler does not
+recognise (different order, unknown transform, unsupported argument) is an error, never silently
+skipped.
+"""
+import copy
+
+import numpy as np
+
+from .registry import Registry, build_from_cfg
+
+DATASETS = Registry('dataset')
+PIPELINES = Registry('pipeline')
+
+
+# --------------------------------------------------------------------------------------------
+# pipeline declarations
+class _Decl(object):
+    """A transform as the config names it: keeps its kwargs, validates them against `ARGS`
+    (name -> default; `...` = required)."""
+    ARGS = {}
+
+    def __init__(self, **kwargs):
+        unknown = set(kwargs) - set(self.ARGS)
+        if unknown:
+            raise TypeError('%s: unsupported argument(s) %s' % (type(self).__name__, sorted(unknown)))
+        missing = [k for k, v in self.ARGS.items() if v is ... and k not in kwargs]
+        if missing:
+            raise TypeError('%s: missing argument(s) %s' % (type(self).__name__, missing))
+        self.args = {k: kwargs.get(k, v) for k, v in self.ARGS.items()}
+
+    def __getitem__(self, k):
+        return self.args[k]
+
+    def __repr__(self):
+        return '%s(%s)' % (type(self).__name__, ', '.join('%s=%r' % kv for kv in self.args.items()))
+
+
+def _decl(name, **args):
+    cls = type(name, (_Decl,), dict(ARGS=args))
+    PIPELINES.register_module(cls, name=name)
+    return cls
+
+
+_FILE = dict(backend='disk')
+LoadImageFromFile = _decl('LoadImageFromFile', to_float32=False, color_type='color', file_client_args=_FILE)
+LoadPointsFromFile = _decl('LoadPointsFromFile', coord_type=..., load_dim=4, use_dim=4, shift_height=False,
+                           use_color=False, file_client_args=_FILE)
+LoadAnnotations3D = _decl('LoadAnnotations3D', with_bbox_3d=True, with_label_3d=True, with_bbox=False,
+                          with_label=False, with_mask=False, with_seg=False, with_attr_label=False,
+                          with_mask_3d=False, with_seg_3d=False, with_bbox_depth=False, poly2mask=True,
+                          seg_3d_dtype='int', file_client_args=_FILE)
+ObjectSampleDecl = _decl('ObjectSample', db_sampler=..., sample_2d=False)
+Resize = _decl('Resize', img_scale=None, multiscale_mode='range', ratio_range=None, keep_ratio=True,
+               bbox_clip_border=True, backend='cv2', override=False)
+RandomFlip3D = _decl('RandomFlip3D', sync_2d=True, flip_ratio_bev_horizontal=0.0,
+                     flip_ratio_bev_vertical=0.0)
+GlobalRotScaleTrans = _decl('GlobalRotScaleTrans', rot_range=[-0.78539816, 0.78539816],
+                            scale_ratio_range=[0.95, 1.05], translation_std=[0, 0, 0], shift_height=False)
+PointsRangeFilter = _decl('PointsRangeFilter', point_cloud_range=...)
+ObjectRangeFilter = _decl('ObjectRangeFilter', point_cloud_range=...)
+PointShuffle = _decl('PointShuffle')
+TVToPILImage = _decl('TVToPILImage')
+TVToTensor = _decl('TVToTensor')
+ToNumpy = _decl('ToNumpy')
+TVColorJitter = _decl('TVColorJitter', brightness=0, contrast=0, saturation=0, hue=0)
+TVRandomGrayscale = _decl('TVRandomGrayscale', p=0.1)
+GaussianBlur = _decl('GaussianBlur', sigma_min=0.1, sigma_max=2.0)
+TVRandomErasing = _decl('TVRandomErasing', p=0.5, scale=(0.02, 0.33), ratio=(0.3, 3.3), value=0,
+                        inplace=False)
+Normalize = _decl('Normalize', mean=..., std=..., to_rgb=True)
+Pad = _decl('Pad', size=None, size_divisor=None, pad_val=0)
+DefaultFormatBundle3D = _decl('DefaultFormatBundle3D', class_names=..., with_gt=True, with_label=True)
+Collect3D = _decl('Collect3D', keys=..., meta_keys=None)
+
+
+@PIPELINES.register_module()
+class RandomAppliedTrans(_Decl):
+    ARGS = dict(transforms=..., p=0.5)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.transforms = [build_from_cfg(t, PIPELINES) for t in self.args['transforms']]
+
+
+@PIPELINES.register_module()
+class MultiScaleFlipAug3D(_Decl):
+    ARGS = dict(transforms=..., img_scale=..., pts_scale_ratio=1, flip=False, flip_direction='horizontal',
+                pcd_horizontal_flip=False, pcd_vertical_flip=False)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.transforms = [build_from_cfg(t, PIPELINES) for t in self.args['transforms']]
+
+
+def build_pipeline(cfgs):
+    return [build_from_cfg(c, PIPELINES) for c in (cfgs or [])]
+
+
+def _only(decls, cls):
+    hit = [d for d in decls if isinstance(d, cls)]
+    if len(hit) > 1:
+        raise ValueError('pipeline holds %d %s transforms' % (len(hit), cls.__name__))
+    return hit[0] if hit else None
+
+
+def _names(decls):
+    return [type(d).__name__ for d in decls]
+
+
+def compile_pipelines(shared, student, teacher, labeled):
+    """shared / student / teacher declaration lists -> keyword arguments of TSSSLDeviceLoader.
+    Checks the ORDER the device program hard-wires (split_0.py:552-700): shared = load*, [ObjectSample],
+    Resize, RandomFlip3D; student = GlobalRotScaleTrans, PointsRangeFilter, [ObjectRangeFilter],
+    PointShuffle, [photometric chain], Normalize, Pad, bundle, collect; teacher = PointsRangeFilter,
+    PointShuffle, Normalize, Pad, bundle, collect."""
+    out = {}
+    n_sh = _names(shared)
+    want = ['LoadImageFromFile', 'LoadPointsFromFile'] + (['LoadAnnotations3D'] if labeled else [])
+    if n_sh[:len(want)] != want:
+        raise ValueError('shared pipeline must start with %s, got %s' % (want, n_sh))
+    rest = n_sh[len(want):]
+    if rest not in (['ObjectSample', 'Resize', 'RandomFlip3D'], ['Resize', 'RandomFlip3D']):
+        raise ValueError('unsupported shared pipeline tail %s' % rest)
+    lp = _only(shared, LoadPointsFromFile)
+    if lp['coord_type'] != 'LIDAR' or lp['load_dim'] != 4 or lp['use_dim'] != 4:
+        raise ValueError('LoadPointsFromFile: only 4-dim LIDAR clouds')
+    os_ = _only(shared, ObjectSampleDecl)
+    out['db_sampler'] = dict(os_['db_sampler']) if os_ is not None else None
+    rs = _only(shared, Resize)
+    if not rs['keep_ratio'] or rs['multiscale_mode'] != 'range' or rs['img_scale'] is None:
+        raise ValueError('Resize: only keep_ratio=True with a scale range')
+    out['img_scale'] = tuple(tuple(s) for s in rs['img_scale'])
+    fl = _only(shared, RandomFlip3D)
+    if fl['flip_ratio_bev_vertical'] or not fl['sync_2d']:
+        raise ValueError('RandomFlip3D: only the synchronised horizontal flip')
+    out['flip_ratio'] = fl['flip_ratio_bev_horizontal']
+
+    n_st = _names(student)
+    head = ['GlobalRotScaleTrans', 'PointsRangeFilter'] + (['ObjectRangeFilter'] if labeled else []) + \
+        ['PointShuffle']
+    if n_st[:len(head)] != head:
+        raise ValueError('student pipeline must start with %s, got %s' % (head, n_st[:len(head)]))
+    tail = ['Normalize', 'Pad', 'DefaultFormatBundle3D', 'Collect3D']
+    if n_st[-4:] != tail or _names(teacher) != ['PointsRangeFilter', 'PointShuffle'] + tail:
+        raise ValueError('student / teacher pipelines must end with %s' % tail)
+    g = _only(student, GlobalRotScaleTrans)
+    if any(float(v) != 0 for v in g['translation_std']):
+        raise ValueError('GlobalRotScaleTrans: translation_std must be 0 (DetMatch setting)')
+    out['rot_range'], out['scale_ratio_range'] = tuple(g['rot_range']), tuple(g['scale_ratio_range'])
+    pcr = [list(d['point_cloud_range']) for d in student + teacher
+           if isinstance(d, (PointsRangeFilter, ObjectRangeFilter))]
+    if any(p != pcr[0] for p in pcr):
+        raise ValueError('all range filters must share one point_cloud_range')
+    out['point_cloud_range'] = pcr[0]
+    # photometric chain (student only)
+    photo = student[len(head):-4]
+    out['student_photometric'] = None
+    if photo:
+        want = ['TVToPILImage', 'RandomAppliedTrans', 'TVRandomGrayscale', 'RandomAppliedTrans', 'TVToTensor',
+                'TVRandomErasing', 'TVRandomErasing', 'TVRandomErasing', 'TVToPILImage', 'ToNumpy']
+        if _names(photo) != want:
+            raise ValueError('unsupported student image chain %s' % _names(photo))
+        cj, blur = photo[1], photo[3]
+        if _names(cj.transforms) != ['TVColorJitter'] or _names(blur.transforms) != ['GaussianBlur']:
+            raise ValueError('RandomAppliedTrans must wrap TVColorJitter / GaussianBlur')
+        j = cj.transforms[0]
+        er = photo[5:8]
+        if any(e['value'] != 'random' for e in er):
+            raise ValueError("TVRandomErasing: only value='random'")
+        out['student_photometric'] = dict(
+            jitter=(j['brightness'], j['contrast'], j['saturation'], j['hue']), p_jitter=cj['p'],
+            p_grey=photo[2]['p'], blur_sigma=(blur.transforms[0]['sigma_min'], blur.transforms[0]['sigma_max']),
+            p_blur=blur['p'], erasing=tuple((e['p'], tuple(e['scale']), tuple(e['ratio'])) for e in er))
+    nm = [_only(student, Normalize), _only(teacher, Normalize)]
+    if any(list(n['mean']) != list(nm[0]['mean']) or list(n['std']) != list(nm[0]['std']) or n['to_rgb']
+           for n in nm):
+        raise ValueError('Normalize: student and teacher must agree, to_rgb=False')
+    out['img_mean'], out['img_std'] = tuple(nm[0]['mean']), tuple(nm[0]['std'])
+    pads = [_only(student, Pad), _only(teacher, Pad)]
+    if any(p['size_divisor'] != pads[0]['size_divisor'] or p['size'] is not None for p in pads):
+        raise ValueError('Pad: only size_divisor')
+    out['size_divisor'] = pads[0]['size_divisor']
+    want_keys = ['points', 'gt_bboxes_3d', 'gt_labels_3d', 'img', 'gt_bboxes', 'gt_labels'] if labeled \
+        else ['points', 'img']
+    if list(_only(student, Collect3D)['keys']) != want_keys or \
+            list(_only(teacher, Collect3D)['keys']) != ['points', 'img']:
+        raise ValueError('Collect3D keys differ from the DetMatch recipes')
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# datasets
+def _kitti():
+    from ..kitti_dataset import KittiDataset
+    return KittiDataset
+
+
+class _LazyKitti(object):
+    """Registered under 'KittiDataset': builds detmatch_amd.kitti_dataset.KittiDataset with the shared
+    pipeline kept as declarations (`.pipeline_decls`)."""
+
+    def __new__(cls, pipeline=None, **kwargs):
+        ds = _kitti()(pipeline=None, **kwargs)
+        ds.pipeline_decls = build_pipeline(pipeline)
+        return ds
+
+
+DATASETS.register_module(_LazyKitti, name='KittiDataset')
+
+
+@DATASETS.register_module()
+class RepeatDataset(object):
+    """mmdet RepeatDataset: `times` passes over the wrapped dataset per epoch."""
+
+    def __init__(self, dataset, times):
+        self.dataset = build_dataset(dataset) if isinstance(dataset, dict) else dataset
+        self.times = int(times)
+        self.CLASSES = getattr(self.dataset, 'CLASSES', None)
+        self._ori_len = len(self.dataset)
+
+    def __len__(self):
+        return self.times * self._ori_len
+
+    def __getattr__(self, name):          # get_data_info / load_points / data_infos ... of the inner set
+        return getattr(self.dataset, name)
+
+    def inner_index(self, idx):
+        return idx % self._ori_len
+
+
+@DATASETS.register_module()
+class TS_SSL_Dataset(object):
+    """teacher_student_ssl_dataset.py:9-33: one shared pipeline (the inner dataset's), then student and
+    teacher pipelines on copies of its result."""
+
+    def __init__(self, dataset, student_pipeline, teacher_pipeline):
+        self.dataset = build_dataset(dataset) if isinstance(dataset, dict) else dataset
+        self.CLASSES = getattr(self.dataset, 'CLASSES', None)
+        self.student_pipeline = build_pipeline(student_pipeline)
+        self.teacher_pipeline = build_pipeline(teacher_pipeline)
+        inner = self.dataset.dataset if isinstance(self.dataset, RepeatDataset) else self.dataset
+        self.shared_pipeline = getattr(inner, 'pipeline_decls', [])
+        self.labeled = any(isinstance(d, type(None)) is False and type(d).__name__ == 'LoadAnnotations3D'
+                           for d in self.shared_pipeline)
+        self.loader_args = compile_pipelines(self.shared_pipeline, self.student_pipeline,
+                                             self.teacher_pipeline, self.labeled)
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def device_loader(self, samples_per_gpu, device, seed=0, rank=0, world_size=1):
+        """The loader `IterBasedSSLRunner.run` takes (replaces mmdet build_dataloader + the CPU
+        pipelines; ssl_train.py:40-57)."""
+        from ..ts_ssl_dataset import TSSSLDeviceLoader
+        a = dict(self.loader_args)
+        photo = a.pop('student_photometric')
+        inner = _IndexView(self.dataset)
+        return TSSSLDeviceLoader(
+            inner, samples_per_gpu, device, labeled=self.labeled, point_cloud_range=a['point_cloud_range'],
+            seed=seed, rot_range=a['rot_range'], scale_ratio_range=a['scale_ratio_range'],
+            flip_ratio=a['flip_ratio'], img_scale=a['img_scale'], student_photometric=photo,
+            db_sampler=a['db_sampler'], img_mean=a['img_mean'], img_std=a['img_std'],
+            size_divisor=a['size_divisor'], rank=rank, world_size=world_size)
+
+
+class _IndexView(object):
+    """Index-mapping view (RepeatDataset) with the reader interface TSSSLDeviceLoader uses."""
+
+    def __init__(self, ds):
+        self.ds = ds
+        self.inner = ds.dataset if isinstance(ds, RepeatDataset) else ds
+        self.n = len(ds)
+
+    def __len__(self):
+        return self.n
+
+    def _i(self, i):
+        return self.ds.inner_index(i) if isinstance(self.ds, RepeatDataset) else i
+
+    def get_data_info(self, i):
+        return self.inner.get_data_info(self._i(i))
+
+    def load_points(self, i):
+        return self.inner.load_points(self._i(i))
+
+    def load_image(self, i):
+        return self.inner.load_image(self._i(i))
+
+    @property
+    def data_infos(self):
+        view = self
+
+        class _Infos(object):
+            def __getitem__(self, i):
+                return view.inner.data_infos[view._i(i)]
+
+            def __len__(self):
+                return view.n
+        return _Infos()
+
+
+def build_dataset(cfg, default_args=None):
+    """mmdet3d/datasets/builder.py build_dataset (the wrappers recurse themselves)."""
+    return build_from_cfg(copy.deepcopy(dict(cfg)), DATASETS, default_args)
+
+
+# --------------------------------------------------------------------------------------------
+# training entry
+def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, timestamp=None, meta=None,
+                       device='cuda', max_iters=None):
+    """mmdet3d/apis/ssl_train.py:15-150 on this repo's runner: two device loaders (the unlabeled one
+    with samples_per_gpu * num_unlabeled_samples, :52), FlatGradDDP instead of MMDistributedData
+    Parallel, build_optimizer(cfg.optimizer), build the runner named by cfg.runner, register the LR /
+    optimizer / custom hooks, run.  Returns the runner (the reference returns None)."""
+    import torch
+    import torch.distributed as dist
+    from . import runner as R
+    from .parallel import FlatGradDDP
+    from .registry import HOOKS, RUNNERS
+    assert len(dataset) == 2, 'labeled and unlabeled TS_SSL_Dataset'
+    data = cfg['data']
+    spg = int(data.get('imgs_per_gpu', data['samples_per_gpu']))
+    rank = dist.get_rank() if distributed and dist.is_initialized() else 0
+    world = dist.get_world_size() if distributed and dist.is_initialized() else 1
+    seed = cfg.get('seed', None) or 0
+    dev = torch.device(device)
+    loaders = [dataset[0].device_loader(spg, dev, seed=seed, rank=rank, world_size=world),
+               dataset[1].device_loader(int(spg * cfg['num_unlabeled_samples']), dev, seed=seed,
+                                        rank=rank, world_size=world)]
+    model = model.to(dev)
+    optimizer = R.build_optimizer(model, cfg['optimizer'])
+    ddp = FlatGradDDP(model, broadcast=distributed and world > 1) if dev.type == 'cuda' else model
+    if isinstance(ddp, FlatGradDDP) and hasattr(optimizer, 'enable_fused'):
+        inner = ddp.module
+        if hasattr(inner, 'build_arenas'):
+            inner.build_arenas(ddp)
+        else:
+            ddp.build_param_arena()
+        optimizer.enable_fused(ddp)
+    rcfg = dict(cfg['runner'])
+    if max_iters is not None:
+        rcfg['max_iters'] = max_iters
+    runner = build_from_cfg(rcfg, RUNNERS, default_args=dict(
+        model=ddp, optimizer=optimizer, work_dir=cfg.get('work_dir', None), logger=None, meta=meta))
+    runner.timestamp = timestamp
+    if cfg.get('fp16', None) is not None:
+        raise NotImplementedError('fp16 optimizer hook: mixed precision is not implemented (DESIGN.md)')
+    custom = [build_from_cfg(dict(h), HOOKS) for h in cfg.get('custom_hooks', [])]
+    runner.register_training_hooks(cfg['lr_config'], cfg['optimizer_config'], custom_hooks=custom,
+                                   momentum_config=cfg.get('momentum_config', None))
+    if validate:
+        raise NotImplementedError('validation hook: use SSL.simple_test + KittiDataset.evaluate')
+    runner.run(loaders, cfg.get('workflow', [('train', 1)]))
+    return runner

@@ -158,17 +158,27 @@ class TSSSLDeviceLoader(object):
     def __init__(self, dataset, samples_per_gpu, device, labeled, point_cloud_range, seed=0,
                  rot_range=(-0.78539816, 0.78539816), scale_ratio_range=(0.95, 1.05), flip_ratio=0.5,
                  img_scale=((640, 192), (2560, 768)), shuffle=True, with_img=True, student_photometric=True,
-                 db_sampler=None):
+                 db_sampler=None, img_mean=(103.530, 116.280, 123.675), img_std=(1.0, 1.0, 1.0),
+                 size_divisor=32, rank=0, world_size=1):
         self.dataset, self.bs, self.device, self.labeled = dataset, samples_per_gpu, torch.device(device), labeled
-        self.rng = np.random.RandomState(seed)
+        # the sample ORDER is drawn from a seed shared by all ranks (+ epoch) and each rank takes every
+        # world_size-th entry (mmdet DistributedGroupSampler's partition); augmentation draws use a
+        # per-rank stream
+        self.seed, self.rank, self.world_size, self.epoch = int(seed), int(rank), int(world_size), 0
+        self.rng = np.random.RandomState((int(seed) * 1000003 + 7919 * int(rank)) % (2 ** 31))
         self.shuffle, self.with_img = shuffle, with_img
         self.flip_ratio = flip_ratio
-        self.image_tf = ImageResizeFlipNormPad(img_scale)
-        self.photometric = StudentPhotometric() if student_photometric else None
+        self.image_tf = ImageResizeFlipNormPad(img_scale, mean=img_mean, std=img_std, size_divisor=size_divisor)
+        if isinstance(student_photometric, dict):
+            self.photometric = StudentPhotometric(**student_photometric)
+        else:
+            self.photometric = StudentPhotometric() if student_photometric else None
         # ObjectSample(db_sampler) of the labeled shared pipeline (split_0.py:570): GT-paste before the flip
         self.object_sample = None
         if db_sampler is not None and labeled:
             from .dbsampler import ObjectSample
+            if isinstance(db_sampler, dict):
+                db_sampler = dict(db_sampler, device=self.device, rng=self.rng)
             self.object_sample = db_sampler if isinstance(db_sampler, ObjectSample) else ObjectSample(db_sampler)
         self.pipe = P3.TSSSLPipeline3D(
             shared=[P3.RandomFlip3D(sync_2d=True, flip_ratio_bev_horizontal=flip_ratio)],
@@ -176,16 +186,23 @@ class TSSSLDeviceLoader(object):
                      P3.PointsRangeFilter(point_cloud_range), P3.PointShuffle()],
             teacher=[P3.PointsRangeFilter(point_cloud_range), P3.PointShuffle()],
             object_range=point_cloud_range if labeled else None)
-        self.sampler = None
+        self.sampler = self          # IterLoader calls loader.sampler.set_epoch(epoch) (mmcv)
 
     def __len__(self):
-        return max(len(self.dataset) // self.bs, 1)
+        return max(len(self.dataset) // (self.bs * self.world_size), 1)
+
+    def set_epoch(self, epoch):
+        """IterLoader calls this when the loader is exhausted: a new shared permutation per epoch."""
+        self.epoch = int(epoch)
 
     def _indices(self):
         n = len(self.dataset)
-        order = self.rng.permutation(n) if self.shuffle else np.arange(n)
-        if n < self.bs:                                   # tiny sets (tests): repeat
-            order = np.resize(order, self.bs)
+        order_rng = np.random.RandomState((self.seed + self.epoch) % (2 ** 31))
+        order = order_rng.permutation(n) if self.shuffle else np.arange(n)
+        need = self.bs * self.world_size
+        if len(order) < need:                             # tiny sets (tests): repeat
+            order = np.resize(order, need)
+        order = order[:len(order) // need * need][self.rank::self.world_size]
         return [order[i:i + self.bs] for i in range(0, len(order) - self.bs + 1, self.bs)]
 
     def __iter__(self):

@@ -91,3 +91,92 @@ def test_ssl_modules_build_from_builder_config():
     for chain in configs.detmatch_ssl_cfg().values():
         for m in chain:
             build_ssl_module(m)
+
+
+@needs_ref
+def test_reference_data_section_resolves_and_compiles():
+    """B1 data section: every `type` of the reference config's data / pipeline
+    sections is in the DATASETS / PIPELINES registries, and the three pipeline lists compile into the
+    device loader's program with exactly the reference's parameters."""
+    from detmatch_amd.mm3d import datasets as D
+    cfg = Config.fromfile(os.path.join(REF, 'detmatch/split_0.py'))
+
+    def walk(node, found):
+        if isinstance(node, dict):
+            if 'type' in node and isinstance(node['type'], str):
+                found.append(node['type'])
+            for v in node.values():
+                walk(v, found)
+        elif isinstance(node, (list, tuple)):
+            for v in node:
+                walk(v, found)
+        return found
+
+    for name in ('labeled_shared_pipeline', 'labeled_student_pipeline', 'labeled_teacher_pipeline',
+                 'unlabeled_shared_pipeline', 'unlabeled_student_pipeline', 'unlabeled_teacher_pipeline',
+                 'test_pipeline'):
+        for t in walk(cfg[name], []):
+            assert t in D.PIPELINES, (name, t)
+        D.build_pipeline(cfg[name])                       # argument names are validated too
+    for t in ('TS_SSL_Dataset', 'RepeatDataset', cfg['dataset_type']):
+        assert t in D.DATASETS, t
+    lab = D.compile_pipelines(D.build_pipeline(cfg['labeled_shared_pipeline']),
+                              D.build_pipeline(cfg['labeled_student_pipeline']),
+                              D.build_pipeline(cfg['labeled_teacher_pipeline']), labeled=True)
+    unlab = D.compile_pipelines(D.build_pipeline(cfg['unlabeled_shared_pipeline']),
+                                D.build_pipeline(cfg['unlabeled_student_pipeline']),
+                                D.build_pipeline(cfg['unlabeled_teacher_pipeline']), labeled=False)
+    assert lab['db_sampler']['sample_groups'] == dict(Car=15, Pedestrian=10, Cyclist=10)
+    assert unlab['db_sampler'] is None
+    for a in (lab, unlab):
+        assert a['img_scale'] == ((640, 192), (2560, 768)) and a['flip_ratio'] == 0.5
+        assert a['rot_range'] == (-0.78539816, 0.78539816) and a['scale_ratio_range'] == (0.95, 1.05)
+        assert a['point_cloud_range'] == list(cfg['point_cloud_range'])
+        assert a['img_mean'] == (103.530, 116.280, 123.675) and a['size_divisor'] == 32
+        ph = a['student_photometric']
+        assert ph['jitter'] == (0.4, 0.4, 0.4, 0.1) and ph['p_jitter'] == 0.8 and ph['p_grey'] == 0.2
+        assert ph['blur_sigma'] == (0.1, 2.0) and ph['p_blur'] == 0.5
+        assert ph['erasing'] == ((0.7, (0.05, 0.2), (0.3, 3.3)), (0.5, (0.02, 0.2), (0.1, 6)),
+                                 (0.3, (0.02, 0.2), (0.05, 8)))
+    # a pipeline the device program does not implement is an error, not a silent skip
+    bad = [dict(t) for t in cfg['unlabeled_student_pipeline']]
+    bad[0], bad[1] = bad[1], bad[0]
+    with pytest.raises(ValueError):
+        D.compile_pipelines(D.build_pipeline(cfg['unlabeled_shared_pipeline']), D.build_pipeline(bad),
+                            D.build_pipeline(cfg['unlabeled_teacher_pipeline']), labeled=False)
+    with pytest.raises(TypeError):
+        D.build_pipeline([dict(type='PointsRangeFilter', point_cloud_range=[0] * 6, bogus=1)])
+
+
+def test_rank_aware_device_loader_partitions_the_epoch():
+    """ADVICE r1 (ts_ssl_dataset.py:158): ranks share the epoch's permutation and take disjoint slices;
+    set_epoch reshuffles consistently."""
+    from detmatch_amd.ts_ssl_dataset import TSSSLDeviceLoader
+
+    class Fake(object):
+        def __len__(self):
+            return 40
+
+    seen = []
+    for rank in range(4):
+        ld = TSSSLDeviceLoader(Fake(), 2, 'cpu', labeled=False, point_cloud_range=[0, -40, -3, 70.4, 40, 1],
+                               seed=3, rank=rank, world_size=4, with_img=False, student_photometric=False)
+        idx = np.concatenate(ld._indices())
+        assert len(idx) == 10 and len(ld) == 5
+        seen.append(idx)
+        ld.set_epoch(1)
+        assert not np.array_equal(np.concatenate(ld._indices()), idx)
+    allidx = np.concatenate(seen)
+    assert sorted(allidx.tolist()) == list(range(40))        # a partition of the dataset
+
+
+import numpy as np  # noqa: E402
+
+
+@needs_ref
+def test_data_builder_equals_reference_config():
+    cfg = Config.fromfile(os.path.join(REF, 'detmatch/split_0.py'))
+    assert _plain(configs.detmatch_data()) == _plain(cfg['data'])
+    pipes = configs.detmatch_pipelines(cfg['data_root'], cfg['db_info_path'])
+    for k, v in pipes.items():
+        assert _plain(v) == _plain(cfg[k]), k

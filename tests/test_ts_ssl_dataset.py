@@ -89,3 +89,37 @@ def test_training_iterations_on_kitti_files():
     assert all(np.isfinite(losses)), losses
     for k in ('sup.sup_3d.loss', 'sup.stu.loss_rpn_cls', 'ssl.unlab.hard_pseudo_3d.loss'):
         assert k in run.log_buffer, sorted(run.log_buffer)
+
+
+def test_train_ssl_detector_from_config():
+    """B1 end to end (mmdet3d/apis/ssl_train.py:15): the DetMatch config (model + data + schedule
+    sections as the reference file holds them; detmatch_amd/configs.py reproduces it value for value,
+    tests/test_ssl_config.py) -> build_detector / build_dataset through the registries ->
+    train_ssl_detector(model, datasets, cfg) runs training iterations on the fixture frame."""
+    from detmatch_amd import configs
+    from detmatch_amd.mm3d import register_all
+    from detmatch_amd.mm3d.datasets import build_dataset, train_ssl_detector
+    from detmatch_amd.mm3d.registry import build_detector
+    register_all()
+    info = os.path.join(ROOT, 'kitti_infos_train.pkl')
+    data = configs.detmatch_data(data_root=ROOT + '/', batch_size=2, lab_info=info, unlab_info=info)
+    # the fixture has no object database: the labeled shared pipeline without its ObjectSample entry
+    inner = data['train_lab']['dataset']['dataset']
+    inner['pipeline'] = [t for t in inner['pipeline'] if t['type'] != 'ObjectSample']
+    # one image scale, so every iteration sees the same convolution shapes (multi-scale is exercised in
+    # test_loader_batches_are_consistent_between_2d_and_3d)
+    for ds in (inner, data['train_unlab']['dataset']):
+        for t in ds['pipeline']:
+            if t['type'] == 'Resize':
+                t['img_scale'] = [(1280, 384), (1280, 384)]
+    cfg = dict(model=configs.detmatch_kitti_model(ssl_cfg=configs.detmatch_ssl_cfg(with_vis=False)), data=data,
+               num_unlabeled_samples=1, seed=0, **configs.detmatch_schedule(2, 1, max_iters=2))
+    torch.manual_seed(0)
+    model = build_detector(cfg['model'])
+    model.teacher.load_state_dict(model.student.state_dict())
+    datasets = [build_dataset(cfg['data']['train_lab']), build_dataset(cfg['data']['train_unlab'])]
+    assert len(datasets[0]) == 100 * len(datasets[1]) and datasets[0].labeled and not datasets[1].labeled
+    run = train_ssl_detector(model, datasets, cfg, device='cuda:0')
+    assert run.iter == 2
+    losses = [float(v) for v in run.log_buffer['loss']]
+    assert all(np.isfinite(losses)), losses
