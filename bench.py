@@ -52,12 +52,24 @@ def gg_bytes(P, ci, co, kvol, rows_out):
     return P * (ci + co) * 4 + P * 8 + kvol * ci * co * 4 + rows_out * co * 4
 
 
+def wgrad_bytes(P, ci, co, kvol):
+    """Algorithmic bytes of one weight-gradient launch: both rows of every pair once, the pair list,
+    the gradient written once (backward formula minus the input-gradient half)."""
+    return P * (ci + co) * 4 + P * 8 + kvol * ci * co * 4
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+
+
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_spconv.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of
+    """HBM-side bytes per launch of `kernel` from this round's rocprofv3 PMC passes
+    (profiles/r02_pmc_spconv.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of
     this same bench command, gfx950 correction applied — tools/pmc_traffic.py); None if absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_spconv.json')
-    if not os.path.exists(path):
+    for name in ('r02_pmc_spconv.json', 'r01_pmc_spconv.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            break
+    else:
         return None
     table = json.load(open(path))
     stem = kernel.rstrip('>')
@@ -83,51 +95,168 @@ def build_workload(dev, rank):
 
 def trace_launches(wl):
     """One extra (untimed) step with the launch trace on: [(ci, co, rows, kvol, P)] per
-    gather-GEMM launch, in launch order."""
+    gather-GEMM launch in launch order, 'fwd' / 'dgrad' per launch, and [(ci, co, kvol, P, n_in,
+    n_out)] per weight-gradient launch."""
     from detmatch_amd.spconv import ops as sp_ops
-    sp_ops.LAUNCH_TRACE = []
+    sp_ops.LAUNCH_TRACE, sp_ops.LAUNCH_TRACE_DIR, sp_ops.LAUNCH_TRACE_W = [], [], []
     try:
         wl.step()
         torch.cuda.synchronize()
-        return list(sp_ops.LAUNCH_TRACE)
+        return list(sp_ops.LAUNCH_TRACE), list(sp_ops.LAUNCH_TRACE_DIR), list(sp_ops.LAUNCH_TRACE_W)
     finally:
-        sp_ops.LAUNCH_TRACE = None
+        sp_ops.LAUNCH_TRACE = sp_ops.LAUNCH_TRACE_DIR = sp_ops.LAUNCH_TRACE_W = None
 
 
-def cpu_baseline(frames):
-    """The oracle (C restatement of the reference CPU path) on ONE step of the same
-    sparse-conv workload, one host core."""
-    import oracle
+def _oracle_stage(oracle, frames, rng_seed=0, timings=None):
+    """voxelize -> 8 rulebooks -> 12 sparse convs forward -> backward on the oracle; optional per-piece
+    wall times (seconds) and §8(d) algorithmic bytes."""
     from detmatch_amd import synth
     from detmatch_amd.pcdet.workload import BACKBONE_LAYERS
-    oracle.build()
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(rng_seed)
+    T = timings if timings is not None else {}
+    for k in ('voxelize', 'rulebook', 'conv_fwd', 'conv_bwd', 'bytes_fwd', 'bytes_bwd'):
+        T.setdefault(k, 0.0)
     t0 = time.perf_counter()
     feats, coors = [], []
     for b, f in enumerate(frames):
         v, c, n = oracle.hard_voxelize(f['points'], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
         feats.append(v.sum(1) / np.maximum(n, 1)[:, None].astype(np.float32))
         coors.append(np.concatenate([np.full((len(n), 1), b, np.int32), c], 1))
+    T['voxelize'] += time.perf_counter() - t0
     x = np.concatenate(feats)
     idx = np.concatenate(coors)
     shape = [41, 1600, 1408]
     books, acts = {}, []
     for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
         if key not in books:
+            t0 = time.perf_counter()
             books[key] = oracle.get_indice_pairs(idx, len(frames), shape, ks, st, pd, subm=subm)
+            T['rulebook'] += time.perf_counter() - t0
         o, p, n, osh = books[key]
-        w = (rng.standard_normal((int(np.prod(ks)), cin, cout)) * 0.05).astype(np.float32)
+        kvol = int(np.prod(ks))
+        w = (rng.standard_normal((kvol, cin, cout)) * 0.05).astype(np.float32)
+        t0 = time.perf_counter()
         y = oracle.indice_conv(x, w, p, n, len(o), subm=subm)
+        T['conv_fwd'] += time.perf_counter() - t0
+        P = int(n.sum())
+        T['bytes_fwd'] += gg_bytes(P, cin, cout, kvol, len(o))
+        T['bytes_bwd'] += P * (2 * cin + 2 * cout) * 4 + P * 8 + 2 * kvol * cin * cout * 4 + len(x) * cin * 4
         acts.append((x, w, p, n, subm))
         x, idx, shape = np.maximum(y, 0), o, osh
     g = np.ones_like(x)
+    t0 = time.perf_counter()
     for (xi, w, p, n, subm) in reversed(acts):
         g, _ = oracle.indice_conv_backward(xi, w, g, p, n, subm=subm)
-    dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit='iters/sec', cores=1, kind='port',
-                sample='1 step of the sparse-conv stage only (voxelize + 8 rulebooks + 12 sparse '
-                       'convs fwd+bwd, bs=%d, no BN/optimizer), oracle/dm_oracle.c, %.1f s'
-                       % (len(frames), dt))
+    T['conv_bwd'] += time.perf_counter() - t0
+    return T
+
+
+def cpu_baseline(frames, gpu_pieces=None):
+    """The oracle (C restatement of the reference CPU path, oracle/dm_oracle.c) on the host cores of
+    this box, per piece as BASELINE.md §4 asks: voxelize ms/frame, rulebooks ms, sparse conv forward /
+    backward ms with the §8(d) algorithmic GB/s, rotated BEV IoU us/pair — at 1 thread and with one
+    independent copy of the stage per core (the port is scalar C; ctypes releases the GIL).  `value` =
+    sparse-conv-stage iterations per second at 1 thread; the GPU's time for the SAME pieces is printed
+    beside it (`gpu_same_pieces`)."""
+    import concurrent.futures
+    import oracle
+    oracle.build()
+    t_all = time.perf_counter()
+    _oracle_stage(oracle, frames[:1])                      # warm-up (page-in, first-touch)
+    T = {}
+    t0 = time.perf_counter()
+    _oracle_stage(oracle, frames, timings=T)
+    dt1 = time.perf_counter() - t0
+    rng = np.random.default_rng(1)
+    nb = 256
+    boxes = np.concatenate([rng.uniform(0, 40, (nb, 2)), rng.uniform(-1, 1, (nb, 1)), rng.uniform(1, 4, (nb, 3)),
+                            rng.uniform(-3, 3, (nb, 1))], 1).astype(np.float32)
+    t0 = time.perf_counter()
+    oracle.boxes_iou_bev(boxes, boxes)
+    iou_us = (time.perf_counter() - t0) / (nb * nb) * 1e6
+    cores = min(os.cpu_count() or 1, 16)     # bounded: the port is memory-bound well before that
+    with concurrent.futures.ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda i: _oracle_stage(oracle, frames, rng_seed=i), range(cores)))
+        dtn = time.perf_counter() - t0
+    pieces = dict(voxelize_ms_per_frame=round(T['voxelize'] / len(frames) * 1e3, 2),
+                  rulebooks_ms=round(T['rulebook'] * 1e3, 1),
+                  conv_fwd_ms=round(T['conv_fwd'] * 1e3, 1), conv_bwd_ms=round(T['conv_bwd'] * 1e3, 1),
+                  conv_fwd_GBps=round(T['bytes_fwd'] / T['conv_fwd'] / 1e9, 2),
+                  conv_bwd_GBps=round(T['bytes_bwd'] / T['conv_bwd'] / 1e9, 2),
+                  bev_iou_us_per_pair=round(iou_us, 3))
+    out = dict(value=round(1.0 / dt1, 4), unit='iters/sec of the sparse-conv stage (voxelize + 8 rulebooks '
+               '+ 12 sparse convs fwd+bwd, bs=%d, no BN/optimizer)' % len(frames), cores=1, kind='port',
+               sample='1 warm-up + 1 timed stage at 1 thread, then %d concurrent copies (one per thread); '
+                      'BEV IoU on %dx%d boxes; %.1f s in all' % (cores, nb, nb, time.perf_counter() - t_all),
+               pieces_1_thread=pieces,
+               all_cores=dict(cores=cores, value=round(cores / dtn, 4),
+                              note='%d independent copies of the stage in %.1f s' % (cores, dtn)))
+    if gpu_pieces is not None:
+        out['gpu_same_pieces'] = gpu_pieces
+    return out
+
+
+def gpu_stage_pieces(frames, dev):
+    """Device time (HIP events on the launch stream) of the same pieces as cpu_baseline."""
+    from detmatch_amd import iou3d_nms, synth, voxel
+    from detmatch_amd.pcdet.workload import BACKBONE_LAYERS
+    from detmatch_amd.spconv import ops
+    pts = [torch.from_numpy(f['points']).to(dev) for f in frames]
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, r
+
+    t_vox, vox = timed(lambda: voxel.voxelize_batch(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000))
+    _, coors, _, mean, _ = vox
+
+    def rulebooks():
+        books, cur, shape = {}, coors, [41, 1600, 1408]
+        for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
+            if key not in books:
+                books[key] = ops.build_rulebook(cur, len(pts), shape, ks, st, pd, 1, subm)
+                cur, shape = books[key].outids, books[key].out_shape
+        return books
+    t_rb, books = timed(rulebooks, reps=3)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    ws = [(torch.randn(int(np.prod(ks)), cin, cout, generator=g) * 0.05).to(dev)
+          for _, _, cin, cout, ks, _, _ in BACKBONE_LAYERS]
+    saved = []
+
+    def fwd():
+        x = mean
+        saved.clear()
+        for (key, subm, cin, cout, ks, st, pd), w in zip(BACKBONE_LAYERS, ws):
+            rb = books[key]
+            y = ops.indice_conv(x, w, rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
+            saved.append((x, w, rb, subm, cin))
+            x = torch.relu(y)
+        return x
+    t_f, xo = timed(fwd)
+
+    def bwd():
+        gq = torch.ones_like(xo)
+        for x, w, rb, subm, cin in reversed(saved):
+            dx, _ = ops.indice_conv_backward(x, w, gq, rb.indice_pairs, rb.indice_num, False, subm,
+                                             need_input_grad=cin >= 16)
+            gq = dx
+    t_b, _ = timed(bwd)
+    boxes = torch.cat([torch.rand(256, 2) * 40, torch.rand(256, 1) * 2 - 1, torch.rand(256, 3) * 3 + 1,
+                       torch.rand(256, 1) * 6 - 3], 1).to(dev)
+    t_iou, _ = timed(lambda: iou3d_nms.boxes_iou_bev(boxes, boxes))
+    return dict(voxelize_ms_per_frame=round(t_vox / len(frames), 4), rulebooks_ms=round(t_rb, 3),
+                conv_fwd_ms=round(t_f, 3), conv_bwd_ms=round(t_b, 3),
+                bev_iou_us_per_pair=round(t_iou * 1e3 / (256 * 256), 5),
+                note='HIP events on the launch stream, same synthetic frames; rulebooks include their '
+                     '4 size read-backs')
 
 
 def self_launch(args):
@@ -230,35 +359,61 @@ def main():
 
     # one extra untimed step with the launch trace on — on EVERY rank (a step contains the gradient
     # and log all-reduces; a rank stepping alone would dead-lock the others)
-    per_step = trace_launches(wl)   # [(ci, co, rows, kvol, P)] in launch order
+    per_step, per_dir, per_w = trace_launches(wl)
     if rank == 0:
-        # ---- roofline of the dominant kernel (HIP events from the timed region) ----
-        gg = [r for r in recs if r[0] == 0]
-        roof = None
+        # ---- roofline of the sparse-conv kernels (HIP events from the timed region) ----
         # the synthetic batch is the same every step, so launch j of a step always sees the same
         # rulebook; data-dependent launches (pseudo-label dependent) would break the 1:1 mapping
+        gg = [r for r in recs if r[0] == 0]
+        wg = [r for r in recs if r[0] == 1]
+        roof = None
         sig = [(r[1], r[2], r[4], r[5]) for r in gg]
         want = [(a, b, c, d) for a, b, c, d, _ in per_step] * args.steps
         if per_step and sig == want:
-            groups = {}
+            groups, by_dir = {}, {}
             for j, r in enumerate(gg):
                 ci, co, rows, kvol, P = per_step[j % len(per_step)]
                 name = ('spconv_gg<%d,%d,%d>' % (r[1], r[2], r[3]) if r[3] else
                         'spconv_gr<%d,%d>' % (r[1], r[2]))
-                g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, launches=0))
-                g['ms'] += r[7]
-                g['bytes'] += gg_bytes(P, ci, co, kvol, rows)
-                g['launches'] += 1
+                for key, table in ((name, groups), (per_dir[j % len(per_step)], by_dir)):
+                    g = table.setdefault(key, dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
+                    g['ms'] += r[7]
+                    g['bytes'] += gg_bytes(P, ci, co, kvol, rows)
+                    g['flops'] += 2.0 * P * ci * co
+                    g['launches'] += 1
+            if per_w and len(wg) == len(per_w) * args.steps:
+                for j, r in enumerate(wg):
+                    ci, co, kvol, P, n_in, n_out = per_w[j % len(per_w)]
+                    g = by_dir.setdefault('wgrad', dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
+                    g['ms'] += r[7]
+                    g['bytes'] += wgrad_bytes(P, ci, co, kvol)
+                    g['flops'] += 2.0 * P * ci * co
+                    g['launches'] += 1
+
+            def rates(g):
+                sec = g['ms'] * 1e-3
+                return dict(GBps=round(g['bytes'] / sec / 1e9, 1), frac_hbm=round(g['bytes'] / sec / 1e9 / HBM_PEAK_GBS, 4),
+                            TFLOPs=round(g['flops'] / sec / 1e12, 2),
+                            frac_of_fp32_mfma=round(g['flops'] / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                            us_per_step=round(g['ms'] / args.steps * 1e3, 1), launches_per_step=g['launches'] // args.steps)
             name, g = max(groups.items(), key=lambda kv: kv[1]['ms'])
-            achieved = g['bytes'] / (g['ms'] * 1e-3) / 1e9
-            tot_ms = sum(v['ms'] for v in groups.values())
-            tot_b = sum(v['bytes'] for v in groups.values())
-            roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name), kernel=name,
+            sec = g['ms'] * 1e-3
+            tf = g['flops'] / sec / 1e12
+            # What bounds the dominant kernel: SQ counters (profiles/r01_pmc_sq_spconv_gr.txt) put its
+            # matrix-pipe floor at 14 of 33 us with 63 % of wave cycles in issue stalls, and its HBM
+            # traffic at 0.27x the algorithmic bytes — matrix-pipe issue, not HBM.  `achieved` / `peak`
+            # are therefore FLOP rates; the per-pair byte convention of SURVEY §8(d), which
+            # BASELINE.json's metric quotes, is reported beside it as `algorithmic_hbm`.
+            roof = dict(bound='mfma', achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=pmc_traffic(name), kernel=name,
+                        bound_detail='mfma-issue (fp32 v_mfma_f32_16x16x4_f32; tiles 70 % full)',
                         avg_us=round(g['ms'] / g['launches'] * 1e3, 2), launches=g['launches'],
+                        flops_per_launch=int(g['flops'] / g['launches']),
                         bytes_per_launch=int(g['bytes'] / g['launches']),
-                        all_spconv_gg=dict(achieved=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
-                                           us_per_step=round(tot_ms / args.steps * 1e3, 1)))
+                        algorithmic_hbm=dict(achieved=round(g['bytes'] / sec / 1e9, 1), peak=HBM_PEAK_GBS,
+                                             unit='GB/s', frac=round(g['bytes'] / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                             convention='SURVEY 8(d): P*(Cin+Cout)*4 + 8P + K*Cin*Cout*4 + N_out*Cout*4'),
+                        all_spconv={k: rates(v) for k, v in by_dir.items()})
         # weak scaling: every rank steps through its own (2 labeled + 2 unlabeled) batch, so the
         # whole-job rate is world x steps / time (per-GPU-batch iterations per second, all ranks)
         out = dict(metric='train iters/sec', value=round(world * args.steps * 1.0 / dt, 3), unit='iters/sec',
@@ -270,8 +425,15 @@ def main():
                                global_batch=BATCH_PER_GPU * world,
                                parallelism='dp%d' % world),
                    roofline=roof)
+        # pseudo-label bookkeeping of the timed steps: proves the step exercises matching (NumPreds
+        # metrics of the SSL chain, mean over the timed steps)
+        lb = getattr(getattr(wl, 'runner', None), 'log_buffer', None) or {}
+        pl = {k: round(float(torch.stack([torch.as_tensor(v, dtype=torch.float32).cpu() for v in vals[-args.steps:]]).mean()), 3)
+              for k, vals in lb.items() if 'metrics.' in k}
+        if pl:
+            out['config']['pseudo_labels_per_step'] = pl
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(wl.frames)
+            out['cpu_baseline'] = cpu_baseline(wl.frames, gpu_stage_pieces(wl.frames, dev))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

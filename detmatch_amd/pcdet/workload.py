@@ -227,6 +227,15 @@ class DetMatchTrainWorkload(object):
         cfg.pop('type')
         torch.manual_seed(0)
         self.model = SSL(**cfg).to(device)
+        # With the reference's focal-loss prior (conv_cls.bias = -log(99), anchor_head_single.py:37) a
+        # RANDOM-INIT teacher scores every box 0.01 < the 0.1 pseudo-label threshold, so the
+        # matching chain would run on empty sets.  By default (DM_BENCH_CONFIDENT_INIT=0 restores the
+        # reference prior) the workload starts the 3D dense
+        # heads at prior 0.5 instead (still random weights): up to 100 teacher boxes per sample
+        # reach the filters / Hungarian matching — an upper bound on what a trained teacher emits.
+        if os.environ.get('DM_BENCH_CONFIDENT_INIT', '1') == '1':
+            with torch.no_grad():
+                self.model.student.detector_3d.model.dense_head.conv_cls.bias.zero_()
         # teacher starts as a copy of the student (SSL._load_from_state_dict fan-out, ssl.py:102-127)
         self.model.teacher.load_state_dict(self.model.student.state_dict())
         with_img = True

@@ -121,8 +121,12 @@ def _tables_for(indice_pairs, indice_pair_num, n_in, n_out, subm):
 
 # bench.py's roofline accounting: when a list is installed here, every gather-GEMM launch appends
 # (c_in, c_out, rows_out, kvol, P) with P = number of rulebook pairs (one read-back per launch —
-# measurement only, never enabled inside a timed region).
+# measurement only, never enabled inside a timed region).  LAUNCH_TRACE_DIR records, in step with
+# it, 'fwd' / 'dgrad' per gather-GEMM launch; LAUNCH_TRACE_W the weight-gradient launches as
+# (c_in, c_out, kvol, P, n_in, n_out).
 LAUNCH_TRACE = None
+LAUNCH_TRACE_DIR = None
+LAUNCH_TRACE_W = None
 
 
 def tile_order(nbr):
@@ -152,6 +156,8 @@ def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k)
     if LAUNCH_TRACE is not None:
         ci, co = (cout, cin) if transpose_w else (cin, cout)
         LAUNCH_TRACE.append((ci, co, int(n_rows_out), int(kvol), int((nbr >= 0).sum().item())))
+        if LAUNCH_TRACE_DIR is not None:
+            LAUNCH_TRACE_DIR.append('dgrad' if transpose_w else 'fwd')
     dev = feat.device
     out = torch.empty((n_rows_out, cin if transpose_w else cout), dtype=torch.float32, device=dev)
     ws = _lib.workspace(L.dm_spconv_workspace_bytes(kvol, cin, cout), dev, 'spconv')
@@ -197,6 +203,8 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
         _, nbr_in = _tables_for(indice_pairs, indice_pair_num, n_in, n_out, subm)
         input_bp = _gather_gemm(out_bp, filters, nbr_in, n_in, cin, cout, 1, 1 if subm else 0)
     filters_bp = torch.empty_like(filters)
+    if LAUNCH_TRACE_W is not None:
+        LAUNCH_TRACE_W.append((cin, cout, int(kvol), int(indice_pair_num.sum().item()), int(n_in), int(n_out)))
     ws = _lib.workspace(L.dm_spconv_wgrad_workspace_bytes(stride, kvol, cin, cout), dev, 'wgrad')
     rc = L.dm_spconv_wgrad(_lib.ptr(features), _lib.ptr(out_bp), _lib.ptr(indice_pairs),
                            _lib.ptr(indice_pair_num), stride, kvol, cin, cout,
