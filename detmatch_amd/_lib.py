@@ -66,6 +66,8 @@ SIGNATURES = {
     'dm_sgd_step_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp]),
     'dm_adamw_step_masked_f32': (ci, [vp, vp, vp, vp, sz, cd, cd, cd, cd, cd, ctypes.c_longlong, vp, vp, vp]),
     'dm_sgd_step_masked_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp, vp]),
+    'dm_anchor_assign_workspace_bytes': (sz, [ci, ci, ci]),
+    'dm_anchor_assign': (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
     'dm_dconv_pack': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, vp]),
     'dm_dconv_gemm_workspace_bytes': (sz, [c_int_p]),
     'dm_dconv_gemm': (ci, [vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), vp, sz, vp]),

@@ -110,6 +110,8 @@ class AxisAlignedTargetAssigner(object):
         shapes = {tuple(a.shape) for a in all_anchors}
         if len(shapes) != 1:         # per-class feature maps differ: fall back to the loop
             return self._assign_targets_loop(all_anchors, gt_boxes_with_classes)
+        if all_anchors[0].is_cuda and gt_boxes_with_classes.shape[-1] == 8:
+            return self._assign_targets_device(all_anchors, gt_boxes_with_classes)
         gt_classes = gt_boxes_with_classes[:, :, -1].int()
         gt_boxes = gt_boxes_with_classes[:, :, :-1]
         B, M = gt_boxes.shape[:2]
@@ -160,6 +162,40 @@ class AxisAlignedTargetAssigner(object):
             1, 2, 3, 4, 0, 5, *range(6, 6 + len(tail))).reshape(B, -1, *tail)
         return {'box_cls_labels': to_loc(labels, ()), 'box_reg_targets': to_loc(tgt, (code,)),
                 'reg_weights': to_loc(fg.to(dt), ())}
+
+    def _assign_targets_device(self, all_anchors, gt):
+        """dm_anchor_assign (csrc/anchor_assign.hip): two launches for the whole batch.  The BEV
+        rectangles come from the same tensor ops as the reference (anchors: once, cached)."""
+        from .. import _lib
+        dev = all_anchors[0].device
+        key = tuple(a.data_ptr() for a in all_anchors)
+        cache = getattr(self, '_dev_cache', None)
+        if cache is None or cache[0] != key:
+            anchors = torch.stack([a.reshape(-1, a.shape[-1])[:, 0:7] for a in all_anchors]).contiguous()
+            abev = U.boxes3d_lidar_to_aligned_bev_boxes(anchors.view(-1, 7)).view(len(all_anchors), -1, 4).contiguous()
+            cids = const([self.class_names.index(n) + 1 for n in self.anchor_class_names], dev, torch.int32)
+            matched = const([self.matched_thresholds[n] for n in self.anchor_class_names], dev, torch.float32)
+            unmatched = const([self.unmatched_thresholds[n] for n in self.anchor_class_names], dev, torch.float32)
+            fmap = all_anchors[0].shape[:3]
+            cache = self._dev_cache = (key, anchors, abev, cids, matched, unmatched,
+                                       anchors.shape[1] // (fmap[0] * fmap[1] * fmap[2]))
+        _, anchors, abev, cids, matched, unmatched, per_loc = cache
+        gt = gt.detach().float().contiguous()
+        B, M = gt.shape[:2]
+        C, A = anchors.shape[:2]
+        gbev = U.boxes3d_lidar_to_aligned_bev_boxes(gt.view(-1, 8)[:, 0:7]).contiguous() if M else gt.new_zeros((0, 4))
+        labels = torch.empty((B, A * C), dtype=torch.int32, device=dev)
+        targets = torch.empty((B, A * C, self.box_coder.code_size), dtype=torch.float32, device=dev)
+        weights = torch.empty((B, A * C), dtype=torch.float32, device=dev)
+        assert self.box_coder.code_size == 7
+        L = _lib.lib()
+        ws = _lib.workspace(L.dm_anchor_assign_workspace_bytes(B, M, C), dev, 'anchor_assign')
+        _lib.check(L.dm_anchor_assign(_lib.ptr(anchors), _lib.ptr(abev), _lib.ptr(gt), _lib.ptr(gbev),
+                                      _lib.ptr(cids), _lib.ptr(matched), _lib.ptr(unmatched), B, M, C, A,
+                                      per_loc, len(self.class_names), _lib.ptr(labels), _lib.ptr(targets),
+                                      _lib.ptr(weights), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                   'dm_anchor_assign')
+        return {'box_cls_labels': labels, 'box_reg_targets': targets, 'reg_weights': weights}
 
     def _assign_targets_loop(self, all_anchors, gt_boxes_with_classes):
         gt_classes = gt_boxes_with_classes[:, :, -1].int()

@@ -324,6 +324,20 @@ int dm_sgd_step_masked_f32(float *params, const float *grads, float *momentum_bu
                            double lr, double momentum, double dampening, double weight_decay,
                            int first_step, const float *grad_scale_dev,
                            const unsigned char *block_live, dm_stream_t stream);
+/* C. Anchor target assignment.  Replaces AxisAlignedTargetAssigner.assign_targets(_single)
+ * (pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:36-209) for all
+ * samples x anchor classes of a batch (POS_FRACTION < 0, MATCH_HEIGHT False, NORM_BY_NUM_EXAMPLES
+ * False).  anchors (C, A, 7) class-major, anchors_bev / gt_bev their axis-aligned BEV rectangles
+ * [x1,y1,x2,y2] (box_utils.py:272-283, computed by the caller), gt_boxes (B, M, 8) with the class id
+ * in the last column, class_ids / matched / unmatched (C).  Outputs in the reference's layout:
+ * labels (B, L*C*R) int32 (-1 = ignore), reg_targets (B, L*C*R, 7), reg_weights (B, L*C*R), index
+ * (l*C + c)*R + r with A = L*R.  Labels are bit-exact with the reference rules. */
+size_t dm_anchor_assign_workspace_bytes(int B, int M, int C);
+int dm_anchor_assign(const float *anchors, const float *anchors_bev, const float *gt_boxes,
+                     const float *gt_bev, const int *class_ids, const float *matched,
+                     const float *unmatched, int B, int M, int C, int A, int R, int num_class,
+                     int *labels, float *reg_targets, float *reg_weights, void *workspace,
+                     size_t workspace_bytes, dm_stream_t stream);
 /* ------------------------------------------------------------------------ */
 /* C / G. Dense 2-D convolutions (BEV backbone, anchor-head convs, ResNet-50 + FPN + RPN)      */
 /* ------------------------------------------------------------------------ */
