@@ -311,9 +311,16 @@ def _pcdet_3d_train_cfg():
                 debug=False)
 
 
-def detmatch_kitti_model(ssl_cfg=None, pretrained=None):
-    """model = dict(type='SSL', ...) of configs/detmatch/001/detmatch/split_0.py:34-531."""
-    det3d = pvrcnn_kitti_model()
+WAYMO_POINT_CLOUD_RANGE = [-75.2, -75.2, -2, 75.2, 75.2, 4]
+WAYMO_VOXEL_SIZE = [0.1, 0.1, 0.15]
+
+
+def detmatch_kitti_model(ssl_cfg=None, pretrained=None, det3d_kwargs=None):
+    """model = dict(type='SSL', ...) of configs/detmatch/001/detmatch/split_0.py:34-531.
+    `det3d_kwargs` re-parameterises the 3D detector's geometry (BASELINE.json configs[4]: the
+    Waymo-SHAPED synthetic run uses WAYMO_POINT_CLOUD_RANGE / WAYMO_VOXEL_SIZE / max_voxels 150000 —
+    upstream OpenPCDet's Waymo PV-RCNN convention; the reference ships no such config)."""
+    det3d = pvrcnn_kitti_model(**(det3d_kwargs or {}))
     test = dict(detector_2d=frcnn_test_cfg(), detector_3d=dict())
     import copy
     return dict(

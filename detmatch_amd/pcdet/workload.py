@@ -210,7 +210,7 @@ class DetMatchTrainWorkload(object):
       (AdamW 3D / SGD 2D), linear LR warm-up — driven by IterBasedSSLRunner exactly as
       mmdet3d/apis/ssl_train.py would.  `ssl_cfg='confthr_pvrcnn'` / `'confthr_frcnn'` select the 3D-only / 2D-only recipes."""
 
-    def __init__(self, batch_size, device, seed=0, ssl_cfg=None):
+    def __init__(self, batch_size, device, seed=0, ssl_cfg=None, profile='kitti'):
         from .. import configs
         from ..mm3d import register_all
         from ..mm3d import runner as R
@@ -223,7 +223,12 @@ class DetMatchTrainWorkload(object):
         chain = {'confthr_pvrcnn': configs.confthr_pvrcnn_ssl_cfg,
                  'confthr_frcnn': lambda: configs.confthr_frcnn_ssl_cfg(with_vis=False),
                  'detmatch': lambda: configs.detmatch_ssl_cfg(with_vis=False)}[self.recipe]()
-        cfg = configs.detmatch_kitti_model(ssl_cfg=chain)
+        self.profile = profile
+        det3d_kwargs = None
+        if profile == 'waymo':
+            det3d_kwargs = dict(point_cloud_range=configs.WAYMO_POINT_CLOUD_RANGE,
+                                voxel_size=configs.WAYMO_VOXEL_SIZE, max_voxels=(150000, 150000))
+        cfg = configs.detmatch_kitti_model(ssl_cfg=chain, det3d_kwargs=det3d_kwargs)
         cfg.pop('type')
         torch.manual_seed(0)
         self.model = SSL(**cfg).to(device)
@@ -240,7 +245,8 @@ class DetMatchTrainWorkload(object):
         self.model.teacher.load_state_dict(self.model.student.state_dict())
         with_img = True
         data = synth.ssl_batch(batch_size, seed, device, with_img,
-                               device_pipeline=os.environ.get('DM_DEVICE_PIPELINE', '0') == '1')
+                               device_pipeline=os.environ.get('DM_DEVICE_PIPELINE', '0') == '1' and profile == 'kitti',
+                               profile=profile)
         lab = dict(stu=data['lab_stu'], tea=data['lab_tea'], img_metas=data['img_metas'])
         unlab = dict(stu=data['unlab_stu'], tea=data['unlab_tea'], img_metas=data['img_metas'])
         self.lab_iter = iter(_RepeatLoader(lab))

@@ -170,12 +170,25 @@ KITTI_IMG_SHAPE = (384, 1280, 3)       # after Resize (keep_ratio) + Pad(32) in 
 IMG_MEAN_BGR = np.array([103.530, 116.280, 123.675], dtype=np.float32)   # caffe-style, std 1
 
 
+WAYMO_ORI_SHAPE = (1280, 1920, 3)
+# Waymo-shaped camera: the KITTI-like projection with its intrinsics scaled to a 1280 x 1920 sensor
+_SCALE_W = np.diag([1920.0 / 1242.0, 1280.0 / 375.0, 1.0, 1.0]).astype(np.float32)
+PROFILES = {
+    'kitti': dict(pc_range=KITTI_RANGE, full360=False, ori_shape=KITTI_ORI_SHAPE, img_shape=KITTI_IMG_SHAPE,
+                  lidar2img=KITTI_LIDAR2IMG),
+    # BASELINE.json configs[4]: Waymo-SHAPED synthetic (no reference config exists): full
+    # 360 deg sweep of ~200 k points, range +-75.2 m x [-2, 4), 1280 x 1920 image
+    'waymo': dict(pc_range=WAYMO_RANGE, full360=True, ori_shape=WAYMO_ORI_SHAPE, img_shape=WAYMO_ORI_SHAPE,
+                  lidar2img=(_SCALE_W @ KITTI_LIDAR2IMG).astype(np.float32)),
+}
+
+
 def _in_range(pts, pc_range):
     return ((pts[:, 0] > pc_range[0]) & (pts[:, 1] > pc_range[1]) & (pts[:, 2] > pc_range[2]) &
             (pts[:, 0] < pc_range[3]) & (pts[:, 1] < pc_range[4]) & (pts[:, 2] < pc_range[5]))
 
 
-def ssl_sample(seed, labeled, device='cpu', with_img=True):
+def ssl_sample(seed, labeled, device='cpu', with_img=True, profile='kitti'):
     """One TS_SSL_Dataset item (teacher_student_ssl_dataset.py:26-33): the shared pipeline (Resize,
     RandomFlip3D with sync_2d) runs once, then the student pipeline (GlobalRotScaleTrans,
     range filters, shuffle) and the teacher pipeline (range filter, shuffle) on copies.
@@ -186,8 +199,11 @@ def ssl_sample(seed, labeled, device='cpu', with_img=True):
     import torch
     from .mm3d.bbox_utils import bbox_2d_transform, bbox_3d_to_bbox_2d
     from .mm3d.box3d import LiDARInstance3DBoxes
+    prof = PROFILES[profile]
+    KITTI_RANGE, KITTI_ORI_SHAPE, KITTI_IMG_SHAPE, KITTI_LIDAR2IMG = (
+        prof['pc_range'], prof['ori_shape'], prof['img_shape'], prof['lidar2img'])   # shadow the module constants
     rng = np.random.default_rng(77_000 + seed)
-    frame = lidar_frame(seed)
+    frame = lidar_frame(seed, full360=prof['full360'])
     pts = frame['points'].copy()
     boxes_np, labels_np = frame_to_mm3d_gt(frame)
     boxes = LiDARInstance3DBoxes(torch.from_numpy(boxes_np))
@@ -281,14 +297,15 @@ def _device_points(samples, seeds, device, generator=None):
         stu['points'], tea['points'] = outs[2 * i], outs[2 * i + 1]
 
 
-def ssl_batch(batch_size, seed=0, device='cpu', with_img=True, device_pipeline=False):
+def ssl_batch(batch_size, seed=0, device='cpu', with_img=True, device_pipeline=False, profile='kitti'):
     """The data_batch IterBasedSSLRunner.train assembles (iter_based_ssl_runner.py:21-27): `batch_size`
     labeled + `batch_size` unlabeled samples, keys lab_stu / lab_tea / unlab_stu / unlab_tea.
     device_pipeline=True: the point clouds are augmented on the GPU (one dm_points_augment call for all
     4 * batch_size views) instead of in numpy."""
-    lab = [ssl_sample(seed + i, True, device, with_img) for i in range(batch_size)]
-    unlab = [ssl_sample(seed + 1000 + i, False, device, with_img) for i in range(batch_size)]
+    lab = [ssl_sample(seed + i, True, device, with_img, profile) for i in range(batch_size)]
+    unlab = [ssl_sample(seed + 1000 + i, False, device, with_img, profile) for i in range(batch_size)]
     if device_pipeline:
+        assert profile == 'kitti'
         _device_points(lab + unlab, [seed + i for i in range(batch_size)] +
                        [seed + 1000 + i for i in range(batch_size)], device)
     return dict(lab_stu=_collate([s for s, _ in lab]), lab_tea=_collate([t for _, t in lab]),
