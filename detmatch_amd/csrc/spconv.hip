@@ -545,6 +545,77 @@ __global__ __launch_bounds__(64) void spconv_wgrad_partial(const float *__restri
   }
 }
 
+// Round 2: one wave per (kernel offset, chunk of pairs) covers ALL channels of both operands.
+// A lane (j = lane & 15, pair slot kq = lane >> 4) fetches CIN/16 CONSECUTIVE input channels of its
+// pair's X row and COUT/16 consecutive channels of its dY row with one vector load each (a wave
+// instruction = 4 whole rows, 16 lanes x 16 B each for 64 channels) — every gathered row leaves
+// memory exactly once per pair, where the round-1 kernel re-read dY once per 16-channel block of
+// cin and X in 64-byte pieces (84 MB per launch).  Component q of the X vector
+// and component r of the dY vector feed MFMA (q, r): its 16x16 output tile holds channel pairs
+// (cin = VA*i + q, cout = VB*j + r), i.e. the channel order inside an MFMA is a permutation that
+// only the final store has to know.  Loads are unconditional (index clamped, X masked): a
+// conditional load makes hipcc branch and wait per element.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(64) void spconv_wgrad_rows(const float *__restrict__ feat,
+                                                        const float *__restrict__ ograd,
+                                                        const int32_t *__restrict__ pairs,
+                                                        const int32_t *__restrict__ indice_num,
+                                                        int pair_stride, int chunk,
+                                                        float *__restrict__ slab) {
+  constexpr int VA = CIN / 16, VB = COUT / 16;
+  typedef float vecA __attribute__((ext_vector_type(VA)));
+  typedef float vecB __attribute__((ext_vector_type(VB)));
+  const int k = blockIdx.y, ch = blockIdx.x, kvol = gridDim.y;
+  const int lane = threadIdx.x, j = lane & 15, kq = lane >> 4;
+  const int npairs = indice_num[k];
+  const int s_begin = ch * chunk;
+  const int s_end = min(s_begin + chunk, npairs);
+  const int32_t *pin = pairs + ((size_t)k * 2 + 0) * pair_stride;
+  const int32_t *pout = pairs + ((size_t)k * 2 + 1) * pair_stride;
+  f32x4 acc[VA][VB];
+#pragma unroll
+  for (int q = 0; q < VA; ++q)
+#pragma unroll
+    for (int r = 0; r < VB; ++r) acc[q][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;                      // groups of 4 pairs in flight
+  for (int s0 = s_begin; s0 < s_end; s0 += 4 * U) {
+    vecA a[U];
+    vecB b[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + 4 * u + kq;
+      ok[u] = s < s_end;
+      const int sc = ok[u] ? s : s_begin;
+      const int ii = pin[sc], oo = pout[sc];
+      ok[u] = ok[u] & (ii >= 0) & (oo >= 0);
+      a[u] = *(const vecA *)(feat + (size_t)(ii >= 0 ? ii : 0) * CIN + VA * j);
+      b[u] = *(const vecB *)(ograd + (size_t)(oo >= 0 ? oo : 0) * COUT + VB * j);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < VA; ++q) {
+        const float av = ok[u] ? a[u][q] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < VB; ++r)
+          acc[q][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][r], acc[q][r], 0, 0, 0);
+      }
+  }
+  // D of MFMA (q, r): row i = 4*kq + reg -> cin channel VA*i + q; col j -> cout channels VB*j + r
+  float *dst = slab + ((size_t)ch * kvol + k) * (size_t)CIN * COUT;
+#pragma unroll
+  for (int q = 0; q < VA; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int c = VA * (4 * kq + reg) + q;
+      vecB v;
+#pragma unroll
+      for (int r = 0; r < VB; ++r) v[r] = acc[q][r][reg];
+      *(vecB *)(dst + (size_t)c * COUT + VB * j) = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void spconv_wgrad_reduce(const float *slab, int nchunks,
                                                            size_t per_chunk, float *filt_grad) {
   size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -713,7 +784,17 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
   float *slab = (float *)workspace;
   dim3 grid(nchunks, dm_ceil_div(cin, 16), kvol);
   int pi = dm_prof_begin(st, DM_PROF_SPCONV_WGRAD, cin, cout, 1, pair_stride, kvol, indice_pairs);
-  switch (cout) {
+#define DM_WGRAD_ROWS(CI, CO)                                                                    \
+  spconv_wgrad_rows<CI, CO><<<dim3(nchunks, kvol), 64, 0, st>>>(feat, out_grad, indice_pairs, \
+                                                                indice_num, pair_stride, chunk, slab)
+  const int key = cin * 1000 + cout;
+  if (key == 16016) DM_WGRAD_ROWS(16, 16);
+  else if (key == 16032) DM_WGRAD_ROWS(16, 32);
+  else if (key == 32032) DM_WGRAD_ROWS(32, 32);
+  else if (key == 32064) DM_WGRAD_ROWS(32, 64);
+  else if (key == 64064) DM_WGRAD_ROWS(64, 64);
+  else if (key == 64128) DM_WGRAD_ROWS(64, 128);
+  else switch (cout) {      // other channel pairs (the 4-channel input layer): one wave per cin block
     case 16:
       spconv_wgrad_partial<16><<<grid, 64, 0, st>>>(feat, out_grad, indice_pairs, indice_num,
                                                     pair_stride, cin, chunk, slab);
@@ -731,6 +812,7 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
                                                      pair_stride, cin, chunk, slab);
       break;
   }
+#undef DM_WGRAD_ROWS
   DM_CHECK_LAUNCH();
   spconv_wgrad_reduce<<<dm_ceil_div((long long)per_chunk, 256), 256, 0, st>>>(slab, nchunks,
                                                                               per_chunk, filt_grad);

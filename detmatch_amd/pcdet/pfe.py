@@ -122,10 +122,17 @@ class VoxelSetAbstraction(nn.Module):
         pts = batch_dict['points']
         if not pts.is_cuda:
             return
+        # a small POOL of side streams, used round-robin: the three passes of a DetMatch iteration
+        # (labeled student, teacher, unlabeled student) issue their FPS back to back at the step
+        # boundary; on ONE side stream the launches would run one after the other (3 x 7 ms with two
+        # CUs busy each), on three they run side by side
         key = pts.device.index
-        side = VoxelSetAbstraction._side_streams.get(key)
-        if side is None:
-            side = VoxelSetAbstraction._side_streams[key] = torch.cuda.Stream(device=pts.device)
+        pool = VoxelSetAbstraction._side_streams.get(key)
+        if pool is None:
+            pool = VoxelSetAbstraction._side_streams[key] = dict(
+                streams=[torch.cuda.Stream(device=pts.device) for _ in range(3)], next=0)
+        side = pool['streams'][pool['next'] % len(pool['streams'])]
+        pool['next'] += 1
         main = torch.cuda.current_stream(pts.device)
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
