@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64) void spconv_wgrad_partial(const float *__restri
 // only the final store has to know.  Loads are unconditional (index clamped, X masked): a
 // conditional load makes hipcc branch and wait per element.
 template <int CIN, int COUT>
-__global__ __launch_bounds__(64) void spconv_wgrad_rows(const float *__restrict__ feat,
+__global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict__ feat,
                                                         const float *__restrict__ ograd,
                                                         const int32_t *__restrict__ pairs,
                                                         const int32_t *__restrict__ indice_num,
@@ -565,11 +565,18 @@ __global__ __launch_bounds__(64) void spconv_wgrad_rows(const float *__restrict_
   constexpr int VA = CIN / 16, VB = COUT / 16;
   typedef float vecA __attribute__((ext_vector_type(VA)));
   typedef float vecB __attribute__((ext_vector_type(VB)));
+  // a workgroup = 4 waves = one chunk of pairs, a quarter each; their partial tiles are summed
+  // through LDS in wave order (deterministic) and written once: 4x less slab traffic per pair.
+  // Chunks beyond this offset's pair count exit at once and are never read by the reduce kernel.
+  __shared__ float tile[CIN * COUT];
   const int k = blockIdx.y, ch = blockIdx.x, kvol = gridDim.y;
-  const int lane = threadIdx.x, j = lane & 15, kq = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
   const int npairs = indice_num[k];
-  const int s_begin = ch * chunk;
-  const int s_end = min(s_begin + chunk, npairs);
+  if (ch * chunk >= npairs) return;
+  const int quarter = chunk / 4;
+  const int s_begin = ch * chunk + wave * quarter;
+  const int s_end = min(s_begin + quarter, npairs);
   const int32_t *pin = pairs + ((size_t)k * 2 + 0) * pair_stride;
   const int32_t *pout = pairs + ((size_t)k * 2 + 1) * pair_stride;
   f32x4 acc[VA][VB];
@@ -578,42 +585,71 @@ __global__ __launch_bounds__(64) void spconv_wgrad_rows(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < VB; ++r) acc[q][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr int U = 4;                      // groups of 4 pairs in flight
-  for (int s0 = s_begin; s0 < s_end; s0 += 4 * U) {
-    vecA a[U];
-    vecB b[U];
-    bool ok[U];
+  // software pipeline: the pair indices AND rows of the next 16 pairs are requested before the
+  // MFMAs of the current 16 are issued
+  vecA a[2][U];
+  vecB b[2][U];
+  bool ok[2][U];
+  auto fetch = [&](int buf, int s0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int s = s0 + 4 * u + kq;
-      ok[u] = s < s_end;
-      const int sc = ok[u] ? s : s_begin;
+      const bool in = s < s_end;
+      const int sc = in ? s : s_begin;
       const int ii = pin[sc], oo = pout[sc];
-      ok[u] = ok[u] & (ii >= 0) & (oo >= 0);
-      a[u] = *(const vecA *)(feat + (size_t)(ii >= 0 ? ii : 0) * CIN + VA * j);
-      b[u] = *(const vecB *)(ograd + (size_t)(oo >= 0 ? oo : 0) * COUT + VB * j);
+      ok[buf][u] = in & (ii >= 0) & (oo >= 0);
+      a[buf][u] = *(const vecA *)(feat + (size_t)(ii >= 0 ? ii : 0) * CIN + VA * j);
+      b[buf][u] = *(const vecB *)(ograd + (size_t)(oo >= 0 ? oo : 0) * COUT + VB * j);
     }
+  };
+  auto mma = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int q = 0; q < VA; ++q) {
-        const float av = ok[u] ? a[u][q] : 0.0f;
+        const float av = ok[buf][u] ? a[buf][u][q] : 0.0f;
 #pragma unroll
         for (int r = 0; r < VB; ++r)
-          acc[q][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][r], acc[q][r], 0, 0, 0);
+          acc[q][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[buf][u][r], acc[q][r], 0, 0, 0);
       }
+  };
+  if (s_begin < s_end) {
+    fetch(0, s_begin);
+    int s0 = s_begin;
+    for (; s0 + 8 * U < s_end; s0 += 8 * U) {      // two 16-pair steps per trip: buffers alternate
+      fetch(1, s0 + 4 * U);
+      mma(0);
+      fetch(0, s0 + 8 * U);
+      mma(1);
+    }
+    if (s0 + 4 * U < s_end) {
+      fetch(1, s0 + 4 * U);
+      mma(0);
+      mma(1);
+    } else {
+      mma(0);
+    }
   }
   // D of MFMA (q, r): row i = 4*kq + reg -> cin channel VA*i + q; col j -> cout channels VB*j + r
-  float *dst = slab + ((size_t)ch * kvol + k) * (size_t)CIN * COUT;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int q = 0; q < VA; ++q)
+      for (int q = 0; q < VA; ++q)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int c = VA * (4 * kq + reg) + q;
-      vecB v;
+        for (int reg = 0; reg < 4; ++reg) {
+          const int c = VA * (4 * kq + reg) + q;
+          vecB *p = (vecB *)(tile + c * COUT + VB * j);
+          vecB v = w == 0 ? vecB(0.0f) : *p;
 #pragma unroll
-      for (int r = 0; r < VB; ++r) v[r] = acc[q][r][reg];
-      *(vecB *)(dst + (size_t)c * COUT + VB * j) = v;
+          for (int r = 0; r < VB; ++r) v[r] += acc[q][r][reg];
+          *p = v;
+        }
     }
+    __syncthreads();
+  }
+  float *dst = slab + ((size_t)ch * kvol + k) * (size_t)CIN * COUT;
+  for (int e = threadIdx.x * 4; e < CIN * COUT; e += 1024)
+    *(float4 *)(dst + e) = *(const float4 *)(tile + e);
 }
 
 __global__ __launch_bounds__(256) void spconv_wgrad_reduce(const float *slab, int nchunks,
@@ -625,10 +661,24 @@ __global__ __launch_bounds__(256) void spconv_wgrad_reduce(const float *slab, in
   filt_grad[e] = s;
 }
 
+// the same over the chunks that exist for each offset (spconv_wgrad_rows writes no others)
+__global__ __launch_bounds__(256) void spconv_wgrad_reduce_active(const float *slab, int chunk,
+                                                                  const int32_t *__restrict__ indice_num,
+                                                                  size_t per_offset, size_t per_chunk,
+                                                                  float *filt_grad) {
+  size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= per_chunk) return;
+  const int k = (int)(e / per_offset);
+  const int n = (indice_num[k] + chunk - 1) / chunk;
+  float s = 0.f;
+  for (int c = 0; c < n; ++c) s += slab[(size_t)c * per_chunk + e];
+  filt_grad[e] = s;
+}
+
 int wgrad_chunks(int n_in, int *chunk) {
-  // ~16 chunks per offset at KITTI sizes; multiples of 4 pairs
+  // a chunk = one 4-wave workgroup (a quarter each): 512 pairs up to 64 k rows; multiples of 64 pairs
   int c = 512;
-  while ((long long)c * 64 < n_in) c *= 2;
+  while ((long long)c * 128 < n_in) c *= 2;
   *chunk = c;
   return dm_ceil_div(n_in > 0 ? n_in : 1, c);
 }
@@ -784,9 +834,10 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
   float *slab = (float *)workspace;
   dim3 grid(nchunks, dm_ceil_div(cin, 16), kvol);
   int pi = dm_prof_begin(st, DM_PROF_SPCONV_WGRAD, cin, cout, 1, pair_stride, kvol, indice_pairs);
-#define DM_WGRAD_ROWS(CI, CO)                                                                    \
-  spconv_wgrad_rows<CI, CO><<<dim3(nchunks, kvol), 64, 0, st>>>(feat, out_grad, indice_pairs, \
-                                                                indice_num, pair_stride, chunk, slab)
+  bool rows_kernel = true;
+#define DM_WGRAD_ROWS(CI, CO)                                                                     \
+  spconv_wgrad_rows<CI, CO><<<dim3(nchunks, kvol), 256, 0, st>>>(feat, out_grad, indice_pairs, \
+                                                                 indice_num, pair_stride, chunk, slab)
   const int key = cin * 1000 + cout;
   if (key == 16016) DM_WGRAD_ROWS(16, 16);
   else if (key == 16032) DM_WGRAD_ROWS(16, 32);
@@ -794,7 +845,7 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
   else if (key == 32064) DM_WGRAD_ROWS(32, 64);
   else if (key == 64064) DM_WGRAD_ROWS(64, 64);
   else if (key == 64128) DM_WGRAD_ROWS(64, 128);
-  else switch (cout) {      // other channel pairs (the 4-channel input layer): one wave per cin block
+  else { rows_kernel = false; switch (cout) {      // other channel pairs (the 4-channel input layer): one wave per cin block
     case 16:
       spconv_wgrad_partial<16><<<grid, 64, 0, st>>>(feat, out_grad, indice_pairs, indice_num,
                                                     pair_stride, cin, chunk, slab);
@@ -811,11 +862,15 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
       spconv_wgrad_partial<128><<<grid, 64, 0, st>>>(feat, out_grad, indice_pairs, indice_num,
                                                      pair_stride, cin, chunk, slab);
       break;
-  }
+  } }
 #undef DM_WGRAD_ROWS
   DM_CHECK_LAUNCH();
-  spconv_wgrad_reduce<<<dm_ceil_div((long long)per_chunk, 256), 256, 0, st>>>(slab, nchunks,
-                                                                              per_chunk, filt_grad);
+  if (rows_kernel)
+    spconv_wgrad_reduce_active<<<dm_ceil_div((long long)per_chunk, 256), 256, 0, st>>>(
+        slab, chunk, indice_num, (size_t)cin * cout, per_chunk, filt_grad);
+  else
+    spconv_wgrad_reduce<<<dm_ceil_div((long long)per_chunk, 256), 256, 0, st>>>(slab, nchunks,
+                                                                                per_chunk, filt_grad);
   dm_prof_end(pi, st);
   DM_CHECK_LAUNCH();
   return DM_OK;
