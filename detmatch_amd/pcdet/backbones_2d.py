@@ -11,7 +11,8 @@ same outputs (`spatial_features_2d`, `spatial_features_<s>x`).  The computation 
   * the reference's `ZeroPad2d(1)` + `Conv2d(padding=0)` pair is one convolution with padding 1 (the
     kernel zero-fills out-of-image taps);
   * BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU run as the fused row kernels of csrc/bn_relu.hip over
-    the (B*H*W, C) row view of the NHWC tensor.
+    the (B*H*W, C) row view of the NHWC tensor in training mode; in evaluation mode (the teacher) they
+    are folded into the convolution (weight scale, bias and ReLU of the GEMM epilogue).
 """
 import numpy as np
 import torch
@@ -43,12 +44,20 @@ class _Stage(object):
         self.conv, self.bn, self.padding = conv, bn, padding
 
     def __call__(self, x):
-        conv = self.conv
+        conv, bn = self.conv, self.bn
         if isinstance(conv, nn.ConvTranspose2d):
-            y = dense_conv.conv_transpose2d(x, conv.weight, conv.stride)
-        else:
-            y = dense_conv.conv2d(x, conv.weight, conv.bias, conv.stride, self.padding)
-        return _bn_relu_nhwc(y, self.bn)
+            return _bn_relu_nhwc(dense_conv.conv_transpose2d(x, conv.weight, conv.stride), bn)
+        if not bn.training and bn.track_running_stats and conv.bias is None and x.is_cuda:
+            # evaluation mode (the EMA teacher): BatchNorm is the constant per-channel map
+            # y*s + b with s = gamma / sqrt(var + eps), b = beta - mean*s — folded into the weight
+            # packing (w_scale), the GEMM's bias and its ReLU epilogue: no BatchNorm kernel, no extra
+            # pass over the feature map
+            with torch.no_grad():
+                s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                b = bn.bias - bn.running_mean * s
+            return dense_conv.conv2d(x, conv.weight, b, conv.stride, self.padding, relu=True, w_scale=s)
+        y = dense_conv.conv2d(x, conv.weight, conv.bias, conv.stride, self.padding)
+        return _bn_relu_nhwc(y, bn)
 
 
 class BaseBEVBackbone(nn.Module):

@@ -101,3 +101,29 @@ def test_tensor_utils_match_reference_gpu(dev):
     close(U.boxes3d_nearest_bev_iou(t('bx_in'), t('bx_in2')), G['bx_nearest_iou'], rtol=1e-5, atol=1e-6)
     d = lambda k: torch.from_numpy(D[k]).to(dev)
     close(bilinear_interpolate_torch(d('bi_im'), d('bi_x'), d('bi_y')), D['bi_out'], atol=1e-5)
+
+
+def test_bev_backbone_eval_mode_fold_matches_reference_gpu(dev):
+    """Evaluation mode (the EMA teacher): BatchNorm folded into the convolution (weight scale + bias
+    + ReLU epilogue) must equal the unfolded computation with the reference's running statistics."""
+    from detmatch_amd.pcdet.backbones_2d import BaseBEVBackbone
+    import torch.nn.functional as F
+    bb = BaseBEVBackbone(ConfigDict(LAYER_NUMS=[2, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[8, 16],
+                                    UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[16, 16]), input_channels=12)
+    bb.load_state_dict(_state('bev_after'), strict=True)      # trained running statistics
+    bb = bb.to(dev).eval()
+    x = torch.from_numpy(D['bev_x']).to(dev)
+    with torch.no_grad():
+        got = bb(dict(spatial_features=x))['spatial_features_2d']
+        # reference formulation, torch ops in float64
+        bb64 = BaseBEVBackbone(ConfigDict(LAYER_NUMS=[2, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[8, 16],
+                                          UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[16, 16]), input_channels=12)
+        bb64.load_state_dict(_state('bev_after'), strict=True)
+        bb64 = bb64.double().eval()
+        h, ups = torch.from_numpy(D['bev_x']).double(), []
+        for blk, de in zip(bb64.blocks, bb64.deblocks):
+            for m in blk:
+                h = m(h)
+            ups.append(de(h))
+        want = torch.cat(ups, dim=1)
+    close(got, want.numpy(), rtol=1e-4, atol=2e-5)

@@ -99,3 +99,14 @@ def test_empty_targets(dev):
     one = [boxes[0], empty_boxes[1]]
     onel = [labels[0], empty_labels[1]]
     assert torch.isfinite(det.forward_train(pts, metas, one, onel)['loss'])
+
+
+def test_pvrcnn_supervised_loss_decreases(dev):
+    """End-to-end sanity of every gradient path (dense conv dgrad / wgrad, sparse conv, BN rows, RoI
+    head, fused AdamW): 25 supervised PV-RCNN steps on one fixed synthetic batch reduce the loss."""
+    from detmatch_amd import synth
+    from detmatch_amd.pcdet.workload import PVRCNNTrainWorkload
+    wl = PVRCNNTrainWorkload([synth.lidar_frame(s) for s in (0, 1)], dev)
+    losses = [float(wl.step()) for _ in range(25)]
+    assert all(np.isfinite(losses)), losses
+    assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:3]), losses
