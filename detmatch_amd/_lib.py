@@ -68,6 +68,12 @@ SIGNATURES = {
     'dm_sgd_step_masked_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp, vp]),
     'dm_anchor_assign_workspace_bytes': (sz, [ci, ci, ci]),
     'dm_anchor_assign': (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
+    'dm_roi_targets_workspace_bytes': (sz, [ci, ci]),
+    'dm_roi_targets': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'dm_rcnn_loss_forward': (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, c_f32_p, c_f32_p, cf, ci, vp, vp, vp, vp, vp]),
+    'dm_rcnn_loss_backward': (ci, [vp, vp, vp, vp, ci, vp, vp, vp]),
+    'dm_point_targets': (ci, [vp, ci, vp, ci, ci, ci, ci, c_f32_p, ci, vp, vp]),
+    'dm_point_focal_loss': (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp]),
     'dm_dconv_pack': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, vp]),
     'dm_dconv_gemm_workspace_bytes': (sz, [c_int_p]),
     'dm_dconv_gemm': (ci, [vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), vp, sz, vp]),

@@ -529,6 +529,29 @@ class AnchorHeadSingle(nn.Module):
 
 
 # ------------------------------------------------------------------- point head
+class _FusedPointFocalLoss(torch.autograd.Function):
+    """dm_point_focal_loss (csrc/roi_targets.hip): the key-point segmentation loss and its gradient in
+    one launch -> tensor [loss, #positive]."""
+
+    @staticmethod
+    def forward(ctx, preds, labels, alpha, weight):
+        from .. import _lib
+        _lib.require_device(preds, labels)
+        n, c = int(preds.shape[0]), int(preds.shape[1])
+        out = torch.empty(2, dtype=torch.float32, device=preds.device)
+        grad = torch.empty_like(preds)
+        _lib.check(_lib.lib().dm_point_focal_loss(_lib.ptr(preds), _lib.ptr(labels), n, c, float(alpha),
+                                                  float(weight), _lib.ptr(out), _lib.ptr(grad),
+                                                  _lib.stream()), 'dm_point_focal_loss')
+        ctx.save_for_backward(grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        return grad * g[0], None, None, None
+
+
 class PointHeadSimple(nn.Module):
     """point_head_template.py:9-153 + point_head_simple.py:7-91 (keypoint segmentation)."""
 
@@ -551,12 +574,14 @@ class PointHeadSimple(nn.Module):
         layers.append(nn.Linear(c_in, output_channels, bias=True))
         return nn.Sequential(*layers)
 
-    def assign_targets(self, input_dict):
+    def assign_targets(self, input_dict, fused=True):
         """point_head_simple.py:20-48 + assign_stack_targets (set_ignore_flag branch),
         batched: every sample has the same number of keypoints."""
         point_coords = input_dict['point_coords']
         gt_boxes = input_dict['gt_boxes']
         batch_size = gt_boxes.shape[0]
+        if fused and point_coords.is_cuda and gt_boxes.shape[1] > 0:
+            return {'point_cls_labels': self._assign_targets_device(point_coords, gt_boxes)}
         extend_gt_boxes = U.enlarge_box3d(gt_boxes.view(-1, gt_boxes.shape[-1]),
                                           extra_width=self.model_cfg.TARGET_CONFIG.GT_EXTRA_WIDTH
                                           ).view(batch_size, -1, gt_boxes.shape[-1])
@@ -573,6 +598,21 @@ class PointHeadSimple(nn.Module):
         labels = torch.where(fg, fg_labels, labels)
         return {'point_cls_labels': labels.view(-1)}
 
+    def _assign_targets_device(self, point_coords, gt_boxes):
+        """dm_point_targets: both point-in-box tests and the label rules in one launch."""
+        from .. import _lib
+        pc = point_coords.detach().float().contiguous()      # (B*P, 4) [batch, x, y, z], P per sample
+        gt = gt_boxes.detach().float().contiguous()
+        _lib.require_device(pc, gt)
+        b, g, gtc = int(gt.shape[0]), int(gt.shape[1]), int(gt.shape[2])
+        p = pc.shape[0] // b
+        labels = torch.empty(b * p, dtype=torch.int64, device=pc.device)
+        _lib.check(_lib.lib().dm_point_targets(
+            _lib.ptr(pc[:, 1:]), 4, _lib.ptr(gt), b, p, g, gtc,
+            _lib.floats(self.model_cfg.TARGET_CONFIG.GT_EXTRA_WIDTH), self.num_class, _lib.ptr(labels),
+            _lib.stream()), 'dm_point_targets')
+        return labels
+
     def forward(self, batch_dict):
         if self.model_cfg.get('USE_POINT_FEATURES_BEFORE_FUSION', False):
             point_features = batch_dict['point_features_before_fusion']
@@ -586,11 +626,17 @@ class PointHeadSimple(nn.Module):
         self.forward_ret_dict = ret_dict
         return batch_dict
 
-    def get_loss(self, tb_dict=None):
+    def get_loss(self, tb_dict=None, fused=True):
         """point_head_template.py:131-154"""
         tb_dict = {} if tb_dict is None else tb_dict
         labels = self.forward_ret_dict['point_cls_labels'].view(-1)
         preds = self.forward_ret_dict['point_cls_preds'].view(-1, self.num_class)
+        if fused and preds.is_cuda and labels.dtype == torch.int64:
+            parts = _FusedPointFocalLoss.apply(
+                preds.contiguous(), labels.contiguous(), 0.25,
+                float(self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['point_cls_weight']))
+            tb_dict.update({'point_loss_cls': parts[0].detach(), 'point_pos_num': parts[1].detach()})
+            return parts[0], tb_dict
         positives = labels > 0
         cls_weights = ((labels == 0) * 1.0 + 1.0 * positives).float()
         pos_normalizer = positives.sum(dim=0).float()

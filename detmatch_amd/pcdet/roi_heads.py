@@ -81,6 +81,45 @@ class ProposalTargetLayer(nn.Module):
                 'roi_labels': batch_roi_labels.detach(), 'roi_scores_full': batch_roi_scores_full,
                 'reg_valid_mask': reg_valid_mask.detach(), 'rcnn_cls_labels': cls_labels.detach()}
 
+    def forward_device(self, batch_dict):
+        """forward() and the canonical transform of RoIHeadTemplate.assign_targets as two launches
+        (dm_roi_targets, csrc/roi_targets.hip); the same random draws as the tensor formulation."""
+        from .. import _lib
+        cfg = self.roi_sampler_cfg
+        assert cfg.CLS_SCORE_TYPE == 'roi_iou'
+        rois = batch_dict['rois'].detach().float().contiguous()
+        scores = batch_dict['roi_scores'].detach().float().contiguous()
+        labels = batch_dict['roi_labels'].detach().long().contiguous()
+        gt = batch_dict['gt_boxes'].detach().float().contiguous()
+        scores_full = batch_dict['roi_scores_full']
+        _lib.require_device(rois, scores, labels, gt)
+        B, R = int(rois.shape[0]), int(rois.shape[1])
+        G, gtc = int(gt.shape[1]), int(gt.shape[2])
+        S = int(cfg.ROI_PER_IMAGE)
+        u_perm, u_pick = self.draw(B, R, rois.device)
+        dev = rois.device
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        i64 = lambda *shape: torch.empty(shape, dtype=torch.int64, device=dev)
+        o_rois, o_src, o_ct = f32(B, S, 7), f32(B, S, gtc), f32(B, S, gtc)
+        o_iou, o_score, o_cls, o_ok = f32(B, S), f32(B, S), f32(B, S), f32(B)
+        o_label, o_valid, o_sampled = i64(B, S), i64(B, S), i64(B, S)
+        L = _lib.lib()
+        ws = _lib.workspace(L.dm_roi_targets_workspace_bytes(B, R), dev, 'roi_targets')
+        _lib.check(L.dm_roi_targets(
+            _lib.ptr(rois), _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(gt), B, R, G, gtc,
+            _lib.ptr(u_perm), _lib.ptr(u_pick), S, int(np.round(cfg.FG_RATIO * S)),
+            float(cfg.REG_FG_THRESH), float(cfg.CLS_FG_THRESH), float(cfg.CLS_BG_THRESH),
+            float(cfg.CLS_BG_THRESH_LO), float(cfg.HARD_BG_RATIO), _lib.ptr(o_rois), _lib.ptr(o_src),
+            _lib.ptr(o_ct), _lib.ptr(o_iou), _lib.ptr(o_score), _lib.ptr(o_label), _lib.ptr(o_valid),
+            _lib.ptr(o_cls), _lib.ptr(o_sampled), _lib.ptr(o_ok), _lib.ptr(ws), ws.numel(),
+            _lib.stream()), 'dm_roi_targets')
+        # the one tensor of the layer that stays in the autograd graph (roi_head_template.py:98)
+        full = torch.gather(scores_full, 1, o_sampled[..., None].expand(-1, -1, scores_full.shape[-1])
+                            ) * o_ok.view(-1, 1, 1)
+        return {'rois': o_rois, 'gt_of_rois': o_ct, 'gt_of_rois_src': o_src, 'gt_iou_of_rois': o_iou,
+                'roi_scores': o_score, 'roi_labels': o_label, 'roi_scores_full': full,
+                'reg_valid_mask': o_valid, 'rcnn_cls_labels': o_cls}
+
     def sample_rois_for_rcnn(self, batch_dict):
         """:69-134, batched over the samples."""
         rois = batch_dict['rois']
@@ -92,7 +131,8 @@ class ProposalTargetLayer(nn.Module):
         gt_valid = valid_gt_mask(gt_boxes)                                       # :101-104
         max_overlaps, gt_assignment = self.get_max_iou_with_same_class(
             rois, roi_labels, gt_boxes[:, :, 0:7], gt_boxes[:, :, -1].long(), gt_valid)
-        sampled, ok = self.subsample_rois(max_overlaps)                          # (B, S), (B,)
+        u_perm, u_pick = self.draw(rois.shape[0], rois.shape[1], rois.device)
+        sampled, ok = self.subsample_rois(max_overlaps, u_perm, u_pick)          # (B, S), (B,)
         okf = ok.view(-1, 1)
         g = lambda t: torch.gather(t, 1, sampled)
         batch_rois = torch.gather(rois, 1, sampled[..., None].expand(-1, -1, rois.shape[-1]))
@@ -124,7 +164,14 @@ class ProposalTargetLayer(nn.Module):
             ga.append(torch.where(has, a, torch.zeros_like(a)))
         return torch.stack(mo), torch.stack(ga)
 
-    def subsample_rois(self, max_overlaps):
+    def draw(self, batch, n_rois, device):
+        """The sampler's random numbers (np.random.permutation / randint / rand in the reference,
+        :153,:185-199): one uniform key per RoI (orders the foreground set) and one uniform per
+        output slot (picks with replacement)."""
+        return (torch.rand((batch, n_rois), device=device),
+                torch.rand((batch, int(self.roi_sampler_cfg.ROI_PER_IMAGE)), device=device))
+
+    def subsample_rois(self, max_overlaps, u_perm, u):
         """:136-215 for all samples at once.  Returns indices (B, ROI_PER_IMAGE) and a
         per-sample flag that is False only in the reference's 'no fg and no bg' error case."""
         cfg = self.roi_sampler_cfg
@@ -143,10 +190,9 @@ class ProposalTargetLayer(nn.Module):
         rank_of = lambda m: torch.sort(torch.where(m, ar, ar + R), dim=1)[1]
         fg_sorted, easy_sorted, hard_sorted = rank_of(fg), rank_of(easy), rank_of(hard)
         # random permutation of the fg members (np.random.permutation, :153)
-        key = torch.where(fg, torch.rand((B, R), device=dev), torch.full((B, R), 2.0, device=dev))
-        fg_perm = torch.sort(key, dim=1)[1]
+        key = torch.where(fg, u_perm, torch.full((B, R), 2.0, device=dev))
+        fg_perm = torch.sort(key, dim=1, stable=True)[1]
         slot = torch.arange(S, device=dev)[None, :].expand(B, -1)
-        u = torch.rand((B, S), device=dev)
         pick = lambda srt, n: torch.gather(
             srt, 1, torch.minimum((u * n[:, None]).long(), (n[:, None] - 1).clamp(min=0)))
         fg_this = torch.minimum(n_fg, torch.full_like(n_fg, fg_per_image))
@@ -164,6 +210,42 @@ class ProposalTargetLayer(nn.Module):
         sampled = torch.where(slot < fg_this[:, None], fg_choice, bg_choice)
         ok = (n_fg + n_bg) > 0
         return sampled, ok
+
+
+class _FusedRcnnLoss(torch.autograd.Function):
+    """dm_rcnn_loss_forward / _backward (csrc/roi_targets.hip): classification, smooth-l1 and corner
+    losses of the RoI head in one launch -> tensor [cls, reg, corner]; the backward is one launch."""
+
+    @staticmethod
+    def forward(ctx, rcnn_cls, rcnn_reg, rois, gt_ct, gt_src, reg_valid, cls_labels, meta):
+        L = _lib.lib()
+        _lib.require_device(rcnn_cls, rcnn_reg, rois, gt_ct, gt_src, reg_valid, cls_labels)
+        w3, cw7, beta, corner = meta
+        n = int(rcnn_reg.shape[0])
+        dev = rcnn_reg.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        g_cls = torch.empty(n, dtype=torch.float32, device=dev)
+        g_sl1 = torch.empty((n, 7), dtype=torch.float32, device=dev)
+        g_corner = torch.empty((n, 7), dtype=torch.float32, device=dev)
+        _lib.check(L.dm_rcnn_loss_forward(
+            _lib.ptr(rcnn_cls), _lib.ptr(rcnn_reg), _lib.ptr(rois), _lib.ptr(gt_ct), _lib.ptr(gt_src),
+            _lib.ptr(reg_valid), _lib.ptr(cls_labels), n, int(gt_ct.shape[-1]), _lib.floats(w3),
+            _lib.floats(cw7), float(beta), int(corner), _lib.ptr(out), _lib.ptr(g_cls), _lib.ptr(g_sl1),
+            _lib.ptr(g_corner), _lib.stream()), 'dm_rcnn_loss_forward')
+        ctx.save_for_backward(g_cls, g_sl1, g_corner)
+        ctx.cls_shape = rcnn_cls.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        g_cls, g_sl1, g_corner = ctx.saved_tensors
+        n = int(g_cls.shape[0])
+        grad = grad.contiguous().float()
+        d_cls, d_reg = torch.empty_like(g_cls), torch.empty_like(g_sl1)
+        _lib.check(_lib.lib().dm_rcnn_loss_backward(
+            _lib.ptr(grad), _lib.ptr(g_cls), _lib.ptr(g_sl1), _lib.ptr(g_corner), n, _lib.ptr(d_cls),
+            _lib.ptr(d_reg), _lib.stream()), 'dm_rcnn_loss_backward')
+        return d_cls.view(ctx.cls_shape), d_reg, None, None, None, None, None, None
 
 
 class PVRCNNHead(nn.Module):
@@ -244,6 +326,13 @@ class PVRCNNHead(nn.Module):
 
     def assign_targets(self, batch_dict):
         """roi_head_template.py:104-134: sample + canonical transform of the GT."""
+        if batch_dict['rois'].is_cuda and batch_dict['gt_boxes'].shape[1] > 0 \
+                and batch_dict['gt_boxes'].shape[2] >= 8:
+            return self.proposal_target_layer.forward_device(batch_dict)
+        return self.assign_targets_tensor(batch_dict)
+
+    def assign_targets_tensor(self, batch_dict):
+        """The same as a chain of tensor operations (host-logic tests on CPU; comparator of the kernel)."""
         batch_size = batch_dict['batch_size']
         targets_dict = self.proposal_target_layer(batch_dict)
         rois = targets_dict['rois']
@@ -404,8 +493,36 @@ class PVRCNNHead(nn.Module):
         loss = loss * loss_cfgs.LOSS_WEIGHTS['rcnn_cls_weight']
         return loss, {'rcnn_loss_cls': loss.detach()}
 
-    def get_loss(self, tb_dict=None):
+    def get_loss_fused(self, tb_dict):
+        """Both layer losses through the one-launch kernel (same values as the tensor formulation)."""
+        d = self.forward_ret_dict
+        cfg = self.model_cfg.LOSS_CONFIG
+        assert cfg.CLS_LOSS == 'BinaryCrossEntropy' and cfg.REG_LOSS == 'smooth-l1'
+        lw = cfg.LOSS_WEIGHTS
+        corner = bool(cfg.CORNER_LOSS_REGULARIZATION)
+        meta = ([float(lw['rcnn_cls_weight']), float(lw['rcnn_reg_weight']),
+                 float(lw['rcnn_corner_weight']) if corner else 0.0],
+                [float(v) for v in lw['code_weights']], float(self.reg_loss_func.beta), corner)
+        gtc = d['gt_of_rois'].shape[-1]
+        parts = _FusedRcnnLoss.apply(
+            d['rcnn_cls'].contiguous(), d['rcnn_reg'].contiguous().view(-1, 7),
+            d['rois'].contiguous().view(-1, 7), d['gt_of_rois'].contiguous().view(-1, gtc),
+            d['gt_of_rois_src'].contiguous().view(-1, gtc), d['reg_valid_mask'].contiguous().view(-1),
+            d['rcnn_cls_labels'].float().contiguous().view(-1), meta)
+        loss_reg = parts[1] + parts[2] if corner else parts[1]
+        tb_dict.update({'rcnn_loss_cls': parts[0].detach(), 'rcnn_loss_reg': parts[1].detach()})
+        if corner:
+            tb_dict['rcnn_loss_corner'] = parts[2].detach()
+        rcnn_loss = parts[0] + loss_reg
+        tb_dict['rcnn_loss'] = rcnn_loss.detach()
+        return rcnn_loss, tb_dict
+
+    def get_loss(self, tb_dict=None, fused=True):
         tb_dict = {} if tb_dict is None else tb_dict
+        d = self.forward_ret_dict
+        if fused and d['rcnn_reg'].is_cuda and self.box_coder.code_size == 7 and d['rcnn_cls'].shape[-1] == 1 \
+                and d['reg_valid_mask'].dtype == torch.int64:
+            return self.get_loss_fused(tb_dict)
         loss_cls, cls_tb = self.get_box_cls_layer_loss(self.forward_ret_dict)
         loss_reg, reg_tb = self.get_box_reg_layer_loss(self.forward_ret_dict)
         tb_dict.update(cls_tb)

@@ -338,6 +338,53 @@ int dm_anchor_assign(const float *anchors, const float *anchors_bev, const float
                      const float *unmatched, int B, int M, int C, int A, int R, int num_class,
                      int *labels, float *reg_targets, float *reg_weights, void *workspace,
                      size_t workspace_bytes, dm_stream_t stream);
+/* D / E. Second-stage targets and losses of PV-RCNN, one or two launches per call for the whole batch.
+ *
+ * dm_roi_targets replaces ProposalTargetLayer.forward (sample_rois_for_rcnn, subsample_rois,
+ * get_max_iou_with_same_class; pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:13-259)
+ * plus the canonical transform of RoIHeadTemplate.assign_targets (roi_head_template.py:104-134).
+ * rois (B, R, 7), roi_scores (B, R), roi_labels (B, R) int64, gt_boxes (B, G, gt_cols) with the class id
+ * in the last column (rows after the last non-zero row are padding).  The reference draws its random
+ * choices with numpy (:153,:185-199); here they are inputs: u_perm (B, R) orders the foreground RoIs
+ * (ascending key), u_pick (B, S) picks with replacement (index = floor(u * count)), both uniform in
+ * [0, 1).  Outputs (S = roi_per_image): rois (B, S, 7), gt_of_rois_src / gt_of_rois (canonical frame)
+ * (B, S, gt_cols), iou / scores (B, S), labels / reg_valid (B, S) int64, rcnn_cls_labels (B, S) for
+ * CLS_SCORE_TYPE roi_iou, the sampled RoI index (B, S) int64 and the per-sample "has fg or bg" flag. */
+size_t dm_roi_targets_workspace_bytes(int batch, int n_rois);
+int dm_roi_targets(const float *rois, const float *roi_scores, const long long *roi_labels,
+                   const float *gt_boxes, int batch, int n_rois, int n_gt, int gt_cols,
+                   const float *u_perm, const float *u_pick, int roi_per_image, int fg_per_image,
+                   float reg_fg_thresh, float cls_fg_thresh, float cls_bg_thresh,
+                   float cls_bg_thresh_lo, float hard_bg_ratio, float *out_rois, float *out_gt_src,
+                   float *out_gt_canonical, float *out_iou, float *out_scores, long long *out_labels,
+                   long long *out_reg_valid, float *out_cls_labels, long long *out_sampled,
+                   float *out_ok, void *workspace, size_t workspace_bytes, dm_stream_t stream);
+/* RoIHeadTemplate.get_box_cls_layer_loss + get_box_reg_layer_loss (roi_head_template.py:136-218:
+ * BinaryCrossEntropy on sigmoid(rcnn_cls), smooth-l1 on the residual code of the canonical GT, corner
+ * regularisation loss_utils.py:209-233).  out3 = [cls, reg, corner] (already weighted by
+ * loss_weights3); g_cls (n), g_sl1 / g_corner (n, 7) are the gradients of out3[0], out3[1], out3[2]
+ * w.r.t. rcnn_cls / rcnn_reg, combined with the upstream gradient by dm_rcnn_loss_backward. */
+int dm_rcnn_loss_forward(const float *rcnn_cls, const float *rcnn_reg, const float *rois,
+                         const float *gt_canonical, const float *gt_src, const long long *reg_valid,
+                         const float *cls_labels, int n, int gt_cols, const float *loss_weights3,
+                         const float *code_weights7, float beta, int corner_loss, float *out3,
+                         float *g_cls, float *g_sl1, float *g_corner, dm_stream_t stream);
+int dm_rcnn_loss_backward(const float *upstream3, const float *g_cls, const float *g_sl1,
+                          const float *g_corner, int n, float *d_rcnn_cls, float *d_rcnn_reg,
+                          dm_stream_t stream);
+/* PointHeadSimple.assign_targets (point_head_simple.py:20-48 -> assign_stack_targets,
+ * point_head_template.py:49-129, set_ignore_flag branch): label of every key point = class of the
+ * first GT box that holds it (1 when num_class == 1), -1 if only the box enlarged by extra_width3
+ * holds it, else 0; the in-box rule is roiaware_pool3d's points_in_boxes.  points: rows of
+ * point_stride floats starting at x (n_points per sample), labels (B * n_points) int64. */
+int dm_point_targets(const float *points, int point_stride, const float *gt_boxes, int batch,
+                     int n_points, int n_gt, int gt_cols, const float *extra_width3, int num_class,
+                     long long *labels, dm_stream_t stream);
+/* PointHeadTemplate.get_cls_layer_loss (point_head_template.py:131-154): sigmoid focal loss
+ * (alpha, gamma 2) over (n, n_cls) with weights 1 / max(#positive, 1) on labels >= 0, times
+ * loss_weight.  out2 = [loss, #positive]; grad (n, n_cls) = d loss / d preds. */
+int dm_point_focal_loss(const float *preds, const long long *labels, int n, int n_cls, float alpha,
+                        float loss_weight, float *out2, float *grad, dm_stream_t stream);
 /* ------------------------------------------------------------------------ */
 /* C / G. Dense 2-D convolutions (BEV backbone, anchor-head convs, ResNet-50 + FPN + RPN)      */
 /* ------------------------------------------------------------------------ */

@@ -48,6 +48,15 @@ def main():
         for name in d.model.module_topology:
             wrap(getattr(d.model, name), 'forward', tag + '3d.' + name)
         wrap(d.model, 'get_training_loss', tag + '3d.losses')
+        for name, methods in (('roi_head', ('proposal_layer', 'assign_targets', 'roi_grid_pool', 'get_loss',
+                                            'generate_predicted_boxes')),
+                              ('dense_head', ('assign_targets', 'generate_predicted_boxes', 'get_loss')),
+                              ('point_head', ('assign_targets', 'get_loss')),
+                              ('pfe', ('get_sampled_points', 'interpolate_from_bev_features'))):
+            mod = getattr(d.model, name, None)
+            for meth in methods:
+                if mod is not None and hasattr(mod, meth):
+                    wrap(mod, meth, tag + '3d.%s.%s' % (name, meth))
         wrap(d.model, 'post_processing', tag + '3d.post_processing')
     for tag, d in dets2d.items():
         wrap(d, 'extract_feat', tag + '2d.backbone+fpn')
