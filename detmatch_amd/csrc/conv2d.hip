@@ -594,6 +594,33 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const float *__restrict
   dst[e] = v;
 }
 
+// the same for a table of weights in one launch (blockIdx.y = table row, grid-stride over its elements):
+// every packed weight of a network is refreshed by one launch after an optimizer / EMA step.
+struct DConvPackDesc {   // 80 bytes; mirrored by dense_conv._DESC (numpy)
+  const float *src;
+  float *dst;
+  const float *scale_n, *scale_k;
+  long long sn, sk, st;
+  int S, N, K, Nsrc, Ksrc, pad;
+};
+
+__global__ __launch_bounds__(256) void dconv_pack_batch_kernel(const DConvPackDesc *__restrict__ table) {
+  const DConvPackDesc d = table[blockIdx.y];
+  const long long total = (long long)d.S * d.N * d.K;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int k = (int)(e % d.K);
+    const long long r = e / d.K;
+    const int n = (int)(r % d.N), s = (int)(r / d.N);
+    float v = 0.0f;
+    if (k < d.Ksrc && n < d.Nsrc) {
+      v = d.src[n * d.sn + k * d.sk + s * d.st];
+      if (d.scale_n) v *= d.scale_n[n];
+      if (d.scale_k) v *= d.scale_k[k];
+    }
+    d.dst[e] = v;
+  }
+}
+
 // y[row(m)][n] = relu?(bias[n] + sum_s partial[s][m][n])   (split-K epilogue; fixed summation order)
 __global__ __launch_bounds__(256) void dconv_splitk_reduce_kernel(const float *__restrict__ partial,
                                                                   const float *__restrict__ bias,
@@ -668,6 +695,17 @@ extern "C" int dm_dconv_pack(const float *src, float *dst, const float *scale_n,
   const long long total = (long long)S * N * K;
   dconv_pack_kernel<<<dm_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(
       src, dst, scale_n, scale_k, S, N, K, Nsrc, Ksrc, sn, sk, st);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_dconv_pack_batch(const void *table_dev, int n_entries, int blocks_per_entry,
+                                   dm_stream_t stream) {
+  static_assert(sizeof(DConvPackDesc) == 80, "descriptor layout is part of the ABI");
+  if (n_entries <= 0) return DM_OK;
+  if (!table_dev || blocks_per_entry <= 0 || n_entries > 65535) return DM_ERR_INVALID_ARG;
+  dconv_pack_batch_kernel<<<dim3(blocks_per_entry, n_entries), 256, 0, (hipStream_t)stream>>>(
+      (const DConvPackDesc *)table_dev);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -31,6 +31,7 @@ def weights_changed():
     _GENERATION[0] += 1
     if len(_PACK_CACHE) > 4096:
         _PACK_CACHE.clear()
+        _TABLES.clear()
 
 
 def _shorts(v):
@@ -67,26 +68,96 @@ def _pad_channels(x, c4):
     return out
 
 
+class _Packed(object):
+    """One cached packed weight: destination buffer, descriptor and what it was packed from."""
+    __slots__ = ('ver', 'dst', 'src', 'wref', 'scale_n', 'scale_k', 'desc', 'batchable', 'stream')
+
+
+# 80-byte rows of dm_dconv_pack_batch (csrc/conv2d.hip: DConvPackDesc)
+_DESC = None
+_TABLES = {}      # HIP stream -> {'entries': [...], 'table': device tensor or None}
+
+
+def _desc_dtype():
+    global _DESC
+    if _DESC is None:
+        import numpy as np
+        _DESC = np.dtype([('src', '<u8'), ('dst', '<u8'), ('scale_n', '<u8'), ('scale_k', '<u8'),
+                          ('sn', '<i8'), ('sk', '<i8'), ('st', '<i8'), ('S', '<i4'), ('N', '<i4'),
+                          ('K', '<i4'), ('Nsrc', '<i4'), ('Ksrc', '<i4'), ('pad', '<i4')])
+        assert _DESC.itemsize == 80
+    return _DESC
+
+
+def _scale_id(t):
+    return None if t is None else (t.data_ptr(), t._version)
+
+
+def _constant(t):
+    """Scale vectors that never change while they live (FrozenBN.scale_shift marks its cached map)."""
+    return t is None or getattr(t, 'dm_constant', False)
+
+
+def _refresh_stream(stream, device):
+    """Re-pack every batchable cached weight of this stream in ONE launch (after the fused optimizer
+    / EMA kernels rewrote the weights: `weights_changed`)."""
+    import numpy as np
+    reg = _TABLES[stream]
+    live = []
+    for e in reg['entries']:
+        w = e.wref()
+        if w is not None and w.data_ptr() == e.desc[0] and _PACK_CACHE.get(e.desc[-1]) is e:
+            live.append(e)
+    if len(live) != len(reg['entries']) or reg['table'] is None:
+        reg['entries'] = live
+        rows = np.zeros(len(live), dtype=_desc_dtype())
+        for i, e in enumerate(live):
+            rows[i] = e.desc[:-1]
+        reg['table'] = torch.from_numpy(rows.view(np.uint8)).to(device) if live else None
+        reg['blocks'] = max(1, min(64, max((e.dst.numel() for e in live), default=1) // 1024))
+    if live:
+        _lib.check(_lib.lib().dm_dconv_pack_batch(_lib.ptr(reg['table']), len(live), reg['blocks'],
+                                                  _lib.stream()), 'dm_dconv_pack_batch')
+    gen = _GENERATION[0]
+    for e in live:
+        e.ver = (gen, e.wref()._version, e.ver[2], e.ver[3])
+
+
 def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None):
     """[S][N][K] packed copy of `weight` (cached until the weight or a scale changes)."""
     cacheable = isinstance(weight, nn.Parameter)     # temporaries may recycle an address
-    key = (id(weight), weight.data_ptr(), tag, N, K)
-    ver = (_GENERATION[0], weight._version,
-           None if scale_n is None else (scale_n.data_ptr(), scale_n._version),
-           None if scale_k is None else (scale_k.data_ptr(), scale_k._version),
-           torch.cuda.current_stream().cuda_stream)
+    stream = torch.cuda.current_stream().cuda_stream
+    key = (id(weight), weight.data_ptr(), tag, N, K, stream)
+    ver = (_GENERATION[0], weight._version, _scale_id(scale_n), _scale_id(scale_k))
     hit = _PACK_CACHE.get(key) if cacheable else None
-    if hit is not None and hit[0] == ver and hit[3]() is weight:
-        return hit[1]
-    dst = torch.empty((S, N, K), dtype=torch.float32, device=weight.device)
+    if hit is not None and hit.wref() is not weight:
+        hit = None
+    if hit is not None:
+        if hit.ver == ver:
+            return hit.dst
+        if hit.batchable and hit.ver[2:] == ver[2:]:
+            _refresh_stream(stream, weight.device)
+            if hit.ver == ver:
+                return hit.dst
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
+    dst = hit.dst if hit is not None else torch.empty((S, N, K), dtype=torch.float32, device=weight.device)
     _lib.check(_lib.lib().dm_dconv_pack(_lib.ptr(w), _lib.ptr(dst), _lib.ptr(scale_n),
                                         _lib.ptr(scale_k), S, N, K, n_src, k_src, sn, sk, st,
                                         _lib.stream()), 'dm_dconv_pack')
     if cacheable:
-        _PACK_CACHE[key] = (ver, dst, w, weakref.ref(weight))
+        e = _Packed()
+        e.ver, e.dst, e.src, e.wref = ver, dst, w, weakref.ref(weight)
+        e.scale_n, e.scale_k, e.stream = scale_n, scale_k, stream
+        e.batchable = w.data_ptr() == weight.data_ptr() and _constant(scale_n) and _constant(scale_k)
+        e.desc = (w.data_ptr(), dst.data_ptr(), 0 if scale_n is None else scale_n.data_ptr(),
+                  0 if scale_k is None else scale_k.data_ptr(), sn, sk, st, S, N, K, n_src, k_src, 0, key)
+        _PACK_CACHE[key] = e
+        if e.batchable:
+            reg = _TABLES.setdefault(stream, {'entries': [], 'table': None, 'blocks': 1})
+            reg['entries'].append(e)
+            reg['table'] = None
     return dst
 
 

@@ -43,6 +43,7 @@ class FrozenBN(nn.Module):
             with torch.no_grad():
                 s = self.weight * torch.rsqrt(self.running_var + self.eps)
                 b = self.bias - self.running_mean * s
+            s.dm_constant = True      # lives as long as it is valid: packed weights may keep its address
             cached = self._affine = (key, s, b)
         return cached[1], cached[2]
 

@@ -125,13 +125,14 @@ def max_iou_assign(boxes, gt_boxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match
     return assigned
 
 
-def random_sample(assigned, num, pos_fraction, generator=None):
+def random_sample(assigned, num, pos_fraction, generator=None, keys=None):
     """mmdet RandomSampler (neg_pos_ub -1): up to int(num*pos_fraction) positives, the rest
-    negatives, uniformly at random.  -> (pos_idx (P), pos_ok (P) bool, neg_idx (num), neg_ok)."""
+    negatives, uniformly at random.  -> (pos_idx (P), pos_ok (P) bool, neg_idx (num), neg_ok).
+    `keys`: one uniform number per box (drawn here when None); the boxes with the smallest keys win."""
     n = assigned.shape[0]
     n_pos = min(int(num * pos_fraction), n)
     n_neg = min(num, n)
-    key = torch.rand((n,), device=assigned.device, generator=generator)
+    key = torch.rand((n,), device=assigned.device, generator=generator) if keys is None else keys[:n]
     two = key.new_full((), 2.0)
     vp, ip = torch.topk(torch.where(assigned > 0, key, two), n_pos, largest=False)
     pos_ok = vp < 1.5
@@ -156,6 +157,91 @@ def nms_fixed(boxes, scores, iou_thr, max_num):
     ok = torch.arange(max_num, device=b.device) < num
     idx = torch.where(ok, keep[:max_num], torch.zeros_like(keep[:max_num]))
     return order[idx], ok
+
+
+# ------------------------------------------------------------------ fused targets / losses
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * max(len(tensors), 1))(*[t.data_ptr() if t is not None and t.numel() else None
+                                                     for t in tensors])
+
+
+def _gt_arrays(gt_bboxes):
+    gts = [g.detach().float().contiguous() for g in gt_bboxes]
+    return gts, _ptr_array(gts), _lib.ints([g.shape[0] for g in gts])
+
+
+class _FusedRpnLoss(torch.autograd.Function):
+    """dm_rpn_loss_forward / _backward (csrc/det2d_targets.hip): assignment, sampling and both RPN
+    losses of the whole batch read straight from the NHWC head outputs -> tensor [cls, bbox]; the
+    gradient comes back as one scatter into a zeroed buffer that the per-level gradients are views of."""
+
+    @staticmethod
+    def forward(ctx, meta, anchors, keys, *levels):
+        (gt_bboxes, a_cfg, num, n_pos, means, stds, w_cls, w_box, n_base) = meta
+        L = _lib.lib()
+        ys = [dense_conv._cl(y) for y in levels]
+        _lib.require_device(anchors, keys, *ys)
+        b, c = int(ys[0].shape[0]), int(ys[0].shape[1])
+        hw = [int(y.shape[2] * y.shape[3]) for y in ys]
+        offs, total = [], 0
+        for n in hw:
+            offs.append(total)
+            total += b * n * c
+        gts, gt_ptrs, n_gt = _gt_arrays(gt_bboxes)
+        n_anchors = int(anchors.shape[0])
+        dev = anchors.device
+        n_ent = b * (n_pos + num) * 5
+        ent_off = torch.empty(n_ent, dtype=torch.int64, device=dev)
+        ent_val = torch.empty(n_ent, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        import ctypes
+        ws = _lib.workspace(L.dm_det2d_assign_workspace_bytes(b, n_anchors), dev, 'det2d')
+        _lib.check(L.dm_rpn_loss_forward(
+            _ptr_array(ys), _lib.ints(hw), len(ys), n_base, c, (ctypes.c_longlong * len(offs))(*offs),
+            _lib.ptr(anchors), n_anchors, gt_ptrs, n_gt, b, _lib.ptr(keys), float(a_cfg['pos_iou_thr']),
+            float(a_cfg['neg_iou_thr']), float(a_cfg['min_pos_iou']),
+            int(bool(a_cfg.get('match_low_quality', True))), num, n_pos, _lib.floats(means), _lib.floats(stds),
+            float(w_cls), float(w_box), _lib.ptr(out), _lib.ptr(ent_off), _lib.ptr(ent_val), None,
+            _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_rpn_loss_forward')
+        ctx.save_for_backward(ent_off, ent_val)
+        ctx.layout = (total, offs, [tuple(y.shape) for y in ys])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        ent_off, ent_val = ctx.saved_tensors
+        total, offs, shapes = ctx.layout
+        flat = torch.zeros(total, dtype=torch.float32, device=ent_val.device)
+        _lib.check(_lib.lib().dm_rpn_loss_backward(
+            _lib.ptr(ent_off), _lib.ptr(ent_val), _lib.ptr(grad.contiguous().float()), int(ent_off.numel()),
+            _lib.ptr(flat), _lib.stream()), 'dm_rpn_loss_backward')
+        grads = [flat[o:o + b * c * h * w].view(b, h, w, c).permute(0, 3, 1, 2)
+                 for o, (b, c, h, w) in zip(offs, shapes)]
+        return (None, None, None) + tuple(grads)
+
+
+class _FusedBBoxHeadLoss(torch.autograd.Function):
+    """dm_bbox_head_loss: focal classification loss, accuracy and class-specific L1 -> [cls, bbox, acc]."""
+
+    @staticmethod
+    def forward(ctx, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, meta):
+        n_classes, agnostic, alpha, w_cls, w_box = meta
+        _lib.require_device(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights)
+        out = torch.empty(3, dtype=torch.float32, device=cls_score.device)
+        g_cls, g_box = torch.empty_like(cls_score), torch.empty_like(bbox_pred)
+        _lib.check(_lib.lib().dm_bbox_head_loss(
+            _lib.ptr(cls_score), _lib.ptr(bbox_pred), _lib.ptr(labels), _lib.ptr(label_weights),
+            _lib.ptr(bbox_targets), _lib.ptr(bbox_weights), int(cls_score.shape[0]), int(cls_score.shape[1]),
+            int(n_classes), int(agnostic), float(alpha), float(w_cls), float(w_box), _lib.ptr(out),
+            _lib.ptr(g_cls), _lib.ptr(g_box), _lib.stream()), 'dm_bbox_head_loss')
+        ctx.save_for_backward(g_cls, g_box)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        g_cls, g_box = ctx.saved_tensors
+        return g_cls * grad[0], g_box * grad[1], None, None, None, None, None
 
 
 # ------------------------------------------------------------------ RPN
@@ -192,12 +278,14 @@ class RPNHead(nn.Module):
         if pad:
             w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
             b = torch.cat([b, b.new_zeros(pad)], dim=0)
-        cls, reg = [], []
+        cls, reg, raw = [], [], []
         for x in feats:
             x = dense_conv.conv2d(x, self.rpn_conv.weight, self.rpn_conv.bias, 1, 1, relu=True)
             y = dense_conv.conv2d(x, w, b, 1, 0)
+            raw.append(y)
             cls.append(y[:, :a])
             reg.append(y[:, a:5 * a])
+        self._raw_levels = raw           # what the fused loss reads (objectness + deltas, NHWC)
         return cls, reg
 
     @staticmethod
@@ -208,13 +296,31 @@ class RPNHead(nn.Module):
         d = torch.cat([r.permute(0, 2, 3, 1).reshape(b, -1, 4) for r in reg], dim=1)
         return s, d
 
-    def loss(self, cls, reg, gt_bboxes, img_metas):
+    def _all_anchors(self, sizes, device):
+        key = (tuple(tuple(int(v) for v in s) for s in sizes), str(device))
+        cache = self.__dict__.setdefault('_anchor_cat', {})
+        if key not in cache:
+            cache[key] = torch.cat(self.anchor_generator.grid_anchors(sizes, device), dim=0).contiguous()
+        return cache[key]
+
+    def loss(self, cls, reg, gt_bboxes, img_metas, fused=True, keys=None):
         """mmdet AnchorHead.loss with sampling: BCE over the 256 sampled anchors, L1 over encoded
         deltas of the sampled positives, both / num_total_samples (summed over the batch)."""
         cfg = self.train_cfg
         a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
         sizes = [c.shape[-2:] for c in cls]
-        anchors = torch.cat(self.anchor_generator.grid_anchors(sizes, cls[0].device), dim=0)
+        anchors = self._all_anchors(sizes, cls[0].device)
+        if keys is None:
+            keys = torch.rand((cls[0].shape[0], anchors.shape[0]), device=anchors.device)
+        raw = getattr(self, '_raw_levels', None)
+        if fused and anchors.is_cuda and raw is not None and len(raw) == len(cls) \
+                and all(c._base is y for c, y in zip(cls, raw)) and cls[0].shape[0] <= 8 \
+                and max(g.shape[0] for g in gt_bboxes) <= 256:
+            meta = (list(gt_bboxes), a_cfg, int(s_cfg['num']), int(s_cfg['num'] * s_cfg['pos_fraction']),
+                    self.bbox_coder.means, self.bbox_coder.stds, self.loss_cls_weight, self.loss_bbox_weight,
+                    self.num_anchors)
+            parts = _FusedRpnLoss.apply(meta, anchors, keys, *raw)
+            return dict(loss_rpn_cls=parts[0], loss_rpn_bbox=parts[1])
         scores, deltas = self._flatten(cls, reg)
         tot_cls, tot_box, tot_n = 0., 0., 0.
         for i in range(scores.shape[0]):
@@ -222,7 +328,8 @@ class RPNHead(nn.Module):
             with torch.no_grad():
                 assigned = max_iou_assign(anchors, gt, a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'],
                                           a_cfg['min_pos_iou'], a_cfg.get('match_low_quality', True))
-                ip, pos_ok, ineg, neg_ok = random_sample(assigned, s_cfg['num'], s_cfg['pos_fraction'])
+                ip, pos_ok, ineg, neg_ok = random_sample(assigned, s_cfg['num'], s_cfg['pos_fraction'],
+                                                         keys=keys[i])
                 if gt.shape[0] > 0:
                     tgt = self.bbox_coder.encode(anchors[ip], gt[(assigned[ip] - 1).clamp(min=0)])
                     tgt = torch.where(pos_ok[:, None], tgt, torch.zeros_like(tgt))
@@ -307,9 +414,20 @@ class Shared2FCBBoxHead(nn.Module):
             x = F.relu(fc(x), inplace=True)
         return self.fc_cls(x), self.fc_reg(x)
 
-    def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights):
+    def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, fused=True):
         """mmdet BBoxHead.loss: cls avg_factor = #(label_weights > 0); box loss over positives of
         the class-specific prediction, averaged over ALL sampled RoIs (bbox_targets.size(0))."""
+        from ..mm3d.losses import FocalLoss, L1Loss
+        if fused and cls_score.is_cuda and isinstance(self.loss_cls, FocalLoss) and self.loss_cls.gamma == 2.0 \
+                and self.loss_cls.reduction == 'mean' and isinstance(self.loss_bbox, L1Loss) \
+                and self.loss_bbox.reduction == 'mean':
+            meta = (self.num_classes, bool(self.reg_class_agnostic), self.loss_cls.alpha,
+                    self.loss_cls.loss_weight, self.loss_bbox.loss_weight)
+            parts = _FusedBBoxHeadLoss.apply(cls_score.contiguous(), bbox_pred.contiguous(),
+                                             labels.long().contiguous(), label_weights.float().contiguous(),
+                                             bbox_targets.float().contiguous(),
+                                             bbox_weights.float().contiguous(), meta)
+            return dict(loss_cls=parts[0], acc=parts[2].detach(), loss_bbox=parts[1])
         n_valid = (label_weights > 0).sum().clamp(min=1).float()
         losses = dict()
         losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=n_valid)
@@ -345,7 +463,38 @@ class StandardRoIHead(nn.Module):
         return roi_align_fpn(feats, rois, self.featmap_strides, self.out_size, self.sampling_ratio,
                              self.aligned, self.finest_scale)
 
-    def forward_train(self, feats, img_metas, proposals, gt_bboxes, gt_labels):
+    def _targets_device(self, proposals, gt_bboxes, gt_labels, keys):
+        """dm_roi2d_targets: assignment, sampling and BBoxHead.get_targets of the batch in 4 launches."""
+        cfg = self.train_cfg
+        a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
+        num, nc = int(s_cfg['num']), self.bbox_head.num_classes
+        props = [p.detach().float().contiguous() for p, _ in proposals]
+        oks = [ok.contiguous() for _, ok in proposals]
+        assert all(o.dtype == torch.bool for o in oks) and len({p.shape for p in props}) == 1
+        gts, gt_ptrs, n_gt = _gt_arrays(gt_bboxes)
+        labs = [l.detach().long().contiguous() for l in gt_labels]
+        b, dev = len(props), props[0].device
+        _lib.require_device(keys, *props)
+        rois = torch.empty((b * num, 5), dtype=torch.float32, device=dev)
+        labels = torch.empty(b * num, dtype=torch.int64, device=dev)
+        lw = torch.empty(b * num, dtype=torch.float32, device=dev)
+        tgts = torch.empty((b * num, 4), dtype=torch.float32, device=dev)
+        bw = torch.empty((b * num, 4), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = _lib.workspace(L.dm_det2d_assign_workspace_bytes(b, int(keys.shape[1])), dev, 'det2d')
+        coder = self.bbox_head.bbox_coder
+        _lib.check(L.dm_roi2d_targets(
+            _ptr_array(props), _ptr_array(oks), int(props[0].shape[0]), int(props[0].shape[1]), gt_ptrs,
+            _ptr_array(labs), n_gt, b, int(bool(s_cfg.get('add_gt_as_proposals', True))), _lib.ptr(keys),
+            int(keys.shape[1]), float(a_cfg['pos_iou_thr']), float(a_cfg['neg_iou_thr']),
+            float(a_cfg['min_pos_iou']), int(bool(a_cfg.get('match_low_quality', False))), num,
+            int(num * s_cfg['pos_fraction']), nc, _lib.floats(coder.means), _lib.floats(coder.stds),
+            _lib.ptr(rois), _lib.ptr(labels), _lib.ptr(lw), _lib.ptr(tgts), _lib.ptr(bw), _lib.ptr(ws),
+            ws.numel(), _lib.stream()), 'dm_roi2d_targets')
+        return rois, labels, lw, tgts, bw
+
+    def _targets_tensor(self, proposals, gt_bboxes, gt_labels, keys):
+        """The same as dense tensor operations per image (comparator of the kernel; CPU host-logic tests)."""
         cfg = self.train_cfg
         a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
         num = s_cfg['num']
@@ -360,7 +509,7 @@ class StandardRoIHead(nn.Module):
                 assigned = max_iou_assign(boxes, gt.float(), a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'],
                                           a_cfg['min_pos_iou'], a_cfg.get('match_low_quality', False),
                                           box_valid=valid)
-                ip, pos_ok, ineg, neg_ok = random_sample(assigned, num, s_cfg['pos_fraction'])
+                ip, pos_ok, ineg, neg_ok = random_sample(assigned, num, s_cfg['pos_fraction'], keys=keys[i])
                 idx = torch.cat([ip, ineg])
                 okk = torch.cat([pos_ok, neg_ok])
                 is_pos = torch.cat([pos_ok, torch.zeros_like(neg_ok)])
@@ -381,10 +530,25 @@ class StandardRoIHead(nn.Module):
                 labels.append(lab), lw.append(okk.float()), tgts.append(t)
                 bw.append(is_pos.float()[:, None].expand(-1, 4))
             rois = torch.cat(rois)
+        return rois, torch.cat(labels), torch.cat(lw), torch.cat(tgts), torch.cat(bw)
+
+    def forward_train(self, feats, img_metas, proposals, gt_bboxes, gt_labels, fused=True, keys=None):
+        cfg = self.train_cfg
+        a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
+        num = s_cfg['num']
+        nc = self.bbox_head.num_classes
+        if keys is None:
+            keys = torch.rand((len(proposals), proposals[0][0].shape[0] + max(g.shape[0] for g in gt_bboxes)),
+                              device=proposals[0][0].device)
+        if fused and keys.is_cuda and len(proposals) <= 8 and max(g.shape[0] for g in gt_bboxes) <= 256 \
+                and num <= 512:
+            rois, labels, lw, tgts, bw = self._targets_device(proposals, gt_bboxes, gt_labels, keys)
+            cls_score, bbox_pred = self.bbox_head(self.extract(feats, rois))
+            return self.bbox_head.loss(cls_score, bbox_pred, labels, lw, tgts, bw)
+        rois, labels, lw, tgts, bw = self._targets_tensor(proposals, gt_bboxes, gt_labels, keys)
         feats_roi = self.extract(feats, rois)
         cls_score, bbox_pred = self.bbox_head(feats_roi)
-        return self.bbox_head.loss(cls_score, bbox_pred, torch.cat(labels), torch.cat(lw),
-                                   torch.cat(tgts), torch.cat(bw))
+        return self.bbox_head.loss(cls_score, bbox_pred, labels, lw, tgts, bw, fused=fused)
 
     def simple_test_pre_nms(self, feats, proposals, img_metas):
         """test_mixins.simple_test_bboxes up to (not including) NMS: per image

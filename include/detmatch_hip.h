@@ -385,6 +385,54 @@ int dm_point_targets(const float *points, int point_stride, const float *gt_boxe
  * loss_weight.  out2 = [loss, #positive]; grad (n, n_cls) = d loss / d preds. */
 int dm_point_focal_loss(const float *preds, const long long *labels, int n, int n_cls, float alpha,
                         float loss_weight, float *out2, float *grad, dm_stream_t stream);
+/* G. Target assignment, sampling and losses of the 2-D detector, 4-5 launches per call for the whole
+ * batch (csrc/det2d_targets.hip).  mmdet 2.14 is an un-vendored dependency of the reference; the rules
+ * are MaxIoUAssigner.assign_wrt_overlaps (gt_max_assign_all), RandomSampler (neg_pos_ub -1),
+ * DeltaXYWHBBoxCoder.encode, AnchorHead.loss (sampling) and BBoxHead.get_targets / loss as configured at
+ * configs/detmatch/001/detmatch/split_0.py:39-99,440-478.  Per-image inputs are host arrays of device
+ * pointers (batch <= 8, <= 256 GT boxes per image).  `keys`: uniform [0,1) numbers, one per box; the
+ * sampled positives / negatives are the boxes with the smallest keys (a uniform random subset).
+ *
+ * dm_rpn_loss_forward: RPNHead.loss.  level_outputs[l]: (B, H_l, W_l, channels) NHWC head output with
+ * the A objectness logits first, then the 4A deltas; anchors (n_anchors, 4) in (level, h, w, a) order.
+ * out2 = [loss_rpn_cls, loss_rpn_bbox]; the gradient w.r.t. the head outputs is returned as sparse
+ * entries (5 per sampled slot: offset into one flat buffer laid out by grad_offsets[l], value) that
+ * dm_rpn_loss_backward scatters, scaled by the upstream gradients, into a zeroed buffer.
+ * assigned_out (B, n_anchors) int32, optional: assigned_gt_inds (-1 ignore, 0 negative, k+1). */
+size_t dm_det2d_assign_workspace_bytes(int batch, int n_boxes_max);
+int dm_rpn_loss_forward(const float *const *level_outputs, const int *level_hw, int n_levels,
+                        int n_base_anchors, int channels, const long long *grad_offsets,
+                        const float *anchors, int n_anchors, const float *const *gt_boxes,
+                        const int *n_gt, int batch, const float *keys, float pos_iou_thr,
+                        float neg_iou_thr, float min_pos_iou, int match_low_quality, int num,
+                        int num_pos_max, const float *means4, const float *stds4,
+                        float loss_cls_weight, float loss_bbox_weight, float *out2,
+                        long long *entry_offsets, float *entry_values, int *assigned_out,
+                        void *workspace, size_t workspace_bytes, dm_stream_t stream);
+int dm_rpn_loss_backward(const long long *entry_offsets, const float *entry_values,
+                         const float *upstream2, int n_entries, float *grad_flat, dm_stream_t stream);
+/* StandardRoIHead.forward_train up to the RoI extractor: assign (proposals, optionally with the GT
+ * boxes in front), sample `num` RoIs per image (at most num_pos_max positives), BBoxHead.get_targets.
+ * proposals[b]: (n_proposals, proposal_stride) rows with xyxy first, proposal_ok[b]: (n_proposals) bool.
+ * keys: (batch, keys_stride), keys_stride >= n_proposals + max n_gt.  Outputs: rois (B*num, 5)
+ * [image, x1, y1, x2, y2], labels (B*num) int64 (n_classes = background), label_weights (B*num),
+ * bbox_targets / bbox_weights (B*num, 4); rows beyond the sampled ones are zero with weight 0. */
+int dm_roi2d_targets(const float *const *proposals, const unsigned char *const *proposal_ok,
+                     int n_proposals, int proposal_stride, const float *const *gt_boxes,
+                     const long long *const *gt_labels, const int *n_gt, int batch,
+                     int add_gt_as_proposals, const float *keys, int keys_stride, float pos_iou_thr,
+                     float neg_iou_thr, float min_pos_iou, int match_low_quality, int num,
+                     int num_pos_max, int n_classes, const float *means4, const float *stds4,
+                     float *rois, long long *labels, float *label_weights, float *bbox_targets,
+                     float *bbox_weights, void *workspace, size_t workspace_bytes, dm_stream_t stream);
+/* BBoxHead.loss with a sigmoid FocalLoss (gamma 2) and L1Loss: out3 = [loss_cls, loss_bbox, acc];
+ * grad_cls (n_rows, n_cls_out), grad_bbox (n_rows, 4 * (reg_class_agnostic ? 1 : n_classes)) are the
+ * gradients of out3[0] / out3[1] w.r.t. cls_score / bbox_pred. */
+int dm_bbox_head_loss(const float *cls_score, const float *bbox_pred, const long long *labels,
+                      const float *label_weights, const float *bbox_targets, const float *bbox_weights,
+                      int n_rows, int n_cls_out, int n_classes, int reg_class_agnostic,
+                      float focal_alpha, float loss_cls_weight, float loss_bbox_weight, float *out3,
+                      float *grad_cls, float *grad_bbox, dm_stream_t stream);
 /* ------------------------------------------------------------------------ */
 /* C / G. Dense 2-D convolutions (BEV backbone, anchor-head convs, ResNet-50 + FPN + RPN)      */
 /* ------------------------------------------------------------------------ */
@@ -419,6 +467,11 @@ int dm_point_focal_loss(const float *preds, const long long *labels, int n, int 
 int dm_dconv_pack(const float *src, float *dst, const float *scale_n, const float *scale_k, int S,
                   int N, int K, int Nsrc, int Ksrc, long long sn, long long sk, long long st,
                   dm_stream_t stream);
+/* The same for n_entries weights in one launch.  table_dev: device array of 80-byte rows
+ * {const float *src; float *dst; const float *scale_n, *scale_k; int64 sn, sk, st;
+ *  int32 S, N, K, Nsrc, Ksrc, pad} — every packed weight of a network is refreshed by one launch after
+ * an optimizer / EMA step instead of one launch per convolution. */
+int dm_dconv_pack_batch(const void *table_dev, int n_entries, int blocks_per_entry, dm_stream_t stream);
 size_t dm_dconv_gemm_workspace_bytes(const int *geom_host);   /* 0 unless the reduction is split */
 int dm_dconv_gemm(const float *x, const float *w_packed, const float *bias, float *y,
                   const int *geom_host, const short *taps_host, void *workspace,

@@ -128,6 +128,66 @@ def test_weight_gradient_is_reproducible_and_cache_invalidates(dev):
     assert torch.allclose(conv(x), y0, rtol=1e-5, atol=1e-5)
 
 
+def test_all_packed_weights_refresh_in_one_launch(dev):
+    """After `weights_changed()` (fused optimizer / EMA wrote through raw pointers) the first
+    convolution re-packs EVERY cached weight of the stream with one dm_dconv_pack_batch launch:
+    forward and input-gradient packings, scaled (frozen-BN fold) and plain, of several layers."""
+    import ctypes
+    from detmatch_amd import _lib, dense_conv
+    torch.manual_seed(1)
+    convs = [dense_conv.Conv2d(c_in, c_out, k, padding=k // 2, bias=False).to(dev)
+             for c_in, c_out, k in ((16, 32, 3), (32, 64, 1), (64, 24, 3))]
+    scale = torch.rand(24, device=dev) + 0.5
+    scale.dm_constant = True
+
+    def run(x):
+        x = x.clone().requires_grad_(True)
+        h = convs[1](convs[0](x))
+        y = dense_conv.conv2d(h, convs[2].weight, None, 1, 1, relu=True, w_scale=scale)
+        y.square().sum().backward()
+        return y.detach(), x.grad.clone()
+
+    def ref(x):
+        x = x.double().clone().requires_grad_(True)
+        h = torch.nn.functional.conv2d(x, convs[0].weight.double(), padding=1)
+        h = torch.nn.functional.conv2d(h, convs[1].weight.double())
+        y = torch.relu(torch.nn.functional.conv2d(h, convs[2].weight.double() * scale.double()[:, None, None, None],
+                                                  padding=1))
+        y.square().sum().backward()
+        return y.detach(), x.grad.clone()
+
+    x = torch.randn(2, 16, 20, 24, device=dev)
+    run(x)                                              # fills the cache (one pack launch per weight)
+    calls = {'single': 0, 'batch': 0}
+    L = _lib.lib()
+    real_single, real_batch = L.dm_dconv_pack, L.dm_dconv_pack_batch
+
+    class Counting(object):
+        def __getattr__(self, name):
+            fn = getattr(L, name)
+            if name in ('dm_dconv_pack', 'dm_dconv_pack_batch'):
+                def counted(*a):
+                    calls['single' if name == 'dm_dconv_pack' else 'batch'] += 1
+                    return fn(*a)
+                return counted
+            return fn
+    orig = _lib.lib
+    _lib.lib = lambda: Counting()
+    try:
+        for step in range(3):
+            with torch.no_grad():
+                for c in convs:
+                    c.weight.data.view(-1)[:] *= 1.1       # raw write: no Tensor._version bump on the Parameter
+            dense_conv.weights_changed()
+            y, gx = run(x)
+            yr, gxr = ref(x)
+            assert torch.allclose(y.double(), yr, rtol=1e-4, atol=1e-4)
+            assert torch.allclose(gx.double(), gxr, rtol=1e-4, atol=1e-3)
+    finally:
+        _lib.lib = orig
+    assert calls == {'single': 0, 'batch': 3}, calls
+
+
 def test_cpu_tensors_are_refused(monkeypatch):
     from detmatch_amd import _lib, dense_conv
     monkeypatch.setattr(dense_conv, 'TORCH_REFERENCE_FOR_TESTS', False)   # the product's setting
