@@ -77,6 +77,8 @@ SIGNATURES = {
     'dm_det2d_assign_workspace_bytes': (sz, [ci, ci]),
     'dm_rpn_loss_forward': (ci, [vp, c_int_p, ci, ci, ci, vp, vp, ci, vp, c_int_p, ci, vp, cf, cf, cf, ci, ci, ci, c_f32_p, c_f32_p, cf, cf, vp, vp, vp, vp, vp, sz, vp]),
     'dm_rpn_loss_backward': (ci, [vp, vp, vp, ci, vp, vp]),
+    'dm_rpn_proposals_workspace_bytes': (sz, [ci, ci]),
+    'dm_rpn_proposals_pre_nms': (ci, [vp, c_int_p, ci, ci, ci, vp, ci, ci, c_f32_p, ci, c_f32_p, c_f32_p, cf, ci, cf, ci, vp, vp, vp, vp, vp, vp, sz, vp]),
     'dm_roi2d_targets': (ci, [vp, vp, ci, ci, vp, vp, c_int_p, ci, ci, vp, ci, cf, cf, cf, ci, ci, ci, ci, c_f32_p, c_f32_p, vp, vp, vp, vp, vp, vp, sz, vp]),
     'dm_bbox_head_loss': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cf, vp, vp, vp, vp]),
     'dm_dconv_pack': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, vp]),

@@ -468,6 +468,183 @@ __global__ __launch_bounds__(1024) void bbox_head_loss_kernel(const float *__res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// RPNHead._get_bboxes_single up to the NMS, for all images and levels at once: per (image, level) the
+// nms_pre highest objectness scores (all anchors of the level if it has no more than that; ties go to
+// the lower anchor index), decoded and clipped boxes, "large enough" flags, and the largest coordinate
+// of the image (batched_nms separates the levels by multiples of max + 1).
+constexpr int kTopMax = 2048;
+
+struct RpnProposalCfg {
+  int nms_pre, T;                       // T = sum over levels of min(nms_pre, level size)
+  int base[DM2D_MAX_LEVELS];            // first output slot of the level
+  float img_h[DM2D_MAX_IMGS], img_w[DM2D_MAX_IMGS];
+  float mean[4], stdv[4], max_ratio, min_size;
+  int clip;
+};
+
+__device__ __forceinline__ int ordered_int(float v) {
+  const int b = __float_as_int(v);
+  return b ^ ((b >> 31) & 0x7FFFFFFF);
+}
+
+__global__ __launch_bounds__(1024) void rpn_topk_decode_kernel(RpnLevels lv, RpnProposalCfg c,
+                                                               const float *__restrict__ anchors,
+                                                               float *__restrict__ boxes, float *__restrict__ scores,
+                                                               int *__restrict__ level_of, unsigned char *__restrict__ live,
+                                                               int *__restrict__ coord_max) {
+  __shared__ unsigned hist[4096];
+  __shared__ unsigned s_prefix, s_rem, s_nl, s_nt;
+  __shared__ unsigned l_key[kTopMax], t_idx[kTopMax];
+  __shared__ int l_idx[kTopMax];
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int A = lv.A, C = lv.C, N = lv.hw[l] * A;
+  const float *y = lv.y[l] + (size_t)b * lv.hw[l] * C;
+  auto score_of = [&](int loc) {
+    const float x = y[(size_t)(loc / A) * C + (loc % A)];
+    return 1.f / (1.f + expf(-x));
+  };
+  // descending order of positive floats = ascending order of the complemented bit pattern
+  auto key_of = [&](int loc) { return 0x7FFFFFFFu - __float_as_uint(score_of(loc)); };
+  const int want = min(c.nms_pre > 0 ? c.nms_pre : N, N);
+  const bool need_select = want < N;
+  if (tid == 0) {
+    s_prefix = 0;
+    s_rem = want;
+    s_nl = 0;
+    s_nt = 0;
+  }
+  __syncthreads();
+  unsigned nl = 0;
+  if (need_select) {
+    const int shifts[3] = {20, 8, 0}, bits[3] = {12, 12, 8};
+    unsigned mask_hi = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int sh = shifts[pass], nb = 1 << bits[pass];
+      for (int i = tid; i < nb; i += 1024) hist[i] = 0;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+      for (int n = tid; n < N; n += 1024) {
+        const unsigned kb = key_of(n);
+        if ((kb & mask_hi) == prefix) atomicAdd(&hist[(kb >> sh) & (nb - 1)], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int per = nb / 64;
+        unsigned mine = 0;
+        for (int i = 0; i < per; ++i) mine += hist[tid * per + i];
+        unsigned incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          unsigned o = __shfl_up(incl, off);
+          if (tid >= off) incl += o;
+        }
+        const unsigned rem = s_rem, excl = incl - mine;
+        if (excl < rem && rem <= incl) {
+          unsigned acc = excl;
+          for (int i = 0; i < per; ++i) {
+            const unsigned h = hist[tid * per + i];
+            if (acc + h >= rem) {
+              s_prefix = prefix | ((unsigned)(tid * per + i) << sh);
+              s_rem = rem - acc;
+              break;
+            }
+            acc += h;
+          }
+        }
+      }
+      mask_hi |= (unsigned)((1 << bits[pass]) - 1) << sh;
+      __syncthreads();
+    }
+    const unsigned T = s_prefix;
+    for (int n = tid; n < N; n += 1024) {
+      const unsigned kb = key_of(n);
+      if (kb < T) {
+        const unsigned p = atomicAdd(&s_nl, 1u);
+        if (p < kTopMax) {
+          l_key[p] = kb;
+          l_idx[p] = n;
+        }
+      } else if (kb == T) {
+        const unsigned p = atomicAdd(&s_nt, 1u);
+        if (p < kTopMax) t_idx[p] = n;
+      }
+    }
+    __syncthreads();
+    nl = min(s_nl, (unsigned)kTopMax);
+    const unsigned nt = min(s_nt, (unsigned)kTopMax), take = s_rem;
+    for (unsigned i = tid; i < nt; i += 1024) {
+      unsigned r = 0;
+      for (unsigned j = 0; j < nt; ++j) r += t_idx[j] < t_idx[i];
+      if (r < take && nl + r < kTopMax) {
+        l_key[nl + r] = T;
+        l_idx[nl + r] = (int)t_idx[i];
+      }
+    }
+    nl = min(nl + min(take, nt), (unsigned)kTopMax);
+    __syncthreads();
+  }
+  int cmax = ordered_int(-3.0e38f);
+  for (int i = tid; i < want; i += 1024) {
+    int loc, r;
+    if (need_select) {
+      if ((unsigned)i >= nl) continue;
+      r = 0;
+      for (unsigned j = 0; j < nl; ++j) r += (l_key[j] < l_key[i]) | ((l_key[j] == l_key[i]) & (l_idx[j] < l_idx[i]));
+      loc = l_idx[i];
+    } else {
+      loc = r = i;
+    }
+    const int a = loc % A, cell = loc / A;
+    const float *row = y + (size_t)cell * C;
+    const float sc = 1.f / (1.f + expf(-row[a]));
+    const float *an = anchors + (size_t)(lv.first[l] + loc) * 4;
+    const float dx = row[A + 4 * a] * c.stdv[0] + c.mean[0], dy = row[A + 4 * a + 1] * c.stdv[1] + c.mean[1];
+    float dw = row[A + 4 * a + 2] * c.stdv[2] + c.mean[2], dh = row[A + 4 * a + 3] * c.stdv[3] + c.mean[3];
+    dw = fminf(fmaxf(dw, -c.max_ratio), c.max_ratio);
+    dh = fminf(fmaxf(dh, -c.max_ratio), c.max_ratio);
+    const float px = (an[0] + an[2]) * 0.5f, py = (an[1] + an[3]) * 0.5f, pw = an[2] - an[0], ph = an[3] - an[1];
+    const float gw = pw * expf(dw), gh = ph * expf(dh), gx = px + pw * dx, gy = py + ph * dy;
+    float x1 = gx - gw * 0.5f, y1 = gy - gh * 0.5f, x2 = gx + gw * 0.5f, y2 = gy + gh * 0.5f;
+    if (c.clip) {
+      x1 = fminf(fmaxf(x1, 0.f), c.img_w[b]);
+      x2 = fminf(fmaxf(x2, 0.f), c.img_w[b]);
+      y1 = fminf(fmaxf(y1, 0.f), c.img_h[b]);
+      y2 = fminf(fmaxf(y2, 0.f), c.img_h[b]);
+    }
+    const size_t o = (size_t)b * c.T + c.base[l] + r;
+    boxes[o * 4 + 0] = x1;
+    boxes[o * 4 + 1] = y1;
+    boxes[o * 4 + 2] = x2;
+    boxes[o * 4 + 3] = y2;
+    scores[o] = sc;
+    level_of[o] = l;
+    live[o] = c.min_size >= 0.f ? ((x2 - x1) > c.min_size && (y2 - y1) > c.min_size) : 1;
+    cmax = max(cmax, max(max(ordered_int(x1), ordered_int(y1)), max(ordered_int(x2), ordered_int(y2))));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+  if ((tid & 63) == 0) atomicMax(&coord_max[b], cmax);
+}
+
+// batched_nms inputs: boxes shifted by level * (max coordinate + 1); dropped boxes far away, score -1
+__global__ __launch_bounds__(256) void rpn_nms_prep_kernel(const float *__restrict__ boxes, const float *__restrict__ scores,
+                                                           const int *__restrict__ level_of,
+                                                           const unsigned char *__restrict__ live,
+                                                           const int *__restrict__ coord_max, int T,
+                                                           float *__restrict__ b_nms, float *__restrict__ s_nms) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T) return;
+  const int om = coord_max[b];
+  const float mx = __int_as_float(om ^ ((om >> 31) & 0x7FFFFFFF));
+  const size_t o = (size_t)b * T + i;
+  const float off = (float)level_of[o] * (mx + 1.f);
+  const bool lv = live[o] != 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b_nms[o * 4 + k] = lv ? boxes[o * 4 + k] + off : -1e6f;
+  s_nms[o] = lv ? scores[o] : -1.f;
+}
+
 int fill_batch(Det2DBatch &d, int batch, const float *const *gt, const int *n_gt, const float *const *boxes,
                const unsigned char *const *valid, int shared_boxes, int P, int box_stride, int prefix_gt) {
   if (batch < 1 || batch > DM2D_MAX_IMGS || P < 0 || box_stride < 4 || !gt || !n_gt || !boxes) return DM_ERR_INVALID_ARG;
@@ -647,4 +824,67 @@ extern "C" int dm_bbox_head_loss(const float *cls_score, const float *bbox_pred,
                                                              loss_bbox_weight, out3, grad_cls, grad_bbox);
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+
+extern "C" int dm_rpn_proposals_pre_nms(const float *const *level_outputs, const int *level_hw, int n_levels,
+                                        int n_base_anchors, int channels, const float *anchors, int n_anchors,
+                                        int batch, const float *img_hw, int nms_pre, const float *means4,
+                                        const float *stds4, float wh_ratio_clip_log, int clip_border,
+                                        float min_bbox_size, int n_out, float *boxes, float *scores,
+                                        unsigned char *live, float *nms_boxes, float *nms_scores,
+                                        void *workspace, size_t workspace_bytes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!level_outputs || !level_hw || !anchors || !img_hw || !means4 || !stds4 || !boxes || !scores || !live ||
+      !nms_boxes || !nms_scores || !workspace)
+    return DM_ERR_INVALID_ARG;
+  if (n_levels < 1 || n_levels > DM2D_MAX_LEVELS || batch < 1 || batch > DM2D_MAX_IMGS) return DM_ERR_INVALID_ARG;
+  if (nms_pre > kTopMax) return DM_ERR_UNSUPPORTED;
+  RpnLevels lv;
+  RpnProposalCfg c;
+  lv.n_levels = n_levels;
+  lv.A = n_base_anchors;
+  lv.C = channels;
+  int first = 0, T = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    lv.y[l] = level_outputs[l];
+    lv.hw[l] = level_hw[l];
+    lv.grad_off[l] = 0;
+    lv.first[l] = first;
+    const int n = level_hw[l] * n_base_anchors;
+    first += n;
+    c.base[l] = T;
+    T += (nms_pre > 0 && n > nms_pre) ? nms_pre : n;
+  }
+  lv.first[n_levels] = first;
+  if (first != n_anchors || T != n_out || channels < 5 * n_base_anchors) return DM_ERR_INVALID_ARG;
+  c.nms_pre = nms_pre;
+  c.T = T;
+  for (int b = 0; b < batch; ++b) {
+    c.img_h[b] = img_hw[2 * b];
+    c.img_w[b] = img_hw[2 * b + 1];
+  }
+  for (int k = 0; k < 4; ++k) {
+    c.mean[k] = means4[k];
+    c.stdv[k] = stds4[k];
+  }
+  c.max_ratio = wh_ratio_clip_log;
+  c.min_size = min_bbox_size;
+  c.clip = clip_border;
+  DmArena arena(workspace, workspace_bytes);
+  int *level_of = arena.take<int>((size_t)batch * T);
+  int *coord_max = arena.take<int>(DM2D_MAX_IMGS);
+  if (!arena.ok()) return DM_ERR_WORKSPACE;
+  DM_HIP(hipMemsetAsync(coord_max, 0x80, DM2D_MAX_IMGS * sizeof(int), st));   // very negative ordered ints
+  rpn_topk_decode_kernel<<<dim3(n_levels, batch), 1024, 0, st>>>(lv, c, anchors, boxes, scores, level_of, live,
+                                                                 coord_max);
+  DM_CHECK_LAUNCH();
+  rpn_nms_prep_kernel<<<dim3(dm_ceil_div(T, 256), batch), 256, 0, st>>>(boxes, scores, level_of, live, coord_max, T,
+                                                                        nms_boxes, nms_scores);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" size_t dm_rpn_proposals_workspace_bytes(int batch, int n_out) {
+  if (batch <= 0 || n_out <= 0) return 0;
+  return dm_align((size_t)batch * n_out * sizeof(int)) + dm_align(DM2D_MAX_IMGS * sizeof(int));
 }

@@ -181,7 +181,9 @@ class _FusedRpnLoss(torch.autograd.Function):
         (gt_bboxes, a_cfg, num, n_pos, means, stds, w_cls, w_box, n_base) = meta
         L = _lib.lib()
         ys = [dense_conv._cl(y) for y in levels]
-        _lib.require_device(anchors, keys, *ys)
+        _lib.require_device(anchors, keys)             # ys: dense NHWC (checked by _cl)
+        if not all(y.is_cuda for y in ys):
+            raise _lib.DetMatchHipError('the RPN loss kernel runs on the MI355X only')
         b, c = int(ys[0].shape[0]), int(ys[0].shape[1])
         hw = [int(y.shape[2] * y.shape[3]) for y in ys]
         offs, total = [], 0
@@ -314,7 +316,8 @@ class RPNHead(nn.Module):
             keys = torch.rand((cls[0].shape[0], anchors.shape[0]), device=anchors.device)
         raw = getattr(self, '_raw_levels', None)
         if fused and anchors.is_cuda and raw is not None and len(raw) == len(cls) \
-                and all(c._base is y for c, y in zip(cls, raw)) and cls[0].shape[0] <= 8 \
+                and all(c.data_ptr() == y.data_ptr() and c.shape[2:] == y.shape[2:] and c.requires_grad == y.requires_grad
+                        for c, y in zip(cls, raw)) and cls[0].shape[0] <= 8 \
                 and max(g.shape[0] for g in gt_bboxes) <= 256:
             meta = (list(gt_bboxes), a_cfg, int(s_cfg['num']), int(s_cfg['num'] * s_cfg['pos_fraction']),
                     self.bbox_coder.means, self.bbox_coder.stds, self.loss_cls_weight, self.loss_bbox_weight,
@@ -347,14 +350,55 @@ class RPNHead(nn.Module):
         return dict(loss_rpn_cls=self.loss_cls_weight * tot_cls / tot_n,
                     loss_rpn_bbox=self.loss_bbox_weight * tot_box / tot_n)
 
+    def _pre_nms_device(self, raw, sizes, img_metas, cfg):
+        """dm_rpn_proposals_pre_nms: top-k per level, decode, flags and batched-NMS inputs of every image
+        in two launches -> boxes (B, T, 4), scores (B, T), live (B, T) bool, nms boxes / scores."""
+        import ctypes
+        L = _lib.lib()
+        ys = [dense_conv._cl(y.detach()) for y in raw]
+        b, c, a = int(ys[0].shape[0]), int(ys[0].shape[1]), self.num_anchors
+        hw = [int(h * w) for h, w in sizes]
+        nms_pre = int(cfg['nms_pre'])
+        t = sum(min(nms_pre, n * a) if nms_pre > 0 else n * a for n in hw)
+        anchors = self._all_anchors(sizes, ys[0].device)
+        dev = anchors.device
+        boxes = torch.empty((b, t, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((b, t), dtype=torch.float32, device=dev)
+        live = torch.empty((b, t), dtype=torch.bool, device=dev)
+        b_nms, s_nms = torch.empty_like(boxes), torch.empty_like(scores)
+        img_hw = []
+        for m in img_metas:
+            img_hw += [float(m['img_shape'][0]), float(m['img_shape'][1])]
+        ws = _lib.workspace(L.dm_rpn_proposals_workspace_bytes(b, t), dev, 'rpn_props')
+        coder = self.bbox_coder
+        _lib.check(L.dm_rpn_proposals_pre_nms(
+            _ptr_array(ys), _lib.ints(hw), len(ys), a, c, _lib.ptr(anchors), int(anchors.shape[0]), b,
+            _lib.floats(img_hw), nms_pre, _lib.floats(coder.means), _lib.floats(coder.stds),
+            float(abs(np.log(16 / 1000))), int(bool(coder.clip_border)), float(cfg.get('min_bbox_size', 0)), t,
+            _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(live), _lib.ptr(b_nms), _lib.ptr(s_nms), _lib.ptr(ws),
+            ws.numel(), _lib.stream()), 'dm_rpn_proposals_pre_nms')
+        return boxes, scores, live, b_nms, s_nms
+
     @torch.no_grad()
-    def get_bboxes(self, cls, reg, img_metas, cfg):
+    def get_bboxes(self, cls, reg, img_metas, cfg, fused=True):
         """mmdet RPNHead._get_bboxes_single per image: per-level top nms_pre, decode, drop empty
         boxes, NMS across levels (boxes of different levels never suppress each other), keep
         max_per_img.  -> list of (proposals (max_per_img, 5) [x1,y1,x2,y2,score], ok (max_per_img))."""
         sizes = [c.shape[-2:] for c in cls]
-        mlvl_anchors = self.anchor_generator.grid_anchors(sizes, cls[0].device)
         nms_thr = cfg['nms'].get('iou_threshold', cfg['nms'].get('iou_thr', 0.7))
+        raw = getattr(self, '_raw_levels', None)
+        if fused and cls[0].is_cuda and raw is not None and len(raw) == len(cls) and cls[0].shape[0] <= 8 \
+                and 0 < cfg['nms_pre'] <= 2048 \
+                and all(c.data_ptr() == y.data_ptr() and c.shape[2:] == y.shape[2:] for c, y in zip(cls, raw)):
+            boxes, s, live, b_nms, s_nms = self._pre_nms_device(raw, sizes, img_metas, cfg)
+            out = []
+            for i in range(cls[0].shape[0]):
+                idx, ok = nms_fixed(b_nms[i], s_nms[i], nms_thr, cfg['max_per_img'])
+                ok = ok & live[i][idx]
+                props = torch.cat([boxes[i][idx], s[i][idx, None]], dim=1) * ok[:, None].float()
+                out.append((props, ok))
+            return out
+        mlvl_anchors = self.anchor_generator.grid_anchors(sizes, cls[0].device)
         out = []
         for i in range(cls[0].shape[0]):
             ss, dd, aa, ll = [], [], [], []

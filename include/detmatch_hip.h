@@ -411,6 +411,20 @@ int dm_rpn_loss_forward(const float *const *level_outputs, const int *level_hw, 
                         void *workspace, size_t workspace_bytes, dm_stream_t stream);
 int dm_rpn_loss_backward(const long long *entry_offsets, const float *entry_values,
                          const float *upstream2, int n_entries, float *grad_flat, dm_stream_t stream);
+/* RPNHead.get_bboxes up to the NMS for all images and levels in two launches: per (image, level) the
+ * nms_pre highest objectness scores (ties: lower anchor index), DeltaXYWHBBoxCoder.decode with border
+ * clipping, min_bbox_size flags, and the batched_nms inputs (boxes shifted by level * (max coordinate
+ * of the image + 1), dropped boxes at -1e6 with score -1).  n_out = sum_l min(nms_pre, H_l W_l A);
+ * img_hw = {h_0, w_0, h_1, w_1, ...}; wh_ratio_clip_log = |log(wh_ratio_clip)|.  Outputs (B, n_out, ...),
+ * level-major, score-descending within a level. */
+size_t dm_rpn_proposals_workspace_bytes(int batch, int n_out);
+int dm_rpn_proposals_pre_nms(const float *const *level_outputs, const int *level_hw, int n_levels,
+                             int n_base_anchors, int channels, const float *anchors, int n_anchors,
+                             int batch, const float *img_hw, int nms_pre, const float *means4,
+                             const float *stds4, float wh_ratio_clip_log, int clip_border,
+                             float min_bbox_size, int n_out, float *boxes, float *scores,
+                             unsigned char *live, float *nms_boxes, float *nms_scores, void *workspace,
+                             size_t workspace_bytes, dm_stream_t stream);
 /* StandardRoIHead.forward_train up to the RoI extractor: assign (proposals, optionally with the GT
  * boxes in front), sample `num` RoIs per image (at most num_pos_max positives), BBoxHead.get_targets.
  * proposals[b]: (n_proposals, proposal_stride) rows with xyxy first, proposal_ok[b]: (n_proposals) bool.

@@ -50,6 +50,7 @@ def test_rpn_loss_kernel_matches_tensor_formulation(dev, n_gt):
         n_anchor = sum(h * w * 3 for h, w in sizes)
         keys = torch.rand((2, n_anchor), generator=torch.Generator().manual_seed(77)).to(dev)
         losses = head.loss(cls, reg, gts, None, fused=fused, keys=keys)
+        assert ('FusedRpnLoss' in type(losses['loss_rpn_cls'].grad_fn.next_functions[0][0]).__name__) == fused
         (losses['loss_rpn_cls'] * 0.7 + losses['loss_rpn_bbox'] * 1.9).backward()
         res.append((losses, [f.grad.clone() for f in feats], head.rpn_conv.weight.grad.clone()))
         head.zero_grad()
@@ -150,3 +151,30 @@ def test_faster_rcnn_step_fused_equals_tensor_path(dev):
         close(out[0][0][k], out[1][0][k], rtol=1e-4, atol=1e-6)
     close(out[0][1], out[1][1], rtol=2e-3, atol=1e-6)
     close(out[0][2], out[1][2], rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize('phase', ['train', 'test'])
+def test_rpn_proposal_kernel_matches_tensor_formulation(dev, phase):
+    """Per-level top-k + decode + batched-NMS inputs in two launches == the per-image tensor chain:
+    the same proposals in the same order."""
+    m = _frcnn(dev)
+    head = m.rpn_head
+    with torch.no_grad():
+        head.rpn_cls.weight.normal_(std=0.05)
+        head.rpn_reg.weight.normal_(std=0.03)
+    sizes = [(96, 312), (48, 156), (24, 78), (12, 39), (6, 20)]
+    feats = [torch.randn(2, 256, h, w, generator=torch.Generator().manual_seed(20 + i))
+             .to(dev).contiguous(memory_format=torch.channels_last) for i, (h, w) in enumerate(sizes)]
+    metas = [dict(img_shape=(375, 1242, 3)), dict(img_shape=(384, 1248, 3))]
+    cfg = m.train_cfg['rpn_proposal'] if phase == 'train' else m.test_cfg['rpn']
+    with torch.no_grad():
+        cls, reg = head(feats)
+        a = head.get_bboxes(cls, reg, metas, cfg)
+        b = head.get_bboxes(cls, reg, metas, cfg, fused=False)
+        pre = head._pre_nms_device(head._raw_levels, [c.shape[-2:] for c in cls], metas, cfg)
+    t = sum(min(cfg['nms_pre'], h * w * 3) for h, w in sizes)
+    assert pre[0].shape == (2, t, 4) and bool(pre[2].any())
+    for (pa, oka), (pb, okb) in zip(a, b):
+        assert pa.shape == (cfg['max_per_img'], 5) and int(oka.sum()) > 100
+        assert torch.equal(oka, okb)
+        assert torch.equal(pa, pb)
