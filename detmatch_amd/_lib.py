@@ -155,8 +155,14 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def raw_stream():
+    """The current HIP stream handle of the current device as an int (torch.cuda.current_stream()
+    builds a Stream object through several Python layers: ~8 us per call, thousands of calls a step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(raw_stream())
 
 
 def ints(v):
@@ -174,8 +180,11 @@ def workspace(nbytes, device, tag='default'):
     """A reusable byte workspace per (device, HIP stream, tag); grows geometrically.  Keyed by the
     current stream: work queued on different streams (2D / 3D lanes, FPS side stream) never shares
     scratch memory."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0, tag)
+    if device.type == 'cuda':
+        idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+        key = (idx, torch._C._cuda_getCurrentRawStream(idx), tag)
+    else:
+        key = (-1, 0, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)

@@ -126,7 +126,7 @@ def _refresh_stream(stream, device):
 def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None):
     """[S][N][K] packed copy of `weight` (cached until the weight or a scale changes)."""
     cacheable = isinstance(weight, nn.Parameter)     # temporaries may recycle an address
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = _lib.raw_stream()
     key = (id(weight), weight.data_ptr(), tag, N, K, stream)
     ver = (_GENERATION[0], weight._version, _scale_id(scale_n), _scale_id(scale_k))
     hit = _PACK_CACHE.get(key) if cacheable else None
@@ -161,27 +161,45 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
     return dst
 
 
+_PLAN_CACHE = {}     # (kind, geometry, taps) -> (ctypes geometry, ctypes taps, workspace bytes)
+
+
+def _plan(kind, geom, taps):
+    """The marshalled argument arrays of one launch geometry (a network has a few dozen; building
+    ctypes arrays per call costs more host time than the launch)."""
+    key = (kind, tuple(geom), tuple(taps))
+    hit = _PLAN_CACHE.get(key)
+    if hit is None:
+        L = _lib.lib()
+        g = _lib.ints(geom)
+        if kind == 'gemm':
+            t = [a for a, _, _ in taps] + [b for _, b, _ in taps] + [c for _, _, c in taps]
+            nbytes = L.dm_dconv_gemm_workspace_bytes(g)
+        else:
+            t = [a for a, _ in taps] + [b for _, b in taps]
+            nbytes = L.dm_dconv_wgrad_workspace_bytes(g)
+        if len(_PLAN_CACHE) > 4096:
+            _PLAN_CACHE.clear()
+        hit = _PLAN_CACHE[key] = (g, _shorts(t), int(nbytes))
+    return hit
+
+
 def _gemm(x, wp, bias, y, geom, taps):
     """geom: the 17 ints of dm_dconv_gemm; taps: [(dy, dx, slice)]."""
-    t = [a for a, _, _ in taps] + [b for _, b, _ in taps] + [c for _, _, c in taps]
-    L = _lib.lib()
-    g = _lib.ints(geom)
-    nbytes = L.dm_dconv_gemm_workspace_bytes(g)
+    g, t, nbytes = _plan('gemm', geom, taps)
     ws = _lib.workspace(nbytes, x.device, 'dconv_gemm') if nbytes else None
-    _lib.check(L.dm_dconv_gemm(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y), g, _shorts(t),
-                               _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
+    _lib.check(_lib.lib().dm_dconv_gemm(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
+                                        y.data_ptr(), g, t, None if ws is None else ws.data_ptr(),
+                                        ws.numel() if ws is not None else 0, _lib.raw_stream()),
                'dm_dconv_gemm')
 
 
 def _wgrad(U, V, out, scale_u, geom, taps, cv_out, su, sv, st):
-    L = _lib.lib()
-    g = _lib.ints(geom)
-    nbytes = L.dm_dconv_wgrad_workspace_bytes(g)
+    g, t, nbytes = _plan('wgrad', geom, taps)
     ws = _lib.workspace(nbytes, U.device, 'dconv_wgrad')
-    t = [a for a, _ in taps] + [b for _, b in taps]
-    _lib.check(L.dm_dconv_wgrad(_lib.ptr(U), _lib.ptr(V), _lib.ptr(out), _lib.ptr(scale_u), g,
-                                _shorts(t), cv_out, su, sv, st, 0, _lib.ptr(ws), ws.numel(),
-                                _lib.stream()), 'dm_dconv_wgrad')
+    _lib.check(_lib.lib().dm_dconv_wgrad(U.data_ptr(), V.data_ptr(), out.data_ptr(),
+                                         None if scale_u is None else scale_u.data_ptr(), g, t, cv_out, su, sv,
+                                         st, 0, ws.data_ptr(), ws.numel(), _lib.raw_stream()), 'dm_dconv_wgrad')
 
 
 def _pair(v):

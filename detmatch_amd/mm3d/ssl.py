@@ -438,6 +438,32 @@ class SSL(nn.Module):
             return self.forward_train(**kwargs)
         return self.forward_test(**kwargs)
 
+    def _run_and_backprop(self, run, module, d, early, ssl_weight):
+        """Run one SSL module; when it is flagged `self_contained_losses` (its forward adds losses and
+        nothing else) back-propagate the new loss terms right away, with the weight they carry in the
+        final sum, and keep their detached values.  Scheduling only (d(sum) = sum of d): the
+        device-bound backward of that pass then runs underneath the host-bound modules that follow,
+        and its graph is freed early.  Gradients accumulate as for any second backward pass."""
+        if not (early and getattr(module, 'self_contained_losses', False)):
+            return run(module, d)
+        before = {k: dict(d[k]) for k in ('sup_losses', 'ssl_losses') if k in d}
+        d = run(module, d)
+        terms = []
+        for group, old in before.items():
+            w = 1.0 if group == 'sup_losses' else float(ssl_weight)
+            cur = self._collapse_losses(d[group])
+            for k, v in cur.items():
+                if (k not in old or old[k] is not v) and v.requires_grad:
+                    if k in old:      # a key two modules add to: only its sum exists any more
+                        return d
+                    if 'loss' in k:
+                        terms.append(v if (w == 1.0 or '.metrics' in k or '.acc' in k) else v * w)
+                    cur[k] = v.detach()
+            d[group] = cur
+        if terms:
+            sum(terms).backward()
+        return d
+
     def forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
         """ssl.py:255-350"""
         if isinstance(unlab_stu, list):
@@ -478,8 +504,10 @@ class SSL(nn.Module):
             for m in sorted(hoisted, key=lambda m: getattr(m, 'has_readback', False)):   # read-back last
                 unlab_dict = run(m, unlab_dict)
             unlab_modules = [m for m in unlab_modules if m not in hoisted]
+        early = lanes is None and getattr(self, 'early_backward', False) and torch.is_grad_enabled()
+        curr_ssl_weight = self._get_curr_ssl_weight()
         for m in self.lab_ssl_modules:
-            lab_dict = run(m, lab_dict)
+            lab_dict = self._run_and_backprop(run, m, lab_dict, early, curr_ssl_weight)
         if lanes is not None:
             lanes.join(lab_dict['sup_losses'], lab_dict['ssl_losses'])
         if getattr(self, 'early_backward', False) and torch.is_grad_enabled():
@@ -496,7 +524,7 @@ class SSL(nn.Module):
                     hook()
             lab_dict['sup_losses'] = {k: v.detach() for k, v in sup.items()}
         for m in unlab_modules:
-            unlab_dict = run(m, unlab_dict)
+            unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
         if lanes is not None:
             lanes.join(unlab_dict['ssl_losses'], lab_dict['ssl_losses'])
         losses = dict()
@@ -508,7 +536,6 @@ class SSL(nn.Module):
         for tag, d in (('lab', lab_dict), ('unlab', unlab_dict)):
             vis_dict.update({'%s/%s' % (tag, k): v for k, v in d.get('vis', {}).items()})
             log_vars_dict.update({'%s/%s' % (tag, k): v for k, v in d.get('log_vars', {}).items()})
-        curr_ssl_weight = self._get_curr_ssl_weight()
         ref = list(losses.values())[0] if len(losses) else list(ssl_losses.values())[0]
         losses['ssl.weight'] = torch.full((), float(curr_ssl_weight), dtype=ref.dtype, device=ref.device)
         ssl_losses = self._collapse_losses(ssl_losses)

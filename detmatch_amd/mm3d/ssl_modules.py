@@ -152,6 +152,10 @@ class Opd_HardPseudoLabel_3D(object):
 class Opd_Supervised_3D(object):
     """consumers/openpcdet.py:215-253"""
 
+    # forward() adds losses and nothing else: no later module reads tensors of this pass's autograd
+    # graph, so SSL.forward_train may back-propagate these losses as soon as they exist
+    self_contained_losses = True
+
     def __init__(self, ssl_obj_attr='student', batch_dict_key='stu', name='sup_3d', weight=1):
         self.ssl_obj_attr = ssl_obj_attr
         self.batch_dict_key = batch_dict_key
@@ -413,6 +417,10 @@ class AverageBboxes_2D(object):
 class TwoStageSupervised_2D(object):
     """consumers_2d.py:8-52"""
 
+    # forward() adds losses and nothing else: no later module reads tensors of this pass's autograd
+    # graph, so SSL.forward_train may back-propagate these losses as soon as they exist
+    self_contained_losses = True
+
     def __init__(self, loss_detach_keys=[], ssl_obj_attr='student', batch_dict_key='stu'):
         self.loss_detach_keys = loss_detach_keys
         self.ssl_obj_attr = ssl_obj_attr
@@ -432,6 +440,10 @@ class TwoStageSupervised_2D(object):
 @SSL_MODULES.register_module()
 class HardPseudoLabel_2D(object):
     """consumers_2d.py:55-121"""
+
+    # forward() adds losses and nothing else: no later module reads tensors of this pass's autograd
+    # graph, so SSL.forward_train may back-propagate these losses as soon as they exist
+    self_contained_losses = True
 
     def __init__(self, score_thr, cls_includes_bg_pred, loss_detach_keys=[], ssl_obj_attr='student',
                  target_bboxes_key='tea.2d_bboxes_nms_stu_aug', target_img_key='stu.img',

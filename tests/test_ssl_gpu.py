@@ -158,13 +158,15 @@ def test_fused_optimizer_matches_torch(dev):
                 assert torch.allclose(pc, pb, rtol=2e-5, atol=2e-6), (it, n)
 
 
-def test_early_backward_and_prefetch_do_not_change_gradients(dev):
-    """Scheduling options (supervised part back-propagated early; geometry of all passes issued
-    up front) leave the accumulated gradient unchanged."""
+@pytest.mark.parametrize('ssl_cfg', ['confthr_pvrcnn', None])
+def test_early_backward_and_prefetch_do_not_change_gradients(dev, ssl_cfg):
+    """Scheduling options (self-contained passes back-propagated as soon as their losses exist;
+    geometry of all passes issued up front) leave the accumulated gradient and the logged losses
+    unchanged (None = the full DetMatch recipe)."""
     from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
-    flats = []
+    flats, logs = [], []
     for early in (True, False):
-        wl = DetMatchTrainWorkload(2, dev, ssl_cfg='confthr_pvrcnn')
+        wl = DetMatchTrainWorkload(2, dev, ssl_cfg=ssl_cfg)
         wl.model.early_backward = early
         if not early:   # also disable the geometry prepass for the plain run
             for m in wl.model.lab_ssl_modules + wl.model.unlab_ssl_modules:
@@ -173,11 +175,15 @@ def test_early_backward_and_prefetch_do_not_change_gradients(dev):
         torch.manual_seed(123)
         wl.step()
         flats.append(wl.ddp.flat.clone())
+        logs.append({k: float(v) for k, v in wl.last_log.items()})
         del wl
     a, b = flats
     assert torch.isfinite(a).all() and a.abs().sum() > 0
     rel = (a - b).norm() / b.norm()
     assert rel < 1e-3, float(rel)      # float atomics: run-to-run noise ~1e-5..1e-4
+    assert set(logs[0]) == set(logs[1])
+    for k in logs[0]:
+        assert abs(logs[0][k] - logs[1][k]) <= 1e-3 * max(1.0, abs(logs[1][k])), k
 
 
 @pytest.mark.parametrize('mode', ['branches', 'glue'])

@@ -1,5 +1,6 @@
-"""cProfile of the host side of 5 DetMatch iterations (top functions by own time): where the Python /
-launch overhead of the step goes (blocking read-backs show up as `tolist` / `item` / `nonzero`).
+"""cProfile of the host side of 5 DetMatch iterations: top functions by own time and by cumulative
+time (where the Python / launch overhead of the step goes; blocking read-backs show up as `tolist` /
+`item` / `nonzero`).
 
     python tools/host_profile.py
 """
@@ -15,7 +16,7 @@ pr.enable()
 for _ in range(5): wl.step()
 torch.cuda.synchronize()
 pr.disable()
-s = io.StringIO()
-st = pstats.Stats(pr, stream=s).sort_stats('tottime')
-st.print_stats(45)
-print(s.getvalue()[:9000])
+for key, n in (('tottime', 45), ('cumulative', 110)):
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(n)
+    print(s.getvalue()[:16000])
