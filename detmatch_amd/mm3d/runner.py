@@ -328,7 +328,8 @@ class OptimizerHook(Hook):
             ddp.zero_grad()
         else:
             runner.optimizer.zero_grad()
-        runner.outputs['loss'].backward()
+        if runner.outputs['loss'].requires_grad:     # else: every term was back-propagated inside train_step
+            runner.outputs['loss'].backward()
         if ddp is not None:
             ddp.finish()
         if self.grad_clip is not None:
