@@ -68,6 +68,8 @@ SIGNATURES = {
     'dm_sgd_step_masked_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp, vp]),
     'dm_anchor_assign_workspace_bytes': (sz, [ci, ci, ci]),
     'dm_anchor_assign': (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
+    'dm_bev_interpolate_forward': (ci, [vp, ci, ci, ci, ci, vp, ci, ci, c_f32_p, vp, vp, vp, vp]),
+    'dm_bev_interpolate_backward': (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     'dm_roi_targets_workspace_bytes': (sz, [ci, ci]),
     'dm_roi_targets': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'dm_rcnn_loss_forward': (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, c_f32_p, c_f32_p, cf, ci, vp, vp, vp, vp, vp]),

@@ -68,3 +68,33 @@ def bn_relu_rows(x, bn, relu=True):
     y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
                      bn.momentum if bn.momentum is not None else 0.0, bn.eps)
     return F.relu(y, inplace=True) if relu else y
+
+
+def fc_rows(seq, x):
+    """An nn.Sequential of Linear / Conv1d(kernel 1) + BatchNorm1d + ReLU (+ Dropout) layers — the FC
+    stacks of the PV-RCNN heads (pvrcnn_head.py:25-52 builds them from Conv1d on (N, C, 1) tensors,
+    point_head_template.py:34-47 and voxel_set_abstraction.py:107-111 from Linear) — evaluated on the
+    (N, C) row view with the same parameters and state-dict keys: a plain GEMM per layer and the
+    fused BatchNorm+ReLU row kernel instead of one convolution / batch-norm library call per layer."""
+    import torch.nn as nn
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv1d):
+            assert m.kernel_size == (1,) and m.stride == (1,) and m.padding == (0,) and m.groups == 1
+            x = F.linear(x, m.weight.squeeze(-1), m.bias)
+        elif isinstance(m, nn.Linear):
+            x = F.linear(x, m.weight, m.bias)
+        elif isinstance(m, nn.BatchNorm1d):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = bn_relu_rows(x, m, relu=relu)
+            i += int(relu)
+        elif isinstance(m, nn.Dropout):
+            x = F.dropout(x, m.p, m.training, False)
+        elif isinstance(m, nn.ReLU):
+            x = F.relu(x)
+        else:
+            raise TypeError('unexpected layer %s in an FC stack' % type(m).__name__)
+        i += 1
+    return x

@@ -22,6 +22,7 @@ from .. import dense_conv
 from .. import roiaware_pool3d
 from ..devconst import const
 from . import utils as U
+from ..bn_relu import fc_rows
 
 
 # ------------------------------------------------------------------- anchors
@@ -618,7 +619,7 @@ class PointHeadSimple(nn.Module):
             point_features = batch_dict['point_features_before_fusion']
         else:
             point_features = batch_dict['point_features']
-        point_cls_preds = self.cls_layers(point_features)
+        point_cls_preds = fc_rows(self.cls_layers, point_features)
         ret_dict = {'point_cls_preds': point_cls_preds}
         batch_dict['point_cls_scores'], _ = torch.sigmoid(point_cls_preds).max(dim=-1)
         if self.training:

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import pointnet2_stack as pn2
+from ..bn_relu import fc_rows
 from ..devconst import upload
 from .utils import get_voxel_centers
 
@@ -40,6 +41,40 @@ def bilinear_interpolate_torch(im, x, y):
     wc = (x - x0.type_as(x)) * (y1.type_as(y) - y)
     wd = (x - x0.type_as(x)) * (y - y0.type_as(y))
     return Ia * wa[:, None] + Ib * wb[:, None] + Ic * wc[:, None] + Id * wd[:, None]
+
+
+class _BevInterpolate(torch.autograd.Function):
+    """dm_bev_interpolate_forward / _backward (csrc/bev_interp.hip): (B, C, H, W) channels_last map,
+    key points (B, K, 3) -> (B, K, C); gradient w.r.t. the map only (key points are sampled points)."""
+
+    @staticmethod
+    def forward(ctx, bev, keypoints, geom):
+        from .. import _lib, dense_conv
+        im = dense_conv._cl(bev.detach())
+        kp = keypoints.detach().float().contiguous()
+        b, c, h, w = im.shape
+        k = int(kp.shape[1])
+        out = torch.empty((b, k, c), dtype=torch.float32, device=im.device)
+        cells = torch.empty((b, k, 4), dtype=torch.int32, device=im.device)
+        weights = torch.empty((b, k, 4), dtype=torch.float32, device=im.device)
+        _lib.check(_lib.lib().dm_bev_interpolate_forward(
+            im.data_ptr(), b, h, w, c, kp.data_ptr(), int(kp.shape[2]), k, _lib.floats(geom), out.data_ptr(),
+            cells.data_ptr(), weights.data_ptr(), _lib.raw_stream()), 'dm_bev_interpolate_forward')
+        ctx.save_for_backward(cells, weights)
+        ctx.shape = (b, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        from .. import _lib
+        cells, weights = ctx.saved_tensors
+        b, c, h, w = ctx.shape
+        grad = grad.contiguous()
+        gim = torch.empty((b, h, w, c), dtype=torch.float32, device=grad.device)
+        _lib.check(_lib.lib().dm_bev_interpolate_backward(
+            grad.data_ptr(), cells.data_ptr(), weights.data_ptr(), b, h, w, c, int(cells.shape[1]),
+            gim.data_ptr(), _lib.raw_stream()), 'dm_bev_interpolate_backward')
+        return gim.permute(0, 3, 1, 2), None, None
 
 
 class VoxelSetAbstraction(nn.Module):
@@ -83,7 +118,11 @@ class VoxelSetAbstraction(nn.Module):
         self.num_point_features = self.model_cfg.NUM_OUTPUT_FEATURES
         self.num_point_features_before_fusion = c_in
 
-    def interpolate_from_bev_features(self, keypoints, bev_features, batch_size, bev_stride):
+    def interpolate_from_bev_features(self, keypoints, bev_features, batch_size, bev_stride, fused=True):
+        if fused and keypoints.is_cuda and bev_features.shape[1] % 4 == 0 and bev_features.shape[1] <= 1024:
+            geom = (float(self.point_cloud_range[0]), float(self.point_cloud_range[1]),
+                    float(self.voxel_size[0]), float(self.voxel_size[1]), float(bev_stride))
+            return _BevInterpolate.apply(bev_features, keypoints, geom)
         x_idxs = (keypoints[:, :, 0] - self.point_cloud_range[0]) / self.voxel_size[0] / bev_stride
         y_idxs = (keypoints[:, :, 1] - self.point_cloud_range[1]) / self.voxel_size[1] / bev_stride
         out = []
@@ -184,7 +223,7 @@ class VoxelSetAbstraction(nn.Module):
         batch_idx = torch.arange(batch_size, device=dev).view(-1, 1).repeat(1, num_keypoints).view(-1)
         point_coords = torch.cat((batch_idx.view(-1, 1).float(), keypoints.view(-1, 3)), dim=1)
         batch_dict['point_features_before_fusion'] = point_features.view(-1, point_features.shape[-1])
-        batch_dict['point_features'] = self.vsa_point_feature_fusion(
-            point_features.view(-1, point_features.shape[-1]))
+        batch_dict['point_features'] = fc_rows(self.vsa_point_feature_fusion,
+                                               point_features.view(-1, point_features.shape[-1]))
         batch_dict['point_coords'] = point_coords
         return batch_dict

@@ -20,6 +20,7 @@ from .. import _lib, iou3d_nms
 from ..devconst import const
 from .. import pointnet2_stack as pn2
 from . import utils as U
+from ..bn_relu import fc_rows
 from .dense_heads import valid_gt_mask
 from .pfe import batch_row_counts
 
@@ -406,9 +407,9 @@ class PVRCNNHead(nn.Module):
         pooled = self.roi_grid_pool(batch_dict)                           # (B*N, 216, C)
         n_rcnn = pooled.shape[0]
         pooled = pooled.permute(0, 2, 1).contiguous()                    # (B*N, C, 216)
-        shared = self.shared_fc_layer(pooled.view(n_rcnn, -1, 1))
-        rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
-        rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        shared = fc_rows(self.shared_fc_layer, pooled.view(n_rcnn, -1))
+        rcnn_cls = fc_rows(self.cls_layers, shared)                # (B*N, 1 or num_class)
+        rcnn_reg = fc_rows(self.reg_layers, shared)                # (B*N, code_size * ...)
         batch_cls_preds, batch_box_preds = self.generate_predicted_boxes(
             batch_dict['batch_size'], batch_dict['rois'], rcnn_cls, rcnn_reg)
         batch_dict['batch_cls_preds'] = batch_cls_preds

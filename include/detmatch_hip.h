@@ -338,6 +338,20 @@ int dm_anchor_assign(const float *anchors, const float *anchors_bev, const float
                      const float *unmatched, int B, int M, int C, int A, int R, int num_class,
                      int *labels, float *reg_targets, float *reg_weights, void *workspace,
                      size_t workspace_bytes, dm_stream_t stream);
+/* D. Key-point features from the BEV map (VoxelSetAbstraction.interpolate_from_bev_features +
+ * bilinear_interpolate_torch, pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:9-40,113-117).
+ * bev_nhwc (B, H, W, C) (C % 4 == 0, <= 1024); keypoints: B * n_keypoints rows of keypoint_stride floats
+ * starting at (x, y); geom5 = {range_x0, range_y0, voxel_x, voxel_y, bev_stride}.  out (B, K, C); cells
+ * (B, K, 4) int32 and weights (B, K, 4) are the four cells / weights of every key point (clamped as in
+ * the reference), kept for the backward pass, which writes the whole gradient map (zeros + one
+ * deterministic scatter, no atomics). */
+int dm_bev_interpolate_forward(const float *bev_nhwc, int batch, int height, int width, int channels,
+                               const float *keypoints, int keypoint_stride, int n_keypoints,
+                               const float *geom5, float *out, int *cells, float *weights,
+                               dm_stream_t stream);
+int dm_bev_interpolate_backward(const float *grad_out, const int *cells, const float *weights, int batch,
+                                int height, int width, int channels, int n_keypoints,
+                                float *grad_bev_nhwc, dm_stream_t stream);
 /* D / E. Second-stage targets and losses of PV-RCNN, one or two launches per call for the whole batch.
  *
  * dm_roi_targets replaces ProposalTargetLayer.forward (sample_rois_for_rcnn, subsample_rois,
