@@ -19,6 +19,8 @@
 // Algorithmic bytes per pair: (cin + cout)*4 + 8.
 #include <hip/hip_ext.h>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "dm_common.h"
 
 // Input channels per pipeline step of spconv_gr = 16 * DM_GR_CTS.  2 (32 channels, 8 KiB of weights
@@ -752,6 +754,64 @@ extern "C" int dm_spconv_tile_order(const int32_t *nbr, int n_rows, int kvol, in
   return DM_OK;
 }
 
+// ---- packing rows with equal neighbour masks into the same tiles --------------------------------
+// A 16-row tile pays a full 16 x cin x cout MFMA block for every kernel offset that ANY of its rows
+// uses.  In rulebook (raster) order only 40-72 % of those rows exist; after a stable sort of the rows
+// by their neighbour mask 72-89 % do (tools/spconv_pack_probe.py), i.e. 20-45 % fewer (tile, offset)
+// units, their weights and MFMA work.  Like the tile order this is a property of the gather table:
+// built once per rulebook (mask keys, one radix sort, one gather), reused by every launch on it; the
+// kernels write row p of the packed order to out[perm[p]].
+__global__ __launch_bounds__(256) void row_mask_kernel(const int32_t *__restrict__ nbr, int n_rows, int kvol,
+                                                       uint32_t *__restrict__ keys, int32_t *__restrict__ idx) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  uint32_t m = 0u;
+  for (int k = 0; k < kvol; ++k) m |= (nbr[(size_t)k * n_rows + r] >= 0 ? 1u : 0u) << k;
+  keys[r] = m;
+  idx[r] = r;
+}
+
+__global__ __launch_bounds__(256) void row_gather_kernel(const int32_t *__restrict__ nbr, int n_rows, int kvol,
+                                                         const int32_t *__restrict__ perm,
+                                                         int32_t *__restrict__ packed) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_rows) return;
+  const int r = perm[p];
+  for (int k = 0; k < kvol; ++k) packed[(size_t)k * n_rows + p] = nbr[(size_t)k * n_rows + r];
+}
+
+extern "C" size_t dm_spconv_pack_rows_workspace_bytes(int n_rows) {
+  if (n_rows <= 0) return 0;
+  size_t need = 0;
+  uint32_t *k = nullptr;
+  int32_t *v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, need, k, k, v, v, (size_t)n_rows, 0, 32, (hipStream_t)0);
+  return 3 * dm_align((size_t)n_rows * 4) + dm_align(need);
+}
+
+extern "C" int dm_spconv_pack_rows(const int32_t *nbr, int n_rows, int kvol, int32_t *perm,
+                                   int32_t *nbr_packed, void *workspace, size_t workspace_bytes,
+                                   dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rows < 0 || kvol <= 0 || kvol > 32) return DM_ERR_INVALID_ARG;
+  if (n_rows == 0) return DM_OK;
+  if (!nbr || !perm || !nbr_packed || !workspace) return DM_ERR_INVALID_ARG;
+  if (workspace_bytes < dm_spconv_pack_rows_workspace_bytes(n_rows)) return DM_ERR_WORKSPACE;
+  DmArena arena(workspace, workspace_bytes);
+  uint32_t *keys = arena.take<uint32_t>(n_rows), *keys_s = arena.take<uint32_t>(n_rows);
+  int32_t *idx = arena.take<int32_t>(n_rows);
+  size_t need = 0;
+  DM_HIP(rocprim::radix_sort_pairs(nullptr, need, keys, keys_s, idx, perm, (size_t)n_rows, 0, kvol, st));
+  void *tmp = arena.take<char>(need);
+  if (!arena.ok()) return DM_ERR_WORKSPACE;
+  row_mask_kernel<<<dm_ceil_div(n_rows, 256), 256, 0, st>>>(nbr, n_rows, kvol, keys, idx);
+  DM_CHECK_LAUNCH();
+  DM_HIP(rocprim::radix_sort_pairs(tmp, need, keys, keys_s, idx, perm, (size_t)n_rows, 0, kvol, st));
+  row_gather_kernel<<<dm_ceil_div(n_rows, 256), 256, 0, st>>>(nbr, n_rows, kvol, perm, nbr_packed);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
 // tuning aid: -1 auto, 0 force the LDS-staged kernel, 1 force the register-weights kernel
 extern "C" int dm_spconv_set_variant(int v) {
   g_gg_variant = v;
@@ -767,16 +827,16 @@ extern "C" size_t dm_spconv_workspace_bytes(int kvol, int cin, int cout) {
   if (ci == CI && co == CO) {                                                           \
     bool use_gr = g_gg_variant < 0 ? (CI >= 32) : (g_gg_variant == 1);                  \
     if constexpr (CI >= 16) {                                                           \
-      if (use_gr) return launch_gr<CI, CO>(feat, wp, nbr, nullptr, tile_order, n_rows_out, kvol, out, st); \
+      if (use_gr) return launch_gr<CI, CO>(feat, wp, nbr, row_perm, tile_order, n_rows_out, kvol, out, st); \
     }                                                                                   \
-    return launch_gg<CI, CO>(feat, wp, nbr, nullptr, n_rows_out, kvol, out, st);         \
+    return launch_gg<CI, CO>(feat, wp, nbr, row_perm, n_rows_out, kvol, out, st);        \
   }
 
 extern "C" int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const float *filters,
                                      const int32_t *nbr, int n_rows_out, int kvol, int cin,
                                      int cout, int transpose_w, int flip_k, float *out,
-                                     const int32_t *tile_order, void *workspace,
-                                     size_t workspace_bytes, dm_stream_t stream) {
+                                     const int32_t *tile_order, const int32_t *row_perm,
+                                     void *workspace, size_t workspace_bytes, dm_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n_rows_in < 0 || n_rows_out < 0 || kvol <= 0 || kvol > 32) return DM_ERR_INVALID_ARG;
   // effective B operand dims: (ci x co)

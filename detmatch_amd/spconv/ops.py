@@ -1,5 +1,7 @@
 """mmdet3d/ops/spconv/ops.py — same function names / argument meaning; compute in
 libdetmatch_hip.so (rulebook.hip, spconv.hip) through the C-ABI."""
+import os
+
 import torch
 
 from .. import _lib
@@ -148,11 +150,35 @@ def tile_order(nbr):
 TILE_ORDER_MIN_ROWS = 4096
 
 
+PACK_ROWS = os.environ.get('DM_SPCONV_PACK_ROWS', '1') == '1'
+
+
+def packed_rows(nbr):
+    """(nbr_packed, perm) of a gather table (dm_spconv_pack_rows): rows grouped by equal neighbour
+    mask, cached on the tensor like the tile order (one build per rulebook, every launch reuses it)."""
+    hit = getattr(nbr, 'dm_packed', None)
+    if hit is None:
+        L = _lib.lib()
+        kvol, n = nbr.shape
+        perm = torch.empty((n,), dtype=torch.int32, device=nbr.device)
+        packed = torch.empty_like(nbr)
+        ws = _lib.workspace(L.dm_spconv_pack_rows_workspace_bytes(n), nbr.device, 'pack_rows')
+        _lib.check(L.dm_spconv_pack_rows(_lib.ptr(nbr), n, kvol, _lib.ptr(perm), _lib.ptr(packed),
+                                         _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_spconv_pack_rows')
+        hit = nbr.dm_packed = (packed, perm)
+    return hit
+
+
 def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k):
     L = _lib.lib()
     kvol = nbr.shape[0]
     ci = cout if transpose_w else cin
-    order = tile_order(nbr) if (ci >= 32 and n_rows_out >= TILE_ORDER_MIN_ROWS) else None
+    order = perm = None
+    table = nbr
+    if ci >= 32 and n_rows_out >= TILE_ORDER_MIN_ROWS:
+        if PACK_ROWS:
+            table, perm = packed_rows(nbr)
+        order = tile_order(table)
     if LAUNCH_TRACE is not None:
         ci, co = (cout, cin) if transpose_w else (cin, cout)
         LAUNCH_TRACE.append((ci, co, int(n_rows_out), int(kvol), int((nbr >= 0).sum().item())))
@@ -161,9 +187,10 @@ def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k)
     dev = feat.device
     out = torch.empty((n_rows_out, cin if transpose_w else cout), dtype=torch.float32, device=dev)
     ws = _lib.workspace(L.dm_spconv_workspace_bytes(kvol, cin, cout), dev, 'spconv')
-    rc = L.dm_spconv_gather_gemm(_lib.ptr(feat), feat.shape[0], _lib.ptr(filters), _lib.ptr(nbr),
+    rc = L.dm_spconv_gather_gemm(_lib.ptr(feat), feat.shape[0], _lib.ptr(filters), _lib.ptr(table),
                                  n_rows_out, kvol, cin, cout, int(transpose_w), int(flip_k),
-                                 _lib.ptr(out), _lib.ptr(order), _lib.ptr(ws), ws.numel(), _lib.stream())
+                                 _lib.ptr(out), _lib.ptr(order), _lib.ptr(perm), _lib.ptr(ws), ws.numel(),
+                                 _lib.stream())
     _lib.check(rc, 'dm_spconv_gather_gemm')
     return out
 

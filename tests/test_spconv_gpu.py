@@ -277,6 +277,7 @@ def test_tile_launch_order(orc, dev, subm, monkeypatch):
     tw = torch.from_numpy(w).to(dev).view(3, 3, 3, cin, cout)
     dy = torch.randn(rb.n_out, cout, device=dev)
     assert min(n, rb.n_out) >= ops.TILE_ORDER_MIN_ROWS
+    monkeypatch.setattr(ops, 'PACK_ROWS', False)                 # the launch order alone: same bits
     out = ops.indice_conv(tf, tw, rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
     dx, _ = ops.indice_conv_backward(tf, tw, dy, rb.indice_pairs, rb.indice_num, False, subm)
     monkeypatch.setattr(ops, 'TILE_ORDER_MIN_ROWS', 1 << 30)      # identity order
@@ -285,6 +286,29 @@ def test_tile_launch_order(orc, dev, subm, monkeypatch):
     assert torch.equal(out, out0) and torch.equal(dx, dx0)
     want = orc.indice_conv(feats, w, p, nn, len(o), subm=subm)
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    # rows packed by neighbour mask (dm_spconv_pack_rows): a permutation of the rows, masks ascending,
+    # the table gathered accordingly; results equal up to the fp32 summation order over the offsets
+    # (the offsets of a tile are dealt to its four waves by rank), run-to-run bitwise reproducible
+    monkeypatch.setattr(ops, 'TILE_ORDER_MIN_ROWS', 4096)
+    monkeypatch.setattr(ops, 'PACK_ROWS', True)
+    for nbr in tables:
+        packed, perm = ops.packed_rows(nbr)
+        rows = nbr.shape[1]
+        assert torch.equal(torch.sort(perm.long())[0], torch.arange(rows, device=dev))
+        assert torch.equal(packed, nbr[:, perm.long()])
+        bits = (1 << torch.arange(nbr.shape[0], device=dev, dtype=torch.int64))[:, None]
+        key = ((packed >= 0).long() * bits).sum(0)
+        assert bool((key[:-1] <= key[1:]).all())
+        same = key[:-1] == key[1:]
+        assert bool((perm[:-1][same] < perm[1:][same]).all())      # stable: raster order inside a group
+        assert ops.packed_rows(nbr)[0] is packed
+    out1 = ops.indice_conv(tf, tw, rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
+    dx1, _ = ops.indice_conv_backward(tf, tw, dy, rb.indice_pairs, rb.indice_num, False, subm)
+    out2 = ops.indice_conv(tf, tw, rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
+    assert torch.equal(out1, out2)
+    np.testing.assert_allclose(out1.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out1.cpu().numpy(), out0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dx1.cpu().numpy(), dx0.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 # ---------------------------------------------------------------------------------------------
