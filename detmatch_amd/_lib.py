@@ -39,7 +39,7 @@ SIGNATURES = {
     'dm_spconv_workspace_bytes': (sz, [ci, ci, ci]),
     'dm_spconv_gather_gemm': (ci, [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
     'dm_spconv_pack_rows_workspace_bytes': (sz, [ci]),
-    'dm_spconv_pack_rows': (ci, [vp, ci, ci, vp, vp, vp, sz, vp]),
+    'dm_spconv_pack_rows': (ci, [vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     'dm_spconv_tile_order_workspace_bytes': (sz, []),
     'dm_spconv_tile_order': (ci, [vp, ci, ci, vp, vp, sz, vp]),
     'dm_spconv_wgrad_workspace_bytes': (sz, [ci, ci, ci, ci]),

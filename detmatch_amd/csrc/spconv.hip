@@ -786,12 +786,12 @@ extern "C" size_t dm_spconv_pack_rows_workspace_bytes(int n_rows) {
   uint32_t *k = nullptr;
   int32_t *v = nullptr;
   (void)rocprim::radix_sort_pairs(nullptr, need, k, k, v, v, (size_t)n_rows, 0, 32, (hipStream_t)0);
-  return 3 * dm_align((size_t)n_rows * 4) + dm_align(need);
+  return 3 * dm_align((size_t)n_rows * 4) + dm_align(need) + dm_spconv_tile_order_workspace_bytes();
 }
 
 extern "C" int dm_spconv_pack_rows(const int32_t *nbr, int n_rows, int kvol, int32_t *perm,
-                                   int32_t *nbr_packed, void *workspace, size_t workspace_bytes,
-                                   dm_stream_t stream) {
+                                   int32_t *nbr_packed, int32_t *tile_order_packed, void *workspace,
+                                   size_t workspace_bytes, dm_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n_rows < 0 || kvol <= 0 || kvol > 32) return DM_ERR_INVALID_ARG;
   if (n_rows == 0) return DM_OK;
@@ -809,6 +809,12 @@ extern "C" int dm_spconv_pack_rows(const int32_t *nbr, int n_rows, int kvol, int
   DM_HIP(rocprim::radix_sort_pairs(tmp, need, keys, keys_s, idx, perm, (size_t)n_rows, 0, kvol, st));
   row_gather_kernel<<<dm_ceil_div(n_rows, 256), 256, 0, st>>>(nbr, n_rows, kvol, perm, nbr_packed);
   DM_CHECK_LAUNCH();
+  if (tile_order_packed) {   // the heavy-first launch order of the packed table, in the same call
+    int *hist = arena.take<int>(66);
+    if (!arena.ok()) return DM_ERR_WORKSPACE;
+    return dm_spconv_tile_order(nbr_packed, n_rows, kvol, tile_order_packed, hist,
+                                dm_spconv_tile_order_workspace_bytes(), stream);
+  }
   return DM_OK;
 }
 

@@ -154,18 +154,21 @@ PACK_ROWS = os.environ.get('DM_SPCONV_PACK_ROWS', '1') == '1'
 
 
 def packed_rows(nbr):
-    """(nbr_packed, perm) of a gather table (dm_spconv_pack_rows): rows grouped by equal neighbour
-    mask, cached on the tensor like the tile order (one build per rulebook, every launch reuses it)."""
+    """(nbr_packed, perm, tile order of nbr_packed) of a gather table (dm_spconv_pack_rows): rows grouped
+    by equal neighbour mask, cached on the tensor (one build per rulebook, every launch reuses it)."""
     hit = getattr(nbr, 'dm_packed', None)
     if hit is None:
         L = _lib.lib()
         kvol, n = nbr.shape
-        perm = torch.empty((n,), dtype=torch.int32, device=nbr.device)
+        buf = torch.empty((n + (n + 15) // 16,), dtype=torch.int32, device=nbr.device)
+        perm, order = buf[:n], buf[n:]
         packed = torch.empty_like(nbr)
         ws = _lib.workspace(L.dm_spconv_pack_rows_workspace_bytes(n), nbr.device, 'pack_rows')
-        _lib.check(L.dm_spconv_pack_rows(_lib.ptr(nbr), n, kvol, _lib.ptr(perm), _lib.ptr(packed),
-                                         _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_spconv_pack_rows')
-        hit = nbr.dm_packed = (packed, perm)
+        _lib.check(L.dm_spconv_pack_rows(nbr.data_ptr(), n, kvol, perm.data_ptr(), packed.data_ptr(),
+                                         order.data_ptr(), ws.data_ptr(), ws.numel(), _lib.raw_stream()),
+                   'dm_spconv_pack_rows')
+        packed.dm_tile_order = order
+        hit = nbr.dm_packed = (packed, perm, order)
     return hit
 
 
@@ -177,8 +180,9 @@ def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k)
     table = nbr
     if ci >= 32 and n_rows_out >= TILE_ORDER_MIN_ROWS:
         if PACK_ROWS:
-            table, perm = packed_rows(nbr)
-        order = tile_order(table)
+            table, perm, order = packed_rows(nbr)
+        else:
+            order = tile_order(table)
     if LAUNCH_TRACE is not None:
         ci, co = (cout, cin) if transpose_w else (cin, cout)
         LAUNCH_TRACE.append((ci, co, int(n_rows_out), int(kvol), int((nbr >= 0).sum().item())))

@@ -192,7 +192,8 @@ size_t dm_spconv_tile_order_workspace_bytes(void);
  * order over the kernel offsets. */
 size_t dm_spconv_pack_rows_workspace_bytes(int n_rows);
 int dm_spconv_pack_rows(const int32_t *nbr /*(kvol, n_rows)*/, int n_rows, int kvol, int32_t *perm,
-                        int32_t *nbr_packed, void *workspace, size_t workspace_bytes,
+                        int32_t *nbr_packed, int32_t *tile_order_packed /* optional: dm_spconv_tile_order
+                        of nbr_packed, int32[ceil(n_rows/16)] */, void *workspace, size_t workspace_bytes,
                         dm_stream_t stream);
 int dm_spconv_tile_order(const int32_t *nbr /*(kvol, n_rows)*/, int n_rows, int kvol,
                          int32_t *order, void *workspace, size_t workspace_bytes,

@@ -292,7 +292,8 @@ def test_tile_launch_order(orc, dev, subm, monkeypatch):
     monkeypatch.setattr(ops, 'TILE_ORDER_MIN_ROWS', 4096)
     monkeypatch.setattr(ops, 'PACK_ROWS', True)
     for nbr in tables:
-        packed, perm = ops.packed_rows(nbr)
+        packed, perm, order = ops.packed_rows(nbr)
+        assert torch.equal(torch.sort(order.long())[0], torch.arange((nbr.shape[1] + 15) // 16, device=dev))
         rows = nbr.shape[1]
         assert torch.equal(torch.sort(perm.long())[0], torch.arange(rows, device=dev))
         assert torch.equal(packed, nbr[:, perm.long()])
