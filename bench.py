@@ -32,8 +32,15 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
-BATCH_PER_GPU = 2
 WORKLOAD = os.environ.get("DM_BENCH_WORKLOAD", "detmatch")
+# 'waymo' (with DM_BENCH_WORKLOAD=detmatch): BASELINE.json configs[4] — Waymo-shaped frames (~200 k points,
+# 1504x1504x41 grid, 1280x1920 image), batch 1 per GPU.  The headline bench is the default 'kitti'.
+PROFILE = os.environ.get("DM_BENCH_PROFILE", "kitti")
+BATCH_PER_GPU = 1 if PROFILE == 'waymo' else 2
+# 'bf16': mixed precision — dense-conv forward / input-gradient GEMMs with bf16 multiplicands and fp32
+# accumulation (dense_conv.set_math), the counterpart of the fp16 autocast of configs[4].  NOT the
+# headline arithmetic: the default is exact fp32 everywhere.
+CONV_MATH = os.environ.get("DM_CONV_MATH", "fp32")
 
 
 def parse():
@@ -85,7 +92,8 @@ def build_workload(dev, rank):
                                               Stage3DWorkload)
     if WORKLOAD in ('detmatch', 'confthr'):
         wl = DetMatchTrainWorkload(BATCH_PER_GPU, dev, seed=5000 * rank,
-                                   ssl_cfg='confthr_pvrcnn' if WORKLOAD == 'confthr' else None)
+                                   ssl_cfg='confthr_pvrcnn' if WORKLOAD == 'confthr' else None,
+                                   profile=PROFILE)
         wl.frames = [synth.lidar_frame(5000 * rank + i) for i in range(BATCH_PER_GPU)]
         return wl
     frames = [synth.lidar_frame(1000 * rank + i) for i in range(BATCH_PER_GPU)]
@@ -331,6 +339,9 @@ def main():
     if os.environ.get('DM_CUDNN_BENCHMARK'):     # tools/miopen_tune.sh: exhaustive MIOpen find
         torch.backends.cudnn.benchmark = True
     from detmatch_amd import _lib
+    if CONV_MATH != 'fp32':
+        from detmatch_amd import dense_conv
+        dense_conv.set_math(CONV_MATH)
     wl = build_workload(dev, rank)
     if world > 1:
         wl.enable_ddp()
@@ -419,8 +430,11 @@ def main():
         out = dict(metric='train iters/sec', value=round(world * args.steps * 1.0 / dt, 3), unit='iters/sec',
                    n_gpus=joined, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=wl.describe(), batch_per_gpu=BATCH_PER_GPU,
+                   scaling='weak', vs_baseline=None,
+                   dtype='f32' if CONV_MATH == 'fp32' else 'mixed: bf16 multiplicands + f32 accumulate in the '
+                   'dense-conv forward/input-gradient GEMMs, f32 everywhere else',
+                   data='synthetic',
+                   config=dict(workload=wl.describe(), batch_per_gpu=BATCH_PER_GPU, conv_math=CONV_MATH,
                                value_is='iterations of one per-GPU batch, summed over ranks',
                                global_batch=BATCH_PER_GPU * world,
                                parallelism='dp%d' % world),

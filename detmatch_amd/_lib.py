@@ -87,6 +87,8 @@ SIGNATURES = {
     'dm_bbox_head_loss': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cf, vp, vp, vp, vp]),
     'dm_dconv_pack': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, vp]),
     'dm_dconv_pack_batch': (ci, [vp, ci, ci, vp]),
+    'dm_dconv_set_math': (ci, [ci]),
+    'dm_dconv_get_math': (ci, []),
     'dm_dconv_gemm_workspace_bytes': (sz, [c_int_p]),
     'dm_dconv_gemm': (ci, [vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), vp, sz, vp]),
     'dm_dconv_wgrad_workspace_bytes': (sz, [c_int_p]),
@@ -106,6 +108,7 @@ SIGNATURES = {
     'dm_group_rows_grad': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     'dm_furthest_point_sampling': (ci, [ci, ci, ci, vp, vp, vp, vp]),
     'dm_furthest_point_sampling_stack': (ci, [ci, c_i32_p, ci, vp, vp, vp, vp]),
+    'dm_fps_set_variant': (ci, [ci]),
     'dm_points_in_boxes': (ci, [ci, ci, ci, vp, vp, vp, vp]),
     'dm_profile_enable': (ci, [ci]),
     'dm_spconv_debug_stamps': (ci, [vp]),

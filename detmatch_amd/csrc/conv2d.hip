@@ -378,6 +378,205 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Mixed-precision variant (dm_dconv_set_math(1)): the same lattice gather-GEMM with bf16 multiplicands
+// and fp32 accumulation / storage on v_mfma_f32_32x32x16_bf16 — what the reference's fp16 configs
+// (BASELINE configs[4], torch autocast) compute in half precision.  Tensors stay fp32 in HBM: a
+// K-tile of 64 is fetched as float4, rounded to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) on
+// its way into LDS (rows of 64 bf16 + 16 bytes: 36-dword stride, conflict-free ds_read_b128), and
+// a lane's fragment is the 8 consecutive k of its half (k = 16*step + 8*(lane >> 5) + j).  One MFMA
+// now does the work of eight fp32 ones, so the kernel is bound by L2 -> LDS staging instead of the
+// matrix pipe: plain double buffering (next tile's loads in flight under the current tile's MFMAs),
+// no pinned schedule.  Cin % 64 == 0 only (every UNI layer of the path except Cin = 32 heads).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
+  union { bf16x2 h; unsigned u; } lo, hi;
+  lo.h = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);
+  hi.h = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
+  return make_uint2(lo.u, hi.u);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LIMIT>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    float *__restrict__ y, const DConvGeom g, const DConvTaps tt, int n_tiles_m, int n_tiles_n,
+    int m_lo, int kt_per_split, float *__restrict__ partial) {
+  constexpr int BK = 64;
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int LDW = BK / 2 + 4;                      // dwords per LDS row
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  constexpr int KQ = BK / 4;                           // float4 pieces per row
+  constexpr int RPP = NT / KQ;
+  constexpr int AP = BM / RPP, BP = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && TM >= 1 && TN >= 1, "tile shape");
+  constexpr int LDS_WORDS = 2 * (BM + BN) * LDW;
+  constexpr int LDS_MIN = LIMIT == 1 ? 21504 : (LIMIT == 2 ? 14336 : 0);
+  __shared__ __attribute__((aligned(16))) unsigned ldsw[LDS_WORDS < LDS_MIN ? LDS_MIN : LDS_WORDS];
+
+  const int L = blockIdx.x;
+  const int xcd = L & 7, seq = L >> 3;
+  const int mt = (seq / n_tiles_n) * 8 + xcd;
+  const int nt = seq % n_tiles_n;
+  if (mt >= n_tiles_m) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int kq = tid % KQ, r0 = tid / KQ;
+  const int m0 = m_lo + mt * BM, n0 = nt * BN;
+
+  int a_iy[AP], a_ix[AP];
+  unsigned a_off[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = m0 + r0 + p * RPP;
+    if (m < g.M) {
+      const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, b = tmp / g.LH;
+      a_iy[p] = i * g.iys;
+      a_ix[p] = j * g.ixs;
+      a_off[p] = (unsigned)(((b * g.Hin + a_iy[p]) * g.Win + a_ix[p]) * g.Cin + kq * 4) * 4u;
+    } else {
+      a_iy[p] = -(1 << 20);
+      a_ix[p] = 0;
+      a_off[p] = 0;
+    }
+  }
+  unsigned b_off[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int n = n0 + r0 + p * RPP;
+    b_off[p] = (unsigned)((n < g.Cout ? n : 0) * g.Cin + kq * 4) * 4u;
+  }
+  const char *xb = (const char *)x, *wb = (const char *)w;
+  const unsigned slice_bytes = (unsigned)g.Cout * g.Cin * 4u;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float4 ra[AP], rb[BP];
+  bool ra_ok[AP];
+  const int KT_all = g.Ktot / BK;
+  const int kt0 = blockIdx.y * kt_per_split;
+  int tU = (kt0 * BK) / g.Cin, cU = (kt0 * BK) % g.Cin;
+  auto gload = [&]() {     // unconditional clamped loads, masked at the LDS store (see the fp32 kernel)
+    const int tr = __builtin_amdgcn_readfirstlane(tU);
+    const int t = tr < g.T ? tr : g.T - 1;
+    const int c0 = __builtin_amdgcn_readfirstlane(cU);
+    cU += BK;
+    const int wrap = cU >= g.Cin;
+    tU += wrap;
+    cU = wrap ? 0 : cU;
+    const int dy = tt.dy[t], dx = tt.dx[t];
+    const unsigned shift = (unsigned)((dy * g.Win + dx) * g.Cin + c0) * 4u;
+    const unsigned wshift = (unsigned)tt.ws[t] * slice_bytes + (unsigned)c0 * 4u;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int iy = a_iy[p] + dy, ix = a_ix[p] + dx;
+      const bool ok = ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
+      ra[p] = *(const float4 *)(xb + (ok ? a_off[p] + shift : 0u));
+      ra_ok[p] = ok;
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) rb[p] = *(const float4 *)(wb + b_off[p] + wshift);
+  };
+  auto sstore = [&](int buf) {
+    unsigned *base = ldsw + buf * (BM + BN) * LDW;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      float4 v = ra[p];
+      const bool ok = ra_ok[p];
+      v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
+      *(uint2 *)(base + (r0 + p * RPP) * LDW + kq * 2) = pack_bf16x4(v);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p)
+      *(uint2 *)(base + BM * LDW + (r0 + p * RPP) * LDW + kq * 2) = pack_bf16x4(rb[p]);
+  };
+  const int lr = lane & 31, lh = lane >> 5;
+  const int KT = min(kt_per_split, KT_all - kt0);
+  gload();
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) gload();
+    const unsigned *As = ldsw + buf * (BM + BN) * LDW + (wm * WM + lr) * LDW + lh * 4;
+    const unsigned *Bs = ldsw + buf * (BM + BN) * LDW + BM * LDW + (wn * WN + lr) * LDW + lh * 4;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = *(const bf16x8 *)(As + a * 32 * LDW + ks * 8);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bfr[b] = *(const bf16x8 *)(Bs + b * 32 * LDW + ks * 8);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: as in the fp32 kernel (LDS-transposed tile, whole rows of 16 bytes per lane)
+  constexpr int LDC = WN + 4;
+  static_assert(WAVES_M * WAVES_N * WM * LDC <= LDS_WORDS, "epilogue tile must fit the LDS");
+  float *cs = (float *)ldsw + wave * WM * LDC;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + wn * WN + b * 32 + lr;
+    const float bv = (bias != nullptr && partial == nullptr && n < g.Cout) ? bias[n] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[a][b][r] + bv;
+        if (g.relu == 1 && partial == nullptr) v = fmaxf(v, 0.0f);
+        cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + b * 32 + lr] = v;
+      }
+  }
+  constexpr int CQ = WN / 4;
+  constexpr int RPI = 64 / CQ;
+  const int cq = lane % CQ, rr = lane / CQ;
+  const int ncol = n0 + wn * WN + cq * 4;
+  const bool vec_ok = (g.Cout & 3) == 0;
+#pragma unroll 4
+  for (int it = 0; it < WM / RPI; ++it) {
+    const int rl = it * RPI + rr;
+    const int m = m0 + wm * WM + rl;
+    if (m >= g.M || ncol >= g.Cout) continue;
+    size_t row;
+    float *obase = y;
+    if (partial != nullptr) {
+      row = (size_t)blockIdx.y * g.M + m;
+      obase = partial;
+    } else if (g.dense_out) {
+      row = (size_t)m;
+    } else {
+      const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, bb = tmp / g.LH;
+      row = ((size_t)bb * g.Hout + g.oy0 + i * g.oys) * g.Wout + g.ox0 + j * g.oxs;
+    }
+    const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
+    float *dst = obase + row * g.Cout + ncol;
+    if (vec_ok && ncol + 3 < g.Cout) {
+      *(float4 *)dst = v;
+    } else {
+      dst[0] = v.x;
+      if (ncol + 1 < g.Cout) dst[1] = v.y;
+      if (ncol + 2 < g.Cout) dst[2] = v.z;
+      if (ncol + 3 < g.Cout) dst[3] = v.w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient:  G[t][u][v] = sum_m U[m][u] * V[b, i*vys + dy[t], j*vxs + dx[t]][v]
 // (Conv2d: U = dy, V = x, G = dW[t][cout][cin]; ConvTranspose2d: U = x, V = dy, G = dW[t][cin][cout]).
 // Grid = (tap, u-tile, v-tile) x nsplit chunks of the pixel range; partial tiles go to the workspace
@@ -647,7 +846,7 @@ __global__ __launch_bounds__(256) void dconv_splitk_reduce_kernel(const float *_
   *(float4 *)(y + row * g.Cout + n) = s;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNI, int LIMIT = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNI, int LIMIT = 0, bool BF = false>
 int launch_gemm(const float *x, const float *w, const float *bias, float *y, DConvGeom g,
                 const DConvTaps &tt, hipStream_t st, int m_lo = 0, int m_hi = -1, int nsplit = 1,
                 float *partial = nullptr) {
@@ -656,12 +855,19 @@ int launch_gemm(const float *x, const float *w, const float *bias, float *y, DCo
   g.M = m_hi;
   const int tm = dm_ceil_div(m_hi - m_lo, BM), tn = dm_ceil_div(g.Cout, BN);
   const int blocks = dm_ceil_div(tm, 8) * 8 * tn;
-  const int KT = dm_ceil_div(g.Ktot, 32);
+  const int KT = dm_ceil_div(g.Ktot, BF ? 64 : 32);
   const int per = dm_ceil_div(KT, nsplit);
   nsplit = dm_ceil_div(KT, per);
-  dconv_gemm_kernel<BM, BN, 32, WAVES_M, WAVES_N, UNI, LIMIT>
-      <<<dim3(blocks, nsplit), WAVES_M * WAVES_N * 64, 0, st>>>(x, w, bias, y, g, tt, tm, tn, m_lo, per,
-                                                               nsplit > 1 ? partial : nullptr);
+  if constexpr (BF) {
+    static_assert(UNI, "the bf16 kernel takes whole-tap K-tiles only");
+    dconv_gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, LIMIT>
+        <<<dim3(blocks, nsplit), WAVES_M * WAVES_N * 64, 0, st>>>(x, w, bias, y, g, tt, tm, tn, m_lo, per,
+                                                                 nsplit > 1 ? partial : nullptr);
+  } else {
+    dconv_gemm_kernel<BM, BN, 32, WAVES_M, WAVES_N, UNI, LIMIT>
+        <<<dim3(blocks, nsplit), WAVES_M * WAVES_N * 64, 0, st>>>(x, w, bias, y, g, tt, tm, tn, m_lo, per,
+                                                                 nsplit > 1 ? partial : nullptr);
+  }
   DM_CHECK_LAUNCH();
   if (nsplit > 1) {
     dconv_splitk_reduce_kernel<<<dm_ceil_div((long long)g.M * g.Cout / 4, 256), 256, 0, st>>>(
@@ -670,6 +876,9 @@ int launch_gemm(const float *x, const float *w, const float *bias, float *y, DCo
   }
   return DM_OK;
 }
+
+// 0: exact fp32 (v_mfma_f32_32x32x2_f32), 1: bf16 multiplicands, fp32 accumulate (mixed precision)
+int g_dconv_math = 0;
 
 // How many ways the reduction of a SMALL problem (fewer 64x64 tiles than half a round) is split.
 static int dconv_gemm_splits(const int *q) {
@@ -763,20 +972,23 @@ extern "C" int dm_dconv_gemm(const float *x, const float *w_packed, const float 
   // chip.  Problems of less than half a 64x64 round split the reduction over workgroups instead
   // (partial sums in the workspace, fixed-order reduce).
   const int nsplit = dconv_gemm_splits(geom_host);
+  const bool bf = g_dconv_math == 1 && (g.Cin % 64) == 0;
+#define DM_LG(BM_, BN_, LIM_, ...)                                                  \
+  (bf ? launch_gemm<BM_, BN_, 2, 2, true, LIM_, true>(x, w_packed, bias, y, g, tt, st, ##__VA_ARGS__) \
+      : launch_gemm<BM_, BN_, 2, 2, true, LIM_, false>(x, w_packed, bias, y, g, tt, st, ##__VA_ARGS__))
   if (nsplit > 1) {
     if (!workspace || workspace_bytes < (size_t)nsplit * g.M * g.Cout * sizeof(float))
       return DM_ERR_WORKSPACE;
-    return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, 0, -1, nsplit,
-                                           (float *)workspace);
+    return DM_LG(64, 64, 0, 0, -1, nsplit, (float *)workspace);
   }
   const int tm128 = dm_ceil_div(g.M, 128), tn128 = dm_ceil_div(g.Cout, 128);
   const long long tiles128 = (long long)tm128 * tn128;
   int m_done = 0;
   if (tiles128 >= 512 && g.Cout > 64) {          // at least one full round of the big tile
     const int rem = (int)(tiles128 % 512);
-    if (rem == 0 || rem > 384) return launch_gemm<128, 128, 2, 2, true>(x, w_packed, bias, y, g, tt, st);
+    if (rem == 0 || rem > 384) return DM_LG(128, 128, 0);
     const int mt_main = (int)((tiles128 - rem) / tn128) / 8 * 8;
-    const int rc = launch_gemm<128, 128, 2, 2, true>(x, w_packed, bias, y, g, tt, st, 0, mt_main * 128);
+    const int rc = DM_LG(128, 128, 0, 0, mt_main * 128);
     if (rc != DM_OK) return rc;
     m_done = mt_main * 128;
   }
@@ -789,15 +1001,24 @@ extern "C" int dm_dconv_gemm(const float *x, const float *w_packed, const float 
   if (full > 0 && rem64 > 0 && rem64 <= 512) m_main = m_done + (int)(full / tn64) / 8 * 8 * 64;
   else if (rem64 == 0 || rem64 > 512) m_main = g.M;
   if (m_main > m_done) {
-    const int rc = launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, m_done, m_main);
+    const int rc = DM_LG(64, 64, 0, m_done, m_main);
     if (rc != DM_OK) return rc;
   }
   if (m_main >= g.M) return DM_OK;
   const long long tail = (long long)dm_ceil_div(g.M - m_main, 64) * tn64;
-  if (tail <= 256) return launch_gemm<64, 64, 2, 2, true, 1>(x, w_packed, bias, y, g, tt, st, m_main);
-  if (tail <= 512) return launch_gemm<64, 64, 2, 2, true, 2>(x, w_packed, bias, y, g, tt, st, m_main);
-  return launch_gemm<64, 64, 2, 2, true>(x, w_packed, bias, y, g, tt, st, m_main);
+  if (tail <= 256) return DM_LG(64, 64, 1, m_main);
+  if (tail <= 512) return DM_LG(64, 64, 2, m_main);
+  return DM_LG(64, 64, 0, m_main);
+#undef DM_LG
 }
+
+extern "C" int dm_dconv_set_math(int mode) {
+  if (mode != 0 && mode != 1) return DM_ERR_INVALID_ARG;
+  g_dconv_math = mode;
+  return DM_OK;
+}
+
+extern "C" int dm_dconv_get_math(void) { return g_dconv_math; }
 
 static int dconv_wgrad_splits(long long M, int T, int Cu, int Cv) {
   // one full round of workgroups: 2 per CU for the 128x128 tile, 4 per CU for the 64x64 tile

@@ -743,6 +743,159 @@ __global__ __launch_bounds__(1024) void fps_kernel_global(FpsSamples smp, int m,
   }
 }
 
+// ---- furthest point sampling of LARGE clouds: several workgroups per sample ----------------------
+// A Waymo-sized frame (~200 k points -> 4096 key points) does not fit one workgroup's registers; the
+// single-workgroup fallback above streams all points from memory in every round (167 ms per call on
+// MI355X).  Here G workgroups own an interleaved share of the sample each (points and running minima
+// in registers, as in fps_kernel); per round every workgroup publishes its best candidate
+// (distance, index, coordinates) in a slot of the scratch buffer, tagged with the round number, and
+// reads everybody's slots back: a grid-wide exchange through L2 without atomics (release store of
+// the tag, acquire polls; slots double-buffered by round parity).  The winner is chosen with the
+// same total order (fps_better), so the indices are those of the one-workgroup kernels bit for bit.
+// All G * batch workgroups must be co-resident: the launcher keeps them to a fraction of the chip.
+// candidate 2 replaces candidate 1?  (a negative distance marks "no candidate")
+__device__ __forceinline__ bool fps_take(float d2, int k2, float d1, int k1, int bs_mask) {
+  if (!(d2 >= 0.f)) return false;
+  if (d1 < 0.f) return true;
+  return fps_better(d2, k2, d1, k1, bs_mask);
+}
+
+struct FpsSlot {   // 32 bytes
+  float d;
+  int k;
+  float x, y, z;
+  int tag;
+  int pad0, pad1;
+};
+
+constexpr int FPS_MT = 1024;
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_MT) void fps_kernel_multi(FpsSamples smp, int m, const float *__restrict__ xyz,
+                                                           float *__restrict__ temp, int *__restrict__ idxs) {
+  __shared__ float s_d[16], s_x[16], s_y[16], s_z[16];
+  __shared__ int s_k[16];
+  __shared__ float s_win[3];
+  const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+  const int n = smp.off[b + 1] - smp.off[b];
+  const float *data = xyz + (size_t)smp.off[b] * 3;
+  FpsSlot *slots = (FpsSlot *)(temp + (size_t)smp.off[b]);   // [2][G]; the launcher aligned and tagged it
+  int *out = idxs + (size_t)b * m;
+  if (n <= 0) return;
+  int bs = 1;
+  while (bs * 2 <= n && bs < 1024) bs *= 2;
+  const int bs_mask = bs - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float px[PPT], py[PPT], pz[PPT], pd[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = (i * G + g) * FPS_MT + tid;
+    const bool in = k < n;
+    const int kc = in ? k : 0;
+    px[i] = data[(size_t)kc * 3], py[i] = data[(size_t)kc * 3 + 1], pz[i] = data[(size_t)kc * 3 + 2];
+    pd[i] = in ? 1e10f : -1.f;
+  }
+  float x1 = data[0], y1 = data[1], z1 = data[2];
+  if (g == 0 && tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    float best = -1.f;
+    int bslot = 0;   // register slot of the running best; its point index is (bslot * G + g) * FPS_MT + tid
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = dist2_fma(px[i] - x1, py[i] - y1, pz[i] - z1);
+      const float d2 = fminf(d, pd[i]);      // slots beyond the sample hold -1 and stay -1
+      pd[i] = d2;
+      bool take = d2 > best;                 // strict '>' is the common path; exact ties take the full rule
+      if (d2 == best && d2 >= 0.f)
+        take = fps_better(d2, (i * G + g) * FPS_MT + tid, best, (bslot * G + g) * FPS_MT + tid, bs_mask);
+      best = take ? d2 : best;
+      bslot = take ? i : bslot;
+    }
+    int besti = (bslot * G + g) * FPS_MT + tid;
+    float bx = px[0], by = py[0], bz = pz[0];
+#pragma unroll
+    for (int i = 1; i < PPT; ++i) {
+      bx = bslot == i ? px[i] : bx;
+      by = bslot == i ? py[i] : by;
+      bz = bslot == i ? pz[i] : bz;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float od = __shfl_xor(best, off), ox = __shfl_xor(bx, off), oy = __shfl_xor(by, off),
+                  oz = __shfl_xor(bz, off);
+      const int ok = __shfl_xor(besti, off);
+      if (fps_take(od, ok, best, besti, bs_mask)) {
+        best = od;
+        besti = ok;
+        bx = ox;
+        by = oy;
+        bz = oz;
+      }
+    }
+    if (lane == 0) s_d[wave] = best, s_k[wave] = besti, s_x[wave] = bx, s_y[wave] = by, s_z[wave] = bz;
+    __syncthreads();
+    if (wave == 0) {
+      float d = lane < 16 ? s_d[lane] : -1.f, x = lane < 16 ? s_x[lane] : 0.f, y = lane < 16 ? s_y[lane] : 0.f,
+            z = lane < 16 ? s_z[lane] : 0.f;
+      int k = lane < 16 ? s_k[lane] : 0;
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(d, off), ox = __shfl_xor(x, off), oy = __shfl_xor(y, off), oz = __shfl_xor(z, off);
+        const int ok = __shfl_xor(k, off);
+        if (fps_take(od, ok, d, k, bs_mask)) {
+          d = od;
+          k = ok;
+          x = ox;
+          y = oy;
+          z = oz;
+        }
+      }
+      FpsSlot *row = slots + (size_t)(j & 1) * G;
+      if (lane == 0) {   // publish this workgroup's candidate, payload first, then the round tag
+        FpsSlot *mine = row + g;
+        __hip_atomic_store(&mine->d, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->k, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->x, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->y, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->z, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->tag, j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // everybody's candidates of this round
+      d = -1.f, k = 0, x = y = z = 0.f;
+      for (int q = lane; q < G; q += 64) {
+        FpsSlot *o = row + q;
+        while (__hip_atomic_load(&o->tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != j) __builtin_amdgcn_s_sleep(1);
+        const float od = __hip_atomic_load(&o->d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ok = __hip_atomic_load(&o->k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fps_take(od, ok, d, k, bs_mask)) {
+          d = od, k = ok;
+          x = __hip_atomic_load(&o->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          y = __hip_atomic_load(&o->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          z = __hip_atomic_load(&o->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(d, off), ox = __shfl_xor(x, off), oy = __shfl_xor(y, off), oz = __shfl_xor(z, off);
+        const int ok = __shfl_xor(k, off);
+        if (fps_take(od, ok, d, k, bs_mask)) {
+          d = od;
+          k = ok;
+          x = ox;
+          y = oy;
+          z = oz;
+        }
+      }
+      if (lane == 0) {
+        s_win[0] = x, s_win[1] = y, s_win[2] = z;
+        if (g == 0) out[j] = k;
+      }
+    }
+    __syncthreads();
+    x1 = s_win[0], y1 = s_win[1], z1 = s_win[2];
+  }
+}
+
 }  // namespace
 
 extern "C" int dm_ball_query_stack(int batch, int m, float radius, int nsample,
@@ -897,6 +1050,14 @@ extern "C" int dm_group_rows_grad(int batch, int m, int c, int n, int nsample, i
   return DM_OK;
 }
 
+// tuning / test aid: 0 auto, 1 one workgroup per sample even for large clouds
+static int g_fps_variant = 0;
+
+extern "C" int dm_fps_set_variant(int v) {
+  g_fps_variant = v;
+  return DM_OK;
+}
+
 static int fps_launch(const FpsSamples &smp, int batch, int max_n, int m, const float *xyz,
                       float *temp, int *idxs, hipStream_t st) {
   int ppt = dm_ceil_div(max_n, FPS_T);
@@ -907,7 +1068,24 @@ static int fps_launch(const FpsSamples &smp, int batch, int max_n, int m, const 
   else if (ppt <= 32) fps_kernel<32><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
   else if (ppt <= 40) fps_kernel<40><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
   else if (ppt <= 48) fps_kernel<48><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
-  else fps_kernel_global<<<batch, 1024, 0, st>>>(smp, m, xyz, temp, idxs);
+  else {
+    // large clouds: G workgroups per sample (see fps_kernel_multi).  The exchange slots live at the
+    // start of each sample's `temp` range (n floats >= 2*G*8); all G * batch workgroups spin on each
+    // other, so they are kept to a quarter of the chip's 512 slots of 1024 threads.
+    int G = 128 / batch;
+    G = G > 64 ? 64 : (G < 1 ? 1 : G);
+    const int ppt_m = dm_ceil_div(max_n, G * FPS_MT);
+    bool aligned = g_fps_variant != 1 && G >= 2 && ppt_m <= 8;     // (slots are 4-byte fields: any offset works)
+    for (int b = 0; b < batch && aligned; ++b) aligned = (smp.off[b + 1] - smp.off[b]) >= 2 * G * 8;
+    if (aligned) {
+      for (int b = 0; b < batch; ++b)
+        DM_HIP(hipMemsetAsync(temp + smp.off[b], 0xFF, (size_t)2 * G * sizeof(FpsSlot), st));
+      if (ppt_m <= 4) fps_kernel_multi<4><<<dim3(G, batch), FPS_MT, 0, st>>>(smp, m, xyz, temp, idxs);
+      else fps_kernel_multi<8><<<dim3(G, batch), FPS_MT, 0, st>>>(smp, m, xyz, temp, idxs);
+    } else {
+      fps_kernel_global<<<batch, 1024, 0, st>>>(smp, m, xyz, temp, idxs);
+    }
+  }
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -27,6 +27,19 @@ _GENERATION = [0]
 _PACK_CACHE = {}
 
 
+def set_math(mode):
+    """'fp32' (default, exact) or 'bf16' (mixed precision: bf16 multiplicands, fp32 accumulate / storage —
+    the counterpart of the reference's fp16 autocast configs, BASELINE configs[4]) for the forward and
+    input-gradient GEMMs.  Also read once from the environment variable DM_CONV_MATH."""
+    if mode not in ('fp32', 'bf16'):
+        raise ValueError("math mode must be 'fp32' or 'bf16'")
+    _lib.check(_lib.lib().dm_dconv_set_math(1 if mode == 'bf16' else 0), 'dm_dconv_set_math')
+
+
+def get_math():
+    return 'bf16' if _lib.lib().dm_dconv_get_math() == 1 else 'fp32'
+
+
 def weights_changed():
     _GENERATION[0] += 1
     if len(_PACK_CACHE) > 4096:

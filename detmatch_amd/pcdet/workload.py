@@ -279,10 +279,13 @@ class DetMatchTrainWorkload(object):
         n = sum(p.numel() for p in self.params)
         cfg_idx = {'detmatch': 3, 'confthr_pvrcnn': 2}.get(self.recipe)
         where = 'BASELINE configs[%d] per-GPU shape' % cfg_idx if cfg_idx is not None else 'configs/detmatch/001'
+        if self.profile == 'waymo':
+            where = 'BASELINE configs[4] per-GPU shape (Waymo range / grid / image size)'
         return ('DetMatch iteration (%s, recipe %s): teacher+student PV-RCNN and '
                 'Faster R-CNN R50-FPN, pseudo-label path, fused EMA, backward, grad exchange, clip, '
-                'HybridOptimizer; KITTI-shaped synthetic, %d labeled + %d unlabeled per GPU, '
-                '%.1f M trainable params' % (where, self.recipe, self.batch_size, self.batch_size, n / 1e6))
+                'HybridOptimizer; %s-shaped synthetic, %d labeled + %d unlabeled per GPU, '
+                '%.1f M trainable params' % (where, self.recipe, 'Waymo' if self.profile == 'waymo' else 'KITTI',
+                                            self.batch_size, self.batch_size, n / 1e6))
 
     def enable_ddp(self):
         self.world = dist.get_world_size()

@@ -508,6 +508,13 @@ int dm_bbox_head_loss(const float *cls_score, const float *bbox_pred, const long
 int dm_dconv_pack(const float *src, float *dst, const float *scale_n, const float *scale_k, int S,
                   int N, int K, int Nsrc, int Ksrc, long long sn, long long sk, long long st,
                   dm_stream_t stream);
+/* Arithmetic of dm_dconv_gemm: 0 (default) exact fp32 (v_mfma_f32_32x32x2_f32); 1 mixed precision —
+ * bf16 multiplicands (inputs and weights rounded to nearest-even on their way into LDS), fp32
+ * accumulation and storage (v_mfma_f32_32x32x16_bf16), the counterpart of the reference's fp16
+ * (autocast) configs; layers with Cin % 64 != 0 stay fp32.  Process-wide; dm_dconv_wgrad is fp32
+ * in both modes. */
+int dm_dconv_set_math(int mode);
+int dm_dconv_get_math(void);
 /* The same for n_entries weights in one launch.  table_dev: device array of 80-byte rows
  * {const float *src; float *dst; const float *scale_n, *scale_k; int64 sn, sk, st;
  *  int32 S, N, K, Nsrc, Ksrc, pad} — every packed weight of a network is refreshed by one launch after
@@ -644,6 +651,9 @@ int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float 
  * in Python, voxel_set_abstraction.py:135-151). */
 int dm_furthest_point_sampling_stack(int batch, const int *offsets_host, int m, const float *xyz,
                                      float *temp, int *idxs, dm_stream_t stream);
+/* Test / tuning aid: 0 (default) clouds beyond one workgroup's registers (> 24576 points) are sampled by
+ * several co-operating workgroups per sample (same indices); 1 forces one workgroup per sample. */
+int dm_fps_set_variant(int variant);
 /* Replaces roiaware_pool3d_cuda.points_in_boxes_gpu (roiaware_pool3d.cpp:98-129,
  * roiaware_pool3d_kernel.cu:313-360).  box_idx (batch, pts_num): first containing box or -1
  * (the callee writes every element; no pre-fill needed). */

@@ -216,3 +216,60 @@ def test_scheduling_paths_agree_with_reference(dev, shape):
     y64 = F.relu(F.conv2d(x.double(), w.double(), b.double(), s, p))
     _close(y, y64, 'forward')
     assert torch.equal(y, dense_conv.conv2d(xd, wd, bd, s, p, relu=True))
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize('shape', [
+    ((2, 128, 100, 88), 128, 3, 1, 1),      # 128x128 rounds + 64x64 tail
+    ((2, 128, 60, 44), 256, 3, 2, 1),       # stride 2: input gradient per residue class
+    ((2, 512, 12, 40), 512, 3, 1, 1),       # split-K
+    ((2, 1024, 24, 80), 256, 1, 1, 0),      # 1x1
+    ((1, 64, 96, 160), 64, 3, 1, 1),        # Cin = 64: one K-tile per tap
+    ((2, 256, 30, 30), 72, 1, 1, 0),        # Cout not a multiple of the tile
+], ids=['3x3 128', '3x3 s2', 'splitk', '1x1', 'cin64', 'cout72'])
+def test_mixed_precision_math_mode(dev, shape):
+    """dm_dconv_set_math(1): bf16 multiplicands, fp32 accumulation.  Forward and input gradient equal the
+    float64 convolution of the bf16-ROUNDED operands to fp32-accumulation accuracy, and the exact
+    convolution to bf16 accuracy (what the reference's fp16 autocast configs accept); the weight
+    gradient stays fp32."""
+    from detmatch_amd import dense_conv
+    xs, cout, k, s, p = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(xs, generator=g)
+    w = torch.randn(cout, xs[1], k, k, generator=g) / (xs[1] * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    gy_seed = 22
+    assert dense_conv.get_math() == 'fp32'
+    dense_conv.set_math('bf16')
+    try:
+        xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd = torch.nn.Parameter(w.to(dev))
+        y = dense_conv.conv2d(xd, wd, b.to(dev), s, p)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(gy_seed))
+        y.backward(gy.to(dev))
+        assert dense_conv.get_math() == 'bf16'
+    finally:
+        dense_conv.set_math('fp32')
+    F = torch.nn.functional
+    # (a) rounded operands, exact arithmetic
+    x64, w64 = _bf16_round(x).requires_grad_(True), _bf16_round(w)
+    yr = F.conv2d(x64, w64, b.double(), s, p)
+    scale = float(yr.abs().max())
+    assert float((y.detach().cpu().double() - yr).abs().max()) <= 2e-5 * scale
+    gxr = torch.autograd.grad(F.conv2d(torch.zeros_like(x64).requires_grad_(True), w64, None, s, p).sum() * 0 +
+                              (F.conv2d(x64, w64, None, s, p) * _bf16_round(gy)).sum(), x64)[0]
+    gscale = float(gxr.abs().max())
+    # the input gradient reduces over Cout: it takes the bf16 kernel when Cout % 64 == 0, else stays fp32
+    tol = 2e-5 if cout % 64 == 0 else 2e-2
+    assert float((xd.grad.cpu().double() - gxr).abs().max()) <= tol * gscale
+    # (b) the exact convolution, to half-precision accuracy
+    ye = F.conv2d(x.double(), w.double(), b.double(), s, p)
+    assert float((y.detach().cpu().double() - ye).abs().max()) <= 2e-2 * scale
+    # (c) weight gradient: fp32 arithmetic on the unrounded tensors
+    xe = x.double()
+    we = w.double().requires_grad_(True)
+    (F.conv2d(xe, we, None, s, p) * gy.double()).sum().backward()
+    assert float((wd.grad.cpu().double() - we.grad).abs().max()) <= 1e-4 * float(we.grad.abs().max())

@@ -351,3 +351,27 @@ def test_reference_grouping_kat_gpu(dev):
     t = lambda a, dt=None: torch.from_numpy(np.asarray(a, dtype=dt)).to(dev)
     got = pn.grouping_operation(t(feats), t(fc, np.int32), t(idx), t(ic, np.int32))
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('n,m,batch', [(60000, 512, 2), (200000, 1024, 1), (30001, 300, 3)])
+def test_fps_large_clouds_multi_workgroup_equals_single_workgroup(dev, n, m, batch):
+    """Clouds beyond one workgroup's registers: several co-operating workgroups per sample (per-round
+    exchange through L2) return the indices of the one-workgroup kernel bit for bit (same distance
+    arithmetic, same total order of the tie rule) — incl. ragged samples and duplicate points."""
+    from detmatch_amd import _lib, pointnet2_stack as pn2
+    g = torch.Generator().manual_seed(n)
+    sizes = [n - 17 * b for b in range(batch)]
+    pts = [torch.rand(s, 3, generator=g) * torch.tensor([150.0, 150.0, 6.0]) for s in sizes]
+    pts[0][1000:1100] = pts[0][2000:2100]            # exact duplicates: ties decided by the index rule
+    xyz = torch.cat(pts).to(dev).contiguous()
+    cnt = torch.tensor(sizes, dtype=torch.int32)
+    out = []
+    for variant in (0, 1):
+        _lib.lib().dm_fps_set_variant(variant)
+        try:
+            out.append(pn2.furthest_point_sample_stack(xyz, cnt, m).cpu())
+        finally:
+            _lib.lib().dm_fps_set_variant(0)
+    assert out[0].shape == (batch, m) and torch.equal(out[0], out[1])
+    assert all(int(out[0][b].max()) < sizes[b] for b in range(batch))
+    assert all(len(set(out[0][b].tolist())) > m * 0.9 for b in range(batch))
