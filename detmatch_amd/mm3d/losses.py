@@ -216,7 +216,11 @@ class AssignResult(object):
 def linear_sum_assignment(cost):
     """Host LAP on an (n, m) cost tensor (any device): one D2H copy of n*m floats, then
     dm_lap_host (libdetmatch_hip.so) — the reference does cost.detach().cpu() + scipy."""
-    c = np.ascontiguousarray(cost.detach().cpu().numpy(), dtype=np.float32)
+    return linear_sum_assignment_host(cost.detach().cpu().numpy())
+
+
+def linear_sum_assignment_host(cost_host):
+    c = np.ascontiguousarray(cost_host, dtype=np.float32)
     n, m = c.shape
     k = min(n, m)
     rows = np.zeros((max(k, 1),), np.int32)

@@ -6,6 +6,7 @@ dicts ("tea.3d_simple_test").  Box lists are list[tuple(boxes, scores, *extras)]
 per sample.  Names, constructor arguments and key semantics follow the reference so its config
 files load unchanged (tests/test_ssl_config.py).
 """
+import numpy as np
 import torch
 from torch.nn import functional as F
 
@@ -29,6 +30,12 @@ def _split(entry):
 
 def _join(boxes, rest, was_tuple):
     return (boxes,) + tuple(rest) if was_tuple else boxes
+
+
+def _lap_host(cost_host):
+    """dm_lap_host on a host (n, m) float32 matrix -> (rows, cols) int64, rows ascending."""
+    from .losses import linear_sum_assignment_host
+    return linear_sum_assignment_host(cost_host)
 
 
 def _fg_scores(scores, includes_bg):
@@ -302,12 +309,59 @@ class FusionHungarianMatching(object):
         self.match_cost_key = match_cost_key
         self.project_3d_to_2d = project_3d_to_2d
 
-    def match(self, entry_3d, entry_2d, img_meta):
+    def _device_costs(self):
+        """(w_cls, w_reg, w_iou, alpha, focal eps) when the assigner is the configured
+        ModHungarianAssigner(DoubleSidedFocalLossCost, BBoxL1Cost xyxy, IoUCost giou), else None."""
+        from .losses import BBoxL1Cost, DoubleSidedFocalLossCost, IoUCost, ModHungarianAssigner
+        a = self.assigner
+        if not (isinstance(a, ModHungarianAssigner) and isinstance(a.cls_cost, DoubleSidedFocalLossCost)
+                and isinstance(a.reg_cost, BBoxL1Cost) and a.reg_cost.box_format == 'xyxy'
+                and isinstance(a.iou_cost, IoUCost) and a.iou_cost.iou_mode == 'giou'
+                and a.cls_cost.focal_loss_cost.gamma == 2):
+            return None
+        f = a.cls_cost.focal_loss_cost
+        return float(f.weight), float(a.reg_cost.weight), float(a.iou_cost.weight), float(f.alpha), float(f.eps)
+
+    def match_device(self, entry_3d, entry_2d, img_meta, costs_cfg):
+        """match() with the whole cost matrix from ONE kernel (dm_fusion_match_cost), the LAP and the
+        cost threshold on the host copy of it, and one upload of the matched index pairs."""
+        from .. import _lib
+        s3 = _fg_scores(entry_3d[1], self.cls_includes_bg_pred_3d).detach().float().contiguous()
+        s2 = _fg_scores(entry_2d[1], self.cls_includes_bg_pred_2d).detach().float().contiguous()
+        boxes2d = entry_2d[0].detach().float().contiguous()
+        dev = boxes2d.device
+        n3, n2, c = int(s3.shape[0]), int(s2.shape[0]), int(s3.shape[1])
+        img_h, img_w, _ = img_meta['ori_shape']
+        b3 = proj = m16 = None
+        if self.project_3d_to_2d:
+            b3 = entry_3d[0].tensor.detach().float().contiguous()
+            m16 = _lib.floats(np.asarray(img_meta['lidar2img'].cpu() if torch.is_tensor(img_meta['lidar2img'])
+                                         else img_meta['lidar2img'], np.float32).reshape(-1))
+        else:
+            proj = entry_3d[0].detach().float().contiguous()
+        cost = torch.empty((n3, n2), dtype=torch.float32, device=dev)
+        w_cls, w_reg, w_iou, alpha, feps = costs_cfg
+        _lib.check(_lib.lib().dm_fusion_match_cost(
+            _lib.ptr(b3), _lib.ptr(proj), _lib.ptr(s3), n3, _lib.ptr(boxes2d), _lib.ptr(s2), n2, c, m16,
+            float(img_w), float(img_h), w_cls, w_reg, w_iou, alpha, feps, 1e-6, _lib.ptr(cost), None,
+            _lib.stream()), 'dm_fusion_match_cost')
+        host = cost.cpu().numpy()                                    # the one read-back of the module
+        rows, cols = _lap_host(host)
+        cm = host[rows, cols]
+        keep = np.ones(len(rows), bool) if self.cost_thr is None else ~(cm > self.cost_thr)
+        rows, cols, cm = rows[keep], cols[keep], cm[keep]
+        packed = torch.from_numpy(np.stack([rows, cols]).astype(np.int64)).to(dev, non_blocking=True)
+        return packed[0], packed[1], torch.from_numpy(cm.astype(np.float32)).to(dev, non_blocking=True)
+
+    def match(self, entry_3d, entry_2d, img_meta, fused=True):
         """-> (index tensor into entry_3d, index tensor into entry_2d, matched costs)"""
         s3 = _fg_scores(entry_3d[1], self.cls_includes_bg_pred_3d)
         s2 = _fg_scores(entry_2d[1], self.cls_includes_bg_pred_2d)
         assert s3.shape[1] == s2.shape[1]
         boxes2d = entry_2d[0]
+        cfg = self._device_costs() if fused else None
+        if cfg is not None and s3.is_cuda and 0 < len(s3) <= 512 and 0 < len(s2) <= 512 and s3.shape[1] <= 8:
+            return self.match_device(entry_3d, entry_2d, img_meta, cfg)
         if self.project_3d_to_2d:
             proj, _ = bbox_3d_to_bbox_2d(entry_3d[0], img_meta['lidar2img'], img_meta['ori_shape'])
         else:

@@ -365,6 +365,19 @@ int dm_bev_interpolate_forward(const float *bev_nhwc, int batch, int height, int
 int dm_bev_interpolate_backward(const float *grad_out, const int *cells, const float *weights, int batch,
                                 int height, int width, int channels, int n_keypoints,
                                 float *grad_bev_nhwc, dm_stream_t stream);
+/* H. Cost matrix of the 2D <-> 3D Hungarian matching in one launch (FusionHungarianMatching.match,
+ * mmdet3d/models/ssl_modules/processors_fusion.py:50-222, with ModHungarianAssigner's costs,
+ * modified_hungarian_assigner.py:19-162: DoubleSidedFocalLossCost on torch.logit'ed foreground
+ * probabilities, BBoxL1Cost on image-normalised xyxy, IoUCost giou).  Rows: n3 <= 512 LiDAR boxes
+ * (x, y, z_bottom, dx, dy, dz, yaw) projected with lidar2img16_host (row-major 4x4; bbox_utils.py:372-441)
+ * — or, with boxes3d == NULL, already projected xyxy boxes in boxes_proj.  Columns: n2 <= 512 image
+ * boxes.  scores*: (n, n_cls) foreground probabilities, n_cls <= 8.  cost (n3, n2); proj_out (n3, 4)
+ * optional.  The assignment itself is dm_lap_host on the copied-back matrix. */
+int dm_fusion_match_cost(const float *boxes3d, const float *boxes_proj, const float *scores3, int n3,
+                         const float *boxes2d, const float *scores2, int n2, int n_cls,
+                         const float *lidar2img16_host, float img_w, float img_h, float w_cls,
+                         float w_reg, float w_iou, float focal_alpha, float focal_eps, float logit_eps,
+                         float *cost, float *proj_out, dm_stream_t stream);
 /* D / E. Second-stage targets and losses of PV-RCNN, one or two launches per call for the whole batch.
  *
  * dm_roi_targets replaces ProposalTargetLayer.forward (sample_rois_for_rcnn, subsample_rois,
