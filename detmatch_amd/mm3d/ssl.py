@@ -506,6 +506,17 @@ class SSL(nn.Module):
             unlab_modules = [m for m in unlab_modules if m not in hoisted]
         early = lanes is None and getattr(self, 'early_backward', False) and torch.is_grad_enabled()
         curr_ssl_weight = self._get_curr_ssl_weight()
+        if lanes is None and getattr(self, 'hoist_teacher', False):
+            # Scheduling only: the unlabeled chain up to the first module that runs the student (teacher
+            # inference + the pseudo-label glue) reads nothing the labeled chain writes, draws no random
+            # numbers and runs the teacher in eval mode, so it may run FIRST.  Its read-backs (NMS counts,
+            # the Hungarian cost matrix) then wait for the teacher's own kernels only, instead of for the
+            # supervised passes' backward work queued in front of them.
+            first_student = next((i for i, m in enumerate(unlab_modules)
+                                  if str(getattr(m, 'ssl_obj_attr', '')).startswith('student')), 0)
+            for m in unlab_modules[:first_student]:
+                unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
+            unlab_modules = unlab_modules[first_student:]
         for m in self.lab_ssl_modules:
             lab_dict = self._run_and_backprop(run, m, lab_dict, early, curr_ssl_weight)
         if lanes is not None:
