@@ -462,6 +462,9 @@ class SSL(nn.Module):
             d[group] = cur
         if terms:
             sum(terms).backward()
+            hook = getattr(self, 'after_partial_backward', None)
+            if hook is not None:      # e.g. FlatGradDDP.collect: batched adds into the flat arena
+                hook()
         return d
 
     def forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
