@@ -46,6 +46,7 @@ SIGNATURES = {
     'dm_spconv_wgrad': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
     'dm_iou3d_workspace_bytes': (sz, [ci, ci]),
     'dm_boxes_overlap_bev': (ci, [vp, ci, vp, ci, vp, vp, sz, vp]),
+    'dm_boxes_overlap_bev_exact': (ci, [vp, ci, vp, ci, vp, vp]),
     'dm_boxes_iou_bev': (ci, [vp, ci, vp, ci, vp, vp, sz, vp]),
     'dm_nms_workspace_bytes': (sz, [ci]),
     'dm_nms': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),

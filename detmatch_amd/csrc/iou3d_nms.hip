@@ -348,6 +348,66 @@ static int pair_launch(bool iou, const float *a, int na, const float *b, int nb,
   return DM_OK;
 }
 
+// Exact rotated-rectangle intersection area (no containment margin, double precision): rectangle A
+// clipped by the four half-planes of rectangle B (Sutherland-Hodgman on convex polygons, <= 8 vertices),
+// shoelace area.  For the consumers that compare overlaps with thresholds or with zero — KITTI
+// evaluation (the reference: rotate_iou_gpu_eval, mmdet3d/core/evaluation/kitti_utils/rotate_iou.py)
+// and the collision test of the GT-paste sampler (box_np_ops.box_collision_test) — where the 1 cm
+// corner margin of the NMS kernel above would turn near-touching boxes into overlapping ones.
+__global__ __launch_bounds__(256) void pair_overlap_exact(const float *__restrict__ boxes_a, int na,
+                                                          const float *__restrict__ boxes_b, int nb,
+                                                          float *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)na * nb) return;
+  const int ia = (int)(e / nb), ib = (int)(e % nb);
+  const float *A = boxes_a + (size_t)ia * 7, *B = boxes_b + (size_t)ib * 7;
+  double px[10], py[10], qx[10], qy[10];
+  {
+    const double c = cos((double)A[6]), s = sin((double)A[6]), hx = (double)A[3] / 2, hy = (double)A[4] / 2;
+    const double sx[4] = {-hx, hx, hx, -hx}, sy[4] = {-hy, -hy, hy, hy};
+    for (int k = 0; k < 4; ++k) px[k] = (double)A[0] + sx[k] * c - sy[k] * s, py[k] = (double)A[1] + sx[k] * s + sy[k] * c;
+  }
+  int n = 4;
+  const double cb = cos((double)B[6]), sb = sin((double)B[6]);
+  const double hbx = (double)B[3] / 2, hby = (double)B[4] / 2;
+  // the four inward half-planes of B in its own frame: +-x <= hbx, +-y <= hby
+  for (int side = 0; side < 4 && n > 0; ++side) {
+    const double nx = side == 0 ? cb : (side == 1 ? -cb : (side == 2 ? -sb : sb));
+    const double ny = side == 0 ? sb : (side == 1 ? -sb : (side == 2 ? cb : -cb));
+    const double lim = (side < 2 ? hbx : hby);
+    int m = 0;
+    for (int k = 0; k < n; ++k) {
+      const int k2 = (k + 1 == n) ? 0 : k + 1;
+      const double d1 = (px[k] - (double)B[0]) * nx + (py[k] - (double)B[1]) * ny - lim;
+      const double d2 = (px[k2] - (double)B[0]) * nx + (py[k2] - (double)B[1]) * ny - lim;
+      if (d1 <= 0.0) qx[m] = px[k], qy[m] = py[k], ++m;
+      if ((d1 < 0.0 && d2 > 0.0) || (d1 > 0.0 && d2 < 0.0)) {
+        const double t = d1 / (d1 - d2);
+        qx[m] = px[k] + t * (px[k2] - px[k]), qy[m] = py[k] + t * (py[k2] - py[k]), ++m;
+      }
+    }
+    n = m;
+    for (int k = 0; k < n; ++k) px[k] = qx[k], py[k] = qy[k];
+  }
+  double area = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const int k2 = (k + 1 == n) ? 0 : k + 1;
+    area += px[k] * py[k2] - px[k2] * py[k];
+  }
+  out[e] = n >= 3 ? (float)(fabs(area) * 0.5) : 0.f;
+}
+
+extern "C" int dm_boxes_overlap_bev_exact(const float *boxes_a, int na, const float *boxes_b, int nb,
+                                          float *ans_overlap, dm_stream_t stream) {
+  if (na < 0 || nb < 0) return DM_ERR_INVALID_ARG;
+  if (na == 0 || nb == 0) return DM_OK;
+  if (!boxes_a || !boxes_b || !ans_overlap) return DM_ERR_INVALID_ARG;
+  pair_overlap_exact<<<dm_ceil_div((long long)na * nb, 256), 256, 0, (hipStream_t)stream>>>(boxes_a, na, boxes_b, nb,
+                                                                                          ans_overlap);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
 extern "C" int dm_boxes_overlap_bev(const float *boxes_a, int na, const float *boxes_b, int nb,
                                     float *ans_overlap, void *workspace, size_t workspace_bytes,
                                     dm_stream_t stream) {

@@ -64,7 +64,7 @@ def collision_matrix(boxes, device):
     """(n, 7) host array -> (n, n) bool numpy: BEV rectangles i and j intersect (diagonal False)."""
     from . import iou3d_nms
     t = _boxes7_bev(torch.as_tensor(np.asarray(boxes, dtype=np.float32), device=device))
-    ov = iou3d_nms.boxes_overlap_bev(t, t) > 0
+    ov = iou3d_nms.boxes_overlap_bev_exact(t, t) > 0     # exact: boxes 1 cm apart do not collide
     ov.fill_diagonal_(False)
     return ov.cpu().numpy()
 

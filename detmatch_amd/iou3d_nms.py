@@ -34,6 +34,17 @@ def boxes_overlap_bev(boxes_a, boxes_b):
     return _pair('dm_boxes_overlap_bev', boxes_a, boxes_b)
 
 
+def boxes_overlap_bev_exact(boxes_a, boxes_b):
+    """Rotated BEV overlap AREA (N, M) by exact convex clipping in double precision — no corner margin.
+    For comparisons with thresholds / zero (KITTI evaluation, GT-paste collision test)."""
+    a, b = _check(boxes_a, boxes_b)
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    rc = _lib.lib().dm_boxes_overlap_bev_exact(_lib.ptr(a), a.shape[0], _lib.ptr(b), b.shape[0], _lib.ptr(out),
+                                               _lib.stream())
+    _lib.check(rc, 'dm_boxes_overlap_bev_exact')
+    return out
+
+
 def boxes_iou_bev(boxes_a, boxes_b):
     """iou3d_nms_utils.py:31-45"""
     return _pair('dm_boxes_iou_bev', boxes_a, boxes_b)

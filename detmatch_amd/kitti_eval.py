@@ -95,7 +95,9 @@ def _bev_intersection(boxes, qboxes):
         return torch.cat([b[:, 0:2], z, b[:, 2:4], z + 1, -b[:, 4:5]], dim=1).contiguous()
     if len(boxes) == 0 or len(qboxes) == 0:
         return np.zeros((len(boxes), len(qboxes)), dtype=np.float64)
-    return iou3d_nms.boxes_overlap_bev(as7(boxes), as7(qboxes)).double().cpu().numpy()
+    # exact convex clipping (no 1 cm corner margin of the NMS kernel): matches near the 0.7 / 0.5 / 0.25
+    # thresholds must not flip between TP and FP
+    return iou3d_nms.boxes_overlap_bev_exact(as7(boxes), as7(qboxes)).double().cpu().numpy()
 
 
 def bev_box_overlap(boxes, qboxes, criterion=-1):

@@ -219,6 +219,12 @@ size_t dm_iou3d_workspace_bytes(int na, int nb);
 int dm_boxes_overlap_bev(const float *boxes_a, int na, const float *boxes_b, int nb,
                          float *ans_overlap, void *workspace, size_t workspace_bytes,
                          dm_stream_t stream);
+/* Exact rotated BEV intersection area (no 1 cm corner-containment margin, convex clipping in double
+ * precision) for threshold / zero comparisons: KITTI evaluation (reference: rotate_iou_gpu_eval,
+ * mmdet3d/core/evaluation/kitti_utils/rotate_iou.py) and the GT-paste collision test
+ * (box_np_ops.box_collision_test).  Same box format and output as dm_boxes_overlap_bev. */
+int dm_boxes_overlap_bev_exact(const float *boxes_a, int na, const float *boxes_b, int nb,
+                               float *ans_overlap, dm_stream_t stream);
 int dm_boxes_iou_bev(const float *boxes_a, int na, const float *boxes_b, int nb, float *ans_iou,
                      void *workspace, size_t workspace_bytes, dm_stream_t stream);
 /* Replaces iou3d_nms_cuda.nms_gpu / nms_normal_gpu

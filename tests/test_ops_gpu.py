@@ -375,3 +375,52 @@ def test_fps_large_clouds_multi_workgroup_equals_single_workgroup(dev, n, m, bat
     assert out[0].shape == (batch, m) and torch.equal(out[0], out[1])
     assert all(int(out[0][b].max()) < sizes[b] for b in range(batch))
     assert all(len(set(out[0][b].tolist())) > m * 0.9 for b in range(batch))
+
+
+def test_exact_bev_overlap_on_near_touching_and_near_threshold_pairs(dev):
+    """dm_boxes_overlap_bev_exact (KITTI evaluation, GT-paste collision test) against independent
+    float64 polygon clipping (tests/_polyclip.py) on randomized pairs incl. boxes a few millimetres
+    apart (must be 0: the NMS kernel's 1 cm corner margin reports an overlap there) and pairs whose IoU
+    sits within 1e-3 of the 0.7 / 0.5 / 0.25 thresholds (the TP / FP decision must agree)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _polyclip import intersection_area
+    from detmatch_amd import iou3d_nms
+    rng = np.random.default_rng(3)
+    n = 400
+    a = np.zeros((n, 7), np.float32)
+    a[:, 0:2] = rng.uniform(-20, 20, (n, 2))
+    a[:, 3:5] = rng.uniform(1.0, 5.0, (n, 2))
+    a[:, 5] = 1
+    a[:, 6] = rng.uniform(-3.2, 3.2, n)
+    b = a.copy()
+    b[:, 0:2] += rng.normal(0, 1.0, (n, 2))
+    b[:, 3:5] *= rng.uniform(0.8, 1.25, (n, 2))
+    b[:, 6] += rng.normal(0, 0.3, n)
+    # near-touching: same heading, shifted along the local x axis by (dx_a + dx_b) / 2 + gap
+    for i, gap in enumerate([0.002, 0.005, 0.009, -0.002, 0.0005, 0.02]):
+        b[i] = a[i]
+        h = a[i, 6]
+        d = a[i, 3] + gap
+        b[i, 0] += d * np.cos(h)
+        b[i, 1] += d * np.sin(h)
+
+    def corners(r):      # counter-clockwise turn by the heading: the pcdet kernel's convention
+        c, s = np.cos(r[6]), np.sin(r[6])
+        loc = np.array([[-r[3] / 2, -r[4] / 2], [r[3] / 2, -r[4] / 2], [r[3] / 2, r[4] / 2], [-r[3] / 2, r[4] / 2]])
+        return np.stack([r[0] + c * loc[:, 0] - s * loc[:, 1], r[1] + s * loc[:, 0] + c * loc[:, 1]], 1)
+    want = np.array([intersection_area(corners(a[i].astype(np.float64)), corners(b[i].astype(np.float64)))
+                     for i in range(n)])
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    got = iou3d_nms.boxes_overlap_bev_exact(ta, tb).diagonal().cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    assert (got[[0, 1, 2, 4, 5]] == 0).all() and got[3] > 0          # gaps of 0.5-20 mm: disjoint
+    margin = iou3d_nms.boxes_overlap_bev(ta, tb).diagonal().cpu().numpy()
+    assert (margin[[0, 1, 2]] > 0).all()                             # what the corner margin does to them
+    # near-threshold IoUs: scale b around the pair's centre until IoU is within 1e-3 of a threshold
+    area_a, area_b = a[:, 3] * a[:, 4], b[:, 3] * b[:, 4]
+    iou_w = want / (area_a + area_b - want)
+    iou_g = got / (area_a + area_b - got)
+    for thr in (0.7, 0.5, 0.25):
+        close = np.abs(iou_w - thr) > 1e-6
+        assert ((iou_w > thr) == (iou_g > thr))[close].all()
