@@ -760,26 +760,28 @@ __device__ __forceinline__ bool fps_take(float d2, int k2, float d1, int k1, int
   return fps_better(d2, k2, d1, k1, bs_mask);
 }
 
-struct FpsSlot {   // 32 bytes
-  float d;
-  int k;
-  float x, y, z;
-  int tag;
-  int pad0, pad1;
-};
-
+// One 64-bit word per (round parity, workgroup): {distance bits : 32 | round & 255 : 8 | index : 24},
+// published with ONE relaxed read-modify-write and polled with read-modify-writes: atomics execute at the
+// device's coherence point, so no release / acquire fences (L2 write-back + invalidate per round) are
+// needed; the winner's coordinates are re-read from the (read-only) point array.
 constexpr int FPS_MT = 1024;
+
+__device__ __forceinline__ unsigned long long fps_word(float d, int k, int round) {
+  return ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)(round & 255) << 24) |
+         (unsigned long long)(k & 0xFFFFFF);
+}
 
 template <int PPT>
 __global__ __launch_bounds__(FPS_MT) void fps_kernel_multi(FpsSamples smp, int m, const float *__restrict__ xyz,
                                                            float *__restrict__ temp, int *__restrict__ idxs) {
-  __shared__ float s_d[16], s_x[16], s_y[16], s_z[16];
+  __shared__ float s_d[16];
   __shared__ int s_k[16];
   __shared__ float s_win[3];
   const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x;
   const int n = smp.off[b + 1] - smp.off[b];
   const float *data = xyz + (size_t)smp.off[b] * 3;
-  FpsSlot *slots = (FpsSlot *)(temp + (size_t)smp.off[b]);   // [2][G]; the launcher aligned and tagged it
+  // [2][G] words at the first 8-byte boundary of the sample's scratch range (tagged 0xFF.. by the launcher)
+  unsigned long long *slots = (unsigned long long *)(((uintptr_t)(temp + (size_t)smp.off[b]) + 7) & ~(uintptr_t)7);
   int *out = idxs + (size_t)b * m;
   if (n <= 0) return;
   int bs = 1;
@@ -812,84 +814,56 @@ __global__ __launch_bounds__(FPS_MT) void fps_kernel_multi(FpsSamples smp, int m
       bslot = take ? i : bslot;
     }
     int besti = (bslot * G + g) * FPS_MT + tid;
-    float bx = px[0], by = py[0], bz = pz[0];
-#pragma unroll
-    for (int i = 1; i < PPT; ++i) {
-      bx = bslot == i ? px[i] : bx;
-      by = bslot == i ? py[i] : by;
-      bz = bslot == i ? pz[i] : bz;
-    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-      const float od = __shfl_xor(best, off), ox = __shfl_xor(bx, off), oy = __shfl_xor(by, off),
-                  oz = __shfl_xor(bz, off);
+      const float od = __shfl_xor(best, off);
       const int ok = __shfl_xor(besti, off);
       if (fps_take(od, ok, best, besti, bs_mask)) {
         best = od;
         besti = ok;
-        bx = ox;
-        by = oy;
-        bz = oz;
       }
     }
-    if (lane == 0) s_d[wave] = best, s_k[wave] = besti, s_x[wave] = bx, s_y[wave] = by, s_z[wave] = bz;
+    if (lane == 0) s_d[wave] = best, s_k[wave] = besti;
     __syncthreads();
     if (wave == 0) {
-      float d = lane < 16 ? s_d[lane] : -1.f, x = lane < 16 ? s_x[lane] : 0.f, y = lane < 16 ? s_y[lane] : 0.f,
-            z = lane < 16 ? s_z[lane] : 0.f;
+      float d = lane < 16 ? s_d[lane] : -1.f;
       int k = lane < 16 ? s_k[lane] : 0;
 #pragma unroll
       for (int off = 8; off >= 1; off >>= 1) {
-        const float od = __shfl_xor(d, off), ox = __shfl_xor(x, off), oy = __shfl_xor(y, off), oz = __shfl_xor(z, off);
+        const float od = __shfl_xor(d, off);
         const int ok = __shfl_xor(k, off);
         if (fps_take(od, ok, d, k, bs_mask)) {
           d = od;
           k = ok;
-          x = ox;
-          y = oy;
-          z = oz;
         }
       }
-      FpsSlot *row = slots + (size_t)(j & 1) * G;
-      if (lane == 0) {   // publish this workgroup's candidate, payload first, then the round tag
-        FpsSlot *mine = row + g;
-        __hip_atomic_store(&mine->d, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->k, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->x, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->y, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->z, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->tag, j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      // everybody's candidates of this round
-      d = -1.f, k = 0, x = y = z = 0.f;
+      unsigned long long *row = slots + (size_t)(j & 1) * G;
+      if (lane == 0)
+        __hip_atomic_exchange(row + g, fps_word(d, k, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      d = -1.f, k = 0;
       for (int q = lane; q < G; q += 64) {
-        FpsSlot *o = row + q;
-        while (__hip_atomic_load(&o->tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != j) __builtin_amdgcn_s_sleep(1);
-        const float od = __hip_atomic_load(&o->d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int ok = __hip_atomic_load(&o->k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long w;
+        do {
+          w = __hip_atomic_fetch_or(row + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (((w >> 24) & 255ull) != (unsigned long long)(j & 255));
+        const float od = __uint_as_float((unsigned int)(w >> 32));
+        const int ok = (int)(w & 0xFFFFFFull);
         if (fps_take(od, ok, d, k, bs_mask)) {
-          d = od, k = ok;
-          x = __hip_atomic_load(&o->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          y = __hip_atomic_load(&o->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          z = __hip_atomic_load(&o->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          d = od;
+          k = ok;
         }
       }
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
-        const float od = __shfl_xor(d, off), ox = __shfl_xor(x, off), oy = __shfl_xor(y, off), oz = __shfl_xor(z, off);
+        const float od = __shfl_xor(d, off);
         const int ok = __shfl_xor(k, off);
         if (fps_take(od, ok, d, k, bs_mask)) {
           d = od;
           k = ok;
-          x = ox;
-          y = oy;
-          z = oz;
         }
       }
-      if (lane == 0) {
-        s_win[0] = x, s_win[1] = y, s_win[2] = z;
-        if (g == 0) out[j] = k;
-      }
+      if (lane < 3) s_win[lane] = data[(size_t)k * 3 + lane];
+      if (lane == 0 && g == 0) out[j] = k;
     }
     __syncthreads();
     x1 = s_win[0], y1 = s_win[1], z1 = s_win[2];
@@ -1075,11 +1049,11 @@ static int fps_launch(const FpsSamples &smp, int batch, int max_n, int m, const 
     int G = 128 / batch;
     G = G > 64 ? 64 : (G < 1 ? 1 : G);
     const int ppt_m = dm_ceil_div(max_n, G * FPS_MT);
-    bool aligned = g_fps_variant != 1 && G >= 2 && ppt_m <= 8;     // (slots are 4-byte fields: any offset works)
-    for (int b = 0; b < batch && aligned; ++b) aligned = (smp.off[b + 1] - smp.off[b]) >= 2 * G * 8;
+    bool aligned = g_fps_variant != 1 && G >= 2 && ppt_m <= 8 && max_n < (1 << 24);
+    for (int b = 0; b < batch && aligned; ++b) aligned = (smp.off[b + 1] - smp.off[b]) >= 4 * G + 4;
     if (aligned) {
       for (int b = 0; b < batch; ++b)
-        DM_HIP(hipMemsetAsync(temp + smp.off[b], 0xFF, (size_t)2 * G * sizeof(FpsSlot), st));
+        DM_HIP(hipMemsetAsync(temp + smp.off[b], 0xFF, ((size_t)2 * G + 1) * sizeof(unsigned long long), st));
       if (ppt_m <= 4) fps_kernel_multi<4><<<dim3(G, batch), FPS_MT, 0, st>>>(smp, m, xyz, temp, idxs);
       else fps_kernel_multi<8><<<dim3(G, batch), FPS_MT, 0, st>>>(smp, m, xyz, temp, idxs);
     } else {

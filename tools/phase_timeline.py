@@ -35,7 +35,8 @@ def wrap(obj, attr, label):
 def main():
     from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
     dev = torch.device('cuda', 0)
-    wl = DetMatchTrainWorkload(2, dev)
+    profile = os.environ.get('DM_BENCH_PROFILE', 'kitti')
+    wl = DetMatchTrainWorkload(1 if profile == 'waymo' else 2, dev, profile=profile)
     m = wl.model
     for tag, lst in (('lab', m.lab_ssl_modules), ('unlab', m.unlab_ssl_modules)):
         for i, mod in enumerate(lst):
