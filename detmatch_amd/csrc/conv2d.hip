@@ -752,6 +752,147 @@ __global__ __launch_bounds__(WAVES_U *WAVES_V * 64) void dconv_wgrad_kernel(
   }
 }
 
+// Mixed-precision weight gradient (dm_dconv_set_math(1)), 128 x 128 tiles: both operands have the
+// reduction index (pixels) as their ROW index in memory, so the MFMA fragments (8 consecutive pixels of
+// one channel) are columns of the staged tile.  The tile is stored as it arrives — [pixel][channel]
+// bf16 rows of 256 B, 16-byte chunks XOR-swizzled — and read with gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: per 16 lanes a block of 4 pixel rows x 16 channels, delivered channel-major),
+// two reads per v_mfma_f32_32x32x16_bf16 operand, conflict-free on this image.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int wg_tile_off(int row, int chunk) {   // bytes; chunk = 16-byte piece of the row
+  return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__restrict__ U, const float *__restrict__ V,
+                                                               float *__restrict__ part, const DWgradGeom g,
+                                                               const DConvTaps tt, int n_tiles_u, int n_tiles_v) {
+  constexpr int BU = 128, BV = 128, BK = 32, WU = 64, WV = 64, TU = 2, TV = 2;
+  constexpr int TILE_BYTES = BK * 256;                       // one operand, one buffer
+  constexpr int LDS_STAGE = 4 * TILE_BYTES, LDS_EPI = 4 * WU * (WV + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_STAGE > LDS_EPI ? LDS_STAGE : LDS_EPI];
+
+  int tile = blockIdx.x;
+  const int vt = tile % n_tiles_v;
+  tile /= n_tiles_v;
+  const int ut = tile % n_tiles_u;
+  const int t = tile / n_tiles_u;
+  const int split = blockIdx.y;
+  const int m_lo = split * g.chunk;
+  const int m_hi = min(g.M, m_lo + g.chunk);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wu = wave >> 1, wv = wave & 1;
+  const int u0 = ut * BU, v0 = vt * BV;
+  const int cq = tid & 31, r0 = tid >> 5;                    // channel quad, first pixel row of the thread
+  const int dy = tt.dy[t], dx = tt.dx[t];
+  const bool u_ok = u0 + cq * 4 < g.Cu, v_ok = v0 + cq * 4 < g.Cv;
+
+  f32x16 acc[TU][TV];
+#pragma unroll
+  for (int a = 0; a < TU; ++a)
+#pragma unroll
+    for (int b = 0; b < TV; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float4 ru[4], rv[4];
+  bool ru_ok[4], rv_ok[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = m_lo + kt * BK + r0 + p * 8;
+      const bool ok = (m < m_hi) & u_ok;
+      ru[p] = *(const float4 *)(U + (size_t)(ok ? m : m_lo) * g.Cu + (u_ok ? u0 + cq * 4 : 0));
+      ru_ok[p] = ok;
+      const int mm = m < m_hi ? m : m_lo;
+      const int j = mm % g.LW, tmp = mm / g.LW, i = tmp % g.LH, b = tmp / g.LH;
+      const int iy = i * g.vys + dy, ix = j * g.vxs + dx;
+      const bool okv = (m < m_hi) & v_ok & ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
+      const int pix = okv ? (b * g.Hv + iy) * g.Wv + ix : 0;
+      rv[p] = *(const float4 *)(V + (size_t)pix * g.Cv + (v_ok ? v0 + cq * 4 : 0));
+      rv_ok[p] = okv;
+    }
+  };
+  auto sstore = [&](int buf) {
+    unsigned char *ub = lds + buf * 2 * TILE_BYTES, *vb = ub + TILE_BYTES;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = r0 + p * 8;
+      const int off = wg_tile_off(row, cq >> 1) + 8 * (cq & 1);
+      float4 a = ru[p], b = rv[p];
+      const bool oka = ru_ok[p], okb = rv_ok[p];
+      a.x = oka ? a.x : 0.0f, a.y = oka ? a.y : 0.0f, a.z = oka ? a.z : 0.0f, a.w = oka ? a.w : 0.0f;
+      b.x = okb ? b.x : 0.0f, b.y = okb ? b.y : 0.0f, b.z = okb ? b.z : 0.0f, b.w = okb ? b.w : 0.0f;
+      *(uint2 *)(ub + off) = pack_bf16x4(a);
+      *(uint2 *)(vb + off) = pack_bf16x4(b);
+    }
+  };
+  // transposed fragment reads: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of its block
+  const int grp = lane >> 4, li = lane & 15, fq = li >> 2, fp = li & 3;
+  const int cb = grp & 1, fh = grp >> 1;
+  auto frag = [&](const unsigned char *base, int ks, int chan0) {   // chan0: first channel of the 32-block
+    bf16x8 out;
+    const int c0 = (chan0 + 16 * cb) / 8 + (fp >> 1);
+    union { s16x4 s[2]; bf16x8 v; } u;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 16 * ks + 8 * fh + 4 * rr + fq;
+      u.s[rr] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4 *)(base + wg_tile_off(row, c0) + 8 * (fp & 1)));
+    }
+    out = u.v;
+    return out;
+  };
+
+  const int KT = (m_hi - m_lo + BK - 1) / BK;
+  if (KT > 0) {
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < KT;
+      if (more) gload(kt + 1);
+      const unsigned char *ub = lds + buf * 2 * TILE_BYTES, *vb = ub + TILE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 af[TU], bfr[TV];
+#pragma unroll
+        for (int a = 0; a < TU; ++a) af[a] = frag(ub, ks, wu * WU + a * 32);
+#pragma unroll
+        for (int b = 0; b < TV; ++b) bfr[b] = frag(vb, ks, wv * WV + b * 32);
+#pragma unroll
+        for (int a = 0; a < TU; ++a)
+#pragma unroll
+          for (int b = 0; b < TV; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+      if (more) sstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  float *dst = part + ((size_t)split * g.T + t) * g.Cu * g.Cv;
+  constexpr int LDC = WV + 4;
+  const int lr = lane & 31, lh = lane >> 5;
+  float *cs = (float *)lds + wave * WU * LDC;
+#pragma unroll
+  for (int b = 0; b < TV; ++b)
+#pragma unroll
+    for (int a = 0; a < TU; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + b * 32 + lr] = acc[a][b][r];
+  constexpr int CQ = WV / 4, RPI = 64 / CQ;
+  const int ccq = lane % CQ, rr = lane / CQ;
+  const int vcol = v0 + wv * WV + ccq * 4;
+#pragma unroll 4
+  for (int it = 0; it < WU / RPI; ++it) {
+    const int rl = it * RPI + rr;
+    const int u = u0 + wu * WU + rl;
+    if (u < g.Cu && vcol < g.Cv) *(float4 *)(dst + (size_t)u * g.Cv + vcol) = *(const float4 *)(cs + rl * LDC + ccq * 4);
+  }
+}
+
 // out[u*su + v*sv + t*st] = scale_u[u] * sum_s part[s][t][u][v]   (v < Cv_out: drops channel padding)
 __global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(
     const float *__restrict__ part, float *__restrict__ out, const float *__restrict__ scale_u,
@@ -1068,6 +1209,9 @@ extern "C" int dm_dconv_wgrad(const float *U, const float *V, float *out, const 
     const int tu = dm_ceil_div(g.Cu, 64), tv = dm_ceil_div(g.Cv, 64);
     dconv_wgrad_kernel<64, 64, 32, 2, 2><<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g, tt,
                                                                                  tu, tv);
+  } else if (g_dconv_math == 1) {      // mixed precision: bf16 multiplicands, fp32 accumulate
+    const int tu = dm_ceil_div(g.Cu, 128), tv = dm_ceil_div(g.Cv, 128);
+    dconv_wgrad_bf16_kernel<<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g, tt, tu, tv);
   } else {
     const int tu = dm_ceil_div(g.Cu, 128), tv = dm_ceil_div(g.Cv, 128);
     dconv_wgrad_kernel<128, 128, 32, 2, 2><<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g,

@@ -530,8 +530,8 @@ int dm_dconv_pack(const float *src, float *dst, const float *scale_n, const floa
 /* Arithmetic of dm_dconv_gemm: 0 (default) exact fp32 (v_mfma_f32_32x32x2_f32); 1 mixed precision —
  * bf16 multiplicands (inputs and weights rounded to nearest-even on their way into LDS), fp32
  * accumulation and storage (v_mfma_f32_32x32x16_bf16), the counterpart of the reference's fp16
- * (autocast) configs; layers with Cin % 64 != 0 stay fp32.  Process-wide; dm_dconv_wgrad is fp32
- * in both modes. */
+ * (autocast) configs; layers with Cin % 64 != 0 stay fp32.  Process-wide; dm_dconv_wgrad follows the
+ * mode for layers with more than 64 channels on both sides (the others stay fp32). */
 int dm_dconv_set_math(int mode);
 int dm_dconv_get_math(void);
 /* The same for n_entries weights in one launch.  table_dev: device array of 80-byte rows

@@ -234,7 +234,7 @@ def test_mixed_precision_math_mode(dev, shape):
     """dm_dconv_set_math(1): bf16 multiplicands, fp32 accumulation.  Forward and input gradient equal the
     float64 convolution of the bf16-ROUNDED operands to fp32-accumulation accuracy, and the exact
     convolution to bf16 accuracy (what the reference's fp16 autocast configs accept); the weight
-    gradient stays fp32."""
+    gradient likewise for layers with more than 64 channels on both sides (the others stay fp32)."""
     from detmatch_amd import dense_conv
     xs, cout, k, s, p = shape
     g = torch.Generator().manual_seed(21)
@@ -268,8 +268,14 @@ def test_mixed_precision_math_mode(dev, shape):
     # (b) the exact convolution, to half-precision accuracy
     ye = F.conv2d(x.double(), w.double(), b.double(), s, p)
     assert float((y.detach().cpu().double() - ye).abs().max()) <= 2e-2 * scale
-    # (c) weight gradient: fp32 arithmetic on the unrounded tensors
-    xe = x.double()
+    # (c) weight gradient: bf16 multiplicands when both channel counts exceed 64, fp32 arithmetic otherwise
+    mixed_w = xs[1] > 64 and cout > 64
+    xe = (_bf16_round(x) if mixed_w else x.double())
+    ge = (_bf16_round(gy) if mixed_w else gy.double())
     we = w.double().requires_grad_(True)
-    (F.conv2d(xe, we, None, s, p) * gy.double()).sum().backward()
+    (F.conv2d(xe, we, None, s, p) * ge).sum().backward()
     assert float((wd.grad.cpu().double() - we.grad).abs().max()) <= 1e-4 * float(we.grad.abs().max())
+    if mixed_w:      # and the exact gradient to half-precision accuracy
+        we2 = w.double().requires_grad_(True)
+        (F.conv2d(x.double(), we2, None, s, p) * gy.double()).sum().backward()
+        assert float((wd.grad.cpu().double() - we2.grad).abs().max()) <= 2e-2 * float(we2.grad.abs().max())
