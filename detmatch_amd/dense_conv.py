@@ -40,11 +40,36 @@ def get_math():
     return 'bf16' if _lib.lib().dm_dconv_get_math() == 1 else 'fp32'
 
 
-def weights_changed():
+_EVENTS = []        # (generation after the event, ptr_lo, ptr_hi) of raw-pointer rewrites; None = everything
+
+
+def weights_changed(ptr_lo=None, ptr_hi=None):
+    """Somebody rewrote weights through raw pointers (fused optimizer / EMA kernels).  With a byte range
+    [ptr_lo, ptr_hi) only packed copies whose source lies inside become stale — the EMA of the teacher
+    then does not force a re-pack of the student's weights in the middle of the iteration."""
     _GENERATION[0] += 1
+    _EVENTS.append((_GENERATION[0], ptr_lo, ptr_hi))
+    if len(_EVENTS) > 64:
+        del _EVENTS[:]
+        _EVENTS.append((_GENERATION[0], None, None))
+        _FLOOR[0] = _GENERATION[0]
     if len(_PACK_CACHE) > 4096:
         _PACK_CACHE.clear()
         _TABLES.clear()
+
+
+_FLOOR = [0]        # entries packed before this generation are stale whatever the events say
+
+
+def _stale(entry_gen, src_ptr):
+    if entry_gen < _FLOOR[0]:
+        return True
+    for gen, lo, hi in reversed(_EVENTS):
+        if gen <= entry_gen:
+            break
+        if lo is None or lo <= src_ptr < hi:
+            return True
+    return False
 
 
 def _shorts(v):
@@ -112,8 +137,8 @@ def _constant(t):
 
 
 def _refresh_stream(stream, device):
-    """Re-pack every batchable cached weight of this stream in ONE launch (after the fused optimizer
-    / EMA kernels rewrote the weights: `weights_changed`)."""
+    """Re-pack the stale batchable cached weights of this stream in ONE launch (after the fused optimizer
+    / EMA kernels rewrote them: `weights_changed`); the others just move to the current generation."""
     import numpy as np
     reg = _TABLES[stream]
     live = []
@@ -121,17 +146,23 @@ def _refresh_stream(stream, device):
         w = e.wref()
         if w is not None and w.data_ptr() == e.desc[0] and _PACK_CACHE.get(e.desc[-1]) is e:
             live.append(e)
-    if len(live) != len(reg['entries']) or reg['table'] is None:
-        reg['entries'] = live
-        rows = np.zeros(len(live), dtype=_desc_dtype())
-        for i, e in enumerate(live):
-            rows[i] = e.desc[:-1]
-        reg['table'] = torch.from_numpy(rows.view(np.uint8)).to(device) if live else None
-        reg['blocks'] = max(1, min(64, max((e.dst.numel() for e in live), default=1) // 1024))
-    if live:
-        _lib.check(_lib.lib().dm_dconv_pack_batch(_lib.ptr(reg['table']), len(live), reg['blocks'],
-                                                  _lib.stream()), 'dm_dconv_pack_batch')
+    reg['entries'] = live
     gen = _GENERATION[0]
+    dirty = [e for e in live if e.ver[1] != e.wref()._version or _stale(e.ver[0], e.desc[0])]
+    if dirty:
+        sig = tuple(id(e) for e in dirty)
+        tables = reg.setdefault('tables', {})
+        hit = tables.get(sig)
+        if hit is None:
+            if len(tables) > 8:
+                tables.clear()
+            rows = np.zeros(len(dirty), dtype=_desc_dtype())
+            for i, e in enumerate(dirty):
+                rows[i] = e.desc[:-1]
+            blocks = max(1, min(256, max(e.dst.numel() for e in dirty) // 2048))
+            hit = tables[sig] = (torch.from_numpy(rows.view(np.uint8)).to(device), blocks, list(dirty))
+        _lib.check(_lib.lib().dm_dconv_pack_batch(hit[0].data_ptr(), len(dirty), hit[1], _lib.raw_stream()),
+                   'dm_dconv_pack_batch')
     for e in live:
         e.ver = (gen, e.wref()._version, e.ver[2], e.ver[3])
 
@@ -147,6 +178,9 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
         hit = None
     if hit is not None:
         if hit.ver == ver:
+            return hit.dst
+        if hit.ver[1:] == ver[1:] and hit.desc[0] == weight.data_ptr() and not _stale(hit.ver[0], hit.desc[0]):
+            hit.ver = ver              # rewritten weights were somebody else's
             return hit.dst
         if hit.batchable and hit.ver[2:] == ver[2:]:
             _refresh_stream(stream, weight.device)
@@ -168,9 +202,9 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
                   0 if scale_k is None else scale_k.data_ptr(), sn, sk, st, S, N, K, n_src, k_src, 0, key)
         _PACK_CACHE[key] = e
         if e.batchable:
-            reg = _TABLES.setdefault(stream, {'entries': [], 'table': None, 'blocks': 1})
+            reg = _TABLES.setdefault(stream, {'entries': []})
             reg['entries'].append(e)
-            reg['table'] = None
+            reg.pop('tables', None)
     return dst
 
 

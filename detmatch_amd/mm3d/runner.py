@@ -194,7 +194,8 @@ class FusedRange(object):
 
     def step(self, grad_scale=None):
         from .. import _lib, dense_conv
-        dense_conv.weights_changed()     # raw-pointer update: packed conv weights are stale now
+        fp = self.ddp.flat_params     # raw-pointer update: packed copies of THESE weights are stale now
+        dense_conv.weights_changed(fp.data_ptr() + 4 * self.lo, fp.data_ptr() + 4 * self.hi)
         L = _lib.lib()
         g0 = self.opt.param_groups[0]
         d = self.ddp

@@ -317,7 +317,8 @@ class SSL(nn.Module):
             raise _lib.DetMatchHipError('EMA runs on the MI355X only')
         self._bump_frozen_bn()
         from .. import dense_conv
-        dense_conv.weights_changed()     # the teacher's conv weights were rewritten through raw pointers
+        # the teacher's conv weights were rewritten through raw pointers (the student's were not)
+        dense_conv.weights_changed(t.flat_f.data_ptr(), t.flat_f.data_ptr() + 4 * t.flat_f.numel())
         if self.use_student_bn_stats_for_teacher:
             tsd, ssd = self.teacher.state_dict(), self.student.state_dict()
             for k in tsd:
