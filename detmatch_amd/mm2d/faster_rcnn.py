@@ -21,6 +21,7 @@ from ..devconst import const
 from ..mm3d.base_detector import DetectorStepMixin
 from ..mm3d.losses import bbox_overlaps
 from ..mm3d.registry import DETECTORS, LOSSES, build_from_cfg
+from ..fused import on as fused_on
 from ..roi_align import roi_align_fpn
 from .backbone import FPN, ResNet
 
@@ -305,7 +306,7 @@ class RPNHead(nn.Module):
             cache[key] = torch.cat(self.anchor_generator.grid_anchors(sizes, device), dim=0).contiguous()
         return cache[key]
 
-    def loss(self, cls, reg, gt_bboxes, img_metas, fused=True, keys=None):
+    def loss(self, cls, reg, gt_bboxes, img_metas, fused=None, keys=None):
         """mmdet AnchorHead.loss with sampling: BCE over the 256 sampled anchors, L1 over encoded
         deltas of the sampled positives, both / num_total_samples (summed over the batch)."""
         cfg = self.train_cfg
@@ -315,7 +316,7 @@ class RPNHead(nn.Module):
         if keys is None:
             keys = torch.rand((cls[0].shape[0], anchors.shape[0]), device=anchors.device)
         raw = getattr(self, '_raw_levels', None)
-        if fused and anchors.is_cuda and raw is not None and len(raw) == len(cls) \
+        if fused_on(fused) and anchors.is_cuda and raw is not None and len(raw) == len(cls) \
                 and all(c.data_ptr() == y.data_ptr() and c.shape[2:] == y.shape[2:] and c.requires_grad == y.requires_grad
                         for c, y in zip(cls, raw)) and cls[0].shape[0] <= 8 \
                 and max(g.shape[0] for g in gt_bboxes) <= 256:
@@ -380,14 +381,14 @@ class RPNHead(nn.Module):
         return boxes, scores, live, b_nms, s_nms
 
     @torch.no_grad()
-    def get_bboxes(self, cls, reg, img_metas, cfg, fused=True):
+    def get_bboxes(self, cls, reg, img_metas, cfg, fused=None):
         """mmdet RPNHead._get_bboxes_single per image: per-level top nms_pre, decode, drop empty
         boxes, NMS across levels (boxes of different levels never suppress each other), keep
         max_per_img.  -> list of (proposals (max_per_img, 5) [x1,y1,x2,y2,score], ok (max_per_img))."""
         sizes = [c.shape[-2:] for c in cls]
         nms_thr = cfg['nms'].get('iou_threshold', cfg['nms'].get('iou_thr', 0.7))
         raw = getattr(self, '_raw_levels', None)
-        if fused and cls[0].is_cuda and raw is not None and len(raw) == len(cls) and cls[0].shape[0] <= 8 \
+        if fused_on(fused) and cls[0].is_cuda and raw is not None and len(raw) == len(cls) and cls[0].shape[0] <= 8 \
                 and 0 < cfg['nms_pre'] <= 2048 \
                 and all(c.data_ptr() == y.data_ptr() and c.shape[2:] == y.shape[2:] for c, y in zip(cls, raw)):
             boxes, s, live, b_nms, s_nms = self._pre_nms_device(raw, sizes, img_metas, cfg)
@@ -458,11 +459,11 @@ class Shared2FCBBoxHead(nn.Module):
             x = F.relu(fc(x), inplace=True)
         return self.fc_cls(x), self.fc_reg(x)
 
-    def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, fused=True):
+    def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, fused=None):
         """mmdet BBoxHead.loss: cls avg_factor = #(label_weights > 0); box loss over positives of
         the class-specific prediction, averaged over ALL sampled RoIs (bbox_targets.size(0))."""
         from ..mm3d.losses import FocalLoss, L1Loss
-        if fused and cls_score.is_cuda and isinstance(self.loss_cls, FocalLoss) and self.loss_cls.gamma == 2.0 \
+        if fused_on(fused) and cls_score.is_cuda and isinstance(self.loss_cls, FocalLoss) and self.loss_cls.gamma == 2.0 \
                 and self.loss_cls.reduction == 'mean' and isinstance(self.loss_bbox, L1Loss) \
                 and self.loss_bbox.reduction == 'mean':
             meta = (self.num_classes, bool(self.reg_class_agnostic), self.loss_cls.alpha,
@@ -576,7 +577,7 @@ class StandardRoIHead(nn.Module):
             rois = torch.cat(rois)
         return rois, torch.cat(labels), torch.cat(lw), torch.cat(tgts), torch.cat(bw)
 
-    def forward_train(self, feats, img_metas, proposals, gt_bboxes, gt_labels, fused=True, keys=None):
+    def forward_train(self, feats, img_metas, proposals, gt_bboxes, gt_labels, fused=None, keys=None):
         cfg = self.train_cfg
         a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
         num = s_cfg['num']
@@ -584,7 +585,7 @@ class StandardRoIHead(nn.Module):
         if keys is None:
             keys = torch.rand((len(proposals), proposals[0][0].shape[0] + max(g.shape[0] for g in gt_bboxes)),
                               device=proposals[0][0].device)
-        if fused and keys.is_cuda and len(proposals) <= 8 and max(g.shape[0] for g in gt_bboxes) <= 256 \
+        if fused_on(fused) and keys.is_cuda and len(proposals) <= 8 and max(g.shape[0] for g in gt_bboxes) <= 256 \
                 and num <= 512:
             rois, labels, lw, tgts, bw = self._targets_device(proposals, gt_bboxes, gt_labels, keys)
             cls_score, bbox_pred = self.bbox_head(self.extract(feats, rois))

@@ -13,6 +13,7 @@ from torch.nn import functional as F
 from .bbox_utils import (apply_3d_transformation_bboxes, bbox_2d_transform, bbox_3d_to_bbox_2d,
                          filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set)
 from ..devconst import const
+from ..fused import on as fused_on
 from .box3d import LiDARInstance3DBoxes
 from .losses import FocalLoss, MSELoss, bbox_xyxy_to_cxcywh
 from .openpcdet import pcdet_to_mm3d_boxes
@@ -353,13 +354,13 @@ class FusionHungarianMatching(object):
         packed = torch.from_numpy(np.stack([rows, cols]).astype(np.int64)).to(dev, non_blocking=True)
         return packed[0], packed[1], torch.from_numpy(cm.astype(np.float32)).to(dev, non_blocking=True)
 
-    def match(self, entry_3d, entry_2d, img_meta, fused=True):
+    def match(self, entry_3d, entry_2d, img_meta, fused=None):
         """-> (index tensor into entry_3d, index tensor into entry_2d, matched costs)"""
         s3 = _fg_scores(entry_3d[1], self.cls_includes_bg_pred_3d)
         s2 = _fg_scores(entry_2d[1], self.cls_includes_bg_pred_2d)
         assert s3.shape[1] == s2.shape[1]
         boxes2d = entry_2d[0]
-        cfg = self._device_costs() if fused else None
+        cfg = self._device_costs() if fused_on(fused) else None
         if cfg is not None and s3.is_cuda and 0 < len(s3) <= 512 and 0 < len(s2) <= 512 and s3.shape[1] <= 8:
             return self.match_device(entry_3d, entry_2d, img_meta, cfg)
         if self.project_3d_to_2d:

@@ -23,6 +23,7 @@ from .. import roiaware_pool3d
 from ..devconst import const
 from . import utils as U
 from ..bn_relu import fc_rows
+from ..fused import on as fused_on
 
 
 # ------------------------------------------------------------------- anchors
@@ -111,7 +112,7 @@ class AxisAlignedTargetAssigner(object):
         shapes = {tuple(a.shape) for a in all_anchors}
         if len(shapes) != 1:         # per-class feature maps differ: fall back to the loop
             return self._assign_targets_loop(all_anchors, gt_boxes_with_classes)
-        if all_anchors[0].is_cuda and gt_boxes_with_classes.shape[-1] == 8:
+        if fused_on() and all_anchors[0].is_cuda and gt_boxes_with_classes.shape[-1] == 8:
             return self._assign_targets_device(all_anchors, gt_boxes_with_classes)
         gt_classes = gt_boxes_with_classes[:, :, -1].int()
         gt_boxes = gt_boxes_with_classes[:, :, :-1]
@@ -486,7 +487,8 @@ class AnchorHeadSingle(nn.Module):
         """anchor_head_template.py:216-223.  On the GPU the three losses come from the fused kernel
         (csrc/anchor_loss.hip); `get_loss_torch` is the element-wise restatement of the reference (the one
         the reference-generated goldens pin, and the numerics reference of the kernel)."""
-        if self.forward_ret_dict['cls_preds'].is_cuda and os.environ.get('DM_ANCHOR_LOSS', 'fused') == 'fused':
+        if fused_on() and self.forward_ret_dict['cls_preds'].is_cuda \
+                and os.environ.get('DM_ANCHOR_LOSS', 'fused') == 'fused':
             return self.get_loss_fused()
         return self.get_loss_torch()
 
@@ -575,13 +577,13 @@ class PointHeadSimple(nn.Module):
         layers.append(nn.Linear(c_in, output_channels, bias=True))
         return nn.Sequential(*layers)
 
-    def assign_targets(self, input_dict, fused=True):
+    def assign_targets(self, input_dict, fused=None):
         """point_head_simple.py:20-48 + assign_stack_targets (set_ignore_flag branch),
         batched: every sample has the same number of keypoints."""
         point_coords = input_dict['point_coords']
         gt_boxes = input_dict['gt_boxes']
         batch_size = gt_boxes.shape[0]
-        if fused and point_coords.is_cuda and gt_boxes.shape[1] > 0:
+        if fused_on(fused) and point_coords.is_cuda and gt_boxes.shape[1] > 0:
             return {'point_cls_labels': self._assign_targets_device(point_coords, gt_boxes)}
         extend_gt_boxes = U.enlarge_box3d(gt_boxes.view(-1, gt_boxes.shape[-1]),
                                           extra_width=self.model_cfg.TARGET_CONFIG.GT_EXTRA_WIDTH
@@ -627,12 +629,12 @@ class PointHeadSimple(nn.Module):
         self.forward_ret_dict = ret_dict
         return batch_dict
 
-    def get_loss(self, tb_dict=None, fused=True):
+    def get_loss(self, tb_dict=None, fused=None):
         """point_head_template.py:131-154"""
         tb_dict = {} if tb_dict is None else tb_dict
         labels = self.forward_ret_dict['point_cls_labels'].view(-1)
         preds = self.forward_ret_dict['point_cls_preds'].view(-1, self.num_class)
-        if fused and preds.is_cuda and labels.dtype == torch.int64:
+        if fused_on(fused) and preds.is_cuda and labels.dtype == torch.int64:
             parts = _FusedPointFocalLoss.apply(
                 preds.contiguous(), labels.contiguous(), 0.25,
                 float(self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['point_cls_weight']))

@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import pointnet2_stack as pn2
 from ..bn_relu import fc_rows
+from ..fused import on as fused_on
 from ..devconst import upload
 from .utils import get_voxel_centers
 
@@ -118,8 +119,8 @@ class VoxelSetAbstraction(nn.Module):
         self.num_point_features = self.model_cfg.NUM_OUTPUT_FEATURES
         self.num_point_features_before_fusion = c_in
 
-    def interpolate_from_bev_features(self, keypoints, bev_features, batch_size, bev_stride, fused=True):
-        if fused and keypoints.is_cuda and bev_features.shape[1] % 4 == 0 and bev_features.shape[1] <= 1024:
+    def interpolate_from_bev_features(self, keypoints, bev_features, batch_size, bev_stride, fused=None):
+        if fused_on(fused) and keypoints.is_cuda and bev_features.shape[1] % 4 == 0 and bev_features.shape[1] <= 1024:
             geom = (float(self.point_cloud_range[0]), float(self.point_cloud_range[1]),
                     float(self.voxel_size[0]), float(self.voxel_size[1]), float(bev_stride))
             return _BevInterpolate.apply(bev_features, keypoints, geom)

@@ -21,6 +21,7 @@ from ..devconst import const
 from .. import pointnet2_stack as pn2
 from . import utils as U
 from ..bn_relu import fc_rows
+from ..fused import on as fused_on
 from .dense_heads import valid_gt_mask
 from .pfe import batch_row_counts
 
@@ -327,7 +328,7 @@ class PVRCNNHead(nn.Module):
 
     def assign_targets(self, batch_dict):
         """roi_head_template.py:104-134: sample + canonical transform of the GT."""
-        if batch_dict['rois'].is_cuda and batch_dict['gt_boxes'].shape[1] > 0 \
+        if fused_on() and batch_dict['rois'].is_cuda and batch_dict['gt_boxes'].shape[1] > 0 \
                 and batch_dict['gt_boxes'].shape[2] >= 8:
             return self.proposal_target_layer.forward_device(batch_dict)
         return self.assign_targets_tensor(batch_dict)
@@ -518,10 +519,10 @@ class PVRCNNHead(nn.Module):
         tb_dict['rcnn_loss'] = rcnn_loss.detach()
         return rcnn_loss, tb_dict
 
-    def get_loss(self, tb_dict=None, fused=True):
+    def get_loss(self, tb_dict=None, fused=None):
         tb_dict = {} if tb_dict is None else tb_dict
         d = self.forward_ret_dict
-        if fused and d['rcnn_reg'].is_cuda and self.box_coder.code_size == 7 and d['rcnn_cls'].shape[-1] == 1 \
+        if fused_on(fused) and d['rcnn_reg'].is_cuda and self.box_coder.code_size == 7 and d['rcnn_cls'].shape[-1] == 1 \
                 and d['reg_valid_mask'].dtype == torch.int64:
             return self.get_loss_fused(tb_dict)
         loss_cls, cls_tb = self.get_box_cls_layer_loss(self.forward_ret_dict)

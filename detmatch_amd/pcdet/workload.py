@@ -166,6 +166,7 @@ class PVRCNNTrainWorkload(object):
             self.ddp.clip_grad_norm_(10.0)
             self.opt.step()
         self.last_loss = loss.detach()
+        self.last_out = {k: v.detach() for k, v in out.items() if torch.is_tensor(v) and v.dim() == 0}
         return loss
 
     def trace_gather_gemm(self):
