@@ -8,7 +8,10 @@ CPU — next to the kernel.  `ENABLED = False` sends CUDA tensors through those 
 clears it.  Convolutions, sparse convolutions, NMS, voxelization etc. have no tensor formulation and are
 not affected.
 """
-ENABLED = True
+import os
+
+# DM_FUSED=0: A/B measurements of the tensor formulations (tools/, DESIGN.md 6.1); never set by the product
+ENABLED = os.environ.get('DM_FUSED', '1') != '0'
 
 
 def on(flag=None):
