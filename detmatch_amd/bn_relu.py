@@ -70,6 +70,13 @@ def bn_relu_rows(x, bn, relu=True):
     return F.relu(y, inplace=True) if relu else y
 
 
+def _linear_rows(x, m):
+    # (the RoI head's 27648 -> 256 layer was also tried as a split-K 1x1 convolution on conv2d.hip:
+    # 290 us forward + backward against 212 us of the BLAS kernels torch picks — kept on BLAS)
+    w = m.weight
+    return F.linear(x, w.squeeze(-1) if w.dim() == 3 else w, m.bias)
+
+
 def fc_rows(seq, x):
     """An nn.Sequential of Linear / Conv1d(kernel 1) + BatchNorm1d + ReLU (+ Dropout) layers — the FC
     stacks of the PV-RCNN heads (pvrcnn_head.py:25-52 builds them from Conv1d on (N, C, 1) tensors,
@@ -81,11 +88,10 @@ def fc_rows(seq, x):
     i = 0
     while i < len(mods):
         m = mods[i]
-        if isinstance(m, nn.Conv1d):
-            assert m.kernel_size == (1,) and m.stride == (1,) and m.padding == (0,) and m.groups == 1
-            x = F.linear(x, m.weight.squeeze(-1), m.bias)
-        elif isinstance(m, nn.Linear):
-            x = F.linear(x, m.weight, m.bias)
+        if isinstance(m, (nn.Conv1d, nn.Linear)):
+            if isinstance(m, nn.Conv1d):
+                assert m.kernel_size == (1,) and m.stride == (1,) and m.padding == (0,) and m.groups == 1
+            x = _linear_rows(x, m)
         elif isinstance(m, nn.BatchNorm1d):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             x = bn_relu_rows(x, m, relu=relu)
