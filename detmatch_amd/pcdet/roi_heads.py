@@ -329,7 +329,7 @@ class PVRCNNHead(nn.Module):
     def assign_targets(self, batch_dict):
         """roi_head_template.py:104-134: sample + canonical transform of the GT."""
         if fused_on() and batch_dict['rois'].is_cuda and batch_dict['gt_boxes'].shape[1] > 0 \
-                and batch_dict['gt_boxes'].shape[2] >= 8:
+                and 8 <= batch_dict['gt_boxes'].shape[2] <= 16 and batch_dict['rois'].shape[1] <= 3072:
             return self.proposal_target_layer.forward_device(batch_dict)
         return self.assign_targets_tensor(batch_dict)
 
