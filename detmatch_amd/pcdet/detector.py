@@ -5,6 +5,8 @@ Module names (vfe, backbone_3d, map_to_bev_module, pfe, backbone_2d, dense_head,
 point_head, roi_head) and the `global_step` buffer follow the reference so that state
 dicts are interchangeable.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -100,8 +102,22 @@ class PVRCNN(nn.Module):
         mods.append(self.roi_head)
         return mods
 
+    def _order(self, batch_dict):
+        """The reference's module order, except that the BEV backbone is issued BEFORE the key-point
+        encoder while the key points are still being sampled on a side stream (`keypoints_async`): the
+        backbone reads only `spatial_features`, which the encoder does not modify, so the order does not
+        change any value — it gives the FPS kernel (6.6 ms per pass) 8 ms of convolutions to hide behind
+        instead of stalling the main stream right after the sparse backbone."""
+        mods = self.module_list
+        if 'keypoints_async' in batch_dict and os.environ.get('DM_BEV_FIRST', '1') == '1':
+            pfe, bev = getattr(self, 'pfe', None), getattr(self, 'backbone_2d', None)
+            if pfe is not None and bev is not None and mods.index(bev) == mods.index(pfe) + 1:
+                i = mods.index(pfe)
+                mods = mods[:i] + [bev, pfe] + mods[i + 2:]
+        return mods
+
     def forward(self, batch_dict):
-        for cur_module in self.module_list:
+        for cur_module in self._order(batch_dict):
             batch_dict = cur_module(batch_dict)
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
