@@ -18,7 +18,21 @@
 
 namespace {
 
-constexpr int BN_ROWS = 512;   // rows per workgroup
+constexpr int BN_ROWS = 512;   // most rows one workgroup folds
+
+// Rows per workgroup: the reductions are a few MB at most and latency bound, so a launch wants ~1 k
+// workgroups (4 per CU) before it wants long per-thread loops — (17.6 k voxels, C = 16) on 35 workgroups
+// of 512 rows took 69 us, the same matrix on 550 workgroups of 32 rows is an HBM-speed read.  A fixed
+// function of (n, c): the summation order, hence the result, depends on the shape only.
+__host__ __device__ inline int bn_rows_per_block(long long n, int c) {
+  const int tpr = c >= 4 ? c / 4 : 1;
+  const int rpi = tpr <= 256 ? 256 / tpr : 1;           // rows one pass of the 256 threads covers
+  long long r = (n + 1023) / 1024;
+  r = (r + rpi - 1) / rpi * rpi;
+  if (r < rpi) r = rpi;
+  if (r > BN_ROWS) r = BN_ROWS;
+  return (int)r;
+}
 
 // block layout: C/4 threads per row (float4 channel groups), 256 / (C/4) rows per iteration
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ x, long long n, int c,
@@ -26,8 +40,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__
   extern __shared__ float sm[];
   const int tpr = c / 4, rpi = 256 / tpr;          // threads per row, rows per iteration
   const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-  const long long row0 = (long long)blockIdx.x * BN_ROWS;
-  const int rows = (int)min((long long)BN_ROWS, n - row0);
+  const int rpb = bn_rows_per_block(n, c);
+  const long long row0 = (long long)blockIdx.x * rpb;
+  const int rows = (int)min((long long)rpb, n - row0);
   const float4 k = *(const float4 *)(x + row0 * c + 4 * cg);   // shift: first row of the block
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (rl < rpi)
@@ -78,9 +93,23 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(
   const int ch = blockIdx.x, lane = threadIdx.x;
   const float *pm = partial + (size_t)ch * blocks, *pq = partial + ((size_t)c + ch) * blocks;
   float cnt = 0.f, mean = 0.f, m2 = 0.f;
-  for (int b = lane; b < blocks; b += 64) {
-    const float nb = (float)min((long long)BN_ROWS, n - (long long)b * BN_ROWS);
-    chan_merge(cnt, mean, m2, nb, pm[b], pq[b]);
+  const int rpb = bn_rows_per_block(n, c);
+  for (int b0 = lane; b0 < blocks; b0 += 64 * 8) {      // eight partial pairs in flight, folded in block order
+    float vm[8], vq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = min(b0 + 64 * u, blocks - 1);       // clamped, unconditional loads
+      vm[u] = pm[b];
+      vq[u] = pq[b];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 64 * u;
+      if (b < blocks) {
+        const float nb = (float)min((long long)rpb, n - (long long)b * rpb);
+        chan_merge(cnt, mean, m2, nb, vm[u], vq[u]);
+      }
+    }
   }
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -130,8 +159,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   extern __shared__ float sm[];
   const int tpr = c / 4, rpi = 256 / tpr;
   const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-  const long long row0 = (long long)blockIdx.x * BN_ROWS;
-  const int rows = (int)min((long long)BN_ROWS, n - row0);
+  const int rpb = bn_rows_per_block(n, c);
+  const long long row0 = (long long)blockIdx.x * rpb;
+  const int rows = (int)min((long long)rpb, n - row0);
   const float4 m = *(const float4 *)(mean + 4 * cg), s = *(const float4 *)(invstd + 4 * cg);
   const float4 g = gamma ? *(const float4 *)(gamma + 4 * cg) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 b = beta ? *(const float4 *)(beta + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -174,7 +204,18 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float *__rest
   const int ch = blockIdx.x, lane = threadIdx.x;
   const float *p1 = partial + (size_t)ch * blocks, *p2 = partial + ((size_t)c + ch) * blocks;
   float s1 = 0.f, s2 = 0.f;
-  for (int b = lane; b < blocks; b += 64) s1 += p1[b], s2 += p2[b];
+  for (int b0 = lane; b0 < blocks; b0 += 64 * 8) {      // eight partial pairs in flight, summed in block order
+    float v1[8], v2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = min(b0 + 64 * u, blocks - 1);       // clamped, unconditional loads
+      v1[u] = p1[b];
+      v2[u] = p2[b];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (b0 + 64 * u < blocks) s1 += v1[u], s2 += v2[u];
+  }
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const float o1 = __shfl_xor(s1, off), o2 = __shfl_xor(s2, off);
@@ -224,7 +265,8 @@ bool bn_shape_ok(long long n, int c) { return n > 0 && c >= 4 && c <= 1024 && (c
 
 extern "C" size_t dm_bn_rows_workspace_bytes(long long n, int c) {
   if (n <= 0 || c <= 0) return 256;
-  return dm_align((size_t)((n + BN_ROWS - 1) / BN_ROWS) * 2 * c * sizeof(float)) + 256;
+  const int rpb = bn_rows_per_block(n, c);
+  return dm_align((size_t)((n + rpb - 1) / rpb) * 2 * c * sizeof(float)) + 256;
 }
 
 extern "C" int dm_bn_rows_forward(const float *x, long long n, int c, const float *gamma,
@@ -236,7 +278,8 @@ extern "C" int dm_bn_rows_forward(const float *x, long long n, int c, const floa
   if (!bn_shape_ok(n, c)) return n == 0 ? DM_OK : DM_ERR_UNSUPPORTED;
   if (!x || !y || !save_mean || !save_invstd || !workspace) return DM_ERR_INVALID_ARG;
   if (workspace_bytes < dm_bn_rows_workspace_bytes(n, c)) return DM_ERR_WORKSPACE;
-  const int blocks = (int)((n + BN_ROWS - 1) / BN_ROWS);
+  const int rpb = bn_rows_per_block(n, c);
+  const int blocks = (int)((n + rpb - 1) / rpb);
   float *partial = (float *)workspace;
   bn_stats_kernel<<<blocks, 256, 2 * 256 * 4 * sizeof(float), st>>>(x, n, c, partial);
   DM_CHECK_LAUNCH();
@@ -260,7 +303,8 @@ extern "C" int dm_bn_rows_backward(const float *grad_out, const float *x, long l
   if (!grad_out || !x || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta || !workspace)
     return DM_ERR_INVALID_ARG;
   if (workspace_bytes < dm_bn_rows_workspace_bytes(n, c)) return DM_ERR_WORKSPACE;
-  const int blocks = (int)((n + BN_ROWS - 1) / BN_ROWS);
+  const int rpb = bn_rows_per_block(n, c);
+  const int blocks = (int)((n + rpb - 1) / rpb);
   float *partial = (float *)workspace;
   bn_bwd_reduce_kernel<<<blocks, 256, 2 * 256 * 4 * sizeof(float), st>>>(
       grad_out, x, n, c, gamma, beta, save_mean, save_invstd, relu, partial);

@@ -906,7 +906,15 @@ __global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(
   const int u = (int)(r % Cu), t = (int)(r / Cu);
   if (v >= Cv_out) return;
   float s = 0.0f;
-  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * total + e];
+  int k = 0;
+  for (; k + 8 <= nsplit; k += 8) {          // eight loads in flight, summed in split order
+    float p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = part[(size_t)(k + j) * total + e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += p[j];
+  }
+  for (; k < nsplit; ++k) s += part[(size_t)k * total + e];
   if (scale_u) s *= scale_u[u];
   float *o = out + u * su + v * sv + t * st;
   *o = accumulate ? *o + s : s;

@@ -296,20 +296,33 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(Pyramid pyr, const flo
     gt[b * C + c] = gsrc[e] * inv_count;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    for (int yy = 0; yy < py; ++yy) {
-      const int b0 = yb_lo[yy], b1 = yb_hi[yy];
-      if (b0 > b1) continue;
-      for (int xx = 0; xx < px; ++xx) {
-        const int a0 = xb_lo[xx], a1 = xb_hi[xx];
-        if (a0 > a1) continue;
-        float acc = 0.0f;
+  // A wave owns every 4th pixel row, a lane the channels lane, lane+64, lane+128, lane+192 of a
+  // 256-channel slab: the range look-ups, the tap weights and the loop control are paid once per four
+  // channels, the LDS reads stay conflict free and every atomic instruction covers 256 contiguous bytes.
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int yy = wave; yy < py; yy += 4) {
+    const int b0 = yb_lo[yy], b1 = yb_hi[yy];
+    if (b0 > b1) continue;
+    for (int xx = 0; xx < px; ++xx) {
+      const int a0 = xb_lo[xx], a1 = xb_hi[xx];
+      if (a0 > a1) continue;
+      float *pix = dst + ((size_t)(y0 + yy) * W + (x0 + xx)) * C;
+      for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + lane;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int by = b0; by <= b1; ++by) {
           const float a = wy[by * RA_MAX_SPAN + yy];
-          for (int bx = a0; bx <= a1; ++bx)
-            acc += (a * wx[bx * RA_MAX_SPAN + xx]) * gt[(by * pw + bx) * C + c];
+          for (int bx = a0; bx <= a1; ++bx) {
+            const float w = a * wx[bx * RA_MAX_SPAN + xx];
+            const float *gp = gt + (by * pw + bx) * C + c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c + 64 * k < C) acc[k] += w * gp[64 * k];
+          }
         }
-        unsafeAtomicAdd(dst + ((size_t)(y0 + yy) * W + (x0 + xx)) * C + c, acc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (c + 64 * k < C) unsafeAtomicAdd(pix + c + 64 * k, acc[k]);
       }
     }
   }
@@ -356,13 +369,48 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(Pyramid pyr, const flo
       const int ya = yp_lo[by], yb = yp_hi[by], xa = xp_lo[bx], xb = xp_hi[bx];
       for (int cg = lane; cg < C / 4; cg += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int yy = ya; yy <= yb; ++yy) {
-          const float a = wy[by * RA_MAX_SPAN + yy];
-          const float4 *row = (const float4 *)(src + ((size_t)(y0 + yy) * W + x0) * C) + cg;
-          for (int xx = xa; xx <= xb; ++xx) {
-            const float w = a * wx[bx * RA_MAX_SPAN + xx];
-            const float4 f = row[(size_t)xx * (C / 4)];
-            acc.x += w * f.x, acc.y += w * f.y, acc.z += w * f.z, acc.w += w * f.w;
+        if (xb - xa < 8) {
+          // the taps of two pixel rows (up to 16 loads of 16 bytes per lane) are requested before the
+          // first is used: one tap per dependent load left the kernel waiting on L2 latency; the sum
+          // keeps the row-major tap order
+          for (int yy = ya; yy <= yb; yy += 2) {
+            const bool two = yy + 1 <= yb;
+            const float a0 = wy[by * RA_MAX_SPAN + yy], a1 = two ? wy[by * RA_MAX_SPAN + yy + 1] : 0.f;
+            const float4 *row0 = (const float4 *)(src + ((size_t)(y0 + yy) * W + x0) * C) + cg;
+            const float4 *row1 = two ? row0 + (size_t)W * (C / 4) : row0;
+            float4 f0[8], f1[8];
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int xs = xa + u <= xb ? xa + u : xb;
+              f0[u] = row0[(size_t)xs * (C / 4)];
+              f1[u] = row1[(size_t)xs * (C / 4)];
+              wv[u] = wx[bx * RA_MAX_SPAN + xs];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (xa + u <= xb) {
+                const float w = a0 * wv[u];
+                acc.x += w * f0[u].x, acc.y += w * f0[u].y, acc.z += w * f0[u].z, acc.w += w * f0[u].w;
+              }
+            if (two) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (xa + u <= xb) {
+                  const float w = a1 * wv[u];
+                  acc.x += w * f1[u].x, acc.y += w * f1[u].y, acc.z += w * f1[u].z, acc.w += w * f1[u].w;
+                }
+            }
+          }
+        } else {
+          for (int yy = ya; yy <= yb; ++yy) {
+            const float a = wy[by * RA_MAX_SPAN + yy];
+            const float4 *row = (const float4 *)(src + ((size_t)(y0 + yy) * W + x0) * C) + cg;
+            for (int xx = xa; xx <= xb; ++xx) {
+              const float w = a * wx[bx * RA_MAX_SPAN + xx];
+              const float4 f = row[(size_t)xx * (C / 4)];
+              acc.x += w * f.x, acc.y += w * f.y, acc.z += w * f.z, acc.w += w * f.w;
+            }
           }
         }
         float *o = ot + b * (C + 1) + 4 * cg;

@@ -94,7 +94,7 @@ def _stacked(rng, counts, lo, hi):
 def test_ball_query_and_group(orc, dev, radius, nsample):
     from detmatch_amd import pointnet2_stack as pn
     rng = np.random.default_rng(int(radius * 10))
-    xyz_cnt, new_cnt = [3000, 0, 1700], [256, 0, 300]
+    xyz_cnt, new_cnt = [3000, 0, 1700], [253, 0, 300]      # sample boundary inside a block of queries
     xyz = _stacked(rng, xyz_cnt, 0, 12)
     new_xyz = _stacked(rng, new_cnt, -1, 13)
     feats = rng.standard_normal((xyz.shape[0], 19)).astype(np.float32)
@@ -115,6 +115,25 @@ def test_ball_query_and_group(orc, dev, radius, nsample):
     g.backward(t(dy))
     want = orc.group_points_grad(dy, oidx, new_cnt, xyz_cnt, xyz.shape[0])
     np.testing.assert_allclose(tf.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('counts', [([5000, 2300], [9001, 8999]), ([1, 1024, 1025], [3, 5, 2]),
+                                    ([700, 64], [1, 2047])])
+def test_ball_query_tile_and_wave_paths(orc, dev, counts):
+    """Both launch shapes (4 queries per wave above 16 k queries), tiles that end exactly on / one past
+    the 1024-point staging tile, one-point samples."""
+    from detmatch_amd import pointnet2_stack as pn
+    xyz_cnt, new_cnt = counts
+    rng = np.random.default_rng(sum(xyz_cnt))
+    xyz = _stacked(rng, xyz_cnt, 0, 6)
+    new_xyz = _stacked(rng, new_cnt, -0.5, 6.5)
+    t = lambda a, dt=None: torch.from_numpy(np.asarray(a, dtype=dt)).to(dev)
+    for radius, nsample in ((0.3, 16), (0.9, 32)):
+        idx, empty = pn.ball_query(radius, nsample, t(xyz), t(xyz_cnt, np.int32), t(new_xyz),
+                                   t(new_cnt, np.int32))
+        oidx, oempty = orc.ball_query(radius, nsample, xyz, xyz_cnt, new_xyz, new_cnt)
+        assert np.array_equal(idx.cpu().numpy(), oidx)
+        assert np.array_equal(empty.cpu().numpy(), oempty)
 
 
 def test_reference_ball_query_kat(dev):
