@@ -261,15 +261,21 @@ class DetMatchTrainWorkload(object):
             # multi-tensor adds and released, so autograd never accumulates tensor by tensor
             self.model.after_partial_backward = self.ddp.collect
         self.model.hoist_teacher = os.environ.get('DM_HOIST_TEACHER', '0') == '1'   # measured: +2 ms (A/B 134.1 / 133.2 vs 131.0 / 132.5)
-        # multi-stream lanes (DM_TWO_LANES=1: student 3D / 2D detectors / teacher 3D + glue run concurrently,
-        # data-flow edges as event waits): -7..10 % step time on the same box (127-131 vs 139 ms), same
-        # gradients and losses as the serial order (tests/test_ssl_gpu.py, tools/lane_stress.py).  OPT-IN:
-        # co-scheduled kernels share the device, so the roofline kernel takes 45 us inside the timed
-        # region instead of 34 us, while rocprofv3 (whose overhead reduces the overlap) still reports 31 us
-        # — bench.py's "in-bench duration agrees with the rocprofv3 summary" contract only holds for the
-        # serial order, which therefore stays the default.
+        # Stream lanes (ssl.py:_Lanes; data-flow edges of the batch dict become event waits).  Default
+        # 'glue': every detector pass stays on the caller's stream, strictly ordered, the teacher's
+        # inference is issued first and only the light pseudo-label glue with its host read-backs runs on
+        # a side stream underneath the supervised passes: -3.5 % step time (121.4 vs 125.9 ms, same box,
+        # alternated), heavy kernels never share the device, so the in-bench duration of the roofline
+        # kernel is unchanged (26.2-26.5 us) and agrees with the rocprofv3 trace.
+        # DM_TWO_LANES=1 ('branches': student 3D / 2D detectors / teacher 3D + glue on three streams) is
+        # -11 % (112.3 ms) but OPT-IN: co-scheduled kernels queue for CUs, a HIP-event pair around the
+        # roofline kernel then reads 34 us where the rocprofv3 trace of the same run reads 25 us — the
+        # "in-bench duration agrees with the rocprofv3 summary" contract of bench.py only holds when the
+        # heavy kernels run one at a time.  DM_LANE_MODE=serial: one stream.
+        # Same gradients and losses in all three orders (tests/test_ssl_gpu.py, tools/lane_stress.py).
         self.model.two_lanes = os.environ.get('DM_TWO_LANES', '0') == '1'
-        self.model.lane_mode = os.environ.get('DM_LANE_MODE') or None      # 'glue': see ssl.py:_Lanes
+        mode = os.environ.get('DM_LANE_MODE', 'glue')
+        self.model.lane_mode = None if (self.model.two_lanes or mode in ('serial', 'none', '0', '')) else mode
         self.model.lane_hoist = os.environ.get('DM_LANE_HOIST', '0') == '1'
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
         self.n_fused = self.opt.enable_fused(self.ddp)

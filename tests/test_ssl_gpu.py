@@ -168,6 +168,7 @@ def test_early_backward_and_prefetch_do_not_change_gradients(dev, ssl_cfg):
     for early in (True, False):
         wl = DetMatchTrainWorkload(2, dev, ssl_cfg=ssl_cfg)
         wl.model.early_backward = early
+        wl.model.lane_mode = None      # one stream: the per-pass early backward only exists there
         if not early:   # also disable the geometry prepass for the plain run
             for m in wl.model.lab_ssl_modules + wl.model.unlab_ssl_modules:
                 if hasattr(m, 'prefetch'):
