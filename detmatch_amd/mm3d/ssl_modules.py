@@ -145,8 +145,7 @@ class Opd_HardPseudoLabel_3D(object):
             self.cls_includes_bg_pred,
             lambda s: LiDARInstance3DBoxes(s.new_zeros((0, self.box_dim))))
         batch = detector.train_to_openpcdet(cur['points'], cur['img_metas'], boxes, labels)
-        for module in detector.model.module_list:
-            batch = module(batch)
+        batch = detector.model.run_modules(batch)
         loss, _, _ = detector.model.get_training_loss()
         batch_dict = _accumulate(ssl_obj, batch_dict, add_prefix(dict(loss=loss.mean()), self.name),
                                  prefer_sup=False)

@@ -116,9 +116,22 @@ class PVRCNN(nn.Module):
                 mods = mods[:i] + [bev, pfe] + mods[i + 2:]
         return mods
 
-    def forward(self, batch_dict):
+    def run_modules(self, batch_dict):
+        """The module chain.  `after_backbone_3d` (a one-shot callable set on the instance by the stream
+        scheduler of SSL.forward_train, mode 'pairs') is called right after the sparse backbone has been
+        issued: from there on the pass consists of many small kernels, underneath which the paired 2D
+        pass is issued on its own stream."""
+        bb = getattr(self, 'backbone_3d', None)
         for cur_module in self._order(batch_dict):
             batch_dict = cur_module(batch_dict)
+            if cur_module is bb:
+                hook = self.__dict__.pop('after_backbone_3d', None)
+                if hook is not None:
+                    hook(batch_dict)
+        return batch_dict
+
+    def forward(self, batch_dict):
+        batch_dict = self.run_modules(batch_dict)
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
             return {'loss': loss}, tb_dict, disp_dict

@@ -267,6 +267,11 @@ class DetMatchTrainWorkload(object):
         # a side stream underneath the supervised passes: -3.5 % step time (121.4 vs 125.9 ms, same box,
         # alternated), heavy kernels never share the device, so the in-bench duration of the roofline
         # kernel is unchanged (26.2-26.5 us) and agrees with the rocprofv3 trace.
+        # DM_LANE_MODE=pairs: 'glue' plus every 2D pass issued from inside its 3D partner right after the
+        # sparse backbone (ssl.py:_Lanes.run_pair), so that the 3D pass's long tail of small kernels runs
+        # underneath the 2D convolutions while the sparse convolutions keep the device to themselves
+        # (roofline kernel 26.6-27.3 us): 117.1-122.7 ms over five runs against 116.1-120.8 ms — inside the
+        # box-to-box noise, not the default.
         # DM_TWO_LANES=1 ('branches': student 3D / 2D detectors / teacher 3D + glue on three streams) is
         # -11 % (112.3 ms) but OPT-IN: co-scheduled kernels queue for CUs, a HIP-event pair around the
         # roofline kernel then reads 34 us where the rocprofv3 trace of the same run reads 25 us — the
