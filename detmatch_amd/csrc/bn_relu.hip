@@ -9,6 +9,11 @@
 // and backward reduce (2 reads) + input gradient (2 reads, 1 write) with the ReLU mask recomputed
 // from x — 3 + 5 passes, HBM bound.
 //
+// (Measured and dropped: folding the partials in the LAST workgroup to arrive at a counter — the
+// threadFenceReduction pattern, one launch instead of two per reduction.  The device-wide fence every
+// workgroup needs before it counts itself in writes back / invalidates the XCD's L2: the BN kernels of a
+// training step took twice as long, 118 -> 153 ms per iteration.)
+//
 // Statistics: per-block shifted sums (shift = the block's first row, so no catastrophic cancellation),
 // turned into (n, mean, M2) and combined over blocks in a fixed order (Chan et al.) -> deterministic.
 #include <hip/hip_runtime.h>

@@ -1,0 +1,65 @@
+// Anchor-head box decoding in one launch.
+//
+// AnchorHeadTemplate.generate_predicted_boxes (pcdet/models/dense_heads/anchor_head_template.py:225-272)
+// = ResidualCoder.decode_torch (pcdet/utils/box_coder_utils.py:43-76) + the direction-classifier
+// correction (limit_period, common_utils.py:20-23): 34 element-wise torch launches over the
+// (B, 211 200, 7) anchor grid per pass.  Here one thread decodes one anchor with the SAME fp32
+// operation sequence (separate multiply and add — the file is compiled with -ffp-contract=off; division
+// by the Python scalar `period` is torch's multiplication by its float reciprocal), so the result is the
+// tensor chain's bit for bit.  No gradient: PV-RCNN's proposal layer detaches these boxes
+// (roi_head_template.py:96-99).
+#include <hip/hip_runtime.h>
+
+#include "../../include/detmatch_hip.h"
+#include "dm_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void anchor_decode_kernel(
+    const float *__restrict__ enc, const float *__restrict__ anchors, const float *__restrict__ dir_logits,
+    long long total, int n_anchors, int n_bins, float dir_offset, float dir_limit_offset, float period,
+    float inv_period, float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float *a = anchors + (size_t)(i % n_anchors) * 7;
+  const float *t = enc + (size_t)i * 7;
+  const float xa = a[0], ya = a[1], za = a[2], dxa = a[3], dya = a[4], dza = a[5], ra = a[6];
+  const float diagonal = sqrtf(dxa * dxa + dya * dya);
+  float *o = out + (size_t)i * 7;
+  o[0] = t[0] * diagonal + xa;
+  o[1] = t[1] * diagonal + ya;
+  o[2] = t[2] * dza + za;
+  o[3] = expf(t[3]) * dxa;
+  o[4] = expf(t[4]) * dya;
+  o[5] = expf(t[5]) * dza;
+  float r = t[6] + ra;
+  if (dir_logits != nullptr) {
+    const float *d = dir_logits + (size_t)i * n_bins;
+    int label = 0;
+    float best = d[0];
+    for (int k = 1; k < n_bins; ++k)
+      if (d[k] > best) best = d[k], label = k;       // first maximum, as torch.max
+    const float val = r - dir_offset;
+    const float dir_rot = val - floorf(val * inv_period + dir_limit_offset) * period;
+    r = dir_rot + dir_offset + period * (float)label;
+  }
+  o[6] = r;
+}
+
+}  // namespace
+
+extern "C" int dm_anchor_decode(const float *box_encodings, const float *anchors, const float *dir_logits,
+                                long long n_total, int n_anchors, int n_dir_bins, float dir_offset,
+                                float dir_limit_offset, float period, float *boxes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_total < 0 || n_anchors <= 0 || (dir_logits && n_dir_bins < 1) || period == 0.0f)
+    return DM_ERR_INVALID_ARG;
+  if (n_total == 0) return DM_OK;
+  if (!box_encodings || !anchors || !boxes) return DM_ERR_INVALID_ARG;
+  const float inv_period = 1.0f / period;   // torch: x / scalar == x * (1.0f / (float)scalar)
+  anchor_decode_kernel<<<dm_ceil_div(n_total, 256), 256, 0, st>>>(
+      box_encodings, anchors, dir_logits, n_total, n_anchors, n_dir_bins, dir_offset, dir_limit_offset,
+      period, inv_period, boxes);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}

@@ -386,8 +386,11 @@ class AnchorHeadSingle(nn.Module):
         """anchor_head_template.py:225-272"""
         anchors = self._cat_anchors()
         num_anchors = anchors.view(-1, anchors.shape[-1]).shape[0]
-        batch_anchors = anchors.view(1, -1, anchors.shape[-1]).repeat(batch_size, 1, 1)
         batch_cls_preds = cls_preds.view(batch_size, num_anchors, -1).float()
+        if fused_on() and box_preds.is_cuda and anchors.shape[-1] == 7 and self.box_coder.code_size == 7 \
+                and box_preds.dtype == torch.float32 and getattr(self, 'boxes_detached_downstream', False):
+            return batch_cls_preds, self._decode_device(batch_size, num_anchors, anchors, box_preds, dir_cls_preds)
+        batch_anchors = anchors.view(1, -1, anchors.shape[-1]).repeat(batch_size, 1, 1)
         batch_box_preds = self.box_coder.decode_torch(box_preds.view(batch_size, num_anchors, -1),
                                                       batch_anchors)
         if dir_cls_preds is not None:
@@ -400,6 +403,26 @@ class AnchorHeadSingle(nn.Module):
             batch_box_preds = torch.cat([batch_box_preds[..., :6], rot.unsqueeze(-1),
                                          batch_box_preds[..., 7:]], dim=-1)
         return batch_cls_preds, batch_box_preds
+
+    @torch.no_grad()
+    def _decode_device(self, batch_size, num_anchors, anchors, box_preds, dir_cls_preds):
+        """The same in one launch (csrc/box_decode.hip, bit-identical); no autograd graph — only taken
+        when the detector declares that nothing differentiates through the decoded boxes."""
+        from .. import _lib
+        L = _lib.lib()
+        enc = box_preds.detach().reshape(batch_size * num_anchors, 7).contiguous()
+        flat = anchors.reshape(-1, 7).contiguous().float()
+        dirs, bins = None, 0
+        if dir_cls_preds is not None:
+            dirs = dir_cls_preds.detach().reshape(batch_size * num_anchors, -1).contiguous().float()
+            bins = dirs.shape[1]
+        out = torch.empty((batch_size, num_anchors, 7), dtype=torch.float32, device=box_preds.device)
+        period = 2 * np.pi / self.model_cfg.NUM_DIR_BINS if dirs is not None else 1.0
+        _lib.check(L.dm_anchor_decode(_lib.ptr(enc), _lib.ptr(flat), _lib.ptr(dirs), enc.shape[0], num_anchors,
+                                      bins, float(self.model_cfg.DIR_OFFSET) if dirs is not None else 0.0,
+                                      float(self.model_cfg.DIR_LIMIT_OFFSET) if dirs is not None else 0.0,
+                                      float(period), _lib.ptr(out), _lib.stream()), 'dm_anchor_decode')
+        return out
 
     # ---- losses -------------------------------------------------------------
     def get_cls_layer_loss(self):

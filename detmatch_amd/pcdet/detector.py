@@ -100,6 +100,9 @@ class PVRCNN(nn.Module):
             model_cfg=cfg.ROI_HEAD, input_channels=info['num_point_features'],
             num_class=self.num_class if not cfg.ROI_HEAD.CLASS_AGNOSTIC else 1)
         mods.append(self.roi_head)
+        # the RoI head's proposal layer detaches the anchor head's boxes (roi_head_template.py:96-99) and
+        # the final predictions are the RoI head's: nothing differentiates through the decoded anchors
+        self.dense_head.boxes_detached_downstream = True
         return mods
 
     def _order(self, batch_dict):

@@ -181,7 +181,54 @@ class VoxelSetAbstraction(nn.Module):
             ev.record(side)
         batch_dict['keypoints_async'] = (kp, ev)
 
+    # ---- feature sources ---------------------------------------------------------------------
+    def _branch_fns(self, batch_dict, keypoints, new_xyz, new_xyz_batch_cnt):
+        """One callable per feature source, in the column order of the fused feature (bev, raw points,
+        x_conv1..4): each reads only the key points and its own source and returns (B, K, C_src)."""
+        batch_size, num_keypoints, _ = keypoints.shape
+        dev = keypoints.device
+        fns = []
+        if 'bev' in self.model_cfg.FEATURES_SOURCE:
+            spatial = batch_dict['spatial_features']
+            stride = batch_dict['spatial_features_stride']
+            fns.append(lambda: self.interpolate_from_bev_features(keypoints, spatial, batch_size,
+                                                                   bev_stride=stride))
+        if 'raw_points' in self.model_cfg.FEATURES_SOURCE:
+            raw_points = batch_dict['points']
+            counts = [int(c) for c in batch_dict['points_batch_cnt_host']]
+
+            def raw():
+                xyz_batch_cnt = upload(counts, dev, torch.int32)
+                point_features = raw_points[:, 4:].contiguous() if raw_points.shape[1] > 4 else None
+                _, pooled = self.SA_rawpoints(xyz=raw_points[:, 1:4].contiguous(),
+                                              xyz_batch_cnt=xyz_batch_cnt, new_xyz=new_xyz,
+                                              new_xyz_batch_cnt=new_xyz_batch_cnt,
+                                              features=point_features)
+                return pooled.view(batch_size, num_keypoints, -1)
+            fns.append(raw)
+        for k, src_name in enumerate(self.SA_layer_names):
+            sp = batch_dict['multi_scale_3d_features'][src_name]
+            feats = sp.features
+
+            def sa(k=k, src_name=src_name, sp=sp, feats=feats):
+                cur_coords = sp.indices
+                xyz = get_voxel_centers(cur_coords[:, 1:4],
+                                        downsample_times=self.downsample_times_map[src_name],
+                                        voxel_size=self.voxel_size,
+                                        point_cloud_range=self.point_cloud_range)
+                xyz_batch_cnt = batch_row_counts(cur_coords[:, 0], batch_size)
+                _, pooled = self.SA_layers[k](xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt,
+                                              new_xyz=new_xyz, new_xyz_batch_cnt=new_xyz_batch_cnt,
+                                              features=feats.contiguous())
+                return pooled.view(batch_size, num_keypoints, -1)
+            fns.append(sa)
+        return fns
+
     def forward(self, batch_dict):
+        # (Measured and dropped: the six sources on three side streams underneath the BEV backbone, with
+        # backward gates in front of the sparse backbone: 117.8-118.6 ms against 111.5-117.0 ms on one
+        # stream, 3 alternations of 40 iterations — the event hand-offs and the convolutions sharing the
+        # device cost more than the dispatch gaps they hide.)
         if 'keypoints_async' in batch_dict:
             keypoints, ev = batch_dict.pop('keypoints_async')
             main = torch.cuda.current_stream(keypoints.device)
@@ -189,37 +236,13 @@ class VoxelSetAbstraction(nn.Module):
             keypoints.record_stream(main)
         else:
             keypoints = self.get_sampled_points(batch_dict)
+        new_xyz = keypoints.view(-1, 3).contiguous()
+        new_xyz_batch_cnt = torch.full((keypoints.shape[0],), keypoints.shape[1], dtype=torch.int32,
+                                       device=keypoints.device)
+        point_features_list = [fn() for fn in self._branch_fns(batch_dict, keypoints, new_xyz,
+                                                               new_xyz_batch_cnt)]
         batch_size, num_keypoints, _ = keypoints.shape
         dev = keypoints.device
-        point_features_list = []
-        if 'bev' in self.model_cfg.FEATURES_SOURCE:
-            point_features_list.append(self.interpolate_from_bev_features(
-                keypoints, batch_dict['spatial_features'], batch_size,
-                bev_stride=batch_dict['spatial_features_stride']))
-        new_xyz = keypoints.view(-1, 3).contiguous()
-        new_xyz_batch_cnt = torch.full((batch_size,), num_keypoints, dtype=torch.int32, device=dev)
-        if 'raw_points' in self.model_cfg.FEATURES_SOURCE:
-            raw_points = batch_dict['points']
-            xyz_batch_cnt = upload([int(c) for c in batch_dict['points_batch_cnt_host']], dev,
-                                   torch.int32)
-            point_features = raw_points[:, 4:].contiguous() if raw_points.shape[1] > 4 else None
-            _, pooled = self.SA_rawpoints(xyz=raw_points[:, 1:4].contiguous(),
-                                          xyz_batch_cnt=xyz_batch_cnt, new_xyz=new_xyz,
-                                          new_xyz_batch_cnt=new_xyz_batch_cnt,
-                                          features=point_features)
-            point_features_list.append(pooled.view(batch_size, num_keypoints, -1))
-        for k, src_name in enumerate(self.SA_layer_names):
-            sp = batch_dict['multi_scale_3d_features'][src_name]
-            cur_coords = sp.indices
-            xyz = get_voxel_centers(cur_coords[:, 1:4],
-                                    downsample_times=self.downsample_times_map[src_name],
-                                    voxel_size=self.voxel_size,
-                                    point_cloud_range=self.point_cloud_range)
-            xyz_batch_cnt = batch_row_counts(cur_coords[:, 0], batch_size)
-            _, pooled = self.SA_layers[k](xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt,
-                                          new_xyz=new_xyz, new_xyz_batch_cnt=new_xyz_batch_cnt,
-                                          features=sp.features.contiguous())
-            point_features_list.append(pooled.view(batch_size, num_keypoints, -1))
         point_features = torch.cat(point_features_list, dim=2)
         batch_idx = torch.arange(batch_size, device=dev).view(-1, 1).repeat(1, num_keypoints).view(-1)
         point_coords = torch.cat((batch_idx.view(-1, 1).float(), keypoints.view(-1, 3)), dim=1)

@@ -59,6 +59,35 @@ def class_agnostic_nms_fixed(box_scores, box_preds, nms_config, score_thresh=Non
     return torch.where(valid, sel, torch.zeros_like(sel)), valid
 
 
+def class_agnostic_nms_fixed_batch(box_scores, box_preds, nms_config):
+    """class_agnostic_nms_fixed for every sample of a batch with ONE top-k, sort and gather over the
+    (B, N) score matrix (the per-sample loop of roi_head_template.py:60-90 repeats the same ~50
+    launches per sample); the NMS itself stays one call per sample.  -> selected (B, POST) int64
+    padded with 0, valid (B, POST) bool."""
+    post = int(nms_config.NMS_POST_MAXSIZE)
+    bsz, n = box_scores.shape
+    dev = box_scores.device
+    if n == 0 or bsz == 0:
+        return (torch.zeros((bsz, post), dtype=torch.int64, device=dev),
+                torch.zeros((bsz, post), dtype=torch.bool, device=dev))
+    k = min(int(nms_config.NMS_PRE_MAXSIZE), n)
+    top_scores, indices = torch.topk(box_scores, k=k, dim=1)
+    order = torch.sort(top_scores, dim=1, descending=True, stable=True)[1]
+    indices = torch.gather(indices, 1, order)                     # original index, NMS order
+    boxes = torch.gather(box_preds[:, :, 0:7], 1, indices[:, :, None].expand(-1, -1, 7)).contiguous().float()
+    L = _lib.lib()
+    keep = torch.zeros((bsz, max(k, post)), dtype=torch.int64, device=dev)
+    num = torch.zeros((bsz,), dtype=torch.int32, device=dev)
+    ws = _lib.workspace(L.dm_nms_workspace_bytes(k), dev, 'nms')
+    fn = L.dm_nms if nms_config.NMS_TYPE == 'nms_gpu' else L.dm_nms_normal
+    for b in range(bsz):
+        _lib.check(fn(_lib.ptr(boxes[b]), k, float(nms_config.NMS_THRESH), post, _lib.ptr(keep[b]),
+                      _lib.ptr(num[b:b + 1]), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms')
+    valid = torch.arange(post, device=dev)[None, :] < num.long()[:, None]
+    sel = torch.gather(indices, 1, keep[:, :post].clamp(0, k - 1))
+    return torch.where(valid, sel, torch.zeros_like(sel)), valid
+
+
 class ProposalTargetLayer(nn.Module):
     """proposal_target_layer.py:8-259"""
 
@@ -306,22 +335,14 @@ class PVRCNNHead(nn.Module):
         batch_box_preds = batch_dict['batch_box_preds']
         batch_cls_preds = batch_dict['batch_cls_preds']
         assert batch_cls_preds.dim() == 3 and not nms_config.MULTI_CLASSES_NMS
-        rois, roi_scores, roi_scores_full, roi_labels = [], [], [], []
-        for index in range(batch_size):
-            box_preds = batch_box_preds[index]
-            cls_preds = batch_cls_preds[index]
-            cur_roi_scores, cur_roi_labels = torch.max(cls_preds, dim=1)
-            selected, valid = class_agnostic_nms_fixed(cur_roi_scores.detach(), box_preds.detach(),
-                                                       nms_config)
-            vf = valid.to(box_preds.dtype)
-            rois.append(box_preds[selected] * vf[:, None])
-            roi_scores.append(cur_roi_scores[selected] * vf)
-            roi_labels.append(cur_roi_labels[selected] * valid.long())
-            roi_scores_full.append(cls_preds[selected] * vf[:, None])
-        batch_dict['rois'] = torch.stack(rois).detach()
-        batch_dict['roi_scores'] = torch.stack(roi_scores).detach()
-        batch_dict['roi_scores_full'] = torch.stack(roi_scores_full)   # not detached (:98)
-        batch_dict['roi_labels'] = (torch.stack(roi_labels) + 1).detach()
+        scores, labels = torch.max(batch_cls_preds, dim=2)
+        sel, valid = class_agnostic_nms_fixed_batch(scores.detach(), batch_box_preds.detach(), nms_config)
+        vf = valid.to(batch_box_preds.dtype)
+        pick = lambda t: torch.gather(t, 1, sel[:, :, None].expand(-1, -1, t.shape[2]))   # noqa: E731
+        batch_dict['rois'] = (pick(batch_box_preds) * vf[:, :, None]).detach()
+        batch_dict['roi_scores'] = (torch.gather(scores, 1, sel) * vf).detach()
+        batch_dict['roi_scores_full'] = pick(batch_cls_preds) * vf[:, :, None]   # not detached (:98)
+        batch_dict['roi_labels'] = (torch.gather(labels, 1, sel) * valid.long() + 1).detach()
         batch_dict['has_class_labels'] = batch_cls_preds.shape[-1] > 1
         batch_dict.pop('batch_index', None)
         return batch_dict

@@ -267,6 +267,15 @@ int dm_bn_rows_backward(const float *grad_out, const float *x, long long n, int 
                         float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
                         size_t workspace_bytes, dm_stream_t stream);
 
+/* Anchor-head box decoding: AnchorHeadTemplate.generate_predicted_boxes
+ * (pcdet/models/dense_heads/anchor_head_template.py:225-272) = ResidualCoder.decode_torch
+ * (pcdet/utils/box_coder_utils.py:43-76) + direction-bin correction (common_utils.limit_period).
+ * box_encodings (n_total, 7), anchors (n_anchors, 7) reused every n_anchors rows, dir_logits
+ * (n_total, n_dir_bins) or NULL -> boxes (n_total, 7).  Bit-identical to the fp32 tensor chain. */
+int dm_anchor_decode(const float *box_encodings, const float *anchors, const float *dir_logits,
+                     long long n_total, int n_anchors, int n_dir_bins, float dir_offset,
+                     float dir_limit_offset, float period, float *boxes, dm_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* G. 2D branch: RoIAlign over an FPN pyramid                                 */
 /* ------------------------------------------------------------------------ */

@@ -443,3 +443,34 @@ def test_exact_bev_overlap_on_near_touching_and_near_threshold_pairs(dev):
     for thr in (0.7, 0.5, 0.25):
         close = np.abs(iou_w - thr) > 1e-6
         assert ((iou_w > thr) == (iou_g > thr))[close].all()
+
+
+def test_anchor_decode_kernel_is_the_tensor_chain(dev):
+    """dm_anchor_decode == AnchorHeadTemplate.generate_predicted_boxes' tensor chain (ResidualCoder
+    decode + direction-bin correction), bit for bit, on the KITTI anchor grid."""
+    from detmatch_amd import configs, fused
+    from detmatch_amd.pcdet.config import ConfigDict
+    from detmatch_amd.pcdet.dense_heads import AnchorHeadSingle
+    cfg = ConfigDict(configs.pvrcnn_kitti_model()['pcdet_model'])
+    head = AnchorHeadSingle(cfg.DENSE_HEAD, input_channels=16, num_class=3, class_names=configs.CLASS_NAMES,
+                            grid_size=np.array([1408, 1600, 40]),
+                            point_cloud_range=np.array(configs.POINT_CLOUD_RANGE, dtype=np.float32)).to(dev).eval()
+    head.boxes_detached_downstream = True      # what PVRCNN.build_networks declares
+    anchors = head._cat_anchors()
+    n = anchors.view(-1, 7).shape[0]
+    g = torch.Generator().manual_seed(5)
+    box = (torch.randn(2, n * 7, generator=g) * 0.7).to(dev).view(2, -1, 7 * 6)
+    cls = torch.randn(2, n * 3, generator=g).to(dev).view(2, -1, 3 * 6)
+    dirs = torch.randn(2, n * 2, generator=g).to(dev).view(2, -1, 2 * 6)
+    dirs.view(-1, 2)[::7] = 0.25                       # ties between the two direction bins
+    assert head.boxes_detached_downstream
+    with torch.no_grad():
+        _, a = head.generate_predicted_boxes(2, cls, box, dirs)
+        prev = fused.ENABLED
+        fused.ENABLED = False
+        try:
+            _, b = head.generate_predicted_boxes(2, cls, box, dirs)
+        finally:
+            fused.ENABLED = prev
+    assert a.shape == b.shape == (2, n, 7)
+    assert torch.equal(a, b)
