@@ -46,6 +46,7 @@ struct DConvGeom {
   int dense_out;   // lattice == every output pixel in order: row m lives at y + m*Cout
   int M;           // B*LH*LW
   int Ktot;        // T*Cin
+  const float *residual;   // optional: added to the output rows (same layout as y) before the ReLU
 };
 
 struct DConvTaps {   // 32-bit entries: a wave-uniform tap index then reads them with s_load_dword
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[a][b][r] + bv;
-        if (g.relu == 1 && partial == nullptr) v = fmaxf(v, 0.0f);
+        if (g.relu == 1 && partial == nullptr && g.residual == nullptr) v = fmaxf(v, 0.0f);
         cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + b * 32 + lr] = v;
       }
   }
@@ -359,8 +360,21 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
       const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, bb = tmp / g.LH;
       row = ((size_t)bb * g.Hout + g.oy0 + i * g.oys) * g.Wout + g.ox0 + j * g.oxs;
     }
-    const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
+    float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
     float *dst = obase + row * g.Cout + ncol;
+    if (g.residual != nullptr && partial == nullptr) {   // shortcut branch of a residual block, then the ReLU
+      const float *rp = g.residual + row * g.Cout + ncol;
+      if (vec_ok && ncol + 3 < g.Cout) {
+        const float4 r = *(const float4 *)rp;
+        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+      } else {
+        v.x += rp[0];
+        if (ncol + 1 < g.Cout) v.y += rp[1];
+        if (ncol + 2 < g.Cout) v.z += rp[2];
+        if (ncol + 3 < g.Cout) v.w += rp[3];
+      }
+      if (g.relu == 1) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    }
     if (vec_ok && ncol + 3 < g.Cout) {
       *(float4 *)dst = v;
     } else {
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[a][b][r] + bv;
-        if (g.relu == 1 && partial == nullptr) v = fmaxf(v, 0.0f);
+        if (g.relu == 1 && partial == nullptr && g.residual == nullptr) v = fmaxf(v, 0.0f);
         cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + b * 32 + lr] = v;
       }
   }
@@ -563,8 +577,21 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
       const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, bb = tmp / g.LH;
       row = ((size_t)bb * g.Hout + g.oy0 + i * g.oys) * g.Wout + g.ox0 + j * g.oxs;
     }
-    const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
+    float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
     float *dst = obase + row * g.Cout + ncol;
+    if (g.residual != nullptr && partial == nullptr) {   // shortcut branch of a residual block, then the ReLU
+      const float *rp = g.residual + row * g.Cout + ncol;
+      if (vec_ok && ncol + 3 < g.Cout) {
+        const float4 r = *(const float4 *)rp;
+        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+      } else {
+        v.x += rp[0];
+        if (ncol + 1 < g.Cout) v.y += rp[1];
+        if (ncol + 2 < g.Cout) v.z += rp[2];
+        if (ncol + 3 < g.Cout) v.w += rp[3];
+      }
+      if (g.relu == 1) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    }
     if (vec_ok && ncol + 3 < g.Cout) {
       *(float4 *)dst = v;
     } else {
@@ -984,7 +1011,6 @@ __global__ __launch_bounds__(256) void dconv_splitk_reduce_kernel(const float *_
     s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
   }
   if (bias) s.x += bias[n], s.y += bias[n + 1], s.z += bias[n + 2], s.w += bias[n + 3];
-  if (g.relu == 1) s.x = fmaxf(s.x, 0.f), s.y = fmaxf(s.y, 0.f), s.z = fmaxf(s.z, 0.f), s.w = fmaxf(s.w, 0.f);
   size_t row;
   if (g.dense_out) {
     row = (size_t)m;
@@ -992,6 +1018,11 @@ __global__ __launch_bounds__(256) void dconv_splitk_reduce_kernel(const float *_
     const int j = m % g.LW, tmp = m / g.LW, i = tmp % g.LH, bb = tmp / g.LH;
     row = ((size_t)bb * g.Hout + g.oy0 + i * g.oys) * g.Wout + g.ox0 + j * g.oxs;
   }
+  if (g.residual != nullptr) {
+    const float4 r = *(const float4 *)(g.residual + row * g.Cout + n);
+    s.x += r.x, s.y += r.y, s.z += r.z, s.w += r.w;
+  }
+  if (g.relu == 1) s.x = fmaxf(s.x, 0.f), s.y = fmaxf(s.y, 0.f), s.z = fmaxf(s.z, 0.f), s.w = fmaxf(s.w, 0.f);
   *(float4 *)(y + row * g.Cout + n) = s;
 }
 
@@ -1079,8 +1110,17 @@ extern "C" size_t dm_dconv_gemm_workspace_bytes(const int *geom_host) {
 extern "C" int dm_dconv_gemm(const float *x, const float *w_packed, const float *bias, float *y,
                              const int *geom_host, const short *taps_host, void *workspace,
                              size_t workspace_bytes, dm_stream_t stream) {
+  return dm_dconv_gemm_residual(x, w_packed, bias, nullptr, y, geom_host, taps_host, workspace,
+                                workspace_bytes, stream);
+}
+
+extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, const float *bias,
+                                      const float *residual, float *y, const int *geom_host,
+                                      const short *taps_host, void *workspace, size_t workspace_bytes,
+                                      dm_stream_t stream) {
   if (!x || !w_packed || !y || !geom_host || !taps_host) return DM_ERR_INVALID_ARG;
   DConvGeom g;
+  g.residual = residual;
   const int *q = geom_host;
   g.B = q[0], g.Hin = q[1], g.Win = q[2], g.Cin = q[3];
   g.Hout = q[4], g.Wout = q[5], g.Cout = q[6];

@@ -231,14 +231,16 @@ def _plan(kind, geom, taps):
     return hit
 
 
-def _gemm(x, wp, bias, y, geom, taps):
-    """geom: the 17 ints of dm_dconv_gemm; taps: [(dy, dx, slice)]."""
+def _gemm(x, wp, bias, y, geom, taps, residual=None):
+    """geom: the 17 ints of dm_dconv_gemm; taps: [(dy, dx, slice)]; residual: tensor in y's layout that
+    the epilogue adds before the ReLU."""
     g, t, nbytes = _plan('gemm', geom, taps)
     ws = _lib.workspace(nbytes, x.device, 'dconv_gemm') if nbytes else None
-    _lib.check(_lib.lib().dm_dconv_gemm(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
-                                        y.data_ptr(), g, t, None if ws is None else ws.data_ptr(),
-                                        ws.numel() if ws is not None else 0, _lib.raw_stream()),
-               'dm_dconv_gemm')
+    _lib.check(_lib.lib().dm_dconv_gemm_residual(
+        x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
+        None if residual is None else residual.data_ptr(), y.data_ptr(), g, t,
+        None if ws is None else ws.data_ptr(), ws.numel() if ws is not None else 0, _lib.raw_stream()),
+        'dm_dconv_gemm')
 
 
 def _wgrad(U, V, out, scale_u, geom, taps, cv_out, su, sv, st):
@@ -265,7 +267,7 @@ class _Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, weight * w_scale[:, None, None, None], bias, stride, padding) [+ ReLU]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_scale, stride, padding, relu):
+    def forward(ctx, x, weight, bias, w_scale, stride, padding, relu, residual=None):
         cout, cin, kh, kw = weight.shape
         (sh, sw), (ph, pw) = stride, padding
         x = _pad_channels(_cl(x.detach()), _pad4(cin))
@@ -275,8 +277,13 @@ class _Conv2dFn(torch.autograd.Function):
         wp = _pack(weight, 'f', T, cout, c4, cout, cin, cin * T, T, 1, scale_n=w_scale)
         y = _empty_cl(n, cout, ho, wo, x)
         taps = [(a - ph, b - pw, a * kw + b) for a in range(kh) for b in range(kw)]
+        if residual is not None:
+            residual = _cl(residual.detach())
+            if tuple(residual.shape) != tuple(y.shape):
+                raise _lib.DetMatchHipError('dense_conv: residual %s does not match the output %s'
+                                            % (tuple(residual.shape), tuple(y.shape)))
         _gemm(x, wp, None if bias is None else bias.detach(), y,
-              [n, h, w, c4, ho, wo, cout, ho, wo, 0, 0, 1, 1, sh, sw, T, int(relu)], taps)
+              [n, h, w, c4, ho, wo, cout, ho, wo, 0, 0, 1, 1, sh, sw, T, int(relu)], taps, residual)
         ctx.geom = (stride, padding, relu, (n, cin, h, w))
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, w_scale, y if relu else None)
@@ -326,7 +333,9 @@ class _Conv2dFn(torch.autograd.Function):
                    cin * T, T, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3))
-        return dx, dw, db, None, None, None, None
+        # the shortcut branch receives the (ReLU-masked) output gradient as it is
+        dres = dy if (len(ctx.needs_input_grad) > 7 and ctx.needs_input_grad[7]) else None
+        return dx, dw, db, None, None, None, None, dres
 
 
 class _ConvTranspose2dFn(torch.autograd.Function):
@@ -371,18 +380,21 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         return dx, dw, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, w_scale=None):
-    """F.conv2d (dilation 1, groups 1) [+ fused ReLU]; `w_scale` (Cout) multiplies the weight rows
-    (frozen-BatchNorm fold).  Returns a channels_last tensor."""
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, w_scale=None, residual=None):
+    """F.conv2d (dilation 1, groups 1) [+ residual] [+ fused ReLU]; `w_scale` (Cout) multiplies the
+    weight rows (frozen-BatchNorm fold); `residual` (the output's shape) is added in the GEMM's epilogue,
+    before the ReLU.  Returns a channels_last tensor."""
     stride, padding = _pair(stride), _pair(padding)
     if not x.is_cuda:
         if TORCH_REFERENCE_FOR_TESTS:
             w = weight if w_scale is None else weight * w_scale.view(-1, 1, 1, 1)
             y = F.conv2d(x, w, bias, stride, padding)
+            if residual is not None:
+                y = y + residual
             return F.relu(y) if relu else y
         _require(x)
-    _require(weight, bias, w_scale)
-    return _Conv2dFn.apply(x, weight, bias, w_scale, stride, padding, bool(relu))
+    _require(weight, bias, w_scale, residual)
+    return _Conv2dFn.apply(x, weight, bias, w_scale, stride, padding, bool(relu), residual)
 
 
 def conv_transpose2d(x, weight, stride):

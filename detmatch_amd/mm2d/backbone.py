@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import dense_conv
+from ..fused import on as fused_on
 
 
 class FrozenBN(nn.Module):
@@ -48,12 +49,13 @@ class FrozenBN(nn.Module):
         return cached[1], cached[2]
 
 
-def conv_frozen_bn(x, conv, bn, relu):
-    """relu?(conv(x, w * s) + b): the fold happens while the weights are packed for the kernel
-    (`w_scale`), bias and ReLU in the GEMM's epilogue; gradients come back w.r.t. the unscaled
-    conv.weight (csrc/conv2d.hip, dense_conv.conv2d)."""
+def conv_frozen_bn(x, conv, bn, relu, residual=None):
+    """relu?(conv(x, w * s) + b [+ residual]): the fold happens while the weights are packed for the
+    kernel (`w_scale`), bias, shortcut and ReLU in the GEMM's epilogue; gradients come back w.r.t. the
+    unscaled conv.weight (csrc/conv2d.hip, dense_conv.conv2d)."""
     s, b = bn.scale_shift()
-    return dense_conv.conv2d(x, conv.weight, b, conv.stride, conv.padding, relu=relu, w_scale=s)
+    return dense_conv.conv2d(x, conv.weight, b, conv.stride, conv.padding, relu=relu, w_scale=s,
+                             residual=residual)
 
 
 class Bottleneck(nn.Module):
@@ -76,9 +78,13 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         out = conv_frozen_bn(x, self.conv1, self.bn1, True)
         out = conv_frozen_bn(out, self.conv2, self.bn2, True)
-        out = conv_frozen_bn(out, self.conv3, self.bn3, False)
         idt = x if self.downsample is None else conv_frozen_bn(x, self.downsample[0],
                                                                self.downsample[1], False)
+        if fused_on() and x.is_cuda:
+            # relu(bn3(conv3(out)) + identity) in conv3's epilogue: the sum and the ReLU were two more
+            # passes over the block's output (the largest tensor of the block)
+            return conv_frozen_bn(out, self.conv3, self.bn3, True, residual=idt)
+        out = conv_frozen_bn(out, self.conv3, self.bn3, False)
         return F.relu_(out + idt)
 
 

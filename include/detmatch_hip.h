@@ -552,6 +552,14 @@ size_t dm_dconv_gemm_workspace_bytes(const int *geom_host);   /* 0 unless the re
 int dm_dconv_gemm(const float *x, const float *w_packed, const float *bias, float *y,
                   const int *geom_host, const short *taps_host, void *workspace,
                   size_t workspace_bytes, dm_stream_t stream);
+/* The same with the shortcut branch of a residual block in the epilogue:
+ * y = relu?(conv + bias + residual), residual in y's layout (mmdet ResNet Bottleneck.forward:
+ * `out += identity; out = relu(out)`, mmdet/models/backbones/resnet.py:286-297 of mmdet 2.x —
+ * un-vendored dependency of the reference's Faster R-CNN config). */
+int dm_dconv_gemm_residual(const float *x, const float *w_packed, const float *bias,
+                           const float *residual, float *y, const int *geom_host,
+                           const short *taps_host, void *workspace, size_t workspace_bytes,
+                           dm_stream_t stream);
 size_t dm_dconv_wgrad_workspace_bytes(const int *geom_host);
 int dm_dconv_wgrad(const float *U, const float *V, float *out, const float *scale_u,
                    const int *geom_host, const short *taps_host, int Cv_out, long long su,

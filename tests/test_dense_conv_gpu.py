@@ -279,3 +279,41 @@ def test_mixed_precision_math_mode(dev, shape):
         we2 = w.double().requires_grad_(True)
         (F.conv2d(x.double(), we2, None, s, p) * gy.double()).sum().backward()
         assert float((wd.grad.cpu().double() - we2.grad).abs().max()) <= 2e-2 * float(we2.grad.abs().max())
+
+
+@pytest.mark.parametrize('shape', [((2, 64, 24, 40), 256), ((1, 512, 6, 10), 2048), ((2, 128, 13, 21), 512),
+                                   ((2, 32, 9, 11), 36)],
+                         ids=['64->256', 'split-K 512->2048', 'odd 128->512', 'ragged 32->36'])
+@pytest.mark.parametrize('math', ['fp32', 'bf16'])
+def test_residual_epilogue_is_add_then_relu(dev, shape, math):
+    """relu(conv(x) * s + b + identity) in the GEMM's epilogue (the last 1x1 of a ResNet bottleneck with
+    its frozen BatchNorm) == the same from separate kernels: outputs bit for bit (same accumulator, same
+    fp32 add), gradients w.r.t. input, weight and identity equal."""
+    from detmatch_amd import dense_conv
+    (n, cin, h, w), cout = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn((n, cin, h, w), generator=g).to(dev)
+    wt = (torch.randn((cout, cin, 1, 1), generator=g) / np.sqrt(cin)).to(dev)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(cout, generator=g).to(dev)
+    idt = torch.randn((n, cout, h, w), generator=g).to(dev)
+    dy = torch.randn((n, cout, h, w), generator=g).to(dev)
+    prev = dense_conv.get_math()
+    dense_conv.set_math(math)
+    try:
+        res = []
+        for fused in (True, False):
+            xs, ws, ids = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), idt.clone().requires_grad_(True)
+            if fused:
+                y = dense_conv.conv2d(xs, ws, shift, 1, 0, relu=True, w_scale=scale, residual=ids)
+            else:
+                y = F.relu(dense_conv.conv2d(xs, ws, shift, 1, 0, w_scale=scale) + ids)
+            y.backward(dy)
+            res.append((y.detach(), xs.grad, ws.grad, ids.grad))
+    finally:
+        dense_conv.set_math(prev)
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    assert float((a[0] == 0).float().mean()) > 0.2          # the ReLU is active
+    for u, v, what in zip(a[1:], b[1:], ('dx', 'dw', 'd identity')):
+        assert torch.equal(u, v), what
