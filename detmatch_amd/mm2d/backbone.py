@@ -170,9 +170,18 @@ class FPN(nn.Module):
                                         for _ in in_channels])
 
     def forward(self, inputs):
-        lat = [l(x) for l, x in zip(self.lateral_convs, inputs)]
-        for i in range(len(lat) - 1, 0, -1):
-            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode='nearest')
+        if fused_on() and inputs[0].is_cuda:
+            # top-down: lateral(x_i) + upsample(lat_{i+1}) with the sum in the lateral conv's epilogue
+            lat = [None] * len(inputs)
+            lat[-1] = self.lateral_convs[-1](inputs[-1])
+            for i in range(len(inputs) - 2, -1, -1):
+                c = self.lateral_convs[i].conv
+                up = F.interpolate(lat[i + 1], size=inputs[i].shape[2:], mode='nearest')
+                lat[i] = dense_conv.conv2d(inputs[i], c.weight, c.bias, c.stride, c.padding, residual=up)
+        else:
+            lat = [l(x) for l, x in zip(self.lateral_convs, inputs)]
+            for i in range(len(lat) - 1, 0, -1):
+                lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode='nearest')
         outs = [c(x) for c, x in zip(self.fpn_convs, lat)]
         for _ in range(self.num_outs - len(outs)):
             outs.append(F.max_pool2d(outs[-1], 1, stride=2))

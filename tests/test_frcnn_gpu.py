@@ -179,3 +179,42 @@ def test_rpn_targets_against_brute_force(dev):
             want[ov[i] == ov[i].max()] = i + 1
     assert np.array_equal(got, want)
     assert (max_iou_assign(boxes, gt[:0], 0.7, 0.3, 0.3, True) == 0).all()
+
+
+def test_backbone_and_fpn_epilogue_sums_are_the_separate_kernels(dev):
+    """ResNet-50 + FPN with the shortcut / top-down sums in the convolutions' epilogues (fused switch on)
+    == the same network with separate add and ReLU kernels: feature maps bit for bit, weight gradients
+    equal up to the summation order of the gradient that reaches a tensor along two paths."""
+    from detmatch_amd import configs, fused
+    from detmatch_amd.mm2d.faster_rcnn import FasterRCNN
+    cfg = configs.frcnn_kitti_model()
+    cfg.pop('type')
+    torch.manual_seed(0)
+    m = FasterRCNN(train_cfg=configs.frcnn_train_cfg(), test_cfg=configs.frcnn_test_cfg(), **cfg).to(dev).train()
+    with torch.no_grad():      # zero_init_residual would hide the last BN of every block
+        for mod in m.backbone.modules():
+            if hasattr(mod, 'bn3'):
+                mod.bn3.weight.fill_(0.7)
+    img = torch.randn(2, 3, 96, 160, generator=torch.Generator().manual_seed(1)).to(dev)
+    out = []
+    prev = fused.ENABLED
+    try:
+        for on in (True, False):
+            fused.ENABLED = on
+            m.zero_grad()
+            feats = m.extract_feat(img)
+            gs = [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)).to(dev)
+                  for i, f in enumerate(feats)]
+            torch.autograd.backward(list(feats), gs)
+            out.append(([f.detach().clone() for f in feats],
+                        m.backbone.layer3[2].conv3.weight.grad.clone(),
+                        m.backbone.layer2[0].conv1.weight.grad.clone(),
+                        m.neck.lateral_convs[1].conv.weight.grad.clone()))
+    finally:
+        fused.ENABLED = prev
+    (fa, *ga), (fb, *gb) = out
+    for a, b in zip(fa, fb):
+        assert torch.equal(a, b)
+    for a, b in zip(ga, gb):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale
