@@ -1,8 +1,9 @@
 """Fused training-mode BatchNorm (+ReLU) over (N, C) row-major activations — host side of
 csrc/bn_relu.hip.  `bn_relu_rows(x, bn, relu)` computes exactly what `relu(bn(x))` does for an
 nn.BatchNorm1d / nn.BatchNorm2d module `bn` whose channels are the last dim of `x`, including the
-running-statistics and num_batches_tracked updates; evaluation mode and shapes the kernel does not
-take fall through to torch.nn.functional.batch_norm."""
+running-statistics and num_batches_tracked updates; evaluation mode without gradients (the EMA teacher)
+is one launch of its own; shapes the kernels do not take, and evaluation mode under autograd, fall
+through to torch.nn.functional.batch_norm."""
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -63,6 +64,15 @@ def bn_relu_rows(x, bn, relu=True):
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
         return _BNReLURows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, relu)
+    if not training and _kernel_takes(x, c) and (bn.weight is None) == (bn.bias is None) and \
+            not (torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad))):
+        # inference (the EMA teacher): normalisation with the running statistics + ReLU in one launch
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().dm_bn_rows_eval(
+            _lib.ptr(x), x.shape[0], c, _lib.ptr(bn.weight), _lib.ptr(bn.bias), _lib.ptr(bn.running_mean),
+            _lib.ptr(bn.running_var), float(bn.eps), int(relu), _lib.ptr(y), _lib.stream()), 'dm_bn_rows_eval')
+        return y
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,

@@ -156,6 +156,30 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
   *(float4 *)(y + i) = o;
 }
 
+// evaluation mode (the EMA teacher): y = relu?((x - running_mean) / sqrt(running_var + eps) * gamma + beta)
+// in one launch — torch runs batch_norm_calc_invstd, the transform and a separate ReLU
+__global__ __launch_bounds__(256) void bn_eval_kernel(const float *__restrict__ x, long long n, int c,
+                                                      const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta,
+                                                      const float *__restrict__ mean,
+                                                      const float *__restrict__ var, float eps, int relu,
+                                                      float *__restrict__ y) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n * c) return;
+  const int ch = (int)((threadIdx.x * 4u) % (unsigned)c);
+  const float4 v = *(const float4 *)(x + i);
+  const float4 m = *(const float4 *)(mean + ch), q = *(const float4 *)(var + ch);
+  const float4 g = gamma ? *(const float4 *)(gamma + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 b = beta ? *(const float4 *)(beta + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float sx = 1.0f / sqrtf(q.x + eps), sy = 1.0f / sqrtf(q.y + eps), sz = 1.0f / sqrtf(q.z + eps),
+              sw = 1.0f / sqrtf(q.w + eps);
+  float4 o;
+  o.x = (v.x - m.x) * sx * g.x + b.x, o.y = (v.y - m.y) * sy * g.y + b.y;
+  o.z = (v.z - m.z) * sz * g.z + b.z, o.w = (v.w - m.w) * sw * g.w + b.w;
+  if (relu) o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
+  *(float4 *)(y + i) = o;
+}
+
 // backward pass 1: per block sum(dy_r) and sum(dy_r * xhat), dy_r = dy masked by the ReLU
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, long long n, int c,
@@ -294,6 +318,19 @@ extern "C" int dm_bn_rows_forward(const float *x, long long n, int c, const floa
   const long long quads = n * c / 4;
   bn_apply_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, st>>>(x, n, c, gamma, beta, save_mean,
                                                                    save_invstd, relu, y);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_bn_rows_eval(const float *x, long long n, int c, const float *gamma, const float *beta,
+                               const float *running_mean, const float *running_var, float eps, int relu,
+                               float *y, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!bn_shape_ok(n, c)) return n == 0 ? DM_OK : DM_ERR_UNSUPPORTED;
+  if (!x || !y || !running_mean || !running_var) return DM_ERR_INVALID_ARG;
+  const long long quads = n * c / 4;
+  bn_eval_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, st>>>(x, n, c, gamma, beta, running_mean,
+                                                                  running_var, eps, relu, y);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -261,6 +261,10 @@ int dm_bn_rows_forward(const float *x, long long n, int c, const float *gamma, c
                        float eps, float momentum, float *running_mean, float *running_var, int relu,
                        float *y, float *save_mean, float *save_invstd, void *workspace,
                        size_t workspace_bytes, dm_stream_t stream);
+/* Evaluation mode (running statistics; the EMA teacher's BatchNorm layers), optional ReLU, one launch. */
+int dm_bn_rows_eval(const float *x, long long n, int c, const float *gamma, const float *beta,
+                    const float *running_mean, const float *running_var, float eps, int relu, float *y,
+                    dm_stream_t stream);
 /* grad_x (N,C), grad_gamma (C), grad_beta (C); the ReLU mask is recomputed from x. */
 int dm_bn_rows_backward(const float *grad_out, const float *x, long long n, int c, const float *gamma,
                         const float *beta, const float *save_mean, const float *save_invstd, int relu,

@@ -316,10 +316,15 @@ def test_fused_bn_relu_rows_matches_torch(dev, n, c, relu):
     assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, rtol=2e-3, atol=2e-3 * float(ref.weight.grad.abs().max()))
     assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=2e-3, atol=2e-3 * float(ref.bias.grad.abs().max()))
     bn.eval()
-    ye = bn_relu_rows(x.detach(), bn, relu=relu)          # evaluation mode falls through to torch
     ref.eval()
     ze = ref(x.detach().double())
-    assert torch.allclose(ye.double(), torch.relu(ze) if relu else ze, rtol=1e-4, atol=1e-4)
+    ze = torch.relu(ze) if relu else ze
+    with torch.no_grad():
+        ye = bn_relu_rows(x.detach(), bn, relu=relu)      # inference: dm_bn_rows_eval, one launch
+    assert float((ye.double() - ze).abs().max()) < 2e-6 * (float(ze.abs().max()) + 1.0)
+    xg = x.detach().clone().requires_grad_()
+    yg = bn_relu_rows(xg, bn, relu=relu)                  # evaluation mode under autograd: torch
+    assert yg.requires_grad and torch.allclose(yg.double(), ze, rtol=1e-4, atol=1e-4)
 
 
 # ---------------------------------------------------------------------------------------------
