@@ -80,6 +80,94 @@ def apply_3d_transformation_bboxes(bbox, img_meta, reverse=False):
     return bbox
 
 
+def compose_3d_transformation(img_meta, reverse=False):
+    """The recorded 3D augmentations of a sample (what apply_3d_transformation_bboxes replays op by op)
+    as ONE affine map of the box parameters: centre' = centre @ A + t, size' = s * size,
+    yaw' = sigma * yaw + off.  Every op of transformation_3d_flow is affine in (centre, size, yaw):
+    T adds to the centre, S scales centre and size, R multiplies the centre by M and adds
+    atan2(M[1, 0], M[0, 0]) to the yaw, HF / VF negate y / x and reflect the yaw.  Composed in float64
+    from the same fp32 records (the inverse rotation is torch.inverse in fp32, as in the replay).
+    -> (A (3, 3), t (3,), s, sigma, off) as float64 numpy / floats."""
+    rot = (torch.as_tensor(np.asarray(img_meta['pcd_rotation']), dtype=torch.float32).cpu()
+           if 'pcd_rotation' in img_meta else torch.eye(3))
+    scale = float(img_meta['pcd_scale_factor']) if 'pcd_scale_factor' in img_meta else 1.0
+    trans = (torch.as_tensor(np.asarray(img_meta['pcd_trans']), dtype=torch.float32).cpu()
+             if 'pcd_trans' in img_meta else torch.zeros(3))
+    flow = list(img_meta.get('transformation_3d_flow', []))
+    if reverse:
+        scale, trans, rot, flow = 1.0 / scale, -trans, rot.inverse(), flow[::-1]
+    rot = rot.double().numpy()
+    trans = trans.double().numpy()
+    A, t, s, sigma, off = np.eye(3), np.zeros(3), 1.0, 1.0, 0.0
+    for op in flow:
+        if op == 'T':
+            t = t + trans
+        elif op == 'S':
+            A, t, s = A * scale, t * scale, s * scale
+        elif op == 'R':
+            A, t = A @ rot, t @ rot
+            off = off + float(np.arctan2(np.float32(rot[1, 0]), np.float32(rot[0, 0])))
+        elif op == 'HF':
+            if img_meta.get('pcd_horizontal_flip', False):
+                A, t = A.copy(), t.copy()
+                A[:, 1], t[1] = -A[:, 1], -t[1]
+                sigma, off = -sigma, -off + np.pi
+        elif op == 'VF':
+            if img_meta.get('pcd_vertical_flip', False):
+                A, t = A.copy(), t.copy()
+                A[:, 0], t[0] = -A[:, 0], -t[0]
+                sigma, off = -sigma, -off
+        else:
+            raise AssertionError('This 3D data transformation op (%s) is not supported' % op)
+    return A, t, s, sigma, off
+
+
+class _UnaugProject(torch.autograd.Function):
+    """boxes3d (N, 7) of the augmented frame -> xyxy (N, 4) in the original image + validity, one launch
+    forward and one backward (csrc/box_project.hip)."""
+
+    @staticmethod
+    def forward(ctx, boxes, xf, m16, img_w, img_h):
+        from .. import _lib
+        boxes = boxes.detach().float().contiguous()
+        n = boxes.shape[0]
+        out = torch.empty((n, 4), dtype=torch.float32, device=boxes.device)
+        valid = torch.empty((n,), dtype=torch.uint8, device=boxes.device)
+        _lib.check(_lib.lib().dm_box3d_project_forward(_lib.ptr(boxes), n, xf, m16, float(img_w), float(img_h),
+                                                       _lib.ptr(out), _lib.ptr(valid), _lib.stream()),
+                   'dm_box3d_project_forward')
+        ctx.save_for_backward(boxes)
+        ctx.cfg = (xf, m16, float(img_w), float(img_h))
+        valid = valid.bool()
+        ctx.mark_non_differentiable(valid)
+        return out, valid
+
+    @staticmethod
+    def backward(ctx, gout, _gvalid):
+        from .. import _lib
+        boxes, = ctx.saved_tensors
+        xf, m16, img_w, img_h = ctx.cfg
+        n = boxes.shape[0]
+        g = torch.empty_like(boxes)
+        _lib.check(_lib.lib().dm_box3d_project_backward(_lib.ptr(boxes), n, xf, m16, img_w, img_h,
+                                                        _lib.ptr(gout.contiguous().float()), _lib.ptr(g),
+                                                        _lib.stream()), 'dm_box3d_project_backward')
+        return g, None, None, None, None
+
+
+def unaug_project_boxes(bboxes_3d, img_meta):
+    """apply_3d_transformation_bboxes(reverse=True) + bbox_3d_to_bbox_2d on the device kernels:
+    (xyxy (N, 4) in the original image, valid (N,) bool); gradient flows to bboxes_3d.tensor."""
+    from .. import _lib
+    assert isinstance(bboxes_3d, LiDARInstance3DBoxes) and bboxes_3d.tensor.shape[1] == 7
+    A, t, s, sigma, off = compose_3d_transformation(img_meta, reverse=True)
+    xf = _lib.floats(list(A.reshape(-1)) + list(t) + [s, sigma, off, 0.0, 0.0])
+    l2i = img_meta['lidar2img']
+    m16 = _lib.floats(np.asarray(l2i.cpu() if torch.is_tensor(l2i) else l2i, np.float32).reshape(-1))
+    img_v, img_h = img_meta['ori_shape'][0], img_meta['ori_shape'][1]
+    return _UnaugProject.apply(bboxes_3d.tensor, xf, m16, img_h, img_v)
+
+
 # ------------------------------------------------------------------ 3D -> 2D projection
 def bbox_3d_to_bbox_2d(bboxes_3d, lidar2img, img_shape):
     """bbox_utils.py:372-441 (autograd preserving).  Returns xyxy (N,4) for ALL boxes and the

@@ -11,7 +11,7 @@ import torch
 from torch.nn import functional as F
 
 from .bbox_utils import (apply_3d_transformation_bboxes, bbox_2d_transform, bbox_3d_to_bbox_2d,
-                         filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set)
+                         filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set, unaug_project_boxes)
 from ..devconst import const
 from ..fused import on as fused_on
 from .box3d import LiDARInstance3DBoxes
@@ -259,8 +259,11 @@ class Bboxes3DTo2D(object):
         out = []
         for entry, meta in zip(mlvl_get(batch_dict, self.in_bboxes_key), metas):
             boxes3d, rest, tup = _split(entry)
-            boxes3d = apply_3d_transformation_bboxes(boxes3d, meta, reverse=True)
-            boxes2d, valid = bbox_3d_to_bbox_2d(boxes3d, meta['lidar2img'], meta['ori_shape'])
+            if fused_on() and boxes3d.tensor.is_cuda and boxes3d.tensor.shape[1] == 7 and len(boxes3d.tensor):
+                boxes2d, valid = unaug_project_boxes(boxes3d, meta)       # two launches, fwd + bwd
+            else:
+                boxes3d = apply_3d_transformation_bboxes(boxes3d, meta, reverse=True)
+                boxes2d, valid = bbox_3d_to_bbox_2d(boxes3d, meta['lidar2img'], meta['ori_shape'])
             if self.filter_invalid:
                 boxes2d, rest = boxes2d[valid], [t[valid] for t in rest]
             out.append(_join(boxes2d, rest, tup))

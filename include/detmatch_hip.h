@@ -271,6 +271,20 @@ int dm_bn_rows_backward(const float *grad_out, const float *x, long long n, int 
                         float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
                         size_t workspace_bytes, dm_stream_t stream);
 
+/* Bboxes3DTo2D on one sample (mmdet3d/models/ssl_modules/processors_3d.py:81-155):
+ * apply_3d_transformation_bboxes(reverse=True) (bbox_utils.py:110-200) composed on the host into
+ * xf17_host = {A[9] (centre' = centre @ A, row-major), t[3], s, sigma, off, 0, 0}
+ * (size' = s * size, yaw' = sigma * yaw + off), then bbox_3d_to_bbox_2d (bbox_utils.py:372-441) with the
+ * row-major 4x4 lidar2img16_host and the ORIGINAL image size.  boxes3d (n, 7) -> boxes2d (n, 4) xyxy,
+ * valid (n) bytes (>= 3 corners inside the image and mean clamped depth >= 0.5).  Backward: gradient of
+ * boxes2d -> gradient of boxes3d (the forward is recomputed; clip / clamp / min / max as torch). */
+int dm_box3d_project_forward(const float *boxes3d, int n, const float *xf17_host,
+                             const float *lidar2img16_host, float img_w, float img_h, float *boxes2d,
+                             unsigned char *valid, dm_stream_t stream);
+int dm_box3d_project_backward(const float *boxes3d, int n, const float *xf17_host,
+                              const float *lidar2img16_host, float img_w, float img_h,
+                              const float *grad_boxes2d, float *grad_boxes3d, dm_stream_t stream);
+
 /* Anchor-head box decoding: AnchorHeadTemplate.generate_predicted_boxes
  * (pcdet/models/dense_heads/anchor_head_template.py:225-272) = ResidualCoder.decode_torch
  * (pcdet/utils/box_coder_utils.py:43-76) + direction-bin correction (common_utils.limit_period).

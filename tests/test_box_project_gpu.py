@@ -1,0 +1,61 @@
+"""csrc/box_project.hip (Bboxes3DTo2D on one sample in one launch, forward and backward) against the tensor
+chain it replaces: apply_3d_transformation_bboxes(reverse=True) + bbox_3d_to_bbox_2d — both pinned to
+reference goldens on the CPU (tests/golden/ssl_geometry.npz)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _meta(rng, flow, hflip, vflip):
+    ang = rng.uniform(-0.78, 0.78)
+    c, s = np.cos(ang), np.sin(ang)
+    # KITTI-like projection: camera looks along +x of the lidar frame
+    p = np.array([[721.5, 0, 609.6, 44.9], [0, 721.5, 172.9, 0.2], [0, 0, 1, 0.003], [0, 0, 0, 1]], np.float32)
+    r = np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]], np.float32)
+    return dict(pcd_rotation=torch.tensor([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=torch.float32),
+                pcd_scale_factor=float(rng.uniform(0.95, 1.05)),
+                pcd_trans=np.asarray(rng.normal(0, 0.2, 3), np.float32),
+                pcd_horizontal_flip=hflip, pcd_vertical_flip=vflip, transformation_3d_flow=flow,
+                lidar2img=p @ r, ori_shape=(375, 1242, 3))
+
+
+@pytest.mark.parametrize('flow,hflip,vflip', [(['HF', 'R', 'S', 'T'], True, False), (['R', 'S', 'T'], False, False),
+                                              (['HF', 'VF', 'R', 'S', 'T'], True, True), ([], False, False),
+                                              (['T', 'S', 'R', 'VF', 'HF'], False, True)])
+def test_unaug_project_kernel_matches_tensor_chain(dev, flow, hflip, vflip):
+    from detmatch_amd.mm3d.bbox_utils import (apply_3d_transformation_bboxes, bbox_3d_to_bbox_2d,
+                                              unaug_project_boxes)
+    from detmatch_amd.mm3d.box3d import LiDARInstance3DBoxes
+    rng = np.random.default_rng(len(flow) * 7 + hflip + 2 * vflip)
+    meta = _meta(rng, flow, hflip, vflip)
+    n = 150
+    b = np.concatenate([rng.uniform([2, -25, -2.5], [60, 25, 0.5], (n, 3)), rng.uniform([0.5, 0.4, 1.0], [4.5, 2.0, 2.2], (n, 3)),
+                        rng.uniform(-3.2, 3.2, (n, 1))], 1).astype(np.float32)
+    b[:10, 0] = rng.uniform(-20, 1.0, 10)              # behind / beside the camera: clamped depth, clipped boxes
+    # the scene is laid out in the ORIGINAL frame; the student sees it through the recorded augmentations
+    b = apply_3d_transformation_bboxes(LiDARInstance3DBoxes(torch.from_numpy(b).to(dev)), meta,
+                                       reverse=False).tensor.cpu().numpy()
+    g = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32)).to(dev)
+    res = []
+    for fused in (True, False):
+        t = torch.from_numpy(b).to(dev).requires_grad_(True)
+        boxes = LiDARInstance3DBoxes(t * 1.0)
+        if fused:
+            xy, valid = unaug_project_boxes(boxes, meta)
+        else:
+            xy, valid = bbox_3d_to_bbox_2d(apply_3d_transformation_bboxes(boxes, meta, reverse=True),
+                                           meta['lidar2img'], meta['ori_shape'])
+        (xy * g).sum().backward()
+        res.append((xy.detach(), valid, t.grad.clone()))
+    (xa, va, ga), (xb, vb, gb) = res
+    assert float((xa - xb).abs().max()) < 2e-2                      # pixels, coordinates up to 1242
+    assert int((va != vb).sum()) <= 1 and int(va.sum()) > 50        # a corner exactly on the border may flip
+    ok = (va & vb)
+    scale = float(gb[ok].abs().max())
+    assert float((ga[ok] - gb[ok]).abs().max()) < 2e-3 * scale
+    # boxes clipped on all four sides give no gradient on either path
+    dead = (xb[:, 0] == xb[:, 2]) | (xb[:, 1] == xb[:, 3])
+    if bool(dead.any()):
+        assert float(ga[dead].abs().max()) <= 1e-3 * scale + float(gb[dead].abs().max())
