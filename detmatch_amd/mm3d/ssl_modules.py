@@ -533,6 +533,40 @@ class HardPseudoLabel_2D(object):
 
 
 # ------------------------------------------------------------------ consistency + metrics
+class _FusedConsistencyLoss(torch.autograd.Function):
+    """(cls, l1, iou) of one sample's matched pairs in one launch, analytic gradients in one more
+    (csrc/consistency_loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, in_boxes, in_scores, tgt_boxes, tgt_scores, img_w, img_h, alpha, gamma):
+        from .. import _lib
+        in_boxes, in_scores = in_boxes.detach().float().contiguous(), in_scores.detach().float().contiguous()
+        tgt_boxes, tgt_scores = tgt_boxes.detach().float().contiguous(), tgt_scores.detach().float().contiguous()
+        n, c = in_scores.shape
+        dev = in_boxes.device
+        out = torch.empty((3,), dtype=torch.float32, device=dev)
+        gs = torch.empty((n, c), dtype=torch.float32, device=dev)
+        gl = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        gi = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().dm_consistency_loss_forward(
+            _lib.ptr(in_boxes), _lib.ptr(in_scores), _lib.ptr(tgt_boxes), _lib.ptr(tgt_scores), n, c,
+            float(img_w), float(img_h), float(alpha), float(gamma), 1e-6, 1e-6, _lib.ptr(out), _lib.ptr(gs),
+            _lib.ptr(gl), _lib.ptr(gi), _lib.stream()), 'dm_consistency_loss_forward')
+        ctx.save_for_backward(gs, gl, gi)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib
+        gs, gl, gi = ctx.saved_tensors
+        n, c = gs.shape
+        d_scores, d_boxes = torch.empty_like(gs), torch.empty_like(gl)
+        _lib.check(_lib.lib().dm_consistency_loss_backward(
+            _lib.ptr(g.contiguous().float()), _lib.ptr(gs), _lib.ptr(gl), _lib.ptr(gi), n, c,
+            _lib.ptr(d_scores), _lib.ptr(d_boxes), _lib.stream()), 'dm_consistency_loss_backward')
+        return d_boxes, d_scores, None, None, None, None, None, None
+
+
 @SSL_MODULES.register_module()
 class HungarianConsistency(object):
     """consumers_3d.py:11-117: box-level 2D<->3D consistency over index-aligned matched lists:
@@ -554,6 +588,14 @@ class HungarianConsistency(object):
         self.target_img_metas_key = target_img_metas_key
         self.name = name
 
+    def _fusable(self, boxes):
+        """The DetMatch configuration (focal on logits + L1 + GIoU, all 'mean') on a CUDA device."""
+        from .losses import GIoULoss, L1Loss
+        return (fused_on() and boxes.is_cuda and isinstance(self.loss_cls, FocalLoss)
+                and isinstance(self.loss_l1, L1Loss) and isinstance(self.loss_iou, GIoULoss)
+                and all(l.reduction == 'mean' for l in (self.loss_cls, self.loss_l1, self.loss_iou))
+                and self.loss_iou.eps == 1e-6)
+
     def forward(self, ssl_obj, batch_dict):
         in_list = mlvl_get(batch_dict, self.in_bboxes_key)
         tgt_list = mlvl_get(batch_dict, self.target_bboxes_key)
@@ -568,6 +610,15 @@ class HungarianConsistency(object):
             in_scores = _fg_scores(cur_in[1], self.cls_includes_bg_pred_in)
             tgt_scores = _fg_scores(cur_tgt[1], self.cls_includes_bg_pred_target)
             assert in_scores.shape[1] == tgt_scores.shape[1] == 3
+            if self._fusable(in_boxes):
+                img_h, img_w, _ = metas[idx]['img_shape']
+                vals = _FusedConsistencyLoss.apply(in_boxes, in_scores, tgt_boxes, tgt_scores, img_w, img_h,
+                                                   self.loss_cls.alpha, self.loss_cls.gamma)
+                for k, (lname, fn) in enumerate((('cls_loss', self.loss_cls), ('l1_loss', self.loss_l1),
+                                                 ('iou_loss', self.loss_iou))):
+                    per_sample.setdefault(lname, []).append(vals[k] if fn.loss_weight == 1.0
+                                                            else vals[k] * fn.loss_weight)
+                continue
             for lname, fn in active:
                 if lname == 'cls_loss':
                     if isinstance(fn, MSELoss):

@@ -285,6 +285,21 @@ int dm_box3d_project_backward(const float *boxes3d, int n, const float *xf17_hos
                               const float *lidar2img16_host, float img_w, float img_h,
                               const float *grad_boxes2d, float *grad_boxes3d, dm_stream_t stream);
 
+/* HungarianConsistency on one sample's index-aligned matched pairs
+ * (mmdet3d/models/ssl_modules/consumers_3d.py:11-117; DetMatch configuration: mmdet FocalLoss on
+ * torch.logit(in_scores, logit_eps) vs arg-max of target_scores, L1Loss on boxes / (w, h, w, h),
+ * GIoULoss; reduction 'mean', loss_weight 1).  losses3 = {cls, l1, iou}; the unit gradients
+ * (d loss / d in_scores (n, n_cls), d l1 / d in_boxes (n, 4), d iou / d in_boxes (n, 4)) are kept for
+ * the backward, which scales them by the upstream gradient of losses3. */
+int dm_consistency_loss_forward(const float *in_boxes, const float *in_scores, const float *target_boxes,
+                                const float *target_scores, int n, int n_cls, float img_w, float img_h,
+                                float alpha, float gamma, float logit_eps, float iou_eps, float *losses3,
+                                float *unit_grad_scores, float *unit_grad_l1, float *unit_grad_iou,
+                                dm_stream_t stream);
+int dm_consistency_loss_backward(const float *grad_losses3, const float *unit_grad_scores,
+                                 const float *unit_grad_l1, const float *unit_grad_iou, int n, int n_cls,
+                                 float *grad_scores, float *grad_boxes, dm_stream_t stream);
+
 /* Anchor-head box decoding: AnchorHeadTemplate.generate_predicted_boxes
  * (pcdet/models/dense_heads/anchor_head_template.py:225-272) = ResidualCoder.decode_torch
  * (pcdet/utils/box_coder_utils.py:43-76) + direction-bin correction (common_utils.limit_period).

@@ -59,3 +59,41 @@ def test_unaug_project_kernel_matches_tensor_chain(dev, flow, hflip, vflip):
     dead = (xb[:, 0] == xb[:, 2]) | (xb[:, 1] == xb[:, 3])
     if bool(dead.any()):
         assert float(ga[dead].abs().max()) <= 1e-3 * scale + float(gb[dead].abs().max())
+
+
+@pytest.mark.parametrize('n', [1, 7, 300])
+def test_consistency_loss_kernel_matches_tensor_losses(dev, n):
+    """csrc/consistency_loss.hip == mmdet-style FocalLoss(logit) + L1Loss(normalised) + GIoULoss of
+    mm3d/losses.py (themselves pinned to reference goldens): values and gradients."""
+    from detmatch_amd.mm3d.losses import FocalLoss, GIoULoss, L1Loss
+    from detmatch_amd.mm3d.ssl_modules import _FusedConsistencyLoss
+    g = torch.Generator().manual_seed(n)
+    c = torch.rand(n, 2, generator=g) * torch.tensor([1100.0, 300.0]) + 60
+    wh = torch.rand(n, 2, generator=g) * 150 + 5
+    tgt = torch.cat([c - wh / 2, c + wh / 2], 1)
+    pred = tgt + torch.randn(n, 4, generator=g) * 25
+    pred[::5] = tgt[::5] + 400.0                                  # disjoint pairs
+    if n > 2:
+        pred[1, 2] = pred[1, 0] - 3.0                             # inverted box: negative width
+        pred[2] = tgt[2]                                          # identical boxes: ties in min / max
+    ps = torch.rand(n, 3, generator=g).clamp(1e-4, 1 - 1e-4)
+    ps[0, 0] = 1e-9                                               # outside the logit clamp: no gradient
+    ts = torch.rand(n, 3, generator=g)
+    up = torch.tensor([2.0, 20.0, 2.0]).to(dev)
+    res = []
+    for fused in (True, False):
+        b = pred.to(dev).requires_grad_(True)
+        s = ps.to(dev).requires_grad_(True)
+        if fused:
+            vals = _FusedConsistencyLoss.apply(b, s, tgt.to(dev), ts.to(dev), 1248.0, 384.0, 0.25, 2.0)
+        else:
+            f = torch.tensor([1248.0, 384.0, 1248.0, 384.0]).to(dev)
+            vals = torch.stack([FocalLoss()(torch.logit(s, eps=1e-6), torch.argmax(ts.to(dev), dim=1)),
+                                L1Loss()(b / f, tgt.to(dev) / f), GIoULoss()(b, tgt.to(dev))])
+        (vals * up).sum().backward()
+        res.append((vals.detach(), b.grad.clone(), s.grad.clone()))
+    (va, ba, sa), (vb, bb, sb) = res
+    assert torch.allclose(va, vb, rtol=2e-5, atol=1e-6), (va, vb)
+    assert float((ba - bb).abs().max()) <= 2e-4 * float(bb.abs().max()) + 1e-9
+    assert float((sa - sb).abs().max()) <= 2e-4 * float(sb.abs().max()) + 1e-9
+    assert float(sa[0, 0]) == 0.0 == float(sb[0, 0])
