@@ -125,6 +125,55 @@ __global__ __launch_bounds__(64) void box_project_bwd_kernel(const float *__rest
   o[6] = gyaw * c.sigma;
 }
 
+// bbox_2d_transform (mmdet3d/models/fusion_layers/coord_transform.py:121-175): scale -> crop offset ->
+// h-flip of xyxy boxes (ori2new), or the reverse order with the inverse operations; the same fp32
+// operations in the same order as the tensor chain (13 launches), and its transpose for the gradient.
+struct Box2DXf {
+  float sx, sy, cx, cy, img_w;
+  int flip, ori2new;
+};
+
+__global__ __launch_bounds__(256) void bbox2d_transform_kernel(const float *__restrict__ in, int n, Box2DXf c,
+                                                               int backward, float *__restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float *b = in + (size_t)i * 4;
+  float *o = out + (size_t)i * 4;
+  if (!backward) {
+    float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+    if (c.ori2new) {
+      x1 = x1 * c.sx + c.cx, x2 = x2 * c.sx + c.cx, y1 = y1 * c.sy + c.cy, y2 = y2 * c.sy + c.cy;
+      if (c.flip) {
+        const float t = x1;
+        x1 = c.img_w - x2, x2 = c.img_w - t;
+      }
+    } else {
+      if (c.flip) {
+        const float t = x1;
+        x1 = c.img_w - x2, x2 = c.img_w - t;
+      }
+      x1 = (x1 - c.cx) / c.sx, x2 = (x2 - c.cx) / c.sx, y1 = (y1 - c.cy) / c.sy, y2 = (y2 - c.cy) / c.sy;
+    }
+    o[0] = x1, o[1] = y1, o[2] = x2, o[3] = y2;
+  } else {            // in = gradient of the transformed boxes
+    float g1 = b[0], h1 = b[1], g2 = b[2], h2 = b[3];
+    if (c.ori2new) {
+      if (c.flip) {
+        const float t = g1;
+        g1 = -g2, g2 = -t;
+      }
+      g1 *= c.sx, g2 *= c.sx, h1 *= c.sy, h2 *= c.sy;
+    } else {
+      g1 /= c.sx, g2 /= c.sx, h1 /= c.sy, h2 /= c.sy;
+      if (c.flip) {
+        const float t = g1;
+        g1 = -g2, g2 = -t;
+      }
+    }
+    o[0] = g1, o[1] = h1, o[2] = g2, o[3] = h2;
+  }
+}
+
 bool fill_cfg(const float *xf17_host, const float *lidar2img16_host, float img_w, float img_h, ProjCfg &c) {
   if (!xf17_host || !lidar2img16_host) return false;
   for (int k = 0; k < 9; ++k) c.A[k] = xf17_host[k];
@@ -161,6 +210,19 @@ extern "C" int dm_box3d_project_backward(const float *boxes3d, int n, const floa
     return DM_ERR_INVALID_ARG;
   box_project_bwd_kernel<<<dm_ceil_div(n, 64), 64, 0, (hipStream_t)stream>>>(boxes3d, n, c, grad_boxes2d,
                                                                               grad_boxes3d);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_bbox2d_transform(const float *boxes_or_grad, int n, float scale_x, float scale_y,
+                                   float crop_x, float crop_y, float img_w, int flip, int ori2new,
+                                   int backward, float *out, dm_stream_t stream) {
+  if (n < 0 || scale_x == 0.f || scale_y == 0.f) return DM_ERR_INVALID_ARG;
+  if (n == 0) return DM_OK;
+  if (!boxes_or_grad || !out) return DM_ERR_INVALID_ARG;
+  Box2DXf c;
+  c.sx = scale_x, c.sy = scale_y, c.cx = crop_x, c.cy = crop_y, c.img_w = img_w, c.flip = flip, c.ori2new = ori2new;
+  bbox2d_transform_kernel<<<dm_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(boxes_or_grad, n, c, backward, out);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -211,8 +211,40 @@ def extract_2d_info(img_meta, tensor):
     return img_h, img_w, ori_h, ori_w, scale, flip, crop
 
 
+class _Box2DTransform(torch.autograd.Function):
+    """bbox_2d_transform on (n, 4) boxes in one launch, its transpose in one more (csrc/box_project.hip)."""
+
+    @staticmethod
+    def forward(ctx, boxes, cfg):
+        ctx.cfg = cfg
+        return _Box2DTransform._run(boxes.detach(), cfg, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Box2DTransform._run(g, ctx.cfg, 1), None
+
+    @staticmethod
+    def _run(t, cfg, backward):
+        t = t.float().contiguous()
+        out = torch.empty_like(t)
+        sx, sy, cx, cy, img_w, flip, ori2new = cfg
+        _lib.check(_lib.lib().dm_bbox2d_transform(_lib.ptr(t), t.shape[0], sx, sy, cx, cy, img_w, flip, ori2new,
+                                                  backward, _lib.ptr(out), _lib.stream()), 'dm_bbox2d_transform')
+        return out
+
+
 def bbox_2d_transform(img_meta, bbox_2d, ori2new):
     """coord_transform.py:121-175 (scale -> crop offset -> h-flip, or the reverse)."""
+    from ..fused import on as fused_on
+    if fused_on() and bbox_2d.is_cuda and bbox_2d.dim() == 2 and bbox_2d.shape[1] == 4 and \
+            bbox_2d.dtype == torch.float32 and bbox_2d.shape[0] > 0:
+        sf = np.asarray(img_meta['scale_factor'][:2], np.float32) if 'scale_factor' in img_meta \
+            else np.ones(2, np.float32)
+        co = np.asarray(img_meta['img_crop_offset'], np.float32) if 'img_crop_offset' in img_meta \
+            else np.zeros(2, np.float32)
+        cfg = (float(sf[0]), float(sf[1]), float(co[0]), float(co[1]), float(img_meta['img_shape'][1]),
+               int(bool(img_meta['flip'] if 'flip' in img_meta else False)), int(bool(ori2new)))
+        return _Box2DTransform.apply(bbox_2d, cfg)
     img_h, img_w, ori_h, ori_w, scale, flip, crop = extract_2d_info(img_meta, bbox_2d)
     x1, y1, x2, y2 = bbox_2d[:, 0], bbox_2d[:, 1], bbox_2d[:, 2], bbox_2d[:, 3]
     if ori2new:

@@ -300,6 +300,13 @@ int dm_consistency_loss_backward(const float *grad_losses3, const float *unit_gr
                                  const float *unit_grad_l1, const float *unit_grad_iou, int n, int n_cls,
                                  float *grad_scores, float *grad_boxes, dm_stream_t stream);
 
+/* bbox_2d_transform (mmdet3d/models/fusion_layers/coord_transform.py:121-175) on (n, 4) xyxy boxes:
+ * ori2new = scale -> crop offset -> h-flip, else the reverse; backward != 0 maps the gradient of the
+ * transformed boxes to the gradient of the input boxes. */
+int dm_bbox2d_transform(const float *boxes_or_grad, int n, float scale_x, float scale_y, float crop_x,
+                        float crop_y, float img_w, int flip, int ori2new, int backward, float *out,
+                        dm_stream_t stream);
+
 /* Anchor-head box decoding: AnchorHeadTemplate.generate_predicted_boxes
  * (pcdet/models/dense_heads/anchor_head_template.py:225-272) = ResidualCoder.decode_torch
  * (pcdet/utils/box_coder_utils.py:43-76) + direction-bin correction (common_utils.limit_period).

@@ -97,3 +97,31 @@ def test_consistency_loss_kernel_matches_tensor_losses(dev, n):
     assert float((ba - bb).abs().max()) <= 2e-4 * float(bb.abs().max()) + 1e-9
     assert float((sa - sb).abs().max()) <= 2e-4 * float(sb.abs().max()) + 1e-9
     assert float(sa[0, 0]) == 0.0 == float(sb[0, 0])
+
+
+@pytest.mark.parametrize('flip', [False, True])
+@pytest.mark.parametrize('ori2new', [False, True])
+def test_bbox2d_transform_kernel_is_the_tensor_chain(dev, flip, ori2new):
+    """dm_bbox2d_transform == bbox_2d_transform's tensor chain (pinned to the reference on the CPU): boxes
+    bit for bit, gradient equal."""
+    from detmatch_amd import fused
+    from detmatch_amd.mm3d.bbox_utils import bbox_2d_transform
+    meta = dict(img_shape=(384, 1248, 3), ori_shape=(375, 1242, 3), flip=flip,
+                scale_factor=np.array([1.0048, 1.024, 1.0048, 1.024], np.float32),
+                img_crop_offset=np.array([3.0, -2.0], np.float32))
+    g = torch.Generator().manual_seed(3)
+    b = torch.rand(40, 4, generator=g) * 1200
+    up = torch.randn(40, 4, generator=g).to(dev)
+    res = []
+    prev = fused.ENABLED
+    try:
+        for on in (True, False):
+            fused.ENABLED = on
+            t = b.to(dev).requires_grad_(True)
+            y = bbox_2d_transform(meta, t, ori2new)
+            (y * up).sum().backward()
+            res.append((y.detach(), t.grad.clone()))
+    finally:
+        fused.ENABLED = prev
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-6, atol=0)
