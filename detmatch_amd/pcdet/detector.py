@@ -16,7 +16,7 @@ from .backbones_3d import HeightCompression, MeanVFE, VoxelBackBone8x
 from .config import ConfigDict
 from .dense_heads import AnchorHeadSingle, PointHeadSimple, valid_gt_mask
 from .pfe import VoxelSetAbstraction
-from .roi_heads import PVRCNNHead, class_agnostic_nms_fixed
+from .roi_heads import PVRCNNHead, class_agnostic_nms_fixed_batch
 
 _MODULES = {
     'MeanVFE': MeanVFE, 'VoxelBackBone8x': VoxelBackBone8x, 'HeightCompression': HeightCompression,
@@ -155,16 +155,22 @@ class PVRCNN(nn.Module):
         recall_dict = {}
         pred_dicts = []
         staged = []
-        # pass 1: everything that stays on the device (scores, labels, fixed-size NMS)
+        # pass 1: everything that stays on the device (scores, labels, fixed-size NMS), over the batch
+        all_cls = batch_dict['batch_cls_preds']
+        assert all_cls.dim() == 3 and all_cls.shape[2] in [1, self.num_class]
+        if not batch_dict['cls_preds_normalized']:
+            all_cls = torch.sigmoid(all_cls)
+        all_cls, all_labels = torch.max(all_cls, dim=-1)
+        all_sel = all_valid = None
+        if not no_nms:
+            all_sel, all_valid = class_agnostic_nms_fixed_batch(
+                all_cls.detach(), batch_dict['batch_box_preds'].detach(), cfg.NMS_CONFIG,
+                score_thresh=cfg.SCORE_THRESH)
         for index in range(batch_size):
             box_preds = batch_dict['batch_box_preds'][index]
             src_box_preds = box_preds
-            cls_preds = batch_dict['batch_cls_preds'][index]
-            src_cls_preds = cls_preds
-            assert cls_preds.shape[1] in [1, self.num_class]
-            if not batch_dict['cls_preds_normalized']:
-                cls_preds = torch.sigmoid(cls_preds)
-            cls_preds, label_preds = torch.max(cls_preds, dim=-1)
+            src_cls_preds = batch_dict['batch_cls_preds'][index]
+            cls_preds, label_preds = all_cls[index], all_labels[index]
             if batch_dict.get('has_class_labels', False):
                 label_key = 'roi_labels' if 'roi_labels' in batch_dict else 'batch_pred_labels'
                 label_preds = batch_dict[label_key][index]
@@ -176,14 +182,13 @@ class PVRCNN(nn.Module):
                 sem_scores_full = src_cls_preds
             sel = valid = None
             if not no_nms:
-                sel, valid = class_agnostic_nms_fixed(cls_preds.detach(), box_preds.detach(),
-                                                      cfg.NMS_CONFIG, score_thresh=cfg.SCORE_THRESH)
+                sel, valid = all_sel[index], all_valid[index]
             staged.append((box_preds, src_box_preds, cls_preds, src_cls_preds, label_preds, sem_scores,
                            sem_scores_full, sel, valid))
         # the ONE read-back of the call: how many boxes survive per sample (the reference returns
         # variable-length tensors too, model_nms_utils.py:20)
         if not no_nms:
-            keep_counts = torch.stack([st[8].sum() for st in staged]).tolist()
+            keep_counts = all_valid.sum(dim=1).tolist()
         # pass 2: variable-length records
         for index, (box_preds, src_box_preds, cls_preds, src_cls_preds, label_preds, sem_scores,
                     sem_scores_full, sel, valid) in enumerate(staged):

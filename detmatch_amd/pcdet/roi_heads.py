@@ -26,52 +26,23 @@ from .dense_heads import valid_gt_mask
 from .pfe import batch_row_counts
 
 
-def class_agnostic_nms_fixed(box_scores, box_preds, nms_config, score_thresh=None):
-    """model_nms_utils.py:6-26 with a fixed-size result: (selected (POST,) int64 padded with 0,
-    valid (POST,) bool).  No device->host copy."""
-    post = int(nms_config.NMS_POST_MAXSIZE)
-    n = box_scores.shape[0]
-    dev = box_scores.device
-    if n == 0:
-        return (torch.zeros((post,), dtype=torch.int64, device=dev),
-                torch.zeros((post,), dtype=torch.bool, device=dev))
-    scores = box_scores
-    if score_thresh is not None:  # below-threshold boxes sort last and are masked out
-        scores = torch.where(box_scores >= score_thresh, box_scores,
-                             box_scores.new_full((), -float('inf')))
-    k = min(int(nms_config.NMS_PRE_MAXSIZE), n)
-    top_scores, indices = torch.topk(scores, k=k)
-    boxes = box_preds[indices][:, 0:7].contiguous().float()
-    order = torch.sort(top_scores, dim=0, descending=True, stable=True)[1]
-    boxes = boxes[order].contiguous()
-    L = _lib.lib()
-    keep = torch.zeros((max(k, post),), dtype=torch.int64, device=dev)
-    num = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ws = _lib.workspace(L.dm_nms_workspace_bytes(k), dev, 'nms')
-    fn = L.dm_nms if nms_config.NMS_TYPE == 'nms_gpu' else L.dm_nms_normal
-    _lib.check(fn(_lib.ptr(boxes), k, float(nms_config.NMS_THRESH), post, _lib.ptr(keep),
-                  _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms')
-    slot = torch.arange(post, device=dev)
-    valid = slot < num.long()
-    sel = indices[order[keep[:post].clamp(0, k - 1)]]
-    if score_thresh is not None:
-        valid = valid & (box_scores[sel] >= score_thresh)
-    return torch.where(valid, sel, torch.zeros_like(sel)), valid
-
-
-def class_agnostic_nms_fixed_batch(box_scores, box_preds, nms_config):
-    """class_agnostic_nms_fixed for every sample of a batch with ONE top-k, sort and gather over the
-    (B, N) score matrix (the per-sample loop of roi_head_template.py:60-90 repeats the same ~50
-    launches per sample); the NMS itself stays one call per sample.  -> selected (B, POST) int64
-    padded with 0, valid (B, POST) bool."""
+def class_agnostic_nms_fixed_batch(box_scores, box_preds, nms_config, score_thresh=None):
+    """model_nms_utils.py:6-26 (class_agnostic_nms) for every sample of a batch with a fixed-size result
+    and no device->host copy: ONE top-k, sort and gather over the (B, N) score matrix (the per-sample
+    loops of roi_head_template.py:60-90 and detector3d_template.py:176-309 repeat the same ~50 launches
+    per sample); the NMS itself stays one call per sample.  -> selected (B, POST) int64 padded with 0,
+    valid (B, POST) bool."""
     post = int(nms_config.NMS_POST_MAXSIZE)
     bsz, n = box_scores.shape
     dev = box_scores.device
     if n == 0 or bsz == 0:
         return (torch.zeros((bsz, post), dtype=torch.int64, device=dev),
                 torch.zeros((bsz, post), dtype=torch.bool, device=dev))
+    scores = box_scores
+    if score_thresh is not None:  # below-threshold boxes sort last and are masked out
+        scores = torch.where(box_scores >= score_thresh, box_scores, box_scores.new_full((), -float('inf')))
     k = min(int(nms_config.NMS_PRE_MAXSIZE), n)
-    top_scores, indices = torch.topk(box_scores, k=k, dim=1)
+    top_scores, indices = torch.topk(scores, k=k, dim=1)
     order = torch.sort(top_scores, dim=1, descending=True, stable=True)[1]
     indices = torch.gather(indices, 1, order)                     # original index, NMS order
     boxes = torch.gather(box_preds[:, :, 0:7], 1, indices[:, :, None].expand(-1, -1, 7)).contiguous().float()
@@ -85,6 +56,8 @@ def class_agnostic_nms_fixed_batch(box_scores, box_preds, nms_config):
                       _lib.ptr(num[b:b + 1]), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms')
     valid = torch.arange(post, device=dev)[None, :] < num.long()[:, None]
     sel = torch.gather(indices, 1, keep[:, :post].clamp(0, k - 1))
+    if score_thresh is not None:
+        valid = valid & (torch.gather(box_scores, 1, sel) >= score_thresh)
     return torch.where(valid, sel, torch.zeros_like(sel)), valid
 
 
