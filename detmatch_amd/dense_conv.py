@@ -297,7 +297,7 @@ class _Conv2dFn(torch.autograd.Function):
         c4 = x.shape[1]
         T = kh * kw
         if relu:
-            dy = dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0)     # dy where y > 0 else 0, one launch
         if cout % 4:       # the kernels read rows of the gradient 16 bytes at a time
             raise _lib.DetMatchHipError('dense_conv: Cout must be a multiple of 4 (pad the layer)')
         dy = _cl(dy)
