@@ -5,6 +5,7 @@ Same names / argument meaning (`ball_query`, `grouping_operation`,
 `furthest_point_sample`, `QueryAndGroup`, `StackSAModuleMSG`); compute in
 libdetmatch_hip.so (pointnet2_stack.hip).
 """
+import weakref
 from typing import List
 
 import torch
@@ -248,6 +249,42 @@ def furthest_point_sample_stack(xyz, batch_cnt_host, npoint):
     return output
 
 
+class _PadXyzColumn(torch.autograd.Function):
+    """(Cout, 3 + C, 1, 1) first-layer weight of a shared MLP -> (Cout, 4 + C) with a zero column for the
+    padding float that follows xyz in a grouped row.  The padded copy is cached per parameter and
+    rewritten (two strided copies) only after the weight changed — in place (`_version`) or through the
+    raw pointers of the fused optimizer / EMA kernels (dense_conv.weights_changed) — instead of a
+    slice / zeros / cat chain per grouper and pass; the backward is one cat of the two column blocks."""
+
+    _cache = {}
+
+    @staticmethod
+    def forward(ctx, weight):
+        from . import dense_conv
+        w = weight.detach().view(weight.shape[0], weight.shape[1])
+        key = (id(weight), w.data_ptr())
+        hit = _PadXyzColumn._cache.get(key)
+        if hit is not None and hit[0]() is not weight:
+            hit = None
+        gen = dense_conv._GENERATION[0]
+        if hit is None:
+            if len(_PadXyzColumn._cache) > 512:
+                _PadXyzColumn._cache.clear()
+            buf = torch.zeros((w.shape[0], w.shape[1] + 1), dtype=w.dtype, device=w.device)
+            hit = [weakref.ref(weight), -1, -1, buf]
+            _PadXyzColumn._cache[key] = hit
+        if hit[1] != weight._version or dense_conv._stale(hit[2], w.data_ptr()):
+            hit[3][:, :3].copy_(w[:, :3])
+            hit[3][:, 4:].copy_(w[:, 3:])
+        hit[1], hit[2] = weight._version, gen
+        ctx.shape = tuple(weight.shape)
+        return hit[3].view(hit[3].shape)       # a fresh tensor object per call over the cached storage
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.cat([g[:, :3], g[:, 4:]], dim=1).view(ctx.shape)
+
+
 class StackSAModuleMSG(nn.Module):
     """pointnet2_modules.py:10-92: multi-scale grouping + shared MLP + max over samples."""
 
@@ -296,9 +333,10 @@ class StackSAModuleMSG(nn.Module):
                 x = rows.view(m * ns, width)
                 mods = list(self.mlps[k])
                 for li, (conv, bn) in enumerate(zip(mods[0::3], mods[1::3])):
-                    w = conv.weight.view(conv.out_channels, conv.in_channels)
                     if li == 0 and g.use_xyz:      # zero column for the padding float after xyz
-                        w = torch.cat([w[:, :3], w.new_zeros((w.shape[0], 1)), w[:, 3:]], dim=1)
+                        w = _PadXyzColumn.apply(conv.weight)
+                    else:
+                        w = conv.weight.view(conv.out_channels, conv.in_channels)
                     x = TallSkinnyLinear.apply(x, w)
                     if conv.bias is not None:
                         x = x + conv.bias
