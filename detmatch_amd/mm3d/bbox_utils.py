@@ -80,6 +80,18 @@ def apply_3d_transformation_bboxes(bbox, img_meta, reverse=False):
     return bbox
 
 
+def take(t, idx):
+    """t[idx] for a 1-D integer index tensor (or boolean mask) over dim 0, as index_select: the same
+    values, but the backward is zeros + index_add (2 launches) instead of the sort-based
+    index_put(accumulate=True) of advanced indexing (~8 launches) — the selections of the pseudo-label
+    glue carry gradients of a few dozen boxes."""
+    if not isinstance(t, torch.Tensor):        # box containers index their tensor the same way
+        return t[idx]
+    if idx.dtype == torch.bool:
+        idx = idx.nonzero(as_tuple=False).squeeze(1)
+    return t.index_select(0, idx)
+
+
 def compose_3d_transformation(img_meta, reverse=False):
     """The recorded 3D augmentations of a sample (what apply_3d_transformation_bboxes replays op by op)
     as ONE affine map of the box parameters: centre' = centre @ A + t, size' = s * size,
@@ -278,7 +290,7 @@ def nms_2d(boxes, scores, iou_threshold, max_num=-1):
                'dm_nms_2d')
     k = int(num.item())
     inds = order[keep[:k]]
-    return torch.cat([boxes[inds], scores[inds][:, None]], -1), inds
+    return torch.cat([take(boxes, inds), take(scores, inds)[:, None]], -1), inds
 
 
 def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
@@ -294,7 +306,7 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
         offsets = idxs.to(boxes) * (max_coordinate + 1)
         boxes_for_nms = boxes + offsets[:, None]
     dets, keep = nms_2d(boxes_for_nms, scores, thr)
-    return torch.cat([boxes[keep], dets[:, -1:]], -1), keep
+    return torch.cat([take(boxes, keep), dets[:, -1:]], -1), keep
 
 
 def modified_multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1):
@@ -313,14 +325,14 @@ def modified_multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_
     labels = labels.reshape(-1)
     valid_mask = scores > score_thr
     inds = valid_mask.nonzero(as_tuple=False).squeeze(1)
-    bboxes, scores, labels = bboxes[inds], scores[inds], labels[inds]
+    bboxes, scores, labels = take(bboxes, inds), take(scores, inds), take(labels, inds)
     if bboxes.numel() == 0:
         return torch.cat([bboxes, scores[:, None]], -1), labels, inds
     dets, keep = batched_nms(bboxes, scores, labels, nms_cfg)
     if max_num > 0:
         dets = dets[:max_num]
         keep = keep[:max_num]
-    return dets, labels[keep], inds[keep]
+    return dets, take(labels, keep), take(inds, keep)
 
 
 def filter_by_nms_2d(bbox_list, nms_cfg, use_sigmoid_cls, return_indices=False):
@@ -333,7 +345,7 @@ def filter_by_nms_2d(bbox_list, nms_cfg, use_sigmoid_cls, return_indices=False):
         if nms_pre > 0 and scores.shape[0] > nms_pre:
             max_scores = scores.max(dim=1)[0] if use_sigmoid_cls else scores[:, :-1].max(dim=1)[0]
             _, topk_inds = max_scores.topk(nms_pre)
-            bboxes, scores = bboxes[topk_inds, :], scores[topk_inds, :]
+            bboxes, scores = take(bboxes, topk_inds), take(scores, topk_inds)
         if use_sigmoid_cls:
             scores_for_nms = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
         else:
@@ -344,7 +356,7 @@ def filter_by_nms_2d(bbox_list, nms_cfg, use_sigmoid_cls, return_indices=False):
                                                     score_thr if score_thr is not None else 0, cfg,
                                                     nms_cfg.get('max_num', -1))
         sel_box = selected.long() // (scores_for_nms.shape[1] - 1)
-        res.append((dets[:, :4], scores[sel_box]))
+        res.append((dets[:, :4], take(scores, sel_box)))
     return res
 
 

@@ -156,7 +156,10 @@ class LiDARInstance3DBoxes(object):
         if isinstance(item, int):
             return LiDARInstance3DBoxes(self.tensor[item].view(1, -1), box_dim=self.box_dim,
                                         with_yaw=self.with_yaw)
-        b = self.tensor[item]
+        if isinstance(item, torch.Tensor) and item.dim() == 1 and item.dtype == torch.int64:
+            b = self.tensor.index_select(0, item)      # == tensor[item]; cheaper backward (bbox_utils.take)
+        else:
+            b = self.tensor[item]
         assert b.dim() == 2
         return LiDARInstance3DBoxes(b, box_dim=self.box_dim, with_yaw=self.with_yaw)
 

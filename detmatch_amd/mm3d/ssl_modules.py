@@ -11,7 +11,7 @@ import torch
 from torch.nn import functional as F
 
 from .bbox_utils import (apply_3d_transformation_bboxes, bbox_2d_transform, bbox_3d_to_bbox_2d,
-                         filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set, unaug_project_boxes)
+                         filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set, take, unaug_project_boxes)
 from ..devconst import const
 from ..fused import on as fused_on
 from .box3d import LiDARInstance3DBoxes
@@ -265,7 +265,8 @@ class Bboxes3DTo2D(object):
                 boxes3d = apply_3d_transformation_bboxes(boxes3d, meta, reverse=True)
                 boxes2d, valid = bbox_3d_to_bbox_2d(boxes3d, meta['lidar2img'], meta['ori_shape'])
             if self.filter_invalid:
-                boxes2d, rest = boxes2d[valid], [t[valid] for t in rest]
+                vi = valid.nonzero(as_tuple=False).squeeze(1)      # one mask -> index conversion
+                boxes2d, rest = take(boxes2d, vi), [take(t, vi) for t in rest]
             out.append(_join(boxes2d, rest, tup))
         mlvl_set(batch_dict, self.out_bboxes_key, out)
         return batch_dict
@@ -288,7 +289,8 @@ class MaxScoreFilter(object):
                 keep = torch.zeros((0,), dtype=torch.bool, device=scores.device)
             else:
                 keep = scores.max(dim=1)[0] > self.score_thr
-            out.append(tuple(t[keep] for t in entry))
+            ki = keep.nonzero(as_tuple=False).squeeze(1)
+            out.append(tuple(take(t, ki) for t in entry))
         mlvl_set(batch_dict, self.out_bboxes_key, out)
         return batch_dict
 
@@ -390,8 +392,8 @@ class FusionHungarianMatching(object):
         for e3, e2, meta in zip(mlvl_get(batch_dict, self.in_bboxes_3d_key),
                                 mlvl_get(batch_dict, self.in_bboxes_2d_key), metas):
             i3, i2, c = self.match(e3, e2, meta)
-            out3.append(tuple(t[i3] for t in e3))
-            out2.append(tuple(t[i2] for t in e2))
+            out3.append(tuple(take(t, i3) for t in e3))
+            out2.append(tuple(take(t, i2) for t in e2))
             costs.append(c)
         mlvl_set(batch_dict, self.out_bboxes_3d_key, out3)
         mlvl_set(batch_dict, self.out_bboxes_2d_key, out2)

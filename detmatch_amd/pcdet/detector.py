@@ -197,13 +197,15 @@ class PVRCNN(nn.Module):
                 selected_scores = cls_preds
             else:
                 selected = sel[:int(keep_counts[index])]
-                selected_scores = cls_preds[selected]
+                selected_scores = cls_preds.index_select(0, selected)
             if cfg.OUTPUT_RAW_SCORE:
-                selected_scores = torch.max(src_cls_preds, dim=-1)[0][selected]
-            record = {'pred_boxes': box_preds[selected], 'pred_scores': selected_scores,
-                      'pred_labels': label_preds[selected],
-                      'pred_sem_scores': torch.sigmoid(sem_scores[selected]),
-                      'pred_sem_scores_full': torch.sigmoid(sem_scores_full[selected])}
+                selected_scores = torch.max(src_cls_preds, dim=-1)[0].index_select(0, selected)
+            # index_select: same values as t[selected]; its backward is zeros + index_add instead of the
+            # sort-based index_put of advanced indexing (these carry the consistency losses' gradients)
+            record = {'pred_boxes': box_preds.index_select(0, selected), 'pred_scores': selected_scores,
+                      'pred_labels': label_preds.index_select(0, selected),
+                      'pred_sem_scores': torch.sigmoid(sem_scores.index_select(0, selected)),
+                      'pred_sem_scores_full': torch.sigmoid(sem_scores_full.index_select(0, selected))}
             pred_dicts.append(record)
             if self.record_recall:
                 recall_dict = self.generate_recall_record(
