@@ -96,10 +96,27 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
         data-dependent size read-backs (voxel count, N_out of the 4 strided rulebooks) happen at
         the step boundary and the passes themselves enqueue without stalling.  Must be called in
         the mode (train / eval) the pass will run in."""
-        res = self._base_batch(points, img_metas)
+        from ..spconv import ops as sp_ops
+        return sp_ops.drive_steps(self.prepare_geometry_steps(points, img_metas))
+
+    @torch.no_grad()
+    def prepare_geometry_steps(self, points, img_metas=None, ws_tag='rulebook'):
+        """prepare_geometry as a generator: yields each device scalar whose value the next launch needs
+        (the voxel count, then N_out of the four strided rulebooks) and is sent the value —
+        spconv/ops.py:drive_steps_together fetches those of all the passes of an iteration in one copy
+        per round.  `ws_tag`: rulebook workspace of this pass (interleaved builds must not share one)."""
+        max_voxels = self.voxel_layer.max_voxels[0 if self.training else 1]
+        pts = [p.float().contiguous() for p in points]
+        v, c, n, mean, counts = voxel.voxelize_batch(pts, self.voxel_layer.voxel_size,
+                                                     self.voxel_layer.point_cloud_range,
+                                                     self.voxel_layer.max_num_points, max_voxels,
+                                                     with_mean=True, sync=False)
+        total = yield counts[len(pts):len(pts) + 1]
+        res = self._fill_base_batch(points, img_metas, v[:total], n[:total], c[:total], mean[:total])
         bb = getattr(self.model, 'backbone_3d', None)
-        if bb is not None and hasattr(bb, 'build_rulebooks'):
-            res['indice_dict_prefetch'] = bb.build_rulebooks(res['voxel_coords'], res['batch_size'])
+        if bb is not None and hasattr(bb, 'build_rulebooks_steps'):
+            res['indice_dict_prefetch'] = yield from bb.build_rulebooks_steps(
+                res['voxel_coords'], res['batch_size'], ws_tag=ws_tag)
         stream = torch.cuda.current_stream(points[0].device) if points[0].is_cuda else None
         self._geom_cache[id(points)] = (points, self.training, res, stream)
 
@@ -115,6 +132,9 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
                 res['frame_id'] = np.array([m.get('sample_idx', i) for i, m in enumerate(img_metas)])
             return res
         voxels, num_points, coors, mean = self.voxelize(points, with_mean=True)
+        return self._fill_base_batch(points, img_metas, voxels, num_points, coors, mean)
+
+    def _fill_base_batch(self, points, img_metas, voxels, num_points, coors, mean):
         res = dict(batch_size=len(points), voxels=voxels, voxel_num_points=num_points,
                    voxel_coords=coors, voxel_features=mean)
         res['points'] = torch.cat([F.pad(p.float(), (1, 0), mode='constant', value=k)

@@ -638,10 +638,22 @@ class SSL(nn.Module):
                 return lanes.run_pair(m.m3, m.m2, self, d)
             return _run(m, d)
         # weight-independent geometry of every pass of the iteration, issued up front
+        jobs = []
         for chain, d in ((self.lab_ssl_modules, lab_dict), (self.unlab_ssl_modules, unlab_dict)):
             for m in chain:
-                if hasattr(m, 'prefetch'):
+                steps = None
+                if hasattr(m, 'prefetch_steps') and getattr(m.prefetch, '__func__', None) is \
+                        getattr(type(m), 'prefetch', None):
+                    steps = m.prefetch_steps(self, d, 'rulebook%d' % len(jobs))
+                if steps is not None:
+                    jobs.append(steps)
+                elif hasattr(m, 'prefetch'):
                     m.prefetch(self, d)
+        if jobs:
+            # the passes' size read-backs (voxel count, N_out of the four strided rulebooks) in lockstep:
+            # one device->host copy per round for all of them
+            from ..spconv.ops import drive_steps_together
+            drive_steps_together(jobs)
         if lanes is not None:
             lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
         unlab_modules = list(self.unlab_ssl_modules)

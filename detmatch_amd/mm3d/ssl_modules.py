@@ -100,6 +100,14 @@ class Opd_SimpleTest_3D(object):
         if hasattr(detector, 'prepare_geometry'):
             detector.prepare_geometry(cur['points'], cur['img_metas'])
 
+    def prefetch_steps(self, ssl_obj, batch_dict, ws_tag):
+        """prefetch as a generator (OpenPCDetDetector.prepare_geometry_steps), or None."""
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        if hasattr(detector, 'prepare_geometry_steps'):
+            return detector.prepare_geometry_steps(cur['points'], cur['img_metas'], ws_tag)
+        return None
+
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
         cur = mlvl_get(batch_dict, self.batch_dict_key)
@@ -136,6 +144,13 @@ class Opd_HardPseudoLabel_3D(object):
         cur = mlvl_get(batch_dict, self.target_batch_dict_key)
         if hasattr(detector, 'prepare_geometry'):
             detector.prepare_geometry(cur['points'], cur['img_metas'])
+
+    def prefetch_steps(self, ssl_obj, batch_dict, ws_tag):
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.target_batch_dict_key)
+        if hasattr(detector, 'prepare_geometry_steps'):
+            return detector.prepare_geometry_steps(cur['points'], cur['img_metas'], ws_tag)
+        return None
 
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
@@ -174,6 +189,14 @@ class Opd_Supervised_3D(object):
         cur = mlvl_get(batch_dict, self.batch_dict_key)
         if hasattr(detector, 'prepare_geometry'):
             detector.prepare_geometry(cur['points'], cur['img_metas'])
+
+    def prefetch_steps(self, ssl_obj, batch_dict, ws_tag):
+        """prefetch as a generator (OpenPCDetDetector.prepare_geometry_steps), or None."""
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        if hasattr(detector, 'prepare_geometry_steps'):
+            return detector.prepare_geometry_steps(cur['points'], cur['img_metas'], ws_tag)
+        return None
 
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)

@@ -109,6 +109,12 @@ class VoxelBackBone8x(nn.Module):
         depend on the weights): {indice_key: (outids, in_indices, indice_pairs, indice_num, shape)},
         the cache format of SparseConvolution.forward (spconv/conv.py:146-172)."""
         from ..spconv import ops as sp_ops
+        return sp_ops.drive_steps(self.build_rulebooks_steps(voxel_coords, batch_size))
+
+    def build_rulebooks_steps(self, voxel_coords, batch_size, ws_tag='rulebook'):
+        """build_rulebooks as a generator that yields the four N_out device scalars it needs
+        (spconv/ops.py:drive_steps_together reads those of several passes back in one copy)."""
+        from ..spconv import ops as sp_ops
         from ..spconv.conv import SparseConvolution
         indice_dict = {}
         indices, shape = voxel_coords.int(), list(self.sparse_shape)
@@ -118,9 +124,9 @@ class VoxelBackBone8x(nn.Module):
             out_shape = shape if m.subm else sp_ops.get_conv_output_size(
                 shape, m.kernel_size, m.stride, m.padding, m.dilation)
             if m.indice_key not in indice_dict:
-                outids, pairs, num = sp_ops.get_indice_pairs(
+                outids, pairs, num = yield from sp_ops.get_indice_pairs_steps(
                     indices, batch_size, shape, m.kernel_size, m.stride, m.padding, m.dilation,
-                    m.output_padding, m.subm, m.transposed)
+                    m.output_padding, m.subm, m.transposed, ws_tag=ws_tag)
                 indice_dict[m.indice_key] = (outids, indices, pairs, num, shape)
             indices, shape = indice_dict[m.indice_key][0], out_shape
         return indice_dict

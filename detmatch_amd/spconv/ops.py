@@ -33,6 +33,50 @@ def _norm(v, ndim):
 def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
                    subm=False, with_pairs=True):
     """Native rulebook build.  indices (N,4) int32 [b,z,y,x] on the GPU."""
+    return drive_steps(build_rulebook_steps(indices, batch_size, spatial_shape, ksize, stride, padding,
+                                            dilation, subm, with_pairs))
+
+
+def drive_steps(gen):
+    """Run a `*_steps` generator on its own: every value it asks for is read back right away."""
+    try:
+        ask = next(gen)
+        while True:
+            ask = gen.send(int(ask.item()))
+    except StopIteration as stop:
+        return stop.value
+
+
+def drive_steps_together(gens):
+    """Run several `*_steps` generators in lockstep: the device scalars they ask for in the same round
+    (voxel counts, N_out of a strided rulebook) come back in ONE device->host copy — three passes of an
+    iteration cost 5 read-backs at the step boundary instead of 15.  -> list of their return values."""
+    results = [None] * len(gens)
+    asks = {}
+    for i, g in enumerate(gens):
+        try:
+            asks[i] = next(g)
+        except StopIteration as stop:
+            results[i] = stop.value
+    while asks:
+        order = sorted(asks)
+        vals = torch.cat([asks[i].reshape(1) for i in order]).tolist()
+        nxt = {}
+        for i, v in zip(order, vals):
+            try:
+                nxt[i] = gens[i].send(int(v))
+            except StopIteration as stop:
+                results[i] = stop.value
+        asks = nxt
+    return results
+
+
+def build_rulebook_steps(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                         subm=False, with_pairs=True, ws_tag='rulebook'):
+    """build_rulebook as a generator: yields the device scalar whose value it needs next (N_out of a
+    strided layer) and is sent that value; returns the Rulebook.  `ws_tag` names the workspace — the
+    count and fill kernels of a strided layer share hash tables in it, so builds that are interleaved
+    (drive_steps_together) must not share one."""
     ndim = indices.shape[1] - 1
     if ndim != 3:
         raise NotImplementedError('only 3-D sparse convolution is on the DetMatch path')
@@ -50,7 +94,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
     rb = Rulebook()
     rb.subm, rb.kvol, rb.n_in = bool(subm), kvol, n
     wsb = L.dm_rulebook_workspace_bytes(n, kvol)
-    ws = _lib.workspace(wsb, dev, 'rulebook')
+    ws = _lib.workspace(wsb, dev, ws_tag)
     rb.indice_num = torch.empty((kvol,), dtype=torch.int32, device=dev)
     rb.indice_pairs = (torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
                        if with_pairs else None)
@@ -76,7 +120,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
     _lib.check(rc, 'dm_rulebook_conv_count')
     # the one data-dependent size of the layer (reference: outInds.slice(0, 0, numActOut),
     # spconv_ops.h:139, which also costs a device->host read)
-    n_out = int(n_out_dev.item())
+    n_out = yield n_out_dev
     rb.n_out = n_out
     rb.outids = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
     rb.nbr_out = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
@@ -86,6 +130,17 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
                                  _lib.ptr(rb.indice_num), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, 'dm_rulebook_conv_fill')
     return rb
+
+
+def get_indice_pairs_steps(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                           out_padding=0, subm=False, transpose=False, grid=None, ws_tag='rulebook'):
+    """get_indice_pairs as a generator (see build_rulebook_steps)."""
+    if transpose:
+        raise NotImplementedError('transposed sparse conv is off the DetMatch hot path')
+    rb = yield from build_rulebook_steps(indices, batch_size, spatial_shape, ksize, stride, padding,
+                                         dilation, subm, ws_tag=ws_tag)
+    rb.indice_pairs.dm_tables = (rb.nbr_out, rb.nbr_in, rb.subm)
+    return rb.outids, rb.indice_pairs, rb.indice_num
 
 
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
