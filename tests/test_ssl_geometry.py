@@ -102,3 +102,57 @@ def test_mm3d_pcdet_conversion_keeps_the_box_geometry():
     back = pcdet_to_mm3d_boxes(pc)
     np.testing.assert_allclose(srt(back.corners), srt(mm.corners), atol=2e-3)
     assert float(pc[:, 6].min()) >= -np.pi - 1e-5 and float(pc[:, 6].max()) < np.pi + 1e-5   # limit_period(., .5, 2 pi)
+
+
+def test_composed_3d_transformation_is_the_replayed_ops():
+    """compose_3d_transformation (the affine map the device projection kernel takes) applied with numpy
+    == the REFERENCE's op-by-op replay (goldens of apply_3d_transformation_bboxes), both directions,
+    plus every flow order / flip combination against the replay itself."""
+    from detmatch_amd.mm3d.bbox_utils import apply_3d_transformation_bboxes, compose_3d_transformation
+    from detmatch_amd.mm3d.box3d import LiDARInstance3DBoxes
+
+    def apply(boxes, meta, reverse):
+        A, t, s, sigma, off = compose_3d_transformation(meta, reverse=reverse)
+        out = boxes.astype(np.float64).copy()
+        out[:, :3] = out[:, :3] @ A + t
+        out[:, 3:6] *= s
+        out[:, 6] = sigma * out[:, 6] + off
+        return out
+
+    meta = dict(pcd_rotation=torch.from_numpy(G['meta_rotation']),
+                pcd_scale_factor=float(G['meta_scale']), pcd_trans=G['meta_trans'],
+                pcd_horizontal_flip=True, pcd_vertical_flip=False,
+                transformation_3d_flow=['HF', 'R', 'S', 'T'])
+    np.testing.assert_allclose(apply(G['boxes'], meta, False), G['aug_forward'], **TOL)
+    np.testing.assert_allclose(apply(G['aug_forward'], meta, True), G['aug_roundtrip'], **TOL)
+    rng = np.random.default_rng(0)
+    for flow, hf, vf in ((['T', 'S', 'R', 'VF', 'HF'], True, True), (['R', 'VF'], False, True),
+                         (['HF', 'VF', 'R', 'S', 'T'], True, False), ([], False, False), (['S'], False, False)):
+        ang = rng.uniform(-0.7, 0.7)
+        m = dict(pcd_rotation=torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0],
+                                            [0, 0, 1]], dtype=torch.float32),
+                 pcd_scale_factor=float(rng.uniform(0.9, 1.1)), pcd_trans=rng.normal(0, 0.3, 3).astype(np.float32),
+                 pcd_horizontal_flip=hf, pcd_vertical_flip=vf, transformation_3d_flow=flow)
+        for reverse in (False, True):
+            want = apply_3d_transformation_bboxes(LiDARInstance3DBoxes(torch.from_numpy(G['boxes'])), m,
+                                                  reverse=reverse).tensor.numpy()
+            np.testing.assert_allclose(apply(G['boxes'], m, reverse), want, **TOL)
+
+
+def test_step_generators_are_driven_in_lockstep():
+    """spconv.ops.drive_steps_together: every round's device scalars come back in one copy, each generator
+    is sent its own value and their return values keep the job order; drive_steps runs one alone."""
+    from detmatch_amd.spconv.ops import drive_steps, drive_steps_together
+    log = []
+
+    def job(name, asks):
+        got = []
+        for a in asks:
+            log.append((name, a))
+            got.append((yield torch.tensor([a], dtype=torch.int32)))
+        return name, got
+
+    res = drive_steps_together([job('a', [3, 5, 7]), job('b', [11]), job('c', []), job('d', [2, 4])])
+    assert res == [('a', [3, 5, 7]), ('b', [11]), ('c', []), ('d', [2, 4])]
+    assert log == [('a', 3), ('b', 11), ('d', 2), ('a', 5), ('d', 4), ('a', 7)]      # round by round
+    assert drive_steps(job('e', [9, 8])) == ('e', [9, 8])

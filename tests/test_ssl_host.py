@@ -397,3 +397,38 @@ def test_training_mode_shortcut_is_only_taken_in_the_steady_state():
     model.eval()
     R._ensure_train_mode(model)
     assert calls == [True, True, False, True] and model.training          # eval() itself is train(False)
+
+
+def test_rng_windows_make_draws_independent_of_module_order():
+    """ssl._RngWindows on a generator with Philox offsets: module i always draws from offset
+    base + (i + 1) * 2^32, whatever was drawn before, and the iteration ends at base + (n + 1) * 2^32."""
+    import torch
+    from detmatch_amd.mm3d import ssl
+
+    class Gen(object):                     # stands in for the device generator (CPU has no offsets)
+        def __init__(self):
+            self.off = 40
+
+        def get_offset(self):
+            return self.off
+
+        def set_offset(self, v):
+            self.off = v
+
+    mods = [object(), object(), object()]
+    w = ssl._RngWindows(torch.device('cpu'), mods)
+    assert w.gen is None and w.offset() is None        # CPU: a no-op
+    w.gen, w.base = Gen(), 40
+    W = ssl._RngWindows.WINDOW
+    w.enter(mods[2])
+    assert w.gen.off == 40 + 3 * W
+    w.gen.off += 12                                    # module 2 drew something
+    saved = w.offset()
+    w.enter(mods[0])                                   # a module issued from inside another one
+    assert w.gen.off == 40 + 1 * W
+    w.restore(saved)
+    assert w.gen.off == 40 + 3 * W + 12
+    w.enter(object())                                  # unknown module: untouched
+    assert w.gen.off == 40 + 3 * W + 12
+    w.finish()
+    assert w.gen.off == 40 + 4 * W
