@@ -8,7 +8,6 @@ files load unchanged (tests/test_ssl_config.py).
 """
 import numpy as np
 import torch
-from torch.nn import functional as F
 
 from .bbox_utils import (apply_3d_transformation_bboxes, bbox_2d_transform, bbox_3d_to_bbox_2d,
                          filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set, take, unaug_project_boxes)

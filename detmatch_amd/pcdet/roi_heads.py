@@ -304,7 +304,6 @@ class PVRCNNHead(nn.Module):
     # ---- proposals ------------------------------------------------------------
     def proposal_layer(self, batch_dict, nms_config):
         """roi_head_template.py:46-102"""
-        batch_size = batch_dict['batch_size']
         batch_box_preds = batch_dict['batch_box_preds']
         batch_cls_preds = batch_dict['batch_cls_preds']
         assert batch_cls_preds.dim() == 3 and not nms_config.MULTI_CLASSES_NMS
