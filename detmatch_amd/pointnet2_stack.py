@@ -34,15 +34,16 @@ class BallQuery(Function):
         _lib.require_device(xyz, new_xyz, xyz_batch_cnt, new_xyz_batch_cnt)
         B = xyz_batch_cnt.shape[0]
         M = new_xyz.shape[0]
-        idx = torch.zeros((M, nsample), dtype=torch.int32, device=xyz.device)
-        empty = torch.zeros((M,), dtype=torch.uint8, device=xyz.device)
+        # the kernel writes all nsample slots and the empty flag (one byte, 0 / 1) of every query
+        idx = torch.empty((M, nsample), dtype=torch.int32, device=xyz.device)
+        empty = torch.empty((M,), dtype=torch.bool, device=xyz.device)
         rc = _lib.lib().dm_ball_query_stack(B, M, float(radius), int(nsample), _lib.ptr(new_xyz),
                                             _lib.ptr(new_xyz_batch_cnt), _lib.ptr(xyz),
                                             _lib.ptr(xyz_batch_cnt), int(max_m_per_sample),
                                             _lib.ptr(idx), _lib.ptr(empty), _lib.stream())
         _lib.check(rc, 'dm_ball_query_stack')
-        ctx.mark_non_differentiable(idx)
-        return idx, empty.bool()
+        ctx.mark_non_differentiable(idx, empty)
+        return idx, empty
 
     @staticmethod
     def backward(ctx, a=None, b=None):

@@ -2,9 +2,10 @@
 record_function ranges around every SSL module, every stage of the 3D / 2D detectors, backward and
 the optimizer; prints launches and device time per range (inclusive).
 
-    python tools/launch_census.py [detmatch|pvrcnn|confthr]
+    python tools/launch_census.py [detmatch|pvrcnn|confthr] [kernel-name regex: count only those]
 """
 import collections
+import re
 import sys
 
 import torch
@@ -73,8 +74,11 @@ def main():
         torch.cuda.synchronize()
     agg = collections.OrderedDict()
 
+    pat = re.compile(sys.argv[2]) if len(sys.argv) > 2 else None
+
     def walk(e):
-        n, t = len(e.kernels), sum(k.duration for k in e.kernels)
+        ks = [k for k in e.kernels if pat is None or pat.search(k.name)]
+        n, t = len(ks), sum(k.duration for k in ks)
         for c in e.cpu_children:
             cn, ct = walk(c)
             n, t = n + cn, t + ct
