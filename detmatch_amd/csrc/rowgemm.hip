@@ -1,0 +1,155 @@
+// Y (R x N) = X (R x K) . W^T for R in the hundreds of thousands and K, N <= 136: the shared 1x1 layers of
+// RoI-grid pooling and the set abstraction (pcdet/ops/pointnet2/pointnet2_stack/pointnet2_modules.py:31-40,
+// Conv2d 1x1 over M * nsample grouped rows) and their input gradients.
+//
+// A BLAS call (and the K-tiled implicit-GEMM kernel of conv2d.hip) re-stages the K x N weights for every
+// 64-row tile and pays a prologue / epilogue per tile: 281 / 139 us for 884 736 x 132 / 64 -> 64 against
+// an fp32-MFMA floor of ~120 / 60 us.  Here a workgroup keeps ALL of W in LDS, walks row tiles of 64
+// (persistent: grid = 2 workgroups per CU), fetches the next tile's rows into registers while the
+// current one is multiplied (v_mfma_f32_32x32x2_f32, 2 x 2 waves, the k order inside an 8-block permuted
+// identically for both operands as in conv2d.hip), and writes the tile back through LDS as whole rows.
+#include <hip/hip_runtime.h>
+
+#include "../../include/detmatch_hip.h"
+#include "dm_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RG_ROWS = 64;       // rows per tile
+constexpr int RG_MAXK = 136;      // K padded to a multiple of 8
+constexpr int RG_MAXLD = RG_MAXK + 4;
+
+// NBW: 32-column blocks per wave (the two column-waves interleave blocks: wn, wn + 2, wn + 4)
+template <int NBW>
+__global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                      float *__restrict__ Y, int R, int K, int N, int KP) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int ld = KP + 4;                         // row stride of both operand tiles (floats)
+  float *Ws = lds;                               // [NBW * 64][ld]   (row n: W[n][0..K), zero padded)
+  float *Xs = lds + NBW * 64 * ld;               // [64][ld]; reused as the output tile [64][ldc]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int kq4 = KP / 4;                        // float4 per staged row
+  // ---- stage W once (rows >= N and columns >= K are zero) ------------------------------------
+  for (int e = tid; e < NBW * 64 * kq4; e += 256) {
+    const int n = e / kq4, q = e - n * kq4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+      const float *src = W + (size_t)n * K + 4 * q;
+      if (4 * q + 3 < K) v = *(const float4 *)src;
+      else if (4 * q < K) {                      // K % 4 == 0: never partial, kept for safety
+        v.x = src[0];
+      }
+    }
+    *(float4 *)(Ws + n * ld + 4 * q) = v;
+  }
+  const int n_tiles = (R + RG_ROWS - 1) / RG_ROWS;
+  constexpr int XP = (RG_ROWS * (RG_MAXK / 4) + 255) / 256;   // float4 fetches per thread and tile (max)
+  float4 xr[XP];
+  auto fetch = [&](int tile) {
+    const int row0 = tile * RG_ROWS;
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int e = p * 256 + tid;
+      const int r = e / kq4, q = e - r * kq4;
+      const int row = row0 + r;
+      const bool ok = r < RG_ROWS && row < R && 4 * q < K;
+      // unconditional load from a clamped address, masked afterwards (a conditional load serialises)
+      const float4 v = *(const float4 *)(X + (ok ? (size_t)row * K + 4 * q : 0));
+      xr[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int e = p * 256 + tid;
+      const int r = e / kq4, q = e - r * kq4;
+      if (r < RG_ROWS) *(float4 *)(Xs + r * ld + 4 * q) = xr[p];
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile);
+  const int ldc = NBW * 64 + 4;
+  for (; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();                              // previous tile's output rows have left Xs
+    stage();
+    __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);   // in flight under the MFMAs
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const float *As = Xs + (wm * 32 + lr) * ld + lh * 4;
+    const float *Bs = Ws + (wn * 32 + lr) * ld + lh * 4;
+    for (int kb = 0; kb < KP / 8; ++kb) {
+      const float4 a = *(const float4 *)(As + kb * 8);
+#pragma unroll
+      for (int b = 0; b < NBW; ++b) {
+        const float4 w = *(const float4 *)(Bs + b * 64 * ld + kb * 8);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc[b], 0, 0, 0);
+      }
+    }
+    __syncthreads();                              // every wave is done with Xs
+    // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float *cs = Xs;
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ldc + (wn + 2 * b) * 32 + lr] = acc[b][r];
+    __syncthreads();
+    const int nq = N / 4;                         // float4 per output row
+    const int row0 = tile * RG_ROWS;
+    for (int e = tid; e < RG_ROWS * nq; e += 256) {
+      const int r = e / nq, q = e - r * nq;
+      if (row0 + r < R) *(float4 *)(Y + (size_t)(row0 + r) * N + 4 * q) = *(const float4 *)(cs + r * ldc + 4 * q);
+    }
+  }
+}
+
+template <int NBW>
+int launch(const float *X, const float *W, float *Y, int R, int K, int N, hipStream_t st) {
+  const int KP = (K + 7) / 8 * 8;
+  const int ld = KP + 4, ldc = NBW * 64 + 4;
+  const int xs = 64 * (ld > ldc ? ld : ldc);
+  const size_t smem = ((size_t)NBW * 64 * ld + xs) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    DM_HIP(hipFuncSetAttribute((const void *)rowgemm_kernel<NBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    attr = true;
+  }
+  if (smem > 160 * 1024) return DM_ERR_UNSUPPORTED;
+  const int n_tiles = (R + RG_ROWS - 1) / RG_ROWS;
+  int per_cu = (int)((150 * 1024) / smem);       // workgroups resident per CU (LDS bound)
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+  const int grid = n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu;
+  rowgemm_kernel<NBW><<<grid, 256, smem, st>>>(X, W, Y, R, K, N, KP);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" int dm_rowgemm_supported(int k, int n) {
+  return k >= 4 && k <= RG_MAXK && (k & 3) == 0 && n >= 4 && n <= 192 && (n & 3) == 0;
+}
+
+extern "C" int dm_rowgemm(const float *x, const float *w, float *y, long long rows, int k, int n,
+                          dm_stream_t stream) {
+  if (rows < 0 || rows > 0x7fffffffLL / 256) return DM_ERR_INT32_RANGE;
+  if (!dm_rowgemm_supported(k, n)) return DM_ERR_UNSUPPORTED;
+  if (rows == 0) return DM_OK;
+  if (!x || !w || !y) return DM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 64) return launch<1>(x, w, y, (int)rows, k, n, st);
+  if (n <= 128) return launch<2>(x, w, y, (int)rows, k, n, st);
+  return launch<3>(x, w, y, (int)rows, k, n, st);
+}

@@ -5,6 +5,7 @@ Same names / argument meaning (`ball_query`, `grouping_operation`,
 `furthest_point_sample`, `QueryAndGroup`, `StackSAModuleMSG`); compute in
 libdetmatch_hip.so (pointnet2_stack.hip).
 """
+import os
 import weakref
 from typing import List
 
@@ -174,15 +175,38 @@ class TallSkinnyLinear(Function):
     weight gradient dW = dy^T x contracts over R, a shape (64 x 131 x 884736) a single GEMM launch
     fills the chip poorly with: it is computed split-K as one batched GEMM over row chunks + a sum."""
 
+    ROWGEMM_MIN_ROWS = 262144      # below this a launch is latency sized and BLAS is as good
+
+    @staticmethod
+    def _rowgemm(x, w):
+        """x (R, K) . w (N, K)^T on csrc/rowgemm.hip (weights resident in LDS), or None if not taken."""
+        if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
+                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and os.environ.get('DM_ROWGEMM', '1') == '1'):
+            return None
+        L = _lib.lib()
+        r, k = x.shape
+        n = w.shape[0]
+        if not L.dm_rowgemm_supported(k, n):
+            return None
+        x, w = x.contiguous(), w.contiguous()
+        y = torch.empty((r, n), dtype=torch.float32, device=x.device)
+        _lib.check(L.dm_rowgemm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), r, k, n, _lib.stream()), 'dm_rowgemm')
+        return y
+
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return x @ w.t()
+        y = TallSkinnyLinear._rowgemm(x, w)
+        return y if y is not None else x @ w.t()
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = TallSkinnyLinear._rowgemm(gy, w.t())
+            if gx is None:
+                gx = gy @ w
         gw = None
         if ctx.needs_input_grad[1]:
             rows = x.shape[0]

@@ -307,6 +307,12 @@ int dm_bbox2d_transform(const float *boxes_or_grad, int n, float scale_x, float 
                         float crop_y, float img_w, int flip, int ori2new, int backward, float *out,
                         dm_stream_t stream);
 
+/* y (rows, n) = x (rows, k) . w^T, w (n, k) row-major as an nn.Linear / 1x1-conv weight — the shared MLP
+ * layers over grouped rows (pointnet2_modules.py:31-40) and their input gradients (pass w^T).
+ * k, n multiples of 4, k <= 136, n <= 192; fp32 MFMA, weights resident in LDS. */
+int dm_rowgemm_supported(int k, int n);
+int dm_rowgemm(const float *x, const float *w, float *y, long long rows, int k, int n, dm_stream_t stream);
+
 /* Anchor-head box decoding: AnchorHeadTemplate.generate_predicted_boxes
  * (pcdet/models/dense_heads/anchor_head_template.py:225-272) = ResidualCoder.decode_torch
  * (pcdet/utils/box_coder_utils.py:43-76) + direction-bin correction (common_utils.limit_period).

@@ -44,8 +44,14 @@ def main():
         g4 = gy.view(1, r, 1, n).permute(0, 3, 1, 2)
         w4.requires_grad_(False)
         cv_d = t(lambda: torch.autograd.grad(y, xg, g4, retain_graph=True))
+        from detmatch_amd.pointnet2_stack import TallSkinnyLinear
+        TallSkinnyLinear.ROWGEMM_MIN_ROWS = 0
+        wt = w.t().contiguous()
+        rg_f = t(lambda: TallSkinnyLinear._rowgemm(x, w))
+        rg_d = t(lambda: TallSkinnyLinear._rowgemm(gy, wt))
+        err = float((TallSkinnyLinear._rowgemm(x, w) - x @ w.t()).abs().max())
         floor = r * (k + n) * 4 / 7.3e12 * 1e6
-        print('%8d x %3d -> %3d | %9.1f %9.1f | %9.1f %9.1f | %7.1f' % (r, k, n, mm_f, cv_f, mm_d, cv_d, floor))
+        print('%8d x %3d -> %3d | %9.1f %9.1f | %9.1f %9.1f | %7.1f | rowgemm fwd %7.1f dgrad %7.1f  err %.1e' % (r, k, n, mm_f, cv_f, mm_d, cv_d, floor, rg_f, rg_d, err))
 
 
 if __name__ == '__main__':
