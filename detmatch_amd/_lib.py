@@ -59,6 +59,7 @@ SIGNATURES = {
     'dm_bbox2d_transform': (ci, [vp, ci, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp]),
     'dm_rowgemm_supported': (ci, [ci, ci]),
     'dm_rowgemm': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, vp]),
+    'dm_rowgemm_strided': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, ci, ci, vp]),
     'dm_anchor_decode': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, cf, cf, cf, vp, vp]),
     'dm_bn_rows_workspace_bytes': (sz, [ctypes.c_longlong, ci]),
     'dm_bn_rows_forward': (ci, [vp, ctypes.c_longlong, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, vp]),

@@ -7,7 +7,11 @@
 // an fp32-MFMA floor of ~120 / 60 us.  Here a workgroup keeps ALL of W in LDS, walks row tiles of 64
 // (persistent: grid = 2 workgroups per CU), fetches the next tile's rows into registers while the
 // current one is multiplied (v_mfma_f32_32x32x2_f32, 2 x 2 waves, the k order inside an 8-block permuted
-// identically for both operands as in conv2d.hip), and writes the tile back through LDS as whole rows.
+// identically for both operands as in conv2d.hip), and writes the tile back through LDS as whole rows
+// (accumulators stored straight from the MFMA layout were measured 1.5x slower here, as in conv2d.hip;
+// weights in registers instead of LDS: 5 % faster, not kept).  Output rows may be wider than N (`ldy`)
+// and start at column `col0` (columns [0, col0) are written as zeros): the input gradient of a first
+// layer skips the xyz / padding columns nobody differentiates (QueryGroupRows.backward).
 #include <hip/hip_runtime.h>
 
 #include "../../include/detmatch_hip.h"
@@ -24,7 +28,8 @@ constexpr int RG_MAXLD = RG_MAXK + 4;
 // NBW: 32-column blocks per wave (the two column-waves interleave blocks: wn, wn + 2, wn + 4)
 template <int NBW>
 __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ X, const float *__restrict__ W,
-                                                      float *__restrict__ Y, int R, int K, int N, int KP) {
+                                                      float *__restrict__ Y, int R, int K, int N, int KP,
+                                                      int ldy, int col0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int ld = KP + 4;                         // row stride of both operand tiles (floats)
   float *Ws = lds;                               // [NBW * 64][ld]   (row n: W[n][0..K), zero padded)
@@ -105,17 +110,21 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
       for (int r = 0; r < 16; ++r)
         cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ldc + (wn + 2 * b) * 32 + lr] = acc[b][r];
     __syncthreads();
-    const int nq = N / 4;                         // float4 per output row
+    // output rows are `ldy` floats wide and start at column col0; columns [0, col0) are zeros
+    const int nq = N / 4, cq = col0 / 4;
     const int row0 = tile * RG_ROWS;
-    for (int e = tid; e < RG_ROWS * nq; e += 256) {
-      const int r = e / nq, q = e - r * nq;
-      if (row0 + r < R) *(float4 *)(Y + (size_t)(row0 + r) * N + 4 * q) = *(const float4 *)(cs + r * ldc + 4 * q);
+    for (int e = tid; e < RG_ROWS * (nq + cq); e += 256) {
+      const int r = e / (nq + cq), q = e - r * (nq + cq);
+      if (row0 + r >= R) continue;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q >= cq) v = *(const float4 *)(cs + r * ldc + 4 * (q - cq));
+      *(float4 *)(Y + (size_t)(row0 + r) * ldy + 4 * q) = v;
     }
   }
 }
 
 template <int NBW>
-int launch(const float *X, const float *W, float *Y, int R, int K, int N, hipStream_t st) {
+int launch(const float *X, const float *W, float *Y, int R, int K, int N, int ldy, int col0, hipStream_t st) {
   const int KP = (K + 7) / 8 * 8;
   const int ld = KP + 4, ldc = NBW * 64 + 4;
   const int xs = 64 * (ld > ldc ? ld : ldc);
@@ -131,7 +140,7 @@ int launch(const float *X, const float *W, float *Y, int R, int K, int N, hipStr
   int per_cu = (int)((150 * 1024) / smem);       // workgroups resident per CU (LDS bound)
   per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
   const int grid = n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu;
-  rowgemm_kernel<NBW><<<grid, 256, smem, st>>>(X, W, Y, R, K, N, KP);
+  rowgemm_kernel<NBW><<<grid, 256, smem, st>>>(X, W, Y, R, K, N, KP, ldy, col0);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -142,14 +151,20 @@ extern "C" int dm_rowgemm_supported(int k, int n) {
   return k >= 4 && k <= RG_MAXK && (k & 3) == 0 && n >= 4 && n <= 192 && (n & 3) == 0;
 }
 
-extern "C" int dm_rowgemm(const float *x, const float *w, float *y, long long rows, int k, int n,
-                          dm_stream_t stream) {
+extern "C" int dm_rowgemm_strided(const float *x, const float *w, float *y, long long rows, int k, int n,
+                                  int ldy, int col0, dm_stream_t stream) {
   if (rows < 0 || rows > 0x7fffffffLL / 256) return DM_ERR_INT32_RANGE;
-  if (!dm_rowgemm_supported(k, n)) return DM_ERR_UNSUPPORTED;
+  if (!dm_rowgemm_supported(k, n) || (ldy & 3) || (col0 & 3) || col0 < 0 || ldy < col0 + n)
+    return DM_ERR_UNSUPPORTED;
   if (rows == 0) return DM_OK;
   if (!x || !w || !y) return DM_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (n <= 64) return launch<1>(x, w, y, (int)rows, k, n, st);
-  if (n <= 128) return launch<2>(x, w, y, (int)rows, k, n, st);
-  return launch<3>(x, w, y, (int)rows, k, n, st);
+  if (n <= 64) return launch<1>(x, w, y, (int)rows, k, n, ldy, col0, st);
+  if (n <= 128) return launch<2>(x, w, y, (int)rows, k, n, ldy, col0, st);
+  return launch<3>(x, w, y, (int)rows, k, n, ldy, col0, st);
+}
+
+extern "C" int dm_rowgemm(const float *x, const float *w, float *y, long long rows, int k, int n,
+                          dm_stream_t stream) {
+  return dm_rowgemm_strided(x, w, y, rows, k, n, n, 0, stream);
 }

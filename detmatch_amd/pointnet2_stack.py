@@ -178,24 +178,30 @@ class TallSkinnyLinear(Function):
     ROWGEMM_MIN_ROWS = 262144      # below this a launch is latency sized and BLAS is as good
 
     @staticmethod
-    def _rowgemm(x, w):
-        """x (R, K) . w (N, K)^T on csrc/rowgemm.hip (weights resident in LDS), or None if not taken."""
+    def _rowgemm(x, w, col0=0):
+        """x (R, K) . w (N, K)^T on csrc/rowgemm.hip (weights resident in LDS), or None if not taken.
+        col0 > 0: the result has col0 leading zero columns (rows of col0 + N floats)."""
         if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
                 and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and os.environ.get('DM_ROWGEMM', '1') == '1'):
             return None
         L = _lib.lib()
         r, k = x.shape
         n = w.shape[0]
-        if not L.dm_rowgemm_supported(k, n):
+        if not L.dm_rowgemm_supported(k, n) or col0 % 4:
             return None
         x, w = x.contiguous(), w.contiguous()
-        y = torch.empty((r, n), dtype=torch.float32, device=x.device)
-        _lib.check(L.dm_rowgemm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), r, k, n, _lib.stream()), 'dm_rowgemm')
+        y = torch.empty((r, col0 + n), dtype=torch.float32, device=x.device)
+        _lib.check(L.dm_rowgemm_strided(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), r, k, n, col0 + n, col0,
+                                        _lib.stream()), 'dm_rowgemm')
         return y
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, dead_cols=0):
+        """dead_cols: leading input columns nobody differentiates (the xyz + padding floats of a grouped
+        row: QueryGroupRows.backward reads the feature columns only) — their input gradient is written
+        as zeros instead of being computed."""
         ctx.save_for_backward(x, w)
+        ctx.dead_cols = int(dead_cols)
         y = TallSkinnyLinear._rowgemm(x, w)
         return y if y is not None else x @ w.t()
 
@@ -204,7 +210,8 @@ class TallSkinnyLinear(Function):
         x, w = ctx.saved_tensors
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = TallSkinnyLinear._rowgemm(gy, w.t())
+            d = ctx.dead_cols
+            gx = TallSkinnyLinear._rowgemm(gy, w.t()[d:], col0=d) if d else TallSkinnyLinear._rowgemm(gy, w.t())
             if gx is None:
                 gx = gy @ w
         gw = None
@@ -216,7 +223,7 @@ class TallSkinnyLinear(Function):
                                x.view(split, rows // split, -1)).sum(dim=0)
             else:
                 gw = gy.t() @ x
-        return gx, gw
+        return gx, gw, None
 
 
 def query_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None,
@@ -362,7 +369,7 @@ class StackSAModuleMSG(nn.Module):
                         w = _PadXyzColumn.apply(conv.weight)
                     else:
                         w = conv.weight.view(conv.out_channels, conv.in_channels)
-                    x = TallSkinnyLinear.apply(x, w)
+                    x = TallSkinnyLinear.apply(x, w, 4 if (li == 0 and g.use_xyz) else 0)
                     if conv.bias is not None:
                         x = x + conv.bias
                     x = bn_relu_rows(x, bn, relu=True)      # fused BatchNorm + ReLU over rows

@@ -312,6 +312,10 @@ int dm_bbox2d_transform(const float *boxes_or_grad, int n, float scale_x, float 
  * k, n multiples of 4, k <= 136, n <= 192; fp32 MFMA, weights resident in LDS. */
 int dm_rowgemm_supported(int k, int n);
 int dm_rowgemm(const float *x, const float *w, float *y, long long rows, int k, int n, dm_stream_t stream);
+/* The same into rows of `ldy` floats starting at column `col0` (columns [0, col0) are written as zeros):
+ * the input gradient of a first shared-MLP layer without the xyz / padding columns nobody differentiates. */
+int dm_rowgemm_strided(const float *x, const float *w, float *y, long long rows, int k, int n, int ldy,
+                       int col0, dm_stream_t stream);
 
 /* Anchor-head box decoding: AnchorHeadTemplate.generate_predicted_boxes
  * (pcdet/models/dense_heads/anchor_head_template.py:225-272) = ResidualCoder.decode_torch

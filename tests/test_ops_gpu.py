@@ -479,3 +479,53 @@ def test_anchor_decode_kernel_is_the_tensor_chain(dev):
             fused.ENABLED = prev
     assert a.shape == b.shape == (2, n, 7)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('rows,k,n', [(70000, 132, 64), (65537, 64, 64), (40000, 64, 128), (33000, 64, 132),
+                                      (9000, 20, 16), (64, 8, 4), (100000, 36, 32)])
+def test_rowgemm_matches_float64_matmul(dev, rows, k, n):
+    """csrc/rowgemm.hip (shared-MLP GEMM with the weights resident in LDS) == x @ w^T, and the strided
+    form used for the input gradient of a first layer: dead leading columns are zeros."""
+    from detmatch_amd import _lib
+    g = torch.Generator().manual_seed(rows + k)
+    x = torch.randn(rows, k, generator=g).to(dev)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    want = x.double() @ w.double().t()
+    L = _lib.lib()
+    assert L.dm_rowgemm_supported(k, n)
+    y = torch.full((rows, n), float('nan'), device=dev)
+    _lib.check(L.dm_rowgemm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), rows, k, n, _lib.stream()), 'dm_rowgemm')
+    scale = float(want.abs().max())
+    assert float((y.double() - want).abs().max()) <= 2e-6 * scale * k ** 0.5
+    if n <= 128:
+        y2 = torch.full((rows, n + 8), float('nan'), device=dev)
+        _lib.check(L.dm_rowgemm_strided(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y2), rows, k, n, n + 8, 8,
+                                        _lib.stream()), 'dm_rowgemm_strided')
+        assert float(y2[:, :8].abs().max()) == 0.0
+        assert torch.equal(y2[:, 8:], y)
+
+
+def test_tall_skinny_linear_autograd_through_rowgemm(dev):
+    """TallSkinnyLinear on the rowgemm path (threshold lowered) == the BLAS path: output, weight gradient,
+    input gradient of the live columns; the dead leading columns get zeros."""
+    from detmatch_amd.pointnet2_stack import TallSkinnyLinear
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(50000, 68, generator=g).to(dev)
+    w0 = (torch.randn(64, 68, generator=g) / 8).to(dev)
+    gy = torch.randn(50000, 64, generator=g).to(dev)
+    res = []
+    prev = TallSkinnyLinear.ROWGEMM_MIN_ROWS
+    try:
+        for thr in (0, 10 ** 9):
+            TallSkinnyLinear.ROWGEMM_MIN_ROWS = thr
+            x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            y = TallSkinnyLinear.apply(x, w, 4)
+            y.backward(gy)
+            res.append((y.detach(), x.grad.clone(), w.grad.clone()))
+    finally:
+        TallSkinnyLinear.ROWGEMM_MIN_ROWS = prev
+    (ya, xa, wa), (yb, xb, wb) = res
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+    assert float(xa[:, :4].abs().max()) == 0.0
+    assert torch.allclose(xa[:, 4:], xb[:, 4:], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(wa, wb, rtol=1e-3, atol=1e-2)
