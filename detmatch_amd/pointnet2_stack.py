@@ -175,7 +175,9 @@ class TallSkinnyLinear(Function):
     weight gradient dW = dy^T x contracts over R, a shape (64 x 131 x 884736) a single GEMM launch
     fills the chip poorly with: it is computed split-K as one batched GEMM over row chunks + a sum."""
 
-    ROWGEMM_MIN_ROWS = 262144      # below this a launch is latency sized and BLAS is as good
+    # rows from which csrc/rowgemm.hip takes the forward / input-gradient GEMM (A/B of the DetMatch step:
+    # 16 k rows 107.0 ms, 256 k rows 107.8 ms, BLAS only 109.5 ms; below ~16 k rows a launch is latency sized)
+    ROWGEMM_MIN_ROWS = int(os.environ.get('DM_ROWGEMM_MIN_ROWS', '16384'))
 
     @staticmethod
     def _rowgemm(x, w, col0=0):
