@@ -12,6 +12,9 @@
 // weights in registers instead of LDS: 5 % faster, not kept).  Output rows may be wider than N (`ldy`)
 // and start at column `col0` (columns [0, col0) are written as zeros): the input gradient of a first
 // layer skips the xyz / padding columns nobody differentiates (QueryGroupRows.backward).
+// (The weight gradient dW = G^T X stays a split batched BLAS GEMM + sum: a persistent kernel with the N x K
+// accumulator blocks in registers and one row pair per MFMA k-step was measured at 502 / 161 us against
+// 250 / 96 us for 884 736 x 132 / 64 x 64.)
 #include <hip/hip_runtime.h>
 
 #include "../../include/detmatch_hip.h"
