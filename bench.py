@@ -439,6 +439,11 @@ def main():
                                global_batch=BATCH_PER_GPU * world,
                                parallelism='dp%d' % world),
                    roofline=roof)
+        model = getattr(wl, 'model', None)
+        if model is not None and hasattr(model, 'lane_mode'):
+            # how SSL.forward_train orders its modules over HIP streams (pcdet/workload.py)
+            out['config']['stream_order'] = 'branches' if getattr(model, 'two_lanes', False) else \
+                (model.lane_mode or 'serial')
         # pseudo-label bookkeeping of the timed steps: proves the step exercises matching (NumPreds
         # metrics of the SSL chain, mean over the timed steps)
         lb = getattr(getattr(wl, 'runner', None), 'log_buffer', None) or {}
