@@ -4,6 +4,8 @@ nn.BatchNorm1d / nn.BatchNorm2d module `bn` whose channels are the last dim of `
 running-statistics and num_batches_tracked updates; evaluation mode without gradients (the EMA teacher)
 is one launch of its own; shapes the kernels do not take, and evaluation mode under autograd, fall
 through to torch.nn.functional.batch_norm."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -46,6 +48,66 @@ class _BNReLURows(Function):
             ws.numel(), _lib.stream()), 'dm_bn_rows_backward')
         return (gx, ggamma if gamma is not None else None, gbeta if beta is not None else None,
                 None, None, None, None, None)
+
+
+class _BNReLUMaxRows(Function):
+    """max over the `ns` rows of every group of relu(bn(x)), x (M * ns, C) -> (M, C): the normalised tensor
+    is never written, the backward goes from the pooled gradient straight to the dense input gradient
+    (csrc/bn_relu.hip: bn_apply_max / bn_max_bwd_*)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, ns):
+        x = x.contiguous()
+        n, c = x.shape
+        m = n // ns
+        L = _lib.lib()
+        pooled = torch.empty((m, c), dtype=torch.float32, device=x.device)
+        arg = torch.empty((m, c), dtype=torch.uint8, device=x.device)
+        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
+        _lib.check(L.dm_bn_rows_max_forward(
+            _lib.ptr(x), m, int(ns), c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
+            _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(pooled), _lib.ptr(arg), _lib.ptr(mean),
+            _lib.ptr(invstd), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_bn_rows_max_forward')
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, arg)
+        ctx.ns = int(ns)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gp):
+        x, gamma, beta, mean, invstd, arg = ctx.saved_tensors
+        gp = gp.contiguous()
+        n, c = x.shape
+        m = n // ctx.ns
+        L = _lib.lib()
+        gx = torch.empty_like(x)
+        ggamma = torch.empty((c,), dtype=torch.float32, device=x.device)
+        gbeta = torch.empty_like(ggamma)
+        ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
+        _lib.check(L.dm_bn_rows_max_backward(
+            _lib.ptr(gp), _lib.ptr(arg), _lib.ptr(x), m, ctx.ns, c, _lib.ptr(gamma), _lib.ptr(beta),
+            _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gx), _lib.ptr(ggamma), _lib.ptr(gbeta), _lib.ptr(ws),
+            ws.numel(), _lib.stream()), 'dm_bn_rows_max_backward')
+        return (gx, ggamma if gamma is not None else None, gbeta if beta is not None else None,
+                None, None, None, None, None)
+
+
+def bn_relu_rows_max(x, bn, ns):
+    """relu(bn(x)).view(M, ns, C).max(dim=1)[0] for x (M * ns, C): one fused pass in training mode (the
+    normalised tensor is not materialised), the two-step form otherwise."""
+    c = x.shape[-1]
+    training = bn.training or not bn.track_running_stats
+    if training and bn.momentum is not None and _kernel_takes(x, c) and 1 <= ns <= 255 and \
+            x.shape[0] % ns == 0 and (bn.weight is None) == (bn.bias is None) and \
+            os.environ.get('DM_BN_MAX', '1') == '1':
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        rm = bn.running_mean if bn.track_running_stats else None
+        rv = bn.running_var if bn.track_running_stats else None
+        return _BNReLUMaxRows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, ns)
+    y = bn_relu_rows(x, bn, relu=True)
+    return y.view(x.shape[0] // ns, ns, c).max(dim=1)[0]
 
 
 def _kernel_takes(x, c):

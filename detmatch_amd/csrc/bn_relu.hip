@@ -288,6 +288,131 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   *(float4 *)(dx + i) = o;
 }
 
+// ---- BatchNorm + ReLU + max over the nsample rows of a group --------------------------------------
+// The last layer of a shared MLP is followed by a max over the nsample grouped references of each query
+// (pointnet2_modules.py:86-90): the normalised tensor (M * nsample, C) is written only to be read once by
+// the pooling, and in the backward pass the pooled gradient is scattered into a dense zero tensor of the
+// same size that the BatchNorm backward then reads twice.  Here the apply pass keeps a running maximum
+// (and its row) per group and channel and writes only (M, C); the backward reduces over the M arg-max
+// rows and writes the dense input gradient directly from (pooled gradient, arg-max, x).
+// thread = 4 channels of one group; a block covers 256 / (C/4) groups.
+__global__ __launch_bounds__(256) void bn_apply_max_kernel(const float *__restrict__ x, long long m, int ns, int c,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           float *__restrict__ pooled,
+                                                           unsigned char *__restrict__ arg) {
+  const int tpr = c / 4, gpb = 256 / tpr;
+  const int cg = threadIdx.x % tpr, gl = threadIdx.x / tpr;
+  const long long grp = (long long)blockIdx.x * gpb + gl;
+  if (gl >= gpb || grp >= m) return;
+  const int ch = 4 * cg;
+  const float4 mu = *(const float4 *)(mean + ch), s = *(const float4 *)(invstd + ch);
+  const float4 g = gamma ? *(const float4 *)(gamma + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 b = beta ? *(const float4 *)(beta + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float *src = x + (size_t)grp * ns * c + ch;
+  float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);      // relu output is >= 0: the first row always wins
+  int ix = 0, iy = 0, iz = 0, iw = 0;
+  for (int j = 0; j < ns; ++j) {
+    const float4 v = *(const float4 *)(src + (size_t)j * c);
+    const float ox = fmaxf((v.x - mu.x) * s.x * g.x + b.x, 0.f), oy = fmaxf((v.y - mu.y) * s.y * g.y + b.y, 0.f);
+    const float oz = fmaxf((v.z - mu.z) * s.z * g.z + b.z, 0.f), ow = fmaxf((v.w - mu.w) * s.w * g.w + b.w, 0.f);
+    if (ox > best.x) best.x = ox, ix = j;
+    if (oy > best.y) best.y = oy, iy = j;
+    if (oz > best.z) best.z = oz, iz = j;
+    if (ow > best.w) best.w = ow, iw = j;
+  }
+  *(float4 *)(pooled + (size_t)grp * c + ch) = best;
+  *(uchar4 *)(arg + (size_t)grp * c + ch) = make_uchar4((unsigned char)ix, (unsigned char)iy, (unsigned char)iz,
+                                                        (unsigned char)iw);
+}
+
+// backward pass 1 over the M arg-max rows only: per block sum(dy_r) and sum(dy_r * xhat)
+__global__ __launch_bounds__(256) void bn_max_bwd_reduce_kernel(
+    const float *__restrict__ gp, const unsigned char *__restrict__ arg, const float *__restrict__ x, long long m,
+    int ns, int c, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ mean, const float *__restrict__ invstd, int groups_per_block,
+    float *__restrict__ partial /*[2][c][blocks]*/) {
+  extern __shared__ float sm[];
+  const int tpr = c / 4, rpi = 256 / tpr;
+  const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const long long g0 = (long long)blockIdx.x * groups_per_block;
+  const int groups = (int)min((long long)groups_per_block, m - g0);
+  const int ch = 4 * cg;
+  const float4 mu = *(const float4 *)(mean + ch), s = *(const float4 *)(invstd + ch);
+  const float4 g = gamma ? *(const float4 *)(gamma + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 b = beta ? *(const float4 *)(beta + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (rl < rpi)
+    for (int q = rl; q < groups; q += rpi) {
+      const long long grp = g0 + q;
+      const uchar4 a = *(const uchar4 *)(arg + (size_t)grp * c + ch);
+      float4 d = *(const float4 *)(gp + (size_t)grp * c + ch);
+      const float *base = x + (size_t)grp * ns * c + ch;
+      const float hx = (base[(size_t)a.x * c + 0] - mu.x) * s.x, hy = (base[(size_t)a.y * c + 1] - mu.y) * s.y;
+      const float hz = (base[(size_t)a.z * c + 2] - mu.z) * s.z, hw = (base[(size_t)a.w * c + 3] - mu.w) * s.w;
+      if (hx * g.x + b.x <= 0.f) d.x = 0.f;
+      if (hy * g.y + b.y <= 0.f) d.y = 0.f;
+      if (hz * g.z + b.z <= 0.f) d.z = 0.f;
+      if (hw * g.w + b.w <= 0.f) d.w = 0.f;
+      s1.x += d.x, s1.y += d.y, s1.z += d.z, s1.w += d.w;
+      s2.x += d.x * hx, s2.y += d.y * hy, s2.z += d.z * hz, s2.w += d.w * hw;
+    }
+  float *a1 = sm, *a2 = sm + 256 * 4;
+  ((float4 *)a1)[threadIdx.x] = s1;
+  ((float4 *)a2)[threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < tpr) {
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+    for (int j = 0; j < rpi; ++j) {
+      const float4 u1 = ((float4 *)a1)[j * tpr + cg], u2 = ((float4 *)a2)[j * tpr + cg];
+      t1.x += u1.x, t1.y += u1.y, t1.z += u1.z, t1.w += u1.w;
+      t2.x += u2.x, t2.y += u2.y, t2.z += u2.z, t2.w += u2.w;
+    }
+    const size_t nb = gridDim.x;
+    float *p0 = partial + (size_t)(4 * cg) * nb + blockIdx.x, *p1 = p0 + (size_t)c * nb;
+    p0[0] = t1.x, p0[nb] = t1.y, p0[2 * nb] = t1.z, p0[3 * nb] = t1.w;
+    p1[0] = t2.x, p1[nb] = t2.y, p1[2 * nb] = t2.z, p1[3 * nb] = t2.w;
+  }
+}
+
+// backward pass 2: dx = gamma * invstd * (dy_r - mean(dy_r) - xhat * mean(dy_r * xhat)), dy_r non-zero only
+// on the arg-max row of each (group, channel)
+__global__ __launch_bounds__(256) void bn_max_bwd_apply_kernel(
+    const float *__restrict__ gp, const unsigned char *__restrict__ arg, const float *__restrict__ x, long long m,
+    int ns, int c, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ dgamma,
+    const float *__restrict__ dbeta, float *__restrict__ dx) {
+  const long long n = m * ns;
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n * c) return;
+  const int ch = (int)((threadIdx.x * 4u) % (unsigned)c);
+  const long long row = i / c;
+  const long long grp = row / ns;
+  const int j = (int)(row - grp * ns);
+  const float inv_n = 1.0f / (float)n;
+  const float4 v = *(const float4 *)(x + i);
+  const uchar4 a = *(const uchar4 *)(arg + (size_t)grp * c + ch);
+  const float4 gv = *(const float4 *)(gp + (size_t)grp * c + ch);
+  float4 d = make_float4(a.x == j ? gv.x : 0.f, a.y == j ? gv.y : 0.f, a.z == j ? gv.z : 0.f, a.w == j ? gv.w : 0.f);
+  const float4 mu = *(const float4 *)(mean + ch), s = *(const float4 *)(invstd + ch);
+  const float4 g = gamma ? *(const float4 *)(gamma + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 b = beta ? *(const float4 *)(beta + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 sg = *(const float4 *)(dgamma + ch), sb = *(const float4 *)(dbeta + ch);
+  const float hx = (v.x - mu.x) * s.x, hy = (v.y - mu.y) * s.y, hz = (v.z - mu.z) * s.z, hw = (v.w - mu.w) * s.w;
+  if (hx * g.x + b.x <= 0.f) d.x = 0.f;
+  if (hy * g.y + b.y <= 0.f) d.y = 0.f;
+  if (hz * g.z + b.z <= 0.f) d.z = 0.f;
+  if (hw * g.w + b.w <= 0.f) d.w = 0.f;
+  float4 o;
+  o.x = g.x * s.x * (d.x - sb.x * inv_n - hx * sg.x * inv_n);
+  o.y = g.y * s.y * (d.y - sb.y * inv_n - hy * sg.y * inv_n);
+  o.z = g.z * s.z * (d.z - sb.z * inv_n - hz * sg.z * inv_n);
+  o.w = g.w * s.w * (d.w - sb.w * inv_n - hw * sg.w * inv_n);
+  *(float4 *)(dx + i) = o;
+}
+
 bool bn_shape_ok(long long n, int c) { return n > 0 && c >= 4 && c <= 1024 && (c % 4) == 0 && 256 % (c / 4) == 0; }
 
 }  // namespace
@@ -318,6 +443,60 @@ extern "C" int dm_bn_rows_forward(const float *x, long long n, int c, const floa
   const long long quads = n * c / 4;
   bn_apply_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, st>>>(x, n, c, gamma, beta, save_mean,
                                                                    save_invstd, relu, y);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_bn_rows_max_forward(const float *x, long long m, int ns, int c, const float *gamma,
+                                      const float *beta, float eps, float momentum, float *running_mean,
+                                      float *running_var, float *pooled, unsigned char *argmax,
+                                      float *save_mean, float *save_invstd, void *workspace,
+                                      size_t workspace_bytes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = m * ns;
+  if (ns < 1 || ns > 255 || m < 0) return DM_ERR_INVALID_ARG;
+  if (!bn_shape_ok(n, c)) return n == 0 ? DM_OK : DM_ERR_UNSUPPORTED;
+  if (!x || !pooled || !argmax || !save_mean || !save_invstd || !workspace) return DM_ERR_INVALID_ARG;
+  if (workspace_bytes < dm_bn_rows_workspace_bytes(n, c)) return DM_ERR_WORKSPACE;
+  const int rpb = bn_rows_per_block(n, c);
+  const int blocks = (int)((n + rpb - 1) / rpb);
+  float *partial = (float *)workspace;
+  bn_stats_kernel<<<blocks, 256, 2 * 256 * 4 * sizeof(float), st>>>(x, n, c, partial);
+  DM_CHECK_LAUNCH();
+  bn_finalize_kernel<<<c, 64, 0, st>>>(partial, blocks, n, c, eps, momentum, running_mean, running_var,
+                                       save_mean, save_invstd);
+  DM_CHECK_LAUNCH();
+  const int gpb = 256 / (c / 4);
+  bn_apply_max_kernel<<<(unsigned)((m + gpb - 1) / gpb), 256, 0, st>>>(x, m, ns, c, gamma, beta, save_mean,
+                                                                       save_invstd, pooled, argmax);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_bn_rows_max_backward(const float *grad_pooled, const unsigned char *argmax, const float *x,
+                                       long long m, int ns, int c, const float *gamma, const float *beta,
+                                       const float *save_mean, const float *save_invstd, float *grad_x,
+                                       float *grad_gamma, float *grad_beta, void *workspace,
+                                       size_t workspace_bytes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = m * ns;
+  if (ns < 1 || ns > 255 || m < 0) return DM_ERR_INVALID_ARG;
+  if (!bn_shape_ok(n, c)) return n == 0 ? DM_OK : DM_ERR_UNSUPPORTED;
+  if (!grad_pooled || !argmax || !x || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta ||
+      !workspace)
+    return DM_ERR_INVALID_ARG;
+  if (workspace_bytes < dm_bn_rows_workspace_bytes(n, c)) return DM_ERR_WORKSPACE;
+  const int gpb = bn_rows_per_block(m, c);              // groups per block of the arg-max reduction
+  const int blocks = (int)((m + gpb - 1) / gpb);
+  float *partial = (float *)workspace;
+  bn_max_bwd_reduce_kernel<<<blocks, 256, 2 * 256 * 4 * sizeof(float), st>>>(
+      grad_pooled, argmax, x, m, ns, c, gamma, beta, save_mean, save_invstd, gpb, partial);
+  DM_CHECK_LAUNCH();
+  bn_bwd_finalize_kernel<<<c, 64, 0, st>>>(partial, blocks, c, grad_gamma, grad_beta);
+  DM_CHECK_LAUNCH();
+  const long long quads = n * c / 4;
+  bn_max_bwd_apply_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, st>>>(
+      grad_pooled, argmax, x, m, ns, c, gamma, beta, save_mean, save_invstd, grad_gamma, grad_beta, grad_x);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

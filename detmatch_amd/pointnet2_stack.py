@@ -15,7 +15,8 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib
-from .bn_relu import bn_relu_rows
+from .bn_relu import bn_relu_rows, bn_relu_rows_max
+from .fused import on as fused_on
 
 
 def _i32(t):
@@ -366,6 +367,7 @@ class StackSAModuleMSG(nn.Module):
                 m, ns, width = rows.shape
                 x = rows.view(m * ns, width)
                 mods = list(self.mlps[k])
+                n_layers = len(mods) // 3
                 for li, (conv, bn) in enumerate(zip(mods[0::3], mods[1::3])):
                     if li == 0 and g.use_xyz:      # zero column for the padding float after xyz
                         w = _PadXyzColumn.apply(conv.weight)
@@ -374,8 +376,11 @@ class StackSAModuleMSG(nn.Module):
                     x = TallSkinnyLinear.apply(x, w, 4 if (li == 0 and g.use_xyz) else 0)
                     if conv.bias is not None:
                         x = x + conv.bias
-                    x = bn_relu_rows(x, bn, relu=True)      # fused BatchNorm + ReLU over rows
-                new_features_list.append(x.view(m, ns, -1).max(dim=1)[0])      # (M, C)
+                    if li == n_layers - 1 and fused_on():
+                        x = bn_relu_rows_max(x, bn, ns)     # ... and the max over nsample in the same pass
+                    else:
+                        x = bn_relu_rows(x, bn, relu=True)  # fused BatchNorm + ReLU over rows
+                new_features_list.append(x if x.shape[0] == m else x.view(m, ns, -1).max(dim=1)[0])      # (M, C)
             return new_xyz, torch.cat(new_features_list, dim=1)
         for k in range(len(self.groupers)):
             new_features, _ = self.groupers[k](xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,

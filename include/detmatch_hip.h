@@ -261,6 +261,18 @@ int dm_bn_rows_forward(const float *x, long long n, int c, const float *gamma, c
                        float eps, float momentum, float *running_mean, float *running_var, int relu,
                        float *y, float *save_mean, float *save_invstd, void *workspace,
                        size_t workspace_bytes, dm_stream_t stream);
+/* BatchNorm (training mode) + ReLU + max over the `ns` consecutive rows of each of `m` groups — the last layer
+ * of a shared MLP followed by the max-pool over nsample (pointnet2_modules.py:79-90): x (m * ns, C) ->
+ * pooled (m, C), argmax (m, C) bytes (row inside the group); the normalised (m * ns, C) tensor is never
+ * written.  Backward: grad_pooled (m, C) -> dense grad_x (m * ns, C), grad_gamma, grad_beta. */
+int dm_bn_rows_max_forward(const float *x, long long m, int ns, int c, const float *gamma, const float *beta,
+                           float eps, float momentum, float *running_mean, float *running_var,
+                           float *pooled, unsigned char *argmax, float *save_mean, float *save_invstd,
+                           void *workspace, size_t workspace_bytes, dm_stream_t stream);
+int dm_bn_rows_max_backward(const float *grad_pooled, const unsigned char *argmax, const float *x, long long m,
+                            int ns, int c, const float *gamma, const float *beta, const float *save_mean,
+                            const float *save_invstd, float *grad_x, float *grad_gamma, float *grad_beta,
+                            void *workspace, size_t workspace_bytes, dm_stream_t stream);
 /* Evaluation mode (running statistics; the EMA teacher's BatchNorm layers), optional ReLU, one launch. */
 int dm_bn_rows_eval(const float *x, long long n, int c, const float *gamma, const float *beta,
                     const float *running_mean, const float *running_var, float eps, int relu, float *y,

@@ -529,3 +529,37 @@ def test_tall_skinny_linear_autograd_through_rowgemm(dev):
     assert float(xa[:, :4].abs().max()) == 0.0
     assert torch.allclose(xa[:, 4:], xb[:, 4:], rtol=1e-4, atol=1e-4)
     assert torch.allclose(wa, wb, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize('m,ns,c', [(4096, 16, 32), (1000, 32, 64), (55296, 16, 64), (7, 5, 128), (300, 16, 16)])
+def test_fused_bn_relu_maxpool_matches_two_step(dev, m, ns, c):
+    """bn_relu_rows_max (BatchNorm + ReLU + max over nsample in one apply pass, backward from the pooled
+    gradient) == relu(bn(x)).view(M, ns, C).max(1) through the row kernels + torch.max: pooled values bit
+    for bit, running statistics equal, gradients w.r.t. x / gamma / beta equal."""
+    import torch.nn as nn
+    from detmatch_amd.bn_relu import bn_relu_rows, bn_relu_rows_max
+    torch.manual_seed(m + c)
+    x0 = torch.randn(m * ns, c, device=dev) * 1.7 + torch.linspace(-3, 3, c, device=dev)
+    gp = torch.randn(m, c, device=dev)
+    res = []
+    for fused in (True, False):
+        bn = nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            y = bn_relu_rows_max(x, bn, ns)
+            assert 'BNReLUMaxRows' in type(y.grad_fn).__name__
+        else:
+            y = bn_relu_rows(x, bn, relu=True).view(m, ns, c).max(dim=1)[0]
+        y.backward(gp)
+        res.append((y.detach(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                    bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]) and a[6] == b[6] == 1
+    gs = float(b[1].abs().max()) + 1e-12
+    assert float((a[1] - b[1]).abs().max()) <= 2e-5 * gs
+    for u, v in ((a[2], b[2]), (a[3], b[3])):
+        assert float((u - v).abs().max()) <= 1e-4 * (float(v.abs().max()) + 1e-6)
