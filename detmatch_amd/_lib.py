@@ -65,6 +65,7 @@ SIGNATURES = {
     'dm_bn_rows_forward': (ci, [vp, ctypes.c_longlong, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
     'dm_bn_rows_max_forward': (ci, [vp, ctypes.c_longlong, ci, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'dm_bn_rows_max_backward': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'dm_bn_rows_eval_max': (ci, [vp, ctypes.c_longlong, ci, ci, vp, vp, vp, vp, cf, vp, vp]),
     'dm_bn_rows_eval': (ci, [vp, ctypes.c_longlong, ci, vp, vp, vp, vp, cf, ci, vp, vp]),
     'dm_bn_rows_backward': (ci, [vp, vp, ctypes.c_longlong, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
     'dm_roi_align_forward': (ci, [vp, c_i32_p, c_i32_p, c_f32_p, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci,

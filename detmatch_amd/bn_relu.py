@@ -106,6 +106,16 @@ def bn_relu_rows_max(x, bn, ns):
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
         return _BNReLUMaxRows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, ns)
+    if not training and _kernel_takes(x, c) and 1 <= ns <= 255 and x.shape[0] % ns == 0 and \
+            (bn.weight is None) == (bn.bias is None) and os.environ.get('DM_BN_MAX', '1') == '1' and \
+            not (torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad))):
+        x = x.contiguous()
+        pooled = torch.empty((x.shape[0] // ns, c), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().dm_bn_rows_eval_max(
+            _lib.ptr(x), x.shape[0] // ns, int(ns), c, _lib.ptr(bn.weight), _lib.ptr(bn.bias),
+            _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), float(bn.eps), _lib.ptr(pooled), _lib.stream()),
+            'dm_bn_rows_eval_max')
+        return pooled
     y = bn_relu_rows(x, bn, relu=True)
     return y.view(x.shape[0] // ns, ns, c).max(dim=1)[0]
 

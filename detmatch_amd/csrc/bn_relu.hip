@@ -296,11 +296,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // (and its row) per group and channel and writes only (M, C); the backward reduces over the M arg-max
 // rows and writes the dense input gradient directly from (pooled gradient, arg-max, x).
 // thread = 4 channels of one group; a block covers 256 / (C/4) groups.
+// EVAL: `invstd` holds the running variance, eps is added and inverted here (the EMA teacher)
+template <bool EVAL>
 __global__ __launch_bounds__(256) void bn_apply_max_kernel(const float *__restrict__ x, long long m, int ns, int c,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ beta,
                                                            const float *__restrict__ mean,
-                                                           const float *__restrict__ invstd,
+                                                           const float *__restrict__ invstd, float eps,
                                                            float *__restrict__ pooled,
                                                            unsigned char *__restrict__ arg) {
   const int tpr = c / 4, gpb = 256 / tpr;
@@ -308,7 +310,9 @@ __global__ __launch_bounds__(256) void bn_apply_max_kernel(const float *__restri
   const long long grp = (long long)blockIdx.x * gpb + gl;
   if (gl >= gpb || grp >= m) return;
   const int ch = 4 * cg;
-  const float4 mu = *(const float4 *)(mean + ch), s = *(const float4 *)(invstd + ch);
+  const float4 mu = *(const float4 *)(mean + ch);
+  float4 s = *(const float4 *)(invstd + ch);
+  if (EVAL) s.x = 1.0f / sqrtf(s.x + eps), s.y = 1.0f / sqrtf(s.y + eps), s.z = 1.0f / sqrtf(s.z + eps), s.w = 1.0f / sqrtf(s.w + eps);
   const float4 g = gamma ? *(const float4 *)(gamma + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 b = beta ? *(const float4 *)(beta + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float *src = x + (size_t)grp * ns * c + ch;
@@ -324,8 +328,9 @@ __global__ __launch_bounds__(256) void bn_apply_max_kernel(const float *__restri
     if (ow > best.w) best.w = ow, iw = j;
   }
   *(float4 *)(pooled + (size_t)grp * c + ch) = best;
-  *(uchar4 *)(arg + (size_t)grp * c + ch) = make_uchar4((unsigned char)ix, (unsigned char)iy, (unsigned char)iz,
-                                                        (unsigned char)iw);
+  if (arg)
+    *(uchar4 *)(arg + (size_t)grp * c + ch) = make_uchar4((unsigned char)ix, (unsigned char)iy, (unsigned char)iz,
+                                                          (unsigned char)iw);
 }
 
 // backward pass 1 over the M arg-max rows only: per block sum(dy_r) and sum(dy_r * xhat)
@@ -467,8 +472,22 @@ extern "C" int dm_bn_rows_max_forward(const float *x, long long m, int ns, int c
                                        save_mean, save_invstd);
   DM_CHECK_LAUNCH();
   const int gpb = 256 / (c / 4);
-  bn_apply_max_kernel<<<(unsigned)((m + gpb - 1) / gpb), 256, 0, st>>>(x, m, ns, c, gamma, beta, save_mean,
-                                                                       save_invstd, pooled, argmax);
+  bn_apply_max_kernel<false><<<(unsigned)((m + gpb - 1) / gpb), 256, 0, st>>>(
+      x, m, ns, c, gamma, beta, save_mean, save_invstd, 0.f, pooled, argmax);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_bn_rows_eval_max(const float *x, long long m, int ns, int c, const float *gamma,
+                                   const float *beta, const float *running_mean, const float *running_var,
+                                   float eps, float *pooled, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (ns < 1 || ns > 255 || m < 0) return DM_ERR_INVALID_ARG;
+  if (!bn_shape_ok(m * ns, c)) return m * ns == 0 ? DM_OK : DM_ERR_UNSUPPORTED;
+  if (!x || !pooled || !running_mean || !running_var) return DM_ERR_INVALID_ARG;
+  const int gpb = 256 / (c / 4);
+  bn_apply_max_kernel<true><<<(unsigned)((m + gpb - 1) / gpb), 256, 0, st>>>(
+      x, m, ns, c, gamma, beta, running_mean, running_var, eps, pooled, nullptr);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -273,6 +273,10 @@ int dm_bn_rows_max_backward(const float *grad_pooled, const unsigned char *argma
                             int ns, int c, const float *gamma, const float *beta, const float *save_mean,
                             const float *save_invstd, float *grad_x, float *grad_gamma, float *grad_beta,
                             void *workspace, size_t workspace_bytes, dm_stream_t stream);
+/* The same in evaluation mode (running statistics, no gradient): one launch. */
+int dm_bn_rows_eval_max(const float *x, long long m, int ns, int c, const float *gamma, const float *beta,
+                        const float *running_mean, const float *running_var, float eps, float *pooled,
+                        dm_stream_t stream);
 /* Evaluation mode (running statistics; the EMA teacher's BatchNorm layers), optional ReLU, one launch. */
 int dm_bn_rows_eval(const float *x, long long n, int c, const float *gamma, const float *beta,
                     const float *running_mean, const float *running_var, float eps, int relu, float *y,

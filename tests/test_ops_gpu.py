@@ -563,3 +563,9 @@ def test_fused_bn_relu_maxpool_matches_two_step(dev, m, ns, c):
     assert float((a[1] - b[1]).abs().max()) <= 2e-5 * gs
     for u, v in ((a[2], b[2]), (a[3], b[3])):
         assert float((u - v).abs().max()) <= 1e-4 * (float(v.abs().max()) + 1e-6)
+    # evaluation mode (the EMA teacher): one launch, equal to the two-step form
+    bn.eval()
+    with torch.no_grad():
+        ye = bn_relu_rows_max(x0, bn, ns)
+        want = bn_relu_rows(x0, bn, relu=True).view(m, ns, c).max(dim=1)[0]
+    assert torch.equal(ye, want)
