@@ -118,6 +118,7 @@ SIGNATURES = {
     'dm_points_augment_workspace_bytes': (sz, [ci, c_int_p]),
     'dm_points_augment': (ci, [vp, ci, ci, c_int_p, c_int_p, c_int_p, vp, vp, vp, vp, vp, sz, vp]),
     'dm_ball_query_stack': (ci, [ci, ci, cf, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
+    'dm_ball_query_stack2': (ci, [ci, ci, cf, ci, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'dm_group_points_stack': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     'dm_group_points_grad_stack': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     'dm_query_group_rows': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -226,6 +226,141 @@ __global__ __launch_bounds__(256) void ball_query_wave(int batch, int m, float r
   }
 }
 
+// Two radii in ONE scan (the two groupers of a set-abstraction source query the same points around the
+// same centres): the distance of a (query, point) pair is computed once and ranked into both hit lists.
+struct BallPair {
+  float radius2[2];
+  int nsample[2];
+  int *idx[2];
+  unsigned char *empty[2];
+};
+
+template <int Q>
+__global__ __launch_bounds__(256) void ball_query_wave2(int batch, int m, BallPair bp,
+                                                       const float *__restrict__ new_xyz,
+                                                       const int *__restrict__ new_cnt,
+                                                       const float *__restrict__ xyz,
+                                                       const int *__restrict__ xyz_cnt) {
+  __shared__ float s_pts[BQ_TILE * 3];
+  const int lane = threadIdx.x & 63;
+  const int bq0 = blockIdx.x * 4 * Q;                          // first query of this block
+  const int wq = bq0 + (threadIdx.x >> 6) * Q;                 // first query of this wave
+  float qx[Q], qy[Q], qz[Q];
+  int cnt[Q][2], first[Q][2], qb[Q];
+  bool live[Q];
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    int q = wq + u;
+    live[u] = q < m;
+    int qq = live[u] ? q : m - 1;
+    int b = 0, acc = new_cnt[0];
+    for (int k = 1; k < batch; ++k) {
+      if (qq < acc) break;
+      acc += new_cnt[k];
+      b = k;
+    }
+    qb[u] = b;
+    qx[u] = new_xyz[(size_t)qq * 3 + 0];
+    qy[u] = new_xyz[(size_t)qq * 3 + 1];
+    qz[u] = new_xyz[(size_t)qq * 3 + 2];
+    cnt[u][0] = cnt[u][1] = 0;
+    first[u][0] = first[u][1] = 0;
+  }
+  // queries are stacked by sample: the block's queries span samples b_lo..b_hi (one, except
+  // at a sample boundary)
+  int b_lo = 0, b_hi = 0;
+  {
+    int q_last = bq0 + 4 * Q - 1 < m ? bq0 + 4 * Q - 1 : m - 1;
+    int acc = 0;
+    for (int k = 0; k < batch; ++k) {
+      if (bq0 >= acc) b_lo = k;
+      if (q_last >= acc) b_hi = k;
+      acc += new_cnt[k];
+    }
+  }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int pstart = 0;
+  for (int k = 0; k < b_lo; ++k) pstart += xyz_cnt[k];
+  for (int b = b_lo; b <= b_hi; ++b) {
+    const int n = xyz_cnt[b];
+    const float *base = xyz + (size_t)pstart * 3;
+    const int n3 = n * 3;
+    float r[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      int e = j * 256 + (int)threadIdx.x;
+      r[j] = e < n3 ? base[e] : 0.f;
+    }
+    for (int t0 = 0; t0 < n; t0 += BQ_TILE) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) s_pts[j * 256 + threadIdx.x] = r[j];
+      __syncthreads();
+      if (t0 + BQ_TILE < n) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          int e = (t0 + BQ_TILE) * 3 + j * 256 + (int)threadIdx.x;
+          r[j] = e < n3 ? base[e] : 0.f;
+        }
+      }
+      bool open = false;
+#pragma unroll
+      for (int u = 0; u < Q; ++u)
+        open = open || (live[u] && qb[u] == b && (cnt[u][0] < bp.nsample[0] || cnt[u][1] < bp.nsample[1]));
+      if (open) {
+        const int lim = n - t0 < BQ_TILE ? n - t0 : BQ_TILE;
+        for (int c0 = 0; c0 < lim; c0 += 64) {
+          int kk = c0 + lane;
+          bool in = kk < lim;
+          float x = s_pts[kk * 3 + 0], y = s_pts[kk * 3 + 1], z = s_pts[kk * 3 + 2];
+          bool still = false;
+#pragma unroll
+          for (int u = 0; u < Q; ++u) {
+            if (!(live[u] && qb[u] == b) || (cnt[u][0] >= bp.nsample[0] && cnt[u][1] >= bp.nsample[1])) continue;
+            float d2 = dist2_fma(qx[u] - x, qy[u] - y, qz[u] - z);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+              if (cnt[u][rr] >= bp.nsample[rr]) continue;
+              bool hit = in && d2 < bp.radius2[rr];
+              unsigned long long mk = __ballot(hit);
+              if (mk != 0ull) {
+                if (cnt[u][rr] == 0) first[u][rr] = t0 + c0 + __ffsll((long long)mk) - 1;
+                int pos = cnt[u][rr] + __popcll(mk & lt);
+                if (hit && pos < bp.nsample[rr]) bp.idx[rr][(size_t)(wq + u) * bp.nsample[rr] + pos] = t0 + kk;
+                cnt[u][rr] += __popcll(mk);
+              }
+              still = still || cnt[u][rr] < bp.nsample[rr];
+            }
+          }
+          if (!still) break;
+        }
+        open = false;
+#pragma unroll
+        for (int u = 0; u < Q; ++u)
+          open = open || (live[u] && qb[u] == b && (cnt[u][0] < bp.nsample[0] || cnt[u][1] < bp.nsample[1]));
+      }
+      if (!__syncthreads_or(open ? 1 : 0)) break;
+    }
+    pstart += n;
+  }
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    if (!live[u]) continue;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int nsample = bp.nsample[rr];
+      int *out = bp.idx[rr] + (size_t)(wq + u) * nsample;
+      int c = cnt[u][rr] < nsample ? cnt[u][rr] : nsample;
+      if (c > 0) {
+        for (int l = c + lane; l < nsample; l += 64) out[l] = first[u][rr];  // pad with first hit
+        if (lane == 0) bp.empty[rr][wq + u] = 0;
+      } else {
+        for (int l = lane; l < nsample; l += 64) out[l] = 0;
+        if (lane == 0) bp.empty[rr][wq + u] = 1;
+      }
+    }
+  }
+}
+
 // ---- grouping -------------------------------------------------------------------
 // One wave per query point: rows are read coalesced (lanes over channels), transposed
 // through a wave-private LDS tile and written as contiguous (C, nsample) blocks.
@@ -904,6 +1039,30 @@ __global__ __launch_bounds__(FPS_MT) void fps_kernel_multi(FpsSamples smp, int m
 }
 
 }  // namespace
+
+extern "C" int dm_ball_query_stack2(int batch, int m, float radius_a, int nsample_a, float radius_b,
+                                    int nsample_b, const float *new_xyz, const int *new_xyz_batch_cnt,
+                                    const float *xyz, const int *xyz_batch_cnt, int *idx_a, int *idx_b,
+                                    unsigned char *empty_a, unsigned char *empty_b, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (batch <= 0 || batch > DM_MAX_BATCH || m < 0 || nsample_a <= 0 || nsample_b <= 0) return DM_ERR_INVALID_ARG;
+  if (m == 0) return DM_OK;
+  if (!new_xyz || !new_xyz_batch_cnt || !xyz_batch_cnt || !idx_a || !idx_b || !empty_a || !empty_b)
+    return DM_ERR_INVALID_ARG;
+  BallPair bp;
+  bp.radius2[0] = radius_a * radius_a, bp.radius2[1] = radius_b * radius_b;   // ball_query_gpu.cu:43
+  bp.nsample[0] = nsample_a, bp.nsample[1] = nsample_b;
+  bp.idx[0] = idx_a, bp.idx[1] = idx_b;
+  bp.empty[0] = empty_a, bp.empty[1] = empty_b;
+  if (m >= 16384)
+    ball_query_wave2<4><<<dm_ceil_div(m, 16), 256, 0, st>>>(batch, m, bp, new_xyz, new_xyz_batch_cnt, xyz,
+                                                            xyz_batch_cnt);
+  else
+    ball_query_wave2<2><<<dm_ceil_div(m, 8), 256, 0, st>>>(batch, m, bp, new_xyz, new_xyz_batch_cnt, xyz,
+                                                           xyz_batch_cnt);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
 
 extern "C" int dm_ball_query_stack(int batch, int m, float radius, int nsample,
                                    const float *new_xyz, const int *new_xyz_batch_cnt,

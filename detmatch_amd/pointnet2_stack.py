@@ -55,6 +55,25 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+@torch.no_grad()
+def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    """Two ball queries around the same centres in one scan of the points (dm_ball_query_stack2):
+    -> ((idx_a, empty_a), (idx_b, empty_b)), each as `ball_query` returns it."""
+    xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
+    xyz_batch_cnt, new_xyz_batch_cnt = _i32(xyz_batch_cnt).contiguous(), _i32(new_xyz_batch_cnt).contiguous()
+    _lib.require_device(xyz, new_xyz, xyz_batch_cnt, new_xyz_batch_cnt)
+    m, dev = new_xyz.shape[0], xyz.device
+    ia = torch.empty((m, nsample_a), dtype=torch.int32, device=dev)
+    ib = torch.empty((m, nsample_b), dtype=torch.int32, device=dev)
+    ea = torch.empty((m,), dtype=torch.bool, device=dev)
+    eb = torch.empty((m,), dtype=torch.bool, device=dev)
+    _lib.check(_lib.lib().dm_ball_query_stack2(
+        xyz_batch_cnt.shape[0], m, float(radius_a), int(nsample_a), float(radius_b), int(nsample_b),
+        _lib.ptr(new_xyz), _lib.ptr(new_xyz_batch_cnt), _lib.ptr(xyz), _lib.ptr(xyz_batch_cnt), _lib.ptr(ia),
+        _lib.ptr(ib), _lib.ptr(ea), _lib.ptr(eb), _lib.stream()), 'dm_ball_query_stack2')
+    return (ia, ea), (ib, eb)
+
+
 class GroupingOperation(Function):
     """pointnet2_utils.py:48-113.  `empty_mask` (extension): rows of empty balls are
     written as zeros by the kernel instead of a separate masked assignment."""
@@ -230,9 +249,11 @@ class TallSkinnyLinear(Function):
 
 
 def query_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None,
-                     use_xyz=True):
-    """QueryAndGroup (pointnet2_utils.py:116-156) in row layout -> (M, nsample, [4+]C), idx."""
-    idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+                     use_xyz=True, found=None):
+    """QueryAndGroup (pointnet2_utils.py:116-156) in row layout -> (M, nsample, [4+]C), idx.
+    `found`: (idx, empty) of this query computed elsewhere (ball_query_pair)."""
+    idx, empty = found if found is not None else \
+        ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
     assert use_xyz or features is not None, 'Cannot have not features and not use xyz as a feature!'
     rows = QueryGroupRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty,
                                 use_xyz)
@@ -361,9 +382,15 @@ class StackSAModuleMSG(nn.Module):
             # Row layout: a grouped reference is one contiguous row, the shared 1x1-conv MLP a GEMM
             # over (M*nsample, C) rows, BatchNorm2d a column reduction over the same M*nsample
             # elements per channel — the math of :72-83 without the (1, C, M, nsample) copies.
+            found = [None] * len(self.groupers)
+            if len(self.groupers) == 2 and fused_on() and xyz.is_cuda and os.environ.get('DM_BALL_PAIR', '1') == '1':
+                # both radii of the source in one scan of its points
+                ga, gb = self.groupers
+                found = ball_query_pair(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, xyz_batch_cnt,
+                                        new_xyz, new_xyz_batch_cnt)
             for k, g in enumerate(self.groupers):
                 rows, _ = query_group_rows(g.radius, g.nsample, xyz, xyz_batch_cnt, new_xyz,
-                                           new_xyz_batch_cnt, features, g.use_xyz)
+                                           new_xyz_batch_cnt, features, g.use_xyz, found=found[k])
                 m, ns, width = rows.shape
                 x = rows.view(m * ns, width)
                 mods = list(self.mlps[k])

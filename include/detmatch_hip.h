@@ -718,6 +718,13 @@ int dm_ball_query_stack(int batch, int m, float radius, int nsample, const float
                         const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt,
                         int max_m_per_sample, int *idx, unsigned char *empty_mask,
                         dm_stream_t stream);
+/* Two radii around the same query centres in ONE scan of the points (the two groupers of a
+ * StackSAModuleMSG source, pointnet2_modules.py:60-78): same results as two dm_ball_query_stack calls with
+ * empty masks. */
+int dm_ball_query_stack2(int batch, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                         const float *new_xyz, const int *new_xyz_batch_cnt, const float *xyz,
+                         const int *xyz_batch_cnt, int *idx_a, int *idx_b, unsigned char *empty_a,
+                         unsigned char *empty_b, dm_stream_t stream);
 /* Replaces group_points_wrapper / group_points_grad_wrapper (group_points_gpu.cu:15-131).
  * out (m, c, nsample).  empty_mask (optional): rows of empty balls are written as zeros
  * (pointnet2_utils.py:145,150). grad_features (n, c) is zeroed by the callee. */

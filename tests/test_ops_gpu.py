@@ -569,3 +569,23 @@ def test_fused_bn_relu_maxpool_matches_two_step(dev, m, ns, c):
         ye = bn_relu_rows_max(x0, bn, ns)
         want = bn_relu_rows(x0, bn, relu=True).view(m, ns, c).max(dim=1)[0]
     assert torch.equal(ye, want)
+
+
+@pytest.mark.parametrize('counts', [([5000, 2300], [2048, 2048]), ([3000, 0, 1700], [253, 0, 300]),
+                                    ([700, 64], [9001, 8999])])
+def test_ball_query_pair_equals_two_queries(orc, dev, counts):
+    """dm_ball_query_stack2 (two radii in one scan) == the oracle's ball query run once per radius:
+    indices and empty flags bit for bit, on both launch shapes."""
+    from detmatch_amd import pointnet2_stack as pn
+    xyz_cnt, new_cnt = counts
+    rng = np.random.default_rng(sum(new_cnt))
+    xyz = _stacked(rng, xyz_cnt, 0, 6)
+    new_xyz = _stacked(rng, new_cnt, -0.5, 6.5)
+    t = lambda a, dt=None: torch.from_numpy(np.asarray(a, dtype=dt)).to(dev)
+    for (ra, na), (rb, nb) in (((0.4, 16), (0.8, 16)), ((1.2, 32), (0.3, 16)), ((2.4, 16), (4.8, 32))):
+        (ia, ea), (ib, eb) = pn.ball_query_pair(ra, na, rb, nb, t(xyz), t(xyz_cnt, np.int32), t(new_xyz),
+                                                t(new_cnt, np.int32))
+        for (idx, empty), (r, n) in (((ia, ea), (ra, na)), ((ib, eb), (rb, nb))):
+            oidx, oempty = orc.ball_query(r, n, xyz, xyz_cnt, new_xyz, new_cnt)
+            assert np.array_equal(idx.cpu().numpy(), oidx)
+            assert np.array_equal(empty.cpu().numpy(), oempty)
