@@ -16,18 +16,25 @@ from . import _lib
 class _BNReLURows(Function):
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, pre=None):
         x = x.contiguous()
         n, c = x.shape
         L = _lib.lib()
         y = torch.empty_like(x)
         mean = torch.empty((c,), dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
-        ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
-        _lib.check(L.dm_bn_rows_forward(
-            _lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
-            _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(y), _lib.ptr(mean),
-            _lib.ptr(invstd), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_bn_rows_forward')
+        if pre is not None:      # column statistics already reduced by the producer (dm_rowgemm_stats)
+            _lib.check(L.dm_bn_rows_forward_pre(
+                _lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
+                _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(y), _lib.ptr(mean),
+                _lib.ptr(invstd), _lib.ptr(pre[0]), _lib.ptr(pre[1]), int(pre[2]), _lib.stream()),
+                'dm_bn_rows_forward_pre')
+        else:
+            ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
+            _lib.check(L.dm_bn_rows_forward(
+                _lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
+                _lib.ptr(running_mean), _lib.ptr(running_var), int(relu), _lib.ptr(y), _lib.ptr(mean),
+                _lib.ptr(invstd), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_bn_rows_forward')
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.relu = relu
         return y
@@ -47,7 +54,7 @@ class _BNReLURows(Function):
             _lib.ptr(invstd), int(ctx.relu), _lib.ptr(gx), _lib.ptr(ggamma), _lib.ptr(gbeta), _lib.ptr(ws),
             ws.numel(), _lib.stream()), 'dm_bn_rows_backward')
         return (gx, ggamma if gamma is not None else None, gbeta if beta is not None else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class _BNReLUMaxRows(Function):
@@ -56,7 +63,7 @@ class _BNReLUMaxRows(Function):
     (csrc/bn_relu.hip: bn_apply_max / bn_max_bwd_*)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, ns):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, ns, pre=None):
         x = x.contiguous()
         n, c = x.shape
         m = n // ns
@@ -65,11 +72,18 @@ class _BNReLUMaxRows(Function):
         arg = torch.empty((m, c), dtype=torch.uint8, device=x.device)
         mean = torch.empty((c,), dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
-        ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
-        _lib.check(L.dm_bn_rows_max_forward(
-            _lib.ptr(x), m, int(ns), c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
-            _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(pooled), _lib.ptr(arg), _lib.ptr(mean),
-            _lib.ptr(invstd), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_bn_rows_max_forward')
+        if pre is not None:
+            _lib.check(L.dm_bn_rows_max_forward_pre(
+                _lib.ptr(x), m, int(ns), c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
+                _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(pooled), _lib.ptr(arg), _lib.ptr(mean),
+                _lib.ptr(invstd), _lib.ptr(pre[0]), _lib.ptr(pre[1]), int(pre[2]), _lib.stream()),
+                'dm_bn_rows_max_forward_pre')
+        else:
+            ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
+            _lib.check(L.dm_bn_rows_max_forward(
+                _lib.ptr(x), m, int(ns), c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
+                _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(pooled), _lib.ptr(arg), _lib.ptr(mean),
+                _lib.ptr(invstd), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_bn_rows_max_forward')
         ctx.save_for_backward(x, gamma, beta, mean, invstd, arg)
         ctx.ns = int(ns)
         return pooled
@@ -90,7 +104,13 @@ class _BNReLUMaxRows(Function):
             _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gx), _lib.ptr(ggamma), _lib.ptr(gbeta), _lib.ptr(ws),
             ws.numel(), _lib.stream()), 'dm_bn_rows_max_backward')
         return (gx, ggamma if gamma is not None else None, gbeta if beta is not None else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
+
+
+def _pre_stats(x, c):
+    """Column statistics attached to x by the GEMM that produced it (TallSkinnyLinear, `dm_bn_pre`)."""
+    pre = getattr(x, 'dm_bn_pre', None)
+    return pre if (pre is not None and pre[0].shape[1] == c and x.is_contiguous()) else None
 
 
 def bn_relu_rows_max(x, bn, ns):
@@ -105,7 +125,7 @@ def bn_relu_rows_max(x, bn, ns):
             bn.num_batches_tracked.add_(1)
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
-        return _BNReLUMaxRows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, ns)
+        return _BNReLUMaxRows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, ns, _pre_stats(x, c))
     if not training and _kernel_takes(x, c) and 1 <= ns <= 255 and x.shape[0] % ns == 0 and \
             (bn.weight is None) == (bn.bias is None) and os.environ.get('DM_BN_MAX', '1') == '1' and \
             not (torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad))):
@@ -135,7 +155,7 @@ def bn_relu_rows(x, bn, relu=True):
             bn.num_batches_tracked.add_(1)
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
-        return _BNReLURows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, relu)
+        return _BNReLURows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, relu, _pre_stats(x, c))
     if not training and _kernel_takes(x, c) and (bn.weight is None) == (bn.bias is None) and \
             not (torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad))):
         # inference (the EMA teacher): normalisation with the running statistics + ReLU in one launch

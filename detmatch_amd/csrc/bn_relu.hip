@@ -91,10 +91,12 @@ __device__ __forceinline__ void chan_merge(float &cnt, float &mean, float &m2, f
   cnt = tot;
 }
 
+// counts != nullptr: rows behind partial b (partials produced elsewhere, e.g. by the GEMM that wrote x:
+// dm_rowgemm_stats); else the regular tiling of bn_stats_kernel
 __global__ __launch_bounds__(64) void bn_finalize_kernel(
     const float *__restrict__ partial, int blocks, long long n, int c, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ save_mean,
-    float *__restrict__ save_invstd) {
+    float *__restrict__ save_invstd, const float *__restrict__ counts = nullptr) {
   const int ch = blockIdx.x, lane = threadIdx.x;
   const float *pm = partial + (size_t)ch * blocks, *pq = partial + ((size_t)c + ch) * blocks;
   float cnt = 0.f, mean = 0.f, m2 = 0.f;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(
     for (int u = 0; u < 8; ++u) {
       const int b = b0 + 64 * u;
       if (b < blocks) {
-        const float nb = (float)min((long long)rpb, n - (long long)b * rpb);
+        const float nb = counts ? counts[b] : (float)min((long long)rpb, n - (long long)b * rpb);
         chan_merge(cnt, mean, m2, nb, vm[u], vq[u]);
       }
     }
@@ -448,6 +450,47 @@ extern "C" int dm_bn_rows_forward(const float *x, long long n, int c, const floa
   const long long quads = n * c / 4;
   bn_apply_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, st>>>(x, n, c, gamma, beta, save_mean,
                                                                    save_invstd, relu, y);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+// The same with the per-column statistics already reduced to `blocks` partials (mean, M2 — layout
+// (2, c, blocks)) over `counts[b]` rows each: no statistics pass over x.
+extern "C" int dm_bn_rows_forward_pre(const float *x, long long n, int c, const float *gamma, const float *beta,
+                                      float eps, float momentum, float *running_mean, float *running_var,
+                                      int relu, float *y, float *save_mean, float *save_invstd,
+                                      const float *partial, const float *counts, int blocks,
+                                      dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!bn_shape_ok(n, c)) return n == 0 ? DM_OK : DM_ERR_UNSUPPORTED;
+  if (!x || !y || !save_mean || !save_invstd || !partial || !counts || blocks < 1) return DM_ERR_INVALID_ARG;
+  bn_finalize_kernel<<<c, 64, 0, st>>>(partial, blocks, n, c, eps, momentum, running_mean, running_var,
+                                       save_mean, save_invstd, counts);
+  DM_CHECK_LAUNCH();
+  const long long quads = n * c / 4;
+  bn_apply_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, st>>>(x, n, c, gamma, beta, save_mean,
+                                                                   save_invstd, relu, y);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_bn_rows_max_forward_pre(const float *x, long long m, int ns, int c, const float *gamma,
+                                          const float *beta, float eps, float momentum, float *running_mean,
+                                          float *running_var, float *pooled, unsigned char *argmax,
+                                          float *save_mean, float *save_invstd, const float *partial,
+                                          const float *counts, int blocks, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = m * ns;
+  if (ns < 1 || ns > 255 || m < 0) return DM_ERR_INVALID_ARG;
+  if (!bn_shape_ok(n, c)) return n == 0 ? DM_OK : DM_ERR_UNSUPPORTED;
+  if (!x || !pooled || !argmax || !save_mean || !save_invstd || !partial || !counts || blocks < 1)
+    return DM_ERR_INVALID_ARG;
+  bn_finalize_kernel<<<c, 64, 0, st>>>(partial, blocks, n, c, eps, momentum, running_mean, running_var,
+                                       save_mean, save_invstd, counts);
+  DM_CHECK_LAUNCH();
+  const int gpb = 256 / (c / 4);
+  bn_apply_max_kernel<false><<<(unsigned)((m + gpb - 1) / gpb), 256, 0, st>>>(
+      x, m, ns, c, gamma, beta, save_mean, save_invstd, 0.f, pooled, argmax);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -32,7 +32,8 @@ constexpr int RG_MAXLD = RG_MAXK + 4;
 template <int NBW>
 __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                       float *__restrict__ Y, int R, int K, int N, int KP,
-                                                      int ldy, int col0) {
+                                                      int ldy, int col0, float *__restrict__ st_partial,
+                                                      float *__restrict__ st_counts) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int ld = KP + 4;                         // row stride of both operand tiles (floats)
   float *Ws = lds;                               // [NBW * 64][ld]   (row n: W[n][0..K), zero padded)
@@ -81,6 +82,17 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
   int tile = blockIdx.x;
   if (tile < n_tiles) fetch(tile);
   const int ldc = NBW * 64 + 4;
+  // optional per-column statistics of the output for the BatchNorm that follows (st_partial != nullptr):
+  // thread = (column, row slice); shifted sums (shift = the workgroup's first output row) over every row
+  // this workgroup produces, folded into (mean, M2) per column at the end — one partial per workgroup,
+  // merged by bn_finalize in workgroup order.  Replaces a full read of Y by bn_stats_kernel.
+  const int st_slices = N <= 256 ? 256 / N : 0;
+  const int st_col = tid % N, st_slice = tid / N;
+  const bool st_on = st_partial != nullptr && st_slices > 0 && st_slice < st_slices;
+  const int st_rows = st_slices > 0 ? (RG_ROWS + st_slices - 1) / st_slices : 0;
+  float st_k = 0.f, st_s1 = 0.f, st_s2 = 0.f;
+  bool st_first = true;
+  int st_cnt = 0;
   for (; tile < n_tiles; tile += gridDim.x) {
     __syncthreads();                              // previous tile's output rows have left Xs
     stage();
@@ -113,6 +125,18 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
       for (int r = 0; r < 16; ++r)
         cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ldc + (wn + 2 * b) * 32 + lr] = acc[b][r];
     __syncthreads();
+    if (st_partial != nullptr) {
+      const int valid = min(RG_ROWS, R - tile * RG_ROWS);
+      if (st_on) {
+        if (st_first) st_k = cs[st_col], st_first = false;          // row 0 of the first tile
+        const int r_lo = st_slice * st_rows, r_hi = min(r_lo + st_rows, valid);
+        for (int r = r_lo; r < r_hi; ++r) {
+          const float d = cs[r * ldc + st_col] - st_k;
+          st_s1 += d, st_s2 += d * d;
+        }
+      }
+      st_cnt += valid;
+    }
     // output rows are `ldy` floats wide and start at column col0; columns [0, col0) are zeros
     const int nq = N / 4, cq = col0 / 4;
     const int row0 = tile * RG_ROWS;
@@ -124,14 +148,41 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
       *(float4 *)(Y + (size_t)(row0 + r) * ldy + 4 * q) = v;
     }
   }
+  if (st_partial != nullptr) {                     // fold the row slices of each column, slice order
+    __syncthreads();
+    float *f1 = Xs, *f2 = Xs + 256;
+    f1[tid] = st_s1, f2[tid] = st_s2;
+    __syncthreads();
+    if (tid < N) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int sl = 0; sl < st_slices; ++sl) a1 += f1[sl * N + tid], a2 += f2[sl * N + tid];
+      const float cnt = (float)st_cnt;
+      const size_t nb = gridDim.x;
+      st_partial[(size_t)tid * nb + blockIdx.x] = cnt > 0.f ? st_k + a1 / cnt : 0.f;
+      st_partial[((size_t)N + tid) * nb + blockIdx.x] = cnt > 0.f ? a2 - a1 * a1 / cnt : 0.f;
+      if (tid == 0) st_counts[blockIdx.x] = cnt;
+    }
+  }
+}
+
+size_t rowgemm_smem(int K, int nbw) {
+  const int KP = (K + 7) / 8 * 8;
+  const int ld = KP + 4, ldc = nbw * 64 + 4;
+  return ((size_t)nbw * 64 * ld + 64 * (size_t)(ld > ldc ? ld : ldc)) * sizeof(float);
+}
+
+int rowgemm_grid(int R, size_t smem) {
+  const int n_tiles = (R + RG_ROWS - 1) / RG_ROWS;
+  int per_cu = (int)((150 * 1024) / smem);       // workgroups resident per CU (LDS bound)
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+  return n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu;
 }
 
 template <int NBW>
-int launch(const float *X, const float *W, float *Y, int R, int K, int N, int ldy, int col0, hipStream_t st) {
+int launch(const float *X, const float *W, float *Y, int R, int K, int N, int ldy, int col0, hipStream_t st,
+           float *st_partial = nullptr, float *st_counts = nullptr) {
   const int KP = (K + 7) / 8 * 8;
-  const int ld = KP + 4, ldc = NBW * 64 + 4;
-  const int xs = 64 * (ld > ldc ? ld : ldc);
-  const size_t smem = ((size_t)NBW * 64 * ld + xs) * sizeof(float);
+  const size_t smem = rowgemm_smem(K, NBW);
   static bool attr = false;
   if (!attr) {
     DM_HIP(hipFuncSetAttribute((const void *)rowgemm_kernel<NBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -139,11 +190,8 @@ int launch(const float *X, const float *W, float *Y, int R, int K, int N, int ld
     attr = true;
   }
   if (smem > 160 * 1024) return DM_ERR_UNSUPPORTED;
-  const int n_tiles = (R + RG_ROWS - 1) / RG_ROWS;
-  int per_cu = (int)((150 * 1024) / smem);       // workgroups resident per CU (LDS bound)
-  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
-  const int grid = n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu;
-  rowgemm_kernel<NBW><<<grid, 256, smem, st>>>(X, W, Y, R, K, N, KP, ldy, col0);
+  const int grid = rowgemm_grid(R, smem);
+  rowgemm_kernel<NBW><<<grid, 256, smem, st>>>(X, W, Y, R, K, N, KP, ldy, col0, st_partial, st_counts);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -165,6 +213,25 @@ extern "C" int dm_rowgemm_strided(const float *x, const float *w, float *y, long
   if (n <= 64) return launch<1>(x, w, y, (int)rows, k, n, ldy, col0, st);
   if (n <= 128) return launch<2>(x, w, y, (int)rows, k, n, ldy, col0, st);
   return launch<3>(x, w, y, (int)rows, k, n, ldy, col0, st);
+}
+
+// y = x . w^T plus the statistics of y's columns for the BatchNorm that follows: partial
+// (2, n, dm_rowgemm_parts(rows, k, n)) = per-workgroup (mean, M2) of every column, counts (parts) = rows per
+// workgroup — what dm_bn_rows_forward_pre / dm_bn_rows_max_forward_pre take instead of reading y again.
+extern "C" int dm_rowgemm_parts(long long rows, int k, int n) {
+  if (rows <= 0 || !dm_rowgemm_supported(k, n)) return 0;
+  return rowgemm_grid((int)rows, rowgemm_smem(k, n <= 64 ? 1 : (n <= 128 ? 2 : 3)));
+}
+
+extern "C" int dm_rowgemm_stats(const float *x, const float *w, float *y, long long rows, int k, int n,
+                                float *partial, float *counts, dm_stream_t stream) {
+  if (rows <= 0 || rows > 0x7fffffffLL / 256) return rows == 0 ? DM_OK : DM_ERR_INT32_RANGE;
+  if (!dm_rowgemm_supported(k, n) || n > 256) return DM_ERR_UNSUPPORTED;
+  if (!x || !w || !y || !partial || !counts) return DM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 64) return launch<1>(x, w, y, (int)rows, k, n, n, 0, st, partial, counts);
+  if (n <= 128) return launch<2>(x, w, y, (int)rows, k, n, n, 0, st, partial, counts);
+  return launch<3>(x, w, y, (int)rows, k, n, n, 0, st, partial, counts);
 }
 
 extern "C" int dm_rowgemm(const float *x, const float *w, float *y, long long rows, int k, int n,

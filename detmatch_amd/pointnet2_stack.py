@@ -218,13 +218,40 @@ class TallSkinnyLinear(Function):
         return y
 
     @staticmethod
-    def forward(ctx, x, w, dead_cols=0):
+    def _rowgemm_stats(x, w):
+        """_rowgemm that also reduces the column statistics of its output for the BatchNorm that follows
+        (per-workgroup (mean, M2) partials from the output tile it already holds in LDS): -> y with the
+        attribute `dm_bn_pre = (partial, counts, parts)`, or None if not taken."""
+        if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
+                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and os.environ.get('DM_ROWGEMM', '1') == '1'
+                and os.environ.get('DM_ROWGEMM_STATS', '1') == '1'):
+            return None
+        L = _lib.lib()
+        r, k = x.shape
+        n = w.shape[0]
+        if not L.dm_rowgemm_supported(k, n) or n > 256:
+            return None
+        x, w = x.contiguous(), w.contiguous()
+        parts = L.dm_rowgemm_parts(r, k, n)
+        y = torch.empty((r, n), dtype=torch.float32, device=x.device)
+        partial = torch.empty((2, n, parts), dtype=torch.float32, device=x.device)
+        counts = torch.empty((parts,), dtype=torch.float32, device=x.device)
+        _lib.check(L.dm_rowgemm_stats(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), r, k, n, _lib.ptr(partial),
+                                      _lib.ptr(counts), _lib.stream()), 'dm_rowgemm_stats')
+        y.dm_bn_pre = (partial, counts, parts)
+        return y
+
+    @staticmethod
+    def forward(ctx, x, w, dead_cols=0, bn_stats=False):
         """dead_cols: leading input columns nobody differentiates (the xyz + padding floats of a grouped
         row: QueryGroupRows.backward reads the feature columns only) — their input gradient is written
-        as zeros instead of being computed."""
+        as zeros instead of being computed.  bn_stats: a training-mode BatchNorm follows; its column
+        statistics ride along on the output (`dm_bn_pre`, read by bn_relu_rows / bn_relu_rows_max)."""
         ctx.save_for_backward(x, w)
         ctx.dead_cols = int(dead_cols)
-        y = TallSkinnyLinear._rowgemm(x, w)
+        y = TallSkinnyLinear._rowgemm_stats(x, w) if bn_stats else None
+        if y is None:
+            y = TallSkinnyLinear._rowgemm(x, w)
         return y if y is not None else x @ w.t()
 
     @staticmethod
@@ -245,7 +272,7 @@ class TallSkinnyLinear(Function):
                                x.view(split, rows // split, -1)).sum(dim=0)
             else:
                 gw = gy.t() @ x
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 def query_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None,
@@ -400,7 +427,8 @@ class StackSAModuleMSG(nn.Module):
                         w = _PadXyzColumn.apply(conv.weight)
                     else:
                         w = conv.weight.view(conv.out_channels, conv.in_channels)
-                    x = TallSkinnyLinear.apply(x, w, 4 if (li == 0 and g.use_xyz) else 0)
+                    x = TallSkinnyLinear.apply(x, w, 4 if (li == 0 and g.use_xyz) else 0,
+                                               bool(bn.training and conv.bias is None and fused_on()))
                     if conv.bias is not None:
                         x = x + conv.bias
                     if li == n_layers - 1 and fused_on():

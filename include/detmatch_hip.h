@@ -273,6 +273,18 @@ int dm_bn_rows_max_backward(const float *grad_pooled, const unsigned char *argma
                             int ns, int c, const float *gamma, const float *beta, const float *save_mean,
                             const float *save_invstd, float *grad_x, float *grad_gamma, float *grad_beta,
                             void *workspace, size_t workspace_bytes, dm_stream_t stream);
+/* dm_bn_rows_forward / dm_bn_rows_max_forward with the column statistics already reduced to `blocks`
+ * partials (layout (2, c, blocks): mean, M2) over counts[b] rows each (dm_rowgemm_stats): no pass over x for
+ * the statistics. */
+int dm_bn_rows_forward_pre(const float *x, long long n, int c, const float *gamma, const float *beta, float eps,
+                           float momentum, float *running_mean, float *running_var, int relu, float *y,
+                           float *save_mean, float *save_invstd, const float *partial, const float *counts,
+                           int blocks, dm_stream_t stream);
+int dm_bn_rows_max_forward_pre(const float *x, long long m, int ns, int c, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean,
+                               float *running_var, float *pooled, unsigned char *argmax, float *save_mean,
+                               float *save_invstd, const float *partial, const float *counts, int blocks,
+                               dm_stream_t stream);
 /* The same in evaluation mode (running statistics, no gradient): one launch. */
 int dm_bn_rows_eval_max(const float *x, long long m, int ns, int c, const float *gamma, const float *beta,
                         const float *running_mean, const float *running_var, float eps, float *pooled,
@@ -328,6 +340,11 @@ int dm_bbox2d_transform(const float *boxes_or_grad, int n, float scale_x, float 
  * k, n multiples of 4, k <= 136, n <= 192; fp32 MFMA, weights resident in LDS. */
 int dm_rowgemm_supported(int k, int n);
 int dm_rowgemm(const float *x, const float *w, float *y, long long rows, int k, int n, dm_stream_t stream);
+/* y = x . w^T plus the statistics of y's columns for the BatchNorm that follows: partial
+ * (2, n, dm_rowgemm_parts(rows, k, n)) per-workgroup (mean, M2), counts (parts) rows per workgroup. */
+int dm_rowgemm_parts(long long rows, int k, int n);
+int dm_rowgemm_stats(const float *x, const float *w, float *y, long long rows, int k, int n, float *partial,
+                     float *counts, dm_stream_t stream);
 /* The same into rows of `ldy` floats starting at column `col0` (columns [0, col0) are written as zeros):
  * the input gradient of a first shared-MLP layer without the xyz / padding columns nobody differentiates. */
 int dm_rowgemm_strided(const float *x, const float *w, float *y, long long rows, int k, int n, int ldy,

@@ -589,3 +589,37 @@ def test_ball_query_pair_equals_two_queries(orc, dev, counts):
             oidx, oempty = orc.ball_query(r, n, xyz, xyz_cnt, new_xyz, new_cnt)
             assert np.array_equal(idx.cpu().numpy(), oidx)
             assert np.array_equal(empty.cpu().numpy(), oempty)
+
+
+@pytest.mark.parametrize('rows,k,n,ns', [(70016, 132, 64, 16), (65536, 36, 32, 16), (131072, 20, 16, 32),
+                                         (40000, 64, 128, 16), (33007 * 16, 64, 64, 16)])
+def test_rowgemm_statistics_feed_the_batchnorm(dev, rows, k, n, ns):
+    """dm_rowgemm_stats: the column statistics reduced in the GEMM's epilogue give the same BatchNorm
+    (+ReLU, + max over nsample) output, running statistics and gradients as the separate statistics pass."""
+    import torch.nn as nn
+    from detmatch_amd.bn_relu import bn_relu_rows, bn_relu_rows_max
+    from detmatch_amd.pointnet2_stack import TallSkinnyLinear
+    g = torch.Generator().manual_seed(rows % 1000 + k)
+    x0 = (torch.randn(rows, k, generator=g) + 0.3).to(dev)
+    w0 = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    prev = TallSkinnyLinear.ROWGEMM_MIN_ROWS
+    TallSkinnyLinear.ROWGEMM_MIN_ROWS = 0
+    try:
+        for pooled in (False, True):
+            res = []
+            for stats in (True, False):
+                bn = nn.BatchNorm2d(n, eps=1e-3, momentum=0.01).to(dev)
+                x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+                y = TallSkinnyLinear.apply(x, w, 0, stats)
+                assert (getattr(y, 'dm_bn_pre', None) is not None) == stats
+                out = bn_relu_rows_max(y, bn, ns) if pooled else bn_relu_rows(y, bn, relu=True)
+                out.backward(torch.ones_like(out) * 0.5 + out.detach() * 0.1)
+                res.append((out.detach(), bn.running_mean.clone(), bn.running_var.clone(), x.grad.clone(),
+                            bn.weight.grad.clone()))
+            a, b = res
+            assert float((a[0] - b[0]).abs().max()) <= 2e-5 * (float(b[0].abs().max()) + 1.0)
+            assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-7) and torch.allclose(a[2], b[2], rtol=1e-4, atol=1e-7)
+            assert float((a[3] - b[3]).abs().max()) <= 1e-4 * (float(b[3].abs().max()) + 1e-9)
+            assert float((a[4] - b[4]).abs().max()) <= 1e-3 * (float(b[4].abs().max()) + 1e-6)
+    finally:
+        TallSkinnyLinear.ROWGEMM_MIN_ROWS = prev
