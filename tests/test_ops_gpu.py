@@ -623,3 +623,27 @@ def test_rowgemm_statistics_feed_the_batchnorm(dev, rows, k, n, ns):
             assert float((a[4] - b[4]).abs().max()) <= 1e-3 * (float(b[4].abs().max()) + 1e-6)
     finally:
         TallSkinnyLinear.ROWGEMM_MIN_ROWS = prev
+
+
+@pytest.mark.parametrize('c', [32, 128])
+def test_query_group_rows_half_wave_kernel(dev, c):
+    """The 16-references-per-wave grouping kernel (taken from 64 k references) == rows assembled with
+    tensor indexing from the ball-query result: [xyz - centre, 0, features], zero rows for empty balls."""
+    from detmatch_amd import pointnet2_stack as pn
+    rng = np.random.default_rng(c)
+    xyz_cnt, new_cnt = [3000, 1700], [2600, 2400]
+    xyz = torch.from_numpy(_stacked(rng, xyz_cnt, 0, 12)).to(dev)
+    new_xyz = torch.from_numpy(_stacked(rng, new_cnt, -2, 14)).to(dev)          # some centres see nothing
+    feats = torch.from_numpy(rng.standard_normal((sum(xyz_cnt), c)).astype(np.float32)).to(dev)
+    xc = torch.tensor(xyz_cnt, dtype=torch.int32, device=dev)
+    nc = torch.tensor(new_cnt, dtype=torch.int32, device=dev)
+    ns = 16
+    rows, idx = pn.query_group_rows(0.9, ns, xyz, xc, new_xyz, nc, feats, True)
+    assert rows.shape == (5000, ns, 4 + c) and 5000 * ns >= 65536
+    _, empty = pn.ball_query(0.9, ns, xyz, xc, new_xyz, nc)
+    assert 0 < int(empty.sum()) < 5000
+    start = torch.cat([torch.zeros(new_cnt[0], dtype=torch.long), torch.full((new_cnt[1],), xyz_cnt[0])]).to(dev)
+    src = idx.long() + start[:, None]
+    want = torch.cat([xyz[src] - new_xyz[:, None, :], torch.zeros(5000, ns, 1, device=dev), feats[src]], dim=2)
+    want[empty] = 0
+    assert torch.equal(rows, want)
