@@ -370,7 +370,10 @@ class RPNHead(nn.Module):
         img_hw = []
         for m in img_metas:
             img_hw += [float(m['img_shape'][0]), float(m['img_shape'][1])]
-        ws = _lib.workspace(L.dm_rpn_proposals_workspace_bytes(b, t), dev, 'rpn_props')
+        # + one selection key per anchor and image (optional part of the workspace: the keys are then
+        # computed once by a chip-wide pre-pass instead of four times inside the one-CU selection kernel)
+        ws = _lib.workspace(L.dm_rpn_proposals_workspace_bytes(b, t) + b * int(anchors.shape[0]) * 4 + 512, dev,
+                            'rpn_props')
         coder = self.bbox_coder
         _lib.check(L.dm_rpn_proposals_pre_nms(
             _ptr_array(ys), _lib.ints(hw), len(ys), a, c, _lib.ptr(anchors), int(anchors.shape[0]), b,
