@@ -39,12 +39,27 @@ def _stamp():
     return h.hexdigest()
 
 
+def _src_stamp(src):
+    """Hash of one source, the shared headers and the flags: an object is rebuilt only when this changes."""
+    h = hashlib.sha1()
+    for f in [src] + HEADERS:
+        with open(os.path.join(HERE, f), 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def _compile(src):
     obj = os.path.join(HERE, src.replace('.hip', '.o'))
+    tag, want = obj + '.stamp', _src_stamp(src)
+    if os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == want:
+        return obj
     cmd = [_hipcc()] + FLAGS + ['-c', os.path.join(HERE, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+    with open(tag, 'w') as fh:
+        fh.write(want)
     return obj
 
 
@@ -55,6 +70,11 @@ def build(force=False, verbose=False):
             and open(stamp_file).read() == stamp):
         return LIB
     srcs = _sources()
+    if force:
+        for s_ in srcs:
+            t_ = os.path.join(HERE, s_.replace('.hip', '.o.stamp'))
+            if os.path.exists(t_):
+                os.remove(t_)
     if verbose:
         print('[detmatch_amd] hipcc', ' '.join(FLAGS), srcs, file=sys.stderr)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:

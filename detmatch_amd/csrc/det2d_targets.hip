@@ -297,13 +297,12 @@ __global__ __launch_bounds__(1024) void rpn_loss_kernel(Det2DBatch d, RpnLevels 
     n = sel_idx[((size_t)b * 2 + (pos ? 0 : 1)) * kSelMax + min(jj, kSelMax - 1)];
     return pos ? jj < pc : (jj < nc && jj < num - pc);
   };
-  double cnt = 0.0;
-  for (int e = tid; e < total; e += 1024) {
-    bool pos;
-    int n;
-    cnt += entry_ok(e / per, e % per, pos, n) ? 1.0 : 0.0;
+  // mmdet anchor_head.py get_targets: num_total_samples = sum_i max(#pos_i, 1) + sum_i max(#neg_i, 1)
+  int cnt = 0;
+  for (int b = 0; b < B; ++b) {
+    const int pc = min(sel_cnt[b * 2], want_pos), nc = max(min(min(sel_cnt[b * 2 + 1], want_neg), num - pc), 0);
+    cnt += max(pc, 1) + max(nc, 1);
   }
-  cnt = block_sum_1024(cnt, red);
   const float inv = 1.f / fmaxf((float)cnt, 1.f);
   double s_cls = 0.0, s_box = 0.0;
   for (int e = tid; e < total; e += 1024) {

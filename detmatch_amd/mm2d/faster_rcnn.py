@@ -308,7 +308,8 @@ class RPNHead(nn.Module):
 
     def loss(self, cls, reg, gt_bboxes, img_metas, fused=None, keys=None):
         """mmdet AnchorHead.loss with sampling: BCE over the 256 sampled anchors, L1 over encoded
-        deltas of the sampled positives, both / num_total_samples (summed over the batch)."""
+        deltas of the sampled positives, both / num_total_samples = sum over the images of max(#pos, 1) +
+        max(#neg, 1) (anchor_head.py get_targets)."""
         cfg = self.train_cfg
         a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
         sizes = [c.shape[-2:] for c in cls]
@@ -346,8 +347,8 @@ class RPNHead(nn.Module):
             bce = F.binary_cross_entropy_with_logits(scores[i, idx], label, reduction='none')
             tot_cls = tot_cls + (bce * w).sum()
             tot_box = tot_box + ((deltas[i, ip] - tgt).abs() * pos_ok[:, None].float()).sum()
-            tot_n = tot_n + w.sum()
-        tot_n = tot_n.clamp(min=1.0) if torch.is_tensor(tot_n) else max(tot_n, 1.0)
+            # mmdet anchor_head.py get_targets: num_total_samples = sum_i max(#pos_i, 1) + sum_i max(#neg_i, 1)
+            tot_n = tot_n + pos_ok.sum().clamp(min=1).float() + neg_ok.sum().clamp(min=1).float()
         return dict(loss_rpn_cls=self.loss_cls_weight * tot_cls / tot_n,
                     loss_rpn_bbox=self.loss_bbox_weight * tot_box / tot_n)
 
