@@ -213,3 +213,48 @@ def test_point_focal_kernel_matches_reference_value_and_autograd(dev):
         res.append((loss.detach(), preds.grad.clone()))
     close(res[0][0], res[1][0], rtol=1e-5)
     close(res[0][1], res[1][1], rtol=1e-4, atol=1e-9)
+
+
+S = np.load(os.path.join(GOLD, 'pcdet_roi_sampler.npz'))
+
+
+@pytest.mark.parametrize('case', range(int(S['n_cases'])))
+def test_roi_target_kernel_against_reference_target_layer(dev, case):
+    """dm_roi_targets (max IoU with the same class, sampling, canonical transform) against the REFERENCE's
+    ProposalTargetLayer.forward + RoIHeadTemplate.assign_targets (tests/golden/gen_roi_sampler_golden.py):
+    every sampled row carries the reference's per-RoI IoU / assigned GT / reg_valid_mask / soft label /
+    canonical GT, and the sample has the reference's foreground / hard / easy background counts (which rows
+    are drawn is random in the reference too)."""
+    h = _head(dev)
+    k = 's%d_' % case
+    bd = dict(batch_size=2, rois=torch.from_numpy(S[k + 'rois']).to(dev),
+              roi_scores=torch.from_numpy(S[k + 'roi_scores']).to(dev),
+              roi_labels=torch.from_numpy(S[k + 'roi_labels']).to(dev),
+              gt_boxes=torch.from_numpy(S[k + 'gt_boxes']).to(dev),
+              roi_scores_full=torch.from_numpy(S[k + 'roi_scores_full']).to(dev).requires_grad_(True))
+    torch.manual_seed(3 + case)
+    td = h.assign_targets(bd)
+    rois_in = S[k + 'rois']
+    got = {n: td[n].detach().cpu().numpy() for n in ('rois', 'gt_iou_of_rois', 'reg_valid_mask', 'rcnn_cls_labels',
+                                                     'gt_of_rois', 'gt_of_rois_src', 'roi_labels', 'roi_scores')}
+    for b in range(2):
+        index = {rois_in[b, j].tobytes(): j for j in range(rois_in.shape[1])}
+        src = np.array([index[r.tobytes()] for r in got['rois'][b]])            # every output row is an input row
+        np.testing.assert_allclose(got['gt_iou_of_rois'][b], S[k + 'all_iou'][b, src], rtol=0, atol=2e-6)
+        assert np.array_equal(got['gt_of_rois_src'][b], S[k + 'all_gt_of_rois_src'][b, src])     # assigned GT: exact
+        assert np.array_equal(got['roi_labels'][b], S[k + 'roi_labels'][b, src])
+        assert np.array_equal(got['roi_scores'][b], S[k + 'roi_scores'][b, src])
+        # rows whose IoU sits within 2e-6 of a threshold may fall on either side; none in these scenes
+        iou = S[k + 'all_iou'][b, src]
+        edge = np.min(np.abs(iou[:, None] - np.array([0.1, 0.25, 0.55, 0.75])[None]), 1) < 1e-5
+        assert not edge.any()
+        assert np.array_equal(got['reg_valid_mask'][b], S[k + 'all_reg_valid'][b, src])
+        np.testing.assert_allclose(got['rcnn_cls_labels'][b], S[k + 'all_cls_labels'][b, src], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(got['gt_of_rois'][b], S[k + 'all_gt_of_rois'][b, src], rtol=1e-5, atol=3e-5)
+        # the sample's structure == the reference's sample
+        g_iou = got['gt_iou_of_rois'][b]
+        assert int((g_iou >= 0.55).sum()) == int(S[k + 'smp_n_fg'][b])
+        assert int(((g_iou < 0.55) & (g_iou >= 0.1)).sum()) == int(S[k + 'smp_n_hard'][b])
+        assert int((g_iou < 0.1).sum()) == int(S[k + 'smp_n_easy'][b])
+        fg = src[g_iou >= 0.55]
+        assert len(np.unique(fg)) == len(fg)                                   # foreground: without replacement
