@@ -86,6 +86,8 @@ SIGNATURES = {
     'dm_sgd_step_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp]),
     'dm_adamw_step_masked_f32': (ci, [vp, vp, vp, vp, sz, cd, cd, cd, cd, cd, ctypes.c_longlong, vp, vp, vp]),
     'dm_sgd_step_masked_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ci, vp, vp, vp]),
+    'dm_adamw_step_blocks_f32': (ci, [vp, vp, vp, vp, sz, cd, cd, cd, cd, cd, ctypes.c_longlong, vp, vp, vp, vp]),
+    'dm_sgd_step_blocks_f32': (ci, [vp, vp, vp, sz, cd, cd, cd, cd, ctypes.c_longlong, vp, vp, vp, vp]),
     'dm_anchor_assign_workspace_bytes': (sz, [ci, ci, ci]),
     'dm_anchor_assign': (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
     'dm_bev_interpolate_forward': (ci, [vp, ci, ci, ci, ci, vp, ci, ci, c_f32_p, vp, vp, vp, vp]),

@@ -66,11 +66,24 @@ __global__ __launch_bounds__(256) void adamw_f32_kernel(float *__restrict__ p,
                                                         float *__restrict__ m, float *__restrict__ v,
                                                         size_t n, AdamWArgs a,
                                                         const float *__restrict__ grad_scale,
-                                                        const unsigned char *__restrict__ live) {
+                                                        const unsigned char *__restrict__ live,
+                                                        const int *__restrict__ first_step, long long step,
+                                                        double lr, double beta1, double beta2) {
   const float gs = grad_scale ? *grad_scale : 1.0f;
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   if (live && !live[i >> 2]) return;   // parameter never received a gradient: torch skips it
+  if (first_step) {
+    // torch.optim.AdamW keeps a per-parameter step that starts at 1 with the parameter's FIRST gradient:
+    // a parameter that became live at step f > 1 takes its bias corrections from step - f + 1
+    const int f = first_step[i >> 2];
+    if (f <= 0) return;
+    if (f > 1) {
+      const double t = (double)(step - f + 1);
+      a.step_size = (float)(lr / (1.0 - pow(beta1, t)));
+      a.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
+    }
+  }
   const int cnt = (int)(n - i < 4 ? n - i : 4);
   float pv[4], gv[4], mv[4], vv[4];
   if (cnt == 4) {
@@ -105,11 +118,17 @@ __global__ __launch_bounds__(256) void sgd_f32_kernel(float *__restrict__ p,
                                                       float *__restrict__ buf, size_t n, float lr,
                                                       float momentum, float dampening, float wd,
                                                       int first, const float *__restrict__ grad_scale,
-                                                      const unsigned char *__restrict__ live) {
+                                                      const unsigned char *__restrict__ live,
+                                                      const int *__restrict__ first_step, long long step) {
   const float gs = grad_scale ? *grad_scale : 1.0f;
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   if (live && !live[i >> 2]) return;
+  if (first_step) {          // torch.optim.SGD creates a parameter's momentum buffer at ITS first gradient
+    const int f = first_step[i >> 2];
+    if (f <= 0) return;
+    first = (long long)f == step;
+  }
   const int cnt = (int)(n - i < 4 ? n - i : 4);
   for (int k = 0; k < cnt; ++k) {
     const float pk = p[i + k];
@@ -125,11 +144,12 @@ __global__ __launch_bounds__(256) void sgd_f32_kernel(float *__restrict__ p,
 
 }  // namespace
 
-extern "C" int dm_adamw_step_masked_f32(float *params, const float *grads, float *exp_avg,
+extern "C" int dm_adamw_step_blocks_f32(float *params, const float *grads, float *exp_avg,
                                         float *exp_avg_sq, size_t n, double lr, double beta1,
                                         double beta2, double eps, double weight_decay,
                                         long long step, const float *grad_scale_dev,
-                                        const unsigned char *block_live, dm_stream_t stream) {
+                                        const unsigned char *block_live, const int *block_first_step,
+                                        dm_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) return DM_OK;
   if (!params || !grads || !exp_avg || !exp_avg_sq || step < 1) return DM_ERR_INVALID_ARG;
@@ -145,9 +165,19 @@ extern "C" int dm_adamw_step_masked_f32(float *params, const float *grads, float
   a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   a.eps = (float)eps;
   adamw_f32_kernel<<<dm_ceil_div((long long)((n + 3) / 4), 256), 256, 0, st>>>(
-      params, grads, exp_avg, exp_avg_sq, n, a, grad_scale_dev, block_live);
+      params, grads, exp_avg, exp_avg_sq, n, a, grad_scale_dev, block_live, block_first_step, step, lr, beta1,
+      beta2);
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+
+extern "C" int dm_adamw_step_masked_f32(float *params, const float *grads, float *exp_avg,
+                                        float *exp_avg_sq, size_t n, double lr, double beta1,
+                                        double beta2, double eps, double weight_decay,
+                                        long long step, const float *grad_scale_dev,
+                                        const unsigned char *block_live, dm_stream_t stream) {
+  return dm_adamw_step_blocks_f32(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                                  step, grad_scale_dev, block_live, nullptr, stream);
 }
 
 extern "C" int dm_adamw_step_f32(float *params, const float *grads, float *exp_avg,
@@ -158,19 +188,28 @@ extern "C" int dm_adamw_step_f32(float *params, const float *grads, float *exp_a
                                   weight_decay, step, grad_scale_dev, nullptr, stream);
 }
 
+extern "C" int dm_sgd_step_blocks_f32(float *params, const float *grads, float *momentum_buf,
+                                      size_t n, double lr, double momentum, double dampening,
+                                      double weight_decay, long long step,
+                                      const float *grad_scale_dev, const unsigned char *block_live,
+                                      const int *block_first_step, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return DM_OK;
+  if (!params || !grads || (momentum != 0.0 && !momentum_buf) || step < 1) return DM_ERR_INVALID_ARG;
+  sgd_f32_kernel<<<dm_ceil_div((long long)((n + 3) / 4), 256), 256, 0, st>>>(
+      params, grads, momentum_buf, n, (float)lr, (float)momentum, (float)dampening,
+      (float)weight_decay, step == 1 ? 1 : 0, grad_scale_dev, block_live, block_first_step, step);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
 extern "C" int dm_sgd_step_masked_f32(float *params, const float *grads, float *momentum_buf,
                                       size_t n, double lr, double momentum, double dampening,
                                       double weight_decay, int first_step,
                                       const float *grad_scale_dev, const unsigned char *block_live,
                                       dm_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if (n == 0) return DM_OK;
-  if (!params || !grads || (momentum != 0.0 && !momentum_buf)) return DM_ERR_INVALID_ARG;
-  sgd_f32_kernel<<<dm_ceil_div((long long)((n + 3) / 4), 256), 256, 0, st>>>(
-      params, grads, momentum_buf, n, (float)lr, (float)momentum, (float)dampening,
-      (float)weight_decay, first_step, grad_scale_dev, block_live);
-  DM_CHECK_LAUNCH();
-  return DM_OK;
+  return dm_sgd_step_blocks_f32(params, grads, momentum_buf, n, lr, momentum, dampening, weight_decay,
+                                first_step ? 1 : 2, grad_scale_dev, block_live, nullptr, stream);
 }
 
 extern "C" int dm_sgd_step_f32(float *params, const float *grads, float *momentum_buf, size_t n,

@@ -364,8 +364,20 @@ def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, t
         raise NotImplementedError('fp16 optimizer hook: mixed precision is not implemented (DESIGN.md)')
     custom = [build_from_cfg(dict(h), HOOKS) for h in cfg.get('custom_hooks', [])]
     runner.register_training_hooks(cfg['lr_config'], cfg['optimizer_config'], custom_hooks=custom,
-                                   momentum_config=cfg.get('momentum_config', None))
+                                   momentum_config=cfg.get('momentum_config', None),
+                                   checkpoint_config=cfg.get('checkpoint_config', None),
+                                   log_config=cfg.get('log_config', None))
     if validate:
         raise NotImplementedError('validation hook: use SSL.simple_test + KittiDataset.evaluate')
+    # ssl_train.py:157-166
+    if cfg.get('resume_from', None):
+        runner.resume(cfg['resume_from'])
+    elif cfg.get('load_from', None):
+        runner.load_checkpoint(cfg['load_from'])
+    elif cfg.get('load_from_with_optimizer', None):
+        runner.resume(cfg['load_from_with_optimizer'])      # "bootstrapped resume": weights + optimizer, counters reset
+        runner._epoch = 0
+        runner._iter = 0
+        runner.meta = {}
     runner.run(loaders, cfg.get('workflow', [('train', 1)]))
     return runner

@@ -89,6 +89,8 @@ class FlatGradDDP(nn.Module):
         self._probe = None
         self._mark_cache = {}
         self._fired = set()
+        self._local_ever = set()    # arena indices that got a gradient on THIS rank (host knowledge)
+        self._dead_cache = None
         self.offset = {}                                 # id(param) -> first element
         self.flat_params = None                          # set by build_param_arena / SSL.build_arenas
         self.buckets = []          # (start, end) element ranges of self.flat
@@ -197,6 +199,9 @@ class FlatGradDDP(nn.Module):
         """used[idxs] = 1 (index tensors cached per distinct set: no H2D copy in the steady state)."""
         if not idxs:
             return
+        if not self._local_ever.issuperset(idxs):
+            self._local_ever.update(idxs)
+            self._dead_cache = None
         key = tuple(idxs)
         t = self._mark_cache.get(key)
         if t is None:
@@ -259,6 +264,7 @@ class FlatGradDDP(nn.Module):
         self._pending = []
         if self.world > 1:
             self.flat.div_(self.world)
+            self._dead_cache = None          # other ranks' flags arrived with the last bucket
         self._update_live()
 
     # ---- liveness ---------------------------------------------------------------------
@@ -294,12 +300,20 @@ class FlatGradDDP(nn.Module):
         return self.block_live[lo // 4:(hi + 3) // 4]
 
     def dead_params(self):
-        """Parameters no rank has produced a gradient for so far (host read-back: slow path, used
-        by non-fused optimizers and state_dict only)."""
+        """Parameters no rank has produced a gradient for so far (used by non-fused optimizers and
+        state_dict only).  One rank: exact from host knowledge (which parameters fired), no read-back.
+        Several ranks: a parameter may be live on another rank only, so the all-reduced flags are read back —
+        once per exchange (cached until the next finish()), and only while some parameter is still dead."""
         if self._all_live:
             return []
-        ever = self.ever.cpu().tolist()
-        return [p for p, e in zip(self.order, ever) if not e]
+        if self.world <= 1:
+            if self._dead_cache is None:
+                self._dead_cache = [p for i, p in enumerate(self.order) if i not in self._local_ever]
+            return self._dead_cache
+        if self._dead_cache is None:
+            ever = self.ever.cpu().tolist()
+            self._dead_cache = [p for p, e in zip(self.order, ever) if not e]
+        return self._dead_cache
 
     def clip_coef(self, max_norm, norm_type=2):
         """-> (total_norm, coef) device scalars of clip_grad_norm_; nothing is scaled (the fused

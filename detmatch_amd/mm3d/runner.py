@@ -77,13 +77,17 @@ class HybridOptimizer(torch.optim.Optimizer):
                     fused[i].step(getattr(self, 'grad_scale', None))
                 else:
                     ddp = getattr(self, '_ddp', None)
+                    hidden = []
                     if ddp is not None:      # never-used parameters: .grad None, as in the reference
                         dead = set(id(p) for p in ddp.dead_params())
                         for g in o.param_groups:
                             for p in g['params']:
-                                if id(p) in dead:
+                                if id(p) in dead and p.grad is not None:
+                                    hidden.append((p, p.grad))
                                     p.grad = None
                     o.step()
+                    for p, g in hidden:      # the arena views stay in place (hooks mode accumulates into them)
+                        p.grad = g
         self.grad_scale = None
         return loss
 
@@ -117,6 +121,10 @@ class FusedRange(object):
             self.buf = torch.zeros(n, device=dev)
         self.step_t = torch.zeros((), dtype=torch.float32)
         self.params = list(params)
+        # first[block] = optimizer step of the parameter's first gradient (0 = none yet): torch.optim counts
+        # steps / creates momentum buffers PER PARAMETER.  Dropped (scalar step for everybody) once every
+        # parameter is live and none of them started late.
+        self.first = torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev)
         if any(opt.state.get(p, None) for p in self.params):
             self.adopt_loaded_state()      # built after a resume: keep the loaded state
         else:
@@ -142,6 +150,13 @@ class FusedRange(object):
         self._publish()
         for p in self.ddp.dead_params():
             self.opt.state.pop(p, None)
+        if self.first is not None and self.kind == 'adamw':
+            first = self.first.cpu()
+            for p in self.params:
+                st = self.opt.state.get(p, None)
+                f = int(first[(self.ddp.offset[id(p)] - self.lo) // 4])
+                if st and f > 0:
+                    st['step'] = torch.tensor(float(self.t - f + 1))
 
     @torch.no_grad()
     def adopt_loaded_state(self):
@@ -162,9 +177,20 @@ class FusedRange(object):
                 self.buf[o:o + p.numel()].copy_(st['momentum_buffer'].reshape(-1))
                 steps.append(1)           # momentum buffer exists: not the first step any more
         if steps:
-            assert len(set(steps)) == 1, 'parameters of one fused range must share the step count'
-            self.t = steps[0]
+            # per-parameter step counts: the range's count is the largest, a parameter that started late
+            # has first = t - step + 1
+            self.t = max(steps)
             self.step_t.fill_(self.t)
+            first = torch.zeros(self.first.numel() if self.first is not None else (self.hi - lo + 3) // 4,
+                                dtype=torch.int32)
+            for p in self.params:
+                st = self.opt.state.get(p, None)
+                if not st:
+                    continue
+                o = (self.ddp.offset[id(p)] - lo) // 4
+                step = int(st['step']) if self.kind == 'adamw' else self.t
+                first[o:o + (p.numel() + 3) // 4] = self.t - step + 1
+            self.first = first.to(self.m.device if self.kind == 'adamw' else self.buf.device)
         self._publish()
 
     @staticmethod
@@ -208,16 +234,25 @@ class FusedRange(object):
         # parameters that never received a gradient are skipped, as torch.optim skips .grad None
         mask = d.live_mask(self.lo, self.hi)
         mk = _lib.ptr(mask) if mask is not None else None
+        if self.first is not None:
+            if mask is not None:       # blocks that turned live this step start counting now
+                torch.where((self.first == 0) & (mask > 0), torch.full_like(self.first, self.t), self.first,
+                            out=self.first)
+            elif d._all_live:          # every parameter is live: keep the vector only if somebody started late
+                self.first.masked_fill_(self.first == 0, self.t)
+                if not bool((self.first > 1).any()):      # one read-back, once
+                    self.first = None
+        fs = _lib.ptr(self.first) if self.first is not None else None
         if self.kind == 'adamw':
-            _lib.check(L.dm_adamw_step_masked_f32(
+            _lib.check(L.dm_adamw_step_blocks_f32(
                 _lib.ptr(p), _lib.ptr(g), _lib.ptr(self.m), _lib.ptr(self.v), n, g0['lr'],
-                g0['betas'][0], g0['betas'][1], g0['eps'], g0['weight_decay'], self.t, gs, mk,
-                _lib.stream()), 'dm_adamw_step_masked_f32')
+                g0['betas'][0], g0['betas'][1], g0['eps'], g0['weight_decay'], self.t, gs, mk, fs,
+                _lib.stream()), 'dm_adamw_step_blocks_f32')
         else:
-            _lib.check(L.dm_sgd_step_masked_f32(
+            _lib.check(L.dm_sgd_step_blocks_f32(
                 _lib.ptr(p), _lib.ptr(g), _lib.ptr(self.buf), n, g0['lr'], g0['momentum'],
-                g0['dampening'], g0['weight_decay'], int(self.t == 1), gs, mk, _lib.stream()),
-                'dm_sgd_step_masked_f32')
+                g0['dampening'], g0['weight_decay'], self.t, gs, mk, fs, _lib.stream()),
+                'dm_sgd_step_blocks_f32')
 
 
 @OPTIMIZER_BUILDERS.register_module()
@@ -468,6 +503,54 @@ class CyclicMomentumUpdaterHook(_CyclicHook):
                 g['betas'] = (m, g['betas'][1])
 
 
+@HOOKS.register_module()
+class CheckpointHook(Hook):
+    """mmcv CheckpointHook (1.3.16; un-vendored: parity unpinned): every `interval` iterations
+    (by_epoch=False -> iter_{n}.pth) or epochs (epoch_{n}.pth) rank 0 writes model + optimizer + meta and
+    points latest.pth at it; `max_keep_ckpts` > 0 removes older files (configs/detmatch/*: interval 5000,
+    by_epoch False)."""
+
+    def __init__(self, interval=-1, by_epoch=True, save_optimizer=True, out_dir=None, max_keep_ckpts=-1,
+                 save_last=True, **kwargs):
+        self.interval, self.by_epoch, self.save_optimizer = interval, by_epoch, save_optimizer
+        self.out_dir, self.max_keep_ckpts, self.save_last = out_dir, max_keep_ckpts, save_last
+
+    def before_run(self, runner):
+        if not self.out_dir:
+            self.out_dir = runner.work_dir
+
+    def _save(self, runner, n, tmpl):
+        if self.out_dir is None or not _is_rank0():
+            return
+        runner.save_checkpoint(self.out_dir, filename_tmpl=tmpl, save_optimizer=self.save_optimizer)
+        if self.max_keep_ckpts > 0:
+            for old in range(n - self.max_keep_ckpts * self.interval, 0, -self.interval):
+                path = os.path.join(self.out_dir, tmpl.format(old))
+                if not os.path.exists(path):
+                    break
+                os.remove(path)
+
+    def after_train_iter(self, runner):
+        if self.by_epoch or self.interval <= 0:
+            return
+        n = runner.iter + 1
+        if n % self.interval == 0 or (self.save_last and runner.max_iters is not None and n == runner.max_iters):
+            self._save(runner, n, 'iter_{}.pth')
+
+    def after_train_epoch(self, runner):
+        if not self.by_epoch or self.interval <= 0:
+            return
+        n = runner.epoch + 1
+        last = getattr(runner, 'max_epochs', None)
+        if n % self.interval == 0 or (self.save_last and last is not None and n == last):
+            self._save(runner, n, 'epoch_{}.pth')
+
+
+def _is_rank0():
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 class _PassThroughHook(Hook):
     def __init__(self, **kwargs):
         pass
@@ -544,11 +627,54 @@ class _RunnerBase(object):
             hook = build_from_cfg(hook, HOOKS)
         self._hooks.append(hook)
 
+    # ---- checkpoints (mmcv BaseRunner.save_checkpoint / load_checkpoint / resume; mmcv format:
+    # dict(meta=dict(epoch, iter, ...), state_dict=..., optimizer=...), 'module.' prefix stripped)
+    def save_checkpoint(self, out_dir, filename_tmpl=None, save_optimizer=True, meta=None, create_symlink=True):
+        by_iter = isinstance(self, IterBasedSSLRunner)
+        if filename_tmpl is None:
+            filename_tmpl = 'iter_{}.pth' if by_iter else 'epoch_{}.pth'
+        n = self.iter + 1 if by_iter else self.epoch + 1
+        info = dict(meta or {}, iter=self.iter + 1 if by_iter else self.iter, epoch=self.epoch + 1)
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, filename_tmpl.format(n))
+        ckpt = dict(meta=info, state_dict={k: v.detach().cpu() for k, v in _inner(self.model).state_dict().items()})
+        if save_optimizer and self.optimizer is not None:
+            ckpt['optimizer'] = self.optimizer.state_dict()
+        torch.save(ckpt, path)
+        if create_symlink:
+            link = os.path.join(out_dir, 'latest.pth')
+            if os.path.lexists(link):
+                os.remove(link)
+            try:
+                os.symlink(os.path.basename(path), link)
+            except OSError:
+                import shutil
+                shutil.copy(path, link)
+        return path
+
+    def load_checkpoint(self, filename, map_location='cpu', strict=False):
+        ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+        sd = ckpt.get('state_dict', ckpt)
+        sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+        _inner(self.model).load_state_dict(sd, strict=strict)
+        from .. import dense_conv
+        dense_conv.weights_changed()          # every packed copy of a convolution weight is stale now
+        return ckpt
+
+    def resume(self, checkpoint, resume_optimizer=True, map_location='cpu'):
+        ckpt = self.load_checkpoint(checkpoint, map_location=map_location)
+        self._epoch = ckpt['meta']['epoch']
+        self._iter = ckpt['meta']['iter']
+        self._inner_iter = 0
+        if 'optimizer' in ckpt and resume_optimizer and self.optimizer is not None:
+            self.optimizer.load_state_dict(ckpt['optimizer'])
+        return ckpt
+
     def register_training_hooks(self, lr_config=None, optimizer_config=None, custom_hooks=None,
-                                momentum_config=None, **ignored):
+                                momentum_config=None, checkpoint_config=None, log_config=None, **ignored):
         """Order = mmcv priorities for this set: LR (VERY_HIGH) < momentum (HIGH) < optimizer
-        (ABOVE_NORMAL) < custom (NORMAL).  checkpoint / log / evaluation configs are outside the
-        step and ignored here."""
+        (ABOVE_NORMAL) < checkpoint (NORMAL) < custom (NORMAL).  log_config names logging back-ends, which
+        are pass-throughs here (outside the step); evaluation configs are not taken."""
         if lr_config is not None:
             cfg = dict(lr_config)
             policy = cfg.pop('policy', 'step')
@@ -564,6 +690,10 @@ class _RunnerBase(object):
             self.register_hook(CyclicMomentumUpdaterHook(**cfg))
         if optimizer_config is not None:
             self.register_hook(OptimizerHook(**dict(optimizer_config)))
+        if checkpoint_config is not None:
+            cfg = dict(checkpoint_config)
+            cfg.setdefault('by_epoch', isinstance(self, EpochBasedRunner))
+            self.register_hook(CheckpointHook(**cfg))
         for h in (custom_hooks or []):
             self.register_hook(h)
 

@@ -570,17 +570,23 @@ class SSL(nn.Module):
             return run(module, d)
         before = {k: dict(d[k]) for k in ('sup_losses', 'ssl_losses') if k in d}
         d = run(module, d)
-        terms = []
+        # first pass: collect (group, key, value, weight) without touching anything — a key that two modules
+        # add to only exists as its sum, so nothing of this module may be detached then
+        picked, collapsed = [], {}
         for group, old in before.items():
             w = 1.0 if group == 'sup_losses' else float(ssl_weight)
-            cur = self._collapse_losses(d[group])
+            cur = collapsed[group] = self._collapse_losses(d[group])
             for k, v in cur.items():
                 if (k not in old or old[k] is not v) and v.requires_grad:
-                    if k in old:      # a key two modules add to: only its sum exists any more
+                    if k in old:
                         return d
-                    if 'loss' in k:
-                        terms.append(v if (w == 1.0 or '.metrics' in k or '.acc' in k) else v * w)
-                    cur[k] = v.detach()
+                    picked.append((group, k, v, w))
+        terms = []
+        for group, k, v, w in picked:
+            if 'loss' in k:
+                terms.append(v if (w == 1.0 or '.metrics' in k or '.acc' in k) else v * w)
+            collapsed[group][k] = v.detach()
+        for group, cur in collapsed.items():
             d[group] = cur
         if terms:
             sum(terms).backward()

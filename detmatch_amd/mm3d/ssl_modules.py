@@ -634,7 +634,9 @@ class HungarianConsistency(object):
             in_scores = _fg_scores(cur_in[1], self.cls_includes_bg_pred_in)
             tgt_scores = _fg_scores(cur_tgt[1], self.cls_includes_bg_pred_target)
             assert in_scores.shape[1] == tgt_scores.shape[1] == 3
-            if self._fusable(in_boxes):
+            # the kernel's backward feeds the INPUT boxes / scores only: a target that carries a graph
+            # (e.g. student 2D against student 3D) takes the tensor losses
+            if self._fusable(in_boxes) and not tgt_boxes.requires_grad and not tgt_scores.requires_grad:
                 img_h, img_w, _ = metas[idx]['img_shape']
                 vals = _FusedConsistencyLoss.apply(in_boxes, in_scores, tgt_boxes, tgt_scores, img_w, img_h,
                                                    self.loss_cls.alpha, self.loss_cls.gamma)

@@ -435,6 +435,21 @@ int dm_sgd_step_masked_f32(float *params, const float *grads, float *momentum_bu
                            double lr, double momentum, double dampening, double weight_decay,
                            int first_step, const float *grad_scale_dev,
                            const unsigned char *block_live, dm_stream_t stream);
+/* The same with a per-block FIRST step: block_first_step[i / 4] = the (1-based) optimizer step at which the
+ * parameter holding elements 4i..4i+3 received its first gradient on any rank, 0 = never (skipped like
+ * block_live == 0).  torch.optim keeps its state per parameter: AdamW's bias corrections run on the
+ * parameter's own step count (step - first + 1), SGD creates the momentum buffer at the parameter's first
+ * gradient (torch/optim/adamw.py, sgd.py, driven per parameter by hybrid_optimizer.py:82-101).  May be NULL
+ * (every parameter live since step 1). */
+int dm_adamw_step_blocks_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                             size_t n, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, long long step, const float *grad_scale_dev,
+                             const unsigned char *block_live, const int *block_first_step,
+                             dm_stream_t stream);
+int dm_sgd_step_blocks_f32(float *params, const float *grads, float *momentum_buf, size_t n,
+                           double lr, double momentum, double dampening, double weight_decay,
+                           long long step, const float *grad_scale_dev, const unsigned char *block_live,
+                           const int *block_first_step, dm_stream_t stream);
 /* C. Anchor target assignment.  Replaces AxisAlignedTargetAssigner.assign_targets(_single)
  * (pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:36-209) for all
  * samples x anchor classes of a batch (POS_FRACTION < 0, MATCH_HEIGHT False, NORM_BY_NUM_EXAMPLES

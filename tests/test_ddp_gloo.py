@@ -229,7 +229,9 @@ def test_never_used_parameters_are_not_stepped():
         opt.step()
     assert torch.equal(net.never.weight, w_never)                 # untouched
     assert not torch.equal(net.mid.weight, w_mid)                 # used once: decays ever after
-    assert net.never.weight.grad is None and net.mid.weight.grad is not None
+    # .grad is hidden from the torch optimizer during its step only; the arena view (zeros) stays in place
+    assert float(net.never.weight.grad.abs().sum()) == 0.0 and net.mid.weight.grad is not None
+    assert net.never.weight not in opt.optimizers[0].state
     assert all(id(p) not in {id(q) for q in ddp.dead_params()} for p in net.mid.parameters())
     # everything live -> the mask is dropped (no per-step cost in the steady state)
     net2 = nn.Linear(4, 4)
@@ -239,3 +241,66 @@ def test_never_used_parameters_are_not_stepped():
         net2(torch.randn(2, 4)).sum().backward()
         d2.finish()
     assert d2._all_live and d2.live_mask(0, d2.flat.numel()) is None
+
+
+def _worker_hooks_unfused(rank, world, port, q):
+    """hooks mode + a NON-fused torch optimizer + a parameter that never gets a gradient: the
+    arena views must stay in place over several iterations, the unused parameter stays untouched (no
+    weight decay, no state), and the dead set is the same on both ranks (rank 1 alone uses `late`)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from detmatch_amd.mm3d.parallel import FlatGradDDP
+        from detmatch_amd.mm3d.runner import HybridOptimizer
+        torch.manual_seed(3)
+        net = _Net()
+        net.late = nn.Linear(16, 4)                   # used from iteration 2 on, by rank 1 only
+        ddp = FlatGradDDP(net, bucket_bytes=256, mode='hooks')
+        opt = HybridOptimizer([torch.optim.AdamW([p for p in net.parameters() if p.requires_grad],
+                                                 lr=1e-2, weight_decay=0.1)])
+        opt._ddp = ddp                                # what enable_fused() records; no fused member here
+        w_unused = net.unused.weight.detach().clone()
+        w_late = net.late.weight.detach().clone()
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(rank))
+        for it in range(4):
+            ddp.zero_grad()                           # raised 'a gradient left the flat arena' at it == 1
+            h = torch.relu(net.bn(net.a(x)))
+            loss = net.frozen(net.b(h)).square().mean()
+            if it >= 2 and rank == 1:
+                loss = loss + net.late(h).square().mean()
+            loss.backward()
+            ddp.finish()
+            opt.step()
+            assert torch.equal(net.unused.weight, w_unused)             # no decay on a never-used parameter
+            assert net.unused.weight not in opt.optimizers[0].state
+            if it < 2:
+                assert torch.equal(net.late.weight, w_late)
+            assert net.a.weight.grad.data_ptr() == ddp._view[id(net.a.weight)].data_ptr()
+            assert net.unused.weight.grad.data_ptr() == ddp._view[id(net.unused.weight)].data_ptr()
+        assert not torch.equal(net.late.weight, w_late)                 # live on rank 1 -> stepped on BOTH ranks
+        st = opt.optimizers[0].state[net.late.weight]
+        assert int(st['step']) == 2                                     # its own step count
+        ws = [torch.zeros_like(net.late.weight) for _ in range(world)]
+        dist.all_gather(ws, net.late.weight.data)
+        assert torch.equal(ws[0], ws[1])
+        q.put((rank, 'ok'))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hooks_mode_with_unfused_optimizer_and_unused_parameter():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hooks_unfused, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', 'rank %d: %s' % (rank, msg)

@@ -302,9 +302,7 @@ def test_filter_by_nms_3d_multiclass(dev):
 def test_fused_optimizer_skips_never_used_parameters(dev):
     """A branch that never receives a gradient (confthr_pvrcnn's 2D student) is left untouched by
     the fused kernels (liveness mask), exactly like torch optimizers skip `.grad is None`; a
-    parameter used once keeps being stepped (weight decay, momentum) with zero gradients.
-    (Known residual deviation, DESIGN §4: a parameter whose FIRST gradient arrives after step 1
-    shares the range's Adam step count instead of starting its own bias correction at 1.)"""
+    parameter used once keeps being stepped (weight decay, momentum) with zero gradients."""
     import copy
     import torch.nn as nn
     from detmatch_amd.mm3d import runner as R
@@ -356,3 +354,84 @@ def test_fused_optimizer_skips_never_used_parameters(dev):
     assert len(sd['state'][1]) == 0                         # no state for the dead branch
     steps = [st['step'] for st in sd['state'][0].values()]
     assert all(int(s) == 4 for s in steps) and len({s.data_ptr() for s in steps}) == len(steps)
+
+
+def test_fused_optimizer_counts_steps_per_parameter(dev):
+    """torch.optim keeps its state per parameter: a parameter whose FIRST gradient arrives at step 3 starts
+    its AdamW bias correction / its SGD momentum buffer there.  The fused kernels take the
+    per-block first-gradient step (dm_adamw_step_blocks_f32 / dm_sgd_step_blocks_f32): the late branch
+    follows torch.optim from its first update on, and the checkpointed `step` is the parameter's own."""
+    import copy
+    import torch.nn as nn
+    from detmatch_amd.mm3d import runner as R
+    from detmatch_amd.mm3d.parallel import FlatGradDDP
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.student = nn.ModuleDict(dict(
+                detector_3d=nn.ModuleDict(dict(a=nn.Linear(37, 53), late=nn.Linear(53, 53), b=nn.Linear(53, 7))),
+                detector_2d=nn.ModuleDict(dict(a=nn.Linear(37, 29), late=nn.Linear(29, 29), b=nn.Linear(29, 3)))))
+
+        def forward(self, x, use_late):
+            out = 0
+            for d in (self.student['detector_3d'], self.student['detector_2d']):
+                h = torch.relu(d['a'](x))
+                if use_late:
+                    h = h + d['late'](h)
+                out = out + d['b'](h).square().mean()
+            return out
+
+    cfg = {'constructor': 'HybridOptimizerConstructor',
+           'student.detector_3d': dict(type='AdamW', lr=0.01, betas=(0.9, 0.99), weight_decay=0.01),
+           'student.detector_2d': dict(type='SGD', lr=0.02, momentum=0.9, weight_decay=0.01)}
+    torch.manual_seed(0)
+    a = Toy().to(dev)
+    b = copy.deepcopy(a)
+    ddp = FlatGradDDP(a, broadcast=False)
+    ddp.build_param_arena()
+    opt_a = R.build_optimizer(a, cfg)
+    assert opt_a.enable_fused(ddp) == 2
+    opt_b = R.build_optimizer(b, cfg)
+    for it in range(7):
+        x = torch.randn(16, 37, device=dev)
+        ddp.zero_grad()
+        a(x, it >= 2).backward()
+        ddp.finish()
+        opt_a.step()
+        for p in b.parameters():            # mmcv zero_grad semantics: tensors stay, never-used stay None
+            if p.grad is not None:
+                p.grad.zero_()
+        b(x, it >= 2).backward()
+        opt_b.step()
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=3e-5, atol=3e-6), (it, n)
+    sd = opt_a.state_dict()
+    names = [n for n, _ in a.student['detector_3d'].named_parameters()]
+    steps = {n: int(st['step']) for n, st in zip(names, sd['state'][0].values())}
+    assert steps['late.weight'] == 5 and steps['a.weight'] == 7, steps
+    # every parameter is live now and one started late: the first-step vector stays in use
+    assert opt_a._fused[0].first is not None and int(opt_a._fused[0].first.max()) == 3
+    # a checkpoint of this state continues identically under plain torch optimizers and under fused ones
+    c = copy.deepcopy(b)
+    opt_c = R.build_optimizer(c, cfg)
+    opt_c.load_state_dict(copy.deepcopy(sd))
+    d = copy.deepcopy(b)
+    ddp_d = FlatGradDDP(d, broadcast=False)
+    ddp_d.build_param_arena()
+    opt_d = R.build_optimizer(d, cfg)
+    opt_d.load_state_dict(copy.deepcopy(sd))
+    assert opt_d.enable_fused(ddp_d) == 2
+    x = torch.randn(16, 37, device=dev)
+    for m, o, dd in ((a, opt_a, ddp), (c, opt_c, None), (d, opt_d, ddp_d)):
+        if dd is not None:
+            dd.zero_grad()
+        else:
+            o.zero_grad()
+        m(x, True).backward()
+        if dd is not None:
+            dd.finish()
+        o.step()
+    for (n, pa), pc, pd in zip(a.named_parameters(), c.parameters(), d.parameters()):
+        assert torch.allclose(pa, pc, rtol=3e-5, atol=3e-6), n
+        assert torch.allclose(pa, pd, rtol=3e-5, atol=3e-6), n

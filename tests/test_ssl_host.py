@@ -261,6 +261,52 @@ def test_hybrid_optimizer_and_runner():
         R.HybridOptimizerConstructor({'student': dict(type='SGD', lr=0.1)})(model)
 
 
+def test_checkpoint_hook_and_resume(tmp_path):
+    """ssl_train.py:113 (checkpoint_config -> CheckpointHook) and :157-166 (resume_from / load_from /
+    load_from_with_optimizer): an interrupted run that resumes from iter_4.pth ends where the uninterrupted
+    one does — weights, optimizer state and the iteration counter come back."""
+    def make(max_iters, work_dir):
+        torch.manual_seed(0)
+        model = _Toy()
+        opt = R.build_optimizer(model, OPT_CFG)
+        run = R.IterBasedSSLRunner(model, optimizer=opt, max_iters=max_iters, work_dir=str(work_dir))
+        run.register_training_hooks(
+            lr_config=dict(policy='step', warmup='linear', warmup_iters=4, warmup_ratio=0.001, step=[]),
+            optimizer_config=dict(grad_clip=dict(max_norm=10, norm_type=2)),
+            checkpoint_config=dict(interval=2, by_epoch=False, max_keep_ckpts=2),
+            log_config=dict(interval=50, hooks=[dict(type='TextLoggerHook')]),
+            custom_hooks=[dict(type='ModelIterEpochHook')])
+        return model, opt, run
+    g = torch.Generator().manual_seed(1)
+    lab = [dict(stu=torch.randn(4, 2, generator=g), img_metas=[0, 1]) for _ in range(2)]
+    unlab = [dict(stu=torch.randn(4, 2, generator=g), img_metas=[0, 1]) for _ in range(3)]
+    full_model, _, full = make(8, tmp_path / 'full')
+    full.run([lab, unlab], [('train', 1)])
+    assert sorted(os.listdir(tmp_path / 'full')) == ['iter_6.pth', 'iter_8.pth', 'latest.pth']    # max_keep_ckpts
+    ckpt = torch.load(tmp_path / 'full' / 'latest.pth', weights_only=False)
+    assert ckpt['meta']['iter'] == 8 and set(ckpt) == {'meta', 'state_dict', 'optimizer'}
+    assert ckpt['optimizer']['num_step_updated'] == 8
+    # interrupted after 4 iterations, resumed in a fresh process state
+    _, _, first = make(4, tmp_path / 'part')
+    first.run([lab, unlab], [('train', 1)])
+    model, opt, second = make(8, tmp_path / 'part')
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)                           # whatever the fresh model holds is overwritten
+    second.resume(str(tmp_path / 'part' / 'iter_4.pth'))
+    assert second.iter == 4 and opt.num_step_updated == 4
+    second.run([lab[0:2], unlab[1:] + unlab[:1]], [('train', 1)])      # the loaders restart; same batches as 4..7
+    assert second.iter == 8
+    # iterations 4..7 of the full run saw lab[0], lab[1], lab[0], lab[1] and unlab[1], unlab[2], unlab[0], unlab[1]
+    for (n, a), (_, b) in zip(full_model.state_dict().items(), model.state_dict().items()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), n
+    # load_from: weights only, counters untouched
+    m3, o3, third = make(8, tmp_path / 'third')
+    third.load_checkpoint(str(tmp_path / 'full' / 'iter_8.pth'))
+    assert third.iter == 0 and o3.num_step_updated == 0
+    assert torch.equal(m3.student['detector_3d'].weight, full_model.student['detector_3d'].weight)
+
+
 def test_checkpoint_key_layout_and_pretrained_loading():
     """the released checkpoints' key layout
     (`teacher.detector_3d.model.backbone_3d.conv1.0.0.weight`, sparse weights (kz,ky,kx,Cin,Cout),
