@@ -26,7 +26,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import detmatch_amd  # noqa: E402,F401  (MIOpen environment, before torch touches MIOpen)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -336,8 +335,6 @@ def main():
         joined = joined_world(dev, os.environ.get('DM_DIST_BACKEND', 'nccl') == 'nccl')
         if joined != args.gpus:
             raise SystemExit('bench.py: %d of %d ranks joined the process group' % (joined, args.gpus))
-    if os.environ.get('DM_CUDNN_BENCHMARK'):     # tools/miopen_tune.sh: exhaustive MIOpen find
-        torch.backends.cudnn.benchmark = True
     from detmatch_amd import _lib
     if CONV_MATH != 'fp32':
         from detmatch_amd import dense_conv

@@ -1,8 +1,1 @@
 """detmatch_amd — MI355X-native DetMatch training step."""
-
-
-def enable_tuned_miopen():
-    """Round 1 shipped a MIOpen find-db for the dense convolutions.  Since round 2 every convolution
-    of the step is a hand-written kernel (csrc/conv2d.hip, detmatch_amd/dense_conv.py) and no MIOpen
-    convolution is called, so there is nothing to tune; kept as a no-op for callers."""
-    return False

@@ -5,9 +5,10 @@ path (pcdet/models/backbones_2d/base_bev_backbone.py:38-69, anchor_head_single.p
 ResNet-50/FPN/RPN at configs/detmatch/001/detmatch/split_0.py:39-99): same argument meaning, same
 (N, C, H, W) logical shapes; tensors are kept in `torch.channels_last` memory format (= NHWC rows),
 which is what the kernels read and write.  Forward, input gradient and weight gradient all run in
-libdetmatch_hip.so; there is no MIOpen / cuDNN call and no CPU path (`DetMatchHipError` on CPU
-tensors) — except when a TEST sets `TORCH_REFERENCE_FOR_TESTS = True`, which routes CPU tensors to
-torch's own convolution so that host logic around the convolutions can be checked without a GPU.
+libdetmatch_hip.so; there is no MIOpen / cuDNN call and no CPU path: a CPU tensor raises
+`DetMatchHipError`.  (CPU-only tests of the HOST logic around the convolutions install their own
+stand-in for host tensors through `HOST_TENSOR_HOOK`; the stand-in lives in tests/_host_conv.py, the
+product, bench.py and smoke() never set the hook.)
 """
 import ctypes
 import weakref
@@ -18,8 +19,9 @@ import torch.nn.functional as F
 
 from . import _lib
 
-# Set by CPU-only tests (tests/conftest.py).  Never set by the product, bench.py or smoke().
-TORCH_REFERENCE_FOR_TESTS = False
+# None in the product.  tests/conftest.py may set it to an object with conv2d(...) / conv_transpose2d(...)
+# that is handed the arguments of a call on HOST tensors (tests/_host_conv.py).
+HOST_TENSOR_HOOK = None
 
 # Bumped by whoever rewrites weights through raw pointers (fused optimizer / EMA kernels): the
 # packed-weight cache is keyed on it (ordinary in-place torch updates bump Tensor._version).
@@ -386,12 +388,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, w_scale=None, 
     before the ReLU.  Returns a channels_last tensor."""
     stride, padding = _pair(stride), _pair(padding)
     if not x.is_cuda:
-        if TORCH_REFERENCE_FOR_TESTS:
-            w = weight if w_scale is None else weight * w_scale.view(-1, 1, 1, 1)
-            y = F.conv2d(x, w, bias, stride, padding)
-            if residual is not None:
-                y = y + residual
-            return F.relu(y) if relu else y
+        if HOST_TENSOR_HOOK is not None:
+            return HOST_TENSOR_HOOK.conv2d(x, weight, bias, stride, padding, relu, w_scale, residual)
         _require(x)
     _require(weight, bias, w_scale, residual)
     return _Conv2dFn.apply(x, weight, bias, w_scale, stride, padding, bool(relu), residual)
@@ -403,8 +401,8 @@ def conv_transpose2d(x, weight, stride):
     if tuple(weight.shape[2:]) != (k, k):
         raise NotImplementedError('conv_transpose2d: only kernel_size == stride is on the path')
     if not x.is_cuda:
-        if TORCH_REFERENCE_FOR_TESTS:
-            return F.conv_transpose2d(x, weight, None, stride=k)
+        if HOST_TENSOR_HOOK is not None:
+            return HOST_TENSOR_HOOK.conv_transpose2d(x, weight, k)
         _require(x)
     _require(weight)
     return _ConvTranspose2dFn.apply(x, weight, k)

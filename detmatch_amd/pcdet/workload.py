@@ -114,8 +114,6 @@ class PVRCNNTrainWorkload(object):
         from .. import configs
         from ..mm3d.box3d import LiDARInstance3DBoxes
         from ..mm3d.openpcdet import OpenPCDetDetector
-        import detmatch_amd
-        detmatch_amd.enable_tuned_miopen()
         self.frames = frames
         self.device = device
         self.points = [torch.from_numpy(f['points']).to(device) for f in frames]
@@ -217,8 +215,6 @@ class DetMatchTrainWorkload(object):
         from ..mm3d import runner as R
         from ..mm3d.ssl import SSL
         register_all()
-        import detmatch_amd
-        self.tuned_miopen = detmatch_amd.enable_tuned_miopen()
         self.batch_size, self.device = batch_size, device
         self.recipe = ssl_cfg or 'detmatch'
         chain = {'confthr_pvrcnn': configs.confthr_pvrcnn_ssl_cfg,
@@ -332,8 +328,6 @@ class PretrainWorkload(object):
         from ..mm3d import runner as R
         from ..mm3d.registry import build_detector
         register_all()
-        import detmatch_amd
-        detmatch_amd.enable_tuned_miopen()
         self.recipe, self.batch_size = recipe, batch_size
         data = synth.ssl_batch(batch_size, seed, device, with_img=recipe == 'pretrain_frcnn')['lab_stu']
         torch.manual_seed(0)

@@ -9,12 +9,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
-import detmatch_amd  # noqa: E402,F401  (sets the MIOpen environment before the first convolution)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _host_conv  # noqa: E402
 from detmatch_amd import dense_conv  # noqa: E402
 
-# CPU tensors only: host logic around the convolutions is checked with torch's own convolution as the
-# stand-in; CUDA tensors always take the HIP kernels (the product never sets this flag).
-dense_conv.TORCH_REFERENCE_FOR_TESTS = True
+# HOST tensors only: the host logic around the convolutions is checked with torch's own convolution as the
+# stand-in (tests/_host_conv.py); CUDA tensors always take the HIP kernels, the product never sets the hook.
+dense_conv.HOST_TENSOR_HOOK = _host_conv
 
 
 def pytest_configure(config):

@@ -190,7 +190,7 @@ def test_all_packed_weights_refresh_in_one_launch(dev):
 
 def test_cpu_tensors_are_refused(monkeypatch):
     from detmatch_amd import _lib, dense_conv
-    monkeypatch.setattr(dense_conv, 'TORCH_REFERENCE_FOR_TESTS', False)   # the product's setting
+    monkeypatch.setattr(dense_conv, 'HOST_TENSOR_HOOK', None)   # the product's setting
     with pytest.raises(_lib.DetMatchHipError):
         dense_conv.conv2d(torch.zeros(1, 4, 8, 8), torch.zeros(4, 4, 3, 3), None, 1, 1)
 

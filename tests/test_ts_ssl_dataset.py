@@ -63,9 +63,7 @@ def test_training_iterations_on_kitti_files():
     from detmatch_amd.mm3d.parallel import FlatGradDDP
     from detmatch_amd.mm3d.registry import build_detector
     from detmatch_amd.ts_ssl_dataset import TSSSLDeviceLoader
-    import detmatch_amd
     register_all()
-    detmatch_amd.enable_tuned_miopen()
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
     model = build_detector(configs.detmatch_kitti_model(ssl_cfg=configs.detmatch_ssl_cfg(with_vis=False))).to(dev)
