@@ -49,8 +49,11 @@ import torch.nn as nn
 class FlatGradDDP(nn.Module):
 
     def __init__(self, module, params=None, bucket_bytes=64 << 20, process_group=None,
-                 broadcast=True, mode='collect', exchange=None):
+                 broadcast=True, mode='collect', exchange=None, always_exchange=False):
         super().__init__()
+        # issue the collectives even in a one-rank group (they are identities there): lets a single GPU
+        # execute the exact exchange code path of an N-rank job (tests/test_ssl_gpu.py)
+        self.always_exchange = always_exchange
         assert mode in ('collect', 'hooks')
         self.mode = mode
         self.exchange = exchange or os.environ.get('DM_GRAD_EXCHANGE', 'all_reduce')
@@ -218,8 +221,9 @@ class FlatGradDDP(nn.Module):
     def _launch(self, b):
         s, e = self.buckets[b]
         self._sent[b] = True
-        if self.world <= 1:
+        if self.world <= 1 and not self.always_exchange:
             return
+        self.n_collectives = getattr(self, 'n_collectives', 0) + (2 if self.exchange == 'rs_ag' else 1)
         buf = self.flat_all[s:e]
         if self.exchange == 'rs_ag':
             if self._shards is None:

@@ -434,3 +434,59 @@ def test_fused_optimizer_counts_steps_per_parameter(dev):
     for (n, pa), pc, pd in zip(a.named_parameters(), c.parameters(), d.parameters()):
         assert torch.allclose(pa, pc, rtol=3e-5, atol=3e-6), n
         assert torch.allclose(pa, pd, rtol=3e-5, atol=3e-6), n
+
+
+def test_gradient_exchange_code_path_on_one_rank_nccl(dev, monkeypatch):
+    """`exchange='rs_ag'` (reduce_scatter_tensor + all_gather_into_tensor per bucket, RCCL) and
+    `mode='hooks'` (buckets issued from autograd hooks, strictly in index order, overlapping backward) need
+    the nccl backend, so the gloo tests cannot run them.  A ONE-rank nccl group on the one GPU executes the
+    very same calls (identities on one rank): (1) on a deterministic network the exchanged gradients equal
+    the default path's bit for bit; (2) a full DetMatch iteration runs through it and agrees with the default
+    path within the run-to-run spread of its atomics."""
+    import socket
+    import torch.distributed as dist
+    import torch.nn as nn
+    from detmatch_amd.mm3d.parallel import FlatGradDDP
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        net = nn.Sequential(nn.Linear(64, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 8)).to(dev)
+        x = torch.randn(32, 64, device=dev)
+        grads = []
+        for kw in (dict(), dict(mode='hooks', exchange='rs_ag', always_exchange=True),
+                   dict(mode='collect', exchange='all_reduce', always_exchange=True)):
+            ddp = FlatGradDDP(net, bucket_bytes=64 << 10, broadcast=False, **kw)
+            assert len(ddp.buckets) >= 3
+            for _ in range(2):
+                ddp.zero_grad()
+                ddp(x).square().mean().backward()
+                ddp.finish()
+            grads.append(ddp.flat.clone())
+            if kw:
+                assert ddp.n_collectives == 2 * len(ddp.buckets) * (2 if kw['exchange'] == 'rs_ag' else 1)
+            for p in net.parameters():
+                p.grad = None
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+        assert float(grads[0].abs().sum()) > 0
+        # a full DetMatch iteration through hooks + rs_ag
+        losses = []
+        for special in (False, True):
+            monkeypatch.setenv('DM_GRAD_MODE', 'hooks' if special else 'collect')
+            monkeypatch.setenv('DM_GRAD_EXCHANGE', 'rs_ag' if special else 'all_reduce')
+            wl = DetMatchTrainWorkload(2, dev, seed=0)
+            wl.ddp.always_exchange = special
+            assert wl.ddp.mode == ('hooks' if special else 'collect') and wl.ddp.exchange == ('rs_ag' if special else 'all_reduce')
+            ls = [float(wl.step().detach()) for _ in range(3)]
+            torch.cuda.synchronize()
+            if special:
+                assert wl.ddp.n_collectives == 3 * 2 * len(wl.ddp.buckets)
+            losses.append(ls)
+            del wl
+        np.testing.assert_allclose(losses[0], losses[1], rtol=2e-3)
+    finally:
+        dist.destroy_process_group()
