@@ -105,6 +105,9 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
         (the voxel count, then N_out of the four strided rulebooks) and is sent the value —
         spconv/ops.py:drive_steps_together fetches those of all the passes of an iteration in one copy
         per round.  `ws_tag`: rulebook workspace of this pass (interleaved builds must not share one)."""
+        hit = self._geom_cache.get(id(points), None)
+        if hit is not None and hit[0] is points and hit[1] == self.training:
+            return           # prepared one iteration ahead (IterBasedSSLRunner look-ahead)
         max_voxels = self.voxel_layer.max_voxels[0 if self.training else 1]
         pts = [p.float().contiguous() for p in points]
         v, c, n, mean, counts = voxel.voxelize_batch(pts, self.voxel_layer.voxel_size,
@@ -117,8 +120,14 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
         if bb is not None and hasattr(bb, 'build_rulebooks_steps'):
             res['indice_dict_prefetch'] = yield from bb.build_rulebooks_steps(
                 res['voxel_coords'], res['batch_size'], ws_tag=ws_tag)
-        stream = torch.cuda.current_stream(points[0].device) if points[0].is_cuda else None
-        self._geom_cache[id(points)] = (points, self.training, res, stream)
+        stream = done = None
+        if points[0].is_cuda:
+            stream = torch.cuda.current_stream(points[0].device)
+            done = torch.cuda.Event()
+            done.record(stream)
+        if len(self._geom_cache) > 8:          # batches that were prepared and never consumed
+            self._geom_cache.clear()
+        self._geom_cache[id(points)] = (points, self.training, res, stream, done)
 
     def _base_batch(self, points, img_metas):
         hit = self._geom_cache.pop(id(points), None)
@@ -126,7 +135,8 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
             res = hit[2]
             if hit[3] is not None:
                 cur = torch.cuda.current_stream(points[0].device)
-                if cur != hit[3]:      # consumed on another lane: keep the allocator informed
+                if cur != hit[3]:      # consumed on another stream: order it, keep the allocator informed
+                    cur.wait_event(hit[4])
                     _record_tree(res, cur)
             if img_metas is not None:
                 res['frame_id'] = np.array([m.get('sample_idx', i) for i, m in enumerate(img_metas)])

@@ -764,18 +764,40 @@ class IterBasedSSLRunner(_RunnerBase):
     prefixed 'lab_' / 'unlab_'; data_batch['img_metas'] is the labeled metas (only used for
     num_samples)."""
 
-    def train(self, lab_data_loader, unlab_data_loader, **kwargs):
-        _ensure_train_mode(self.model)
-        self.mode = 'train'
-        self._epoch = getattr(lab_data_loader, 'epoch', 0)
+    # Look-ahead (scheduling only; DM_LOOKAHEAD=0 disables): the batches of iteration i+1 are drawn before
+    # iteration i is issued, and once i is issued the model prepares their weight-independent 3D geometry on a
+    # side stream (SSL.prefetch_geometry) — the data-dependent size read-backs of the voxelizer / rulebooks
+    # then overlap the tail of iteration i instead of idling the device at the step boundary.
+    lookahead = os.environ.get('DM_LOOKAHEAD', '1') == '1'
+
+    @staticmethod
+    def _draw(lab_data_loader, unlab_data_loader):
         lab = next(lab_data_loader)
         unlab = next(unlab_data_loader)
         data_batch = {'lab_%s' % k: v for k, v in lab.items()}
         data_batch.update({'unlab_%s' % k: v for k, v in unlab.items()})
         data_batch['img_metas'] = lab['img_metas']
+        ready = None
+        if torch.cuda.is_available():
+            ready = torch.cuda.Event()
+            ready.record()
+        return data_batch, ready
+
+    def train(self, lab_data_loader, unlab_data_loader, **kwargs):
+        _ensure_train_mode(self.model)
+        self.mode = 'train'
+        self._epoch = getattr(lab_data_loader, 'epoch', 0)
+        ahead = getattr(self, '_ahead', None)
+        data_batch, _ = ahead if ahead is not None else self._draw(lab_data_loader, unlab_data_loader)
+        self._ahead = None
+        prefetch = getattr(_inner(self.model), 'prefetch_geometry', None)
+        if self.lookahead and prefetch is not None and (self._max_iters is None or self.iter + 1 < self._max_iters):
+            self._ahead = self._draw(lab_data_loader, unlab_data_loader)
         self.call_hook('before_train_iter')
         self._after_step(self.model.train_step(data_batch, self.optimizer, **kwargs))
         self.call_hook('after_train_iter')
+        if self._ahead is not None:
+            prefetch(self._ahead[0], self._ahead[1], tag='ahead%d_' % (self.iter & 1))
         self._inner_iter += 1
         self._iter += 1
 

@@ -560,6 +560,35 @@ class SSL(nn.Module):
             return self.forward_train(**kwargs)
         return self.forward_test(**kwargs)
 
+    def prefetch_geometry(self, data, ready=None, tag='ahead'):
+        """The weight-independent geometry (voxels, rulebooks, FPS key points) of every 3D pass of a FUTURE
+        iteration's batch `data` (the dict train_step will be called with), on a side stream: its size
+        read-backs then wait for a few small kernels instead of for the step that is still executing, and
+        the iteration itself starts with the geometry on the table (OpenPCDetDetector._geom_cache).  `ready`:
+        event after which the batch's tensors exist.  Scheduling only — geometry depends on the points."""
+        lab_stu, unlab_stu = data.get('lab_stu'), data.get('unlab_stu')
+        if lab_stu is None or isinstance(unlab_stu, list):
+            return
+        dev = next(self.student.parameters()).device
+        if dev.type != 'cuda':
+            return
+        if getattr(self, '_geom_stream', None) is None:
+            self._geom_stream = torch.cuda.Stream(dev)
+        dicts = (dict(stu=lab_stu, tea=data.get('lab_tea')), dict(stu=unlab_stu, tea=data.get('unlab_tea')))
+        if ready is not None:
+            self._geom_stream.wait_event(ready)
+        with torch.cuda.stream(self._geom_stream):
+            jobs = []
+            for chain, d in zip((self.lab_ssl_modules, self.unlab_ssl_modules), dicts):
+                for m in chain:
+                    if hasattr(m, 'prefetch_steps'):
+                        steps = m.prefetch_steps(self, d, '%s%d' % (tag, len(jobs)))
+                        if steps is not None:
+                            jobs.append(steps)
+            if jobs:
+                from ..spconv.ops import drive_steps_together
+                drive_steps_together(jobs)
+
     def _run_and_backprop(self, run, module, d, early, ssl_weight):
         """Run one SSL module; when it is flagged `self_contained_losses` (its forward adds losses and
         nothing else) back-propagate the new loss terms right away, with the weight they carry in the
