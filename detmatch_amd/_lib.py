@@ -136,6 +136,7 @@ SIGNATURES = {
     'dm_profile_enable': (ci, [ci]),
     'dm_spconv_debug_stamps': (ci, [vp]),
     'dm_spconv_set_variant': (ci, [ci]),
+    'dm_spconv_set_wgrad_chunk': (ci, [ci]),
     'dm_profile_count': (ci, []),
     'dm_profile_get': (ci, [ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
                             ctypes.POINTER(ctypes.c_ulonglong), c_f32_p]),

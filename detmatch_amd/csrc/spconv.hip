@@ -733,7 +733,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict
                                                         const int32_t *__restrict__ pairs,
                                                         const int32_t *__restrict__ indice_num,
                                                         int pair_stride, int chunk,
-                                                        float *__restrict__ slab) {
+                                                        float *__restrict__ slab, int nchunks, int kvol,
+                                                        int order) {
   constexpr int VA = CIN / 16, VB = COUT / 16;
   typedef float vecA __attribute__((ext_vector_type(VA)));
   typedef float vecB __attribute__((ext_vector_type(VB)));
@@ -741,7 +742,23 @@ __global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict
   // through LDS in wave order (deterministic) and written once: 4x less slab traffic per pair.
   // Chunks beyond this offset's pair count exit at once and are never read by the reduce kernel.
   __shared__ float tile[CIN * COUT];
-  const int k = blockIdx.y, ch = blockIdx.x, kvol = gridDim.y;
+  // (chunk, offset) of this workgroup.  order 0: chunks fastest; 1: offsets fastest (workgroups that run
+  // at the same time read the same stretch of rows); 2: offsets fastest AND all offsets of a chunk on one XCD
+  // (workgroup ids go round-robin over the 8 XCDs, each with its own L2)
+  int k, ch;
+  {
+    const int id = blockIdx.x;
+    if (order == 0) {
+      ch = id % nchunks, k = id / nchunks;
+    } else if (order == 1) {
+      k = id % kvol, ch = id / kvol;
+    } else {
+      const int xcd = id & 7, slot = id >> 3;
+      k = slot % kvol;
+      ch = xcd + 8 * (slot / kvol);
+      if (ch >= nchunks) return;
+    }
+  }
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
   const int npairs = indice_num[k];
@@ -757,21 +774,33 @@ __global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict
 #pragma unroll
     for (int r = 0; r < VB; ++r) acc[q][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr int U = 4;                      // groups of 4 pairs in flight
-  // software pipeline: the pair indices AND rows of the next 16 pairs are requested before the
-  // MFMAs of the current 16 are issued
+  // Three-stage software pipeline over steps of 16 pairs: the pair INDICES of step n+2 and the ROWS of
+  // step n+1 are requested before the MFMAs of step n are issued.  (Round 2 fetched indices and rows of
+  // step n+1 together: the wave then sat out the index latency inside every fetch, with nothing to
+  // issue — the rows depend on the indices.)  Loads past the wave's range are clamped, not branched.
   vecA a[2][U];
   vecB b[2][U];
   bool ok[2][U];
-  auto fetch = [&](int buf, int s0) {
+  int ii[2][U], oo[2][U];
+  bool inr[2][U];
+  auto fetch_idx = [&](int buf, int s0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int s = s0 + 4 * u + kq;
       const bool in = s < s_end;
       const int sc = in ? s : s_begin;
-      const int ii = pin[sc], oo = pout[sc];
-      ok[buf][u] = in & (ii >= 0) & (oo >= 0);
-      a[buf][u] = *(const vecA *)(feat + (size_t)(ii >= 0 ? ii : 0) * CIN + VA * j);
-      b[buf][u] = *(const vecB *)(ograd + (size_t)(oo >= 0 ? oo : 0) * COUT + VB * j);
+      ii[buf][u] = pin[sc];
+      oo[buf][u] = pout[sc];
+      inr[buf][u] = in;
+    }
+  };
+  auto fetch_rows = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i0 = ii[buf][u], o0 = oo[buf][u];
+      ok[buf][u] = inr[buf][u] & (i0 >= 0) & (o0 >= 0);
+      a[buf][u] = *(const vecA *)(feat + (size_t)(i0 >= 0 ? i0 : 0) * CIN + VA * j);
+      b[buf][u] = *(const vecB *)(ograd + (size_t)(o0 >= 0 ? o0 : 0) * COUT + VB * j);
     }
   };
   auto mma = [&](int buf) {
@@ -786,20 +815,18 @@ __global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict
       }
   };
   if (s_begin < s_end) {
-    fetch(0, s_begin);
-    int s0 = s_begin;
-    for (; s0 + 8 * U < s_end; s0 += 8 * U) {      // two 16-pair steps per trip: buffers alternate
-      fetch(1, s0 + 4 * U);
-      mma(0);
-      fetch(0, s0 + 8 * U);
-      mma(1);
-    }
-    if (s0 + 4 * U < s_end) {
-      fetch(1, s0 + 4 * U);
-      mma(0);
-      mma(1);
-    } else {
-      mma(0);
+    const int nsteps = (s_end - s_begin + 4 * U - 1) / (4 * U);
+    fetch_idx(0, s_begin);
+    fetch_idx(1, s_begin + 4 * U);
+    fetch_rows(0);
+    for (int n = 0; n < nsteps; n += 2) {          // two steps per trip: the buffers alternate
+      fetch_idx(0, s_begin + (n + 2) * 4 * U);     // step n's indices are consumed (rows requested)
+      fetch_rows(1);                               // rows of step n+1
+      mma(0);                                      // step n
+      if (n + 1 >= nsteps) break;
+      fetch_idx(1, s_begin + (n + 3) * 4 * U);
+      fetch_rows(0);                               // rows of step n+2
+      mma(1);                                      // step n+1
     }
   }
   // D of MFMA (q, r): row i = 4*kq + reg -> cin channel VA*i + q; col j -> cout channels VB*j + r
@@ -847,9 +874,15 @@ __global__ __launch_bounds__(256) void spconv_wgrad_reduce_active(const float *s
   filt_grad[e] = s;
 }
 
+int g_wgrad_chunk = 0;   // 0 = heuristic; dm_spconv_set_wgrad_chunk (developer switch)
+int g_wgrad_order = 1;   // workgroup -> (chunk, offset) map of spconv_wgrad_rows, see the kernel; offsets fastest:
+                         // 58 -> 41 us on the 64 -> 64 layer with 16.8 k rows (order 2, XCD-aware: no better)
+
 int wgrad_chunks(int n_in, int *chunk) {
-  // a chunk = one 4-wave workgroup (a quarter each): 512 pairs up to 64 k rows; multiples of 64 pairs
-  int c = 512;
+  // a chunk = one 4-wave workgroup (a quarter each); multiples of 64 pairs.  Measured (round 3,
+  // tools/bench_spconv_layers.py --wgrad-chunk): 256 wins on the layers below ~12 k rows (more workgroups
+  // than CUs), 512 above (the per-workgroup merge + slab write is a fixed cost)
+  int c = g_wgrad_chunk > 0 ? g_wgrad_chunk : (n_in < 12000 ? 256 : 512);
   while ((long long)c * 128 < n_in) c *= 2;
   *chunk = c;
   return dm_ceil_div(n_in > 0 ? n_in : 1, c);
@@ -1000,6 +1033,16 @@ extern "C" int dm_spconv_pack_rows(const int32_t *nbr, int n_rows, int kvol, int
 }
 
 // tuning aid: -1 auto, 0 force the LDS-staged kernel, 1 force the register-weights kernel
+extern "C" int dm_spconv_set_wgrad_chunk(int pairs) {
+  if (pairs < 0) {                 // -1 - order: developer switch for the workgroup map
+    g_wgrad_order = -1 - pairs;
+    return g_wgrad_order <= 2 ? DM_OK : DM_ERR_INVALID_ARG;
+  }
+  if (pairs != 0 && (pairs < 64 || pairs % 64)) return DM_ERR_INVALID_ARG;
+  g_wgrad_chunk = pairs;
+  return DM_OK;
+}
+
 extern "C" int dm_spconv_set_variant(int v) {
   g_gg_variant = v;
   return DM_OK;
@@ -1091,9 +1134,10 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
   dim3 grid(nchunks, dm_ceil_div(cin, 16), kvol);
   int pi = dm_prof_begin(st, DM_PROF_SPCONV_WGRAD, cin, cout, 1, pair_stride, kvol, indice_pairs);
   bool rows_kernel = true;
-#define DM_WGRAD_ROWS(CI, CO)                                                                     \
-  spconv_wgrad_rows<CI, CO><<<dim3(nchunks, kvol), 256, 0, st>>>(feat, out_grad, indice_pairs, \
-                                                                 indice_num, pair_stride, chunk, slab)
+  const int n_wg = g_wgrad_order == 2 ? 8 * dm_ceil_div(nchunks, 8) * kvol : nchunks * kvol;
+#define DM_WGRAD_ROWS(CI, CO)                                                                   \
+  spconv_wgrad_rows<CI, CO><<<n_wg, 256, 0, st>>>(feat, out_grad, indice_pairs, indice_num,    \
+                                                  pair_stride, chunk, slab, nchunks, kvol, g_wgrad_order)
   const int key = cin * 1000 + cout;
   if (key == 16016) DM_WGRAD_ROWS(16, 16);
   else if (key == 16032) DM_WGRAD_ROWS(16, 32);

@@ -816,6 +816,8 @@ int dm_profile_enable(int on); /* clears all records */
 int dm_spconv_debug_stamps(void *buf);
 /* tuning aid: -1 auto, 0 LDS-staged-weights kernel, 1 register-weights kernel */
 int dm_spconv_set_variant(int v);
+/* Developer switch: pairs per weight-gradient workgroup (0 = heuristic; a multiple of 64). */
+int dm_spconv_set_wgrad_chunk(int pairs);
 int dm_profile_count(void);
 int dm_profile_get(int i, int *kind, int *a, int *b, int *c, int *rows, int *kvol,
                    unsigned long long *table, float *ms);

@@ -44,10 +44,14 @@ def main():
     ap.add_argument('--only', default=None)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--wgrad-chunk", type=int, default=0)
+    ap.add_argument("--wgrad-order", type=int, default=1)
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     from detmatch_amd import _lib
     _lib.lib().dm_spconv_set_variant(args.variant)
+    _lib.lib().dm_spconv_set_wgrad_chunk(args.wgrad_chunk)
+    _lib.lib().dm_spconv_set_wgrad_chunk(-1 - args.wgrad_order)
     pts = [torch.from_numpy(synth.lidar_frame(s)['points']).to(dev) for s in range(args.batch)]
     _, coors, _, mean, _ = voxel.voxelize_batch(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
     idx, shape = coors, [41, 1600, 1408]
