@@ -337,8 +337,8 @@ def main():
             raise SystemExit('bench.py: %d of %d ranks joined the process group' % (joined, args.gpus))
     from detmatch_amd import _lib
     if CONV_MATH != 'fp32':
-        from detmatch_amd import dense_conv
-        dense_conv.set_math(CONV_MATH)
+        from detmatch_amd import precision
+        precision.set_mixed(True)      # dense AND sparse convolutions: bf16 multiplicands, fp32 accumulate
     wl = build_workload(dev, rank)
     if world > 1:
         wl.enable_ddp()
@@ -381,7 +381,8 @@ def main():
             groups, by_dir = {}, {}
             for j, r in enumerate(gg):
                 ci, co, rows, kvol, P = per_step[j % len(per_step)]
-                name = ('spconv_gg<%d,%d,%d>' % (r[1], r[2], r[3]) if r[3] else
+                name = ('spconv_gr16<%d,%d>' % (r[1], r[2]) if r[3] >= 16 else
+                        'spconv_gg<%d,%d,%d>' % (r[1], r[2], r[3]) if r[3] else
                         'spconv_gr<%d,%d>' % (r[1], r[2]))
                 for key, table in ((name, groups), (per_dir[j % len(per_step)], by_dir)):
                     g = table.setdefault(key, dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
@@ -429,7 +430,7 @@ def main():
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling='weak', vs_baseline=None,
                    dtype='f32' if CONV_MATH == 'fp32' else 'mixed: bf16 multiplicands + f32 accumulate in the '
-                   'dense-conv forward/input-gradient GEMMs, f32 everywhere else',
+                   'dense- and sparse-conv GEMMs, f32 storage and f32 everywhere else',
                    data='synthetic',
                    config=dict(workload=wl.describe(), batch_per_gpu=BATCH_PER_GPU, conv_math=CONV_MATH,
                                value_is='iterations of one per-GPU batch, summed over ranks',

@@ -38,6 +38,8 @@ SIGNATURES = {
     'dm_pairs_to_table': (ci, [vp, vp, ci, ci, ci, vp, ci, vp]),
     'dm_spconv_workspace_bytes': (sz, [ci, ci, ci]),
     'dm_spconv_gather_gemm': (ci, [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
+    'dm_spconv16_workspace_bytes': (sz, [ci, ci, ci]),
+    'dm_spconv_gather_gemm16': (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
     'dm_spconv_pack_rows_workspace_bytes': (sz, [ci]),
     'dm_spconv_pack_rows': (ci, [vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     'dm_spconv_tile_order_workspace_bytes': (sz, []),

@@ -360,8 +360,10 @@ def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, t
     runner = build_from_cfg(rcfg, RUNNERS, default_args=dict(
         model=ddp, optimizer=optimizer, work_dir=cfg.get('work_dir', None), logger=None, meta=meta))
     runner.timestamp = timestamp
-    if cfg.get('fp16', None) is not None:
-        raise NotImplementedError('fp16 optimizer hook: mixed precision is not implemented (DESIGN.md)')
+    # ssl_train.py:100-105: cfg.fp16 -> Fp16OptimizerHook.  Here: the mixed-precision mode of the GEMM-shaped
+    # kernels (bf16 multiplicands, fp32 accumulation / storage / master weights: detmatch_amd/precision.py);
+    # bf16 has fp32's exponent range, so the hook's loss_scale is accepted and not needed
+    fp16_cfg = cfg.get('fp16', None)
     custom = [build_from_cfg(dict(h), HOOKS) for h in cfg.get('custom_hooks', [])]
     runner.register_training_hooks(cfg['lr_config'], cfg['optimizer_config'], custom_hooks=custom,
                                    momentum_config=cfg.get('momentum_config', None),
@@ -379,5 +381,8 @@ def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, t
         runner._epoch = 0
         runner._iter = 0
         runner.meta = {}
-    runner.run(loaders, cfg.get('workflow', [('train', 1)]))
+    from .. import precision
+    with precision.mixed_precision(fp16_cfg is not None or precision.mixed()):
+        runner.run(loaders, cfg.get('workflow', [('train', 1)]))
+    runner.fp16 = fp16_cfg is not None
     return runner

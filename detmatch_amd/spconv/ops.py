@@ -227,6 +227,9 @@ def packed_rows(nbr):
     return hit
 
 
+_STORAGE = {torch.float16: 1, torch.bfloat16: 2}      # DM_SP16_F16 / DM_SP16_BF16; 0 = DM_SP16_F32ROWS
+
+
 def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k):
     L = _lib.lib()
     kvol = nbr.shape[0]
@@ -244,7 +247,23 @@ def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k)
         if LAUNCH_TRACE_DIR is not None:
             LAUNCH_TRACE_DIR.append('dgrad' if transpose_w else 'fwd')
     dev = feat.device
-    out = torch.empty((n_rows_out, cin if transpose_w else cout), dtype=torch.float32, device=dev)
+    out = torch.empty((n_rows_out, cin if transpose_w else cout), dtype=feat.dtype, device=dev)
+    storage = _STORAGE.get(feat.dtype)
+    if storage is None and min(cin, cout) >= 16:
+        from .. import precision
+        if precision.sparse_bf16():
+            storage = 0
+    if storage is not None:
+        # 16-bit matrix instructions (csrc/spconv16.hip): half-precision rows (indice_conv_half), or fp32 rows
+        # with bf16 multiplicands in the mixed-precision mode
+        if filters.dtype != feat.dtype:
+            raise _lib.DetMatchHipError('sparse conv: features %s and filters %s differ' % (feat.dtype, filters.dtype))
+        ws = _lib.workspace(L.dm_spconv16_workspace_bytes(kvol, cin, cout), dev, 'spconv16')
+        rc = L.dm_spconv_gather_gemm16(_lib.ptr(feat), feat.shape[0], _lib.ptr(filters), storage, _lib.ptr(table),
+                                       n_rows_out, kvol, cin, cout, int(transpose_w), int(flip_k), _lib.ptr(out),
+                                       _lib.ptr(order), _lib.ptr(perm), _lib.ptr(ws), ws.numel(), _lib.stream())
+        _lib.check(rc, 'dm_spconv_gather_gemm16')
+        return out
     ws = _lib.workspace(L.dm_spconv_workspace_bytes(kvol, cin, cout), dev, 'spconv')
     rc = L.dm_spconv_gather_gemm(_lib.ptr(feat), feat.shape[0], _lib.ptr(filters), _lib.ptr(table),
                                  n_rows_out, kvol, cin, cout, int(transpose_w), int(flip_k),
@@ -256,11 +275,14 @@ def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k)
 
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
                 inverse=False, subm=False):
-    """ops.py:108-126 / spconv_ops.h:260-360 (fp32)."""
+    """ops.py:108-126 / spconv_ops.h:260-360: indice_conv_fp32 for fp32 tensors, indice_conv_half for
+    torch.float16 (and, beyond the reference, torch.bfloat16) — the dtype dispatch of ops.py:111-126."""
     if inverse:
         raise NotImplementedError('inverse sparse conv is off the DetMatch hot path')
-    if filters.dtype != torch.float32 or features.dtype != torch.float32:
-        raise NotImplementedError('fp32 only (no DetMatch config sets fp16)')
+    if features.dtype not in (torch.float32, torch.float16, torch.bfloat16) or filters.dtype != features.dtype:
+        raise NotImplementedError('sparse conv: fp32, fp16 or bf16 features and filters of one dtype')
+    if features.dtype != torch.float32 and min(filters.shape[-2], filters.shape[-1]) < 16:
+        raise NotImplementedError('half-precision sparse conv needs >= 16 channels on both sides')
     features = features.contiguous()
     filters = filters.contiguous()
     _lib.require_device(features, filters, indice_pairs)
@@ -288,6 +310,11 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     if need_input_grad:
         _, nbr_in = _tables_for(indice_pairs, indice_pair_num, n_in, n_out, subm)
         input_bp = _gather_gemm(out_bp, filters, nbr_in, n_in, cin, cout, 1, 1 if subm else 0)
+    half = features.dtype if features.dtype != torch.float32 else None
+    if half is not None:
+        # indice_conv_backward_half: the weight gradient accumulates over all pairs — computed by the fp32
+        # kernel on widened rows and rounded once (fp32 accumulation, as the gather-GEMMs)
+        features, out_bp, filters = features.float(), out_bp.float(), filters.float()
     filters_bp = torch.empty_like(filters)
     if LAUNCH_TRACE_W is not None:
         LAUNCH_TRACE_W.append((cin, cout, int(kvol), int(indice_pair_num.sum().item()), int(n_in), int(n_out)))
@@ -296,4 +323,4 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
                            _lib.ptr(indice_pair_num), stride, kvol, cin, cout,
                            _lib.ptr(filters_bp), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, 'dm_spconv_wgrad')
-    return input_bp, filters_bp
+    return input_bp, (filters_bp.to(half) if half is not None else filters_bp)

@@ -178,6 +178,22 @@ int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const float *filters
                           const int32_t *row_perm /* from dm_spconv_pack_rows (then nbr is the packed
                                                      table and row p is written to out[row_perm[p]]), or NULL */,
                           void *workspace, size_t workspace_bytes, dm_stream_t stream);
+/* The same on the 16-bit matrix instructions (v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulation).
+ * Replaces sparse_conv_ext.indice_conv_half / indice_conv_backward_half (spconv/src/all.cc:35-36; the
+ * input-gradient half of the latter: transpose_w = 1) and serves the mixed-precision mode behind the
+ * reference's fp16 configs (mmdet3d/apis/ssl_train.py:100-105).  `storage`:
+ *   DM_SP16_F32ROWS  feat / filters / out are fp32 (same buffers as dm_spconv_gather_gemm); the multiplicands
+ *                    are rounded to bf16 (round to nearest even) inside the kernel
+ *   DM_SP16_F16      feat / filters / out are IEEE half (at::Half)
+ *   DM_SP16_BF16     feat / filters / out are bfloat16
+ * cin, cout in {16,32,64,128}; tables, tile order and row permutation exactly as above. */
+enum { DM_SP16_F32ROWS = 0, DM_SP16_F16 = 1, DM_SP16_BF16 = 2 };
+size_t dm_spconv16_workspace_bytes(int kvol, int cin, int cout);
+int dm_spconv_gather_gemm16(const void *feat, int n_rows_in, const void *filters, int storage,
+                            const int32_t *nbr, int n_rows_out, int kvol, int cin, int cout,
+                            int transpose_w, int flip_k, void *out, const int32_t *tile_order,
+                            const int32_t *row_perm, void *workspace, size_t workspace_bytes,
+                            dm_stream_t stream);
 /* Launch order of the 16-row output tiles of a gather table: tiles sorted by descending number of
  * active kernel offsets (a launch lasts as long as the compute unit that received the heaviest
  * tiles; heavy-first dispatch balances them).  A property of the table: build once per rulebook,

@@ -1,8 +1,10 @@
 """BASELINE.json configs[4], geometry leg: the Waymo-SHAPED synthetic frame (full 360 deg sweep,
 ~200 k points, range +-75.2 m x [-2, 4), voxel [0.1, 0.1, 0.15] -> grid 1504 x 1504 x 40, sparse shape
 [41, 1504, 1504], max_voxels 150000, image 1280 x 1920) through the hot path in fp32:
-voxelize + all 8 rulebooks + the 12 sparse convolutions against the oracle, then one full DetMatch
-iteration at bs = 1.  (The fp16 mixed-precision half of that config is NOT implemented — DESIGN.md.)"""
+voxelize + all 8 rulebooks + the 12 sparse convolutions against the oracle, then full DetMatch
+iterations at bs = 1 in fp32 AND in the mixed-precision mode that config asks for (cfg.fp16 of the reference ->
+detmatch_amd/precision.py: bf16 multiplicands with fp32 accumulation in the dense and sparse GEMMs), whose
+logged losses must agree with the fp32 run."""
 import numpy as np
 import pytest
 import torch
@@ -64,3 +66,29 @@ def test_waymo_shaped_full_iteration(dev):
     log = wl.runner.log_buffer
     for k in ('sup.sup_3d.loss', 'sup.stu.loss_rpn_cls', 'ssl.unlab.hard_pseudo_3d.loss'):
         assert k in log and all(bool(torch.isfinite(torch.as_tensor(v)).all()) for v in log[k]), k
+
+
+def test_waymo_shaped_mixed_precision_iteration(dev):
+    """configs[4] as the reference would run it (fp16 mixed precision): the same iteration in the mixed mode.
+    Tolerances: the supervised losses are smooth functions of the network outputs for fixed targets — bf16
+    multiplicands (relative 2^-8 per product, fp32 accumulation) through ~30 layers move them by < 3 %; the
+    pseudo-label losses additionally depend on thresholded teacher outputs (discrete), so only their scale is
+    compared."""
+    from detmatch_amd import precision
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    logs = []
+    for on in (False, True):
+        with precision.mixed_precision(on):
+            wl = DetMatchTrainWorkload(1, dev, seed=11, profile='waymo')
+            assert precision.mixed() == on
+            wl.step()
+            torch.cuda.synchronize()
+            logs.append({k: float(torch.as_tensor(v[-1]).float().mean()) for k, v in wl.runner.log_buffer.items()})
+            del wl
+    assert not precision.mixed()
+    a, b = logs
+    for k in ('sup.sup_3d.loss', 'sup.stu.loss_rpn_cls', 'sup.stu.loss_cls'):
+        assert np.isfinite(b[k]) and abs(a[k] - b[k]) <= 3e-2 * abs(a[k]) + 1e-4, (k, a[k], b[k])
+    assert any(abs(a[k] - b[k]) > 0 for k in a if 'loss' in k)           # the mode is really on
+    for k in ('ssl.unlab.hard_pseudo_3d.loss', 'loss'):
+        assert np.isfinite(b[k]) and 0.5 * abs(a[k]) - 1e-3 <= abs(b[k]) <= 2.0 * abs(a[k]) + 1e-3, (k, a[k], b[k])
