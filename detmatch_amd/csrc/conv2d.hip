@@ -412,12 +412,36 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
   return make_uint2(lo.u, hi.u);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LIMIT>
+//
+// SPLIT = 3 (dm_dconv_set_math(2)): fp32-CLASS arithmetic on the bf16 pipe.  Every fp32 operand is split on
+// its way into LDS into three bf16 planes, x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m):
+// together the 24 significand bits of x.  Products of two bf16 numbers are exact in fp32, so the six products
+// of weight 2^-16 and larger — hh, hm, mh, hl, lh, mm — summed into the fp32 accumulator carry the fp32
+// product to 2^-24 relative (the three dropped terms are below the rounding of the sum).  Measured against
+// float64 (tools/probe_bf16_split.py): rms error 2.0e-7 of the output against 6.0e-7 for the native
+// v_mfma_f32_32x32x2_f32 kernel — the matrix pipe's own fp32 instruction is the LESS accurate path — at 6
+// bf16 instructions of 32 cycles per 16 k against 8 fp32 instructions of 64 (2.7x less matrix-pipe time).
+// K-tile 16 (one instruction deep), three planes per buffer: 72 KB of LDS, two workgroups per CU.
+template <typename T4>
+__device__ __forceinline__ void split_bf16x3(const float4 v, uint2 *h, uint2 *m, uint2 *l) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+  union { bf16x4v b; uint2 u; } a, b, c;
+  const f32x4v x = {v.x, v.y, v.z, v.w};
+  a.b = __builtin_convertvector(x, bf16x4v);
+  const f32x4v r1 = x - __builtin_convertvector(a.b, f32x4v);
+  b.b = __builtin_convertvector(r1, bf16x4v);
+  const f32x4v r2 = r1 - __builtin_convertvector(b.b, f32x4v);
+  c.b = __builtin_convertvector(r2, bf16x4v);
+  *h = a.u, *m = b.u, *l = c.u;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LIMIT, int SPLIT = 1>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     float *__restrict__ y, const DConvGeom g, const DConvTaps tt, int n_tiles_m, int n_tiles_n,
     int m_lo, int kt_per_split, float *__restrict__ partial) {
-  constexpr int BK = 64;
+  constexpr int BK = SPLIT == 3 ? 16 : 64;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDW = BK / 2 + 4;                      // dwords per LDS row
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
@@ -425,7 +449,8 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
   constexpr int RPP = NT / KQ;
   constexpr int AP = BM / RPP, BP = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0 && TM >= 1 && TN >= 1, "tile shape");
-  constexpr int LDS_WORDS = 2 * (BM + BN) * LDW;
+  constexpr int PLANE = (BM + BN) * LDW;               // dwords of one bf16 plane of one buffer
+  constexpr int LDS_WORDS = 2 * SPLIT * PLANE;
   constexpr int LDS_MIN = LIMIT == 1 ? 21504 : (LIMIT == 2 ? 14336 : 0);
   __shared__ __attribute__((aligned(16))) unsigned ldsw[LDS_WORDS < LDS_MIN ? LDS_MIN : LDS_WORDS];
 
@@ -499,17 +524,32 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
     for (int p = 0; p < BP; ++p) rb[p] = *(const float4 *)(wb + b_off[p] + wshift);
   };
   auto sstore = [&](int buf) {
-    unsigned *base = ldsw + buf * (BM + BN) * LDW;
+    unsigned *base = ldsw + buf * SPLIT * PLANE;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       float4 v = ra[p];
       const bool ok = ra_ok[p];
       v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
-      *(uint2 *)(base + (r0 + p * RPP) * LDW + kq * 2) = pack_bf16x4(v);
+      unsigned *dst = base + (r0 + p * RPP) * LDW + kq * 2;
+      if constexpr (SPLIT == 3) {
+        uint2 h, m, l;
+        split_bf16x3<float4>(v, &h, &m, &l);
+        *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
+      } else {
+        *(uint2 *)dst = pack_bf16x4(v);
+      }
     }
 #pragma unroll
-    for (int p = 0; p < BP; ++p)
-      *(uint2 *)(base + BM * LDW + (r0 + p * RPP) * LDW + kq * 2) = pack_bf16x4(rb[p]);
+    for (int p = 0; p < BP; ++p) {
+      unsigned *dst = base + BM * LDW + (r0 + p * RPP) * LDW + kq * 2;
+      if constexpr (SPLIT == 3) {
+        uint2 h, m, l;
+        split_bf16x3<float4>(rb[p], &h, &m, &l);
+        *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
+      } else {
+        *(uint2 *)dst = pack_bf16x4(rb[p]);
+      }
+    }
   };
   const int lr = lane & 31, lh = lane >> 5;
   const int KT = min(kt_per_split, KT_all - kt0);
@@ -520,20 +560,31 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
     const int buf = kt & 1;
     const bool more = kt + 1 < KT;
     if (more) gload();
-    const unsigned *As = ldsw + buf * (BM + BN) * LDW + (wm * WM + lr) * LDW + lh * 4;
-    const unsigned *Bs = ldsw + buf * (BM + BN) * LDW + BM * LDW + (wn * WN + lr) * LDW + lh * 4;
+    const unsigned *As = ldsw + buf * SPLIT * PLANE + (wm * WM + lr) * LDW + lh * 4;
+    const unsigned *Bs = ldsw + buf * SPLIT * PLANE + BM * LDW + (wn * WN + lr) * LDW + lh * 4;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 af[TM], bfr[TN];
+      bf16x8 af[SPLIT][TM], bfr[SPLIT][TN];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = *(const bf16x8 *)(As + a * 32 * LDW + ks * 8);
+      for (int s = 0; s < SPLIT; ++s) {
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bfr[b] = *(const bf16x8 *)(Bs + b * 32 * LDW + ks * 8);
+        for (int a = 0; a < TM; ++a) af[s][a] = *(const bf16x8 *)(As + s * PLANE + a * 32 * LDW + ks * 8);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bfr[s][b] = *(const bf16x8 *)(Bs + s * PLANE + b * 32 * LDW + ks * 8);
+      }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TN; ++b) {
+          if constexpr (SPLIT == 3) {      // smallest terms first: l h, h l, m m, m h, h m, h h
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bfr[0][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[2][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[0][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[1][b], acc[a][b], 0, 0, 0);
+          }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
+        }
     }
     if (more) sstore(buf ^ 1);
     __syncthreads();
@@ -791,12 +842,16 @@ __device__ __forceinline__ int wg_tile_off(int row, int chunk) {   // bytes; chu
   return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
+// SPLIT = 3: the fp32-class mode of dconv_gemm_bf16_kernel (three bf16 planes per operand, six products),
+// K-tile of 16 pixels.
+template <int SPLIT>
 __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__restrict__ U, const float *__restrict__ V,
                                                                float *__restrict__ part, const DWgradGeom g,
                                                                const DConvTaps tt, int n_tiles_u, int n_tiles_v) {
-  constexpr int BU = 128, BV = 128, BK = 32, WU = 64, WV = 64, TU = 2, TV = 2;
-  constexpr int TILE_BYTES = BK * 256;                       // one operand, one buffer
-  constexpr int LDS_STAGE = 4 * TILE_BYTES, LDS_EPI = 4 * WU * (WV + 4) * 4;
+  constexpr int BU = 128, BV = 128, BK = SPLIT == 3 ? 16 : 32, WU = 64, WV = 64, TU = 2, TV = 2;
+  constexpr int NP = BK / 8;                                 // pixel rows per thread and tile
+  constexpr int TILE_BYTES = BK * 256;                       // one operand, one plane, one buffer
+  constexpr int LDS_STAGE = 4 * SPLIT * TILE_BYTES, LDS_EPI = 4 * WU * (WV + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_STAGE > LDS_EPI ? LDS_STAGE : LDS_EPI];
 
   int tile = blockIdx.x;
@@ -822,11 +877,11 @@ __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__re
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  float4 ru[4], rv[4];
-  bool ru_ok[4], rv_ok[4];
+  float4 ru[NP], rv[NP];
+  bool ru_ok[NP], rv_ok[NP];
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int m = m_lo + kt * BK + r0 + p * 8;
       const bool ok = (m < m_hi) & u_ok;
       ru[p] = *(const float4 *)(U + (size_t)(ok ? m : m_lo) * g.Cu + (u_ok ? u0 + cq * 4 : 0));
@@ -841,17 +896,25 @@ __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__re
     }
   };
   auto sstore = [&](int buf) {
-    unsigned char *ub = lds + buf * 2 * TILE_BYTES, *vb = ub + TILE_BYTES;
+    unsigned char *ub = lds + buf * 2 * SPLIT * TILE_BYTES, *vb = ub + SPLIT * TILE_BYTES;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int row = r0 + p * 8;
       const int off = wg_tile_off(row, cq >> 1) + 8 * (cq & 1);
       float4 a = ru[p], b = rv[p];
       const bool oka = ru_ok[p], okb = rv_ok[p];
       a.x = oka ? a.x : 0.0f, a.y = oka ? a.y : 0.0f, a.z = oka ? a.z : 0.0f, a.w = oka ? a.w : 0.0f;
       b.x = okb ? b.x : 0.0f, b.y = okb ? b.y : 0.0f, b.z = okb ? b.z : 0.0f, b.w = okb ? b.w : 0.0f;
-      *(uint2 *)(ub + off) = pack_bf16x4(a);
-      *(uint2 *)(vb + off) = pack_bf16x4(b);
+      if constexpr (SPLIT == 3) {
+        uint2 h, m, l;
+        split_bf16x3<float4>(a, &h, &m, &l);
+        *(uint2 *)(ub + off) = h, *(uint2 *)(ub + TILE_BYTES + off) = m, *(uint2 *)(ub + 2 * TILE_BYTES + off) = l;
+        split_bf16x3<float4>(b, &h, &m, &l);
+        *(uint2 *)(vb + off) = h, *(uint2 *)(vb + TILE_BYTES + off) = m, *(uint2 *)(vb + 2 * TILE_BYTES + off) = l;
+      } else {
+        *(uint2 *)(ub + off) = pack_bf16x4(a);
+        *(uint2 *)(vb + off) = pack_bf16x4(b);
+      }
     }
   };
   // transposed fragment reads: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of its block
@@ -880,19 +943,30 @@ __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__re
       const int buf = kt & 1;
       const bool more = kt + 1 < KT;
       if (more) gload(kt + 1);
-      const unsigned char *ub = lds + buf * 2 * TILE_BYTES, *vb = ub + TILE_BYTES;
+      const unsigned char *ub = lds + buf * 2 * SPLIT * TILE_BYTES, *vb = ub + SPLIT * TILE_BYTES;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8 af[TU], bfr[TV];
+        bf16x8 af[SPLIT][TU], bfr[SPLIT][TV];
 #pragma unroll
-        for (int a = 0; a < TU; ++a) af[a] = frag(ub, ks, wu * WU + a * 32);
+        for (int s = 0; s < SPLIT; ++s) {
 #pragma unroll
-        for (int b = 0; b < TV; ++b) bfr[b] = frag(vb, ks, wv * WV + b * 32);
+          for (int a = 0; a < TU; ++a) af[s][a] = frag(ub + s * TILE_BYTES, ks, wu * WU + a * 32);
+#pragma unroll
+          for (int b = 0; b < TV; ++b) bfr[s][b] = frag(vb + s * TILE_BYTES, ks, wv * WV + b * 32);
+        }
 #pragma unroll
         for (int a = 0; a < TU; ++a)
 #pragma unroll
-          for (int b = 0; b < TV; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TV; ++b) {
+            if constexpr (SPLIT == 3) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bfr[0][b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[2][b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[0][b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[1][b], acc[a][b], 0, 0, 0);
+            }
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
+          }
       }
       if (more) sstore(buf ^ 1);
       __syncthreads();
@@ -1026,7 +1100,7 @@ __global__ __launch_bounds__(256) void dconv_splitk_reduce_kernel(const float *_
   *(float4 *)(y + row * g.Cout + n) = s;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNI, int LIMIT = 0, bool BF = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNI, int LIMIT = 0, int BF = 0>
 int launch_gemm(const float *x, const float *w, const float *bias, float *y, DConvGeom g,
                 const DConvTaps &tt, hipStream_t st, int m_lo = 0, int m_hi = -1, int nsplit = 1,
                 float *partial = nullptr) {
@@ -1035,12 +1109,12 @@ int launch_gemm(const float *x, const float *w, const float *bias, float *y, DCo
   g.M = m_hi;
   const int tm = dm_ceil_div(m_hi - m_lo, BM), tn = dm_ceil_div(g.Cout, BN);
   const int blocks = dm_ceil_div(tm, 8) * 8 * tn;
-  const int KT = dm_ceil_div(g.Ktot, BF ? 64 : 32);
+  const int KT = dm_ceil_div(g.Ktot, BF == 1 ? 64 : (BF == 2 ? 16 : 32));
   const int per = dm_ceil_div(KT, nsplit);
   nsplit = dm_ceil_div(KT, per);
-  if constexpr (BF) {
+  if constexpr (BF != 0) {
     static_assert(UNI, "the bf16 kernel takes whole-tap K-tiles only");
-    dconv_gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, LIMIT>
+    dconv_gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, LIMIT, BF == 2 ? 3 : 1>
         <<<dim3(blocks, nsplit), WAVES_M * WAVES_N * 64, 0, st>>>(x, w, bias, y, g, tt, tm, tn, m_lo, per,
                                                                  nsplit > 1 ? partial : nullptr);
   } else {
@@ -1057,7 +1131,8 @@ int launch_gemm(const float *x, const float *w, const float *bias, float *y, DCo
   return DM_OK;
 }
 
-// 0: exact fp32 (v_mfma_f32_32x32x2_f32), 1: bf16 multiplicands, fp32 accumulate (mixed precision)
+// 0: fp32 on the matrix pipe's own fp32 instruction (v_mfma_f32_32x32x2_f32), 1: bf16 multiplicands, fp32
+// accumulate (mixed precision), 2: fp32-class through six bf16 products of the three-way split operands
 int g_dconv_math = 0;
 
 // How many ways the reduction of a SMALL problem (fewer 64x64 tiles than half a round) is split.
@@ -1161,10 +1236,11 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
   // chip.  Problems of less than half a 64x64 round split the reduction over workgroups instead
   // (partial sums in the workspace, fixed-order reduce).
   const int nsplit = dconv_gemm_splits(geom_host);
-  const bool bf = g_dconv_math == 1 && (g.Cin % 64) == 0;
+  const int bf = (g_dconv_math == 1 && (g.Cin % 64) == 0) ? 1 : (g_dconv_math == 2 ? 2 : 0);
 #define DM_LG(BM_, BN_, LIM_, ...)                                                  \
-  (bf ? launch_gemm<BM_, BN_, 2, 2, true, LIM_, true>(x, w_packed, bias, y, g, tt, st, ##__VA_ARGS__) \
-      : launch_gemm<BM_, BN_, 2, 2, true, LIM_, false>(x, w_packed, bias, y, g, tt, st, ##__VA_ARGS__))
+  (bf == 1 ? launch_gemm<BM_, BN_, 2, 2, true, LIM_, 1>(x, w_packed, bias, y, g, tt, st, ##__VA_ARGS__) \
+   : bf == 2 ? launch_gemm<BM_, BN_, 2, 2, true, LIM_, 2>(x, w_packed, bias, y, g, tt, st, ##__VA_ARGS__) \
+             : launch_gemm<BM_, BN_, 2, 2, true, LIM_, 0>(x, w_packed, bias, y, g, tt, st, ##__VA_ARGS__))
   if (nsplit > 1) {
     if (!workspace || workspace_bytes < (size_t)nsplit * g.M * g.Cout * sizeof(float))
       return DM_ERR_WORKSPACE;
@@ -1202,7 +1278,7 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
 }
 
 extern "C" int dm_dconv_set_math(int mode) {
-  if (mode != 0 && mode != 1) return DM_ERR_INVALID_ARG;
+  if (mode < 0 || mode > 2) return DM_ERR_INVALID_ARG;
   g_dconv_math = mode;
   return DM_OK;
 }
@@ -1259,7 +1335,10 @@ extern "C" int dm_dconv_wgrad(const float *U, const float *V, float *out, const 
                                                                                  tu, tv);
   } else if (g_dconv_math == 1) {      // mixed precision: bf16 multiplicands, fp32 accumulate
     const int tu = dm_ceil_div(g.Cu, 128), tv = dm_ceil_div(g.Cv, 128);
-    dconv_wgrad_bf16_kernel<<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g, tt, tu, tv);
+    dconv_wgrad_bf16_kernel<1><<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g, tt, tu, tv);
+  } else if (g_dconv_math == 2) {      // fp32-class: six bf16 products of the three-way split operands
+    const int tu = dm_ceil_div(g.Cu, 128), tv = dm_ceil_div(g.Cv, 128);
+    dconv_wgrad_bf16_kernel<3><<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g, tt, tu, tv);
   } else {
     const int tu = dm_ceil_div(g.Cu, 128), tv = dm_ceil_div(g.Cv, 128);
     dconv_wgrad_kernel<128, 128, 32, 2, 2><<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g,

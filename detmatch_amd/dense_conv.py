@@ -11,6 +11,7 @@ stand-in for host tensors through `HOST_TENSOR_HOOK`; the stand-in lives in test
 product, bench.py and smoke() never set the hook.)
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -29,17 +30,38 @@ _GENERATION = [0]
 _PACK_CACHE = {}
 
 
+_MATH = {'fp32_mfma': 0, 'bf16': 1, 'fp32_split': 2}
+
+
 def set_math(mode):
-    """'fp32' (default, exact) or 'bf16' (mixed precision: bf16 multiplicands, fp32 accumulate / storage —
-    the counterpart of the reference's fp16 autocast configs, BASELINE configs[4]) for the forward and
-    input-gradient GEMMs.  Also read once from the environment variable DM_CONV_MATH."""
-    if mode not in ('fp32', 'bf16'):
-        raise ValueError("math mode must be 'fp32' or 'bf16'")
-    _lib.check(_lib.lib().dm_dconv_set_math(1 if mode == 'bf16' else 0), 'dm_dconv_set_math')
+    """Arithmetic of the convolution GEMMs (forward, input gradient, weight gradient of the >= 128-channel layers):
+      'fp32_split'  fp32-class: every operand is split into three bf16 numbers (together its 24 significand
+                    bits) and the six significant cross products run on the bf16 matrix instruction with fp32
+                    accumulation — MORE accurate against float64 than 'fp32_mfma' (2.0e-7 vs 6.0e-7 rms,
+                    tools/probe_bf16_split.py) at 2.7x less matrix-pipe time;
+      'fp32_mfma'   the matrix pipe's own fp32 instruction (v_mfma_f32_32x32x2_f32);
+      'bf16'        mixed precision: operands ROUNDED to bf16, fp32 accumulate / storage — the counterpart of
+                    the reference's fp16 autocast configs (BASELINE configs[4]); see detmatch_amd/precision.py.
+    'fp32' selects the default fp32 flavour (FP32_DEFAULT)."""
+    if mode == 'fp32':
+        mode = FP32_DEFAULT
+    if mode not in _MATH:
+        raise ValueError("math mode must be one of 'fp32', %s" % sorted(_MATH))
+    _lib.check(_lib.lib().dm_dconv_set_math(_MATH[mode]), 'dm_dconv_set_math')
 
 
 def get_math():
-    return 'bf16' if _lib.lib().dm_dconv_get_math() == 1 else 'fp32'
+    code = _lib.lib().dm_dconv_get_math()
+    return [k for k, v in _MATH.items() if v == code][0]
+
+
+# which kernels serve exact-class fp32 (environment DM_FP32_CONV=fp32_mfma|fp32_split for A/B runs)
+FP32_DEFAULT = os.environ.get('DM_FP32_CONV', 'fp32_mfma')
+if FP32_DEFAULT != 'fp32_mfma':
+    try:
+        set_math(FP32_DEFAULT)
+    except OSError:       # library not built yet (first import inside build())
+        pass
 
 
 _EVENTS = []        # (generation after the event, ptr_lo, ptr_hi) of raw-pointer rewrites; None = everything

@@ -17,7 +17,7 @@ _STATE = {'mixed': False}
 
 def set_mixed(on):
     from . import dense_conv
-    dense_conv.set_math('bf16' if on else 'fp32')
+    dense_conv.set_math('bf16' if on else 'fp32')      # 'fp32' = the default fp32 flavour of dense_conv
     _STATE['mixed'] = bool(on)
 
 

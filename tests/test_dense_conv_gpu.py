@@ -242,7 +242,7 @@ def test_mixed_precision_math_mode(dev, shape):
     w = torch.randn(cout, xs[1], k, k, generator=g) / (xs[1] * k * k) ** 0.5
     b = torch.randn(cout, generator=g)
     gy_seed = 22
-    assert dense_conv.get_math() == 'fp32'
+    assert dense_conv.get_math() in ('fp32_mfma', 'fp32_split')
     dense_conv.set_math('bf16')
     try:
         xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
@@ -317,3 +317,46 @@ def test_residual_epilogue_is_add_then_relu(dev, shape, math):
     assert float((a[0] == 0).float().mean()) > 0.2          # the ReLU is active
     for u, v, what in zip(a[1:], b[1:], ('dx', 'dw', 'd identity')):
         assert torch.equal(u, v), what
+
+
+@pytest.mark.parametrize('shape', [
+    ((2, 128, 40, 44), 128, 3, 1, 1),       # 3x3, 128x128 tiles + 64x64 tail
+    ((2, 128, 40, 44), 256, 3, 2, 1),       # strided (input gradient per residue class)
+    ((2, 512, 12, 40), 512, 3, 1, 1),       # split-K
+    ((2, 1024, 24, 80), 256, 1, 1, 0),      # 1x1
+    ((2, 256, 30, 30), 72, 1, 1, 0),        # Cout not a multiple of the tile
+    ((1, 32, 20, 24), 64, 3, 1, 1),         # Cin = 32
+], ids=['3x3 128', '3x3 s2', 'splitk', '1x1', 'cout72', 'cin32'])
+def test_fp32_split_mode_is_at_least_as_accurate_as_the_fp32_instruction(dev, shape):
+    """dm_dconv_set_math(2): fp32-class arithmetic from six bf16 products of the three-way split operands.
+    Against the float64 convolution its error must not exceed that of the matrix pipe's own fp32 instruction
+    (measured: about a third of it), forward and both gradients — and must meet the fp32 bar of this file (1e-4
+    of the output scale) with two orders of magnitude to spare."""
+    from detmatch_amd import dense_conv
+    xs, cout, k, s, p = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(xs, generator=g)
+    w = torch.randn(cout, xs[1], k, k, generator=g) / (xs[1] * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    F = torch.nn.functional
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, b.double(), s, p)
+    gy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(32))
+    y64.backward(gy.double())
+    want = (y64.detach(), x64.grad, w64.grad)
+    errs = {}
+    prev = dense_conv.get_math()
+    try:
+        for mode in ('fp32_mfma', 'fp32_split'):
+            dense_conv.set_math(mode)
+            xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            wd = torch.nn.Parameter(w.to(dev))
+            y = dense_conv.conv2d(xd, wd, b.to(dev), s, p)
+            y.backward(gy.to(dev))
+            errs[mode] = [float((got.detach().cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+                          for got, ref in zip((y, xd.grad, wd.grad), want)]
+    finally:
+        dense_conv.set_math(prev)
+    for i, what in enumerate(('forward', 'input gradient', 'weight gradient')):
+        assert errs['fp32_split'][i] <= 1e-6, (what, errs)
+        assert errs['fp32_split'][i] <= 1.05 * errs['fp32_mfma'][i] + 2e-8, (what, errs)

@@ -46,12 +46,19 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--wgrad-chunk", type=int, default=0)
     ap.add_argument("--wgrad-order", type=int, default=1)
+    ap.add_argument("--mixed", action='store_true', help='fp32 rows, bf16 multiplicands (precision.set_mixed)')
+    ap.add_argument("--half", default=None, choices=['float16', 'bfloat16'], help='16-bit storage')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     from detmatch_amd import _lib
     _lib.lib().dm_spconv_set_variant(args.variant)
     _lib.lib().dm_spconv_set_wgrad_chunk(args.wgrad_chunk)
     _lib.lib().dm_spconv_set_wgrad_chunk(-1 - args.wgrad_order)
+    if args.mixed:
+        from detmatch_amd import precision
+        precision.set_mixed(True)
+    sdt = getattr(torch, args.half) if args.half else torch.float32
+    T = 2 if args.half else 4
     pts = [torch.from_numpy(synth.lidar_frame(s)['points']).to(dev) for s in range(args.batch)]
     _, coors, _, mean, _ = voxel.voxelize_batch(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
     idx, shape = coors, [41, 1600, 1408]
@@ -68,20 +75,21 @@ def main():
         rb = books[key]
         P = int(rb.indice_num.sum().item())
         kvol = rb.kvol
-        x = torch.randn(rb.n_in, cin, device=dev)
-        w = torch.randn(*ks, cin, cout, device=dev) * 0.05
-        dy = torch.randn(rb.n_out, cout, device=dev)
+        lt = sdt if cin >= 16 else torch.float32
+        x = torch.randn(rb.n_in, cin, device=dev).to(lt)
+        w = (torch.randn(*ks, cin, cout, device=dev) * 0.05).to(lt)
+        dy = torch.randn(rb.n_out, cout, device=dev).to(lt)
         rb.indice_pairs.dm_tables = (rb.nbr_out, rb.nbr_in, rb.subm)
         if args.only is None or args.only == key:
             tf = timed(lambda: ops.indice_conv(x, w, rb.indice_pairs, rb.indice_num, rb.n_out,
                                                False, subm), args.reps, 0)
-            bf = P * (cin + cout) * 4 + P * 8 + kvol * cin * cout * 4 + rb.n_out * cout * 4
+            bf = P * (cin + cout) * T + P * 8 + kvol * cin * cout * T + rb.n_out * cout * T
             td = tb = 0.0
             if cin >= 16:
                 nbr = rb.nbr_out if subm else rb.nbr_in
                 td = timed(lambda: ops._gather_gemm(dy, w, nbr, rb.n_in, cin, cout, 1,
                                                     1 if subm else 0), args.reps, 0)
-                tb = P * (cin + cout) * 4 + P * 8 + kvol * cin * cout * 4 + rb.n_in * cin * 4
+                tb = P * (cin + cout) * T + P * 8 + kvol * cin * cout * T + rb.n_in * cin * T
             tw = timed(lambda: ops.indice_conv_backward(x, w, dy, rb.indice_pairs, rb.indice_num,
                                                         False, subm, need_input_grad=False),
                        args.reps, 1)
