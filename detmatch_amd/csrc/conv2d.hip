@@ -29,6 +29,8 @@
 // inside an 8-block is permuted identically for A and B (lane half h, element j -> k = 4h + j), which
 // a dot product does not care about.  The weight gradient is a second kernel (pixels are the
 // reduction index, split over workgroups, fixed-order reduce -> bitwise reproducible).
+#include <type_traits>
+
 #include "dm_common.h"
 
 namespace {
@@ -422,7 +424,6 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
 // v_mfma_f32_32x32x2_f32 kernel — the matrix pipe's own fp32 instruction is the LESS accurate path — at 6
 // bf16 instructions of 32 cycles per 16 k against 8 fp32 instructions of 64 (2.7x less matrix-pipe time).
 // K-tile 16 (one instruction deep), three planes per buffer: 72 KB of LDS, two workgroups per CU.
-template <typename T4>
 __device__ __forceinline__ void split_bf16x3(const float4 v, uint2 *h, uint2 *m, uint2 *l) {
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
@@ -437,7 +438,8 @@ __device__ __forceinline__ void split_bf16x3(const float4 v, uint2 *h, uint2 *m,
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int LIMIT, int SPLIT = 1>
-__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(SPLIT == 3 ? 2 : 1)))
+void dconv_gemm_bf16_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     float *__restrict__ y, const DConvGeom g, const DConvTaps tt, int n_tiles_m, int n_tiles_n,
     int m_lo, int kt_per_split, float *__restrict__ partial) {
@@ -497,12 +499,23 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  float4 ra[AP], rb[BP];
-  bool ra_ok[AP];
+  // Register ring of fetched K-tiles: DEPTH tiles in flight (slot of tile kt = kt % DEPTH).  The mixed-precision
+  // kernel (SPLIT 1, K-tile 64) keeps one.  The split kernel's K-tile is one instruction deep — 6 * TM * TN matrix
+  // instructions per wave, a fraction of an L2 round trip — so it fetches DEPTH tiles ahead, and its memory work is
+  // woven into the instruction stream in pieces (one global load, or one split + three LDS stores) in front of
+  // each (a, b) group of six instructions, pinned by sched_barriers: the split's VALU work and the LDS traffic
+  // run in the shadow of the matrix pipe instead of between its bursts.  Everything in the steady-state loop is
+  // unconditional (fetches past the last tile are clamped to valid, unused data; the store of a tile past the
+  // end goes to the idle buffer), so the loop body is one basic block.
+  constexpr int DEPTH = SPLIT == 3 ? (BM * BN > 64 * 64 ? 2 : 3) : 1;   // 128 x 128: a ring of three spills
+  float4 ra[DEPTH][AP], rb[DEPTH][BP];
+  bool ra_ok[DEPTH][AP];
   const int KT_all = g.Ktot / BK;
   const int kt0 = blockIdx.y * kt_per_split;
   int tU = (kt0 * BK) / g.Cin, cU = (kt0 * BK) % g.Cin;
-  auto gload = [&]() {     // unconditional clamped loads, masked at the LDS store (see the fp32 kernel)
+  int g_dy = 0, g_dx = 0;
+  unsigned g_shift = 0, g_wshift = 0;
+  auto gprep = [&]() {
     const int tr = __builtin_amdgcn_readfirstlane(tU);
     const int t = tr < g.T ? tr : g.T - 1;
     const int c0 = __builtin_amdgcn_readfirstlane(cU);
@@ -510,84 +523,152 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_bf16_kernel(
     const int wrap = cU >= g.Cin;
     tU += wrap;
     cU = wrap ? 0 : cU;
-    const int dy = tt.dy[t], dx = tt.dx[t];
-    const unsigned shift = (unsigned)((dy * g.Win + dx) * g.Cin + c0) * 4u;
-    const unsigned wshift = (unsigned)tt.ws[t] * slice_bytes + (unsigned)c0 * 4u;
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      const int iy = a_iy[p] + dy, ix = a_ix[p] + dx;
-      const bool ok = ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
-      ra[p] = *(const float4 *)(xb + (ok ? a_off[p] + shift : 0u));
-      ra_ok[p] = ok;
-    }
-#pragma unroll
-    for (int p = 0; p < BP; ++p) rb[p] = *(const float4 *)(wb + b_off[p] + wshift);
+    g_dy = tt.dy[t], g_dx = tt.dx[t];
+    g_shift = (unsigned)((g_dy * g.Win + g_dx) * g.Cin + c0) * 4u;
+    g_wshift = (unsigned)tt.ws[t] * slice_bytes + (unsigned)c0 * 4u;
   };
-  auto sstore = [&](int buf) {
-    unsigned *base = ldsw + buf * SPLIT * PLANE;
+  auto gA = [&](auto slot, int p) {     // unconditional clamped loads, masked at the LDS store (see the fp32 kernel)
+    constexpr int R = decltype(slot)::value;
+    const int iy = a_iy[p] + g_dy, ix = a_ix[p] + g_dx;
+    const bool ok = ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
+    ra[R][p] = *(const float4 *)(xb + (ok ? a_off[p] + g_shift : 0u));
+    ra_ok[R][p] = ok;
+  };
+  auto gB = [&](auto slot, int p) {
+    constexpr int R = decltype(slot)::value;
+    rb[R][p] = *(const float4 *)(wb + b_off[p] + g_wshift);
+  };
+  auto gload = [&](auto slot) {
+    gprep();
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      float4 v = ra[p];
-      const bool ok = ra_ok[p];
-      v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
-      unsigned *dst = base + (r0 + p * RPP) * LDW + kq * 2;
-      if constexpr (SPLIT == 3) {
-        uint2 h, m, l;
-        split_bf16x3<float4>(v, &h, &m, &l);
-        *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
-      } else {
-        *(uint2 *)dst = pack_bf16x4(v);
-      }
-    }
+    for (int p = 0; p < AP; ++p) gA(slot, p);
 #pragma unroll
-    for (int p = 0; p < BP; ++p) {
-      unsigned *dst = base + BM * LDW + (r0 + p * RPP) * LDW + kq * 2;
-      if constexpr (SPLIT == 3) {
-        uint2 h, m, l;
-        split_bf16x3<float4>(rb[p], &h, &m, &l);
-        *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
-      } else {
-        *(uint2 *)dst = pack_bf16x4(rb[p]);
-      }
+    for (int p = 0; p < BP; ++p) gB(slot, p);
+  };
+  auto sA = [&](int buf, auto slot, int p) {
+    constexpr int R = decltype(slot)::value;
+    float4 v = ra[R][p];
+    const bool ok = ra_ok[R][p];
+    v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
+    unsigned *dst = ldsw + buf * SPLIT * PLANE + (r0 + p * RPP) * LDW + kq * 2;
+    if constexpr (SPLIT == 3) {
+      uint2 h, m, l;
+      split_bf16x3(v, &h, &m, &l);
+      *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
+    } else {
+      *(uint2 *)dst = pack_bf16x4(v);
     }
+  };
+  auto sB = [&](int buf, auto slot, int p) {
+    constexpr int R = decltype(slot)::value;
+    unsigned *dst = ldsw + buf * SPLIT * PLANE + BM * LDW + (r0 + p * RPP) * LDW + kq * 2;
+    if constexpr (SPLIT == 3) {
+      uint2 h, m, l;
+      split_bf16x3(rb[R][p], &h, &m, &l);
+      *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
+    } else {
+      *(uint2 *)dst = pack_bf16x4(rb[R][p]);
+    }
+  };
+  auto sstore = [&](int buf, auto slot) {
+#pragma unroll
+    for (int p = 0; p < AP; ++p) sA(buf, slot, p);
+#pragma unroll
+    for (int p = 0; p < BP; ++p) sB(buf, slot, p);
   };
   const int lr = lane & 31, lh = lane >> 5;
   const int KT = min(kt_per_split, KT_all - kt0);
-  gload();
-  sstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) gload();
+  bf16x8 af[SPLIT][TM], bfr[SPLIT][TN];
+  auto frags = [&](int buf, int ks) {
     const unsigned *As = ldsw + buf * SPLIT * PLANE + (wm * WM + lr) * LDW + lh * 4;
     const unsigned *Bs = ldsw + buf * SPLIT * PLANE + BM * LDW + (wn * WN + lr) * LDW + lh * 4;
 #pragma unroll
+    for (int s = 0; s < SPLIT; ++s) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[s][a] = *(const bf16x8 *)(As + s * PLANE + a * 32 * LDW + ks * 8);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bfr[s][b] = *(const bf16x8 *)(Bs + s * PLANE + b * 32 * LDW + ks * 8);
+    }
+  };
+  auto mma_ab = [&](int a, int b) {
+    if constexpr (SPLIT == 3) {      // smallest terms first: l h, h l, m m, m h, h m, h h
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bfr[0][b], acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[2][b], acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[0][b], acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[1][b], acc[a][b], 0, 0, 0);
+    }
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 af[SPLIT][TM], bfr[SPLIT][TN];
-#pragma unroll
-      for (int s = 0; s < SPLIT; ++s) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) af[s][a] = *(const bf16x8 *)(As + s * PLANE + a * 32 * LDW + ks * 8);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) bfr[s][b] = *(const bf16x8 *)(Bs + s * PLANE + b * 32 * LDW + ks * 8);
-      }
+      frags(buf, ks);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          if constexpr (SPLIT == 3) {      // smallest terms first: l h, h l, m m, m h, h m, h h
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bfr[0][b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[2][b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[0][b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[1][b], acc[a][b], 0, 0, 0);
-          }
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
-        }
+        for (int b = 0; b < TN; ++b) mma_ab(a, b);
     }
-    if (more) sstore(buf ^ 1);
+  };
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1 % DEPTH> S1;
+  typedef std::integral_constant<int, 2 % DEPTH> S2;
+  if constexpr (DEPTH == 1) {
+    gload(S0());
+    sstore(0, S0());
     __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < KT;
+      if (more) gload(S0());
+      compute(buf);
+      if (more) sstore(buf ^ 1, S0());
+      __syncthreads();
+    }
+  } else {
+    gload(S0());
+    gload(S1());
+    if constexpr (DEPTH == 3) gload(S2());
+    sstore(0, S0());
+    __syncthreads();
+    int kt = 0;
+    constexpr int G = TM * TN, NP = AP + BP;
+    constexpr int PPG = (2 * NP + G - 1) / G;         // pieces of memory work per (a, b) group
+    auto step = [&](auto cur, auto nxt) {      // cur: slot of tile kt (in LDS already), nxt: slot of tile kt + 1
+      const int buf = kt & 1;
+      frags(buf, 0);
+      gprep();                                 // tile kt + DEPTH goes into the slot tile kt left
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+        for (int q = 0; q < PPG; ++q) {
+          const int piece = gi * PPG + q;      // 0 .. NP-1: loads of tile kt + DEPTH; NP .. 2 NP-1: stores of tile kt + 1
+          if (piece < NP) {
+            if (piece < AP) gA(cur, piece); else gB(cur, piece - AP);
+          } else if (piece < 2 * NP) {
+            const int p = piece - NP;
+            if (p < AP) sA(buf ^ 1, nxt, p); else sB(buf ^ 1, nxt, p - AP);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_ab(gi / TN, gi % TN);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      ++kt;
+    };
+    while (kt < KT) {
+      step(S0(), S1());
+      if (kt >= KT) break;
+      if constexpr (DEPTH == 3) {
+        step(S1(), S2());
+        if (kt >= KT) break;
+        step(S2(), S0());
+      } else {
+        step(S1(), S0());
+      }
+    }
   }
 
   // epilogue: as in the fp32 kernel (LDS-transposed tile, whole rows of 16 bytes per lane)
@@ -907,9 +988,9 @@ __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__re
       b.x = okb ? b.x : 0.0f, b.y = okb ? b.y : 0.0f, b.z = okb ? b.z : 0.0f, b.w = okb ? b.w : 0.0f;
       if constexpr (SPLIT == 3) {
         uint2 h, m, l;
-        split_bf16x3<float4>(a, &h, &m, &l);
+        split_bf16x3(a, &h, &m, &l);
         *(uint2 *)(ub + off) = h, *(uint2 *)(ub + TILE_BYTES + off) = m, *(uint2 *)(ub + 2 * TILE_BYTES + off) = l;
-        split_bf16x3<float4>(b, &h, &m, &l);
+        split_bf16x3(b, &h, &m, &l);
         *(uint2 *)(vb + off) = h, *(uint2 *)(vb + TILE_BYTES + off) = m, *(uint2 *)(vb + 2 * TILE_BYTES + off) = l;
       } else {
         *(uint2 *)(ub + off) = pack_bf16x4(a);

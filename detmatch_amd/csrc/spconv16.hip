@@ -8,6 +8,11 @@
 //                    multiplicands rounded to bf16 (RNE) on their way into the matrix pipe
 //   DM_SP16_F16      rows / filters / output IEEE half (the reference's at::Half path)
 //   DM_SP16_BF16     rows / filters / output bfloat16
+//   DM_SP16_F32SPLIT rows, filters and output fp32; fp32-CLASS arithmetic: every multiplicand is split into three
+//                    bf16 numbers (h + m + l = the 24 significand bits), the six cross products of weight 2^-16
+//                    and larger run on the bf16 instruction with fp32 accumulation — more accurate against
+//                    float64 than v_mfma_f32_16x16x4_f32 (see conv2d.hip / tools/probe_bf16_split.py) at 3/8 of
+//                    its matrix-pipe time, which is what bounds the fp32 kernel
 // Same output-stationary structure as spconv_gr (spconv.hip): a workgroup = 4 waves = one tile of 16
 // output rows, the tile's active kernel offsets dealt round-robin to the waves, the (cin x cout) B operand
 // of the current offset in registers, one LDS meeting of the four fp32 partial tiles summed in wave order
@@ -74,7 +79,8 @@ __device__ __forceinline__ void store4(ST *p, f32x4 v) {
 // wp[k][t][nb][lane][j] = B_k[32 t + 8 (lane >> 4) + j][16 nb + (lane & 15)], zero beyond ci rows:
 // the order in which a wave's lanes consume B operands of v_mfma_f32_16x16x32.  B_k = W[k] (forward) or
 // W[kk]^T, kk = flip ? kvol-1-k : k (input gradient).  W: (kvol, cin_w, cout_w) of type WT.
-template <typename WT, typename MT>
+// SPLIT = 3: three planes per (k, t, nb) block, wp[k][t][nb][plane][lane][j], plane 0 = h, 1 = m, 2 = l.
+template <typename WT, typename MT, int SPLIT>
 __global__ __launch_bounds__(256) void pack_weights16(const WT *__restrict__ w, MT *__restrict__ wp, int kvol,
                                                       int ci, int co, int transpose_w, int flip_k) {
   const int ct = (ci + 31) / 32, nbs = co / 16;
@@ -87,11 +93,20 @@ __global__ __launch_bounds__(256) void pack_weights16(const WT *__restrict__ w, 
   const int kk = flip_k ? kvol - 1 - k : k;
   float v = 0.f;
   if (c < ci) v = (float)(transpose_w ? w[((size_t)kk * co + col) * ci + c] : w[((size_t)kk * ci + c) * co + col]);
-  wp[e] = (MT)v;
+  if constexpr (SPLIT == 3) {
+    const MT h = (MT)v;
+    const float r1 = v - (float)h;
+    const MT m = (MT)r1;
+    const MT l = (MT)(r1 - (float)m);
+    MT *dst = wp + ((size_t)(k * ct + t) * nbs + nb) * (3 * 512) + lane * 8 + j;
+    dst[0] = h, dst[512] = m, dst[1024] = l;
+  } else {
+    wp[e] = (MT)v;
+  }
 }
 
 // ---- main kernel ------------------------------------------------------------------------------
-template <int CIN, int COUT, typename ST, typename MT>
+template <int CIN, int COUT, typename ST, typename MT, int SPLIT>
 __global__ __launch_bounds__(256) void spconv_gr16(const ST *__restrict__ feat, const MT *__restrict__ wpack,
                                                    const int32_t *__restrict__ nbr,
                                                    const int32_t *__restrict__ perm, int n_out, int kvol,
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256) void spconv_gr16(const ST *__restrict__ feat, 
   typedef typename Math<MT>::v8 v8;
   constexpr int NB = COUT / 16;
   constexpr int CT = (CIN + 31) / 32;          // 32-channel k blocks per kernel offset
-  constexpr int CTS = CT < 2 ? CT : 2;         // ... per pipeline step
+  constexpr int CTS = (CT < 2 || SPLIT == 3) ? 1 : 2;   // ... per pipeline step (the split keeps 3 planes of B live)
   constexpr int S = CT / CTS;
   constexpr int LDP = COUT + 4;
   __shared__ int32_t tbl[4][32][16];
@@ -148,29 +163,55 @@ __global__ __launch_bounds__(256) void spconv_gr16(const ST *__restrict__ feat, 
 #pragma unroll
   for (int i = 0; i < NB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // w: [t][nb][plane], a: [t][plane]
   auto load_step = [&](int k, int s, v8 *w, v8 *a) {
     const int idx = tbl[wave][k][r];
     const bool ok = (idx >= 0) && chan_live;
     const ST *src = feat + (size_t)(idx >= 0 ? idx : 0) * CIN + 32 * (s * CTS) + (chan_live ? 8 * kq : 0);
+    v8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (MT)0.f;
 #pragma unroll
     for (int t = 0; t < CTS; ++t) {
-      const v8 raw = load8<ST, MT>(src + 32 * t);          // unconditional (index clamped), then masked
-      v8 z;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = (MT)0.f;
-      a[t] = ok ? raw : z;
+      if constexpr (SPLIT == 3) {
+        const f32x4 lo = *(const f32x4 *)(src + 32 * t), hi = *(const f32x4 *)(src + 32 * t + 4);
+        const f32x8 x = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const v8 h = __builtin_convertvector(x, v8);
+        const f32x8 r1 = x - __builtin_convertvector(h, f32x8);
+        const v8 m = __builtin_convertvector(r1, v8);
+        const v8 l = __builtin_convertvector(r1 - __builtin_convertvector(m, f32x8), v8);
+        a[3 * t + 0] = ok ? h : z, a[3 * t + 1] = ok ? m : z, a[3 * t + 2] = ok ? l : z;
+      } else {
+        const v8 raw = load8<ST, MT>(src + 32 * t);          // unconditional (index clamped), then masked
+        a[t] = ok ? raw : z;
+      }
     }
-    const v8 *wk = (const v8 *)wpack + (size_t)k * (CT * (size_t)nb_full * 64);
+    const v8 *wk = (const v8 *)wpack + (size_t)k * (CT * (size_t)nb_full * 64 * SPLIT);
 #pragma unroll
     for (int t = 0; t < CTS; ++t)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) w[t * NB + nb] = wk[((s * CTS + t) * nb_full + nb0 + nb) * 64 + lane];
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int pl = 0; pl < SPLIT; ++pl)
+          w[(t * NB + nb) * SPLIT + pl] = wk[(((s * CTS + t) * nb_full + nb0 + nb) * SPLIT + pl) * 64 + lane];
   };
   auto compute = [&](const v8 *w, const v8 *a) {
 #pragma unroll
     for (int t = 0; t < CTS; ++t)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[nb] = Math<MT>::mfma(a[t], w[t * NB + nb], acc[nb]);
+      for (int nb = 0; nb < NB; ++nb) {
+        const v8 *wb = w + (t * NB + nb) * SPLIT;
+        if constexpr (SPLIT == 3) {     // smallest terms first: l h, h l, m m, m h, h m, h h
+          acc[nb] = Math<MT>::mfma(a[3 * t + 2], wb[0], acc[nb]);
+          acc[nb] = Math<MT>::mfma(a[3 * t + 0], wb[2], acc[nb]);
+          acc[nb] = Math<MT>::mfma(a[3 * t + 1], wb[1], acc[nb]);
+          acc[nb] = Math<MT>::mfma(a[3 * t + 1], wb[0], acc[nb]);
+          acc[nb] = Math<MT>::mfma(a[3 * t + 0], wb[1], acc[nb]);
+          acc[nb] = Math<MT>::mfma(a[3 * t + 0], wb[0], acc[nb]);
+        } else {
+          acc[nb] = Math<MT>::mfma(a[t], wb[0], acc[nb]);
+        }
+      }
   };
 
   if (mine != 0u) {
@@ -186,7 +227,7 @@ __global__ __launch_bounds__(256) void spconv_gr16(const ST *__restrict__ feat, 
         s = 0;
       }
     };
-    v8 w0[CTS * NB], w1[CTS * NB], a0[CTS], a1[CTS];
+    v8 w0[CTS * NB * SPLIT], w1[CTS * NB * SPLIT], a0[CTS * SPLIT], a1[CTS * SPLIT];
     load_step(k, s, w0, a0);
     int i = 0;
     while (true) {
@@ -222,7 +263,7 @@ __global__ __launch_bounds__(256) void spconv_gr16(const ST *__restrict__ feat, 
   }
 }
 
-template <int CIN, int COUT_FULL, typename ST, typename MT>
+template <int CIN, int COUT_FULL, typename ST, typename MT, int SPLIT>
 int launch16(const void *feat, const void *wpack, const int32_t *nbr, const int32_t *perm,
              const int32_t *tile_order, int n_out, int kvol, void *out, int mode, hipStream_t st) {
   constexpr int COUT = COUT_FULL > 64 ? 64 : COUT_FULL;
@@ -230,10 +271,10 @@ int launch16(const void *feat, const void *wpack, const int32_t *nbr, const int3
   hipEvent_t e0, e1;
   // profile tag c = 16 + storage mode: bench.py tells these launches from the fp32 kernels
   if (dm_prof_open(DM_PROF_SPCONV_GG, CIN, COUT_FULL, 16 + mode, n_out, kvol, nbr, &e0, &e1) >= 0)
-    hipExtLaunchKernelGGL((spconv_gr16<CIN, COUT, ST, MT>), grid, dim3(256), 0, st, e0, e1, 0, (const ST *)feat,
+    hipExtLaunchKernelGGL((spconv_gr16<CIN, COUT, ST, MT, SPLIT>), grid, dim3(256), 0, st, e0, e1, 0, (const ST *)feat,
                           (const MT *)wpack, nbr, perm, n_out, kvol, (int)COUT_FULL, (ST *)out, tile_order);
   else
-    spconv_gr16<CIN, COUT, ST, MT><<<grid, 256, 0, st>>>((const ST *)feat, (const MT *)wpack, nbr, perm, n_out,
+    spconv_gr16<CIN, COUT, ST, MT, SPLIT><<<grid, 256, 0, st>>>((const ST *)feat, (const MT *)wpack, nbr, perm, n_out,
                                                          kvol, COUT_FULL, (ST *)out, tile_order);
   DM_CHECK_LAUNCH();
   return DM_OK;
@@ -241,18 +282,18 @@ int launch16(const void *feat, const void *wpack, const int32_t *nbr, const int3
 
 bool chan_ok16(int c) { return c == 16 || c == 32 || c == 64 || c == 128; }
 
-template <typename ST, typename WT, typename MT>
+template <typename ST, typename WT, typename MT, int SPLIT>
 int run16(const void *feat, const void *filters, const int32_t *nbr, int n_rows_out, int kvol, int cin, int cout,
           int transpose_w, int flip_k, void *out, const int32_t *tile_order, const int32_t *row_perm, void *workspace,
           int mode, hipStream_t st) {
   const int ci = transpose_w ? cout : cin, co = transpose_w ? cin : cout;
   const int total = kvol * ((ci + 31) / 32) * (co / 16) * 512;
-  pack_weights16<WT, MT><<<dm_ceil_div(total, 256), 256, 0, st>>>((const WT *)filters, (MT *)workspace, kvol, ci, co,
+  pack_weights16<WT, MT, SPLIT><<<dm_ceil_div(total, 256), 256, 0, st>>>((const WT *)filters, (MT *)workspace, kvol, ci, co,
                                                                  transpose_w, flip_k);
   DM_CHECK_LAUNCH();
 #define DM_CASE16(CI, CO)   \
   if (ci == CI && co == CO) \
-    return launch16<CI, CO, ST, MT>(feat, workspace, nbr, row_perm, tile_order, n_rows_out, kvol, out, mode, st);
+    return launch16<CI, CO, ST, MT, SPLIT>(feat, workspace, nbr, row_perm, tile_order, n_rows_out, kvol, out, mode, st);
   DM_CASE16(16, 16)
   DM_CASE16(16, 32)
   DM_CASE16(32, 16)
@@ -271,7 +312,7 @@ int run16(const void *feat, const void *filters, const int32_t *nbr, int n_rows_
 extern "C" size_t dm_spconv16_workspace_bytes(int kvol, int cin, int cout) {
   if (kvol <= 0 || cin <= 0 || cout <= 0) return 0;
   const size_t a = (size_t)kvol * ((cin + 31) / 32) * 32 * cout, b = (size_t)kvol * ((cout + 31) / 32) * 32 * cin;
-  return dm_align((a > b ? a : b) * 2);
+  return dm_align((a > b ? a : b) * 2 * 3);        // three planes in the split mode
 }
 
 extern "C" int dm_spconv_gather_gemm16(const void *feat, int n_rows_in, const void *filters, int storage,
@@ -288,14 +329,17 @@ extern "C" int dm_spconv_gather_gemm16(const void *feat, int n_rows_in, const vo
   if (workspace_bytes < dm_spconv16_workspace_bytes(kvol, cin, cout)) return DM_ERR_WORKSPACE;
   switch (storage) {
     case DM_SP16_F32ROWS:
-      return run16<float, float, __bf16>(feat, filters, nbr, n_rows_out, kvol, cin, cout, transpose_w, flip_k, out,
+      return run16<float, float, __bf16, 1>(feat, filters, nbr, n_rows_out, kvol, cin, cout, transpose_w, flip_k, out,
                                          tile_order, row_perm, workspace, storage, st);
     case DM_SP16_F16:
-      return run16<_Float16, _Float16, _Float16>(feat, filters, nbr, n_rows_out, kvol, cin, cout, transpose_w,
+      return run16<_Float16, _Float16, _Float16, 1>(feat, filters, nbr, n_rows_out, kvol, cin, cout, transpose_w,
                                                  flip_k, out, tile_order, row_perm, workspace, storage, st);
     case DM_SP16_BF16:
-      return run16<__bf16, __bf16, __bf16>(feat, filters, nbr, n_rows_out, kvol, cin, cout, transpose_w, flip_k,
+      return run16<__bf16, __bf16, __bf16, 1>(feat, filters, nbr, n_rows_out, kvol, cin, cout, transpose_w, flip_k,
                                            out, tile_order, row_perm, workspace, storage, st);
+    case DM_SP16_F32SPLIT:
+      return run16<float, float, __bf16, 3>(feat, filters, nbr, n_rows_out, kvol, cin, cout, transpose_w, flip_k, out,
+                                            tile_order, row_perm, workspace, storage, st);
     default:
       return DM_ERR_INVALID_ARG;
   }

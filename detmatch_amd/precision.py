@@ -30,6 +30,14 @@ def sparse_bf16():
     return _STATE['mixed']
 
 
+def fp32_flavour():
+    """'fp32_mfma' (the matrix pipe's own fp32 instructions) or 'fp32_split' (fp32-class arithmetic from six bf16
+    products of three-way split operands — dense_conv.set_math): which kernels serve EXACT-class fp32, for the
+    dense and the sparse convolutions alike (dense_conv.FP32_DEFAULT, environment DM_FP32_CONV)."""
+    from . import dense_conv
+    return dense_conv.FP32_DEFAULT
+
+
 @contextlib.contextmanager
 def mixed_precision(on=True):
     prev = mixed()

@@ -253,6 +253,8 @@ def _gather_gemm(feat, filters, nbr, n_rows_out, cin, cout, transpose_w, flip_k)
         from .. import precision
         if precision.sparse_bf16():
             storage = 0
+        elif precision.fp32_flavour() == 'fp32_split':
+            storage = 3         # DM_SP16_F32SPLIT: fp32-class arithmetic on the bf16 instruction
     if storage is not None:
         # 16-bit matrix instructions (csrc/spconv16.hip): half-precision rows (indice_conv_half), or fp32 rows
         # with bf16 multiplicands in the mixed-precision mode

@@ -186,8 +186,12 @@ int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const float *filters
  *                    are rounded to bf16 (round to nearest even) inside the kernel
  *   DM_SP16_F16      feat / filters / out are IEEE half (at::Half)
  *   DM_SP16_BF16     feat / filters / out are bfloat16
+ *   DM_SP16_F32SPLIT feat / filters / out are fp32 and so is the arithmetic, to fp32 accuracy: each multiplicand is
+ *                    split into three bf16 numbers (its 24 significand bits) inside the kernel and the six
+ *                    significant cross products are accumulated in fp32 — an alternative to
+ *                    dm_spconv_gather_gemm's v_mfma_f32_16x16x4_f32 at 3/8 of its matrix-pipe time
  * cin, cout in {16,32,64,128}; tables, tile order and row permutation exactly as above. */
-enum { DM_SP16_F32ROWS = 0, DM_SP16_F16 = 1, DM_SP16_BF16 = 2 };
+enum { DM_SP16_F32ROWS = 0, DM_SP16_F16 = 1, DM_SP16_BF16 = 2, DM_SP16_F32SPLIT = 3 };
 size_t dm_spconv16_workspace_bytes(int kvol, int cin, int cout);
 int dm_spconv_gather_gemm16(const void *feat, int n_rows_in, const void *filters, int storage,
                             const int32_t *nbr, int n_rows_out, int kvol, int cin, int cout,

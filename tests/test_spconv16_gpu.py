@@ -98,3 +98,37 @@ def test_half_precision_module_path(dev):
     y.features.float().square().mean().backward()
     assert x.grad.dtype == torch.float16 and float(x.grad.float().abs().sum()) > 0
     assert net[0].weight.grad.dtype == torch.float16 and torch.isfinite(net[1].weight.grad).all()
+
+
+@pytest.mark.parametrize('cin,cout,subm', [(16, 16, True), (16, 32, False), (32, 32, True), (32, 64, False),
+                                           (64, 64, True), (64, 128, False)])
+def test_fp32_split_mode_matches_float64_better_than_the_fp32_instruction(dev, monkeypatch, cin, cout, subm):
+    """DM_SP16_F32SPLIT: three-way bf16 split of both multiplicands, six products, fp32 accumulate.  Against a
+    float64 evaluation of the same gather-GEMM its error must not exceed that of v_mfma_f32_16x16x4_f32
+    (spconv_gr), forward and input gradient, and must sit at fp32 rounding level."""
+    from detmatch_amd import dense_conv
+    from detmatch_amd.spconv import ops
+    rng = np.random.default_rng(cin + 5 * cout)
+    idx, rb = _scene(dev, rng, 6000, subm)
+    x = torch.from_numpy(rng.standard_normal((rb.n_in, cin)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((27, cin, cout)) * 0.1).astype(np.float32)).to(dev)
+    dy = torch.from_numpy(rng.standard_normal((rb.n_out, cout)).astype(np.float32)).to(dev)
+    # float64 reference from the gather table (pairs (in, out) per offset)
+    p, num = rb.indice_pairs.cpu().numpy(), rb.indice_num.cpu().numpy()
+    x64, w64, dy64 = x.cpu().double().numpy(), w.cpu().double().numpy(), dy.cpu().double().numpy()
+    y_ref = np.zeros((rb.n_out, cout))
+    dx_ref = np.zeros((rb.n_in, cin))
+    for k in range(27):
+        i, o = p[k, 0, :num[k]], p[k, 1, :num[k]]
+        np.add.at(y_ref, o, x64[i] @ w64[k])
+        np.add.at(dx_ref, i, dy64[o] @ w64[k].T)
+    errs = {}
+    for mode in ('fp32_mfma', 'fp32_split'):
+        monkeypatch.setattr(dense_conv, 'FP32_DEFAULT', mode)
+        y = ops.indice_conv(x, w.view(3, 3, 3, cin, cout), rb.indice_pairs, rb.indice_num, rb.n_out, False, subm)
+        dx, _ = ops.indice_conv_backward(x, w.view(3, 3, 3, cin, cout), dy, rb.indice_pairs, rb.indice_num, False, subm)
+        errs[mode] = [float(np.sqrt(((got.cpu().double().numpy() - ref) ** 2).mean() / (ref ** 2).mean()))
+                      for got, ref in ((y, y_ref), (dx, dx_ref))]
+    for i in range(2):
+        assert errs['fp32_split'][i] <= 2e-7, errs
+        assert errs['fp32_split'][i] <= 1.05 * errs['fp32_mfma'][i] + 1e-8, errs
