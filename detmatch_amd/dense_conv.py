@@ -55,8 +55,9 @@ def get_math():
     return [k for k, v in _MATH.items() if v == code][0]
 
 
-# which kernels serve exact-class fp32 (environment DM_FP32_CONV=fp32_mfma|fp32_split for A/B runs)
-FP32_DEFAULT = os.environ.get('DM_FP32_CONV', 'fp32_mfma')
+# which kernels serve exact-class fp32 (environment DM_FP32_CONV=fp32_mfma|fp32_split for A/B runs): the split
+# kernels — more accurate against float64 AND faster (103 -> 93 ms per DetMatch iteration)
+FP32_DEFAULT = os.environ.get('DM_FP32_CONV', 'fp32_split')
 if FP32_DEFAULT != 'fp32_mfma':
     try:
         set_math(FP32_DEFAULT)

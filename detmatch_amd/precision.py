@@ -33,9 +33,14 @@ def sparse_bf16():
 def fp32_flavour():
     """'fp32_mfma' (the matrix pipe's own fp32 instructions) or 'fp32_split' (fp32-class arithmetic from six bf16
     products of three-way split operands — dense_conv.set_math): which kernels serve EXACT-class fp32, for the
-    dense and the sparse convolutions alike (dense_conv.FP32_DEFAULT, environment DM_FP32_CONV)."""
-    from . import dense_conv
-    return dense_conv.FP32_DEFAULT
+    dense convolutions (dense_conv.FP32_DEFAULT, environment DM_FP32_CONV, default fp32_split) and the sparse
+    ones (environment DM_FP32_SPCONV, default fp32_mfma: the sparse gather-GEMM is paced by its table -> row
+    fetches, the split's extra weight traffic and VALU work cancel what the matrix pipe saves — measured 28 vs
+    29 us on the 64 -> 64 layer, slower on the 16-channel ones)."""
+    return SPARSE_FP32
+
+
+SPARSE_FP32 = __import__('os').environ.get('DM_FP32_SPCONV', 'fp32_mfma')
 
 
 @contextlib.contextmanager
