@@ -68,21 +68,73 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vec
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from this round's rocprofv3 PMC passes
-    (profiles/r02_pmc_spconv.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of
-    this same bench command, gfx950 correction applied — tools/pmc_traffic.py); None if absent."""
-    for name in ('r02_pmc_spconv.json', 'r01_pmc_spconv.json'):
+    """(HBM-side bytes per launch of `kernel`, the committed file they come from): rocprofv3 PMC passes of this
+    same bench command (FETCH_SIZE and WRITE_SIZE in separate --pmc runs, gfx950 correction applied —
+    tools/pmc_traffic.py, tools/collect_profiles.sh).  NOT measured in this run: the counters need the profiler."""
+    for name in ('r03_pmc_spconv.json', 'r02_pmc_spconv.json', 'r01_pmc_spconv.json'):
         path = os.path.join(ROOT, 'profiles', name)
-        if os.path.exists(path):
-            break
-    else:
-        return None
-    table = json.load(open(path))
-    stem = kernel.rstrip('>')
-    for k, v in table.items():
-        if k == kernel or k.startswith(stem + ','):
-            return v['traffic_bytes_per_launch']
-    return None
+        if not os.path.exists(path):
+            continue
+        table = json.load(open(path))
+        stem = kernel.rstrip('>')
+        for k, v in table.items():
+            if k == kernel or k.startswith(stem + ','):
+                return v['traffic_bytes_per_launch'], 'profiles/' + name
+    return None, None
+
+
+def other_kernel_groups(wl):
+    """One extra (untimed) step with HIP events around every dense-convolution launch and every FPS launch:
+    the kernels that decide the step time, beside the sparse group BASELINE's metric names.
+    dense_conv: flops 2 M N K of every lattice-GEMM / weight-gradient launch over the summed event time, against
+    the fp32 matrix peak (the arithmetic is fp32-class whichever instruction serves it); fps: compulsory bytes
+    N * 12 per launch — the kernel is a latency chain of npoint dependent rounds, reported as such."""
+    from detmatch_amd import dense_conv, pointnet2_stack as pn2
+    recs = {'gemm': [], 'wgrad': [], 'fps': []}
+
+    def timed(kind, work, fn, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **k)
+        e1.record()
+        recs[kind].append((work, e0, e1))
+        return out
+    g0, w0, f0 = dense_conv._gemm, dense_conv._wgrad, pn2.furthest_point_sample_stack
+
+    def gemm(x, wp, bias, y, geom, taps, residual=None):
+        return timed('gemm', 2.0 * geom[0] * geom[7] * geom[8] * geom[6] * geom[15] * geom[3], g0, x, wp, bias, y, geom,
+                     taps, residual)
+
+    def wgrad(U, V, out, scale_u, geom, taps, *rest):
+        return timed('wgrad', 2.0 * geom[0] * geom[1] * geom[2] * geom[3] * geom[4] * geom[9], w0, U, V, out, scale_u,
+                     geom, taps, *rest)
+
+    def fps(xyz, cnt, npoint):
+        return timed('fps', float(xyz.shape[0]) * 12, f0, xyz, cnt, npoint)
+    dense_conv._gemm, dense_conv._wgrad, pn2.furthest_point_sample_stack = gemm, wgrad, fps
+    try:
+        wl.step()
+        torch.cuda.synchronize()
+    finally:
+        dense_conv._gemm, dense_conv._wgrad, pn2.furthest_point_sample_stack = g0, w0, f0
+    out = {}
+    for kind in ('gemm', 'wgrad'):
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs[kind])
+        fl = sum(w for w, _, _ in recs[kind])
+        if ms > 0:
+            out['dense_conv.' + ('fwd+dgrad' if kind == 'gemm' else 'wgrad')] = dict(
+                bound='mfma', launches_per_step=len(recs[kind]), ms_per_step=round(ms, 3),
+                GFLOP_per_step=round(fl / 1e9, 1), achieved=round(fl / ms / 1e9, 1), peak=MFMA_F32_PEAK_TFLOPS,
+                unit='TFLOP/s', frac=round(fl / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), math=dense_conv.get_math(),
+                timing='HIP events around each launch (includes the launch gap of short kernels)')
+    if recs['fps']:
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs['fps'])
+        by = sum(w for w, _, _ in recs['fps'])
+        out['fps'] = dict(bound='latency (npoint dependent rounds on one workgroup per sample; side streams)',
+                          launches_per_step=len(recs['fps']), ms_per_step=round(ms, 3),
+                          achieved=round(by / ms / 1e6, 3), peak=HBM_PEAK_GBS, unit='GB/s',
+                          frac=round(by / ms / 1e6 / HBM_PEAK_GBS, 6))
+    return out
 
 
 def build_workload(dev, rank):
@@ -368,6 +420,7 @@ def main():
     # one extra untimed step with the launch trace on — on EVERY rank (a step contains the gradient
     # and log all-reduces; a rank stepping alone would dead-lock the others)
     per_step, per_dir, per_w = trace_launches(wl)
+    others = other_kernel_groups(wl)       # on every rank too (the step contains collectives)
     if rank == 0:
         # ---- roofline of the sparse-conv kernels (HIP events from the timed region) ----
         # the synthetic batch is the same every step, so launch j of a step always sees the same
@@ -413,8 +466,11 @@ def main():
             # traffic at 0.27x the algorithmic bytes — matrix-pipe issue, not HBM.  `achieved` / `peak`
             # are therefore FLOP rates; the per-pair byte convention of SURVEY §8(d), which
             # BASELINE.json's metric quotes, is reported beside it as `algorithmic_hbm`.
+            traffic, traffic_src = pmc_traffic(name)
             roof = dict(bound='mfma', achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=pmc_traffic(name), kernel=name,
+                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic,
+                        traffic_source=('%s (rocprofv3 --pmc passes of this command, not measured in this run)'
+                                        % traffic_src) if traffic_src else None, kernel=name,
                         bound_detail='mfma-issue (fp32 v_mfma_f32_16x16x4_f32; rows packed by neighbour mask, tiles ~89 % full; weights re-read from L2 per (tile, offset))',
                         avg_us=round(g['ms'] / g['launches'] * 1e3, 2), launches=g['launches'],
                         flops_per_launch=int(g['flops'] / g['launches']),
@@ -422,7 +478,7 @@ def main():
                         algorithmic_hbm=dict(achieved=round(g['bytes'] / sec / 1e9, 1), peak=HBM_PEAK_GBS,
                                              unit='GB/s', frac=round(g['bytes'] / sec / 1e9 / HBM_PEAK_GBS, 4),
                                              convention='SURVEY 8(d): P*(Cin+Cout)*4 + 8P + K*Cin*Cout*4 + N_out*Cout*4'),
-                        all_spconv={k: rates(v) for k, v in by_dir.items()})
+                        all_spconv={k: rates(v) for k, v in by_dir.items()}, other_kernels=others)
         # weak scaling: every rank steps through its own (2 labeled + 2 unlabeled) batch, so the
         # whole-job rate is world x steps / time (per-GPU-batch iterations per second, all ranks)
         out = dict(metric='train iters/sec', value=round(world * args.steps * 1.0 / dt, 3), unit='iters/sec',

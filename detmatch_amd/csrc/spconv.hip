@@ -878,11 +878,11 @@ int g_wgrad_chunk = 0;   // 0 = heuristic; dm_spconv_set_wgrad_chunk (developer 
 int g_wgrad_order = 1;   // workgroup -> (chunk, offset) map of spconv_wgrad_rows, see the kernel; offsets fastest:
                          // 58 -> 41 us on the 64 -> 64 layer with 16.8 k rows (order 2, XCD-aware: no better)
 
-int wgrad_chunks(int n_in, int *chunk) {
+int wgrad_chunks(int n_in, int *chunk, bool rows_kernel = true) {
   // a chunk = one 4-wave workgroup (a quarter each); multiples of 64 pairs.  Measured (round 3,
   // tools/bench_spconv_layers.py --wgrad-chunk): 256 wins on the layers below ~12 k rows (more workgroups
   // than CUs), 512 above (the per-workgroup merge + slab write is a fixed cost)
-  int c = g_wgrad_chunk > 0 ? g_wgrad_chunk : (n_in < 12000 ? 256 : 512);
+  int c = g_wgrad_chunk > 0 ? g_wgrad_chunk : ((n_in < 12000 && rows_kernel) ? 256 : 512);
   while ((long long)c * 128 < n_in) c *= 2;
   *chunk = c;
   return dm_ceil_div(n_in > 0 ? n_in : 1, c);
@@ -1127,7 +1127,7 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
   }
   if (!feat || !out_grad || !indice_pairs || !indice_num || !workspace) return DM_ERR_INVALID_ARG;
   int chunk;
-  int nchunks = wgrad_chunks(pair_stride, &chunk);
+  int nchunks = wgrad_chunks(pair_stride, &chunk, cin >= 16);
   if (workspace_bytes < dm_spconv_wgrad_workspace_bytes(pair_stride, kvol, cin, cout))
     return DM_ERR_WORKSPACE;
   float *slab = (float *)workspace;
