@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void dconv_gemm_kernel(
     b_off[p] = (unsigned)((n < g.Cout ? n : 0) * g.Cin + kq * 4) * 4u;
   }
   const char *xb = (const char *)x, *wb = (const char *)w;
-  const unsigned slice_bytes = (unsigned)g.Cout * g.Cin * 10u;      // DCONV_SLICE_BYTES: fp32 block + 3 bf16 planes
+  const unsigned slice_bytes = (unsigned)g.Cout * g.Cin * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -489,7 +489,7 @@ void dconv_gemm_bf16_kernel(
     b_off[p] = (unsigned)((n < g.Cout ? n : 0) * g.Cin + kq * 4) * 4u;
   }
   const char *xb = (const char *)x, *wb = (const char *)w;
-  const unsigned slice_bytes = (unsigned)g.Cout * g.Cin * 10u;      // DCONV_SLICE_BYTES: fp32 block + 3 bf16 planes
+  const unsigned slice_bytes = (unsigned)g.Cout * g.Cin * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -508,15 +508,13 @@ void dconv_gemm_bf16_kernel(
   // unconditional (fetches past the last tile are clamped to valid, unused data; the store of a tile past the
   // end goes to the idle buffer), so the loop body is one basic block.
   constexpr int DEPTH = SPLIT == 3 ? (BM * BN > 64 * 64 ? 2 : 3) : 1;   // 128 x 128: a ring of three spills
-  float4 ra[DEPTH][AP], rb[DEPTH][SPLIT == 3 ? 1 : BP];
-  uint2 rbp[DEPTH][SPLIT == 3 ? BP : 1][3];      // split mode: the weights arrive as their three bf16 planes
+  float4 ra[DEPTH][AP], rb[DEPTH][BP];
   bool ra_ok[DEPTH][AP];
   const int KT_all = g.Ktot / BK;
   const int kt0 = blockIdx.y * kt_per_split;
   int tU = (kt0 * BK) / g.Cin, cU = (kt0 * BK) % g.Cin;
   int g_dy = 0, g_dx = 0;
   unsigned g_shift = 0, g_wshift = 0;
-  const unsigned nk2 = (unsigned)g.Cout * g.Cin * 2u;            // bytes of one bf16 plane of a slice
   auto gprep = [&]() {
     const int tr = __builtin_amdgcn_readfirstlane(tU);
     const int t = tr < g.T ? tr : g.T - 1;
@@ -527,8 +525,7 @@ void dconv_gemm_bf16_kernel(
     cU = wrap ? 0 : cU;
     g_dy = tt.dy[t], g_dx = tt.dx[t];
     g_shift = (unsigned)((g_dy * g.Win + g_dx) * g.Cin + c0) * 4u;
-    g_wshift = SPLIT == 3 ? (unsigned)tt.ws[t] * slice_bytes + 2u * nk2 + (unsigned)c0 * 2u   // first plane of the slice
-                          : (unsigned)tt.ws[t] * slice_bytes + (unsigned)c0 * 4u;
+    g_wshift = (unsigned)tt.ws[t] * slice_bytes + (unsigned)c0 * 4u;
   };
   auto gA = [&](auto slot, int p) {     // unconditional clamped loads, masked at the LDS store (see the fp32 kernel)
     constexpr int R = decltype(slot)::value;
@@ -539,12 +536,7 @@ void dconv_gemm_bf16_kernel(
   };
   auto gB = [&](auto slot, int p) {
     constexpr int R = decltype(slot)::value;
-    if constexpr (SPLIT == 3) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) rbp[R][p][pl] = *(const uint2 *)(wb + g_wshift + pl * nk2 + (b_off[p] >> 1));
-    } else {
-      rb[R][p] = *(const float4 *)(wb + b_off[p] + g_wshift);
-    }
+    rb[R][p] = *(const float4 *)(wb + b_off[p] + g_wshift);
   };
   auto gload = [&](auto slot) {
     gprep();
@@ -571,7 +563,9 @@ void dconv_gemm_bf16_kernel(
     constexpr int R = decltype(slot)::value;
     unsigned *dst = ldsw + buf * SPLIT * PLANE + BM * LDW + (r0 + p * RPP) * LDW + kq * 2;
     if constexpr (SPLIT == 3) {
-      *(uint2 *)dst = rbp[R][p][0], *(uint2 *)(dst + PLANE) = rbp[R][p][1], *(uint2 *)(dst + 2 * PLANE) = rbp[R][p][2];
+      uint2 h, m, l;
+      split_bf16x3(rb[R][p], &h, &m, &l);
+      *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
     } else {
       *(uint2 *)dst = pack_bf16x4(rb[R][p]);
     }
@@ -1108,25 +1102,7 @@ __global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(
   *o = accumulate ? *o + s : s;
 }
 
-// Packed weights, one SLICE of DCONV_SLICE_BYTES(N, K) = 10 N K bytes per tap s:
-//   [N][K] fp32                         what the fp32 / mixed kernels read
-//   3 x [N][K] bf16 planes h, m, l      the three-way split (h + m + l == the fp32 value, 24 significand
-//                                       bits) the fp32-class split kernel feeds to the bf16 matrix instruction
-// — split ONCE per weight update here instead of per tile and per k-block inside the GEMM.
-__device__ __forceinline__ void dconv_pack_store(float *dst, int s, int n, int k, int N, int K, float v) {
-  const size_t nk = (size_t)N * K;
-  char *slice = (char *)dst + (size_t)s * nk * 10;
-  const size_t e = (size_t)n * K + k;
-  ((float *)slice)[e] = v;
-  const __bf16 h = (__bf16)v;
-  const float r1 = v - (float)h;
-  const __bf16 m = (__bf16)r1;
-  const __bf16 l = (__bf16)(r1 - (float)m);
-  __bf16 *planes = (__bf16 *)(slice + nk * 4);
-  planes[e] = h, planes[nk + e] = m, planes[2 * nk + e] = l;
-}
-
-// dst slice s, [n][k] = src[n*sn + k*sk + s*st] * scale_n[n] * scale_k[k]   (k >= Ksrc, n >= Nsrc: zero)
+// dst[s][n][k] = src[n*sn + k*sk + s*st] * scale_n[n] * scale_k[k]   (k >= Ksrc, n >= Nsrc: zero)
 __global__ __launch_bounds__(256) void dconv_pack_kernel(const float *__restrict__ src,
                                                          float *__restrict__ dst,
                                                          const float *__restrict__ scale_n,
@@ -1145,7 +1121,7 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const float *__restrict
     if (scale_n) v *= scale_n[n];
     if (scale_k) v *= scale_k[k];
   }
-  dconv_pack_store(dst, s, n, k, N, K, v);
+  dst[e] = v;
 }
 
 // the same for a table of weights in one launch (blockIdx.y = table row, grid-stride over its elements):
@@ -1171,7 +1147,7 @@ __global__ __launch_bounds__(256) void dconv_pack_batch_kernel(const DConvPackDe
       if (d.scale_n) v *= d.scale_n[n];
       if (d.scale_k) v *= d.scale_k[k];
     }
-    dconv_pack_store(d.dst, s, n, k, d.N, d.K, v);
+    d.dst[e] = v;
   }
 }
 
@@ -1316,7 +1292,7 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
   for (int t = 0; t < g.T; ++t) max_slice = taps_host[2 * g.T + t] > max_slice ? taps_host[2 * g.T + t] : max_slice;
   // the kernel addresses both operands with 32-bit byte offsets
   if (M < 0 || M > 0x7fffffffLL || (long long)g.B * g.Hin * g.Win * g.Cin * 4 >= 0xffffffffLL ||
-      (long long)(max_slice + 1) * g.Cout * g.Cin * 10 >= 0xffffffffLL)
+      (long long)(max_slice + 1) * g.Cout * g.Cin * 4 >= 0xffffffffLL)
     return DM_ERR_INT32_RANGE;
   g.M = (int)M;
   g.Ktot = g.T * g.Cin;

@@ -214,8 +214,7 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
-    # per slice: [N][K] fp32 + three [N][K] bf16 planes (csrc/conv2d.hip: dconv_pack_store) = 10 N K bytes
-    dst = hit.dst if hit is not None else torch.empty((S, N * K * 10 // 4), dtype=torch.float32, device=weight.device)
+    dst = hit.dst if hit is not None else torch.empty((S, N, K), dtype=torch.float32, device=weight.device)
     _lib.check(_lib.lib().dm_dconv_pack(_lib.ptr(w), _lib.ptr(dst), _lib.ptr(scale_n),
                                         _lib.ptr(scale_k), S, N, K, n_src, k_src, sn, sk, st,
                                         _lib.stream()), 'dm_dconv_pack')

@@ -633,10 +633,8 @@ int dm_bbox_head_loss(const float *cls_score, const float *bbox_pred, const long
  * (the reference has no binding of its own here: F.conv2d -> cudnn).  Activations NHWC fp32,
  * implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).
  *
- * dm_dconv_pack: weights -> the packed layout the GEMM reads, one slice of 10*N*K bytes per tap s (dst must
- *   hold S*N*K*10 bytes): [N][K] fp32 (K contiguous) followed by three [N][K] bf16 planes h, m, l with
- *   h + m + l == the fp32 value (its three-way bf16 split, read by math mode 2):
- *   slice s, [n][k] = src[n*sn + k*sk + s*st] * scale_n[n] * scale_k[k], zero for n >= Nsrc, k >= Ksrc
+ * dm_dconv_pack: weights -> the [S][N][K] layout the GEMM reads (K contiguous):
+ *   dst[s][n][k] = src[n*sn + k*sk + s*st] * scale_n[n] * scale_k[k], zero for n >= Nsrc, k >= Ksrc
  *   (scales may be NULL; the frozen-BatchNorm fold of the 2D backbone is a scale per output
  *   channel).  Conv2d weight (Cout,Cin,KH,KW): forward N=Cout,K=Cin: sn=Cin*T, sk=T, st=1;
  *   input gradient N=Cin,K=Cout: sn=T, sk=Cin*T, st=1.
@@ -662,10 +660,10 @@ int dm_dconv_pack(const float *src, float *dst, const float *scale_n, const floa
  * 1 mixed precision — bf16 multiplicands (inputs and weights rounded to nearest-even on their way into
  * LDS), fp32 accumulation and storage (v_mfma_f32_32x32x16_bf16), the counterpart of the reference's fp16
  * (autocast) configs; layers with Cin % 64 != 0 stay fp32;
- * 2 fp32-class arithmetic on the bf16 instruction: both operands as three-way bf16 splits (their 24
- * significand bits; the weights pre-split by dm_dconv_pack, the activations on their way into LDS), the six
- * cross products of weight >= 2^-16 accumulated in fp32 — more accurate against float64 than mode 0
- * (tools/probe_bf16_split.py) at 3/8 of its matrix-pipe time; layers with Cin % 32 != 0 or Cout <= 32 use mode 0.
+ * 2 fp32-class arithmetic on the bf16 instruction: both operands are split on their way into LDS into three
+ * bf16 numbers (together their 24 significand bits) and the six cross products of weight >= 2^-16 are
+ * accumulated in fp32 — more accurate against float64 than mode 0 (tools/probe_bf16_split.py) at 3/8 of its
+ * matrix-pipe time; layers with Cin % 32 != 0 or Cout <= 32 use mode 0.
  * Process-wide; dm_dconv_wgrad follows the mode for layers with more than 64 channels on both sides. */
 int dm_dconv_set_math(int mode);
 int dm_dconv_get_math(void);
