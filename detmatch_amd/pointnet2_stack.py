@@ -441,7 +441,10 @@ class StackSAModuleMSG(nn.Module):
             new_features, _ = self.groupers[k](xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
                                                features)  # (M, C, nsample)
             new_features = new_features.permute(1, 0, 2).unsqueeze(dim=0)  # (1, C, M, nsample)
-            new_features = self.mlps[k](new_features)
+            # torch's own convolution / BatchNorm, NOT MIOpen: MIOpen may compile a kernel at run time, which
+            # forks a compiler from a process that has initialised the GPU
+            with torch.backends.cudnn.flags(enabled=False):
+                new_features = self.mlps[k](new_features)
             if self.pool_method == 'max_pool':
                 new_features = F.max_pool2d(new_features,
                                             kernel_size=[1, new_features.size(3)]).squeeze(dim=-1)

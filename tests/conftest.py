@@ -18,6 +18,16 @@ from detmatch_amd import dense_conv  # noqa: E402
 dense_conv.HOST_TENSOR_HOOK = _host_conv
 
 
+# Reference computations of the GPU tests use torch's native kernels, never MIOpen: MIOpen's find step may build a
+# kernel at run time (fork + exec of a compiler from a process that already holds the GPU), which aborts the
+# test process on hosts that forbid it — and the choice of solver depends on how much memory earlier tests hold.
+try:
+    import torch
+    torch.backends.cudnn.enabled = False
+except Exception:      # noqa
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
