@@ -588,6 +588,12 @@ class SSL(nn.Module):
             if jobs:
                 from ..spconv.ops import drive_steps_together
                 drive_steps_together(jobs)
+        # the batch's point clouds were allocated on another stream and are read here: keep the allocator informed
+        for d in dicts:
+            for part in d.values():
+                for t in (part or {}).get('points', []) if isinstance(part, dict) else []:
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(self._geom_stream)
 
     def _run_and_backprop(self, run, module, d, early, ssl_weight):
         """Run one SSL module; when it is flagged `self_contained_losses` (its forward adds losses and
