@@ -643,11 +643,64 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
     def extract_feat(self, img):
         return self.neck(self.backbone(img))
 
+    # ---- one trunk pass for several forward_train calls of an iteration (scheduling only) --------------------
+    # The backbone's BatchNorm is frozen (eval), FPN and RPN have none: the samples of a batch are independent, so
+    # backbone + FPN + RPN convolutions of the labeled and the unlabeled images of a DetMatch iteration can run as
+    # ONE batch (half the launches, fuller tiles on the small pyramid levels) although their losses are formed at
+    # different times.  The trunk outputs are cut from the graph (leaf copies); the heads and losses of each
+    # forward_train work on batch slices of the leaves and back-propagate into leaf.grad whenever their backward
+    # runs; finish_deferred_backward() then sends the accumulated gradients through the trunk once.
+    def prefetch_trunk(self, imgs):
+        """imgs: image batches (B_i, 3, H, W) of equal H, W that forward_train will be called with (same tensor
+        objects) before finish_deferred_backward()."""
+        self._shared = None
+        if len(imgs) < 2 or len({tuple(i.shape[1:]) for i in imgs}) != 1 or not torch.is_grad_enabled() \
+                or not self.training:
+            return False
+        x = self.extract_feat(torch.cat([i for i in imgs], dim=0))
+        self.rpn_head(x)
+        raw = self.rpn_head._raw_levels
+        outs = list(x) + list(raw)
+        leaves = [t.detach().requires_grad_(True) for t in outs]
+        spans, lo = {}, 0
+        for i in imgs:
+            spans[id(i)] = (i, lo, lo + i.shape[0])
+            lo += i.shape[0]
+        self._shared = dict(outs=outs, leaves=leaves, spans=spans, n_feat=len(x))
+        return True
+
+    def _shared_slices(self, img):
+        sh = getattr(self, '_shared', None)
+        hit = sh['spans'].get(id(img)) if sh else None
+        if hit is None or hit[0] is not img:
+            return None
+        _, lo, hi = hit
+        nf = sh['n_feat']
+        x = tuple(t[lo:hi] for t in sh['leaves'][:nf])
+        raw = [t[lo:hi] for t in sh['leaves'][nf:]]
+        a = self.rpn_head.num_anchors
+        self.rpn_head._raw_levels = raw
+        return x, [y[:, :a] for y in raw], [y[:, a:5 * a] for y in raw]
+
+    def finish_deferred_backward(self):
+        """Trunk backward of a prefetch_trunk() pass with everything the heads have accumulated so far."""
+        sh = getattr(self, '_shared', None)
+        self._shared = None
+        if not sh:
+            return
+        pairs = [(o, l.grad) for o, l in zip(sh['outs'], sh['leaves']) if l.grad is not None and o.requires_grad]
+        if pairs:
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, **kwargs):
         """mmdet TwoStageDetector.forward_train -> loss_rpn_cls, loss_rpn_bbox, loss_cls, acc, loss_bbox."""
         assert gt_bboxes_ignore is None
-        x = self.extract_feat(img)
-        cls, reg = self.rpn_head(x)
+        shared = self._shared_slices(img)
+        if shared is not None:
+            x, cls, reg = shared
+        else:
+            x = self.extract_feat(img)
+            cls, reg = self.rpn_head(x)
         losses = self.rpn_head.loss(cls, reg, gt_bboxes, img_metas)
         proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg['rpn'] if self.test_cfg else None)
         proposals = self.rpn_head.get_bboxes([c.detach() for c in cls], [r.detach() for r in reg],

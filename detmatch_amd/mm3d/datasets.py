@@ -345,6 +345,8 @@ def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, t
                dataset[1].device_loader(int(spg * cfg['num_unlabeled_samples']), dev, seed=seed,
                                         rank=rank, world_size=world)]
     model = model.to(dev)
+    if hasattr(model, '_share_2d_trunk'):
+        model.share_2d_trunk = True      # the OptimizerHook below finishes the deferred trunk backward
     optimizer = R.build_optimizer(model, cfg['optimizer'])
     ddp = FlatGradDDP(model, broadcast=distributed and world > 1) if dev.type == 'cuda' else model
     if isinstance(ddp, FlatGradDDP) and hasattr(optimizer, 'enable_fused'):

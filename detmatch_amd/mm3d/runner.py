@@ -366,6 +366,9 @@ class OptimizerHook(Hook):
             runner.optimizer.zero_grad()
         if runner.outputs['loss'].requires_grad:     # else: every term was back-propagated inside train_step
             runner.outputs['loss'].backward()
+        deferred = getattr(_inner(runner.model), 'finish_deferred_backward', None)
+        if deferred is not None:      # e.g. the shared 2D trunk of SSL: its backward runs once, after all the heads'
+            deferred()
         if ddp is not None:
             ddp.finish()
         if self.grad_clip is not None:

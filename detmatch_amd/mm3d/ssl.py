@@ -560,6 +560,38 @@ class SSL(nn.Module):
             return self.forward_train(**kwargs)
         return self.forward_test(**kwargs)
 
+    def _share_2d_trunk(self, lab_dict, unlab_dict, lane_mode):
+        """Scheduling only (FasterRCNN.prefetch_trunk): one backbone + FPN + RPN pass of a 2D detector for ALL
+        the image batches its training modules of this iteration will be called with (the student's labeled and
+        unlabeled images).  Needs a driver that calls finish_deferred_backward() after the last backward pass
+        (OptimizerHook does): `share_2d_trunk` is set by the callers that have one."""
+        self._deferred = []
+        if not getattr(self, 'share_2d_trunk', False) or lane_mode not in (None, 'glue', 'serial') \
+                or not torch.is_grad_enabled():
+            return
+        from .bbox_utils import mlvl_get, mlvl_getattr
+        from .ssl_modules import HardPseudoLabel_2D, TwoStageSupervised_2D
+        groups = {}
+        for chain, d in ((self.lab_ssl_modules, lab_dict), (self.unlab_ssl_modules, unlab_dict)):
+            for m in chain:
+                if isinstance(m, TwoStageSupervised_2D):
+                    img = mlvl_get(d, m.batch_dict_key + '.img')
+                elif isinstance(m, HardPseudoLabel_2D):
+                    img = mlvl_get(d, m.target_img_key)
+                else:
+                    continue
+                det = mlvl_getattr(self, m.ssl_obj_attr)
+                if torch.is_tensor(img) and hasattr(det, 'prefetch_trunk'):
+                    groups.setdefault(id(det), (det, []))[1].append(img)
+        for det, imgs in groups.values():
+            if len(imgs) >= 2 and det.prefetch_trunk(imgs):
+                self._deferred.append(det)
+
+    def finish_deferred_backward(self):
+        for det in getattr(self, '_deferred', []):
+            det.finish_deferred_backward()
+        self._deferred = []
+
     def prefetch_geometry(self, data, ready=None, tag='ahead'):
         """The weight-independent geometry (voxels, rulebooks, FPS key points) of every 3D pass of a FUTURE
         iteration's batch `data` (the dict train_step will be called with), on a side stream: its size
@@ -695,6 +727,7 @@ class SSL(nn.Module):
             # one device->host copy per round for all of them
             from ..spconv.ops import drive_steps_together
             drive_steps_together(jobs)
+        self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
         if lanes is not None:
             lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
         unlab_modules = list(self.unlab_ssl_modules)

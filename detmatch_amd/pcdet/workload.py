@@ -252,6 +252,9 @@ class DetMatchTrainWorkload(object):
         self.ddp = FlatGradDDP(self.model, broadcast=False, mode=os.environ.get('DM_GRAD_MODE', 'collect'))
         self.opt = R.build_optimizer(self.model, sched['optimizer'])
         self.model.early_backward = True
+        # one backbone + FPN + RPN pass for the student's labeled and unlabeled images (mm2d/faster_rcnn.py:
+        # prefetch_trunk; the OptimizerHook of the runner finishes the deferred trunk backward)
+        self.model.share_2d_trunk = os.environ.get('DM_SHARE_2D_TRUNK', '1') == '1'
         if os.environ.get('DM_COLLECT_EARLY', '0') == '1' and self.ddp.mode == 'collect':
             # (measured neutral, off by default) gradients of every early backward pass are folded into the flat arena by batched
             # multi-tensor adds and released, so autograd never accumulates tensor by tensor

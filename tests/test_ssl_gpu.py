@@ -490,3 +490,40 @@ def test_gradient_exchange_code_path_on_one_rank_nccl(dev, monkeypatch):
         np.testing.assert_allclose(losses[0], losses[1], rtol=2e-3)
     finally:
         dist.destroy_process_group()
+
+
+def test_shared_student_2d_trunk_equals_separate_passes(dev, monkeypatch):
+    """The student's backbone + FPN + RPN convolutions run ONCE per iteration on the labeled and the unlabeled
+    images together (FasterRCNN.prefetch_trunk, frozen BatchNorm makes the samples independent) with the trunk
+    backward deferred until both heads' gradients are in: same losses and the same parameter update as two
+    half-batch passes, up to the summation order of the weight gradients."""
+    from detmatch_amd.mm2d.faster_rcnn import FasterRCNN
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    res = []
+    for share in ('1', '0'):
+        monkeypatch.setenv('DM_SHARE_2D_TRUNK', share)
+        monkeypatch.setenv('DM_LOOKAHEAD', '0')
+        calls = []
+        orig = FasterRCNN.extract_feat
+        monkeypatch.setattr(FasterRCNN, 'extract_feat', lambda self, img, _o=orig: (calls.append((id(self), int(img.shape[0]))), _o(self, img))[1])
+        wl = DetMatchTrainWorkload(2, dev, seed=3)
+        stu = wl.model.student.detector_2d
+        w0 = stu.neck.lateral_convs[0].conv.weight.detach().clone()
+        logs = []
+        for _ in range(2):
+            wl.step()
+            logs.append({k: float(v) for k, v in wl.last_log.items() if 'loss' in k})
+        torch.cuda.synchronize()
+        mine = [b for i, b in calls if i == id(stu)]
+        assert mine == ([4, 4] if share == '1' else [2, 2, 2, 2]), mine
+        res.append((logs, (stu.neck.lateral_convs[0].conv.weight.detach() - w0).clone(),
+                    stu.backbone.layer3[0].conv2.weight.detach().clone()))
+        monkeypatch.setattr(FasterRCNN, 'extract_feat', orig)
+        del wl
+    (la, da, wa), (lb, db, wb) = res
+    for k in la[0]:
+        assert la[0][k] == pytest.approx(lb[0][k], rel=2e-4, abs=1e-6), k          # first iteration: same weights
+    assert float((da - db).abs().max()) <= 2e-3 * float(db.abs().max())
+    assert float((wa - wb).abs().max()) <= 1e-4 * float(wb.abs().max())
+    for k in ('sup.stu.loss_rpn_cls', 'sup.stu.loss_cls', 'loss'):
+        assert la[1][k] == pytest.approx(lb[1][k], rel=5e-3), k                    # second: after one update
