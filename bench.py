@@ -248,6 +248,10 @@ def cpu_baseline(frames, gpu_pieces=None):
                '+ 12 sparse convs fwd+bwd, bs=%d, no BN/optimizer)' % len(frames), cores=1, kind='port',
                sample='1 warm-up + 1 timed stage at 1 thread, then %d concurrent copies (one per thread); '
                       'BEV IoU on %dx%d boxes; %.1f s in all' % (cores, nb, nb, time.perf_counter() - t_all),
+               note='the port is plain C (gcc -O3 -mavx2, loops vectorised without reassociation); the REFERENCE\'s '
+                    'own CPU path compiled in the build container (MKL-backed torch::mm_out between its gather and '
+                    'scatter) is 2.1x faster on the convolutions forward, 3.5x backward, equal on the rulebooks and '
+                    '2x slower on the voxelizer at one thread: profiles/r03_cpu_reference_vs_port.txt',
                pieces_1_thread=pieces,
                all_cores=dict(cores=cores, value=round(cores / dtn, 4),
                               note='%d independent copies of the stage in %.1f s' % (cores, dtn)))
