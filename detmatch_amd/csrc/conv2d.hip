@@ -911,6 +911,222 @@ __global__ __launch_bounds__(WAVES_U *WAVES_V * 64) void dconv_wgrad_kernel(
   }
 }
 
+// ---- 3 x 3, stride 1: the split kernel on an input PATCH ------------------------------------------------------
+// The lattice GEMM above stages, per k-block, the input pixels of ONE tap — so every input element is fetched,
+// split into its three bf16 planes and written to LDS nine times (once per tap), and that VALU work, not the matrix
+// pipe, paces dconv_gemm_bf16_kernel<.., 3> (rocprofv3 SQ counters, DESIGN §6.3: 8.3 vector instructions per
+// matrix instruction).  For the 3 x 3 / stride-1 layers (BEV blocks, ResNet conv2, FPN and RPN 3 x 3, and their
+// input gradients — 60 % of the dense flops) a workgroup here owns an 8 x 16 patch of output pixels x BN output
+// channels and stages, per 16-channel block, the 10 x 18 input patch ONCE: the nine taps read their A fragments
+// from the same LDS image at shifted rows.  A-side fetch + split work drops 6.4x; the weights (BN x 16 per tap)
+// are staged per (tap, block) as before, double-buffered, fetched two tiles ahead.
+// LDS: A 3 planes x 180 rows x 12 words (25.9 KB, single buffer: refreshed between channel blocks), B 2 buffers x 3
+// planes x BN rows x 12 words (36.9 KB at BN = 128): 62.8 KB, two workgroups per CU.
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                              const float *__restrict__ bias, float *__restrict__ y, const DConvGeom g,
+                              const DConvTaps tt, int tiles_y, int tiles_x, int n_tiles_m, int n_tiles_n) {
+  static_assert(WAVES_M * WAVES_N == 4, "four waves");
+  constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PR = PH * PW;     // 180 patch rows
+  constexpr int LDW = 12;
+  constexpr int A_PLANE = PR * LDW, B_PLANE = BN * LDW;
+  constexpr int WM = 128 / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  constexpr int ROWS_W = TH / WAVES_M;                 // patch rows of output pixels per wave
+  constexpr int AP = (PR * 4 + 255) / 256;             // float4 pieces of the A patch per thread (3)
+  constexpr int BP = BN * 4 / 256;                     // ... of a weight tile (2 at BN = 128)
+  static_assert(TM >= 1 && TN >= 1 && BP >= 1 && ROWS_W * 16 == WM, "tile shape");
+  constexpr int LDS_WORDS = 3 * A_PLANE + 2 * 3 * B_PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned ldsw[LDS_WORDS];
+  unsigned *lds_a = ldsw, *lds_b = ldsw + 3 * A_PLANE;
+
+  const int L = blockIdx.x;
+  const int xcd = L & 7, seq = L >> 3;
+  const int mt = (seq / n_tiles_n) * 8 + xcd;
+  const int nt = seq % n_tiles_n;
+  if (mt >= n_tiles_m) return;
+  const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, bimg = mt / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // A patch pieces of this thread: piece index q = tid + 256 p -> patch row q / 4, channel quad q % 4
+  unsigned a_off[AP];
+  bool a_ok[AP];
+  int a_lds[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int q = tid + 256 * p;
+    const int row = q >> 2, kq = q & 3;
+    const int py = row / PW, px = row % PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = (row < PR) & ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
+    a_ok[p] = ok;
+    a_off[p] = ok ? (unsigned)(((bimg * g.Hin + iy) * g.Win + ix) * g.Cin + kq * 4) * 4u : 0u;
+    a_lds[p] = row < PR ? row * LDW + kq * 2 : -1;
+  }
+  unsigned b_off[BP];
+  int b_lds[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int q = tid + 256 * p;
+    const int n = n0 + (q >> 2), kq = q & 3;
+    b_off[p] = (unsigned)((n < g.Cout ? n : 0) * g.Cin + kq * 4) * 4u;
+    b_lds[p] = (q >> 2) * LDW + kq * 2;
+  }
+  const char *xb = (const char *)x, *wb = (const char *)w;
+  const unsigned slice_bytes = (unsigned)g.Cout * g.Cin * 4u;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int NCB = g.Cin / 16, T = g.T, KT = NCB * T;
+  float4 ra[AP], rb[2][BP];
+  auto gA = [&](int cb) {
+#pragma unroll
+    for (int p = 0; p < AP; ++p) ra[p] = *(const float4 *)(xb + a_off[p] + (a_ok[p] ? (unsigned)cb * 64u : 0u));
+  };
+  auto sA = [&]() {
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      if (a_lds[p] < 0) continue;
+      float4 v = ra[p];
+      const bool ok = a_ok[p];
+      v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
+      uint2 h, m, l;
+      split_bf16x3(v, &h, &m, &l);
+      unsigned *dst = lds_a + a_lds[p];
+      *(uint2 *)dst = h, *(uint2 *)(dst + A_PLANE) = m, *(uint2 *)(dst + 2 * A_PLANE) = l;
+    }
+  };
+  int ktf = 0;           // k-tile the next gB() fetches: tap = ktf % T, channel block = ktf / T (clamped at the end)
+  auto gB = [&](auto slot) {
+    constexpr int R = decltype(slot)::value;
+    const int kc = ktf < KT ? ktf : KT - 1;
+    const int tap = __builtin_amdgcn_readfirstlane(kc % T), cb = __builtin_amdgcn_readfirstlane(kc / T);
+    ++ktf;
+    const unsigned wshift = (unsigned)tt.ws[tap] * slice_bytes + (unsigned)cb * 64u;
+#pragma unroll
+    for (int p = 0; p < BP; ++p) rb[R][p] = *(const float4 *)(wb + b_off[p] + wshift);
+  };
+  auto sB = [&](int buf, auto slot, int p) {
+    constexpr int R = decltype(slot)::value;
+    uint2 h, m, l;
+    split_bf16x3(rb[R][p], &h, &m, &l);
+    unsigned *dst = lds_b + buf * 3 * B_PLANE + b_lds[p];
+    *(uint2 *)dst = h, *(uint2 *)(dst + B_PLANE) = m, *(uint2 *)(dst + 2 * B_PLANE) = l;
+  };
+  // fragment addresses: MFMA tile a of this wave covers patch rows ROWS_W*wm + 2a, +1 (16 pixels each)
+  int a_base[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+    a_base[a] = ((ROWS_W * wm + 2 * a + (lr >> 4) + 1) * PW + (lr & 15) + 1) * LDW + lh * 4;
+  const int b_base = (wn * WN + lr) * LDW + lh * 4;
+
+  bf16x8 af[3][TM], bfr[3][TN];
+  auto frags = [&](int buf, int tap) {
+    const int shift = (tt.dy[tap] * PW + tt.dx[tap]) * LDW;
+    const unsigned *Bs = lds_b + buf * 3 * B_PLANE + b_base;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[s][a] = *(const bf16x8 *)(lds_a + s * A_PLANE + a_base[a] + shift);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bfr[s][b] = *(const bf16x8 *)(Bs + s * B_PLANE + b * 32 * LDW);
+    }
+  };
+  auto mma_ab = [&](int a, int b) {      // smallest terms first: l h, h l, m m, m h, h m, h h
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bfr[0][b], acc[a][b], 0, 0, 0);
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[2][b], acc[a][b], 0, 0, 0);
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[0][b], acc[a][b], 0, 0, 0);
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[1][b], acc[a][b], 0, 0, 0);
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
+  };
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+
+  gA(0);
+  gB(S0());
+  gB(S1());
+  sA();
+#pragma unroll
+  for (int p = 0; p < BP; ++p) sB(0, S0(), p);
+  __syncthreads();
+  int kt = 0;
+  constexpr int G = TM * TN;
+  auto step = [&](int tap, auto cur, auto nxt) {   // cur: ring slot of tile kt (in LDS already), nxt: of tile kt + 1
+    const int buf = kt & 1;
+    frags(buf, tap);
+    gB(cur);                                   // tile kt + 2 into the slot tile kt left
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+      if (gi < BP) sB(buf ^ 1, nxt, gi);       // split + store of tile kt + 1, one piece per (a, b) group
+      __builtin_amdgcn_sched_barrier(0);
+      mma_ab(gi / TN, gi % TN);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = G; p < BP; ++p) sB(buf ^ 1, nxt, p);
+    __syncthreads();
+    ++kt;
+  };
+  for (int cb = 0; cb < NCB; ++cb) {
+    if (cb + 1 < NCB) gA(cb + 1);
+    for (int tap = 0; tap < T; ++tap) {
+      if (kt & 1) step(tap, S1(), S0());
+      else step(tap, S0(), S1());
+    }
+    if (cb + 1 < NCB) {        // every wave has passed the last tap's barrier: the A image is free
+      sA();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: per 32-column block the wave's WM x 32 tile through LDS (the B buffers are idle now), rows of 16 bytes
+  constexpr int LDC = 36;
+  static_assert(4 * WM * LDC <= 2 * 3 * B_PLANE + 3 * A_PLANE, "epilogue tile must fit the LDS");
+  float *cs = (float *)ldsw + wave * WM * LDC;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int ncol0 = n0 + wn * WN + b * 32;
+    const float bv = (bias != nullptr && ncol0 + lr < g.Cout) ? bias[ncol0 + lr] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[a][b][r] + bv;
+        if (g.relu == 1) v = fmaxf(v, 0.0f);
+        cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + lr] = v;
+      }
+    const int cq = lane & 7, rr = lane >> 3;
+    const int ncol = ncol0 + cq * 4;
+#pragma unroll
+    for (int it = 0; it < WM / 8; ++it) {
+      const int rl = it * 8 + rr;                       // pixel of the wave's tile: row rl / 16, column rl % 16
+      const int oy = y0 + ROWS_W * wm + (rl >> 4), ox = x0 + (rl & 15);
+      if (oy < g.LH && ox < g.LW && ncol < g.Cout) {
+        const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
+        float *dst = y + (((size_t)bimg * g.LH + oy) * g.LW + ox) * g.Cout + ncol;
+        if (ncol + 3 < g.Cout) {
+          *(float4 *)dst = v;
+        } else {
+          dst[0] = v.x;
+          if (ncol + 1 < g.Cout) dst[1] = v.y;
+          if (ncol + 2 < g.Cout) dst[2] = v.z;
+        }
+      }
+    }
+  }
+}
+
 // Mixed-precision weight gradient (dm_dconv_set_math(1)), 128 x 128 tiles: both operands have the
 // reduction index (pixels) as their ROW index in memory, so the MFMA fragments (8 consecutive pixels of
 // one channel) are columns of the staged tile.  The tile is stored as it arrives — [pixel][channel]
@@ -1215,6 +1431,7 @@ int launch_gemm(const float *x, const float *w, const float *bias, float *y, DCo
 // 0: fp32 on the matrix pipe's own fp32 instruction (v_mfma_f32_32x32x2_f32), 1: bf16 multiplicands, fp32
 // accumulate (mixed precision), 2: fp32-class through six bf16 products of the three-way split operands
 int g_dconv_math = 0;
+int g_dconv_patch = 1;    // math mode 2: 3 x 3 / stride-1 layers on dconv_patch_split_kernel (dm_dconv_set_math(2 + 16) turns it off)
 
 // How many ways the reduction of a SMALL problem (fewer 64x64 tiles than half a round) is split.
 static int dconv_gemm_splits(const int *q) {
@@ -1316,6 +1533,25 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
   // of 64x64 tiles limited to 1 (2) workgroups per CU, which spreads <= 256 (512) tiles over the
   // chip.  Problems of less than half a 64x64 round split the reduction over workgroups instead
   // (partial sums in the workspace, fixed-order reduce).
+  // 3 x 3 (or fewer taps within one pixel), stride 1, same size: the patch kernel (fp32-class split arithmetic)
+  if (g_dconv_math == 2 && g_dconv_patch && residual == nullptr && g.dense_out && g.iys == 1 && g.ixs == 1 &&
+      g.Hin == g.LH && g.Win == g.LW && g.T <= 9 && (g.Cin % 16) == 0 && (g.Cout % 4) == 0 && g.Cout >= 64) {
+    bool near = true;
+    for (int t = 0; t < g.T; ++t) near = near && tt.dy[t] >= -1 && tt.dy[t] <= 1 && tt.dx[t] >= -1 && tt.dx[t] <= 1;
+    const int tiles_y = dm_ceil_div(g.LH, 8), tiles_x = dm_ceil_div(g.LW, 16);
+    const int tm = g.B * tiles_y * tiles_x;
+    const int bn = g.Cout >= 128 ? 128 : 64;
+    const int tn = dm_ceil_div(g.Cout, bn);
+    if (near && g.T >= 4 && (long long)tm * tn >= 200) {
+      const int blocks = dm_ceil_div(tm, 8) * 8 * tn;
+      if (bn == 128)
+        dconv_patch_split_kernel<128, 2, 2><<<blocks, 256, 0, st>>>(x, w_packed, bias, y, g, tt, tiles_y, tiles_x, tm, tn);
+      else
+        dconv_patch_split_kernel<64, 4, 1><<<blocks, 256, 0, st>>>(x, w_packed, bias, y, g, tt, tiles_y, tiles_x, tm, tn);
+      DM_CHECK_LAUNCH();
+      return DM_OK;
+    }
+  }
   const int nsplit = dconv_gemm_splits(geom_host);
   const int bf = (g_dconv_math == 1 && (g.Cin % 64) == 0) ? 1 : (g_dconv_math == 2 ? 2 : 0);
 #define DM_LG(BM_, BN_, LIM_, ...)                                                  \
@@ -1359,8 +1595,13 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
 }
 
 extern "C" int dm_dconv_set_math(int mode) {
+  if (mode == 2 + 16) {       // developer switch: split arithmetic without the patch kernel (A/B)
+    g_dconv_math = 2, g_dconv_patch = 0;
+    return DM_OK;
+  }
   if (mode < 0 || mode > 2) return DM_ERR_INVALID_ARG;
   g_dconv_math = mode;
+  g_dconv_patch = 1;
   return DM_OK;
 }
 

@@ -30,7 +30,7 @@ _GENERATION = [0]
 _PACK_CACHE = {}
 
 
-_MATH = {'fp32_mfma': 0, 'bf16': 1, 'fp32_split': 2}
+_MATH = {'fp32_mfma': 0, 'bf16': 1, 'fp32_split': 2, 'fp32_split_nopatch': 18}
 
 
 def set_math(mode):
@@ -52,7 +52,7 @@ def set_math(mode):
 
 def get_math():
     code = _lib.lib().dm_dconv_get_math()
-    return [k for k, v in _MATH.items() if v == code][0]
+    return [k for k, v in _MATH.items() if v == code][0]      # ('fp32_split_nopatch' reads back as 'fp32_split')
 
 
 # which kernels serve exact-class fp32 (environment DM_FP32_CONV=fp32_mfma|fp32_split for A/B runs): the split

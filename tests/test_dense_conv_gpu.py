@@ -326,7 +326,11 @@ def test_residual_epilogue_is_add_then_relu(dev, shape, math):
     ((2, 1024, 24, 80), 256, 1, 1, 0),      # 1x1
     ((2, 256, 30, 30), 72, 1, 1, 0),        # Cout not a multiple of the tile
     ((1, 32, 20, 24), 64, 3, 1, 1),         # Cin = 32
-], ids=['3x3 128', '3x3 s2', 'splitk', '1x1', 'cout72', 'cin32'])
+    ((2, 128, 104, 176), 128, 3, 1, 1),     # patch kernel (3x3 stride 1, >= 200 tiles): BN = 128
+    ((2, 256, 100, 88), 256, 3, 1, 1),      # patch kernel: partial 8 x 16 tiles on both axes, two column tiles
+    ((2, 64, 96, 160), 64, 3, 1, 1),        # patch kernel: BN = 64 (4 x 1 waves)
+    ((1, 64, 200, 176), 72, 3, 1, 1),       # patch kernel: Cout not a multiple of the tile
+], ids=['3x3 128', '3x3 s2', 'splitk', '1x1', 'cout72', 'cin32', 'patch128', 'patch partial', 'patch64', 'patch cout72'])
 def test_fp32_split_mode_is_at_least_as_accurate_as_the_fp32_instruction(dev, shape):
     """dm_dconv_set_math(2): fp32-class arithmetic from six bf16 products of the three-way split operands.
     Against the float64 convolution its error must not exceed that of the matrix pipe's own fp32 instruction

@@ -13,8 +13,8 @@ from bench_dense_conv import LAYERS
 
 def main():
     dev = torch.device('cuda:0')
-    print('%-26s %8s | %9s %7s | %9s %7s %5s | %9s %7s %5s' % ('layer', 'GFLOP', 'fp32 MFMA', 'TF/s', 'split us', 'TF/s',
-                                                               'x', 'bf16 us', 'TF/s', 'x'))
+    print('%-26s %8s | %9s %7s | %9s %7s %5s | %9s %7s %5s | %9s' % ('layer', 'GFLOP', 'fp32 MFMA', 'TF/s', 'split us', 'TF/s',
+                                                                     'x', 'bf16 us', 'TF/s', 'x', 'no patch'))
     for name, xs, cout, k, s, p in LAYERS:
         if xs[1] % 32:
             continue
@@ -23,7 +23,7 @@ def main():
         ho, wo = (xs[2] + 2 * p - k) // s + 1, (xs[3] + 2 * p - k) // s + 1
         gf = 2.0 * xs[0] * ho * wo * cout * xs[1] * k * k / 1e9
         res = []
-        for mode in ('fp32_mfma', 'fp32_split', 'bf16'):
+        for mode in ('fp32_mfma', 'fp32_split', 'bf16', 'fp32_split_nopatch'):
             dense_conv.set_math(mode)
             with torch.no_grad():
                 for _ in range(3):
@@ -37,9 +37,9 @@ def main():
                 torch.cuda.synchronize()
             res.append(e0.elapsed_time(e1) / 20 * 1e3)
         dense_conv.set_math('fp32')
-        print('%-26s %8.2f | %9.1f %7.1f | %9.1f %7.1f %5.2f | %9.1f %7.1f %5.2f' % (
+        print('%-26s %8.2f | %9.1f %7.1f | %9.1f %7.1f %5.2f | %9.1f %7.1f %5.2f | %9.1f' % (
             name, gf, res[0], gf / res[0] * 1e3, res[1], gf / res[1] * 1e3, res[0] / res[1], res[2], gf / res[2] * 1e3,
-            res[0] / res[2]))
+            res[0] / res[2], res[3]))
 
 
 if __name__ == '__main__':
