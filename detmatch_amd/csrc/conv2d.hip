@@ -633,14 +633,18 @@ void dconv_gemm_bf16_kernel(
     __syncthreads();
     int kt = 0;
     constexpr int G = TM * TN, NP = AP + BP;
-    constexpr int PPG = (2 * NP + G - 1) / G;         // pieces of memory work per (a, b) group
+    constexpr int NGRP = 6;                            // one group per cross product, G independent accumulators each
+    constexpr int PPG = (2 * NP + NGRP - 1) / NGRP;    // pieces of memory work per group
+    // product order: smallest terms first (l h, h l, m m, m h, h m, h h); consecutive instructions of a group hit
+    // DIFFERENT accumulators, so none waits for its predecessor's result
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
     auto step = [&](auto cur, auto nxt) {      // cur: slot of tile kt (in LDS already), nxt: slot of tile kt + 1
       const int buf = kt & 1;
       frags(buf, 0);
       gprep();                                 // tile kt + DEPTH goes into the slot tile kt left
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
+      for (int gi = 0; gi < NGRP; ++gi) {
 #pragma unroll
         for (int q = 0; q < PPG; ++q) {
           const int piece = gi * PPG + q;      // 0 .. NP-1: loads of tile kt + DEPTH; NP .. 2 NP-1: stores of tile kt + 1
@@ -652,7 +656,10 @@ void dconv_gemm_bf16_kernel(
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        mma_ab(gi / TN, gi % TN);
+#pragma unroll
+        for (int ab = 0; ab < G; ++ab)
+          acc[ab / TN][ab % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[gi]][ab / TN], bfr[PB[gi]][ab % TN],
+                                                                           acc[ab / TN][ab % TN], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
@@ -1061,20 +1068,22 @@ void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restri
   __syncthreads();
   int kt = 0;
   constexpr int G = TM * TN;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
   auto step = [&](int tap, auto cur, auto nxt) {   // cur: ring slot of tile kt (in LDS already), nxt: of tile kt + 1
     const int buf = kt & 1;
     frags(buf, tap);
     gB(cur);                                   // tile kt + 2 into the slot tile kt left
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) {
-      if (gi < BP) sB(buf ^ 1, nxt, gi);       // split + store of tile kt + 1, one piece per (a, b) group
+    for (int gi = 0; gi < 6; ++gi) {           // one group per cross product: G independent accumulators
+      if (gi < BP) sB(buf ^ 1, nxt, gi);       // split + store of tile kt + 1, one piece per group
       __builtin_amdgcn_sched_barrier(0);
-      mma_ab(gi / TN, gi % TN);
+#pragma unroll
+      for (int ab = 0; ab < G; ++ab)
+        acc[ab / TN][ab % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[gi]][ab / TN], bfr[PB[gi]][ab % TN],
+                                                                         acc[ab / TN][ab % TN], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int p = G; p < BP; ++p) sB(buf ^ 1, nxt, p);
     __syncthreads();
     ++kt;
   };
@@ -1534,22 +1543,40 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
   // chip.  Problems of less than half a 64x64 round split the reduction over workgroups instead
   // (partial sums in the workspace, fixed-order reduce).
   // 3 x 3 (or fewer taps within one pixel), stride 1, same size: the patch kernel (fp32-class split arithmetic)
+  // takes the tiles that fill whole rounds of the chip (two workgroups per CU at BN = 128, three at 64); what is
+  // left — the last tile rows of the last image, a contiguous range of output pixels — goes to the lattice GEMM's
+  // spread-out 64 x 64 tail below, like the remainder of its own 128 x 128 rounds.
+  int m_patch = 0;
   if (g_dconv_math == 2 && g_dconv_patch && residual == nullptr && g.dense_out && g.iys == 1 && g.ixs == 1 &&
-      g.Hin == g.LH && g.Win == g.LW && g.T <= 9 && (g.Cin % 16) == 0 && (g.Cout % 4) == 0 && g.Cout >= 64) {
+      g.Hin == g.LH && g.Win == g.LW && g.T <= 9 && g.T >= 4 && (g.Cin % 32) == 0 && (g.Cout % 4) == 0 &&
+      g.Cout >= 64) {
     bool near = true;
     for (int t = 0; t < g.T; ++t) near = near && tt.dy[t] >= -1 && tt.dy[t] <= 1 && tt.dx[t] >= -1 && tt.dx[t] <= 1;
     const int tiles_y = dm_ceil_div(g.LH, 8), tiles_x = dm_ceil_div(g.LW, 16);
     const int tm = g.B * tiles_y * tiles_x;
     const int bn = g.Cout >= 128 ? 128 : 64;
     const int tn = dm_ceil_div(g.Cout, bn);
-    if (near && g.T >= 4 && (long long)tm * tn >= 200) {
-      const int blocks = dm_ceil_div(tm, 8) * 8 * tn;
+    const int slots = bn == 128 ? 512 : 768;
+    const long long wgs = (long long)tm * tn;
+    if (near && wgs >= slots / 2) {
+      int tm_main = tm;
+      const int rem = (int)(wgs % slots);
+      if (wgs > slots && rem != 0 && rem <= slots * 3 / 4) {
+        // whole rounds only; cut at a tile-row boundary of the LAST image so that the rest is one pixel range
+        const int want = (int)((wgs - rem) / tn);
+        const int last0 = (g.B - 1) * tiles_y * tiles_x;
+        tm_main = want <= last0 ? tm : last0 + (want - last0) / tiles_x * tiles_x;
+        if ((tm_main - last0) / tiles_x * 8 >= g.LH) tm_main = tm;
+      }
+      const int blocks = dm_ceil_div(tm_main, 8) * 8 * tn;
       if (bn == 128)
-        dconv_patch_split_kernel<128, 2, 2><<<blocks, 256, 0, st>>>(x, w_packed, bias, y, g, tt, tiles_y, tiles_x, tm, tn);
+        dconv_patch_split_kernel<128, 2, 2><<<blocks, 256, 0, st>>>(x, w_packed, bias, y, g, tt, tiles_y, tiles_x, tm_main, tn);
       else
-        dconv_patch_split_kernel<64, 4, 1><<<blocks, 256, 0, st>>>(x, w_packed, bias, y, g, tt, tiles_y, tiles_x, tm, tn);
+        dconv_patch_split_kernel<64, 4, 1><<<blocks, 256, 0, st>>>(x, w_packed, bias, y, g, tt, tiles_y, tiles_x, tm_main, tn);
       DM_CHECK_LAUNCH();
-      return DM_OK;
+      if (tm_main == tm) return DM_OK;
+      const int rows_done = (tm_main - (g.B - 1) * tiles_y * tiles_x) / tiles_x * 8;
+      m_patch = ((g.B - 1) * g.LH + rows_done) * g.LW;
     }
   }
   const int nsplit = dconv_gemm_splits(geom_host);
@@ -1565,8 +1592,8 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
   }
   const int tm128 = dm_ceil_div(g.M, 128), tn128 = dm_ceil_div(g.Cout, 128);
   const long long tiles128 = (long long)tm128 * tn128;
-  int m_done = 0;
-  if (tiles128 >= 512 && g.Cout > 64) {          // at least one full round of the big tile
+  int m_done = m_patch;
+  if (m_patch == 0 && tiles128 >= 512 && g.Cout > 64) {          // at least one full round of the big tile
     const int rem = (int)(tiles128 % 512);
     if (rem == 0 || rem > 384) return DM_LG(128, 128, 0);
     const int mt_main = (int)((tiles128 - rem) / tn128) / 8 * 8;
