@@ -35,6 +35,7 @@ SIGNATURES = {
                                     vp, sz, vp]),
     'dm_rulebook_conv_fill': (ci, [vp, ci, ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, ci,
                                    vp, vp, vp, vp, vp, vp, sz, vp]),
+    'dm_rulebook_set_mode': (ci, [ci]),
     'dm_pairs_to_table': (ci, [vp, vp, ci, ci, ci, vp, ci, vp]),
     'dm_spconv_workspace_bytes': (sz, [ci, ci, ci]),
     'dm_spconv_gather_gemm': (ci, [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),

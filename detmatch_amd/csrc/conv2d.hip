@@ -1554,7 +1554,15 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
     for (int t = 0; t < g.T; ++t) near = near && tt.dy[t] >= -1 && tt.dy[t] <= 1 && tt.dx[t] >= -1 && tt.dx[t] <= 1;
     const int tiles_y = dm_ceil_div(g.LH, 8), tiles_x = dm_ceil_div(g.LW, 16);
     const int tm = g.B * tiles_y * tiles_x;
-    const int bn = g.Cout >= 128 ? 128 : 64;
+    // column tile: 128 (two workgroups per CU) unless 64-wide tiles (three per CU, half the work each, the A patch
+    // staged twice as often) fill their rounds of the chip clearly better
+    int bn = g.Cout >= 128 ? 128 : 64;
+    if (bn == 128) {
+      const long long w128 = (long long)tm * dm_ceil_div(g.Cout, 128), w64 = (long long)tm * dm_ceil_div(g.Cout, 64);
+      const double e128 = (double)w128 / ((double)dm_ceil_div(w128, 512) * 512);
+      const double e64 = 0.85 * (double)w64 / ((double)dm_ceil_div(w64, 768) * 768);
+      if (w128 < 512 && e64 > e128) bn = 64;
+    }
     const int tn = dm_ceil_div(g.Cout, bn);
     const int slots = bn == 128 ? 512 : 768;
     const long long wgs = (long long)tm * tn;

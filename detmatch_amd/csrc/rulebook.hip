@@ -11,6 +11,7 @@
 //   nbr_out (kvol, n_out)   nbr_in (kvol, n_in)   indice_pairs (kvol, 2, n_in)
 // Offset-major tables make every wave read/write 256 contiguous bytes per
 // wave-instruction (64 consecutive rows of one kernel offset).
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -148,8 +149,7 @@ __global__ __launch_bounds__(256) void rb_assign_out(const uint32_t *sorted, int
 __global__ __launch_bounds__(256) void rb_table_conv_out(const int4 *out_ids, int n_out, RbGeom g,
                                                          const uint32_t *hkeys,
                                                          const int32_t *hvals, int log2_size,
-                                                         int32_t *nbr, int32_t *chunk_cnt,
-                                                         int nchunks) {
+                                                         int32_t *nbr) {
   int o = blockIdx.x * 256 + threadIdx.x;
   int k = blockIdx.y;
   int v = -1;
@@ -164,24 +164,28 @@ __global__ __launch_bounds__(256) void rb_table_conv_out(const int4 *out_ids, in
       v = dm_hash_find(hkeys, hvals, log2_size, in_key(g, c.x, z, y, x));
     nbr[(size_t)k * n_out + o] = v;
   }
+}
+
+// nbr_in[k][i] and, per 256 inputs, how many of them have an output through offset k (the pair lists
+// of a strided conv are filled in ascending INPUT row order from this table)
+__global__ __launch_bounds__(256) void rb_table_conv_in(const int4 *indices, int n, RbGeom g,
+                                                        const uint32_t *hkeys, const int32_t *hvals,
+                                                        int log2_size, int32_t *nbr_in,
+                                                        int32_t *chunk_cnt, int nchunks) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  int v = -1;
+  if (i < n) {
+    int4 c = indices[i];
+    int kk[3], q[3];
+    decode_k(g, k, kk);
+    if (conv_out_pos(g, c, kk, q))
+      v = dm_hash_find(hkeys, hvals, log2_size, out_key(g, c.x, q[0], q[1], q[2]));
+    nbr_in[(size_t)k * n + i] = v;
+  }
   int total;
   block_excl_scan_flag(v >= 0, &total);
   if (threadIdx.x == 0) chunk_cnt[k * nchunks + blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(256) void rb_table_conv_in(const int4 *indices, int n, RbGeom g,
-                                                        const uint32_t *hkeys, const int32_t *hvals,
-                                                        int log2_size, int32_t *nbr_in) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  int k = blockIdx.y;
-  if (i >= n) return;
-  int4 c = indices[i];
-  int kk[3], q[3];
-  decode_k(g, k, kk);
-  int v = -1;
-  if (conv_out_pos(g, c, kk, q))
-    v = dm_hash_find(hkeys, hvals, log2_size, out_key(g, c.x, q[0], q[1], q[2]));
-  nbr_in[(size_t)k * n + i] = v;
 }
 
 // per kernel offset: exclusive scan of the chunk counts, total -> indice_num[k]
@@ -215,19 +219,42 @@ __global__ __launch_bounds__(256) void rb_scan_chunks(const int32_t *chunk_cnt, 
   if (threadIdx.x == 0) indice_num[k] = carry_s;
 }
 
+// Pair lists from a gather table in ONE launch: each block sums the chunk counts before it (its slot
+// offset) and all of them (indice_num[k]) — a few hundred int32 per kernel offset — scans its own 256
+// rows, writes their pairs and takes its share of the -1 padding of slots [indice_num[k], pair_stride).
+// pair_stride == 0: counts only.
 __global__ __launch_bounds__(256) void rb_fill_pairs(const int32_t *nbr, int n_rows,
-                                                     const int32_t *chunk_off, int nchunks,
-                                                     int32_t *pairs, int pair_stride) {
-  int o = blockIdx.x * 256 + threadIdx.x;
-  int k = blockIdx.y;
-  int v = o < n_rows ? nbr[(size_t)k * n_rows + o] : -1;
-  int total;
-  int pos = block_excl_scan_flag(v >= 0, &total);
-  if (v >= 0) {
-    int s = chunk_off[k * nchunks + blockIdx.x] + pos;
-    pairs[((size_t)k * 2 + 0) * pair_stride + s] = v;
-    pairs[((size_t)k * 2 + 1) * pair_stride + s] = o;
+                                                     const int32_t *chunk_cnt, int nchunks,
+                                                     int32_t *pairs, int pair_stride,
+                                                     int32_t *indice_num, int rows_are_inputs) {
+  __shared__ int red[2][4];
+  const int k = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int before = 0, all = 0;
+  for (int i = threadIdx.x; i < nchunks; i += 256) {
+    const int c = chunk_cnt[k * nchunks + i];
+    all += c;
+    if (i < (int)blockIdx.x) before += c;
   }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d), all += __shfl_xor(all, d);
+  if (lane == 0) red[0][w] = before, red[1][w] = all;
+  __syncthreads();
+  before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) indice_num[k] = all;
+  if (pair_stride <= 0) return;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int v = o < n_rows ? nbr[(size_t)k * n_rows + o] : -1;
+  int total;
+  const int pos = block_excl_scan_flag(v >= 0, &total);
+  int32_t *p_in = pairs + ((size_t)k * 2 + 0) * pair_stride, *p_out = pairs + ((size_t)k * 2 + 1) * pair_stride;
+  if (v >= 0) {
+    p_in[before + pos] = rows_are_inputs ? o : v;
+    p_out[before + pos] = rows_are_inputs ? v : o;
+  }
+  // padding of the unused slots, spread over the blocks of this offset
+  for (int sl = all + blockIdx.x * 256 + threadIdx.x; sl < pair_stride; sl += gridDim.x * 256)
+    p_in[sl] = -1, p_out[sl] = -1;
 }
 
 __global__ __launch_bounds__(256) void rb_pairs_to_table(const int32_t *pairs,
@@ -241,6 +268,153 @@ __global__ __launch_bounds__(256) void rb_pairs_to_table(const int32_t *pairs,
   int out = pairs[((size_t)k * 2 + 1) * pair_stride + s];
   if (side) table[(size_t)k * n_rows + out] = in;
   else table[(size_t)k * n_rows + in] = out;
+}
+
+
+// ---- strided conv, occupancy-bitmap path --------------------------------------------------------
+// One bit per OUTPUT cell (batch * out_vol bits; 3 MB for KITTI's spconv2 at B = 2) replaces the
+// candidate hash + radix sort: the ascending flat cell id the reference orders outputs by
+// (indice_cuda.cu:64-70, torch::_unique) IS the rank of a set bit, so
+//   mark (atomicOr) -> per-1024-word popcount prefix -> prefix of the block sums -> n_out
+// is the whole count phase (memset, mark, scan, block prefix: 4 launches), and in the fill phase (emit, tables,
+// pair lists: 3 launches) nbr_in[k][i] is a rank lookup (two prefix reads + one popcount) and
+// nbr_out[k][rank] = i its scatter (for one offset k an output has at most one input).  No input
+// hash, no sort, no per-pair atomics; same results bit for bit.
+// One thread per (input, offset).  Device-scope atomics execute at the memory side of the fabric, so
+// they are made few: neighbouring lanes (neighbouring inputs, same offset) mostly hit the same 32-cell
+// word, a segmented OR over each run of equal words leaves ONE atomicOr per run, and a word whose bits
+// are already seen set is skipped (a stale read only costs a redundant atomic).
+__global__ __launch_bounds__(256) void rb_bitmap_mark(const int4 *indices, int n, RbGeom g,
+                                                      uint32_t *bits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  uint32_t word = 0xffffffffu, m = 0;
+  if (i < n) {
+    const int4 c = indices[i];
+    int kk[3], q[3];
+    decode_k(g, k, kk);
+    if (conv_out_pos(g, c, kk, q)) {
+      const uint32_t key = out_key(g, c.x, q[0], q[1], q[2]);
+      word = key >> 5, m = 1u << (key & 31);
+    }
+  }
+  if (__ballot(m != 0) == 0) return;
+  const uint32_t prev = __shfl_up(word, 1), next = __shfl_down(word, 1);
+  bool head = lane == 0 || prev != word;
+  const bool tail = lane == 63 || next != word;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t mp = __shfl_up(m, d);
+    const int hp = __shfl_up((int)head, d);
+    if (lane >= d && !head) m |= mp, head = hp != 0;
+  }
+  if (tail && m != 0 && (bits[word] & m) != m) atomicOr(&bits[word], m);
+}
+
+// 1024 words per block: word_pre[w] = set bits in the block's words before w, blk_sum[b] = the block's
+// bits (their exclusive prefix blk_off and the total n_out come from one 256-thread rb_scan_chunks block:
+// a same-address atomic per block costs more than that launch)
+__global__ __launch_bounds__(256) void rb_bitmap_scan(const uint32_t *bits, int32_t *word_pre,
+                                                      int32_t *blk_sum) {
+  __shared__ int wsum[4];
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const uint4 b = ((const uint4 *)bits)[q];
+  const int c0 = __popc(b.x), c1 = __popc(b.y), c2 = __popc(b.z), c3 = __popc(b.w);
+  const int t = c0 + c1 + c2 + c3;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = t;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int u = __shfl_up(incl, d);
+    if (lane >= d) incl += u;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int j = 0; j < w; ++j) base += wsum[j];
+  const int e = base + incl - t;
+  ((int4 *)word_pre)[q] = make_int4(e, e + c0, e + c0 + c1, e + c0 + c1 + c2);
+  if (threadIdx.x == 255) blk_sum[blockIdx.x] = base + incl;
+}
+
+__device__ __forceinline__ int4 out_cell(const RbGeom &g, uint32_t key) {
+  uint32_t b = key / g.out_vol, cell = key % g.out_vol;
+  int x = cell % g.out_shape[2];
+  int t = cell / g.out_shape[2];
+  return make_int4((int)b, t / g.out_shape[1], t % g.out_shape[1], x);
+}
+
+// One thread per BYTE of the bitmap (a lane walking a whole word of a dense region serialises 32
+// dependent stores): every set bit becomes one row of out_ids in ascending cell order — one full decode
+// per non-empty byte, then +1 in x with carries per bit.  The blocks launched behind the bitmap's own
+// do the -1 fill of nbr_out that rb_bitmap_tables scatters into.
+__global__ __launch_bounds__(256) void rb_bitmap_emit(const uint32_t *bits, const int32_t *word_pre,
+                                                      const int32_t *blk_off, RbGeom g, int4 *out_ids,
+                                                      int n_out, int32_t *nbr_out, size_t nbr_words,
+                                                      int nblk_emit) {
+  if ((int)blockIdx.x >= nblk_emit) {
+    const size_t f = (size_t)(blockIdx.x - nblk_emit) * 256 + threadIdx.x, step = (size_t)(gridDim.x - nblk_emit) * 256;
+    if (((uintptr_t)nbr_out & 15) == 0) {
+      const int4 neg = make_int4(-1, -1, -1, -1);
+      const size_t quads = nbr_words / 4;
+      for (size_t i = f; i < quads; i += step) ((int4 *)nbr_out)[i] = neg;
+      if (f < (nbr_words & 3)) nbr_out[quads * 4 + f] = -1;
+    } else {
+      for (size_t i = f; i < nbr_words; i += step) nbr_out[i] = -1;
+    }
+    return;
+  }
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;      // 64 words per block
+  const size_t w = t >> 2;
+  const int sh = (int)(t & 3) * 8;
+  const uint32_t word = bits[w];
+  uint32_t b = (word >> sh) & 0xffu;
+  if (!b) return;
+  int r = blk_off[w >> 10] + word_pre[w] + __popc(word & ((1u << sh) - 1u));
+  const int4 c0 = out_cell(g, (uint32_t)(w * 32 + sh));
+  while (b) {
+    const int bit = __ffs((int)b) - 1;
+    b &= b - 1;
+    int4 c = c0;
+    c.w += bit;
+    while (c.w >= g.out_shape[2]) {
+      c.w -= g.out_shape[2];
+      if (++c.z >= g.out_shape[1]) {
+        c.z = 0;
+        if (++c.y >= g.out_shape[0]) c.y = 0, ++c.x;
+      }
+    }
+    if (r < n_out) out_ids[r] = c;
+    ++r;
+  }
+}
+
+// nbr_in[k][i] = rank of the output cell, nbr_out[k][rank] = i, and the per-256-input pair counts
+__global__ __launch_bounds__(256) void rb_bitmap_tables(const int4 *indices, int n, RbGeom g,
+                                                        const uint32_t *bits, const int32_t *word_pre,
+                                                        const int32_t *blk_off, int32_t *nbr_in,
+                                                        int32_t *nbr_out, int n_out,
+                                                        int32_t *chunk_cnt, int nchunks) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  int v = -1;
+  if (i < n) {
+    int4 c = indices[i];
+    int kk[3], q[3];
+    decode_k(g, k, kk);
+    if (conv_out_pos(g, c, kk, q)) {
+      const uint32_t key = out_key(g, c.x, q[0], q[1], q[2]);
+      const uint32_t w = key >> 5;
+      v = blk_off[w >> 10] + word_pre[w] + __popc(bits[w] & ((1u << (key & 31)) - 1u));
+      if (v < n_out) nbr_out[(size_t)k * n_out + v] = i;
+      else v = -1;                                 // n_out smaller than the count phase reported
+    }
+    nbr_in[(size_t)k * n + i] = v;
+  }
+  int total;
+  block_excl_scan_flag(v >= 0, &total);
+  if (threadIdx.x == 0) chunk_cnt[k * nchunks + blockIdx.x] = total;
 }
 
 struct RbWorkspace {
@@ -310,19 +484,53 @@ int make_geom(RbGeom *g, int batch, const int *spatial, const int *out_shape, co
   return DM_OK;
 }
 
+
+// 0: bitmap path whenever its arrays fit the workspace region of the hash path's candidate
+// structures (dm_rulebook_workspace_bytes is a function of n_in and kvol only); 1: hash + sort always
+// (developer A/B switch and the path of tiny inputs on huge grids); 2: bitmap or DM_ERR_WORKSPACE
+int g_rb_mode = 0;
+
+struct RbBitmap {
+  uint32_t *bits;
+  int32_t *word_pre;
+  int32_t *blk_sum;
+  int32_t *blk_off;
+  size_t words;       // multiple of 1024
+  int nblk;
+  bool fits;
+};
+
+RbBitmap carve_bitmap(const RbWorkspace &w, const RbGeom &g, int batch, int n) {
+  RbBitmap b;
+  const unsigned long long cells = (unsigned long long)g.out_vol * batch;
+  b.words = (size_t)((cells + 32767) / 32768) * 1024;
+  b.nblk = (int)(b.words / 1024);
+  // the region between the input hash and the chunk counters: hb_keys, hb_vals, uniq, sorted
+  char *lo = (char *)w.hb_keys, *hi = (char *)w.counter;
+  DmArena a(lo, (size_t)(hi - lo));
+  b.bits = a.take<uint32_t>(b.words);
+  b.word_pre = a.take<int32_t>(b.words);
+  b.blk_sum = a.take<int32_t>(b.nblk);
+  b.blk_off = a.take<int32_t>(b.nblk);
+  b.fits = a.off <= (size_t)(hi - lo);
+  (void)n;
+  return b;
+}
+
 int pairs_from_table(const int32_t *nbr, int n_rows, int kvol, int32_t *chunk_cnt,
                      int32_t *chunk_off, int nchunks, int32_t *pairs, int pair_stride,
-                     int32_t *indice_num, hipStream_t st) {
-  rb_scan_chunks<<<kvol, 256, 0, st>>>(chunk_cnt, nchunks, chunk_off, indice_num);
-  DM_CHECK_LAUNCH();
-  if (pairs != nullptr && pair_stride > 0) {
-    DM_HIP(hipMemsetAsync(pairs, 0xff, (size_t)kvol * 2 * pair_stride * sizeof(int32_t), st));
-    if (n_rows > 0) {
-      rb_fill_pairs<<<dim3(nchunks, kvol), 256, 0, st>>>(nbr, n_rows, chunk_off, nchunks, pairs,
-                                                         pair_stride);
-      DM_CHECK_LAUNCH();
-    }
+                     int32_t *indice_num, hipStream_t st, int rows_are_inputs = 0) {
+  (void)chunk_off;
+  const bool lists = pairs != nullptr && pair_stride > 0;
+  if (lists && n_rows <= 0) DM_HIP(hipMemsetAsync(pairs, 0xff, (size_t)kvol * 2 * pair_stride * sizeof(int32_t), st));
+  if (n_rows <= 0 || nchunks <= 0) {
+    DM_HIP(hipMemsetAsync(indice_num, 0, kvol * sizeof(int32_t), st));
+    return DM_OK;
   }
+  rb_fill_pairs<<<dim3(lists ? nchunks : 1, kvol), 256, 0, st>>>(nbr, n_rows, chunk_cnt, nchunks, pairs,
+                                                                 lists ? pair_stride : 0, indice_num,
+                                                                 rows_are_inputs);
+  DM_CHECK_LAUNCH();
   return DM_OK;
 }
 
@@ -382,10 +590,24 @@ extern "C" int dm_rulebook_conv_count(const int32_t *indices, int n, int batch,
   if (!indices || !workspace) return DM_ERR_INVALID_ARG;
   RbWorkspace w = carve(workspace, workspace_bytes, n, g.kvol);
   if (w.total > workspace_bytes) return DM_ERR_WORKSPACE;
+  int nb = dm_ceil_div(n, 256);
+  if (g_rb_mode != 1) {
+    RbBitmap bm = carve_bitmap(w, g, batch, n);
+    if (bm.fits) {
+      DM_HIP(hipMemsetAsync(bm.bits, 0, bm.words * sizeof(uint32_t), st));
+      rb_bitmap_mark<<<dim3(nb, g.kvol), 256, 0, st>>>((const int4 *)indices, n, g, bm.bits);
+      DM_CHECK_LAUNCH();
+      rb_bitmap_scan<<<bm.nblk, 256, 0, st>>>(bm.bits, bm.word_pre, bm.blk_sum);
+      DM_CHECK_LAUNCH();
+      rb_scan_chunks<<<1, 256, 0, st>>>(bm.blk_sum, bm.nblk, bm.blk_off, n_out_dev);
+      DM_CHECK_LAUNCH();
+      return DM_OK;
+    }
+    if (g_rb_mode == 2) return DM_ERR_WORKSPACE;
+  }
   DM_HIP(hipMemsetAsync(w.ha_keys, 0xff, sizeof(uint32_t) << w.log2_a, st));
   DM_HIP(hipMemsetAsync(w.hb_keys, 0xff, sizeof(uint32_t) << w.log2_b, st));
   DM_HIP(hipMemsetAsync(w.counter, 0, sizeof(int32_t), st));
-  int nb = dm_ceil_div(n, 256);
   rb_insert_inputs<<<nb, 256, 0, st>>>((const int4 *)indices, n, g, w.ha_keys, w.ha_vals,
                                        w.log2_a);
   DM_CHECK_LAUNCH();
@@ -419,6 +641,23 @@ extern "C" int dm_rulebook_conv_fill(const int32_t *indices, int n, int batch,
   if ((size_t)n_out > (size_t)n * g.kvol) return DM_ERR_INVALID_ARG;
   RbWorkspace w = carve(workspace, workspace_bytes, n, g.kvol);
   if (w.total > workspace_bytes) return DM_ERR_WORKSPACE;
+  if (g_rb_mode != 1) {
+    RbBitmap bm = carve_bitmap(w, g, batch, n);
+    if (bm.fits) {      // same decision as the count phase that filled the bitmap in this workspace
+      const int nbo = dm_ceil_div(n_out, 256), nbi = dm_ceil_div(n, 256);
+      const size_t nbr_words = (size_t)g.kvol * n_out;
+      const int fill_blocks = (int)std::min<size_t>(2048, dm_ceil_div(nbr_words / 4 + 1, 256));
+      const int emit_blocks = (int)(bm.words / 64);
+      rb_bitmap_emit<<<emit_blocks + fill_blocks, 256, 0, st>>>(bm.bits, bm.word_pre, bm.blk_off, g, (int4 *)out_ids,
+                                                                n_out, nbr_out, nbr_words, emit_blocks);
+      DM_CHECK_LAUNCH();
+      rb_bitmap_tables<<<dim3(nbi, g.kvol), 256, 0, st>>>((const int4 *)indices, n, g, bm.bits, bm.word_pre,
+                                                         bm.blk_off, nbr_in, nbr_out, n_out, w.chunk_cnt, nbi);
+      DM_CHECK_LAUNCH();
+      return pairs_from_table(nbr_in, n, g.kvol, w.chunk_cnt, w.chunk_off, nbi, indice_pairs, n, indice_num, st, 1);
+    }
+    if (g_rb_mode == 2) return DM_ERR_WORKSPACE;
+  }
   // ascending flat cell id == the reference GPU output order (torch::_unique)
   int end_bit = 1;
   while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)g.out_vol * batch) ++end_bit;
@@ -433,14 +672,18 @@ extern "C" int dm_rulebook_conv_fill(const int32_t *indices, int n, int batch,
                                      (int4 *)out_ids);
   DM_CHECK_LAUNCH();
   rb_table_conv_out<<<dim3(nbo, g.kvol), 256, 0, st>>>((const int4 *)out_ids, n_out, g,
-                                                       w.ha_keys, w.ha_vals, w.log2_a, nbr_out,
-                                                       w.chunk_cnt, nbo);
+                                                       w.ha_keys, w.ha_vals, w.log2_a, nbr_out);
   DM_CHECK_LAUNCH();
   rb_table_conv_in<<<dim3(nbi, g.kvol), 256, 0, st>>>((const int4 *)indices, n, g, w.hb_keys,
-                                                      w.hb_vals, w.log2_b, nbr_in);
+                                                      w.hb_vals, w.log2_b, nbr_in, w.chunk_cnt, nbi);
   DM_CHECK_LAUNCH();
-  return pairs_from_table(nbr_out, n_out, g.kvol, w.chunk_cnt, w.chunk_off, nbo, indice_pairs, n,
-                          indice_num, st);
+  return pairs_from_table(nbr_in, n, g.kvol, w.chunk_cnt, w.chunk_off, nbi, indice_pairs, n, indice_num, st, 1);
+}
+
+extern "C" int dm_rulebook_set_mode(int mode) {
+  if (mode < 0 || mode > 2) return DM_ERR_INVALID_ARG;
+  g_rb_mode = mode;
+  return DM_OK;
 }
 
 extern "C" int dm_pairs_to_table(const int32_t *indice_pairs, const int32_t *indice_num, int kvol,

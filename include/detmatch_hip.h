@@ -102,8 +102,10 @@ int dm_hard_voxelize(const float *points, int n_total, int c,
  * plus, for API parity and for the weight-gradient kernel, the reference's
  *   indice_pairs (kvol, 2, n_in) int32, -1 padded; [k][0][s] = in, [k][1][s] = out
  *   indice_num   (kvol)
- * Pair slots are filled in ascending OUTPUT row order (deterministic; the
- * reference GPU order is an atomicAdd race, indice.cu.h:46-52).
+ * Pair slots are filled in ascending row order of the table they are read from
+ * — output rows (= input rows) for a sub-manifold conv, INPUT rows for a strided
+ * conv — deterministic; the reference GPU order is an atomicAdd race
+ * (indice.cu.h:46-52).
  * Kernel offset index k = kz*ky_size*kx_size + ky*kx_size + kx with
  * k_axis = in - out*stride + pad  (geometry.h:62-71).
  * Output rows of a strided conv are sorted by ascending flat cell id
@@ -111,13 +113,24 @@ int dm_hard_voxelize(const float *points, int n_total, int c,
  * spconv_ops.h:130).  dilation is 1 (the only value VoxelBackBone8x uses).
  *
  * Strided convs are two-phase because n_out is data dependent:
- *   dm_rulebook_conv_count  -> n_out_dev (device int32), sorted cell ids kept
- *                              in the workspace
+ *   dm_rulebook_conv_count  -> n_out_dev (device int32); the occupancy bitmap of
+ *                              the output grid with its popcount prefixes (or,
+ *                              on the hash path, the candidate cell ids) kept in
+ *                              the workspace
  *   (caller reads n_out, allocates exact-size outputs)
  *   dm_rulebook_conv_fill   -> out_ids, tables, pair lists
  * The same workspace must be passed, untouched, to both phases.
+ *
+ * Two implementations with identical results.  Bitmap (default whenever one bit
+ * per output cell plus a 32-bit prefix per word fits the workspace, i.e. for any
+ * real frame): mark -> popcount prefix -> rank lookups; 4 launches for the count
+ * phase, 3 for the fill phase, no hash, no sort.  Hash + radix sort: inputs of a
+ * few rows on a huge grid, where clearing and scanning the bitmap would cost
+ * more than the candidates.  dm_rulebook_set_mode: 0 automatic, 1 hash + sort
+ * always, 2 bitmap or DM_ERR_WORKSPACE (developer / test switch, process-wide).
  */
 size_t dm_rulebook_workspace_bytes(int n_in, int kvol);
+int dm_rulebook_set_mode(int mode);
 
 int dm_rulebook_subm(const int32_t *indices /*(n,4) b,z,y,x*/, int n, int batch,
                      const int *spatial_shape_host /*[3] z,y,x*/,

@@ -82,7 +82,54 @@ def _rand_indices(rng, n, batch, shape):
     dict(ks=[3, 1, 1], st=[2, 1, 1], pd=[0, 0, 0], subm=False),
 ])
 @pytest.mark.parametrize('n', [1, 37, 700])
-def test_rulebook_random(orc, dev, cfg, n):
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_rulebook_random(orc, dev, cfg, n, mode):
+    """mode 0: automatic choice, 1: hash + radix sort, 2: occupancy bitmap (strided convs only)."""
+    from detmatch_amd import _lib
+    if mode and cfg['subm']:
+        pytest.skip('sub-manifold rulebooks have one implementation')
+    _lib.check(_lib.lib().dm_rulebook_set_mode(mode), 'dm_rulebook_set_mode')
+    try:
+        _rulebook_random(orc, dev, cfg, n)
+    except RuntimeError as e:
+        if mode == 2 and 'workspace' in str(e).lower():
+            pytest.skip('bitmap larger than the workspace of %d rows' % n)
+        raise
+    finally:
+        _lib.lib().dm_rulebook_set_mode(0)
+
+
+def test_rulebook_bitmap_equals_hash_path_full_frame(dev):
+    """The two strided-rulebook implementations on the four strided layers of a KITTI-sized frame
+    pair: every output (cells, both tables, pair lists in slot order, counts) identical."""
+    from detmatch_amd import _lib, synth, voxel
+    from detmatch_amd.pcdet.workload import BACKBONE_LAYERS
+    from detmatch_amd.spconv import ops
+    pts = [torch.from_numpy(synth.lidar_frame(s)['points']).to(dev) for s in range(2)]
+    _, coors, _, _, _ = voxel.voxelize_batch(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    idx, shape, seen, n_strided = coors, [41, 1600, 1408], set(), 0
+    for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
+        if key in seen:
+            continue
+        seen.add(key)
+        books = []
+        for mode in ((1, 2) if not subm else (0,)):
+            _lib.check(_lib.lib().dm_rulebook_set_mode(mode), 'dm_rulebook_set_mode')
+            try:
+                books.append(ops.build_rulebook(idx, 2, shape, ks, st, pd, 1, subm))
+            finally:
+                _lib.lib().dm_rulebook_set_mode(0)
+        if not subm:
+            a, b = books
+            n_strided += 1
+            assert a.n_out == b.n_out and a.out_shape == b.out_shape
+            for f in ('outids', 'nbr_out', 'nbr_in', 'indice_pairs', 'indice_num'):
+                assert torch.equal(getattr(a, f), getattr(b, f)), (key, f)
+        idx, shape = books[-1].outids, books[-1].out_shape
+    assert n_strided == 4
+
+
+def _rulebook_random(orc, dev, cfg, n):
     rng = np.random.default_rng(n)
     shape = [9, 14, 11]
     idx = _rand_indices(rng, n, 3, shape)

@@ -16,6 +16,10 @@ from detmatch_amd.pcdet.workload import BACKBONE_LAYERS  # noqa: E402
 from detmatch_amd.spconv import ops  # noqa: E402
 
 
+def _n3(v):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * 3
+
+
 def timed(fn, reps, kind=None):
     """kind None: wall time per call (torch events around the loop, includes host launch
     overhead); kind 0/1: mean in-library HIP-event time of the gather-GEMM / wgrad kernel."""
@@ -36,6 +40,29 @@ def timed(fn, reps, kind=None):
         _lib.lib().dm_profile_enable(0)
         return sum(r[7] for r in recs) / max(len(recs), 1) * 1e3
     return e0.elapsed_time(e1) / reps * 1e3
+
+
+def strided_chain_us(idx, batch, shape, ks, st, pd, rb, reps=20):
+    """Device time of one strided rulebook's launch chain (count phase + fill phase back to back with
+    N_out already known — what the GPU executes per build, without the host's read of N_out)."""
+    from detmatch_amd import _lib
+    L = _lib.lib()
+    dev = idx.device
+    n, kvol = idx.shape[0], rb.kvol
+    ws = torch.empty((L.dm_rulebook_workspace_bytes(n, kvol),), dtype=torch.uint8, device=dev)
+    n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+    args = (_lib.ptr(idx), n, batch, _lib.ints(shape), _lib.ints(rb.out_shape), _lib.ints(ks), _lib.ints(st),
+            _lib.ints(pd))
+    outs = (torch.empty_like(rb.outids), torch.empty_like(rb.nbr_out), torch.empty_like(rb.nbr_in),
+            torch.empty_like(rb.indice_pairs), torch.empty_like(rb.indice_num))
+
+    def once():
+        _lib.check(L.dm_rulebook_conv_count(*args, _lib.ptr(n_out_dev), _lib.ptr(ws), ws.numel(), _lib.stream()), 'count')
+        _lib.check(L.dm_rulebook_conv_fill(*args, rb.n_out, *[_lib.ptr(o) for o in outs], _lib.ptr(ws), ws.numel(),
+                                           _lib.stream()), 'fill')
+    t = timed(once, reps)
+    assert torch.equal(outs[1], rb.nbr_out) and int(n_out_dev.item()) == rb.n_out
+    return t
 
 
 def main():
@@ -71,7 +98,12 @@ def main():
             t_rb = timed(lambda: ops.build_rulebook(idx, args.batch, shape, ks, st, pd, 1, subm), 10)
             books[key] = ops.build_rulebook(idx, args.batch, shape, ks, st, pd, 1, subm)
             tot['rb'] += t_rb
-            print('  rulebook %-12s %.1f us' % (key, t_rb))
+            chain = ''
+            if not subm:
+                t_ch = strided_chain_us(idx.int().contiguous(), args.batch, shape, _n3(ks), _n3(st), _n3(pd), books[key])
+                tot['ch'] = tot.get('ch', 0.0) + t_ch
+                chain = '   launch chain alone %.1f us' % t_ch
+            print('  rulebook %-12s %.1f us (build incl. host read of N_out)%s' % (key, t_rb, chain))
         rb = books[key]
         P = int(rb.indice_num.sum().item())
         kvol = rb.kvol
@@ -102,9 +134,10 @@ def main():
             tot['bf'] += bf
             tot['bb'] += tb
         idx, shape = rb.outids, rb.out_shape
-    print('TOTAL fwd %.1f us (%.0f GB/s)  dgrad %.1f us (%.0f GB/s)  wgrad %.1f us  rulebooks %.1f us'
+    print('TOTAL fwd %.1f us (%.0f GB/s)  dgrad %.1f us (%.0f GB/s)  wgrad %.1f us  rulebooks %.1f us '
+          '(strided launch chains alone %.1f us)'
           % (tot['f'], tot['bf'] / max(tot['f'], 1e-9) / 1e3, tot['d'],
-             tot['bb'] / max(tot['d'], 1e-9) / 1e3, tot['w'], tot['rb']))
+             tot['bb'] / max(tot['d'], 1e-9) / 1e3, tot['w'], tot['rb'], tot.get('ch', 0.0)))
 
 
 if __name__ == '__main__':
