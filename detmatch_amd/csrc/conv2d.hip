@@ -424,17 +424,28 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
 // v_mfma_f32_32x32x2_f32 kernel — the matrix pipe's own fp32 instruction is the LESS accurate path — at 6
 // bf16 instructions of 32 cycles per 16 k against 8 fp32 instructions of 64 (2.7x less matrix-pipe time).
 // K-tile 16 (one instruction deep), three planes per buffer: 72 KB of LDS, two workgroups per CU.
+// 18 VALU instructions per four elements: v_cvt_pk_bf16_f32 rounds a PAIR to nearest-even, the pair is
+// widened back with one shift and one mask, the residual is one v_pk_add_f32 (the vector form of the same
+// three conversions costs 30: it converts every element once more on its own to widen it).  Measured: 1-4 %
+// on the split kernels — they are not bound by the VALU count alone.
+__device__ __forceinline__ unsigned pack_bf16x2_rne(float a, float b) {
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  union { bf16x2v b; unsigned u; } r;
+  const f32x2v x = {a, b};
+  r.b = __builtin_convertvector(x, bf16x2v);
+  return r.u;
+}
+__device__ __forceinline__ void split_bf16x3_pair(float a, float b, unsigned *h, unsigned *m, unsigned *l) {
+  const unsigned ph = pack_bf16x2_rne(a, b);
+  const float a1 = a - __uint_as_float(ph << 16), b1 = b - __uint_as_float(ph & 0xffff0000u);
+  const unsigned pm = pack_bf16x2_rne(a1, b1);
+  const float a2 = a1 - __uint_as_float(pm << 16), b2 = b1 - __uint_as_float(pm & 0xffff0000u);
+  *h = ph, *m = pm, *l = pack_bf16x2_rne(a2, b2);
+}
 __device__ __forceinline__ void split_bf16x3(const float4 v, uint2 *h, uint2 *m, uint2 *l) {
-  typedef float f32x4v __attribute__((ext_vector_type(4)));
-  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-  union { bf16x4v b; uint2 u; } a, b, c;
-  const f32x4v x = {v.x, v.y, v.z, v.w};
-  a.b = __builtin_convertvector(x, bf16x4v);
-  const f32x4v r1 = x - __builtin_convertvector(a.b, f32x4v);
-  b.b = __builtin_convertvector(r1, bf16x4v);
-  const f32x4v r2 = r1 - __builtin_convertvector(b.b, f32x4v);
-  c.b = __builtin_convertvector(r2, bf16x4v);
-  *h = a.u, *m = b.u, *l = c.u;
+  split_bf16x3_pair(v.x, v.y, &h->x, &m->x, &l->x);
+  split_bf16x3_pair(v.z, v.w, &h->y, &m->y, &l->y);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int LIMIT, int SPLIT = 1>

@@ -192,9 +192,12 @@ def _refresh_stream(stream, device):
         e.ver = (gen, e.wref()._version, e.ver[2], e.ver[3])
 
 
+CAPTURING = [False]     # graphs.StaticSection: inside a hipGraph capture every pack is issued (and so recorded), never cached
+
+
 def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None):
     """[S][N][K] packed copy of `weight` (cached until the weight or a scale changes)."""
-    cacheable = isinstance(weight, nn.Parameter)     # temporaries may recycle an address
+    cacheable = isinstance(weight, nn.Parameter) and not CAPTURING[0]     # temporaries may recycle an address
     stream = _lib.raw_stream()
     key = (id(weight), weight.data_ptr(), tag, N, K, stream)
     ver = (_GENERATION[0], weight._version, _scale_id(scale_n), _scale_id(scale_k))

@@ -708,10 +708,33 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
         losses.update(self.roi_head.forward_train(x, img_metas, proposals, gt_bboxes, gt_labels))
         return losses
 
-    def simple_test_pre_nms(self, img, img_metas):
-        """The body of SimpleTest_2D.forward (processors_2d.py:36-84)."""
+    def _frozen(self):
+        """No parameter of the trunk requires grad (the EMA teacher): its forward records no autograd graph."""
+        sentinel = self.rpn_head.rpn_conv.weight
+        hit = self.__dict__.get('_frozen_state')
+        if hit is None or hit[0] != sentinel.requires_grad:
+            trunk = list(self.backbone.parameters()) + list(self.neck.parameters()) + list(self.rpn_head.parameters())
+            hit = self.__dict__['_frozen_state'] = (sentinel.requires_grad, not any(p.requires_grad for p in trunk))
+        return hit[1]
+
+    def _trunk_inference(self, img):
         x = self.extract_feat(img)
         cls, reg = self.rpn_head(x)
+        return x, cls, reg, self.rpn_head._raw_levels
+
+    def simple_test_pre_nms(self, img, img_metas):
+        """The body of SimpleTest_2D.forward (processors_2d.py:36-84)."""
+        frozen = self._frozen()
+        if (frozen or not torch.is_grad_enabled()) and img.is_cuda:
+            # backbone + FPN + RPN convolutions: shape-static, replayed as one hipGraph (graphs.py)
+            sec = self.__dict__.get('_trunk_section')
+            if sec is None:
+                from ..graphs import StaticSection
+                sec = self.__dict__['_trunk_section'] = StaticSection(self._trunk_inference, 'faster_rcnn.trunk')
+            x, cls, reg, self.rpn_head._raw_levels = sec(img, frozen=frozen)
+        else:
+            x = self.extract_feat(img)
+            cls, reg = self.rpn_head(x)
         proposals = self.rpn_head.get_bboxes(cls, reg, img_metas, self.test_cfg['rpn'])
         return self.roi_head.simple_test_pre_nms(x, proposals, img_metas)
 

@@ -534,7 +534,9 @@ def test_shared_student_2d_trunk_equals_separate_passes(dev, monkeypatch):
     for k in la[0]:
         tol = 2e-3 if ('loss_cls' in k or 'loss_bbox' in k or k == 'loss') else 1e-5
         assert la[0][k] == pytest.approx(lb[0][k], rel=tol, abs=1e-6), k
-    assert float((da - db).abs().max()) <= 2e-2 * float(db.abs().max())
+    # (+ 1e-8: two iterations at the warm-up learning rate move these weights by ~1e-7, a few dozen fp32 ulps of the
+    # weights themselves, so the difference of two updates is quantised in steps of 3.7e-9)
+    assert float((da - db).abs().max()) <= 2e-2 * float(db.abs().max()) + 1e-8
     assert float((wa - wb).abs().max()) <= 1e-3 * float(wb.abs().max())
     for k in ('sup.stu.loss_rpn_cls', 'sup.stu.loss_cls', 'loss'):
         assert la[1][k] == pytest.approx(lb[1][k], rel=1e-2), k                    # second: after one update
