@@ -35,6 +35,13 @@ def test_python_binding_covers_header():
     assert L.dm_spconv_workspace_bytes(27, 64, 64) == 27 * 64 * 64 * 4
 
 
+def test_integration_guide_names_every_entry_point():
+    """INTEGRATION.md shows, for each C-ABI entry, the reference binding / behaviour it stands in for."""
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    missing = [n for n in _declared() if n not in doc]
+    assert not missing, missing
+
+
 def test_ops_refuse_cpu_tensors():
     import pytest
     import torch

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collects the round's judged artifacts on the GPU box into gpurun_out/r02/ (copied to profiles/ afterwards).
+# Collects the round's judged artifacts on the GPU box into gpurun_out/r03/ (copied to profiles/ afterwards).
 #   bash tools/collect_profiles.sh
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/r03
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the default bench command
@@ -33,4 +33,11 @@ python3 tools/bench_fps.py 2>&1 | grep -v "amdgpu.ids" > $O/fps.txt
 (cd tools && python3 bench_dense_conv_math.py 2>&1 | grep -v "amdgpu.ids" > $O/dense_conv_math_modes.txt)
 python3 tools/bench_spconv_layers.py 2>&1 | grep -v "amdgpu.ids" > $O/spconv_layers.txt
 python3 tools/cpu_vs_gpu_bound.py 2>&1 | tail -1 > $O/host_vs_device.txt
+# 4. round-3 A/Bs (same box, alternated)
+for i in 1 2; do
+  for v in "default:A=1" "hipgraph_teacher_trunk:DM_HIPGRAPH=1" "separate_2d_trunks:DM_SHARE_2D_TRUNK=0" "no_lookahead:DM_LOOKAHEAD=0" "fp32_mfma_dense:DM_FP32_CONV=fp32_mfma" "split_no_patch:DM_FP32_CONV=fp32_split_nopatch" "branches:DM_TWO_LANES=1"; do
+    n=${v%%:*}; e=${v#*:}
+    env $e python3 bench.py --no-cpu-baseline --steps 30 --warmup 6 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-26s run $i  %.1f ms/step  roofline kernel %.1f us' % ('$n', d['ms_per_step'], d['roofline'].get('avg_us') or 0))" >> $O/ab_step_variants.txt
+  done
+done
 ls -la $O
