@@ -1,14 +1,12 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3y; rm -rf $O; mkdir -p $O; cd $R
-for i in 1 2 3 4 5; do
-  for v in "default:A=1" "hipgraph:DM_HIPGRAPH=1" "nopatch:DM_FP32_CONV=fp32_split_nopatch"; do
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3z; rm -rf $O; mkdir -p $O; cd $R
+for i in 1 2 3; do
+  for v in "fp32:A=1" "mixed:DM_CONV_MATH=bf16"; do
     n=${v%%:*}; e=${v#*:}
-    env $e python3 bench.py --no-cpu-baseline --steps 60 --warmup 10 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-10s %d %.2f' % ('$n', $i, d['ms_per_step']))" >> $O/ab.txt
+    env $e python3 bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-10s %d %.2f %s' % ('$n', $i, d['ms_per_step'], d['dtype']))"
   done
 done
-python3 - <<'PY'
-import collections,statistics
-d=collections.defaultdict(list)
-for l in open('gpurun_out/r3y/ab.txt'):
-    n,i,v=l.split(); d[n].append(float(v))
-for n,v in d.items(): print(n, ' '.join('%.1f'%x for x in v), '| median %.1f mean %.1f' % (statistics.median(v), statistics.mean(v)))
-PY
+cd /tmp; export TMPDIR=/tmp
+DM_CONV_MATH=bf16 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline > $O/b.json 2> $O/err.txt
+f=$(find $O/kt -name "*kernel_trace.csv" | head -1)
+python3 $R/tools/steady_profile.py $f --marker ema_f32 --steps 8 --top 30 > $O/steady_mixed.txt
+rm -rf $O/kt; head -24 $O/steady_mixed.txt | cut -c1-120

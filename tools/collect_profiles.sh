@@ -33,6 +33,7 @@ python3 tools/bench_fps.py 2>&1 | grep -v "amdgpu.ids" > $O/fps.txt
 (cd tools && python3 bench_dense_conv_math.py 2>&1 | grep -v "amdgpu.ids" > $O/dense_conv_math_modes.txt)
 python3 tools/bench_spconv_layers.py 2>&1 | grep -v "amdgpu.ids" > $O/spconv_layers.txt
 python3 tools/cpu_vs_gpu_bound.py 2>&1 | tail -1 > $O/host_vs_device.txt
+python3 tools/find_syncs.py 2>&1 | grep -v "amdgpu.ids" > $O/host_syncs.txt
 # 4. round-3 A/Bs (same box, alternated)
 for i in 1 2; do
   for v in "default:A=1" "hipgraph_teacher_trunk:DM_HIPGRAPH=1" "separate_2d_trunks:DM_SHARE_2D_TRUNK=0" "no_lookahead:DM_LOOKAHEAD=0" "fp32_mfma_dense:DM_FP32_CONV=fp32_mfma" "split_no_patch:DM_FP32_CONV=fp32_split_nopatch" "branches:DM_TWO_LANES=1"; do
