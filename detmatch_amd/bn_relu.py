@@ -107,6 +107,54 @@ class _BNReLUMaxRows(Function):
                 None, None, None, None, None, None)
 
 
+# num_batches_tracked of the training-mode layers: inside SSL.forward_train the +1 of every layer call is
+# collected and applied by ONE multi-tensor add before the EMA reads the counters (118 one-element launches per
+# iteration otherwise); anywhere else the counter moves at once, like nn.BatchNorm's.
+_DEFER = [False]
+_PENDING = []
+
+
+_DEFER_ON = os.environ.get('DM_BN_DEFER', '1') == '1'
+
+
+def _bump(bn):
+    if _DEFER[0] and _DEFER_ON:
+        _PENDING.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
+def flush_counters():
+    if not _PENDING:
+        return
+    times = {}
+    for t in _PENDING:
+        e = times.setdefault(id(t), [t, 0])
+        e[1] += 1
+    del _PENDING[:]
+    by_count = {}
+    for t, n in times.values():
+        by_count.setdefault((n, t.device, t.dtype), []).append(t)
+    with torch.no_grad():
+        for (n, _, _), ts in by_count.items():
+            torch._foreach_add_(ts, n)
+
+
+class deferred_counters(object):
+    """with deferred_counters(): ... — see _DEFER; flushes on exit (also when the body raises)."""
+
+    def __enter__(self):
+        self.outer = _DEFER[0]
+        _DEFER[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER[0] = self.outer
+        if not self.outer:
+            flush_counters()
+        return False
+
+
 def _pre_stats(x, c):
     """Column statistics attached to x by the GEMM that produced it (TallSkinnyLinear, `dm_bn_pre`)."""
     pre = getattr(x, 'dm_bn_pre', None)
@@ -122,7 +170,7 @@ def bn_relu_rows_max(x, bn, ns):
             x.shape[0] % ns == 0 and (bn.weight is None) == (bn.bias is None) and \
             os.environ.get('DM_BN_MAX', '1') == '1':
         if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            _bump(bn)
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
         return _BNReLUMaxRows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, ns, _pre_stats(x, c))
@@ -152,7 +200,7 @@ def bn_relu_rows(x, bn, relu=True):
     if training and bn.momentum is not None and _kernel_takes(x, c) and \
             (bn.weight is None) == (bn.bias is None):
         if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            _bump(bn)
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
         return _BNReLURows.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, relu, _pre_stats(x, c))

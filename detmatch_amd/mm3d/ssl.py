@@ -664,6 +664,11 @@ class SSL(nn.Module):
 
     def forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
         """ssl.py:255-350"""
+        from ..bn_relu import deferred_counters
+        with deferred_counters():      # BatchNorm call counters: one multi-tensor add before the EMA reads them
+            return self._forward_train(lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs)
+
+    def _forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
         if isinstance(unlab_stu, list):
             unlab_stu = self._collate(unlab_stu)
             unlab_tea = self._collate(unlab_tea)
@@ -801,6 +806,8 @@ class SSL(nn.Module):
                                              device=ref.device)
         # the EMA runs INSIDE forward_train, before this iteration's backward / step
         # (ssl.py:348): teacher_t = d teacher_{t-1} + (1-d) student_{t-1, post-step}
+        from ..bn_relu import flush_counters
+        flush_counters()
         with torch.no_grad():
             self._update_teacher()
         self._lanes = None
