@@ -129,6 +129,54 @@ def test_rulebook_bitmap_equals_hash_path_full_frame(dev):
     assert n_strided == 4
 
 
+@pytest.mark.parametrize('profile', ['kitti', 'waymo'])
+def test_strided_rulebook_properties_full_size(dev, profile):
+    """Size-independent properties of the strided rulebooks at BASELINE's full frame sizes (KITTI B = 2, the
+    Waymo-shaped 200 k-point sweep at B = 1): output cells strictly ascending by flat cell id (the reference's
+    torch::_unique order) and inside the output grid; every output reached by at least one pair; nbr_in and nbr_out
+    are each other's transpose; the pair lists hold exactly the table's pairs, padded with -1; indice_num counts
+    them; every pair obeys out = (in + pad - k) / stride."""
+    from detmatch_amd import synth, voxel
+    from detmatch_amd.spconv import ops
+    if profile == 'kitti':
+        pts = [torch.from_numpy(synth.lidar_frame(s)['points']).to(dev) for s in range(2)]
+        vs, rng, shape, mv, batch = synth.KITTI_VOXEL, synth.KITTI_RANGE, [41, 1600, 1408], 16000, 2
+    else:
+        pts = [torch.from_numpy(synth.lidar_frame(7, full360=True)['points']).to(dev)]
+        vs, rng, shape, mv, batch = synth.WAYMO_VOXEL, synth.WAYMO_RANGE, [41, 1504, 1504], 150000, 1      # grid (z, y, x)
+    _, coors, _, _, _ = voxel.voxelize_batch(pts, vs, rng, 5, mv)
+    idx = coors
+    for level in range(3):
+        ks, st, pd = [3, 3, 3], [2, 2, 2], ([1, 1, 1] if level < 2 else [0, 1, 1])
+        rb = ops.build_rulebook(idx, batch, shape, ks, st, pd, 1, False)
+        out, osh = rb.outids.long(), rb.out_shape
+        flat = ((out[:, 0] * osh[0] + out[:, 1]) * osh[1] + out[:, 2]) * osh[2] + out[:, 3]
+        assert bool((flat[1:] > flat[:-1]).all())
+        for a in range(3):
+            assert int(out[:, a + 1].min()) >= 0 and int(out[:, a + 1].max()) < osh[a]
+        n_in, n_out = idx.shape[0], out.shape[0]
+        assert bool((rb.nbr_out >= 0).any(dim=0).all())
+        total = 0
+        for k in range(27):
+            ni, no = rb.nbr_in[k].long(), rb.nbr_out[k].long()
+            src = torch.nonzero(ni >= 0).flatten()
+            dst = ni[src]
+            assert torch.equal(no[dst], src)
+            assert int((no >= 0).sum()) == src.numel() == int(rb.indice_num[k])
+            m = src.numel()
+            pin, pout = rb.indice_pairs[k, 0].long(), rb.indice_pairs[k, 1].long()
+            assert bool((pin[m:] == -1).all()) and bool((pout[m:] == -1).all())
+            assert torch.equal(ni[pin[:m]], pout[:m]) and pin[:m].unique().numel() == m
+            kk = (k // 9, (k // 3) % 3, k % 3)
+            a_in, a_out = idx.long()[src], out[dst]
+            assert torch.equal(a_in[:, 0], a_out[:, 0])
+            for a in range(3):
+                assert torch.equal(a_in[:, a + 1] + pd[a] - kk[a], a_out[:, a + 1] * st[a])
+            total += m
+        assert total >= n_in          # every input reaches at least one output
+        idx, shape = rb.outids, osh
+
+
 def _rulebook_random(orc, dev, cfg, n):
     rng = np.random.default_rng(n)
     shape = [9, 14, 11]
