@@ -65,6 +65,7 @@ def wgrad_bytes(P, ci, co, kvol):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak
 
 
 def pmc_traffic(kernel):
@@ -122,10 +123,18 @@ def other_kernel_groups(wl):
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs[kind])
         fl = sum(w for w, _, _ in recs[kind])
         if ms > 0:
+            # the ceiling of the arithmetic that actually runs: fp32 matrix instruction, bf16 matrix instruction, or
+            # six bf16 products per fp32-class product (three-way split operands)
+            math = dense_conv.get_math()
+            peak = {'fp32_mfma': MFMA_F32_PEAK_TFLOPS, 'bf16': MFMA_BF16_PEAK_TFLOPS}.get(
+                math, MFMA_BF16_PEAK_TFLOPS / 6.0)
             out['dense_conv.' + ('fwd+dgrad' if kind == 'gemm' else 'wgrad')] = dict(
                 bound='mfma', launches_per_step=len(recs[kind]), ms_per_step=round(ms, 3),
-                GFLOP_per_step=round(fl / 1e9, 1), achieved=round(fl / ms / 1e9, 1), peak=MFMA_F32_PEAK_TFLOPS,
-                unit='TFLOP/s', frac=round(fl / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), math=dense_conv.get_math(),
+                GFLOP_per_step=round(fl / 1e9, 1), achieved=round(fl / ms / 1e9, 1), peak=round(peak, 1),
+                unit='TFLOP/s', frac=round(fl / ms / 1e9 / peak, 4),
+                frac_of_fp32_mfma_peak=round(fl / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), math=math,
+                peak_is='dense bf16 matrix peak / 6 (six bf16 products per fp32-class product)'
+                if peak not in (MFMA_F32_PEAK_TFLOPS, MFMA_BF16_PEAK_TFLOPS) else 'dense matrix peak of the instruction',
                 timing='HIP events around each launch (includes the launch gap of short kernels)')
     if recs['fps']:
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs['fps'])

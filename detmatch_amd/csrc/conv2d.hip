@@ -676,16 +676,22 @@ void dconv_gemm_bf16_kernel(
       __syncthreads();
       ++kt;
     };
-    while (kt < KT) {
-      step(S0(), S1());
-      if (kt >= KT) break;
-      if constexpr (DEPTH == 3) {
+    // whole turns of the ring as ONE straight-line loop body, the remainder behind the loop: with an exit between
+    // the steps the accumulators of the two paths land in different registers and every turn copies all of them
+    if constexpr (DEPTH == 3) {
+      while (kt + 2 < KT) {
+        step(S0(), S1());
         step(S1(), S2());
-        if (kt >= KT) break;
         step(S2(), S0());
-      } else {
+      }
+      if (kt < KT) step(S0(), S1());
+      if (kt < KT) step(S1(), S2());
+    } else {
+      while (kt + 1 < KT) {
+        step(S0(), S1());
         step(S1(), S0());
       }
+      if (kt < KT) step(S0(), S1());
     }
   }
 
@@ -1098,17 +1104,26 @@ void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restri
     __syncthreads();
     ++kt;
   };
-  for (int cb = 0; cb < NCB; ++cb) {
-    if (cb + 1 < NCB) gA(cb + 1);
-    for (int tap = 0; tap < T; ++tap) {
-      if (kt & 1) step(tap, S1(), S0());
-      else step(tap, S0(), S1());
+  // (channel block, tap) steps in PAIRS as one straight-line loop body (a branch on the parity of kt puts the
+  // accumulators of the two paths into different registers and copies all 64 of them every other tap)
+  int cb = 0, tap = 0;
+  auto one = [&](auto cur, auto nxt) {
+    if (tap == 0 && cb + 1 < NCB) gA(cb + 1);
+    step(tap, cur, nxt);
+    if (++tap == T) {
+      tap = 0;
+      if (++cb < NCB) {        // every wave has passed the last tap's barrier: the A image is free
+        sA();
+        __syncthreads();
+      }
     }
-    if (cb + 1 < NCB) {        // every wave has passed the last tap's barrier: the A image is free
-      sA();
-      __syncthreads();
-    }
+  };
+  const int total = NCB * T;
+  while (kt + 1 < total) {
+    one(S0(), S1());
+    one(S1(), S0());
   }
+  if (kt < total) one(S0(), S1());
 
   // epilogue: per 32-column block the wave's WM x 32 tile through LDS (the B buffers are idle now), rows of 16 bytes
   constexpr int LDC = 36;

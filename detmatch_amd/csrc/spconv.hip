@@ -411,16 +411,18 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
     unsigned int ok0, ok1;
     load_step(k, s, w0, a0, &ok0);
     int i = 0;
-    while (true) {
+    // pairs of steps as ONE straight-line loop body, the odd step behind the loop: with an exit between the two
+    // halves the accumulators of the two paths get different registers and are copied (through VGPRs) every turn.
+    // The last pair's second load re-reads the last step (advance() sticks there).
+    for (; i + 2 <= n_steps; i += 2) {
       advance();
       load_step(k, s, w1, a1, &ok1);
       compute(w0, a0, ok0);
-      if (++i >= n_steps) break;
       advance();
       load_step(k, s, w0, a0, &ok0);
       compute(w1, a1, ok1);
-      if (++i >= n_steps) break;
     }
+    if (i < n_steps) compute(w0, a0, ok0);
   }
   // meet in LDS: D layout col = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
@@ -568,16 +570,18 @@ __global__ __launch_bounds__(512) void spconv_gr32(const float *__restrict__ fea
     unsigned int ok0, ok1;
     load_step(k, s, w0, a0, &ok0);
     int i = 0;
-    while (true) {
+    // pairs of steps as ONE straight-line loop body, the odd step behind the loop: with an exit between the two
+    // halves the accumulators of the two paths get different registers and are copied (through VGPRs) every turn.
+    // The last pair's second load re-reads the last step (advance() sticks there).
+    for (; i + 2 <= n_steps; i += 2) {
       advance();
       load_step(k, s, w1, a1, &ok1);
       compute(w0, a0, ok0);
-      if (++i >= n_steps) break;
       advance();
       load_step(k, s, w0, a0, &ok0);
       compute(w1, a1, ok1);
-      if (++i >= n_steps) break;
     }
+    if (i < n_steps) compute(w0, a0, ok0);
   }
   // C layout of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
 #pragma unroll

@@ -230,16 +230,16 @@ __global__ __launch_bounds__(256) void spconv_gr16(const ST *__restrict__ feat, 
     v8 w0[CTS * NB * SPLIT], w1[CTS * NB * SPLIT], a0[CTS * SPLIT], a1[CTS * SPLIT];
     load_step(k, s, w0, a0);
     int i = 0;
-    while (true) {
+    // pairs of steps as one straight-line loop body, the odd step behind the loop (see spconv_gr)
+    for (; i + 2 <= n_steps; i += 2) {
       advance();
       load_step(k, s, w1, a1);
       compute(w0, a0);
-      if (++i >= n_steps) break;
       advance();
       load_step(k, s, w0, a0);
       compute(w1, a1);
-      if (++i >= n_steps) break;
     }
+    if (i < n_steps) compute(w0, a0);
   }
   // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll

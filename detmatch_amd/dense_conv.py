@@ -56,7 +56,7 @@ def get_math():
 
 
 # which kernels serve exact-class fp32 (environment DM_FP32_CONV=fp32_mfma|fp32_split for A/B runs): the split
-# kernels — more accurate against float64 AND faster (103 -> 93 ms per DetMatch iteration)
+# kernels — more accurate against float64 AND faster (107 -> 96 ms per DetMatch iteration)
 FP32_DEFAULT = os.environ.get('DM_FP32_CONV', 'fp32_split')
 if FP32_DEFAULT != 'fp32_mfma':
     try:
