@@ -518,7 +518,9 @@ void dconv_gemm_bf16_kernel(
   // run in the shadow of the matrix pipe instead of between its bursts.  Everything in the steady-state loop is
   // unconditional (fetches past the last tile are clamped to valid, unused data; the store of a tile past the
   // end goes to the idle buffer), so the loop body is one basic block.
-  constexpr int DEPTH = SPLIT == 3 ? (BM * BN > 64 * 64 ? 2 : 3) : 1;   // 128 x 128: a ring of three spills
+  // (128 x 128 with a ring of three fits since the loops are straight-line — 214 VGPRs, no scratch — and measures the
+  // same: 285 / 150 / 419 us against 281 / 149 / 415 us on BEV 256->128, 128->128 and FPN P2)
+  constexpr int DEPTH = SPLIT == 3 ? (BM * BN > 64 * 64 ? 2 : 3) : 1;
   float4 ra[DEPTH][AP], rb[DEPTH][BP];
   bool ra_ok[DEPTH][AP];
   const int KT_all = g.Ktot / BK;
