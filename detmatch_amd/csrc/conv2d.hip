@@ -1211,32 +1211,49 @@ __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__re
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  float4 ru[NP], rv[NP];
-  bool ru_ok[NP], rv_ok[NP];
-  auto gload = [&](int kt) {
+  // Two register sets: tile kt + 2 is requested while tile kt is multiplied and leaves for the LDS at the end of
+  // step kt + 1 — a whole step (~1000 cycles of MFMAs) more than an L2 / HBM round trip under load, which a
+  // one-step distance did not cover.  The pixel coordinates of a thread's rows advance by BK per tile: carried
+  // along instead of two integer divisions per row and tile.
+  float4 ru[2][NP], rv[2][NP];
+  bool ru_ok[2][NP], rv_ok[2][NP];
+  int pj[NP], pi[NP], pb[NP];            // (column, row, image) of this thread's pixel rows in the NEXT tile to fetch
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int m = min(m_lo + r0 + p * 8, g.M - 1);
+    pj[p] = m % g.LW;
+    const int tmp = m / g.LW;
+    pi[p] = tmp % g.LH, pb[p] = tmp / g.LH;
+  }
+  auto gload = [&](auto set, int kt) {   // called with kt = 0, 1, 2, ... (the coordinates follow)
+    constexpr int S = decltype(set)::value;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int m = m_lo + kt * BK + r0 + p * 8;
       const bool ok = (m < m_hi) & u_ok;
-      ru[p] = *(const float4 *)(U + (size_t)(ok ? m : m_lo) * g.Cu + (u_ok ? u0 + cq * 4 : 0));
-      ru_ok[p] = ok;
-      const int mm = m < m_hi ? m : m_lo;
-      const int j = mm % g.LW, tmp = mm / g.LW, i = tmp % g.LH, b = tmp / g.LH;
-      const int iy = i * g.vys + dy, ix = j * g.vxs + dx;
+      ru[S][p] = *(const float4 *)(U + (size_t)(ok ? m : m_lo) * g.Cu + (u_ok ? u0 + cq * 4 : 0));
+      ru_ok[S][p] = ok;
+      const int iy = pi[p] * g.vys + dy, ix = pj[p] * g.vxs + dx;
       const bool okv = (m < m_hi) & v_ok & ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
-      const int pix = okv ? (b * g.Hv + iy) * g.Wv + ix : 0;
-      rv[p] = *(const float4 *)(V + (size_t)pix * g.Cv + (v_ok ? v0 + cq * 4 : 0));
-      rv_ok[p] = okv;
+      const int pix = okv ? (pb[p] * g.Hv + iy) * g.Wv + ix : 0;
+      rv[S][p] = *(const float4 *)(V + (size_t)pix * g.Cv + (v_ok ? v0 + cq * 4 : 0));
+      rv_ok[S][p] = okv;
+      pj[p] += BK;                        // the same rows of the next tile
+      while (pj[p] >= g.LW) {
+        pj[p] -= g.LW;
+        if (++pi[p] >= g.LH) pi[p] = 0, ++pb[p];
+      }
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](auto set, int buf) {
+    constexpr int S = decltype(set)::value;
     unsigned char *ub = lds + buf * 2 * SPLIT * TILE_BYTES, *vb = ub + SPLIT * TILE_BYTES;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int row = r0 + p * 8;
       const int off = wg_tile_off(row, cq >> 1) + 8 * (cq & 1);
-      float4 a = ru[p], b = rv[p];
-      const bool oka = ru_ok[p], okb = rv_ok[p];
+      float4 a = ru[S][p], b = rv[S][p];
+      const bool oka = ru_ok[S][p], okb = rv_ok[S][p];
       a.x = oka ? a.x : 0.0f, a.y = oka ? a.y : 0.0f, a.z = oka ? a.z : 0.0f, a.w = oka ? a.w : 0.0f;
       b.x = okb ? b.x : 0.0f, b.y = okb ? b.y : 0.0f, b.z = okb ? b.z : 0.0f, b.w = okb ? b.w : 0.0f;
       if constexpr (SPLIT == 3) {
@@ -1269,42 +1286,51 @@ __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__re
   };
 
   const int KT = (m_hi - m_lo + BK - 1) / BK;
-  if (KT > 0) {
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-      const int buf = kt & 1;
-      const bool more = kt + 1 < KT;
-      if (more) gload(kt + 1);
-      const unsigned char *ub = lds + buf * 2 * SPLIT * TILE_BYTES, *vb = ub + SPLIT * TILE_BYTES;
+  typedef std::integral_constant<int, 0> R0;
+  typedef std::integral_constant<int, 1> R1;
+  int kt = 0;
+  auto step = [&](auto fetch_set, auto store_set) {      // fetch_set: free, its tile (kt) is in the LDS already
+    const int buf = kt & 1;
+    if (kt + 2 < KT) gload(fetch_set, kt + 2);
+    const unsigned char *ub = lds + buf * 2 * SPLIT * TILE_BYTES, *vb = ub + SPLIT * TILE_BYTES;
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8 af[SPLIT][TU], bfr[SPLIT][TV];
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[SPLIT][TU], bfr[SPLIT][TV];
 #pragma unroll
-        for (int s = 0; s < SPLIT; ++s) {
+      for (int s = 0; s < SPLIT; ++s) {
 #pragma unroll
-          for (int a = 0; a < TU; ++a) af[s][a] = frag(ub + s * TILE_BYTES, ks, wu * WU + a * 32);
+        for (int a = 0; a < TU; ++a) af[s][a] = frag(ub + s * TILE_BYTES, ks, wu * WU + a * 32);
 #pragma unroll
-          for (int b = 0; b < TV; ++b) bfr[s][b] = frag(vb + s * TILE_BYTES, ks, wv * WV + b * 32);
-        }
-#pragma unroll
-        for (int a = 0; a < TU; ++a)
-#pragma unroll
-          for (int b = 0; b < TV; ++b) {
-            if constexpr (SPLIT == 3) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bfr[0][b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[2][b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[0][b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[1][b], acc[a][b], 0, 0, 0);
-            }
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
-          }
+        for (int b = 0; b < TV; ++b) bfr[s][b] = frag(vb + s * TILE_BYTES, ks, wv * WV + b * 32);
       }
-      if (more) sstore(buf ^ 1);
-      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < TU; ++a)
+#pragma unroll
+        for (int b = 0; b < TV; ++b) {
+          if constexpr (SPLIT == 3) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bfr[0][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[2][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bfr[0][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[1][b], acc[a][b], 0, 0, 0);
+          }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
+        }
     }
+    if (kt + 1 < KT) sstore(store_set, buf ^ 1);
+    __syncthreads();
+    ++kt;
+  };
+  if (KT > 0) {
+    gload(R0(), 0);
+    sstore(R0(), 0);
+    if (KT > 1) gload(R1(), 1);
+    __syncthreads();
+    while (kt + 1 < KT) {                 // pairs as one straight-line body (see dconv_gemm_bf16_kernel)
+      step(R0(), R1());
+      step(R1(), R0());
+    }
+    if (kt < KT) step(R0(), R1());
   }
   float *dst = part + ((size_t)split * g.T + t) * g.Cu * g.Cv;
   constexpr int LDC = WV + 4;
