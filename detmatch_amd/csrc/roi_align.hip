@@ -369,7 +369,39 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(Pyramid pyr, const flo
       const int ya = yp_lo[by], yb = yp_hi[by], xa = xp_lo[bx], xb = xp_hi[bx];
       for (int cg = lane; cg < C / 4; cg += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (xb - xa < 8) {
+        if (xb - xa < 4) {
+          // (the usual case — an RoI of ~14 pixels at its level has bins of 2-3 pixels: four columns instead of
+          // eight halves the clamped duplicate loads: 299 -> 286 us for 1024 RoIs)
+          for (int yy = ya; yy <= yb; yy += 2) {
+            const bool two = yy + 1 <= yb;
+            const float a0 = wy[by * RA_MAX_SPAN + yy], a1 = two ? wy[by * RA_MAX_SPAN + yy + 1] : 0.f;
+            const float4 *row0 = (const float4 *)(src + ((size_t)(y0 + yy) * W + x0) * C) + cg;
+            const float4 *row1 = two ? row0 + (size_t)W * (C / 4) : row0;
+            float4 f0[4], f1[4];
+            float wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int xs = xa + u <= xb ? xa + u : xb;
+              f0[u] = row0[(size_t)xs * (C / 4)];
+              f1[u] = row1[(size_t)xs * (C / 4)];
+              wv[u] = wx[bx * RA_MAX_SPAN + xs];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (xa + u <= xb) {
+                const float w = a0 * wv[u];
+                acc.x += w * f0[u].x, acc.y += w * f0[u].y, acc.z += w * f0[u].z, acc.w += w * f0[u].w;
+              }
+            if (two) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (xa + u <= xb) {
+                  const float w = a1 * wv[u];
+                  acc.x += w * f1[u].x, acc.y += w * f1[u].y, acc.z += w * f1[u].z, acc.w += w * f1[u].w;
+                }
+            }
+          }
+        } else if (xb - xa < 8) {
           // the taps of two pixel rows (up to 16 loads of 16 bytes per lane) are requested before the
           // first is used: one tap per dependent load left the kernel waiting on L2 latency; the sum
           // keeps the row-major tap order
