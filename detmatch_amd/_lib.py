@@ -55,6 +55,8 @@ SIGNATURES = {
     'dm_nms': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
     'dm_nms_normal': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
     'dm_nms_2d': (ci, [vp, ci, cf, ci, vp, vp, vp, sz, vp]),
+    'dm_nms_batch': (ci, [vp, ci, ci, cf, ci, ci, vp, ctypes.c_longlong, vp, vp, sz, vp]),
+    'dm_nms_2d_batch': (ci, [vp, ci, ci, cf, ci, vp, ctypes.c_longlong, vp, vp, sz, vp]),
     'dm_box3d_project_forward': (ci, [vp, ci, c_f32_p, c_f32_p, cf, cf, vp, vp, vp]),
     'dm_box3d_project_backward': (ci, [vp, ci, c_f32_p, c_f32_p, cf, cf, vp, vp, vp]),
     'dm_consistency_loss_forward': (ci, [vp, vp, vp, vp, ci, ci, cf, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp]),

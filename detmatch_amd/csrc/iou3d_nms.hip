@@ -21,6 +21,13 @@
 
 namespace {
 
+// Several independent NMS problems of equal size in ONE launch chain (blockIdx.z = problem): element strides of the
+// per-problem arrays; all zero for a single problem.  The greedy pass is one wave per problem, so B problems
+// issued one after the other leave the chip idle B times as long.
+struct NmsBatch {
+  long long boxes, cs, mask, keep;
+};
+
 __global__ __launch_bounds__(256) void heading_cos_sin(const float *boxes, int n, float2 *cs) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -66,7 +73,9 @@ __device__ __forceinline__ float iou_xyxy(const float *a, const float *b) {
 
 __global__ __launch_bounds__(64) void nms_mask_2d(const float *boxes, int n, float thresh,
                                                   unsigned long long *mask, int col_begin,
-                                                  const int *num_keep, int max_keep) {
+                                                  const int *num_keep, int max_keep, NmsBatch bt) {
+  boxes += blockIdx.z * bt.boxes, mask += blockIdx.z * bt.mask;
+  if (num_keep) num_keep += blockIdx.z;
   const int row_start = blockIdx.y, col_start = blockIdx.x + col_begin;
   if (col_start < row_start) return;
   if (num_keep && *num_keep >= max_keep) return;   // second phase not needed (see nms_two_phase)
@@ -96,7 +105,9 @@ __global__ __launch_bounds__(64) void nms_mask_2d(const float *boxes, int n, flo
 template <bool NORMAL>
 __global__ __launch_bounds__(64) void nms_mask(const float *boxes, const float2 *cs, int n,
                                                float thresh, unsigned long long *mask, int col_begin,
-                                               const int *num_keep, int max_keep) {
+                                               const int *num_keep, int max_keep, NmsBatch bt) {
+  boxes += blockIdx.z * bt.boxes, cs += blockIdx.z * bt.cs, mask += blockIdx.z * bt.mask;
+  if (num_keep) num_keep += blockIdx.z;
   const int row_start = blockIdx.y, col_start = blockIdx.x + col_begin;
   if (col_start < row_start) return;
   if (num_keep && *num_keep >= max_keep) return;   // second phase not needed (see nms_two_phase)
@@ -149,7 +160,9 @@ __device__ __forceinline__ int select_bit(unsigned long long word, int k) {   //
 
 __global__ __launch_bounds__(64) void nms_mask_rot(const float *boxes, const float2 *cs, int n, float thresh,
                                                    unsigned long long *mask, int col_begin,
-                                                   const int *num_keep, int max_keep) {
+                                                   const int *num_keep, int max_keep, NmsBatch bt) {
+  boxes += blockIdx.z * bt.boxes, cs += blockIdx.z * bt.cs, mask += blockIdx.z * bt.mask;
+  if (num_keep) num_keep += blockIdx.z;
   const int row_start = blockIdx.y, col_start = blockIdx.x + col_begin;
   if (col_start < row_start) return;
   if (num_keep && *num_keep >= max_keep) return;
@@ -227,7 +240,8 @@ __device__ __forceinline__ unsigned long long wave_bcast64(unsigned long long v,
 // (quadratic) mask + the rest of this pass run only if the budget was not met (`resume`).
 __global__ __launch_bounds__(64) void nms_greedy(const unsigned long long *__restrict__ mask, int n,
                                                  int max_keep, long long *keep, int *num_keep,
-                                                 int blk_begin, int blk_end, int resume) {
+                                                 int blk_begin, int blk_end, int resume, NmsBatch bt) {
+  mask += blockIdx.z * bt.mask, keep += blockIdx.z * bt.keep, num_keep += blockIdx.z;
   const int col_blocks = (n + 63) / 64;
   const int lane = threadIdx.x;
   constexpr int MAXW = 16;  // up to 64*16 words = 65536 boxes
@@ -442,40 +456,43 @@ static int nms_lead_blocks(int n, int max_keep) {
 static bool g_nms_plain = false;   // tuning aid (DM_NMS_PLAIN=1): the one-row-per-lane mask kernel
 
 static int nms_launch(bool normal, const float *boxes, int n, float thresh, int max_keep,
-                      long long *keep, int *num_keep, void *ws, size_t ws_bytes, hipStream_t st) {
-  if (n < 0 || !num_keep) return DM_ERR_INVALID_ARG;
+                      long long *keep, int *num_keep, void *ws, size_t ws_bytes, hipStream_t st,
+                      int batch = 1, long long keep_stride = 0) {
+  if (n < 0 || batch < 1 || !num_keep) return DM_ERR_INVALID_ARG;
   if (n == 0) {
-    DM_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), st));
+    DM_HIP(hipMemsetAsync(num_keep, 0, batch * sizeof(int), st));
     return DM_OK;
   }
-  if (n > 64 * 64 * 16) return DM_ERR_UNSUPPORTED;
+  if (n > 64 * 64 * 16 || batch > 65535) return DM_ERR_UNSUPPORTED;
   if (!boxes || !keep || !ws) return DM_ERR_INVALID_ARG;
   {
     static const bool plain = getenv("DM_NMS_PLAIN") && getenv("DM_NMS_PLAIN")[0] == '1';
     g_nms_plain = plain;
   }
-  if (ws_bytes < dm_nms_workspace_bytes(n)) return DM_ERR_WORKSPACE;
+  if (ws_bytes < dm_nms_workspace_bytes(n) * (size_t)batch) return DM_ERR_WORKSPACE;
   if (max_keep <= 0 || max_keep > n) max_keep = n;
   int col_blocks = (n + 63) / 64;
+  const size_t mask_bytes = dm_align((size_t)n * col_blocks * 8);
   unsigned long long *mask = (unsigned long long *)ws;
-  float2 *cs = (float2 *)((char *)ws + dm_align((size_t)n * col_blocks * 8));
-  if (!normal) {
-    heading_cos_sin<<<dm_ceil_div(n, 256), 256, 0, st>>>(boxes, n, cs);
+  float2 *cs = (float2 *)((char *)ws + mask_bytes * batch);
+  NmsBatch bt{0, 0, 0, 0};
+  if (batch > 1) bt = NmsBatch{(long long)n * 7, (long long)n, (long long)(mask_bytes / 8), keep_stride};
+  if (!normal) {      // the problems' boxes are contiguous: one launch over batch * n headings
+    heading_cos_sin<<<dm_ceil_div(n * batch, 256), 256, 0, st>>>(boxes, n * batch, cs);
     DM_CHECK_LAUNCH();
   }
-  dim3 grid(col_blocks, col_blocks);
   const int lead = nms_lead_blocks(n, max_keep);
   for (int phase = 0; phase < (lead < col_blocks ? 2 : 1); ++phase) {
     // phase 0: tiles (r <= c < lead), greedy over the leading blocks; phase 1 (skipped on the
     // device when the budget is already met): tiles with c >= lead, greedy over the rest
     const int c0 = phase == 0 ? 0 : lead, c1 = phase == 0 ? lead : col_blocks;
-    dim3 g(c1 - c0, c1);
+    dim3 g(c1 - c0, c1, batch);
     const int *flag = phase == 0 ? nullptr : num_keep;
-    if (normal) nms_mask<true><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
-    else if (g_nms_plain) nms_mask<false><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
-    else nms_mask_rot<<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep);
+    if (normal) nms_mask<true><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep, bt);
+    else if (g_nms_plain) nms_mask<false><<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep, bt);
+    else nms_mask_rot<<<g, 64, 0, st>>>(boxes, cs, n, thresh, mask, c0, flag, max_keep, bt);
     DM_CHECK_LAUNCH();
-    nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep, c0, c1, phase);
+    nms_greedy<<<dim3(1, 1, batch), 64, 0, st>>>(mask, n, max_keep, keep, num_keep, c0, c1, phase, bt);
   }
   DM_CHECK_LAUNCH();
   return DM_OK;
@@ -494,32 +511,57 @@ extern "C" int dm_nms_normal(const float *boxes, int n, float thresh, int max_ke
                     (hipStream_t)stream);
 }
 
+extern "C" int dm_nms_batch(const float *boxes, int batch, int n, float thresh, int max_keep, int normal,
+                            long long *keep, long long keep_stride, int *num_keep, void *workspace,
+                            size_t workspace_bytes, dm_stream_t stream) {
+  if (keep_stride < (max_keep > 0 && max_keep < n ? max_keep : n)) return DM_ERR_INVALID_ARG;
+  return nms_launch(normal != 0, boxes, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes,
+                    (hipStream_t)stream, batch, keep_stride);
+}
+
 // 2-D axis-aligned NMS on (n, 4) xyxy boxes sorted by descending score — replaces
 // mmcv.ops.nms (mmcv-full 1.3.16) as called through batched_nms at
 // mmdet3d/models/ssl_modules/bbox_utils.py:97 and by the Faster R-CNN RPN / bbox head.
-extern "C" int dm_nms_2d(const float *boxes_xyxy, int n, float thresh, int max_keep,
-                         long long *keep, int *num_keep, void *workspace,
-                         size_t workspace_bytes, dm_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if (n < 0 || !num_keep) return DM_ERR_INVALID_ARG;
+static int nms_2d_launch(const float *boxes_xyxy, int n, float thresh, int max_keep, long long *keep,
+                         int *num_keep, void *workspace, size_t workspace_bytes, hipStream_t st, int batch,
+                         long long keep_stride) {
+  if (n < 0 || batch < 1 || !num_keep) return DM_ERR_INVALID_ARG;
   if (n == 0) {
-    DM_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), st));
+    DM_HIP(hipMemsetAsync(num_keep, 0, batch * sizeof(int), st));
     return DM_OK;
   }
-  if (n > 64 * 64 * 16) return DM_ERR_UNSUPPORTED;
+  if (n > 64 * 64 * 16 || batch > 65535) return DM_ERR_UNSUPPORTED;
   if (!boxes_xyxy || !keep || !workspace) return DM_ERR_INVALID_ARG;
-  if (workspace_bytes < dm_nms_workspace_bytes(n)) return DM_ERR_WORKSPACE;
+  if (workspace_bytes < dm_nms_workspace_bytes(n) * (size_t)batch) return DM_ERR_WORKSPACE;
   if (max_keep <= 0 || max_keep > n) max_keep = n;
   int col_blocks = (n + 63) / 64;
+  const size_t mask_bytes = dm_align((size_t)n * col_blocks * 8);
   unsigned long long *mask = (unsigned long long *)workspace;
+  NmsBatch bt{0, 0, 0, 0};
+  if (batch > 1) bt = NmsBatch{(long long)n * 4, 0, (long long)(mask_bytes / 8), keep_stride};
   const int lead = nms_lead_blocks(n, max_keep);
   for (int phase = 0; phase < (lead < col_blocks ? 2 : 1); ++phase) {
     const int c0 = phase == 0 ? 0 : lead, c1 = phase == 0 ? lead : col_blocks;
-    nms_mask_2d<<<dim3(c1 - c0, c1), 64, 0, st>>>(boxes_xyxy, n, thresh, mask, c0,
-                                                   phase == 0 ? nullptr : num_keep, max_keep);
+    nms_mask_2d<<<dim3(c1 - c0, c1, batch), 64, 0, st>>>(boxes_xyxy, n, thresh, mask, c0,
+                                                          phase == 0 ? nullptr : num_keep, max_keep, bt);
     DM_CHECK_LAUNCH();
-    nms_greedy<<<1, 64, 0, st>>>(mask, n, max_keep, keep, num_keep, c0, c1, phase);
+    nms_greedy<<<dim3(1, 1, batch), 64, 0, st>>>(mask, n, max_keep, keep, num_keep, c0, c1, phase, bt);
   }
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+
+extern "C" int dm_nms_2d(const float *boxes_xyxy, int n, float thresh, int max_keep,
+                         long long *keep, int *num_keep, void *workspace,
+                         size_t workspace_bytes, dm_stream_t stream) {
+  return nms_2d_launch(boxes_xyxy, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes,
+                       (hipStream_t)stream, 1, 0);
+}
+
+extern "C" int dm_nms_2d_batch(const float *boxes_xyxy, int batch, int n, float thresh, int max_keep,
+                               long long *keep, long long keep_stride, int *num_keep, void *workspace,
+                               size_t workspace_bytes, dm_stream_t stream) {
+  if (keep_stride < (max_keep > 0 && max_keep < n ? max_keep : n)) return DM_ERR_INVALID_ARG;
+  return nms_2d_launch(boxes_xyxy, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes,
+                       (hipStream_t)stream, batch, keep_stride);
 }

@@ -160,6 +160,23 @@ def nms_fixed(boxes, scores, iou_thr, max_num):
     return order[idx], ok
 
 
+def nms_fixed_batch(boxes, scores, iou_thr, max_num):
+    """nms_fixed for B images of N candidates each in one launch chain -> (idx (B, max_num), ok (B, max_num))."""
+    order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
+    b = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4)).contiguous().float()
+    _lib.require_device(b)
+    bsz, n = b.shape[0], b.shape[1]
+    L = _lib.lib()
+    keep = torch.zeros((bsz, max(n, max_num)), dtype=torch.int64, device=b.device)
+    num = torch.zeros((bsz,), dtype=torch.int32, device=b.device)
+    ws = _lib.workspace(L.dm_nms_workspace_bytes(n) * bsz, b.device, 'nms')
+    _lib.check(L.dm_nms_2d_batch(_lib.ptr(b), bsz, n, float(iou_thr), int(max_num), _lib.ptr(keep), keep.stride(0),
+                                 _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms_2d_batch')
+    ok = torch.arange(max_num, device=b.device)[None, :] < num[:, None]
+    idx = torch.where(ok, keep[:, :max_num], torch.zeros_like(keep[:, :max_num]))
+    return torch.gather(order, 1, idx), ok
+
+
 # ------------------------------------------------------------------ fused targets / losses
 def _ptr_array(tensors):
     import ctypes
@@ -397,8 +414,11 @@ class RPNHead(nn.Module):
                 and all(c.data_ptr() == y.data_ptr() and c.shape[2:] == y.shape[2:] for c, y in zip(cls, raw)):
             boxes, s, live, b_nms, s_nms = self._pre_nms_device(raw, sizes, img_metas, cfg)
             out = []
+            same = isinstance(b_nms, torch.Tensor) and isinstance(s_nms, torch.Tensor) and b_nms.dim() == 3
+            if same:       # every image has the same candidate count: all images in one launch chain
+                idx_all, ok_all = nms_fixed_batch(b_nms, s_nms, nms_thr, cfg['max_per_img'])
             for i in range(cls[0].shape[0]):
-                idx, ok = nms_fixed(b_nms[i], s_nms[i], nms_thr, cfg['max_per_img'])
+                idx, ok = (idx_all[i], ok_all[i]) if same else nms_fixed(b_nms[i], s_nms[i], nms_thr, cfg['max_per_img'])
                 ok = ok & live[i][idx]
                 props = torch.cat([boxes[i][idx], s[i][idx, None]], dim=1) * ok[:, None].float()
                 out.append((props, ok))

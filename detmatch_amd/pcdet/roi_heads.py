@@ -49,11 +49,11 @@ def class_agnostic_nms_fixed_batch(box_scores, box_preds, nms_config, score_thre
     L = _lib.lib()
     keep = torch.zeros((bsz, max(k, post)), dtype=torch.int64, device=dev)
     num = torch.zeros((bsz,), dtype=torch.int32, device=dev)
-    ws = _lib.workspace(L.dm_nms_workspace_bytes(k), dev, 'nms')
-    fn = L.dm_nms if nms_config.NMS_TYPE == 'nms_gpu' else L.dm_nms_normal
-    for b in range(bsz):
-        _lib.check(fn(_lib.ptr(boxes[b]), k, float(nms_config.NMS_THRESH), post, _lib.ptr(keep[b]),
-                      _lib.ptr(num[b:b + 1]), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms')
+    # all samples in one launch chain (the greedy pass is one wave per sample)
+    ws = _lib.workspace(L.dm_nms_workspace_bytes(k) * bsz, dev, 'nms')
+    _lib.check(L.dm_nms_batch(_lib.ptr(boxes), bsz, k, float(nms_config.NMS_THRESH), post,
+                              0 if nms_config.NMS_TYPE == 'nms_gpu' else 1, _lib.ptr(keep), keep.stride(0),
+                              _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms_batch')
     valid = torch.arange(post, device=dev)[None, :] < num.long()[:, None]
     sel = torch.gather(indices, 1, keep[:, :post].clamp(0, k - 1))
     if score_thresh is not None:

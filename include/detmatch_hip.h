@@ -279,6 +279,19 @@ int dm_nms_normal(const float *boxes, int n, float thresh, int max_keep, long lo
 int dm_nms_2d(const float *boxes_xyxy, int n, float thresh, int max_keep, long long *keep,
               int *num_keep, void *workspace, size_t workspace_bytes, dm_stream_t stream);
 
+/* `batch` independent problems of n boxes each in one launch chain (the per-sample loops of
+ * class_agnostic_nms, model_nms_utils.py:5-22 called per sample from pvrcnn_head / roi_head_template.py:52-75, and
+ * of mmdet's per-image RPN NMS): boxes (batch, n, 7 | 4) contiguous and score-sorted per problem, keep
+ * (batch, keep_stride) with keep_stride >= n, num_keep (batch), workspace >= batch * dm_nms_workspace_bytes(n).
+ * Results per problem are identical to the single-problem entries; the greedy pass is one wave per problem, so
+ * problems issued one after the other leave the chip idle `batch` times as long.  normal != 0: dm_nms_normal. */
+int dm_nms_batch(const float *boxes, int batch, int n, float thresh, int max_keep, int normal, long long *keep,
+                 long long keep_stride, int *num_keep, void *workspace, size_t workspace_bytes,
+                 dm_stream_t stream);
+int dm_nms_2d_batch(const float *boxes_xyxy, int batch, int n, float thresh, int max_keep, long long *keep,
+                    long long keep_stride, int *num_keep, void *workspace, size_t workspace_bytes,
+                    dm_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* B/D. Fused training-mode BatchNorm (+ReLU) over row-major (N, C) activations */
 /* ------------------------------------------------------------------------ */

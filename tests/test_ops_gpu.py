@@ -647,3 +647,53 @@ def test_query_group_rows_half_wave_kernel(dev, c):
     want = torch.cat([xyz[src] - new_xyz[:, None, :], torch.zeros(5000, ns, 1, device=dev), feats[src]], dim=2)
     want[empty] = 0
     assert torch.equal(rows, want)
+
+
+@pytest.mark.parametrize('kind', ['rot', 'normal', '2d'])
+def test_batched_nms_equals_per_sample_calls(dev, kind):
+    """dm_nms_batch / dm_nms_2d_batch: B problems in one launch chain give the keep lists of B single calls (both
+    phases: the survivor budget is met inside the leading blocks for one sample and not for another)."""
+    from detmatch_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(3)
+    bsz, n, post = 3, 1500, 100
+    if kind == '2d':
+        xy = torch.rand(bsz, n, 2, device=dev) * 300
+        wh = torch.rand(bsz, n, 2, device=dev) * 40 + 4
+        boxes = torch.cat([xy, xy + wh], dim=2)
+        boxes[1, :, :2] = boxes[1, :1, :2]            # one sample of near-duplicates: few survivors, second phase runs
+        boxes[1, :, 2:] = boxes[1, :, :2] + 30 + torch.rand(n, 2, device=dev)
+    else:
+        boxes = torch.rand(bsz, n, 7, device=dev)
+        boxes[:, :, :2] *= 60
+        boxes[:, :, 3:6] = boxes[:, :, 3:6] * 3 + 1
+        boxes[:, :, 6] = boxes[:, :, 6] * 6.28
+        boxes[1, :, :3] = boxes[1, :1, :3] + torch.rand(n, 3, device=dev) * 0.3
+    boxes = boxes.contiguous()
+    ws1 = torch.empty((L.dm_nms_workspace_bytes(n),), dtype=torch.uint8, device=dev)
+    wsb = torch.empty((L.dm_nms_workspace_bytes(n) * bsz,), dtype=torch.uint8, device=dev)
+    keep1 = torch.full((bsz, n), -1, dtype=torch.int64, device=dev)
+    num1 = torch.zeros((bsz,), dtype=torch.int32, device=dev)
+    for b in range(bsz):
+        if kind == '2d':
+            rc = L.dm_nms_2d(_lib.ptr(boxes[b]), n, 0.5, post, _lib.ptr(keep1[b]), _lib.ptr(num1[b:b + 1]), _lib.ptr(ws1),
+                             ws1.numel(), _lib.stream())
+        else:
+            fn = L.dm_nms if kind == 'rot' else L.dm_nms_normal
+            rc = fn(_lib.ptr(boxes[b]), n, 0.5, post, _lib.ptr(keep1[b]), _lib.ptr(num1[b:b + 1]), _lib.ptr(ws1), ws1.numel(),
+                    _lib.stream())
+        _lib.check(rc, 'single')
+    keepb = torch.full((bsz, n), -1, dtype=torch.int64, device=dev)
+    numb = torch.zeros((bsz,), dtype=torch.int32, device=dev)
+    if kind == '2d':
+        rc = L.dm_nms_2d_batch(_lib.ptr(boxes), bsz, n, 0.5, post, _lib.ptr(keepb), keepb.stride(0), _lib.ptr(numb),
+                               _lib.ptr(wsb), wsb.numel(), _lib.stream())
+    else:
+        rc = L.dm_nms_batch(_lib.ptr(boxes), bsz, n, 0.5, post, 0 if kind == 'rot' else 1, _lib.ptr(keepb), keepb.stride(0),
+                            _lib.ptr(numb), _lib.ptr(wsb), wsb.numel(), _lib.stream())
+    _lib.check(rc, 'batch')
+    assert torch.equal(num1, numb)
+    assert int(num1.min()) < post <= int(num1.max()) or int(num1.max()) == post
+    for b in range(bsz):
+        k = int(num1[b])
+        assert torch.equal(keep1[b, :k], keepb[b, :k])

@@ -1,3 +1,3 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3u; mkdir -p $O; cd $R
-python -m pytest tests/test_dense_conv_gpu.py -m gpu -q 2>&1 | tail -1
-(cd tools && python3 bench_dense_conv_math.py 2>&1 | grep -v "amdgpu.ids" > $O/math_modes5.txt); cat $O/math_modes5.txt | cut -c1-130
+R=$GRAFT_REPO_ROOT; cd $R
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|Error" | tail -3
+for i in 1 2 3; do python bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"; done
