@@ -1,3 +1,5 @@
-R=$GRAFT_REPO_ROOT; cd $R
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|Error" | tail -3
-for i in 1 2 3; do python bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"; done
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3y; mkdir -p $O; cd $R
+for i in 1 2 3; do
+DM_GC_PAUSE=0 python3 tools/phase_timeline.py 2>&1 | grep "host issued" | sed 's/^/gc-auto  /'
+DM_GC_PAUSE=1 python3 tools/phase_timeline.py 2>&1 | grep "host issued" | sed 's/^/gc-pause /'
+done
