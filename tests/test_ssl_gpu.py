@@ -540,3 +540,26 @@ def test_shared_student_2d_trunk_equals_separate_passes(dev, monkeypatch):
     assert float((wa - wb).abs().max()) <= 1e-3 * float(wb.abs().max())
     for k in ('sup.stu.loss_rpn_cls', 'sup.stu.loss_cls', 'loss'):
         assert la[1][k] == pytest.approx(lb[1][k], rel=1e-2), k                    # second: after one update
+
+
+def test_lookahead_geometry_is_scheduling_only(dev, monkeypatch):
+    """IterBasedSSLRunner's look-ahead (batches of iteration i + 1 drawn before iteration i is issued, their
+    weight-independent 3D geometry prepared on a side stream under iteration i) changes WHEN things are issued,
+    not what is computed: the same batches in the same order, and the same losses as the plain order — the
+    first iteration to rounding of its atomics, the following ones within the spread those leave after an update."""
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    logs = {}
+    for ahead in ('1', '0'):
+        wl = DetMatchTrainWorkload(2, dev, seed=11)
+        wl.runner.lookahead = ahead == '1'        # (the class default comes from DM_LOOKAHEAD at import)
+        out = []
+        for _ in range(3):
+            wl.step()
+            out.append({k: float(v) for k, v in wl.last_log.items() if 'loss' in k})
+        torch.cuda.synchronize()
+        logs[ahead] = out
+        del wl
+    for k in logs['1'][0]:
+        assert logs['1'][0][k] == pytest.approx(logs['0'][0][k], rel=1e-5, abs=1e-6), k
+    for it in (1, 2):
+        assert logs['1'][it]['loss'] == pytest.approx(logs['0'][it]['loss'], rel=2e-2), it
