@@ -331,6 +331,21 @@ def gpu_stage_pieces(frames, dev):
                      '4 size read-backs')
 
 
+def conv_math_label():
+    """What arithmetic the GEMM-shaped kernels of the timed steps ran in (read back from the library, not
+    from the environment): `dtype` alone would hide that the fp32 dense convolutions are bf16 splits."""
+    from detmatch_amd import dense_conv, precision
+    dense = {'fp32_split': 'fp32_split(3xbf16,6 products,f32 acc) on v_mfma_f32_32x32x16_bf16',
+             'fp32_mfma': 'fp32 on v_mfma_f32_32x32x2_f32',
+             'bf16': 'bf16 multiplicands (rounded once), f32 acc, v_mfma_f32_32x32x16_bf16'}[dense_conv.get_math()]
+    sparse = ('bf16 multiplicands, f32 acc, v_mfma_f32_16x16x32_bf16' if precision.sparse_bf16() else
+              {'fp32_mfma': 'fp32 on v_mfma_f32_16x16x4_f32',
+               'fp32_split': 'fp32_split(3xbf16,6 products,f32 acc) on v_mfma_f32_16x16x32_bf16'}.get(
+                   precision.fp32_flavour(), precision.fp32_flavour()))
+    return dict(mode=CONV_MATH, dense_conv=dense, sparse_conv=sparse,
+                fc_and_rows='fp32 (v_mfma_f32_32x32x2_f32 / BLAS sgemm)')
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher (reference: tools/dist_train.sh:7-9 spawns
     --nproc_per_node ranks): start N fresh ranks through torch.distributed.run as a CHILD process
@@ -501,7 +516,7 @@ def main():
                    dtype='f32' if CONV_MATH == 'fp32' else 'mixed: bf16 multiplicands + f32 accumulate in the '
                    'dense- and sparse-conv GEMMs, f32 storage and f32 everywhere else',
                    data='synthetic',
-                   config=dict(workload=wl.describe(), batch_per_gpu=BATCH_PER_GPU, conv_math=CONV_MATH,
+                   config=dict(workload=wl.describe(), batch_per_gpu=BATCH_PER_GPU, conv_math=conv_math_label(),
                                value_is='iterations of one per-GPU batch, summed over ranks',
                                global_batch=BATCH_PER_GPU * world,
                                parallelism='dp%d' % world),

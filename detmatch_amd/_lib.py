@@ -152,6 +152,19 @@ class DetMatchHipError(RuntimeError):
     pass
 
 
+# Callables run ONCE with the freshly loaded library (process-wide defaults such as the arithmetic of the
+# dense convolutions): importing a module never has to load the library, and the default is applied whenever
+# and by whomever the library is first loaded.
+_POST_LOAD = []
+
+
+def on_load(fn):
+    """Register fn(lib) to run right after libdetmatch_hip.so is loaded (at once if it already is)."""
+    _POST_LOAD.append(fn)
+    if _lib is not None:
+        fn(_lib)
+
+
 def lib():
     """Load the C-ABI library (once).  Raises if it has not been built."""
     global _lib
@@ -166,6 +179,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        for hook in _POST_LOAD:
+            hook(l)
     return _lib
 
 

@@ -58,11 +58,11 @@ def get_math():
 # which kernels serve exact-class fp32 (environment DM_FP32_CONV=fp32_mfma|fp32_split for A/B runs): the split
 # kernels — more accurate against float64 AND faster (107 -> 96 ms per DetMatch iteration)
 FP32_DEFAULT = os.environ.get('DM_FP32_CONV', 'fp32_split')
-if FP32_DEFAULT != 'fp32_mfma':
-    try:
-        set_math(FP32_DEFAULT)
-    except OSError:       # library not built yet (first import inside build())
-        pass
+if FP32_DEFAULT not in _MATH:
+    raise ValueError('DM_FP32_CONV must be one of %s' % sorted(_MATH))
+# The library starts in mode 0 (fp32_mfma); the default flavour is applied by a post-load hook, so importing
+# this module never loads (or needs) the .so and the mode is set whenever the library is first loaded.
+_lib.on_load(lambda l: _lib.check(l.dm_dconv_set_math(_MATH[FP32_DEFAULT]), 'dm_dconv_set_math'))
 
 
 _EVENTS = []        # (generation after the event, ptr_lo, ptr_hi) of raw-pointer rewrites; None = everything
@@ -234,6 +234,17 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
             reg['entries'].append(e)
             reg.pop('tables', None)
     return dst
+
+
+def forget(weights):
+    """Drop the cached packed copies of these weights (their convolutions moved into a hipGraph that records
+    its own packs: the one-launch refresh of a stream must not keep re-packing copies nobody reads)."""
+    ids = {id(w) for w in weights}
+    for key in [k for k in _PACK_CACHE if k[0] in ids]:
+        del _PACK_CACHE[key]
+    for reg in _TABLES.values():
+        reg['entries'] = [e for e in reg['entries'] if e.wref() is not None and id(e.wref()) not in ids]
+        reg.pop('tables', None)
 
 
 _PLAN_CACHE = {}     # (kind, geometry, taps) -> (ctypes geometry, ctypes taps, workspace bytes)

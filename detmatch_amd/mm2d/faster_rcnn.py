@@ -677,10 +677,23 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
         if len(imgs) < 2 or len({tuple(i.shape[1:]) for i in imgs}) != 1 or not torch.is_grad_enabled() \
                 or not self.training:
             return False
-        x = self.extract_feat(torch.cat([i for i in imgs], dim=0))
-        self.rpn_head(x)
-        raw = self.rpn_head._raw_levels
-        outs = list(x) + list(raw)
+        batch = torch.cat([i for i in imgs], dim=0)
+        from .. import graphs
+        if graphs.TRAIN_ENABLED and batch.is_cuda:
+            # backbone + FPN + RPN convolutions, forward AND backward, as two hipGraphs behind one autograd node
+            sec = self.__dict__.get('_train_trunk_section')
+            if sec is None:
+                mods = (self.backbone, self.neck, self.rpn_head)
+                sec = self.__dict__['_train_trunk_section'] = graphs.TrainSection(
+                    self._trunk_train, mods, 'faster_rcnn.trunk.train')
+            outs = list(sec(batch))
+            n_feat = len(outs) // 2
+            x, raw = tuple(outs[:n_feat]), outs[n_feat:]
+        else:
+            x = self.extract_feat(batch)
+            self.rpn_head(x)
+            raw = self.rpn_head._raw_levels
+            outs = list(x) + list(raw)
         leaves = [t.detach().requires_grad_(True) for t in outs]
         spans, lo = {}, 0
         for i in imgs:
@@ -688,6 +701,11 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
             lo += i.shape[0]
         self._shared = dict(outs=outs, leaves=leaves, spans=spans, n_feat=len(x))
         return True
+
+    def _trunk_train(self, batch):
+        x = self.extract_feat(batch)
+        self.rpn_head(x)
+        return tuple(x) + tuple(self.rpn_head._raw_levels)
 
     def _shared_slices(self, img):
         sh = getattr(self, '_shared', None)

@@ -669,6 +669,8 @@ class SSL(nn.Module):
             return self._forward_train(lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs)
 
     def _forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
+        from .. import graphs
+        graphs.new_iteration()      # no forward of the previous iteration still waits for its backward
         if isinstance(unlab_stu, list):
             unlab_stu = self._collate(unlab_stu)
             unlab_tea = self._collate(unlab_tea)

@@ -348,12 +348,11 @@ class AnchorHeadSingle(nn.Module):
     def _cat_anchors(self):
         return torch.cat(self.anchors, dim=-3)
 
-    def forward(self, data_dict):
-        x = data_dict['spatial_features_2d']
-        # the three 1x1 heads (anchor_head_single.py:20-37) are ONE implicit GEMM over the NHWC
-        # feature map: weights / biases concatenated along the output channels (padded to a multiple
-        # of 4 for the kernel's 16-byte rows), the (B, H, W, 18 | 42 | 12) predictions are column
-        # slices of its output — the reference's permute(0, 2, 3, 1) is the layout we already have
+    def conv_heads(self, x):
+        """The three 1x1 heads (anchor_head_single.py:20-37) as ONE implicit GEMM over the NHWC feature map:
+        weights / biases concatenated along the output channels (padded to a multiple of 4 for the kernel's
+        16-byte rows), the (B, H, W, 18 | 42 | 12) predictions are column slices of its output — the
+        reference's permute(0, 2, 3, 1) is the layout we already have."""
         heads = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
         widths = [m.out_channels for m in heads]
         pad = (-sum(widths)) % 4
@@ -363,7 +362,12 @@ class AnchorHeadSingle(nn.Module):
             w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
             b = torch.cat([b, b.new_zeros(pad)], dim=0)
         y = dense_conv.conv2d(x, w, b, 1, 0).permute(0, 2, 3, 1)          # (B, H, W, sum) NHWC view
-        outs = [t.contiguous() for t in torch.split(y, widths + ([pad] if pad else []), dim=-1)[:len(heads)]]
+        return [t.contiguous() for t in torch.split(y, widths + ([pad] if pad else []), dim=-1)[:len(heads)]]
+
+    def forward(self, data_dict):
+        outs = data_dict.pop('dense_head_convs', None)      # issued with the BEV backbone (backbones_2d._graphed)
+        if outs is None:
+            outs = self.conv_heads(data_dict['spatial_features_2d'])
         cls_preds, box_preds = outs[0], outs[1]
         self.forward_ret_dict['cls_preds'] = cls_preds
         self.forward_ret_dict['box_preds'] = box_preds

@@ -103,6 +103,10 @@ class PVRCNN(nn.Module):
         # the RoI head's proposal layer detaches the anchor head's boxes (roi_head_template.py:96-99) and
         # the final predictions are the RoI head's: nothing differentiates through the decoded anchors
         self.dense_head.boxes_detached_downstream = True
+        # the anchor head's 1x1 convolutions are the tail of the BEV backbone's shape-static chain (graphs.py);
+        # a plain dict entry, not a sub-module: the state-dict keys stay the reference's
+        if hasattr(self.dense_head, 'conv_heads') and getattr(self, 'backbone_2d', None) is not None:
+            self.backbone_2d.__dict__['fused_head'] = self.dense_head
         return mods
 
     def _order(self, batch_dict):

@@ -368,6 +368,26 @@ class _PadXyzColumn(torch.autograd.Function):
         return torch.cat([g[:, :3], g[:, 4:]], dim=1).view(ctx.shape)
 
 
+def _shared_mlp_1x1(mlp, x):
+    """nn.Sequential of [Conv2d 1x1, BatchNorm2d, ReLU]* on a (1, C, M, nsample) tensor without a convolution
+    call (pointnet2_modules.py:31-40 builds exactly this pattern)."""
+    for mod in mlp:
+        if isinstance(mod, nn.Conv2d):
+            if mod.kernel_size != (1, 1) or mod.stride != (1, 1) or mod.groups != 1:
+                raise ValueError('shared MLPs are 1x1 convolutions')
+            b, c, m, ns = x.shape
+            y = torch.matmul(mod.weight.view(mod.out_channels, c), x.reshape(b, c, m * ns))
+            if mod.bias is not None:
+                y = y + mod.bias.view(1, -1, 1)
+            x = y.view(b, mod.out_channels, m, ns)
+        elif isinstance(mod, nn.BatchNorm2d):
+            with torch.backends.cudnn.flags(enabled=False):
+                x = mod(x)
+        else:
+            x = mod(x)
+    return x
+
+
 class StackSAModuleMSG(nn.Module):
     """pointnet2_modules.py:10-92: multi-scale grouping + shared MLP + max over samples."""
 
@@ -441,10 +461,11 @@ class StackSAModuleMSG(nn.Module):
             new_features, _ = self.groupers[k](xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
                                                features)  # (M, C, nsample)
             new_features = new_features.permute(1, 0, 2).unsqueeze(dim=0)  # (1, C, M, nsample)
-            # torch's own convolution / BatchNorm, NOT MIOpen: MIOpen may compile a kernel at run time, which
-            # forks a compiler from a process that has initialised the GPU
-            with torch.backends.cudnn.flags(enabled=False):
-                new_features = self.mlps[k](new_features)
+            # Never MIOpen (it may compile a kernel at run time, which forks a compiler from a process that has
+            # initialised the GPU): the 1x1 convolutions are matrix products (their backward is a matrix
+            # product too — a `cudnn.flags` context around the forward would not cover convolution_backward,
+            # which picks its backend when it runs), BatchNorm records its backend at forward time.
+            new_features = _shared_mlp_1x1(self.mlps[k], new_features)
             if self.pool_method == 'max_pool':
                 new_features = F.max_pool2d(new_features,
                                             kernel_size=[1, new_features.size(3)]).squeeze(dim=-1)

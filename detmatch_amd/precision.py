@@ -7,7 +7,11 @@ accumulation while every tensor in HBM, the master weights, the optimizer state 
   * sparse convolutions (csrc/spconv16.hip, storage mode DM_SP16_F32ROWS): v_mfma_f32_16x16x32_bf16 for the
     forward and input-gradient gather-GEMMs of every layer with >= 16 input channels.
 bfloat16 keeps fp32's exponent range, so no loss scaling is needed: `loss_scale` of the reference's fp16 config
-is accepted and ignored.  The default — and the headline benchmark — is exact fp32 everywhere.
+is accepted and ignored.  The default — and the headline benchmark — is fp32-CLASS arithmetic: the sparse
+gather-GEMMs on the matrix pipe's own fp32 instruction (v_mfma_f32_16x16x4_f32), the dense convolutions on the
+three-way bf16 split (six products on v_mfma_f32_32x32x16_bf16, fp32 accumulate: within 1.25x of the fp32
+instruction's error against float64, finite inputs; see dense_conv.set_math and DESIGN §6.0) — bench.py prints
+the flavour as config.conv_math.
 (Half-precision STORAGE of sparse features, the reference's `indice_conv_half`, is a property of the tensors
 handed to spconv.ops.indice_conv, not of this switch.)"""
 import contextlib

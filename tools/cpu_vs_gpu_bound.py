@@ -14,6 +14,22 @@ import detmatch_amd  # noqa: E402,F401
 import torch  # noqa: E402
 
 
+def thread_cpu():
+    """{tid: (name, cpu seconds)} of every thread of this process (/proc/self/task)."""
+    out = {}
+    tck = os.sysconf('SC_CLK_TCK')
+    for tid in os.listdir('/proc/self/task'):
+        try:
+            with open('/proc/self/task/%s/stat' % tid) as fh:
+                f = fh.read()
+            name = f[f.index('(') + 1:f.rindex(')')]
+            rest = f[f.rindex(')') + 2:].split()
+            out[int(tid)] = (name, (int(rest[11]) + int(rest[12])) / tck)
+        except OSError:
+            pass
+    return out
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'detmatch'
     from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
@@ -23,6 +39,7 @@ def main():
         wl.step()
     torch.cuda.synchronize()
     n = 20
+    th0 = thread_cpu()
     w0, t0, p0 = time.perf_counter(), time.thread_time(), time.process_time()
     for _ in range(n):
         wl.step()
@@ -32,6 +49,15 @@ def main():
     print('%s: wall %.1f ms/step | main-thread CPU %.1f ms | process CPU (all threads) %.1f ms | '
           'host finished issuing %.1f ms before the device' % (
               which, (w1 - w0) / n * 1e3, (t1 - t0) / n * 1e3, (p1 - p0) / n * 1e3, (w1 - t_launch_done) * 1e3))
+    th1 = thread_cpu()
+    rows = sorted(((c - th0.get(tid, (nm, 0.0))[1]) / n * 1e3, nm, tid) for tid, (nm, c) in th1.items())
+    print('  CPU ms per step by thread: ' + ', '.join('%s[%d] %.1f' % (nm, tid, ms) for ms, nm, tid in rows[::-1] if ms >= 0.5))
+    from detmatch_amd import graphs
+    for ref in graphs._ALL_TRAIN_SECTIONS:
+        s = ref()
+        if s is not None and (s.captures or s.fallbacks):
+            print('  graph section %-28s captures %d  replays %d  backward replays %d  plain calls %d  host time in replays: fwd %.2f ms, bwd %.2f ms per step'
+                  % (s.name, s.captures, s.replays, s.bwd_replays, s.fallbacks, s.t_replay / (n + 5) * 1e3, s.t_replay_bwd / (n + 5) * 1e3))
 
 
 if __name__ == '__main__':
