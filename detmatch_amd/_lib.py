@@ -117,6 +117,9 @@ SIGNATURES = {
     'dm_dconv_gemm_workspace_bytes': (sz, [c_int_p]),
     'dm_dconv_gemm': (ci, [vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), vp, sz, vp]),
     'dm_dconv_gemm_residual': (ci, [vp, vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), vp, sz, vp]),
+    'dm_dconv_planes_bytes': (sz, [ci, ci, ci]),
+    'dm_dconv_pack_planes': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, vp]),
+    'dm_dconv_gemm_planes': (ci, [vp, vp, vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), vp, sz, vp]),
     'dm_dconv_wgrad_workspace_bytes': (sz, [c_int_p]),
     'dm_dconv_wgrad': (ci, [vp, vp, vp, vp, c_int_p, ctypes.POINTER(ctypes.c_short), ci, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ci, vp, sz, vp]),
     'dm_fusion_match_cost': (ci, [vp, vp, vp, ci, vp, vp, ci, ci, c_f32_p, cf, cf, cf, cf, cf, cf, cf, cf, vp, vp, vp]),

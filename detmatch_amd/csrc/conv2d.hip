@@ -565,9 +565,13 @@ void dconv_gemm_bf16_kernel(
     v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
     unsigned *dst = ldsw + buf * SPLIT * PLANE + (r0 + p * RPP) * LDW + kq * 2;
     if constexpr (SPLIT == 3) {
+#ifndef DCONV_PROBE_NO_ASPLIT
       uint2 h, m, l;
       split_bf16x3(v, &h, &m, &l);
       *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
+#else
+      if (v.x == 123.456f) *(uint2 *)dst = make_uint2(1, 2);
+#endif
     } else {
       *(uint2 *)dst = pack_bf16x4(v);
     }
@@ -576,9 +580,13 @@ void dconv_gemm_bf16_kernel(
     constexpr int R = decltype(slot)::value;
     unsigned *dst = ldsw + buf * SPLIT * PLANE + BM * LDW + (r0 + p * RPP) * LDW + kq * 2;
     if constexpr (SPLIT == 3) {
+#ifndef DCONV_PROBE_NO_BSPLIT       // timing probe (tools/probe_dconv.sh): results are garbage
       uint2 h, m, l;
       split_bf16x3(rb[R][p], &h, &m, &l);
       *(uint2 *)dst = h, *(uint2 *)(dst + PLANE) = m, *(uint2 *)(dst + 2 * PLANE) = l;
+#else
+      if (rb[R][p].x == 123.456f) *(uint2 *)dst = make_uint2(1, 2);
+#endif
     } else {
       *(uint2 *)dst = pack_bf16x4(rb[R][p]);
     }
@@ -1025,10 +1033,14 @@ void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restri
       float4 v = ra[p];
       const bool ok = a_ok[p];
       v.x = ok ? v.x : 0.0f, v.y = ok ? v.y : 0.0f, v.z = ok ? v.z : 0.0f, v.w = ok ? v.w : 0.0f;
+      unsigned *dst = lds_a + a_lds[p];
+#ifndef DCONV_PROBE_NO_ASPLIT
       uint2 h, m, l;
       split_bf16x3(v, &h, &m, &l);
-      unsigned *dst = lds_a + a_lds[p];
       *(uint2 *)dst = h, *(uint2 *)(dst + A_PLANE) = m, *(uint2 *)(dst + 2 * A_PLANE) = l;
+#else
+      if (v.x == 123.456f) *(uint2 *)dst = make_uint2(1, 2);
+#endif
     }
   };
   int ktf = 0;           // k-tile the next gB() fetches: tap = ktf % T, channel block = ktf / T (clamped at the end)
@@ -1043,10 +1055,14 @@ void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restri
   };
   auto sB = [&](int buf, auto slot, int p) {
     constexpr int R = decltype(slot)::value;
+    unsigned *dst = lds_b + buf * 3 * B_PLANE + b_lds[p];
+#ifndef DCONV_PROBE_NO_BSPLIT
     uint2 h, m, l;
     split_bf16x3(rb[R][p], &h, &m, &l);
-    unsigned *dst = lds_b + buf * 3 * B_PLANE + b_lds[p];
     *(uint2 *)dst = h, *(uint2 *)(dst + B_PLANE) = m, *(uint2 *)(dst + 2 * B_PLANE) = l;
+#else
+    if (rb[R][p].x == 123.456f) *(uint2 *)dst = make_uint2(1, 2);
+#endif
   };
   // fragment addresses: MFMA tile a of this wave covers patch rows ROWS_W*wm + 2a, +1 (16 pixels each)
   int a_base[TM];
@@ -1148,6 +1164,281 @@ void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restri
 #pragma unroll
     for (int it = 0; it < WM / 8; ++it) {
       const int rl = it * 8 + rr;                       // pixel of the wave's tile: row rl / 16, column rl % 16
+      const int oy = y0 + ROWS_W * wm + (rl >> 4), ox = x0 + (rl & 15);
+      if (oy < g.LH && ox < g.LW && ncol < g.Cout) {
+        const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
+        float *dst = y + (((size_t)bimg * g.LH + oy) * g.LW + ox) * g.Cout + ncol;
+        if (ncol + 3 < g.Cout) {
+          *(float4 *)dst = v;
+        } else {
+          dst[0] = v.x;
+          if (ncol + 1 < g.Cout) dst[1] = v.y;
+          if (ncol + 2 < g.Cout) dst[2] = v.z;
+        }
+      }
+    }
+  }
+}
+
+// ---- the patch kernel with the weights through LDS-DMA ---------------------------------------------------------
+// Timing probes (tools/probe_dconv.sh: the kernel above with the weight split + LDS stores compiled out) put the
+// in-loop weight work at 15-20 % of the 3 x 3 layers' time: every workgroup re-fetches, re-splits and re-stores
+// the same (tap, 16-channel) weight tile that every other workgroup of the layer handles too.  Here the pack
+// kernels (`planes` copy: dconv_pack_planes) split the weights ONCE per weight update and lay the three bf16
+// planes out in MFMA-fragment order — [slice][16-channel block][32-column block][plane][lane][8 bf16]: one
+// (column block, plane) fragment is 1 KiB, a (tap, channel block) tile of BN columns BN/32 x 3 KiB, contiguous —
+// and a workgroup moves a tile into LDS with BN/32 x 3 `global_load_lds_dwordx4` instructions (no VGPR, no VALU,
+// no ds_write: the LDS image of such an instruction is lane-linear, which IS the fragment order).  Ring of four
+// tiles: tile kt + 3 is requested at step kt into the slot step kt - 1 read; before the barrier that ends step kt
+// a counted `s_waitcnt vmcnt` retires tile kt + 1 (tiles kt + 2, kt + 3 stay in flight across the barrier — raw
+// s_barrier: __syncthreads() would drain the DMA).  The A patch is still fetched through registers (it needs the
+// split), by inline-asm loads: the compiler's own wait insertion would answer the first use of an ordinary load
+// with vmcnt(0) while a DMA is in flight; the loads are nine steps old when sA() reads them, long retired by the
+// steps' counted waits (vmcnt retires in issue order).
+// Fragment reads as inline asm: the compiler answers a C++ read of an LDS array that an LDS-DMA may be writing
+// with vmcnt(0) — which would drain the ring at every step.  The reads are fenced by hand: one lgkmcnt(0) behind
+// the last of them (dm_frags_ready), and the values pass through an empty asm so that no use moves above it.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ f32x4v dm_ds_read128(unsigned addr) {
+  f32x4v v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ unsigned dm_lds_addr(const void *p) {     // byte offset inside the workgroup's LDS
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void dm_static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    dm_static_for<I + 1, N>(f);
+  }
+}
+template <int N>
+__device__ __forceinline__ void dm_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void dm_lds_barrier() {      // LDS operations of this wave done, then the workgroup barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void dconv_patch_gl_kernel(const float *__restrict__ x, const unsigned char *__restrict__ wpl,
+                           const float *__restrict__ bias, float *__restrict__ y, const DConvGeom g,
+                           const DConvTaps tt, int tiles_y, int tiles_x, int n_tiles_m, int n_tiles_n, int nnb) {
+  static_assert(WAVES_M * WAVES_N == 4, "four waves");
+  constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PR = PH * PW;     // 180 patch rows
+  constexpr int LDW = 12;
+  constexpr int A_PLANE = PR * LDW;
+  constexpr int WM = 128 / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  constexpr int ROWS_W = TH / WAVES_M;
+  constexpr int AP = (PR * 4 + 255) / 256;
+#ifndef DCONV_GL_NBUF
+#define DCONV_GL_NBUF 4
+#endif
+  constexpr int NBUF = DCONV_GL_NBUF;
+  constexpr int PIECES = BN / 32 * 3;          // 1 KiB fragments of a weight tile
+  constexpr int PPW = (PIECES + 3) / 4;        // DMA instructions per wave and tile: piece j * 4 + wave (BN = 64: waves 2, 3 one less)
+  constexpr int REM = PIECES % 4;              // 0: every wave issues PPW
+  constexpr int SLOT_W = PIECES * 256;         // words of a ring slot
+  static_assert(TM >= 1 && TN >= 1 && ROWS_W * 16 == WM, "tile shape");
+  __shared__ __attribute__((aligned(16))) unsigned lds_a[3 * A_PLANE];
+  __shared__ __attribute__((aligned(1024))) unsigned lds_b[NBUF * SLOT_W];
+
+  const int L = blockIdx.x;
+  const int xcd = L & 7, seq = L >> 3;
+  const int mt = (seq / n_tiles_n) * 8 + xcd;
+  const int nt = seq % n_tiles_n;
+  if (mt >= n_tiles_m) return;
+  const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, bimg = mt / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  unsigned a_off[AP];
+  bool a_ok[AP];
+  int a_lds[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int q = tid + 256 * p;
+    const int row = q >> 2, kq = q & 3;
+    const int py = row / PW, px = row % PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = (row < PR) & ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
+    a_ok[p] = ok;
+    a_off[p] = ok ? (unsigned)(((bimg * g.Hin + iy) * g.Win + ix) * g.Cin + kq * 4) * 4u : 0u;
+    a_lds[p] = row < PR ? row * LDW + kq * 2 : -1;
+  }
+  const char *xb = (const char *)x;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int NCB = g.Cin / 16, T = g.T, KT = NCB * T;
+  f32x4v ra[AP];
+  auto gA = [&](int cb) {       // asm: invisible to the compiler's wait insertion (see the header comment)
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const char *src = xb + a_off[p] + (a_ok[p] ? (unsigned)cb * 64u : 0u);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[p]) : "v"(src) : "memory");
+    }
+  };
+  auto sA = [&]() {
+#pragma unroll
+    for (int p = 0; p < AP; ++p) asm volatile("" : "+v"(ra[p])::"memory");     // not before the wait that retired the loads
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      if (a_lds[p] < 0) continue;
+      const bool ok = a_ok[p];
+      float4 v;
+      v.x = ok ? ra[p][0] : 0.0f, v.y = ok ? ra[p][1] : 0.0f, v.z = ok ? ra[p][2] : 0.0f, v.w = ok ? ra[p][3] : 0.0f;
+      uint2 h, m, l;
+      split_bf16x3(v, &h, &m, &l);
+      unsigned *dst = lds_a + a_lds[p];
+      *(uint2 *)dst = h, *(uint2 *)(dst + A_PLANE) = m, *(uint2 *)(dst + 2 * A_PLANE) = l;
+    }
+  };
+  // weight tiles: slice tt.ws[tap], channel block cb, column blocks n0/32 ... of the planes copy
+  const unsigned char *wbase = wpl + (size_t)(n0 >> 5) * 3072 + lane * 16;
+  const size_t cb_stride = (size_t)nnb * 3072;
+  int ktf = 0;
+  auto gB = [&]() {
+    const int kc = ktf < KT ? ktf : KT - 1;
+    const int tap = __builtin_amdgcn_readfirstlane(kc % T), cb = __builtin_amdgcn_readfirstlane(kc / T);
+    const unsigned char *src = wbase + ((size_t)tt.ws[tap] * NCB + cb) * cb_stride;
+    unsigned *dst = lds_b + (ktf % NBUF) * SLOT_W;
+    ++ktf;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int p = j * 4 + wave;
+      if (REM == 0 || j + 1 < PPW || wave < REM)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 1024),
+                                         (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
+    }
+  };
+  auto wait_tiles = [&](auto keep_) {      // all but the youngest `keep` tiles of this wave's requests have landed
+    constexpr int keep = decltype(keep_)::value;
+    if constexpr (REM == 0) {
+      dm_wait_vmcnt<keep * PPW>();
+    } else {
+      if (wave < REM) dm_wait_vmcnt<keep * PPW>();
+      else dm_wait_vmcnt<keep * (PPW - 1)>();
+    }
+  };
+  unsigned a_base[TM];        // byte addresses inside LDS
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+    a_base[a] = dm_lds_addr(lds_a) + (((ROWS_W * wm + 2 * a + (lr >> 4) + 1) * PW + (lr & 15) + 1) * LDW + lh * 4) * 4u;
+  const unsigned b_base = dm_lds_addr(lds_b) + ((wn * TN * 3) * 256 + lane * 4) * 4u;
+
+  f32x4v afr[3][TM], bfrr[3][TN];
+  bf16x8 af[3][TM], bfr[3][TN];
+  auto frags = [&](int slot, int tap) {
+    const unsigned shift = (unsigned)((tt.dy[tap] * PW + tt.dx[tap]) * LDW * 4);
+    const unsigned bs = b_base + (unsigned)slot * (SLOT_W * 4u);
+    dm_static_for<0, 3>([&](auto s_) {
+      constexpr int s = decltype(s_)::value;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) afr[s][a] = dm_ds_read128<s * A_PLANE * 4>(a_base[a] + shift);
+      dm_static_for<0, TN>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        bfrr[s][b] = dm_ds_read128<(b * 3 + s) * 1024>(bs);
+      });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        asm volatile("" : "+v"(afr[s][a])::"memory");
+        af[s][a] = __builtin_bit_cast(bf16x8, afr[s][a]);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        asm volatile("" : "+v"(bfrr[s][b])::"memory");
+        bfr[s][b] = __builtin_bit_cast(bf16x8, bfrr[s][b]);
+      }
+    }
+  };
+  constexpr int G = TM * TN;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+
+  gA(0);
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) gB();
+  wait_tiles(std::integral_constant<int, NBUF - 2>());      // the A patch and tile 0
+  sA();
+  dm_lds_barrier();
+  int cb = 0, tap = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+#ifndef DCONV_GL_PROBE_NOA       // timing probes (tools/probe_dconv.sh): results are garbage
+    if (tap == 0 && cb + 1 < NCB) gA(cb + 1);
+#endif
+#ifndef DCONV_GL_PROBE_NOB
+    gB();                                   // tile kt + 3 into the slot step kt - 1 read
+#endif
+    frags(kt % NBUF, tap);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef DCONV_GL_PROBE_NOMFMA
+#pragma unroll
+#else
+    for (int s_ = 0; s_ < 3; ++s_) { acc[0][0][s_] += (float)af[s_][0][0] + (float)bfr[s_][TN - 1][1] + (float)af[s_][TM - 1][2]; }
+#pragma unroll 1
+    for (int gi_ = 0; gi_ < 0; ++gi_)
+#endif
+    for (int gi = 0; gi < 6; ++gi) {
+#pragma unroll
+      for (int ab = 0; ab < G; ++ab)
+        acc[ab / TN][ab % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[gi]][ab / TN], bfr[PB[gi]][ab % TN],
+                                                                         acc[ab / TN][ab % TN], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_tiles(std::integral_constant<int, NBUF - 2>());      // tile kt + 1 has landed (this wave's pieces; the barrier covers the others')
+    dm_lds_barrier();
+    if (++tap == T) {
+      tap = 0;
+      if (++cb < NCB) {        // every wave has passed the last tap's barrier: the A image is free
+#ifndef DCONV_GL_PROBE_NOA
+        sA();
+        dm_lds_barrier();
+#endif
+      }
+    }
+  }
+  dm_wait_vmcnt<0>();          // the clamped tail requests: nothing may land in LDS after the epilogue took it over
+  dm_lds_barrier();
+
+  constexpr int LDC = 36;
+  static_assert(4 * WM * LDC <= NBUF * SLOT_W, "epilogue tile must fit the weight ring");
+  float *cs = (float *)lds_b + wave * WM * LDC;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int ncol0 = n0 + wn * WN + b * 32;
+    const float bv = (bias != nullptr && ncol0 + lr < g.Cout) ? bias[ncol0 + lr] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[a][b][r] + bv;
+        if (g.relu == 1) v = fmaxf(v, 0.0f);
+        cs[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + lr] = v;
+      }
+    const int cq = lane & 7, rr = lane >> 3;
+    const int ncol = ncol0 + cq * 4;
+#pragma unroll
+    for (int it = 0; it < WM / 8; ++it) {
+      const int rl = it * 8 + rr;
       const int oy = y0 + ROWS_W * wm + (rl >> 4), ox = x0 + (rl & 15);
       if (oy < g.LH && ox < g.LW && ncol < g.Cout) {
         const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
@@ -1403,6 +1694,56 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const float *__restrict
   dst[e] = v;
 }
 
+// The `planes` copy of a packed weight for dconv_patch_gl_kernel: the three bf16 planes of dst[s][n][k] in MFMA
+// fragment order, [s][k / 16][n / 32][plane][lane = 32 * ((k % 16) / 8) + n % 32][k % 8] — chunk c of this function
+// is one lane's 8 values of one (s, 16-channel block, 32-column block): three 16-byte stores.  N is padded to a
+// multiple of 32 with zeros; K % 16 == 0.
+__device__ __forceinline__ long long dconv_planes_chunks(int S, int N, int K) {
+  return (long long)S * (K / 16) * ((N + 31) / 32) * 64;
+}
+__device__ __forceinline__ void dconv_pack_planes_chunk(long long c, const float *__restrict__ src,
+                                                        unsigned char *__restrict__ planes,
+                                                        const float *__restrict__ scale_n,
+                                                        const float *__restrict__ scale_k, int N, int K, int Nsrc,
+                                                        int Ksrc, long long sn, long long sk, long long st) {
+  const int NNB = (N + 31) / 32, NCB = K / 16;
+  const int lane = (int)(c & 63);
+  long long r = c >> 6;
+  const int nb = (int)(r % NNB);
+  r /= NNB;
+  const int cb = (int)(r % NCB), s = (int)(r / NCB);
+  const int n = nb * 32 + (lane & 31), k0 = cb * 16 + (lane >> 5) * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    float t = 0.0f;
+    if (k < Ksrc && n < Nsrc) {
+      t = src[n * sn + k * sk + s * st];
+      if (scale_n) t *= scale_n[n];
+      if (scale_k) t *= scale_k[k];
+    }
+    v[j] = t;
+  }
+  uint2 h0, m0, l0, h1, m1, l1;
+  split_bf16x3(make_float4(v[0], v[1], v[2], v[3]), &h0, &m0, &l0);
+  split_bf16x3(make_float4(v[4], v[5], v[6], v[7]), &h1, &m1, &l1);
+  unsigned char *dst = planes + (((size_t)(s * NCB + cb) * NNB + nb) * 3) * 1024 + lane * 16;
+  *(uint4 *)dst = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *(uint4 *)(dst + 1024) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+  *(uint4 *)(dst + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+__global__ __launch_bounds__(256) void dconv_pack_planes_kernel(const float *__restrict__ src,
+                                                                unsigned char *__restrict__ planes,
+                                                                const float *__restrict__ scale_n,
+                                                                const float *__restrict__ scale_k, int S, int N,
+                                                                int K, int Nsrc, int Ksrc, long long sn,
+                                                                long long sk, long long st) {
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (c < dconv_planes_chunks(S, N, K)) dconv_pack_planes_chunk(c, src, planes, scale_n, scale_k, N, K, Nsrc, Ksrc, sn, sk, st);
+}
+
 // the same for a table of weights in one launch (blockIdx.y = table row, grid-stride over its elements):
 // every packed weight of a network is refreshed by one launch after an optimizer / EMA step.
 struct DConvPackDesc {   // 80 bytes; mirrored by dense_conv._DESC (numpy)
@@ -1427,6 +1768,12 @@ __global__ __launch_bounds__(256) void dconv_pack_batch_kernel(const DConvPackDe
       if (d.scale_k) v *= d.scale_k[k];
     }
     d.dst[e] = v;
+  }
+  if (d.pad == 1) {      // the planes copy behind the fp32 block (dm_dconv_planes_offset_bytes)
+    unsigned char *planes = (unsigned char *)(d.dst + total);
+    const long long chunks = dconv_planes_chunks(d.S, d.N, d.K);
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (long long)gridDim.x * 256)
+      dconv_pack_planes_chunk(c, d.src, planes, d.scale_n, d.scale_k, d.N, d.K, d.Nsrc, d.Ksrc, d.sn, d.sk, d.st);
   }
 }
 
@@ -1494,6 +1841,7 @@ int launch_gemm(const float *x, const float *w, const float *bias, float *y, DCo
 // 0: fp32 on the matrix pipe's own fp32 instruction (v_mfma_f32_32x32x2_f32), 1: bf16 multiplicands, fp32
 // accumulate (mixed precision), 2: fp32-class through six bf16 products of the three-way split operands
 int g_dconv_math = 0;
+int g_dconv_planes = 1;   // the patch kernel takes a layer's `planes` weight copy when the caller hands one (dm_dconv_gemm_planes)
 int g_dconv_patch = 1;    // math mode 2: 3 x 3 / stride-1 layers on dconv_patch_split_kernel (dm_dconv_set_math(2 + 16) turns it off)
 
 // How many ways the reduction of a SMALL problem (fewer 64x64 tiles than half a round) is split.
@@ -1554,6 +1902,32 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
                                       const float *residual, float *y, const int *geom_host,
                                       const short *taps_host, void *workspace, size_t workspace_bytes,
                                       dm_stream_t stream) {
+  return dm_dconv_gemm_planes(x, w_packed, nullptr, bias, residual, y, geom_host, taps_host, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" size_t dm_dconv_planes_bytes(int S, int N, int K) {
+  if (S <= 0 || N <= 0 || K <= 0 || (K % 16) != 0) return 0;
+  // + one tile of slack: a workgroup whose column tile hangs over N reads (and discards) the blocks behind it
+  return (size_t)S * (K / 16) * ((N + 31) / 32) * 3072 + 4 * 3072;
+}
+
+extern "C" int dm_dconv_pack_planes(const float *src, void *planes, const float *scale_n, const float *scale_k,
+                                    int S, int N, int K, int Nsrc, int Ksrc, long long sn, long long sk,
+                                    long long st, dm_stream_t stream) {
+  if (S <= 0 || N <= 0 || K <= 0) return DM_OK;
+  if (!src || !planes || Ksrc > K || Nsrc > N || (K % 16) != 0) return DM_ERR_INVALID_ARG;
+  const long long chunks = (long long)S * (K / 16) * ((N + 31) / 32) * 64;
+  dconv_pack_planes_kernel<<<dm_ceil_div(chunks, 256), 256, 0, (hipStream_t)stream>>>(
+      src, (unsigned char *)planes, scale_n, scale_k, S, N, K, Nsrc, Ksrc, sn, sk, st);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_dconv_gemm_planes(const float *x, const float *w_packed, const void *w_planes,
+                                    const float *bias, const float *residual, float *y, const int *geom_host,
+                                    const short *taps_host, void *workspace, size_t workspace_bytes,
+                                    dm_stream_t stream) {
   if (!x || !w_packed || !y || !geom_host || !taps_host) return DM_ERR_INVALID_ARG;
   DConvGeom g;
   g.residual = residual;
@@ -1631,7 +2005,13 @@ extern "C" int dm_dconv_gemm_residual(const float *x, const float *w_packed, con
         if ((tm_main - last0) / tiles_x * 8 >= g.LH) tm_main = tm;
       }
       const int blocks = dm_ceil_div(tm_main, 8) * 8 * tn;
-      if (bn == 128)
+      const int nnb = dm_ceil_div(g.Cout, 32);
+      const unsigned char *wpl = (const unsigned char *)w_planes;
+      if (wpl != nullptr && g_dconv_planes && bn == 128)
+        dconv_patch_gl_kernel<128, 2, 2><<<blocks, 256, 0, st>>>(x, wpl, bias, y, g, tt, tiles_y, tiles_x, tm_main, tn, nnb);
+      else if (wpl != nullptr && g_dconv_planes)
+        dconv_patch_gl_kernel<64, 4, 1><<<blocks, 256, 0, st>>>(x, wpl, bias, y, g, tt, tiles_y, tiles_x, tm_main, tn, nnb);
+      else if (bn == 128)
         dconv_patch_split_kernel<128, 2, 2><<<blocks, 256, 0, st>>>(x, w_packed, bias, y, g, tt, tiles_y, tiles_x, tm_main, tn);
       else
         dconv_patch_split_kernel<64, 4, 1><<<blocks, 256, 0, st>>>(x, w_packed, bias, y, g, tt, tiles_y, tiles_x, tm_main, tn);

@@ -195,10 +195,22 @@ def _refresh_stream(stream, device):
 CAPTURING = [False]     # graphs.StaticSection: inside a hipGraph capture every pack is issued (and so recorded), never cached
 
 
-def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None):
-    """[S][N][K] packed copy of `weight` (cached until the weight or a scale changes)."""
+PLANES = os.environ.get('DM_DCONV_PLANES', '1') == '1'     # A/B: pre-split weight planes for the patch kernel
+
+
+def _wants_planes(T, N, K, stride_one):
+    """The layers dconv_patch_* takes in the split arithmetic (csrc/conv2d.hip: dm_dconv_gemm_planes)."""
+    return PLANES and stride_one and 4 <= T <= 9 and K % 32 == 0 and N % 4 == 0 and N >= 64 and \
+        _lib.lib().dm_dconv_get_math() == 2
+
+
+def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None, planes=False):
+    """[S][N][K] packed copy of `weight` (cached until the weight or a scale changes).  planes=True: the flat
+    buffer also holds the pre-split bf16 planes behind the fp32 block (`dst.dm_planes` = their byte offset)."""
     cacheable = isinstance(weight, nn.Parameter) and not CAPTURING[0]     # temporaries may recycle an address
     stream = _lib.raw_stream()
+    if planes:
+        tag = tag + 'P'
     key = (id(weight), weight.data_ptr(), tag, N, K, stream)
     ver = (_GENERATION[0], weight._version, _scale_id(scale_n), _scale_id(scale_k))
     hit = _PACK_CACHE.get(key) if cacheable else None
@@ -217,17 +229,29 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
-    dst = hit.dst if hit is not None else torch.empty((S, N, K), dtype=torch.float32, device=weight.device)
+    if hit is not None:
+        dst = hit.dst
+    elif planes:
+        nb = int(_lib.lib().dm_dconv_planes_bytes(S, N, K))
+        dst = torch.empty(S * N * K + (nb + 3) // 4, dtype=torch.float32, device=weight.device)
+        dst.dm_planes = S * N * K * 4
+    else:
+        dst = torch.empty((S, N, K), dtype=torch.float32, device=weight.device)
     _lib.check(_lib.lib().dm_dconv_pack(_lib.ptr(w), _lib.ptr(dst), _lib.ptr(scale_n),
                                         _lib.ptr(scale_k), S, N, K, n_src, k_src, sn, sk, st,
                                         _lib.stream()), 'dm_dconv_pack')
+    if planes:
+        _lib.check(_lib.lib().dm_dconv_pack_planes(_lib.ptr(w), dst.data_ptr() + dst.dm_planes, _lib.ptr(scale_n),
+                                                   _lib.ptr(scale_k), S, N, K, n_src, k_src, sn, sk, st,
+                                                   _lib.stream()), 'dm_dconv_pack_planes')
     if cacheable:
         e = _Packed()
         e.ver, e.dst, e.src, e.wref = ver, dst, w, weakref.ref(weight)
         e.scale_n, e.scale_k, e.stream = scale_n, scale_k, stream
         e.batchable = w.data_ptr() == weight.data_ptr() and _constant(scale_n) and _constant(scale_k)
         e.desc = (w.data_ptr(), dst.data_ptr(), 0 if scale_n is None else scale_n.data_ptr(),
-                  0 if scale_k is None else scale_k.data_ptr(), sn, sk, st, S, N, K, n_src, k_src, 0, key)
+                  0 if scale_k is None else scale_k.data_ptr(), sn, sk, st, S, N, K, n_src, k_src,
+                  1 if planes else 0, key)
         _PACK_CACHE[key] = e
         if e.batchable:
             reg = _TABLES.setdefault(stream, {'entries': []})
@@ -275,8 +299,10 @@ def _gemm(x, wp, bias, y, geom, taps, residual=None):
     the epilogue adds before the ReLU."""
     g, t, nbytes = _plan('gemm', geom, taps)
     ws = _lib.workspace(nbytes, x.device, 'dconv_gemm') if nbytes else None
-    _lib.check(_lib.lib().dm_dconv_gemm_residual(
-        x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
+    off = getattr(wp, 'dm_planes', None)
+    _lib.check(_lib.lib().dm_dconv_gemm_planes(
+        x.data_ptr(), wp.data_ptr(), None if off is None else wp.data_ptr() + off,
+        None if bias is None else bias.data_ptr(),
         None if residual is None else residual.data_ptr(), y.data_ptr(), g, t,
         None if ws is None else ws.data_ptr(), ws.numel() if ws is not None else 0, _lib.raw_stream()),
         'dm_dconv_gemm')
@@ -313,7 +339,8 @@ class _Conv2dFn(torch.autograd.Function):
         n, c4, h, w = x.shape
         ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
         T = kh * kw
-        wp = _pack(weight, 'f', T, cout, c4, cout, cin, cin * T, T, 1, scale_n=w_scale)
+        wp = _pack(weight, 'f', T, cout, c4, cout, cin, cin * T, T, 1, scale_n=w_scale,
+                   planes=residual is None and _wants_planes(T, cout, c4, sh == 1 and sw == 1 and ho == h and wo == w))
         y = _empty_cl(n, cout, ho, wo, x)
         taps = [(a - ph, b - pw, a * kw + b) for a in range(kh) for b in range(kw)]
         if residual is not None:
@@ -343,7 +370,8 @@ class _Conv2dFn(torch.autograd.Function):
         ho, wo = dy.shape[2], dy.shape[3]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = _pack(weight, 'b', T, c4, cout, cin, cout, T, cin * T, 1, scale_k=w_scale)
+            wt = _pack(weight, 'b', T, c4, cout, cin, cout, T, cin * T, 1, scale_k=w_scale,
+                       planes=_wants_planes(T, c4, cout, sh == 1 and sw == 1 and ho == h and wo == w))
             dxp = _empty_cl(n, c4, h, w, dy)
             if sh == 1 and sw == 1:
                 taps = [(ph - a, pw - b, a * kw + b) for a in range(kh) for b in range(kw)]

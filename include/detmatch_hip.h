@@ -710,6 +710,22 @@ int dm_dconv_gemm_residual(const float *x, const float *w_packed, const float *b
                            const float *residual, float *y, const int *geom_host,
                            const short *taps_host, void *workspace, size_t workspace_bytes,
                            dm_stream_t stream);
+/* The `planes` copy of a packed weight (math mode 2, the 3 x 3 / stride-1 layers that dconv_patch_* takes): the
+ * three bf16 planes of the split weights in MFMA-fragment order, written ONCE per weight update instead of split
+ * by every workgroup of every launch; the kernel moves its tiles into LDS with direct-to-LDS loads
+ * (global_load_lds_dwordx4).  Layout: [s][k / 16][n / 32 (N padded to 32)][plane h, m, l][lane][8 bf16],
+ * lane = 32 * ((k % 16) / 8) + n % 32; K % 16 == 0.  dm_dconv_planes_bytes: bytes of the copy (incl. one tile of
+ * slack); dm_dconv_pack_planes: same arguments as dm_dconv_pack; a dm_dconv_pack_batch row with pad == 1 writes
+ * the copy right behind its fp32 block (dst + S*N*K floats).  dm_dconv_gemm_planes = dm_dconv_gemm_residual with
+ * the copy handed along (w_planes may be NULL: then it IS dm_dconv_gemm_residual); results are bit-identical
+ * with and without it (same split, same product order).  Replaces the same cuDNN call as dm_dconv_gemm. */
+size_t dm_dconv_planes_bytes(int S, int N, int K);
+int dm_dconv_pack_planes(const float *src, void *planes, const float *scale_n, const float *scale_k,
+                         int S, int N, int K, int Nsrc, int Ksrc, long long sn, long long sk, long long st,
+                         dm_stream_t stream);
+int dm_dconv_gemm_planes(const float *x, const float *w_packed, const void *w_planes, const float *bias,
+                         const float *residual, float *y, const int *geom_host, const short *taps_host,
+                         void *workspace, size_t workspace_bytes, dm_stream_t stream);
 size_t dm_dconv_wgrad_workspace_bytes(const int *geom_host);
 int dm_dconv_wgrad(const float *U, const float *V, float *out, const float *scale_u,
                    const int *geom_host, const short *taps_host, int Cv_out, long long su,

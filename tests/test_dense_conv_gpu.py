@@ -365,3 +365,35 @@ def test_fp32_split_mode_is_at_least_as_accurate_as_the_fp32_instruction(dev, sh
     for i, what in enumerate(('forward', 'input gradient', 'weight gradient')):
         assert errs['fp32_split'][i] <= 1e-6, (what, errs)
         assert errs['fp32_split'][i] <= 1.25 * errs['fp32_mfma'][i] + 2e-8, (what, errs)
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 40, 48, 128), (1, 64, 33, 70, 64), (2, 256, 24, 80, 256), (2, 128, 200, 176, 128),
+                                   (1, 96, 17, 19, 72)])
+def test_planes_weights_are_bit_identical(dev, shape):
+    """3 x 3 / stride-1 layers with the weights pre-split into bf16 planes and moved by LDS-DMA (dm_dconv_gemm_planes,
+    dconv_patch_gl_kernel) against the in-kernel split of the same layers: same split, same product order, so the
+    forward outputs and the input gradients are bit-identical (ragged image borders, column tiles hanging over
+    Cout, the lattice tail behind the whole rounds included)."""
+    from detmatch_amd import dense_conv
+    b, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wt = torch.nn.Parameter((torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev))
+    bias = torch.randn(cout, generator=g).to(dev)
+    dy = torch.randn(b, cout, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    res = []
+    prev = dense_conv.PLANES
+    try:
+        for planes in (True, False):
+            dense_conv.PLANES = planes
+            dense_conv._PACK_CACHE.clear()
+            xg = x.clone().requires_grad_(True)
+            y = dense_conv.conv2d(xg, wt, bias, 1, 1, relu=True)
+            y.backward(dy)
+            res.append((y.detach().clone(), xg.grad.clone(), wt.grad.clone()))
+            wt.grad = None
+    finally:
+        dense_conv.PLANES = prev
+        dense_conv._PACK_CACHE.clear()
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)
