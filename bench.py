@@ -471,14 +471,16 @@ def main():
                     g['bytes'] += gg_bytes(P, ci, co, kvol, rows)
                     g['flops'] += 2.0 * P * ci * co
                     g['launches'] += 1
-            if per_w and len(wg) == len(per_w) * args.steps:
-                for j, r in enumerate(wg):
-                    ci, co, kvol, P, n_in, n_out = per_w[j % len(per_w)]
-                    g = by_dir.setdefault('wgrad', dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
-                    g['ms'] += r[7]
-                    g['bytes'] += wgrad_bytes(P, ci, co, kvol)
-                    g['flops'] += 2.0 * P * ci * co
-                    g['launches'] += 1
+            if per_w and wg:
+                # a record covers one layer (dm_spconv_wgrad) or all queued layers of a backward pass
+                # (dm_spconv_wgrad_batch); every traced layer of a step is inside exactly one of them, so the
+                # group is the steps' records against the traced layers' algorithmic bytes
+                g = by_dir.setdefault('wgrad', dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
+                g['ms'] += sum(r[7] for r in wg)
+                g['launches'] += len(wg)
+                for ci, co, kvol, P, n_in, n_out in per_w:
+                    g['bytes'] += wgrad_bytes(P, ci, co, kvol) * args.steps
+                    g['flops'] += 2.0 * P * ci * co * args.steps
 
             def rates(g):
                 sec = g['ms'] * 1e-3

@@ -22,6 +22,12 @@ ci = ctypes.c_int
 sz = ctypes.c_size_t
 cf = ctypes.c_float
 
+class SpconvWgradJob(ctypes.Structure):
+    """dm_spconv_wgrad_job (include/detmatch_hip.h)"""
+    _fields_ = [('feat', vp), ('out_grad', vp), ('indice_pairs', vp), ('indice_num', vp), ('filt_grad', vp),
+                ('pair_stride', ci), ('kvol', ci), ('cin', ci), ('cout', ci)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/detmatch_hip.h declares
 SIGNATURES = {
     'dm_version': (ctypes.c_char_p, []),
@@ -47,6 +53,8 @@ SIGNATURES = {
     'dm_spconv_tile_order': (ci, [vp, ci, ci, vp, vp, sz, vp]),
     'dm_spconv_wgrad_workspace_bytes': (sz, [ci, ci, ci, ci]),
     'dm_spconv_wgrad': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
+    'dm_spconv_wgrad_batch_workspace_bytes': (sz, [ctypes.POINTER(SpconvWgradJob), ci]),
+    'dm_spconv_wgrad_batch': (ci, [ctypes.POINTER(SpconvWgradJob), ci, ci, vp, sz, vp]),
     'dm_iou3d_workspace_bytes': (sz, [ci, ci]),
     'dm_boxes_overlap_bev': (ci, [vp, ci, vp, ci, vp, vp, sz, vp]),
     'dm_boxes_overlap_bev_exact': (ci, [vp, ci, vp, ci, vp, vp]),

@@ -731,38 +731,20 @@ __global__ __launch_bounds__(64) void spconv_wgrad_partial(const float *__restri
 // (cin = VA*i + q, cout = VB*j + r), i.e. the channel order inside an MFMA is a permutation that
 // only the final store has to know.  Loads are unconditional (index clamped, X masked): a
 // conditional load makes hipcc branch and wait per element.
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict__ feat,
-                                                        const float *__restrict__ ograd,
-                                                        const int32_t *__restrict__ pairs,
-                                                        const int32_t *__restrict__ indice_num,
-                                                        int pair_stride, int chunk,
-                                                        float *__restrict__ slab, int nchunks, int kvol,
-                                                        int order) {
+template <int CIN, int COUT, bool CIN4 = false>      // CIN4: the rows of `feat` hold 4 channels (the input layer), padded with zeros to 16 here
+__device__ __forceinline__ void spconv_wgrad_rows_body(const float *__restrict__ feat,
+                                                       const float *__restrict__ ograd,
+                                                       const int32_t *__restrict__ pairs,
+                                                       const int32_t *__restrict__ indice_num,
+                                                       int pair_stride, int chunk,
+                                                       float *__restrict__ slab, int kvol, int k, int ch,
+                                                       float *tile) {
   constexpr int VA = CIN / 16, VB = COUT / 16;
   typedef float vecA __attribute__((ext_vector_type(VA)));
   typedef float vecB __attribute__((ext_vector_type(VB)));
   // a workgroup = 4 waves = one chunk of pairs, a quarter each; their partial tiles are summed
-  // through LDS in wave order (deterministic) and written once: 4x less slab traffic per pair.
-  // Chunks beyond this offset's pair count exit at once and are never read by the reduce kernel.
-  __shared__ float tile[CIN * COUT];
-  // (chunk, offset) of this workgroup.  order 0: chunks fastest; 1: offsets fastest (workgroups that run
-  // at the same time read the same stretch of rows); 2: offsets fastest AND all offsets of a chunk on one XCD
-  // (workgroup ids go round-robin over the 8 XCDs, each with its own L2)
-  int k, ch;
-  {
-    const int id = blockIdx.x;
-    if (order == 0) {
-      ch = id % nchunks, k = id / nchunks;
-    } else if (order == 1) {
-      k = id % kvol, ch = id / kvol;
-    } else {
-      const int xcd = id & 7, slot = id >> 3;
-      k = slot % kvol;
-      ch = xcd + 8 * (slot / kvol);
-      if (ch >= nchunks) return;
-    }
-  }
+  // through LDS (`tile`, CIN * COUT floats) in wave order (deterministic) and written once: 4x less slab
+  // traffic per pair.  Chunks beyond this offset's pair count exit at once and are never read by the reduce.
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
   const int npairs = indice_num[k];
@@ -803,7 +785,13 @@ __global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict
     for (int u = 0; u < U; ++u) {
       const int i0 = ii[buf][u], o0 = oo[buf][u];
       ok[buf][u] = inr[buf][u] & (i0 >= 0) & (o0 >= 0);
-      a[buf][u] = *(const vecA *)(feat + (size_t)(i0 >= 0 ? i0 : 0) * CIN + VA * j);
+      if constexpr (CIN4) {
+        static_assert(CIN == 16, "the 4-channel layer rides on the 16-row tile");
+        a[buf][u] = (vecA)(feat[(size_t)(i0 >= 0 ? i0 : 0) * 4 + (j & 3)]);
+        ok[buf][u] = ok[buf][u] & (j < 4);
+      } else {
+        a[buf][u] = *(const vecA *)(feat + (size_t)(i0 >= 0 ? i0 : 0) * CIN + VA * j);
+      }
       b[buf][u] = *(const vecB *)(ograd + (size_t)(o0 >= 0 ? o0 : 0) * COUT + VB * j);
     }
   };
@@ -853,6 +841,118 @@ __global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict
   float *dst = slab + ((size_t)ch * kvol + k) * (size_t)CIN * COUT;
   for (int e = threadIdx.x * 4; e < CIN * COUT; e += 1024)
     *(float4 *)(dst + e) = *(const float4 *)(tile + e);
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_wgrad_rows(const float *__restrict__ feat,
+                                                        const float *__restrict__ ograd,
+                                                        const int32_t *__restrict__ pairs,
+                                                        const int32_t *__restrict__ indice_num,
+                                                        int pair_stride, int chunk,
+                                                        float *__restrict__ slab, int nchunks, int kvol,
+                                                        int order) {
+  __shared__ float tile[CIN * COUT];
+  // (chunk, offset) of this workgroup.  order 0: chunks fastest; 1: offsets fastest (workgroups that run
+  // at the same time read the same stretch of rows); 2: offsets fastest AND all offsets of a chunk on one XCD
+  // (workgroup ids go round-robin over the 8 XCDs, each with its own L2)
+  int k, ch;
+  {
+    const int id = blockIdx.x;
+    if (order == 0) {
+      ch = id % nchunks, k = id / nchunks;
+    } else if (order == 1) {
+      k = id % kvol, ch = id / kvol;
+    } else {
+      const int xcd = id & 7, slot = id >> 3;
+      k = slot % kvol;
+      ch = xcd + 8 * (slot / kvol);
+      if (ch >= nchunks) return;
+    }
+  }
+  spconv_wgrad_rows_body<CIN, COUT>(feat, ograd, pairs, indice_num, pair_stride, chunk, slab, kvol, k, ch, tile);
+}
+
+// ---- the weight gradients of a whole backward pass in ONE launch pair --------------------------------------
+// A layer's weight gradient needs its saved input rows and the gradient of its output rows — both exist once
+// the input-gradient chain has passed the layer, and nothing downstream reads dW.  So the caller queues the
+// layers of a backward pass (spconv/ops.py: deferred weight gradients) and hands all of them over at its end:
+// one grid over every (layer, kernel offset, chunk of pairs) unit, one reduce over every weight element.  The
+// small layers (<= 90 k pairs: two launches of ~10 us each whatever they move) ride along underneath the big
+// ones, and 22 launches per pass become 2.
+#define DM_WGRAD_MAX_JOBS 16
+struct WgradBatch {
+  const float *feat[DM_WGRAD_MAX_JOBS], *ograd[DM_WGRAD_MAX_JOBS];
+  const int32_t *pairs[DM_WGRAD_MAX_JOBS], *indice_num[DM_WGRAD_MAX_JOBS];
+  float *filt_grad[DM_WGRAD_MAX_JOBS];
+  unsigned long long slab_off[DM_WGRAD_MAX_JOBS];      // floats
+  int pair_stride[DM_WGRAD_MAX_JOBS], kvol[DM_WGRAD_MAX_JOBS], cin[DM_WGRAD_MAX_JOBS], cout[DM_WGRAD_MAX_JOBS];
+  int cin_rows[DM_WGRAD_MAX_JOBS];                     // channels the layer really has (4 for the input layer, else cin)
+  int chunk[DM_WGRAD_MAX_JOBS], nchunks[DM_WGRAD_MAX_JOBS];
+  int unit_base[DM_WGRAD_MAX_JOBS + 1];                // workgroups of the rows kernel
+  int red_base[DM_WGRAD_MAX_JOBS + 1];                 // 256-thread blocks of the reduce kernel
+  int n;
+};
+
+// One instantiation per REGISTER CLASS of the layer bodies (64 ... 404 VGPRs from 16 -> 16 to 64 -> 128): a kernel
+// that switched over all of them would run every layer at the occupancy of the widest (measured: 1.4x slower
+// than the per-layer launches).  Class 0: Cin, Cout <= 32 (and the 4-channel input layer on the 16-row tile),
+// 1: 32 -> 64, 2: 64 -> 64, 3: 64 -> 128.
+__host__ __device__ inline int wgrad_class(int cin, int cout) {
+  const int key = cin * 1000 + cout;
+  if (key == 16016 || key == 16032 || key == 32032) return 0;
+  if (key == 32064) return 1;
+  if (key == 64064) return 2;
+  if (key == 64128) return 3;
+  return -1;
+}
+
+template <int CLS>
+__global__ __launch_bounds__(256) void spconv_wgrad_batch_rows(const WgradBatch t, float *__restrict__ slab) {
+  constexpr int TILE = CLS == 0 ? 32 * 32 : (CLS == 1 ? 32 * 64 : (CLS == 2 ? 64 * 64 : 64 * 128));
+  __shared__ float tile[TILE];
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.unit_base[j + 1]) ++j;
+  const int id = blockIdx.x - t.unit_base[j];
+  const int kvol = t.kvol[j];
+  const int k = id % kvol, ch = id / kvol;            // offsets fastest (see spconv_wgrad_rows)
+  float *sl = slab + t.slab_off[j];
+#define DM_WB(CI, CO, C4)                                                                                    \
+  spconv_wgrad_rows_body<CI, CO, C4>(t.feat[j], t.ograd[j], t.pairs[j], t.indice_num[j], t.pair_stride[j],  \
+                                     t.chunk[j], sl, kvol, k, ch, tile)
+  if constexpr (CLS == 0) {
+    const int key = t.cin[j] * 1000 + t.cout[j];
+    if (key == 16016) {
+      if (t.cin_rows[j] == 4) DM_WB(16, 16, true);
+      else DM_WB(16, 16, false);
+    } else if (key == 16032) DM_WB(16, 32, false);
+    else DM_WB(32, 32, false);
+  } else if constexpr (CLS == 1) {
+    DM_WB(32, 64, false);
+  } else if constexpr (CLS == 2) {
+    DM_WB(64, 64, false);
+  } else {
+    DM_WB(64, 128, false);
+  }
+#undef DM_WB
+}
+
+__global__ __launch_bounds__(256) void spconv_wgrad_batch_reduce(const WgradBatch t, const float *__restrict__ slab,
+                                                                 int accumulate) {
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.red_base[j + 1]) ++j;
+  const int cin = t.cin[j], cout = t.cout[j], rows = t.cin_rows[j];
+  const size_t per_offset = (size_t)cin * cout, per_chunk = per_offset * t.kvol[j];
+  const size_t e = (size_t)(blockIdx.x - t.red_base[j]) * 256 + threadIdx.x;
+  if (e >= per_chunk) return;
+  const int k = (int)(e / per_offset);
+  const int c = (int)(e % per_offset) / cout, nn = (int)(e % cout);
+  if (c >= rows) return;                               // padding rows of the 4-channel layer's tile
+  const int n = (t.indice_num[j][k] + t.chunk[j] - 1) / t.chunk[j];
+  const float *sl = slab + t.slab_off[j];
+  float s = 0.f;
+  for (int cc = 0; cc < n; ++cc) s += sl[(size_t)cc * per_chunk + e];
+  float *o = t.filt_grad[j] + ((size_t)k * rows + c) * cout + nn;
+  *o = accumulate ? *o + s : s;
 }
 
 __global__ __launch_bounds__(256) void spconv_wgrad_reduce(const float *slab, int nchunks,
@@ -1039,8 +1139,10 @@ extern "C" int dm_spconv_pack_rows(const int32_t *nbr, int n_rows, int kvol, int
 // tuning aid: -1 auto, 0 force the LDS-staged kernel, 1 force the register-weights kernel
 extern "C" int dm_spconv_set_wgrad_chunk(int pairs) {
   if (pairs < 0) {                 // -1 - order: developer switch for the workgroup map
-    g_wgrad_order = -1 - pairs;
-    return g_wgrad_order <= 2 ? DM_OK : DM_ERR_INVALID_ARG;
+    const int order = -1 - pairs;
+    if (order > 2) return DM_ERR_INVALID_ARG;      // validated BEFORE it is stored
+    g_wgrad_order = order;
+    return DM_OK;
   }
   if (pairs != 0 && (pairs < 64 || pairs % 64)) return DM_ERR_INVALID_ARG;
   g_wgrad_chunk = pairs;
@@ -1138,7 +1240,7 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
   dim3 grid(nchunks, dm_ceil_div(cin, 16), kvol);
   int pi = dm_prof_begin(st, DM_PROF_SPCONV_WGRAD, cin, cout, 1, pair_stride, kvol, indice_pairs);
   bool rows_kernel = true;
-  const int n_wg = g_wgrad_order == 2 ? 8 * dm_ceil_div(nchunks, 8) * kvol : nchunks * kvol;
+  const int n_wg = g_wgrad_order >= 2 ? 8 * dm_ceil_div(nchunks, 8) * kvol : nchunks * kvol;
 #define DM_WGRAD_ROWS(CI, CO)                                                                   \
   spconv_wgrad_rows<CI, CO><<<n_wg, 256, 0, st>>>(feat, out_grad, indice_pairs, indice_num,    \
                                                   pair_stride, chunk, slab, nchunks, kvol, g_wgrad_order)
@@ -1177,5 +1279,83 @@ extern "C" int dm_spconv_wgrad(const float *feat, const float *out_grad,
                                                                                 per_chunk, filt_grad);
   dm_prof_end(pi, st);
   DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+static bool wgrad_batchable(int cin, int cout) { return (cin == 4 && cout == 16) || wgrad_class(cin, cout) >= 0; }
+
+// one job = the arguments of dm_spconv_wgrad (include/detmatch_hip.h: dm_spconv_wgrad_job)
+extern "C" size_t dm_spconv_wgrad_batch_workspace_bytes(const dm_spconv_wgrad_job *jobs, int n_jobs) {
+  if (!jobs || n_jobs <= 0) return 0;
+  size_t total = 0, single = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const int cin = jobs[i].cin == 4 ? 16 : jobs[i].cin;      // the 4-channel layer's tiles are 16 rows high
+    const size_t b = dm_spconv_wgrad_workspace_bytes(jobs[i].pair_stride, jobs[i].kvol, cin, jobs[i].cout);
+    if (wgrad_batchable(jobs[i].cin, jobs[i].cout)) total += b;
+    else single = b > single ? b : single;
+  }
+  return total + single;
+}
+
+extern "C" int dm_spconv_wgrad_batch(const dm_spconv_wgrad_job *jobs, int n_jobs, int accumulate,
+                                     void *workspace, size_t workspace_bytes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_jobs <= 0) return DM_OK;
+  if (!jobs || !workspace) return DM_ERR_INVALID_ARG;
+  if (workspace_bytes < dm_spconv_wgrad_batch_workspace_bytes(jobs, n_jobs)) return DM_ERR_WORKSPACE;
+  WgradBatch all, cls[4];
+  all.n = 0;
+  all.red_base[0] = 0;
+  for (int c = 0; c < 4; ++c) cls[c].n = 0, cls[c].unit_base[0] = 0;
+  size_t off = 0;      // floats
+  long long P = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const dm_spconv_wgrad_job &jb = jobs[i];
+    if (jb.kvol <= 0 || jb.pair_stride < 0 || !jb.filt_grad) return DM_ERR_INVALID_ARG;
+    if (!wgrad_batchable(jb.cin, jb.cout) || jb.pair_stride == 0) continue;
+    if (!jb.feat || !jb.out_grad || !jb.indice_pairs || !jb.indice_num) return DM_ERR_INVALID_ARG;
+    if (all.n == DM_WGRAD_MAX_JOBS) return DM_ERR_INVALID_ARG;
+    const int cin = jb.cin == 4 ? 16 : jb.cin;
+    int chunk;
+    const int nchunks = wgrad_chunks(jb.pair_stride, &chunk, true);
+    WgradBatch *tabs[2] = {&all, &cls[wgrad_class(cin, jb.cout)]};
+    for (WgradBatch *t : tabs) {
+      const int j = t->n++;
+      t->feat[j] = jb.feat, t->ograd[j] = jb.out_grad, t->pairs[j] = jb.indice_pairs, t->indice_num[j] = jb.indice_num;
+      t->filt_grad[j] = jb.filt_grad;
+      t->pair_stride[j] = jb.pair_stride, t->kvol[j] = jb.kvol, t->cin[j] = cin, t->cout[j] = jb.cout;
+      t->cin_rows[j] = jb.cin;
+      t->chunk[j] = chunk, t->nchunks[j] = nchunks;
+      t->slab_off[j] = off;
+    }
+    WgradBatch &tc = cls[wgrad_class(cin, jb.cout)];
+    tc.unit_base[tc.n] = tc.unit_base[tc.n - 1] + nchunks * jb.kvol;
+    all.red_base[all.n] = all.red_base[all.n - 1] + dm_ceil_div((long long)jb.kvol * cin * jb.cout, 256);
+    off += dm_spconv_wgrad_workspace_bytes(jb.pair_stride, jb.kvol, cin, jb.cout) / sizeof(float);
+    P += (long long)jb.pair_stride * jb.kvol;
+  }
+  if (all.n > 0) {
+    int pi = dm_prof_begin(st, DM_PROF_SPCONV_WGRAD, -all.n, 0, 1, (int)(P > 0x7fffffffLL ? 0x7fffffffLL : P), 0, all.pairs[0]);
+    float *slab = (float *)workspace;
+    if (cls[0].n) spconv_wgrad_batch_rows<0><<<cls[0].unit_base[cls[0].n], 256, 0, st>>>(cls[0], slab);
+    if (cls[1].n) spconv_wgrad_batch_rows<1><<<cls[1].unit_base[cls[1].n], 256, 0, st>>>(cls[1], slab);
+    if (cls[2].n) spconv_wgrad_batch_rows<2><<<cls[2].unit_base[cls[2].n], 256, 0, st>>>(cls[2], slab);
+    if (cls[3].n) spconv_wgrad_batch_rows<3><<<cls[3].unit_base[cls[3].n], 256, 0, st>>>(cls[3], slab);
+    DM_CHECK_LAUNCH();
+    spconv_wgrad_batch_reduce<<<all.red_base[all.n], 256, 0, st>>>(all, slab, accumulate);
+    dm_prof_end(pi, st);
+    DM_CHECK_LAUNCH();
+  }
+  // layers outside the batched channel pairs, and empty ones: one by one
+  char *single_ws = (char *)workspace + off * sizeof(float);
+  for (int i = 0; i < n_jobs; ++i) {
+    const dm_spconv_wgrad_job &jb = jobs[i];
+    if (wgrad_batchable(jb.cin, jb.cout) && jb.pair_stride != 0) continue;
+    if (accumulate) return DM_ERR_UNSUPPORTED;      // (the caller adds such a layer's gradient itself)
+    const int rc = dm_spconv_wgrad(jb.feat, jb.out_grad, jb.indice_pairs, jb.indice_num, jb.pair_stride, jb.kvol,
+                                   jb.cin, jb.cout, jb.filt_grad, single_ws, workspace_bytes - off * sizeof(float),
+                                   stream);
+    if (rc != DM_OK) return rc;
+  }
   return DM_OK;
 }

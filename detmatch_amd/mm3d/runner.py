@@ -365,7 +365,9 @@ class OptimizerHook(Hook):
         else:
             runner.optimizer.zero_grad()
         if runner.outputs['loss'].requires_grad:     # else: every term was back-propagated inside train_step
-            runner.outputs['loss'].backward()
+            from ..spconv.ops import deferred_weight_grads
+            with deferred_weight_grads():      # the pass's sparse weight gradients in one launch pair
+                runner.outputs['loss'].backward()
         deferred = getattr(_inner(runner.model), 'finish_deferred_backward', None)
         if deferred is not None:      # e.g. the shared 2D trunk of SSL: its backward runs once, after all the heads'
             deferred()

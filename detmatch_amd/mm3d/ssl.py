@@ -656,7 +656,9 @@ class SSL(nn.Module):
         for group, cur in collapsed.items():
             d[group] = cur
         if terms:
-            sum(terms).backward()
+            from ..spconv.ops import deferred_weight_grads
+            with deferred_weight_grads():      # the pass's sparse weight gradients in one launch pair
+                sum(terms).backward()
             hook = getattr(self, 'after_partial_backward', None)
             if hook is not None:      # e.g. FlatGradDDP.collect: batched adds into the flat arena
                 hook()
@@ -777,7 +779,9 @@ class SSL(nn.Module):
             sup = self._collapse_losses(dict(lab_dict['sup_losses']))
             terms = [v for k, v in sup.items() if 'loss' in k and v.requires_grad]
             if terms:
-                sum(terms).backward()
+                from ..spconv.ops import deferred_weight_grads
+                with deferred_weight_grads():
+                    sum(terms).backward()
                 hook = getattr(self, 'after_partial_backward', None)
                 if hook is not None:      # e.g. FlatGradDDP.collect
                     hook()

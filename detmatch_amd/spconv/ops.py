@@ -294,9 +294,103 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     return _gather_gemm(features, filters, nbr_out, int(num_activate_out), cin, cout, 0, 0)
 
 
+# ---- weight gradients of a backward pass in one launch pair (csrc/spconv.hip: dm_spconv_wgrad_batch) ------------
+# Inside `with deferred_weight_grads():` the sparse-conv Functions hand their weight gradient to a queue instead of
+# computing it: (saved input rows, output-row gradient, rulebook, the weight Parameter).  Leaving the context — on
+# the thread that called backward(), after it has returned — flushes the queue: one rows launch + one reduce for
+# all queued layers, results added straight into the parameters' .grad (allocated when absent).  Values are those
+# of the per-layer calls (same chunks, same fixed-order sums).  The drivers that own a backward pass wrap it
+# (SSL's early backward passes, OptimizerHook); a plain loss.backward() outside the context computes every weight
+# gradient inside the pass as before.
+WGRAD_BATCH = os.environ.get('DM_SPCONV_WGRAD_BATCH', '1') == '1'
+_WGRAD_QUEUE = []
+_WGRAD_DEPTH = [0]
+WGRAD_BATCHES = [0]      # flushes so far (tests)
+
+
+class deferred_weight_grads(object):
+    def __enter__(self):
+        _WGRAD_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _WGRAD_DEPTH[0] -= 1
+        if _WGRAD_DEPTH[0] == 0:
+            if exc[0] is None:
+                _flush_weight_grads()
+            else:
+                del _WGRAD_QUEUE[:]
+        return False
+
+
+def defer_weight_grad(features, weight, out_bp, indice_pairs, indice_pair_num):
+    """True: the layer's weight gradient was queued (the caller returns None for it)."""
+    if not WGRAD_BATCH or _WGRAD_DEPTH[0] == 0 or features.dtype != torch.float32 or weight.dtype != torch.float32 or \
+            not isinstance(weight, torch.nn.Parameter) or not weight.is_contiguous() or not features.is_cuda or \
+            getattr(weight, '_post_accumulate_grad_hooks', None):
+        # (a parameter somebody watches with a post-accumulate hook — FlatGradDDP in hooks mode — gets its
+        # gradient inside the pass, where the hook expects it)
+        return False
+    cin, cout = weight.shape[-2], weight.shape[-1]
+    if (cin, cout) not in ((4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128)) or indice_pairs.shape[2] == 0:
+        return False
+    if LAUNCH_TRACE_W is not None:
+        LAUNCH_TRACE_W.append((cin, cout, int(indice_pairs.shape[0]), int(indice_pair_num.sum().item()),
+                               int(features.shape[0]), int(out_bp.shape[0])))
+    _WGRAD_QUEUE.append((features.contiguous(), weight, out_bp.contiguous(), indice_pairs, indice_pair_num,
+                         torch.cuda.current_stream(features.device)))
+    return True
+
+
+def _flush_weight_grads():
+    jobs = list(_WGRAD_QUEUE)
+    del _WGRAD_QUEUE[:]
+    if not jobs:
+        return
+    L = _lib.lib()
+    dev = jobs[0][0].device
+    # on the stream the pass's sparse layers ran on (the torch Stream object recorded at queue time — NOT an
+    # ExternalStream around its raw handle: the caching allocator files allocations made under such a wrapper of
+    # the default stream under a different stream id, and their blocks are then recycled out of stream order)
+    with torch.no_grad(), torch.cuda.stream(jobs[0][5]):
+        parts, seen = [[], []], set()
+        for j in jobs:          # a weight queued twice (two passes in one backward): its second job adds to the first one's result
+            first = j[1].grad is None and id(j[1]) not in seen
+            seen.add(id(j[1]))
+            parts[0 if first else 1].append(j)
+        for accumulate, part in enumerate(parts):
+            for lo in range(0, len(part), 16):
+                chunk = part[lo:lo + 16]
+                arr = (_lib.SpconvWgradJob * len(chunk))()
+                outs = []
+                for a, (feat, w, dy, pairs, num, _) in zip(arr, chunk):
+                    if accumulate:
+                        tgt = w.grad if w.grad.is_contiguous() else None
+                        out = tgt if tgt is not None else torch.empty_like(w)
+                    else:
+                        tgt, out = None, torch.empty_like(w)
+                    outs.append((w, out, tgt))
+                    kvol, _, stride = pairs.shape
+                    a.feat, a.out_grad, a.indice_pairs, a.indice_num = feat.data_ptr(), dy.data_ptr(), pairs.data_ptr(), num.data_ptr()
+                    a.filt_grad = out.data_ptr()
+                    a.pair_stride, a.kvol, a.cin, a.cout = int(stride), int(kvol), int(w.shape[-2]), int(w.shape[-1])
+                acc_all = bool(accumulate) and all(t is not None for _, _, t in outs)
+                ws = _lib.workspace(L.dm_spconv_wgrad_batch_workspace_bytes(arr, len(chunk)), dev, 'wgrad_batch')
+                _lib.check(L.dm_spconv_wgrad_batch(arr, len(chunk), int(acc_all), _lib.ptr(ws), ws.numel(),
+                                                   _lib.stream()), 'dm_spconv_wgrad_batch')
+                for w, out, tgt in outs:
+                    if w.grad is None:
+                        w.grad = out
+                    elif not acc_all:
+                        w.grad.add_(out)
+        WGRAD_BATCHES[0] += 1
+
+
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num,
-                         inverse=False, subm=False, need_input_grad=True):
-    """ops.py:142-158 / spconv_ops.h:363-456 -> [input_bp, filters_bp]."""
+                         inverse=False, subm=False, need_input_grad=True, defer_weight=None):
+    """ops.py:142-158 / spconv_ops.h:363-456 -> [input_bp, filters_bp].  defer_weight: the weight Parameter when
+    the caller is an autograd Function inside a backward pass — the weight gradient may then be queued for the
+    pass's batched launch (defer_weight_grad) and filters_bp comes back as None."""
     if inverse:
         raise NotImplementedError('inverse sparse conv is off the DetMatch hot path')
     features = features.contiguous()
@@ -312,6 +406,8 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     if need_input_grad:
         _, nbr_in = _tables_for(indice_pairs, indice_pair_num, n_in, n_out, subm)
         input_bp = _gather_gemm(out_bp, filters, nbr_in, n_in, cin, cout, 1, 1 if subm else 0)
+    if defer_weight is not None and defer_weight_grad(features, defer_weight, out_bp, indice_pairs, indice_pair_num):
+        return input_bp, None
     half = features.dtype if features.dtype != torch.float32 else None
     if half is not None:
         # indice_conv_backward_half: the weight gradient accumulates over all pairs — computed by the fp32

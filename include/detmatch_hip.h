@@ -235,6 +235,24 @@ int dm_spconv_tile_order(const int32_t *nbr /*(kvol, n_rows)*/, int n_rows, int 
 /* filt_grad[k] = sum_s feat[pairs[k][0][s],:]^T (x) out_grad[pairs[k][1][s],:]
  * (spconv_ops.h:436-441).  Deterministic two-stage reduction (partial slabs in
  * the workspace, then a fixed-order sum) — no float atomics. */
+/* The weight gradients of SEVERAL layers (a whole backward pass of the sparse backbone: every layer's inputs exist
+ * once the input-gradient chain has passed it) in one launch pair: one grid over all (layer, offset, chunk of
+ * pairs) units + one reduce over all weight elements, instead of two launches per layer (spconv_ops.h:363-456 runs
+ * per layer and per offset).  A job holds the arguments of dm_spconv_wgrad; accumulate != 0: filt_grad += (the
+ * caller's gradient buffer already holds an earlier pass); layers outside the batched channel pairs run through
+ * dm_spconv_wgrad inside the call (not with accumulate).  Launches: one rows kernel per register class of the
+ * layers present (Cin, Cout <= 32 incl. the 4-channel input layer | 32 -> 64 | 64 -> 64 | 64 -> 128) + one reduce.
+ * At most 16 batched jobs per call; results are bit-identical to dm_spconv_wgrad's (same chunks, same fixed-order
+ * sums) except for the 4-channel layer, which rides on the 16-row tile here (equal to fp32 rounding). */
+typedef struct dm_spconv_wgrad_job {
+  const float *feat, *out_grad;
+  const int32_t *indice_pairs, *indice_num;
+  float *filt_grad;
+  int pair_stride, kvol, cin, cout;
+} dm_spconv_wgrad_job;
+size_t dm_spconv_wgrad_batch_workspace_bytes(const dm_spconv_wgrad_job *jobs, int n_jobs);
+int dm_spconv_wgrad_batch(const dm_spconv_wgrad_job *jobs, int n_jobs, int accumulate, void *workspace,
+                          size_t workspace_bytes, dm_stream_t stream);
 size_t dm_spconv_wgrad_workspace_bytes(int n_in, int kvol, int cin, int cout);
 int dm_spconv_wgrad(const float *feat, const float *out_grad,
                     const int32_t *indice_pairs /*(kvol,2,pair_stride)*/,

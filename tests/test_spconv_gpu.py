@@ -336,6 +336,54 @@ def test_autograd_through_modules(orc, dev):
                                rtol=1e-3, atol=1e-3)
 
 
+def test_batched_weight_gradients_equal_per_layer_calls(dev, monkeypatch):
+    """The weight gradients of a backward pass delivered by ONE dm_spconv_wgrad_batch call at the end of the pass
+    (queued by the autograd Functions inside `deferred_weight_grads()`, flushed when the context is left) are bit-identical to the
+    per-layer dm_spconv_wgrad results — first pass (gradients absent), second pass (accumulated in place), the
+    4-channel input layer (rides on the 16-row tile) and a layer watched by a post-accumulate hook (never deferred:
+    the hook must find the gradient) included."""
+    from detmatch_amd import spconv
+    from detmatch_amd.spconv import ops
+    rng = np.random.default_rng(5)
+    shape = [12, 48, 48]
+    idx = _rand_indices(rng, 6000, 2, shape)
+    feats = torch.from_numpy(rng.standard_normal((6000, 4)).astype(np.float32)).to(dev)
+    torch.manual_seed(3)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(4, 16, 3, padding=1, bias=False, indice_key='s1'), torch.nn.ReLU(),
+        spconv.SubMConv3d(16, 16, 3, padding=1, bias=False, indice_key='s1'), torch.nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key='c2'), torch.nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key='s2'), torch.nn.ReLU(),
+        spconv.SparseConv3d(32, 64, 3, stride=2, padding=1, bias=False, indice_key='c3'), torch.nn.ReLU(),
+        spconv.SubMConv3d(64, 64, 3, padding=1, bias=False, indice_key='s3'),
+        spconv.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), padding=0, bias=False, indice_key='d'),
+    ).to(dev)
+    fired = []
+    net[4].weight.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+    res = {}
+    for batch in (False, True):
+        monkeypatch.setattr(ops, 'WGRAD_BATCH', batch)
+        for p in net.parameters():
+            p.grad = None
+        before = ops.WGRAD_BATCHES[0]
+        snaps = []
+        for rep in range(2):          # the second pass accumulates into the first one's gradients
+            x = spconv.SparseConvTensor(feats * (rep + 1), torch.from_numpy(idx).to(dev), shape, 2)
+            y = net(x).features
+            with ops.deferred_weight_grads():
+                (y * y).sum().backward()
+            snaps.append([p.grad.clone() for p in net.parameters()])
+        res[batch] = snaps
+        assert ops.WGRAD_BATCHES[0] - before == (2 if batch else 0)
+    for sa, sb in zip(res[False], res[True]):
+        for i, (a, b) in enumerate(zip(sa, sb)):
+            if i == 0:      # 4 -> 16: the per-layer call uses another kernel (one wave per 16-channel block, other chunks)
+                torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6 * float(a.abs().max()))
+            else:
+                assert torch.equal(a, b), i
+    assert len(fired) == 4
+
+
 @pytest.mark.parametrize('subm', [True, False])
 def test_tile_launch_order(orc, dev, subm, monkeypatch):
     """dm_spconv_tile_order: a permutation of the 16-row tiles by descending number of active kernel
