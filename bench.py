@@ -398,6 +398,13 @@ def main():
         if n != args.gpus:
             raise SystemExit('bench.py: %d of %d ranks joined' % (n, args.gpus))
         return
+    if world > 1 and os.environ.get('DM_PIN_THREADS', '1') == '1' and hasattr(os, 'sched_setaffinity'):
+        # the iteration is issued by one Python thread + the autograd thread per rank: give every rank its own
+        # slice of the host cores (before anything touches the GPU: the runtime's helper threads inherit it)
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if per >= 2:
+            os.sched_setaffinity(0, cores[local_rank * per:(local_rank + 1) * per])
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
     # test hooks: several ranks on ONE GPU over gloo (validates the N>1 control flow on a 1-GPU box)
     if os.environ.get('DM_FORCE_DEVICE') is not None:
@@ -440,10 +447,21 @@ def main():
     dt = time.perf_counter() - t0
     recs = _lib.profile_records()
     _lib.lib().dm_profile_enable(0)
+    sync_check = None
     if world > 1:
+        from detmatch_amd.mm3d.parallel import all_reduce as dm_all_reduce
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dm_all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if os.environ.get('DM_BENCH_CHECK_SYNC'):
+            # data parallel by construction: after the same number of steps every rank holds the same student
+            # (gradients are averaged, optimizers are deterministic) and the same EMA teacher
+            flat = torch.cat([p.detach().reshape(-1).float() for p in wl.model.parameters()])
+            hi, lo = flat.clone(), flat.clone()
+            dm_all_reduce(hi, op=dist.ReduceOp.MAX)
+            dm_all_reduce(lo, op=dist.ReduceOp.MIN)
+            sync_check = dict(max_abs_diff_between_ranks=float((hi - lo).abs().max()), n_values=int(flat.numel()),
+                              finite=bool(torch.isfinite(flat).all()))
 
     # one extra untimed step with the launch trace on — on EVERY rank (a step contains the gradient
     # and log all-reduces; a rank stepping alone would dead-lock the others)
@@ -535,6 +553,10 @@ def main():
               for k, vals in lb.items() if 'metrics.' in k}
         if pl:
             out['config']['pseudo_labels_per_step'] = pl
+        if sync_check is not None:
+            out['param_sync'] = sync_check
+        out['last_loss'] = float(wl.runner.outputs['loss'].detach()) if getattr(wl, 'runner', None) is not None and \
+            getattr(wl.runner, 'outputs', None) else None
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl.frames, gpu_stage_pieces(wl.frames, dev))
         print(json.dumps(out))

@@ -1045,6 +1045,8 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const int32_t *__restri
 
 // rows per tile of the register-weights gather-GEMM the launcher will pick (g_gg_variant)
 static int gr_tile_rows() { return g_gg_variant == 2 ? 32 : 16; }
+// (spconv16.hip launches 16-row tiles only: an order built for 32-row tiles must not reach it)
+int dm_spconv_tile_order_rows(void) { return gr_tile_rows(); }
 
 extern "C" size_t dm_spconv_tile_order_workspace_bytes(void) { return dm_align(66 * sizeof(int)); }
 

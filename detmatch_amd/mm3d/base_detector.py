@@ -25,7 +25,8 @@ class DetectorStepMixin(object):
         keys = list(log_vars.keys())
         packed = torch.stack([log_vars[k].detach().float() for k in keys])
         if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(packed)
+            from .parallel import all_reduce
+            all_reduce(packed)
             packed = packed / dist.get_world_size()
         return loss, {k: packed[i] for i, k in enumerate(keys)}
 

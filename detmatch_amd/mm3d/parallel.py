@@ -46,6 +46,38 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def _host_staged(group=None):
+    """True when the process group cannot take device tensors (gloo on this image): collectives on device tensors
+    are then staged through host copies — the TEST path that runs several ranks on one GPU (bench.py:
+    DM_FORCE_DEVICE + DM_DIST_BACKEND=gloo, tests/test_multirank_gpu.py); RCCL takes the device tensors as they are."""
+    return dist.is_initialized() and dist.get_backend(group) == 'gloo'
+
+
+class _Done(object):
+    def wait(self):
+        return True
+
+
+def all_reduce(t, group=None, async_op=False, op=None):
+    """dist.all_reduce for device tensors under either backend (see _host_staged)."""
+    kw = {} if op is None else dict(op=op)
+    if t.is_cuda and _host_staged(group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=group, **kw)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, group=group, async_op=async_op, **kw)
+
+
+def broadcast(t, src, group=None):
+    if t.is_cuda and _host_staged(group):
+        h = t.detach().cpu()
+        dist.broadcast(h, src, group=group)
+        t.copy_(h)
+        return
+    dist.broadcast(t, src, group=group)
+
+
 class FlatGradDDP(nn.Module):
 
     def __init__(self, module, params=None, bucket_bytes=64 << 20, process_group=None,
@@ -156,7 +188,7 @@ class FlatGradDDP(nn.Module):
                 if not ts:
                     continue
                 flat = torch.cat([t.reshape(-1) for t in ts])
-                dist.broadcast(flat, src, group=self.group)
+                broadcast(flat, src, group=self.group)
                 off = 0
                 for t in ts:
                     t.copy_(flat[off:off + t.numel()].view_as(t))
@@ -234,7 +266,7 @@ class FlatGradDDP(nn.Module):
             dist.reduce_scatter_tensor(sh, buf, group=self.group, async_op=True)
             self._pending.append(dist.all_gather_into_tensor(buf, sh, group=self.group, async_op=True))
         else:
-            self._pending.append(dist.all_reduce(buf, group=self.group, async_op=True))
+            self._pending.append(all_reduce(buf, group=self.group, async_op=True))
 
     def _launch_ready(self, limit):
         """Issue buckets strictly in index order while the next one is complete."""

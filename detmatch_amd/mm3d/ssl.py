@@ -522,7 +522,8 @@ class SSL(nn.Module):
         keys = list(log_vars.keys())
         packed = torch.stack([log_vars[k].detach().float() for k in keys])
         if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(packed)
+            from .parallel import all_reduce
+            all_reduce(packed)
             packed = packed / dist.get_world_size()
         # kept on the device: the logger calls .item() when (and if) it prints
         return loss, {k: packed[i] for i, k in enumerate(keys)}

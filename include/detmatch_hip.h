@@ -708,6 +708,11 @@ int dm_dconv_pack(const float *src, float *dst, const float *scale_n, const floa
  * bf16 numbers (together their 24 significand bits) and the six cross products of weight >= 2^-16 are
  * accumulated in fp32 — more accurate against float64 than mode 0 (tools/probe_bf16_split.py) at 3/8 of its
  * matrix-pipe time; layers with Cin % 32 != 0 or Cout <= 32 use mode 0.
+ * Range of mode 2 (tests/test_dense_conv_gpu.py: max-error and non-finite tests): full fp32-class precision for
+ * finite operands with 2^-109 <= |x| <= 3.38e38 (below, the lowest — then the middle — bf16 plane underflows and
+ * up to 16 of the 24 significand bits of THAT operand are dropped; above bf16's largest finite value 3.3895e38
+ * the high plane rounds to infinity).  +-inf / NaN operands make the same output elements non-finite as in mode 0,
+ * but an infinite operand yields NaN where mode 0 yields +-inf (inf splits into inf + NaN + NaN).
  * Process-wide; dm_dconv_wgrad follows the mode for layers with more than 64 channels on both sides. */
 int dm_dconv_set_math(int mode);
 int dm_dconv_get_math(void);

@@ -397,3 +397,101 @@ def test_planes_weights_are_bit_identical(dev, shape):
         dense_conv._PACK_CACHE.clear()
     for a, b_ in zip(*res):
         assert torch.equal(a, b_)
+
+
+def _both_modes(dev, x, w, gy, s, p):
+    """(forward, input gradient, weight gradient) of the convolution in the native fp32 and in the split arithmetic."""
+    from detmatch_amd import dense_conv
+    out = {}
+    prev = dense_conv.get_math()
+    try:
+        for mode in ('fp32_mfma', 'fp32_split'):
+            dense_conv.set_math(mode)
+            dense_conv._PACK_CACHE.clear()
+            xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            wd = torch.nn.Parameter(w.to(dev))
+            y = dense_conv.conv2d(xd, wd, None, s, p)
+            y.backward(gy.to(dev))
+            out[mode] = [t.detach().cpu().double() for t in (y, xd.grad, wd.grad)]
+    finally:
+        dense_conv.set_math(prev)
+        dense_conv._PACK_CACHE.clear()
+    return out
+
+
+_ADVERSARIAL = [((2, 128, 24, 32), 128, 3, 1, 1), ((2, 256, 20, 24), 64, 1, 1, 0), ((1, 64, 33, 40), 128, 3, 2, 1)]
+
+
+@pytest.mark.parametrize('shape', _ADVERSARIAL, ids=['3x3 patch', '1x1', '3x3 s2'])
+@pytest.mark.parametrize('kind', ['exponent spread 2^30', 'powers of two', 'tiny (FLT_MIN * 2^17 ...)'])
+def test_fp32_split_max_error_on_adversarial_inputs(dev, shape, kind):
+    """MAXIMUM error (not rms) of the split arithmetic against float64, element by element, in units of the natural
+    scale of each output S = sum_k |x_k| |w_k| (what an fp32 accumulation of K products is measured against):
+      * inputs whose magnitudes spread over 2^30 (per element random exponent in [-15, 15]);
+      * exact powers of two (the split is exact: m = l = 0; only the fp32 accumulation rounds);
+      * inputs just above the range where the LOWEST plane would underflow (|x| in FLT_MIN * [2^17, 2^20]): all three
+        planes are normal numbers there, so full precision is kept (include/detmatch_hip.h states the range below it).
+    The bound: the split's worst element is within 4 fp32 ulps (4 * 2^-24) of S per sqrt(K) accumulated products —
+    and never worse than 1.5x the worst element of the matrix pipe's own fp32 instruction on the same inputs."""
+    xs, cout, k, s, p = shape
+    g = torch.Generator().manual_seed(77)
+    K = xs[1] * k * k
+    if kind.startswith('exponent'):
+        x = torch.randn(xs, generator=g) * torch.exp2(torch.randint(-15, 16, xs, generator=g).float())
+        w = torch.randn(cout, xs[1], k, k, generator=g) * torch.exp2(torch.randint(-15, 16, (cout, xs[1], k, k), generator=g).float())
+    elif kind.startswith('powers'):
+        x = torch.exp2(torch.randint(-8, 9, xs, generator=g).float()) * (torch.randint(0, 2, xs, generator=g).float() * 2 - 1)
+        w = torch.exp2(torch.randint(-8, 9, (cout, xs[1], k, k), generator=g).float()) * \
+            (torch.randint(0, 2, (cout, xs[1], k, k), generator=g).float() * 2 - 1)
+    else:
+        tiny = float(np.float32(1.17549435e-38)) * 2.0 ** 17
+        x = (torch.rand(xs, generator=g) * 7 + 1) * tiny * (torch.randint(0, 2, xs, generator=g).float() * 2 - 1)
+        w = torch.randn(cout, xs[1], k, k, generator=g)
+    F = torch.nn.functional
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, s, p)
+    gy = torch.randn(y64.shape, generator=g)
+    y64.backward(gy.double())
+    # natural scales: the same three contractions of the absolute values
+    xa, wa = x.double().abs().requires_grad_(True), w.double().abs().requires_grad_(True)
+    ya = F.conv2d(xa, wa, None, s, p)
+    ya.backward(gy.double().abs())
+    scales = (ya.detach(), xa.grad, wa.grad)
+    refs = (y64.detach(), x64.grad, w64.grad)
+    depth = (K, cout * k * k, xs[0] * y64.shape[2] * y64.shape[3])      # products accumulated per output element
+    res = _both_modes(dev, x, w, gy, s, p)
+    ulp = 2.0 ** -24
+    for i, what in enumerate(('forward', 'input gradient', 'weight gradient')):
+        sc = scales[i].clamp_min(1e-300)
+        e_split = float(((res['fp32_split'][i] - refs[i]).abs() / sc).max())
+        e_mfma = float(((res['fp32_mfma'][i] - refs[i]).abs() / sc).max())
+        bound = 4 * ulp * depth[i] ** 0.5
+        assert e_split <= bound, (what, kind, e_split, bound, e_mfma)
+        assert e_split <= 1.5 * e_mfma + ulp, (what, kind, e_split, e_mfma)
+
+
+@pytest.mark.parametrize('shape', _ADVERSARIAL, ids=['3x3 patch', '1x1', '3x3 s2'])
+def test_fp32_split_non_finite_inputs_stay_non_finite(dev, shape):
+    """+-inf and NaN in the input: every output element the native fp32 instruction makes non-finite is non-finite
+    in the split arithmetic too, and every other element is finite and equal to the clean result (an infinite x
+    splits into h = inf, m = l = NaN, so the split answers NaN where the fp32 instruction answers +-inf: which kind
+    of non-finite value is NOT preserved — include/detmatch_hip.h says so)."""
+    xs, cout, k, s, p = shape
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(xs, generator=g)
+    w = torch.randn(cout, xs[1], k, k, generator=g) / (xs[1] * k * k) ** 0.5
+    gy = torch.randn((xs[0], cout, (xs[2] + 2 * p - k) // s + 1, (xs[3] + 2 * p - k) // s + 1), generator=g)
+    clean = _both_modes(dev, x, w, gy, s, p)
+    xb = x.clone()
+    xb[0, 3, 5, 7] = float('inf')
+    xb[0, 9, 11, 2] = float('-inf')
+    xb[xs[0] - 1, 1, 2, 3] = float('nan')
+    bad = _both_modes(dev, xb, w, gy, s, p)
+    for i, what in enumerate(('forward', 'weight gradient')):
+        j = 0 if i == 0 else 2                   # (the input gradient does not read x)
+        nf_mfma = ~torch.isfinite(bad['fp32_mfma'][j])
+        nf_split = ~torch.isfinite(bad['fp32_split'][j])
+        assert nf_mfma.any()
+        assert torch.equal(nf_mfma, nf_split), what
+        ok = ~nf_split
+        torch.testing.assert_close(bad['fp32_split'][j][ok], clean['fp32_split'][j][ok], rtol=0, atol=0)

@@ -1,0 +1,33 @@
+"""The REAL DetMatch step with world size 2 on one GPU: `bench.py --gpus 2` as a fresh child process, both ranks on
+cuda:0 (DM_FORCE_DEVICE=0), gloo process group (RCCL refuses two ranks on one device; device tensors of the
+collectives are staged through the host, mm3d/parallel.py:_host_staged).  Everything that exists per rank runs
+together for the first time here: look-ahead geometry, early backward passes, the deferred 2D trunk backward,
+bucket order of the gradient exchange, the log all-reduce, the fused optimizers — and the ranks must end with
+identical parameters."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('mode', ['collect', 'hooks'])
+def test_two_ranks_on_one_gpu_stay_in_sync(dev, mode):
+    env = dict(os.environ, DM_FORCE_DEVICE='0', DM_DIST_BACKEND='gloo', DM_BENCH_CHECK_SYNC='1', DM_GRAD_MODE=mode)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0
+    assert out['last_loss'] is not None and out['last_loss'] == out['last_loss'] and abs(out['last_loss']) < 1e9
+    ps = out['param_sync']
+    assert ps['finite'] and ps['n_values'] > 1e7
+    assert ps['max_abs_diff_between_ranks'] == 0.0, ps

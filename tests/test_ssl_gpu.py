@@ -254,6 +254,36 @@ def test_pretrain_recipes_run_through_epoch_based_runner(dev, recipe):
         assert g['lr'] != g['initial_lr'] and g['betas'][0] != 0.9      # cyclic schedules are live
 
 
+def test_baseline_config0_pretrain_pvrcnn_one_iteration_batch_one(dev):
+    """BASELINE.json configs[0]: configs/detmatch/001/pretrain_pvrcnn/split_0.py, ONE iteration at batch size 1 —
+    the reference's CPU-runnable plumbing case (voxelise + sparse backbone + losses).  The product has no CPU path
+    by design, so the same workload runs on the device: the loss and the clipped gradient norm are finite, the
+    gradient reaches every head and the first sparse layer, one optimizer step moves the weights, and the voxel
+    grid of the single frame equals the oracle's (the CPU restatement of the reference's voxeliser)."""
+    import oracle
+    from detmatch_amd import synth
+    from detmatch_amd.pcdet.workload import PretrainWorkload
+    wl = PretrainWorkload(1, dev, recipe='pretrain_pvrcnn', iters_per_epoch=1, max_epochs=1)
+    m = wl.model.model
+    first = m.backbone_3d.conv_input[0].weight
+    before = first.detach().clone()
+    wl.run()
+    r = wl.runner
+    assert r.iter == 1
+    log = {k: float(v[-1]) for k, v in r.log_buffer.items()}
+    assert np.isfinite(log['loss']) and log['loss'] > 0
+    assert np.isfinite(log['grad_norm']) and log['grad_norm'] > 0
+    for head in (m.dense_head, m.point_head, m.roi_head):      # every head took part: its parameters moved
+        assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in head.parameters()), type(head).__name__
+    assert not torch.equal(first.detach(), before)
+    # the frame's voxels against the oracle
+    pts = wl.loader[0]['points'][0]
+    ov, oc, on = oracle.hard_voxelize(pts.cpu().numpy(), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    from detmatch_amd import voxel
+    v, c, n, mean, counts = voxel.voxelize_batch([pts], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    assert np.array_equal(c[:, 1:].cpu().numpy(), oc) and np.array_equal(n.cpu().numpy(), on)
+
+
 def test_filter_by_nms_3d_multiclass(dev):
     """ssl_modules/bbox_utils.py:203-279 + core/post_processing/box3d_nms.py: per-class rotated BEV NMS;
     the kept set per class equals the oracle's greedy NMS on the same rotated rectangles, survivors keep
