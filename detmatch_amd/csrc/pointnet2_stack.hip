@@ -876,6 +876,131 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsSamples smp, int m,
   }
 }
 
+// ---- round 4: the same sampling with the per-round critical path cut to the arithmetic --------------------------
+// fps_kernel carries (distance, index) pairs through the scan (a compare + two selects per point), through twelve
+// ds_bpermute steps per wave and a second shuffle tree on wave 0, and fetches the winner's coordinates from global
+// memory behind three barriers: 3.3 us per round at KITTI size (20 k points), of which the arithmetic is a third.
+// Here a round reduces the VALUE only:
+//   * the scan updates two points per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: the same IEEE operations per
+//     element as dist2_fma) and keeps a running maximum with one v_max3 per pair: 4.5 instead of ~10 instructions
+//     per point;
+//   * the wave maximum is six DPP steps (no LDS), the workgroup maximum is one LDS exchange: every wave reads all
+//     eight wave maxima and reduces them itself — one barrier;
+//   * only then the winning INDEX is recovered: the threads whose maximum equals the workgroup's look up which of
+//     their points it was and compete with the reference's tie rule as a 64-bit key through one LDS atomic min
+//     (normally one thread takes part) — second barrier; everybody reads the key and fetches the winner's
+//     coordinates with a wave-uniform (scalar) load.
+// Same total order as fps_kernel / the reference (larger distance; bit-reversed stride class; smaller index), so
+// the indices are bit-identical (tests/test_ops_gpu.py).
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float fps_dpp_max(float v) {
+  const int o = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return fmaxf(v, __builtin_bit_cast(float, o));
+}
+// maximum over the wave, valid in lane 63 (row butterflies, then the last lane of each row broadcast downstream)
+__device__ __forceinline__ float fps_wave_max(float v) {
+  v = fps_dpp_max<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+  v = fps_dpp_max<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+  v = fps_dpp_max<0x141, 0xf>(v);    // row_half_mirror
+  v = fps_dpp_max<0x140, 0xf>(v);    // row_mirror: every lane of a row holds the row's maximum
+  v = fps_dpp_max<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+  v = fps_dpp_max<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_T) void fps_kernel2(FpsSamples smp, int m, const float *__restrict__ xyz,
+                                                     float *__restrict__ temp, int *__restrict__ idxs) {
+  static_assert(PPT % 2 == 0, "points are scanned in pairs");
+  constexpr int NW = FPS_T / 64;
+  __shared__ __attribute__((aligned(16))) float s_d[2][NW];
+  __shared__ unsigned long long s_key[3];
+  const int b = blockIdx.x;
+  const int n = smp.off[b + 1] - smp.off[b];
+  const float *data = xyz + (size_t)smp.off[b] * 3;
+  float *tmp = temp + (size_t)smp.off[b];
+  int *out = idxs + (size_t)b * m;
+  if (n <= 0) return;
+  int bs = 1;
+  while (bs * 2 <= n && bs < 1024) bs *= 2;
+  const unsigned bs_mask = (unsigned)(bs - 1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  fps_f2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], pt[PPT / 2];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * FPS_T;
+    const bool ok = k < n;
+    px[i / 2][i & 1] = ok ? data[(size_t)k * 3 + 0] : 0.f;
+    py[i / 2][i & 1] = ok ? data[(size_t)k * 3 + 1] : 0.f;
+    pz[i / 2][i & 1] = ok ? data[(size_t)k * 3 + 2] : 0.f;
+    pt[i / 2][i & 1] = ok ? tmp[k] : -1.f;      // padding: min(d, -1) = -1 never wins (real distances are >= 0)
+  }
+  if (tid == 0) {
+    out[0] = 0;
+    s_key[0] = s_key[1] = s_key[2] = ~0ull;
+  }
+  float x1 = data[0], y1 = data[1], z1 = data[2];
+  __syncthreads();
+  for (int j = 1; j < m; ++j) {
+    const fps_f2 vx = {x1, x1}, vy = {y1, y1}, vz = {z1, z1};
+    // distances are >= 0 (or the padding's -1): their bit patterns order like the values, so min / max run on
+    // the integer pipe's forms (no NaN canonicalisation: one v_min_i32 per point, one v_max3_i32 per pair)
+    int besti = __float_as_int(-1.f);
+#pragma unroll
+    for (int i = 0; i < PPT / 2; ++i) {
+      const fps_f2 dx = px[i] - vx, dy = py[i] - vy, dz = pz[i] - vz;
+      const fps_f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      const float d0 = d[0], d1 = d[1], p0 = pt[i][0], p1 = pt[i][1];     // (bit casts of vector ELEMENTS in place read element 0)
+      const int a0 = min(__float_as_int(d0), __float_as_int(p0));
+      const int a1 = min(__float_as_int(d1), __float_as_int(p1));
+      fps_f2 nv;
+      nv[0] = __int_as_float(a0);
+      nv[1] = __int_as_float(a1);
+      pt[i] = nv;
+      besti = max(besti, max(a0, a1));
+    }
+    const float best = __int_as_float(besti);
+    const float wbest = fps_wave_max(best);
+    const int buf = j & 1, kb = j % 3;
+    if (lane == 0) s_d[buf][wave] = wbest;
+    if (tid == 0) s_key[(j + 1) % 3] = ~0ull;       // the key slot of the NEXT round (last read two rounds ago)
+    __syncthreads();
+    const float4 a = *(const float4 *)&s_d[buf][0], c = *(const float4 *)&s_d[buf][4];
+    const float g = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)));
+    if (wbest == g) {                                // wave-uniform: normally one wave gets here
+      if (best == g) {
+        // which of this thread's points: among its own candidates (k = tid + 512 i) the stride class k & bs_mask
+        // differs only for block size 1024, where the odd slots' class has its lowest reversed bit set — they lose
+        // to the even slots; otherwise the smaller index wins.  Walked downwards: the last hit is the smallest.
+        int se = PPT, so = PPT;
+#pragma unroll
+        for (int i = PPT - 1; i >= 0; --i) {
+          const bool hit = pt[i / 2][i & 1] == g;
+          if (i & 1) so = hit ? i : so;
+          else se = hit ? i : se;
+        }
+        const int slot = bs_mask == 1023u ? (se < PPT ? se : so) : (se < so ? se : so);
+        const unsigned k = (unsigned)(tid + slot * FPS_T);
+        atomicMin(&s_key[kb], ((unsigned long long)__brev(k & bs_mask) << 32) | k);
+      }
+    }
+    __syncthreads();
+    const int k = __builtin_amdgcn_readfirstlane((int)(unsigned)(s_key[kb] & 0xffffffffull));
+    if (tid == 0) out[j] = k;
+    x1 = data[(size_t)k * 3 + 0];
+    y1 = data[(size_t)k * 3 + 1];
+    z1 = data[(size_t)k * 3 + 2];
+  }
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * FPS_T;
+    if (k < n) tmp[k] = pt[i / 2][i & 1];
+  }
+}
+
 // fallback for point counts whose per-thread share does not fit the register file:
 // the running minima live in `temp` (global), as in the reference
 __global__ __launch_bounds__(1024) void fps_kernel_global(FpsSamples smp, int m,
@@ -1263,7 +1388,7 @@ extern "C" int dm_group_rows_grad(int batch, int m, int c, int n, int nsample, i
   return DM_OK;
 }
 
-// tuning / test aid: 0 auto, 1 one workgroup per sample even for large clouds
+// tuning / test aid: 0 auto, 1 one workgroup per sample even for large clouds, 2 the pair-carrying one-workgroup kernel of rounds 1-3
 static int g_fps_variant = 0;
 
 extern "C" int dm_fps_set_variant(int v) {
@@ -1274,6 +1399,19 @@ extern "C" int dm_fps_set_variant(int v) {
 static int fps_launch(const FpsSamples &smp, int batch, int max_n, int m, const float *xyz,
                       float *temp, int *idxs, hipStream_t st) {
   int ppt = dm_ceil_div(max_n, FPS_T);
+  if (g_fps_variant != 2 && ppt <= 48) {       // (variant 2: the round-1..3 kernel, for A/B and the equality test)
+#define DM_FPS2(P) fps_kernel2<P><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs)
+    if (ppt <= 4) DM_FPS2(4);
+    else if (ppt <= 8) DM_FPS2(8);
+    else if (ppt <= 16) DM_FPS2(16);
+    else if (ppt <= 24) DM_FPS2(24);
+    else if (ppt <= 32) DM_FPS2(32);
+    else if (ppt <= 40) DM_FPS2(40);
+    else DM_FPS2(48);
+#undef DM_FPS2
+    DM_CHECK_LAUNCH();
+    return DM_OK;
+  }
   if (ppt <= 4) fps_kernel<4><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
   else if (ppt <= 8) fps_kernel<8><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
   else if (ppt <= 16) fps_kernel<16><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);

@@ -884,7 +884,9 @@ int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float 
 int dm_furthest_point_sampling_stack(int batch, const int *offsets_host, int m, const float *xyz,
                                      float *temp, int *idxs, dm_stream_t stream);
 /* Test / tuning aid: 0 (default) clouds beyond one workgroup's registers (> 24576 points) are sampled by
- * several co-operating workgroups per sample (same indices); 1 forces one workgroup per sample. */
+ * several co-operating workgroups per sample (same indices); 1 forces one workgroup per sample; 2 takes the
+ * one-workgroup kernel of rounds 1-3 (distance AND index carried through the reductions) instead of round 4's
+ * value-only reduction with packed arithmetic (same indices). */
 int dm_fps_set_variant(int variant);
 /* Replaces roiaware_pool3d_cuda.points_in_boxes_gpu (roiaware_pool3d.cpp:98-129,
  * roiaware_pool3d_kernel.cu:313-360).  box_idx (batch, pts_num): first containing box or -1
