@@ -148,6 +148,7 @@ SIGNATURES = {
     'dm_furthest_point_sampling': (ci, [ci, ci, ci, vp, vp, vp, vp]),
     'dm_furthest_point_sampling_stack': (ci, [ci, c_i32_p, ci, vp, vp, vp, vp]),
     'dm_fps_set_variant': (ci, [ci]),
+    'dm_voxel_centers': (ci, [vp, ci, ci, cf, cf, cf, cf, cf, cf, vp, vp, vp]),
     'dm_points_in_boxes': (ci, [ci, ci, ci, vp, vp, vp, vp]),
     'dm_profile_enable': (ci, [ci]),
     'dm_spconv_debug_stamps': (ci, [vp]),

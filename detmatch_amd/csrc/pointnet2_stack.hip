@@ -1388,6 +1388,48 @@ extern "C" int dm_group_rows_grad(int batch, int m, int c, int n, int nsample, i
   return DM_OK;
 }
 
+// ---- voxel centres + rows per sample of a sparse level (the set abstraction's xyz / xyz_batch_cnt) ----------------
+// common_utils.get_voxel_centers (pcdet/utils/common_utils.py:65-82: (idx[x,y,z] + 0.5) * voxel * stride +
+// range_min on the flipped coordinate columns — five element-wise launches) and the per-sample row counts
+// (voxel_set_abstraction.py:209-214 counts them with a Python loop of `.sum()` read-backs) in ONE launch: thread i
+// converts row i with the same fp32 operations in the same order (bit-identical); the first `batch` threads find
+// the row range of their sample by binary search in the batch column (rows of a sparse level are sample-major,
+// which the stacked operators behind it rely on anyway).
+__global__ __launch_bounds__(256) void voxel_centers_kernel(const int32_t *__restrict__ coords, int n, int batch,
+                                                            float vx, float vy, float vz, float rx, float ry, float rz,
+                                                            float *__restrict__ xyz, int32_t *__restrict__ counts) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int4 c = *(const int4 *)(coords + (size_t)i * 4);      // [b, z, y, x]
+    xyz[(size_t)i * 3 + 0] = ((float)c.w + 0.5f) * vx + rx;
+    xyz[(size_t)i * 3 + 1] = ((float)c.z + 0.5f) * vy + ry;
+    xyz[(size_t)i * 3 + 2] = ((float)c.y + 0.5f) * vz + rz;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < batch) {
+    auto lower = [&](int key) {      // first row whose sample index is >= key
+      int lo = 0, hi = n;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (coords[(size_t)mid * 4] < key) lo = mid + 1;
+        else hi = mid;
+      }
+      return lo;
+    };
+    const int b = threadIdx.x;
+    counts[b] = lower(b + 1) - lower(b);
+  }
+}
+
+extern "C" int dm_voxel_centers(const int32_t *coords, int n, int batch, float vx, float vy, float vz, float rx,
+                                float ry, float rz, float *xyz, int32_t *counts, dm_stream_t stream) {
+  if (n < 0 || batch <= 0 || batch > 256) return DM_ERR_INVALID_ARG;
+  if (!counts || (n > 0 && (!coords || !xyz))) return DM_ERR_INVALID_ARG;
+  voxel_centers_kernel<<<dm_ceil_div(n > 0 ? n : 1, 256), 256, 0, (hipStream_t)stream>>>(coords, n, batch, vx, vy, vz, rx, ry,
+                                                                                 rz, xyz, counts);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
 // tuning / test aid: 0 auto, 1 one workgroup per sample even for large clouds, 2 the pair-carrying one-workgroup kernel of rounds 1-3
 static int g_fps_variant = 0;
 

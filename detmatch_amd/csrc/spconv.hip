@@ -896,11 +896,11 @@ struct WgradBatch {
 // One instantiation per REGISTER CLASS of the layer bodies (64 ... 404 VGPRs from 16 -> 16 to 64 -> 128): a kernel
 // that switched over all of them would run every layer at the occupancy of the widest (measured: 1.4x slower
 // than the per-layer launches).  Class 0: Cin, Cout <= 32 (and the 4-channel input layer on the 16-row tile),
-// 1: 32 -> 64, 2: 64 -> 64, 3: 64 -> 128.
+// 2: 32 -> 64 and 64 -> 64, 3: 64 -> 128 (1: unused).
 __host__ __device__ inline int wgrad_class(int cin, int cout) {
   const int key = cin * 1000 + cout;
   if (key == 16016 || key == 16032 || key == 32032) return 0;
-  if (key == 32064) return 1;
+  if (key == 32064) return 2;      // (136 VGPRs: rides in the 64 -> 64 kernel's 248 for free)
   if (key == 64064) return 2;
   if (key == 64128) return 3;
   return -1;
@@ -929,7 +929,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_batch_rows(const WgradBatch 
   } else if constexpr (CLS == 1) {
     DM_WB(32, 64, false);
   } else if constexpr (CLS == 2) {
-    DM_WB(64, 64, false);
+    if (t.cin[j] == 32) DM_WB(32, 64, false);
+    else DM_WB(64, 64, false);
   } else {
     DM_WB(64, 128, false);
   }

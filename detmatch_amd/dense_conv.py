@@ -271,14 +271,24 @@ def forget(weights):
         reg.pop('tables', None)
 
 
+_PLAN_BY_ID = {}
+_FWD_GEOM = {}       # launch geometry of a forward convolution by its shape signature
 _PLAN_CACHE = {}     # (kind, geometry, taps) -> (ctypes geometry, ctypes taps, workspace bytes)
 
 
 def _plan(kind, geom, taps):
     """The marshalled argument arrays of one launch geometry (a network has a few dozen; building
     ctypes arrays per call costs more host time than the launch)."""
+    fast = (kind, id(geom), id(taps))       # cached geometry lists (_FWD_GEOM) are looked up by identity
+    hit = _PLAN_BY_ID.get(fast)
+    if hit is not None and hit[3] is geom and hit[4] is taps:
+        return hit[:3]
     key = (kind, tuple(geom), tuple(taps))
     hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        if len(_PLAN_BY_ID) > 8192:
+            _PLAN_BY_ID.clear()
+        _PLAN_BY_ID[fast] = hit + (geom, taps)
     if hit is None:
         L = _lib.lib()
         g = _lib.ints(geom)
@@ -337,19 +347,26 @@ class _Conv2dFn(torch.autograd.Function):
         (sh, sw), (ph, pw) = stride, padding
         x = _pad_channels(_cl(x.detach()), _pad4(cin))
         n, c4, h, w = x.shape
-        ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+        # geometry of the launch: a network has a few dozen distinct ones, rebuilt lists cost more than the launch
+        key = (n, c4, h, w, cout, kh, kw, sh, sw, ph, pw, relu)
+        hit = _FWD_GEOM.get(key)
+        if hit is None:
+            ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+            taps = [(a - ph, b - pw, a * kw + b) for a in range(kh) for b in range(kw)]
+            if len(_FWD_GEOM) > 4096:
+                _FWD_GEOM.clear()
+            hit = _FWD_GEOM[key] = (ho, wo, [n, h, w, c4, ho, wo, cout, ho, wo, 0, 0, 1, 1, sh, sw, kh * kw, int(relu)], taps)
+        ho, wo, geom, taps = hit
         T = kh * kw
         wp = _pack(weight, 'f', T, cout, c4, cout, cin, cin * T, T, 1, scale_n=w_scale,
                    planes=residual is None and _wants_planes(T, cout, c4, sh == 1 and sw == 1 and ho == h and wo == w))
         y = _empty_cl(n, cout, ho, wo, x)
-        taps = [(a - ph, b - pw, a * kw + b) for a in range(kh) for b in range(kw)]
         if residual is not None:
             residual = _cl(residual.detach())
             if tuple(residual.shape) != tuple(y.shape):
                 raise _lib.DetMatchHipError('dense_conv: residual %s does not match the output %s'
                                             % (tuple(residual.shape), tuple(y.shape)))
-        _gemm(x, wp, None if bias is None else bias.detach(), y,
-              [n, h, w, c4, ho, wo, cout, ho, wo, 0, 0, 1, 1, sh, sw, T, int(relu)], taps, residual)
+        _gemm(x, wp, None if bias is None else bias.detach(), y, geom, taps, residual)
         ctx.geom = (stride, padding, relu, (n, cin, h, w))
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, w_scale, y if relu else None)

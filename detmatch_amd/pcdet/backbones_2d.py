@@ -38,23 +38,33 @@ def _bn_relu_nhwc(x, bn):
 
 class _Stage(object):
     """One (convolution, BatchNorm) pair of a block, resolved from the Sequential slots once."""
-    __slots__ = ('conv', 'bn', 'padding')
+    __slots__ = ('conv', 'bn', 'padding', 'fold')
 
     def __init__(self, conv, bn, padding):
         self.conv, self.bn, self.padding = conv, bn, padding
+        self.fold = None      # (scale, shift) of the evaluation-mode BatchNorm, set per pass by fold_eval_stages
+
+    def folds(self, x):
+        bn = self.bn
+        return not isinstance(self.conv, nn.ConvTranspose2d) and not bn.training and bn.track_running_stats and \
+            self.conv.bias is None and x.is_cuda
 
     def __call__(self, x):
         conv, bn = self.conv, self.bn
         if isinstance(conv, nn.ConvTranspose2d):
             return _bn_relu_nhwc(dense_conv.conv_transpose2d(x, conv.weight, conv.stride), bn)
-        if not bn.training and bn.track_running_stats and conv.bias is None and x.is_cuda:
+        if self.folds(x):
             # evaluation mode (the EMA teacher): BatchNorm is the constant per-channel map
             # y*s + b with s = gamma / sqrt(var + eps), b = beta - mean*s — folded into the weight
             # packing (w_scale), the GEMM's bias and its ReLU epilogue: no BatchNorm kernel, no extra
             # pass over the feature map
-            with torch.no_grad():
-                s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-                b = bn.bias - bn.running_mean * s
+            if self.fold is not None:
+                s, b = self.fold
+                self.fold = None
+            else:
+                with torch.no_grad():
+                    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                    b = bn.bias - bn.running_mean * s
             return dense_conv.conv2d(x, conv.weight, b, conv.stride, self.padding, relu=True, w_scale=s)
         y = dense_conv.conv2d(x, conv.weight, conv.bias, conv.stride, self.padding)
         return _bn_relu_nhwc(y, bn)
@@ -116,9 +126,27 @@ class BaseBEVBackbone(nn.Module):
             self._stages = plan
         return plan
 
+    @staticmethod
+    def fold_eval_stages(stages, x):
+        """The (scale, shift) maps of all evaluation-mode stages of a pass with five multi-tensor launches instead of
+        five element-wise launches PER LAYER (the same operations per element: + eps, rsqrt, * gamma, * mean, beta -)."""
+        todo = [st for st in stages if st.folds(x)]
+        if len(todo) < 2 or len({st.bn.eps for st in todo}) != 1:
+            return
+        with torch.no_grad():
+            s = torch._foreach_add([st.bn.running_var for st in todo], todo[0].bn.eps)
+            torch._foreach_rsqrt_(s)
+            torch._foreach_mul_(s, [st.bn.weight for st in todo])
+            ms = torch._foreach_mul([st.bn.running_mean for st in todo], s)
+            b = torch._foreach_sub([st.bn.bias for st in todo], ms)
+        for st, si, bi in zip(todo, s, b):
+            st.fold = (si, bi)
+
     def _levels(self, x):
         """-> (spatial_features_2d, [(stride, feature map) per block])"""
         blocks, deblocks = self._plan()
+        if not self.training and not dense_conv.CAPTURING[0]:
+            self.fold_eval_stages([st for blk in blocks for st in blk], x)
         full = x.shape[2]
         branches, levels = [], []
         for lvl, block in enumerate(blocks):

@@ -241,7 +241,7 @@ int dm_spconv_tile_order(const int32_t *nbr /*(kvol, n_rows)*/, int n_rows, int 
  * per layer and per offset).  A job holds the arguments of dm_spconv_wgrad; accumulate != 0: filt_grad += (the
  * caller's gradient buffer already holds an earlier pass); layers outside the batched channel pairs run through
  * dm_spconv_wgrad inside the call (not with accumulate).  Launches: one rows kernel per register class of the
- * layers present (Cin, Cout <= 32 incl. the 4-channel input layer | 32 -> 64 | 64 -> 64 | 64 -> 128) + one reduce.
+ * layers present (Cin, Cout <= 32 incl. the 4-channel input layer | 32 -> 64 and 64 -> 64 | 64 -> 128) + one reduce.
  * At most 16 batched jobs per call; results are bit-identical to dm_spconv_wgrad's (same chunks, same fixed-order
  * sums) except for the 4-channel layer, which rides on the 16-row tile here (equal to fp32 rounding). */
 typedef struct dm_spconv_wgrad_job {
@@ -883,6 +883,11 @@ int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float 
  * in Python, voxel_set_abstraction.py:135-151). */
 int dm_furthest_point_sampling_stack(int batch, const int *offsets_host, int m, const float *xyz,
                                      float *temp, int *idxs, dm_stream_t stream);
+/* Voxel centres + rows per sample of a sparse level in one launch: xyz[i] = (coords[i][x,y,z] + 0.5) * v + r
+ * (pcdet/utils/common_utils.py:65-82 get_voxel_centers, the same fp32 operations in the same order), counts[b] =
+ * rows of sample b (voxel_set_abstraction.py:209-214; coords (n, 4) int32 [b, z, y, x], sample-major). */
+int dm_voxel_centers(const int32_t *coords, int n, int batch, float vx, float vy, float vz, float rx, float ry,
+                     float rz, float *xyz, int32_t *counts, dm_stream_t stream);
 /* Test / tuning aid: 0 (default) clouds beyond one workgroup's registers (> 24576 points) are sampled by
  * several co-operating workgroups per sample (same indices); 1 forces one workgroup per sample; 2 takes the
  * one-workgroup kernel of rounds 1-3 (distance AND index carried through the reductions) instead of round 4's

@@ -720,3 +720,22 @@ def test_batched_nms_equals_per_sample_calls(dev, kind):
     for b in range(bsz):
         k = int(num1[b])
         assert torch.equal(keep1[b, :k], keepb[b, :k])
+
+
+def test_voxel_centers_and_counts_kernel(dev):
+    """dm_voxel_centers: centres bit-identical to get_voxel_centers' tensor chain, rows per sample equal to the
+    counting formulation — ragged samples, an empty sample in the middle, strided level geometry."""
+    from detmatch_amd.pcdet import pfe
+    from detmatch_amd.pcdet.utils import get_voxel_centers
+    rng = np.random.default_rng(4)
+    sizes = [700, 0, 1301, 5]
+    coords = np.concatenate([np.concatenate([np.full((n, 1), b), rng.integers(0, [11, 400, 352], (n, 3))], 1)
+                             for b, n in enumerate(sizes)]).astype(np.int32)
+    c = torch.from_numpy(coords).to(dev)
+    for down in (1, 4):
+        xyz, cnt = pfe.voxel_centers_and_counts(c, len(sizes), down, [0.05, 0.05, 0.1], [0, -40, -3, 70.4, 40, 1])
+        want = get_voxel_centers(c[:, 1:4], downsample_times=down, voxel_size=[0.05, 0.05, 0.1],
+                                 point_cloud_range=[0, -40, -3, 70.4, 40, 1])
+        assert torch.equal(xyz, want.contiguous())
+        assert cnt.dtype == torch.int32 and cnt.cpu().tolist() == sizes
+    assert torch.equal(cnt, pfe.batch_row_counts(c[:, 0], len(sizes)))

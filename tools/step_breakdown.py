@@ -63,12 +63,37 @@ def main():
             cur_e = max(cur_e, e)
     busy += cur_e - cur_s
     print('steps=%d  wall %.1f ms/step  launches %.0f/step  sum of kernel time %.1f ms  union busy %.1f ms  idle %.1f ms'
-          % (steps, wall / 1e3, len(win) / steps, sum(cat_t.values()) / 1e3, busy / 1e3 / steps, (wall - busy / 1e3 / steps) / 1e3))
+          % (steps, wall / 1e3, len(win) / steps, sum(cat_t.values()) / 1e3, busy / 1e6 / steps, (wall - busy / 1e3 / steps) / 1e3))
     print('%-36s %10s %10s' % ('category', 'ms/step', 'launches'))
     for name, t in sorted(cat_t.items(), key=lambda kv: -kv[1]):
         print('%-36s %10.2f %10.0f' % (name, t / 1e3, cat_n[name] / steps))
     print('busy per (queue, stream): ' + ', '.join('%s/%s %.1f ms' % (q, st, t / 1e3) for (q, st), t in
                                                    sorted(per_q.items(), key=lambda kv: -kv[1])[:8]))
+    # the two phases of an iteration on the main queue: [optimizer of the previous step .. EMA] = the forward passes
+    # with their early backward passes; [EMA .. optimizer] = the final backward (deferred 2D trunk included)
+    opt = [i for i, r in enumerate(rows) if re.search(r'adamw', r[2])]
+    phases = {'forward + early backward': defaultdict(float), 'final backward': defaultdict(float)}
+    spans = {'forward + early backward': 0.0, 'final backward': 0.0}
+    n_ph = 0
+    for mi in marks[-(steps + 1):-1]:
+        prev_opt = max([o for o in opt if o < mi], default=None)
+        next_opt = min([o for o in opt if o > mi], default=None)
+        if prev_opt is None or next_opt is None:
+            continue
+        n_ph += 1
+        for name, lo_i, hi_i in (('forward + early backward', prev_opt, mi), ('final backward', mi, next_opt)):
+            spans[name] += (rows[hi_i][0] - rows[lo_i][0]) / 1e6
+            for s, e, n, q, st in rows[lo_i:hi_i]:
+                for cname, pat in CATS:
+                    if re.search(pat, n):
+                        break
+                else:
+                    cname = 'other own kernels'
+                phases[name][cname] += (e - s) / 1e6
+    if n_ph:
+        for name, d in phases.items():
+            print('%s: %.1f ms of wall per step; kernel ms: %s' % (name, spans[name] / n_ph, ', '.join(
+                '%s %.1f' % (k, v / n_ph) for k, v in sorted(d.items(), key=lambda kv: -kv[1])[:9])))
     edges = [(0, 2), (2, 5), (5, 10), (10, 20), (20, 50), (50, 100), (100, 500), (500, 10 ** 9)]
     print('idle gaps of the union (us): ' + ', '.join(
         '%s-%s: %d x = %.2f ms' % (lo_, hi_ if hi_ < 10 ** 9 else 'inf', sum(1 for g in gaps if lo_ * 1e3 <= g < hi_ * 1e3) / steps,
