@@ -1645,6 +1645,180 @@ __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__re
   }
 }
 
+// ---- 3 x 3 / stride 1 weight gradient with the nine taps in ONE workgroup ---------------------------------------
+// dconv_wgrad_bf16_kernel gives every tap its own workgroups: the same 16 pixels of dY and (shifted) X are fetched
+// from L2, split into planes and written to LDS nine times over, for 24 matrix instructions per wave and step.
+// Here a workgroup owns a 64 x 64 (dY channels x X channels) tile of ALL nine taps (nine 32 x 32 accumulators per
+// wave: 144 registers).  A step is 16 pixels of ONE image row, and a workgroup walks DOWN a column of such segments
+// (steps are numbered (image, segment column, row) with the row fastest): the three X rows a step needs — 18 pixels
+// each, one halo pixel either side — live in a ring of four row slots in the LDS, so each step fetches, splits and
+// stores ONE new X row (row + 2, for the step after next) and the next step's 16 dY pixels: 2.1 float4 per thread for
+// 54 matrix instructions per wave (1728 cycles), against 2 float4 per 24 instructions above.  The taps read their
+// B fragments from ring slot (row - 1 + t / 3) & 3 at pixel offset t % 3.  A run (the part of a column inside the
+// workgroup's step range) starts with three load-only iterations that fill the ring.
+// Same planes and transposing LDS reads (ds_read_tr16_b64) as the kernel above; pixel rows of 128 bytes (64 bf16
+// channels), the 64-byte halves swapped on every second row pair: the four pixel rows of a transposed read are
+// 128 bytes apart (two of them per 256-byte bank span) and a wave reads one 64-byte half of each — without the
+// swap rows r and r + 2 hit the same banks (measured: 3.5x on the whole kernel).
+__device__ __forceinline__ int wg9_off(int row, int chunk) {     // bytes inside one row slot; chunk = 16-byte piece
+  return 128 * row + 16 * (chunk ^ (((row >> 1) & 1) << 2));
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void dconv_wgrad9_kernel(const float *__restrict__ U, const float *__restrict__ V, float *__restrict__ part,
+                         const DWgradGeom g, int n_tiles_u, int n_tiles_v, int njt, int kt_total, int kt_chunk) {
+  constexpr int U_BUF = 16 * 128, V_SLOT = 18 * 128;         // one plane of one dY segment / of one X row
+  constexpr int U_PLANE = 2 * U_BUF, V_PLANE = 4 * V_SLOT;
+  constexpr int LDS_MAIN = 3 * (U_PLANE + V_PLANE);          // 39 KB
+  constexpr int LDS_EPI = 4 * 32 * 36 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI];
+  unsigned char *const ubase = lds, *const vbase = lds + 3 * U_PLANE;
+
+  const int tile = blockIdx.x;
+  const int vt = tile % n_tiles_v, ut = tile / n_tiles_v;
+  const int kt_lo = blockIdx.y * kt_chunk;
+  const int kt_hi = min(kt_total, kt_lo + kt_chunk);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wu = wave >> 1, wv = wave & 1;
+  const int u0 = ut * 64, v0 = vt * 64;
+  const int cq = tid & 15, pr = tid >> 4;                    // channel quad (4 channels), pixel 0..15 of the thread
+  const bool u_ok = u0 + cq * 4 < g.Cu, v_ok = v0 + cq * 4 < g.Cv;
+  const float *const Uc = U + (u_ok ? u0 + cq * 4 : 0), *const Vc = V + (v_ok ? v0 + cq * 4 : 0);
+  const int st_off = wg9_off(pr, cq >> 1) + 8 * (cq & 1);                  // where the thread's pixel goes in a slot
+  const int st_off2 = wg9_off(16 + (pr & 1), cq >> 1) + 8 * (cq & 1);      // threads 0..31: halo pixels 16, 17
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  float4 ru, rv, rv2;
+  bool ru_ok, rv_ok, rv2_ok;
+  // iteration r of a run over rows [i0, i1) of column (b, jt): dY row r + 1 and X row r + 2
+  auto gload = [&](int b, int jt, int r, int i0, int i1) {
+    const int ui = r + 1, j = jt * 16 + pr;
+    ru_ok = u_ok & (j < g.LW) & (ui >= i0) & (ui < i1);
+    ru = *(const float4 *)(Uc + (ru_ok ? ((size_t)(b * g.LH + ui) * g.LW + j) * g.Cu : 0));
+    const int iy = r + 2, ix = jt * 16 - 1 + pr;
+    const bool row_ok = v_ok & (iy >= 0) & (iy <= i1) & (iy < g.Hv);
+    rv_ok = row_ok & ((unsigned)ix < (unsigned)g.Wv);
+    rv = *(const float4 *)(Vc + (rv_ok ? ((size_t)(b * g.Hv + iy) * g.Wv + ix) * g.Cv : 0));
+    if (tid < 32) {
+      const int ix2 = jt * 16 + 15 + (pr & 1);
+      rv2_ok = row_ok & (ix2 < g.Wv);
+      rv2 = *(const float4 *)(Vc + (rv2_ok ? ((size_t)(b * g.Hv + iy) * g.Wv + ix2) * g.Cv : 0));
+    }
+  };
+  auto put = [&](unsigned char *dst, int plane_bytes, float4 a, bool ok) {
+    a.x = ok ? a.x : 0.0f, a.y = ok ? a.y : 0.0f, a.z = ok ? a.z : 0.0f, a.w = ok ? a.w : 0.0f;
+    uint2 h, m, l;
+    split_bf16x3(a, &h, &m, &l);
+    *(uint2 *)dst = h, *(uint2 *)(dst + plane_bytes) = m, *(uint2 *)(dst + 2 * plane_bytes) = l;
+  };
+  auto sstore = [&](int r) {
+    put(ubase + ((r + 1) & 1) * U_BUF + st_off, U_PLANE, ru, ru_ok);
+    unsigned char *vs = vbase + ((r + 2) & 3) * V_SLOT;
+    put(vs + st_off, V_PLANE, rv, rv_ok);
+    if (tid < 32) put(vs + st_off2, V_PLANE, rv2, rv2_ok);
+  };
+  // transposed fragment reads (see dconv_wgrad_bf16_kernel): lane 4q+p of a 16-lane group supplies row q, columns
+  // 4p..4p+3 of its 4 x 16 block; group = (8-pixel half, 16-channel half).  The lane's byte offsets inside a slot
+  // are loop constants (two row groups x three pixel offsets t % 3 — the swizzle depends on the row); the slot's
+  // own offset is a scalar that changes with the step.  The sum is formed by ONE instruction right before the reads
+  // that use it (inline asm: left to itself the compiler forms all 20 sums of a step ahead of time and spills).
+  const int grp = lane >> 4, li = lane & 15, fq = li >> 2, fp = li & 3;
+  const int cb = grp & 1, fh = grp >> 1;
+  auto lane_off = [&](int row0, int chan0, int rr) {
+    return wg9_off(row0 + 8 * fh + 4 * rr + fq, (chan0 + 16 * cb) / 8 + (fp >> 1)) + 8 * (fp & 1);
+  };
+  const unsigned lds0 = dm_lds_addr(lds);
+  unsigned ua[2], va[3][2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    ua[rr] = lds0 + lane_off(0, wu * 32, rr);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) va[dx][rr] = lds0 + 3 * U_PLANE + lane_off(dx, wv * 32, rr);
+  }
+  auto frag3 = [&](bf16x8 (&out)[3], const unsigned (&la)[2], unsigned slot_off, auto PLANE) {
+    constexpr int plane = decltype(PLANE)::value;
+    unsigned a0, a1;
+    asm volatile("v_add_u32 %0, %2, %3\n\tv_add_u32 %1, %2, %4" : "=&v"(a0), "=v"(a1) : "s"(slot_off), "v"(la[0]), "v"(la[1]));
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+      union { s16x4 s[2]; bf16x8 v; } u;
+      u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a0 + sp * plane));
+      u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a1 + sp * plane));
+      out[sp] = u.v;
+    }
+  };
+
+  int k = kt_lo;
+  while (k < kt_hi) {
+    const int col = k / g.LH, i0 = k - col * g.LH;
+    const int i1 = min(g.LH, i0 + (kt_hi - k));
+    const int b = col / njt, jt = col - b * njt;
+#pragma unroll 1
+    for (int r = i0 - 3; r < i0; ++r) {                       // fill the ring: X rows i0 - 1, i0, i0 + 1 and dY row i0
+      gload(b, jt, r, i0, i1);
+      sstore(r);
+      __syncthreads();
+    }
+#pragma unroll 1
+    for (int r = i0; r < i1; ++r) {
+#ifndef W9_PROBE_NOSTAGE
+      gload(b, jt, r, i0, i1);                                // travels underneath the products below
+#endif
+      {
+        bf16x8 af[3], bf[2][3];
+        frag3(af, ua, (unsigned)((r & 1) * U_BUF), std::integral_constant<int, U_PLANE>());
+        frag3(bf[0], va[0], (unsigned)(((r - 1) & 3) * V_SLOT), std::integral_constant<int, V_PLANE>());
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          // the next tap's fragments are on their way while this tap's six products run
+          if (t < 8)
+            frag3(bf[(t + 1) & 1], va[(t + 1) % 3], (unsigned)(((r - 1 + (t + 1) / 3) & 3) * V_SLOT),
+                  std::integral_constant<int, V_PLANE>());
+          const bf16x8 (&bt)[3] = bf[t & 1];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bt[0], acc[t], 0, 0, 0);      // smallest terms first
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bt[2], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bt[1], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bt[0], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bt[1], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bt[0], acc[t], 0, 0, 0);
+        }
+      }
+#ifndef W9_PROBE_NOSTAGE
+      sstore(r);
+#endif
+      __syncthreads();
+    }
+    k += i1 - i0;
+  }
+  // nine 32 x 32 tiles per wave, each through LDS into 16-byte stores (see dconv_gemm_kernel's epilogue)
+  constexpr int LDC = 36;
+  const int lr = lane & 31, lh = lane >> 5;
+  float *cs = (float *)lds + wave * 32 * LDC;
+  const int ccq = lane & 7, rr = lane >> 3;
+  const int vcol = v0 + wv * 32 + ccq * 4;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float *dst = part + ((size_t)blockIdx.y * 9 + t) * g.Cu * g.Cv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + lr] = acc[t][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = it * 8 + rr;
+      const int u = u0 + wu * 32 + rl;
+      if (u < g.Cu && vcol < g.Cv) *(float4 *)(dst + (size_t)u * g.Cv + vcol) = *(const float4 *)(cs + rl * LDC + ccq * 4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // out[u*su + v*sv + t*st] = scale_u[u] * sum_s part[s][t][u][v]   (v < Cv_out: drops channel padding)
 __global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(
     const float *__restrict__ part, float *__restrict__ out, const float *__restrict__ scale_u,
@@ -1843,6 +2017,7 @@ int launch_gemm(const float *x, const float *w, const float *bias, float *y, DCo
 int g_dconv_math = 0;
 int g_dconv_planes = 1;   // the patch kernel takes a layer's `planes` weight copy when the caller hands one (dm_dconv_gemm_planes)
 int g_dconv_patch = 1;    // math mode 2: 3 x 3 / stride-1 layers on dconv_patch_split_kernel (dm_dconv_set_math(2 + 16) turns it off)
+int g_dconv_wgrad9 = 1;      // math mode 2: 3 x 3 / stride-1 weight gradients on dconv_wgrad9_kernel (developer switch: dm_dconv_set_math(2 + 32) turns it off)
 
 // How many ways the reduction of a SMALL problem (fewer 64x64 tiles than half a round) is split.
 static int dconv_gemm_splits(const int *q) {
@@ -2068,13 +2243,42 @@ extern "C" int dm_dconv_set_math(int mode) {
     g_dconv_math = 2, g_dconv_patch = 0;
     return DM_OK;
   }
+  if (mode == 2 + 32) {       // developer switch: split arithmetic with one workgroup set per tap in the weight gradient (A/B)
+    g_dconv_math = 2, g_dconv_wgrad9 = 0;
+    return DM_OK;
+  }
   if (mode < 0 || mode > 2) return DM_ERR_INVALID_ARG;
   g_dconv_math = mode;
   g_dconv_patch = 1;
+  g_dconv_wgrad9 = 1;
   return DM_OK;
 }
 
 extern "C" int dm_dconv_get_math(void) { return g_dconv_math; }
+
+
+// the tap-fused kernel's decomposition: 64 x 64 tiles, steps = 16-pixel segments of image rows, split so that the
+// workgroups fill about one round of two per CU
+static bool dconv_wgrad9_plan(const int *q, const short *taps, int *njt, int *kt_total, int *ns) {
+  const int B = q[0], LH = q[1], LW = q[2], Cu = q[3], Cv = q[4], Hv = q[5], Wv = q[6], T = q[9];
+  if (T != 9 || q[7] != 1 || q[8] != 1 || Hv != LH || Wv != LW || Cu < 64 || Cv < 64 || LW < 8) return false;
+  if (taps)
+    for (int t = 0; t < 9; ++t)
+      if (taps[t] != t / 3 - 1 || taps[9 + t] != t % 3 - 1) return false;
+  *njt = dm_ceil_div(LW, 16);
+  const long long kt = (long long)B * LH * *njt;
+  if (kt > 0x7fffffffLL) return false;
+  *kt_total = (int)kt;
+  const long long tiles = (long long)dm_ceil_div(Cu, 64) * dm_ceil_div(Cv, 64);
+  long long want = 512 / tiles;
+  if (want > kt / 8) want = kt / 8;
+  if (want < 1) want = 1;
+  *ns = (int)want;
+  // short step ranges (small feature maps with many channel tiles) spend their time on the 9-tap partial sums and
+  // the ring fill: the per-tap kernel is faster there — except for 64-channel operands, whose per-tap tiles are small
+  if (kt / want < 24 && (Cu > 64 || Cv > 64)) return false;
+  return true;
+}
 
 static int dconv_wgrad_splits(long long M, int T, int Cu, int Cv) {
   // one full round of workgroups: 2 per CU for the 128x128 tile, 4 per CU for the 64x64 tile
@@ -2092,7 +2296,9 @@ static int dconv_wgrad_splits(long long M, int T, int Cu, int Cv) {
 extern "C" size_t dm_dconv_wgrad_workspace_bytes(const int *geom_host) {
   const int *q = geom_host;
   const long long M = (long long)q[0] * q[1] * q[2];
-  const int ns = dconv_wgrad_splits(M, q[9], q[3], q[4]);
+  int ns = dconv_wgrad_splits(M, q[9], q[3], q[4]);
+  int njt, ktt, ns9;
+  if (dconv_wgrad9_plan(q, nullptr, &njt, &ktt, &ns9) && ns9 > ns) ns = ns9;      // whichever kernel the mode picks
   return dm_align((size_t)ns * q[9] * q[3] * q[4] * sizeof(float));
 }
 
@@ -2113,13 +2319,28 @@ extern "C" int dm_dconv_wgrad(const float *U, const float *V, float *out, const 
   g.M = (int)M;
   if (workspace_bytes < dm_dconv_wgrad_workspace_bytes(geom_host) || !workspace)
     return DM_ERR_WORKSPACE;
-  const int ns = dconv_wgrad_splits(M, g.T, g.Cu, g.Cv);
+  int ns = dconv_wgrad_splits(M, g.T, g.Cu, g.Cv);
   g.chunk = (int)(((M + ns - 1) / ns + 31) / 32 * 32);
+  hipStream_t st = (hipStream_t)stream;
+  float *part = (float *)workspace;
+  {
+    int njt, ktt, ns9;
+    if (g_dconv_math == 2 && g_dconv_wgrad9 && dconv_wgrad9_plan(q, taps_host, &njt, &ktt, &ns9)) {
+      const int tu = dm_ceil_div(g.Cu, 64), tv = dm_ceil_div(g.Cv, 64);
+      const int chunk9 = dm_ceil_div(ktt, ns9);
+      ns = dm_ceil_div(ktt, chunk9);
+      dconv_wgrad9_kernel<<<dim3(tu * tv, ns), 256, 0, st>>>(U, V, part, g, tu, tv, njt, ktt, chunk9);
+      DM_CHECK_LAUNCH();
+      const long long total = (long long)g.T * g.Cu * g.Cv;
+      dconv_wgrad_reduce_kernel<<<dm_ceil_div(total, 256), 256, 0, st>>>(
+          part, out, scale_u, ns, g.T, g.Cu, g.Cv, Cv_out, su, sv, st_, accumulate);
+      DM_CHECK_LAUNCH();
+      return DM_OK;
+    }
+  }
   DConvTaps tt;
   for (int t = 0; t < DCONV_MAX_TAPS; ++t) tt.dy[t] = tt.dx[t] = tt.ws[t] = 0;
   for (int t = 0; t < g.T; ++t) tt.dy[t] = taps_host[t], tt.dx[t] = taps_host[g.T + t];
-  hipStream_t st = (hipStream_t)stream;
-  float *part = (float *)workspace;
   if (g.Cu <= 64 || g.Cv <= 64) {
     const int tu = dm_ceil_div(g.Cu, 64), tv = dm_ceil_div(g.Cv, 64);
     dconv_wgrad_kernel<64, 64, 32, 2, 2><<<dim3(g.T * tu * tv, ns), 256, 0, st>>>(U, V, part, g, tt,

@@ -30,7 +30,7 @@ _GENERATION = [0]
 _PACK_CACHE = {}
 
 
-_MATH = {'fp32_mfma': 0, 'bf16': 1, 'fp32_split': 2, 'fp32_split_nopatch': 18}
+_MATH = {'fp32_mfma': 0, 'bf16': 1, 'fp32_split': 2, 'fp32_split_nopatch': 18, 'fp32_split_tapwise_wgrad': 34}
 
 
 def set_math(mode):

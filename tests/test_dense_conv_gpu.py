@@ -495,3 +495,56 @@ def test_fp32_split_non_finite_inputs_stay_non_finite(dev, shape):
         assert torch.equal(nf_mfma, nf_split), what
         ok = ~nf_split
         torch.testing.assert_close(bad['fp32_split'][j][ok], clean['fp32_split'][j][ok], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('shape', [
+    ((2, 128, 24, 32), 128),      # two full 16-pixel segments per row
+    ((2, 64, 13, 25), 64),        # ragged last segment (25 = 16 + 9), odd height
+    ((1, 256, 9, 8), 128),        # rows shorter than one segment
+    ((3, 128, 7, 50), 72),        # dY channels not a multiple of 4 x 16; three images
+    ((2, 72, 20, 44), 256),       # X channels not a multiple of the tile
+], ids=['24x32', '13x25 ragged', '9x8 short', 'cout72', 'cin72'])
+def test_tap_fused_weight_gradient_equals_per_tap_kernel(dev, shape):
+    """3 x 3 / stride-1 weight gradients in the split arithmetic: dconv_wgrad9_kernel (all nine taps in one workgroup,
+    the 3 x 18-pixel halo of X staged once) against (a) the per-tap kernel on the same inputs — same six products per
+    term, another summation order over the pixels, so agreement to the fp32 accumulation error — and (b) float64.
+    Also: bit-for-bit run-to-run reproducibility and accumulation into an existing gradient."""
+    from detmatch_amd import dense_conv
+    xs, cout = shape
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(xs, generator=g)
+    w = torch.randn(cout, xs[1], 3, 3, generator=g) / (xs[1] * 9) ** 0.5
+    gy = torch.randn((xs[0], cout, xs[2], xs[3]), generator=g)
+    ref = F.conv2d(x.double(), w.double().requires_grad_(True), None, 1, 1)
+    w64 = torch.nn.Parameter(w.double())
+    F.conv2d(x.double(), w64, None, 1, 1).backward(gy.double())
+    wa = torch.nn.Parameter(w.double().abs())
+    F.conv2d(x.double().abs(), wa, None, 1, 1).backward(gy.double().abs())
+    scale = wa.grad.clamp_min(1e-300)
+    depth = xs[0] * xs[2] * xs[3]
+    prev = dense_conv.get_math()
+    got = {}
+    try:
+        for mode in ('fp32_split', 'fp32_split_tapwise_wgrad'):
+            dense_conv.set_math(mode)
+            dense_conv._PACK_CACHE.clear()
+            runs = []
+            for _ in range(2):
+                xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                wd = torch.nn.Parameter(w.to(dev))
+                dense_conv.conv2d(xd, wd, None, 1, 1).backward(gy.to(dev))
+                runs.append(wd.grad.clone())
+            assert torch.equal(runs[0], runs[1]), mode
+            # a second backward accumulates into the existing gradient (the kernel's accumulate path)
+            dense_conv.conv2d(xd, wd, None, 1, 1).backward(gy.to(dev))
+            torch.testing.assert_close(wd.grad, 2 * runs[0], rtol=1e-6, atol=1e-6)
+            got[mode] = runs[0].cpu().double()
+    finally:
+        dense_conv.set_math(prev)
+        dense_conv._PACK_CACHE.clear()
+    ulp = 2.0 ** -24
+    for mode, v in got.items():
+        err = float(((v - w64.grad).abs() / scale).max())
+        assert err <= 4 * ulp * depth ** 0.5, (mode, err)
+    d = float(((got['fp32_split'] - got['fp32_split_tapwise_wgrad']).abs() / scale).max())
+    assert d <= 4 * ulp * depth ** 0.5, d
