@@ -1660,6 +1660,9 @@ __global__ __launch_bounds__(256) void dconv_wgrad_bf16_kernel(const float *__re
 // channels), the 64-byte halves swapped on every second row pair: the four pixel rows of a transposed read are
 // 128 bytes apart (two of them per 256-byte bank span) and a wave reads one 64-byte half of each — without the
 // swap rows r and r + 2 hit the same banks (measured: 3.5x on the whole kernel).
+#ifndef W9_STORE_AT
+#define W9_STORE_AT 5
+#endif
 __device__ __forceinline__ int wg9_off(int row, int chunk) {     // bytes inside one row slot; chunk = 16-byte piece
   return 128 * row + 16 * (chunk ^ (((row >> 1) & 1) << 2));
 }
@@ -1786,11 +1789,13 @@ void dconv_wgrad9_kernel(const float *__restrict__ U, const float *__restrict__ 
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bt[0], acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bt[1], acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bt[0], acc[t], 0, 0, 0);
+#ifndef W9_PROBE_NOSTAGE
+          // the rows fetched at the top of the step have had W9_STORE_AT + 1 taps' worth of products to arrive; their
+          // split and LDS stores (slots this step does not read) issue underneath the remaining products
+          if (t == W9_STORE_AT) sstore(r);
+#endif
         }
       }
-#ifndef W9_PROBE_NOSTAGE
-      sstore(r);
-#endif
       __syncthreads();
     }
     k += i1 - i0;
