@@ -474,7 +474,12 @@ void dconv_gemm_bf16_kernel(
   if (mt >= n_tiles_m) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int kq = tid % KQ, r0 = tid / KQ;
+  // SPLIT == 3 (rows of 48 bytes, 8-byte plane stores banked mod 128 bytes per 16 contiguous lanes): four lanes store
+  // one row's 32 bytes, so a group of 16 lanes must take rows {r, r + 2, r + 4, r + 6} (offsets 0, 96, 64, 32 mod 128)
+  // — with rows {r .. r + 3} the fourth lands on the first two (a 2-way conflict on every store: one third of the
+  // kernel's LDS cycles by SQ_LDS_BANK_CONFLICT)
+  const int kq = tid % KQ, rj = tid / KQ;
+  const int r0 = SPLIT == 3 ? ((rj & ~7) | ((rj & 3) << 1) | ((rj >> 2) & 1)) : rj;
   const int m0 = m_lo + mt * BM, n0 = nt * BN;
 
   int a_iy[AP], a_ix[AP];
@@ -956,6 +961,23 @@ __global__ __launch_bounds__(WAVES_U *WAVES_V * 64) void dconv_wgrad_kernel(
 // are staged per (tap, block) as before, double-buffered, fetched two tiles ahead.
 // LDS: A 3 planes x 180 rows x 12 words (25.9 KB, single buffer: refreshed between channel blocks), B 2 buffers x 3
 // planes x BN rows x 12 words (36.9 KB at BN = 128): 62.8 KB, two workgroups per CU.
+// Which pixel of a 2 x 16 block the MFMA row i (= lane & 31 of the A operand) stands for.  ds_read_b128 serves a wave in
+// four NON-contiguous groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32); with the
+// plain map (i >> 4, i & 15) a group reads patch rows {0-3, 12-15, 22-29} + const of the 48-byte rows: rows 12/28 and
+// 13/29 are 16 rows = 768 bytes = 3 bank rows apart, a 2-way conflict on every A fragment read (SQ_LDS_BANK_CONFLICT
+// 35 % of the LDS cycles).  Here each group gets 16 rows that are distinct mod 16: 3 * row mod 16 then covers the
+// sixteen 16-byte slots of the 256-byte bank row once (checked for every tap shift).  The epilogue places row i at
+// the same pixel.
+__device__ __forceinline__ void dm_patch_pixel(int i, int *py, int *px) {
+  const int blk = i >> 2;                    // groups of four lanes move together
+  // blk:      0  1  2  3  4  5  6  7
+  // row:      0  0  0  0  1  1  1  1
+  // column:   0  8 12  4 14  6 10  2   (+ i & 3; blk 4: 14, 15, 0, 1)
+  const int col0 = (0x2A6E4C80u >> (4 * blk)) & 15;
+  *py = i >> 4;
+  *px = (col0 + (i & 3)) & 15;
+}
+
 template <int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restrict__ w,
@@ -992,7 +1014,9 @@ void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restri
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
     const int q = tid + 256 * p;
-    const int row = q >> 2, kq = q & 3;
+    const int rj = q >> 2, kq = q & 3;
+    // 16 contiguous lanes store rows {r, r + 2, r + 4, r + 6} of the 48-byte rows (see dconv_gemm_bf16_kernel)
+    const int row = rj < (PR & ~7) ? ((rj & ~7) | ((rj & 3) << 1) | ((rj >> 2) & 1)) : rj;
     const int py = row / PW, px = row % PW;
     const int iy = y0 - 1 + py, ix = x0 - 1 + px;
     const bool ok = (row < PR) & ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
@@ -1065,10 +1089,12 @@ void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restri
 #endif
   };
   // fragment addresses: MFMA tile a of this wave covers patch rows ROWS_W*wm + 2a, +1 (16 pixels each)
+  int apy, apx;
+  dm_patch_pixel(lr, &apy, &apx);
   int a_base[TM];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
-    a_base[a] = ((ROWS_W * wm + 2 * a + (lr >> 4) + 1) * PW + (lr & 15) + 1) * LDW + lh * 4;
+    a_base[a] = ((ROWS_W * wm + 2 * a + apy + 1) * PW + apx + 1) * LDW + lh * 4;
   const int b_base = (wn * WN + lr) * LDW + lh * 4;
 
   bf16x8 af[3][TM], bfr[3][TN];
@@ -1164,7 +1190,9 @@ void dconv_patch_split_kernel(const float *__restrict__ x, const float *__restri
 #pragma unroll
     for (int it = 0; it < WM / 8; ++it) {
       const int rl = it * 8 + rr;                       // pixel of the wave's tile: row rl / 16, column rl % 16
-      const int oy = y0 + ROWS_W * wm + (rl >> 4), ox = x0 + (rl & 15);
+      int epy, epx;
+      dm_patch_pixel(rl & 31, &epy, &epx);
+      const int oy = y0 + ROWS_W * wm + 2 * (rl >> 5) + epy, ox = x0 + epx;
       if (oy < g.LH && ox < g.LW && ncol < g.Cout) {
         const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
         float *dst = y + (((size_t)bimg * g.LH + oy) * g.LW + ox) * g.Cout + ncol;
@@ -1267,7 +1295,9 @@ void dconv_patch_gl_kernel(const float *__restrict__ x, const unsigned char *__r
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
     const int q = tid + 256 * p;
-    const int row = q >> 2, kq = q & 3;
+    const int rj = q >> 2, kq = q & 3;
+    // 16 contiguous lanes store rows {r, r + 2, r + 4, r + 6} of the 48-byte rows (see dconv_gemm_bf16_kernel)
+    const int row = rj < (PR & ~7) ? ((rj & ~7) | ((rj & 3) << 1) | ((rj >> 2) & 1)) : rj;
     const int py = row / PW, px = row % PW;
     const int iy = y0 - 1 + py, ix = x0 - 1 + px;
     const bool ok = (row < PR) & ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
@@ -1336,10 +1366,12 @@ void dconv_patch_gl_kernel(const float *__restrict__ x, const unsigned char *__r
       else dm_wait_vmcnt<keep * (PPW - 1)>();
     }
   };
+  int apy, apx;
+  dm_patch_pixel(lr, &apy, &apx);
   unsigned a_base[TM];        // byte addresses inside LDS
 #pragma unroll
   for (int a = 0; a < TM; ++a)
-    a_base[a] = dm_lds_addr(lds_a) + (((ROWS_W * wm + 2 * a + (lr >> 4) + 1) * PW + (lr & 15) + 1) * LDW + lh * 4) * 4u;
+    a_base[a] = dm_lds_addr(lds_a) + (((ROWS_W * wm + 2 * a + apy + 1) * PW + apx + 1) * LDW + lh * 4) * 4u;
   const unsigned b_base = dm_lds_addr(lds_b) + ((wn * TN * 3) * 256 + lane * 4) * 4u;
 
   f32x4v afr[3][TM], bfrr[3][TN];
@@ -1439,7 +1471,9 @@ void dconv_patch_gl_kernel(const float *__restrict__ x, const unsigned char *__r
 #pragma unroll
     for (int it = 0; it < WM / 8; ++it) {
       const int rl = it * 8 + rr;
-      const int oy = y0 + ROWS_W * wm + (rl >> 4), ox = x0 + (rl & 15);
+      int epy, epx;
+      dm_patch_pixel(rl & 31, &epy, &epx);
+      const int oy = y0 + ROWS_W * wm + 2 * (rl >> 5) + epy, ox = x0 + epx;
       if (oy < g.LH && ox < g.LW && ncol < g.Cout) {
         const float4 v = *(const float4 *)(cs + rl * LDC + cq * 4);
         float *dst = y + (((size_t)bimg * g.LH + oy) * g.LW + ox) * g.Cout + ncol;
