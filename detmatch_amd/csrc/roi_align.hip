@@ -286,14 +286,15 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(Pyramid pyr, const flo
   float *wy = (float *)smem;                 // [ph][RA_MAX_SPAN]
   float *wx = wy + ph * RA_MAX_SPAN;         // [pw][RA_MAX_SPAN]
   short *rng = (short *)(wx + pw * RA_MAX_SPAN);   // bin / pixel ranges, see build_tap_tables
-  float *gt = (float *)(rng + 4 * RA_MAX_SPAN + 4 * 16);   // [ph*pw][C]
+  float *gt = (float *)(rng + 4 * RA_MAX_SPAN + 4 * 16);   // [ph*pw][C + 1]
+  const int CP = C + 1;      // odd row pitch: the transposed stores below (bins run fastest over the lanes) spread over the banks
   build_tap_tables(g, H, W, y0, x0, py, px, ph, pw, wy, wx, rng);
   const short *yb_lo = rng, *yb_hi = rng + RA_MAX_SPAN, *xb_lo = rng + 2 * RA_MAX_SPAN,
               *xb_hi = rng + 3 * RA_MAX_SPAN;
   const float *gsrc = gout + (size_t)r * C * bins;
   for (int e = threadIdx.x; e < C * bins; e += 256) {   // coalesced read, transposed LDS write
     const int c = e / bins, b = e - c * bins;
-    gt[b * C + c] = gsrc[e] * inv_count;
+    gt[b * CP + c] = gsrc[e] * inv_count;   // (pitch C: every lane of a bin run on ONE bank — 58 % of the LDS cycles were conflicts)
   }
   __syncthreads();
   // A wave owns every 4th pixel row, a lane the channels lane, lane+64, lane+128, lane+192 of a
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(Pyramid pyr, const flo
           const float a = wy[by * RA_MAX_SPAN + yy];
           for (int bx = a0; bx <= a1; ++bx) {
             const float w = a * wx[bx * RA_MAX_SPAN + xx];
-            const float *gp = gt + (by * pw + bx) * C + c;
+            const float *gp = gt + (by * pw + bx) * CP + c;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
               if (c + 64 * k < C) acc[k] += w * gp[64 * k];
@@ -445,8 +446,16 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(Pyramid pyr, const flo
             }
           }
         }
+        // four 4-byte stores per lane at a lane pitch of 4 words: in element order they use 8 of the 32 banks (4-way
+        // conflicts); each group of eight lanes starts one element later and the 32 lanes cover every bank
         float *o = ot + b * (C + 1) + 4 * cg;
-        o[0] = acc.x * inv_count, o[1] = acc.y * inv_count, o[2] = acc.z * inv_count, o[3] = acc.w * inv_count;
+        const float v[4] = {acc.x * inv_count, acc.y * inv_count, acc.z * inv_count, acc.w * inv_count};
+        const int rot = (cg >> 3) & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = (j + rot) & 3;
+          o[k] = k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
+        }
       }
     }
   } else
@@ -538,7 +547,7 @@ extern "C" int dm_roi_align_backward_nhwc(float *const *grads_nhwc_host, const i
   }
   if (pooled_h > 16 || pooled_w > 16) return DM_ERR_UNSUPPORTED;
   const size_t shm = (size_t)(pooled_h + pooled_w) * RA_MAX_SPAN * 4 + (4 * RA_MAX_SPAN + 64) * 2 +
-                     (size_t)pooled_h * pooled_w * channels * 4;
+                     (size_t)pooled_h * pooled_w * (channels + 1) * 4;
   if (shm > 150 * 1024) return DM_ERR_UNSUPPORTED;
   static bool attr = false;
   if (!attr) {
