@@ -41,6 +41,9 @@ if has tools; then
   python3 tools/bench_fps.py 2>&1 | grep -v "amdgpu.ids" > $O/fps.txt
   (cd tools && python3 bench_dense_conv_math.py 2>&1 | grep -v "amdgpu.ids" > $O/dense_conv_math_modes.txt)
   python3 tools/bench_spconv_layers.py 2>&1 | grep -v "amdgpu.ids" > $O/spconv_layers.txt
+  python3 tools/bench_dense_wgrad.py 2>&1 | grep -v "amdgpu.ids" > $O/dense_wgrad_fused_vs_per_tap.txt
+  python3 tools/bench_tall_wgrad.py 2>&1 | grep -v "amdgpu.ids" > $O/tall_skinny_wgrad_blas_vs_own.txt
+  bash tools/pmc_step_lds.sh r04_lds > /dev/null 2>&1; cp $R/gpurun_out/r04_lds/lds_conflicts.txt $O/lds_conflicts.txt
   python3 tools/cpu_vs_gpu_bound.py 2>&1 | grep "detmatch:\|CPU ms" > $O/host_vs_device.txt
   python3 tools/find_syncs.py 2>&1 | grep -v "amdgpu.ids" > $O/host_syncs.txt
   tools/launch_cost_bin > $O/launch_cost.txt 2>&1
@@ -50,7 +53,7 @@ if has ab; then
   # 3. round-4 A/Bs (same box, alternated)
   rm -f $O/ab_step_variants.txt
   for i in 1 2 3; do
-    for v in "default:A=1" "no_weight_planes:DM_DCONV_PLANES=0" "per_layer_sparse_wgrad:DM_SPCONV_WGRAD_BATCH=0" "no_collect_early:DM_COLLECT_EARLY=0" "hipgraph_sections:DM_HIPGRAPH=1" "branches:DM_TWO_LANES=1" "pairs:DM_LANE_MODE=pairs"; do
+    for v in "default:A=1" "per_tap_dense_wgrad:DM_FP32_CONV=fp32_split_tapwise_wgrad" "no_weight_planes:DM_DCONV_PLANES=0" "per_layer_sparse_wgrad:DM_SPCONV_WGRAD_BATCH=0" "no_collect_early:DM_COLLECT_EARLY=0" "hipgraph_sections:DM_HIPGRAPH=1" "branches:DM_TWO_LANES=1" "pairs:DM_LANE_MODE=pairs"; do
       n=${v%%:*}; e=${v#*:}
       env $e python3 bench.py --no-cpu-baseline --steps 30 --warmup 6 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); o=d['roofline']['other_kernels']; w=d['roofline']['all_spconv']['wgrad']; print('%-26s run $i  %.1f ms/step  roofline kernel %.1f us  dense fwd+dgrad %.2f ms  sparse wgrad %.0f us (%d launches)' % ('$n', d['ms_per_step'], d['roofline'].get('avg_us') or 0, o['dense_conv.fwd+dgrad']['ms_per_step'], w['us_per_step'], w['launches_per_step']))" >> $O/ab_step_variants.txt
     done
