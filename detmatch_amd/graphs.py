@@ -6,8 +6,11 @@ A section is a function of a few tensors whose launches depend on the shapes onl
 issues such a section in 2-4 ms of Python although the device needs about the same time, and the step is
 host-bound right behind it (the 3D passes with their data-dependent sizes cannot be captured).  Captured
 once per input signature, the section costs one copy of the inputs into static buffers and one
-hipGraphLaunch; every kernel inside is the very same C-ABI launch on the capture stream — the weight packs
-included, so a replay reads the CURRENT weights (the arenas never move).
+hipGraphLaunch; every kernel inside is the very same C-ABI launch on the capture stream.  The packed copies of
+the weights are NOT in the graph (round 4): its convolutions read the replay stream's cached copies, which
+`dense_conv.ensure_fresh` brings up to date with ONE launch in front of a replay (the arenas never move, the
+cached copies never move, the section keeps them alive); only weights with per-call scales (BatchNorm folds of
+a moving teacher) keep recorded packs.
 
 Rules a section must keep (checked by the capture itself, which fails on a violation): no device->host
 read, no allocation outside torch's allocator, no launch on another stream.  The outputs are static
@@ -75,6 +78,8 @@ class StaticSection(object):
             self._capture(e, tensors)
         for s, t in zip(e['static_in'], tensors):
             s.copy_(t)
+        from . import dense_conv
+        dense_conv.ensure_fresh(tensors[0].device, e['keep'])      # the graph's convolutions read the stream's cached packs
         e['graph'].replay()
         self.replays += 1
         return e['out']
@@ -89,14 +94,20 @@ class StaticSection(object):
         with torch.cuda.stream(side):       # once more on a side stream: whatever is keyed by the stream settles
             self.fn(*static_in)
         cur.wait_stream(side)
-        from . import dense_conv
+        from . import dense_conv, _lib
         g = torch.cuda.CUDAGraph()
-        dense_conv.CAPTURING[0] = True      # weight packs and folded-BatchNorm maps are recorded, not taken from caches
+        dense_conv.ensure_fresh(tensors[0].device)
+        dense_conv.CAPTURING[0] = True      # constant-scale weight packs come from the replay stream's cache; folded-BatchNorm maps are recorded
+        dense_conv.CAPTURE_STREAM[0] = _lib.raw_stream()
+        del dense_conv.CAPTURE_KEEP[:]
         try:
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 out = self.fn(*static_in)
         finally:
             dense_conv.CAPTURING[0] = False
+            dense_conv.CAPTURE_STREAM[0] = None
+        e['keep'] = list(dense_conv.CAPTURE_KEEP)
+        del dense_conv.CAPTURE_KEEP[:]
         e['graph'], e['static_in'], e['out'] = g, static_in, out
         self.captures += 1
 
@@ -196,7 +207,12 @@ class TrainSection(object):
         aliases = [torch.nn.Parameter(p.detach(), requires_grad=True) for p in self.params]
         for (m, k), a in zip(self.slots, aliases):
             m._parameters[k] = a
-        dense_conv.CAPTURING[0] = True        # weight packs / BatchNorm folds are recorded, not taken from caches
+        from . import _lib
+        dense_conv.ensure_fresh(tensors[0].device)
+        dense_conv.CAPTURING[0] = True        # constant-scale weight packs come from the replay stream's cache (see dense_conv)
+        dense_conv.CAPTURE_STREAM[0] = _lib.raw_stream()
+        dense_conv.ALIAS_OF.update({id(a): p for a, p in zip(aliases, self.params)})
+        del dense_conv.CAPTURE_KEEP[:]
         bn_relu.CAPTURING[0] = True           # call counters move inside the graph
         torch.cuda.synchronize()
         try:
@@ -230,6 +246,9 @@ class TrainSection(object):
                 inst.bwd = None
         finally:
             dense_conv.CAPTURING[0] = False
+            dense_conv.CAPTURE_STREAM[0] = None
+            for a in aliases:
+                dense_conv.ALIAS_OF.pop(id(a), None)
             bn_relu.CAPTURING[0] = False
             for (m, k), p in zip(self.slots, self.params):
                 m._parameters[k] = p
@@ -237,12 +256,12 @@ class TrainSection(object):
         for b, v in zip(self.buffers, saved):      # a capture executes nothing, but be explicit
             b.copy_(v)
         inst.static_in, inst.outs, inst.diff, inst.gouts = static_in, outs, diff, gouts
-        inst.keep = aliases
+        inst.keep = (aliases, list(dense_conv.CAPTURE_KEEP))
+        del dense_conv.CAPTURE_KEEP[:]
         grad_of = {id(w): g for w, g in zip(wrt, gins)}
         inst.gins = [grad_of.get(id(t)) if t.requires_grad else None for t in static_in] + \
                     [grad_of.get(id(a)) for a in aliases]
         inst.fn_cls = self._node(inst)
-        dense_conv.forget(self.params)
         self.captures += 1
         return inst
 
@@ -258,6 +277,8 @@ class TrainSection(object):
                 for s, t in zip(inst.static_in, args[:n_in]):
                     if s.data_ptr() != t.data_ptr():
                         s.detach().copy_(t)
+                from . import dense_conv
+                dense_conv.ensure_fresh(inst.static_in[0].device, inst.keep[1])      # the graphs read the stream's cached packs
                 t0 = time.perf_counter() if TIMING else 0.0
                 inst.fwd.replay()
                 if TIMING:
@@ -281,6 +302,8 @@ class TrainSection(object):
                     elif g.data_ptr() != dst.data_ptr():
                         dst.copy_(g)
                 if inst.bwd is not None:
+                    from . import dense_conv
+                    dense_conv.ensure_fresh(inst.static_in[0].device, inst.keep[1])
                     t0 = time.perf_counter() if TIMING else 0.0
                     inst.bwd.replay()
                     if TIMING:
