@@ -7,7 +7,13 @@ for m in random zeros; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$m -o kt -- python3 $R/tools/prof_dense_conv.py $a > /dev/null 2>&1
   f=$(find $O/kt_$m -name "*kernel_stats.csv" | head -1)
   echo "== $m operands" >> $O/clock_probe.txt
-  grep "dconv_patch\|dconv_wgrad9\|dconv_gemm_bf16" $f | awk -F'","' '{gsub(/"/,"",$1); n=$1; sub(/\(.*/,"",n); printf "%-60s calls %5s  mean %10.1f us\n", substr(n,1,60), $2, $4/1000}' >> $O/clock_probe.txt
+  python3 - $f >> $O/clock_probe.txt <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+    if n.startswith(('dconv_patch', 'dconv_wgrad9', 'dconv_gemm_bf16', 'dconv_wgrad_bf16')):
+        print('%-50s calls %5s  mean %9.1f us' % (n[:50], r['Calls'], float(r['AverageNs']) / 1e3))
+PY
   rm -rf $O/kt_$m
 done
 cat $O/clock_probe.txt
