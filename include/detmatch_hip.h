@@ -713,7 +713,12 @@ int dm_dconv_pack(const float *src, float *dst, const float *scale_n, const floa
  * up to 16 of the 24 significand bits of THAT operand are dropped; above bf16's largest finite value 3.3895e38
  * the high plane rounds to infinity).  +-inf / NaN operands make the same output elements non-finite as in mode 0,
  * but an infinite operand yields NaN where mode 0 yields +-inf (inf splits into inf + NaN + NaN).
- * Process-wide; dm_dconv_wgrad follows the mode for layers with more than 64 channels on both sides. */
+ * Process-wide; dm_dconv_wgrad follows the mode for layers with more than 64 channels on both sides; in mode 2 the
+ * weight gradient of a 3 x 3 / stride-1 / same-size layer with >= 64 channels on both sides is computed by a
+ * tap-fused kernel (nine taps per workgroup) when the layer gives a workgroup >= 24 steps of 16 pixels — same six
+ * products per term, another summation order over the pixels than the per-tap kernel (agreement to the fp32
+ * accumulation error; bitwise reproducible run to run).  Developer switches for A/B timing: 2 + 16 = mode 2 without
+ * the patch kernels, 2 + 32 = mode 2 with the per-tap weight gradient everywhere (dm_dconv_get_math reports 2). */
 int dm_dconv_set_math(int mode);
 int dm_dconv_get_math(void);
 /* The same for n_entries weights in one launch.  table_dev: device array of 80-byte rows
