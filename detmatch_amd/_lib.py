@@ -75,11 +75,13 @@ SIGNATURES = {
     'dm_rowgemm_parts': (ci, [ctypes.c_longlong, ci, ci]),
     'dm_rowgemm_stats': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, vp, vp, vp]),
     'dm_rowgemm_strided': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, ci, ci, vp]),
+    'dm_rowgemm_wt': (ci, [vp, vp, ci, vp, ctypes.c_longlong, ci, ci, ci, ci, vp]),
     'dm_anchor_decode': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, cf, cf, cf, vp, vp]),
     'dm_bn_rows_workspace_bytes': (sz, [ctypes.c_longlong, ci]),
     'dm_bn_rows_forward': (ci, [vp, ctypes.c_longlong, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
     'dm_bn_rows_max_forward': (ci, [vp, ctypes.c_longlong, ci, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'dm_bn_rows_max_backward': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'dm_bn_rows_max_backward_ld': (ci, [vp, ctypes.c_longlong, vp, vp, ctypes.c_longlong, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'dm_bn_rows_forward_pre': (ci, [vp, ctypes.c_longlong, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp]),
     'dm_bn_rows_max_forward_pre': (ci, [vp, ctypes.c_longlong, ci, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
     'dm_bn_rows_eval_max': (ci, [vp, ctypes.c_longlong, ci, ci, vp, vp, vp, vp, cf, vp, vp]),

@@ -91,7 +91,10 @@ class _BNReLUMaxRows(Function):
     @staticmethod
     def backward(ctx, gp):
         x, gamma, beta, mean, invstd, arg = ctx.saved_tensors
-        gp = gp.contiguous()
+        # the pooled gradient usually is a column block of the concatenated features' gradient: read in place
+        if not (gp.dim() == 2 and gp.stride(1) == 1 and gp.stride(0) % 4 == 0 and gp.stride(0) >= gp.shape[1]
+                and gp.data_ptr() % 16 == 0):
+            gp = gp.contiguous()
         n, c = x.shape
         m = n // ctx.ns
         L = _lib.lib()
@@ -99,10 +102,10 @@ class _BNReLUMaxRows(Function):
         ggamma = torch.empty((c,), dtype=torch.float32, device=x.device)
         gbeta = torch.empty_like(ggamma)
         ws = _lib.workspace(L.dm_bn_rows_workspace_bytes(n, c), x.device, 'bn_rows')
-        _lib.check(L.dm_bn_rows_max_backward(
-            _lib.ptr(gp), _lib.ptr(arg), _lib.ptr(x), m, ctx.ns, c, _lib.ptr(gamma), _lib.ptr(beta),
+        _lib.check(L.dm_bn_rows_max_backward_ld(
+            gp.data_ptr(), int(gp.stride(0)), _lib.ptr(arg), _lib.ptr(x), m, ctx.ns, c, _lib.ptr(gamma), _lib.ptr(beta),
             _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gx), _lib.ptr(ggamma), _lib.ptr(gbeta), _lib.ptr(ws),
-            ws.numel(), _lib.stream()), 'dm_bn_rows_max_backward')
+            ws.numel(), _lib.stream()), 'dm_bn_rows_max_backward_ld')
         return (gx, ggamma if gamma is not None else None, gbeta if beta is not None else None,
                 None, None, None, None, None, None)
 

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void bn_max_bwd_reduce_kernel(
     const float *__restrict__ gp, const unsigned char *__restrict__ arg, const float *__restrict__ x, long long m,
     int ns, int c, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, int groups_per_block,
-    float *__restrict__ partial /*[2][c][blocks]*/) {
+    float *__restrict__ partial /*[2][c][blocks]*/, long long ldg /* row pitch of gp, floats */) {
   extern __shared__ float sm[];
   const int tpr = c / 4, rpi = 256 / tpr;
   const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void bn_max_bwd_reduce_kernel(
     for (int q = rl; q < groups; q += rpi) {
       const long long grp = g0 + q;
       const uchar4 a = *(const uchar4 *)(arg + (size_t)grp * c + ch);
-      float4 d = *(const float4 *)(gp + (size_t)grp * c + ch);
+      float4 d = *(const float4 *)(gp + (size_t)grp * ldg + ch);
       const float *base = x + (size_t)grp * ns * c + ch;
       const float hx = (base[(size_t)a.x * c + 0] - mu.x) * s.x, hy = (base[(size_t)a.y * c + 1] - mu.y) * s.y;
       const float hz = (base[(size_t)a.z * c + 2] - mu.z) * s.z, hw = (base[(size_t)a.w * c + 3] - mu.w) * s.w;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void bn_max_bwd_apply_kernel(
     const float *__restrict__ gp, const unsigned char *__restrict__ arg, const float *__restrict__ x, long long m,
     int ns, int c, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ dgamma,
-    const float *__restrict__ dbeta, float *__restrict__ dx) {
+    const float *__restrict__ dbeta, float *__restrict__ dx, long long ldg) {
   const long long n = m * ns;
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n * c) return;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void bn_max_bwd_apply_kernel(
   const float inv_n = 1.0f / (float)n;
   const float4 v = *(const float4 *)(x + i);
   const uchar4 a = *(const uchar4 *)(arg + (size_t)grp * c + ch);
-  const float4 gv = *(const float4 *)(gp + (size_t)grp * c + ch);
+  const float4 gv = *(const float4 *)(gp + (size_t)grp * ldg + ch);
   float4 d = make_float4(a.x == j ? gv.x : 0.f, a.y == j ? gv.y : 0.f, a.z == j ? gv.z : 0.f, a.w == j ? gv.w : 0.f);
   const float4 mu = *(const float4 *)(mean + ch), s = *(const float4 *)(invstd + ch);
   const float4 g = gamma ? *(const float4 *)(gamma + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -535,14 +535,14 @@ extern "C" int dm_bn_rows_eval_max(const float *x, long long m, int ns, int c, c
   return DM_OK;
 }
 
-extern "C" int dm_bn_rows_max_backward(const float *grad_pooled, const unsigned char *argmax, const float *x,
-                                       long long m, int ns, int c, const float *gamma, const float *beta,
-                                       const float *save_mean, const float *save_invstd, float *grad_x,
-                                       float *grad_gamma, float *grad_beta, void *workspace,
-                                       size_t workspace_bytes, dm_stream_t stream) {
+extern "C" int dm_bn_rows_max_backward_ld(const float *grad_pooled, long long ldg, const unsigned char *argmax,
+                                          const float *x, long long m, int ns, int c, const float *gamma,
+                                          const float *beta, const float *save_mean, const float *save_invstd,
+                                          float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
+                                          size_t workspace_bytes, dm_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const long long n = m * ns;
-  if (ns < 1 || ns > 255 || m < 0) return DM_ERR_INVALID_ARG;
+  if (ns < 1 || ns > 255 || m < 0 || ldg < c || (ldg & 3) || ((size_t)grad_pooled & 15)) return DM_ERR_INVALID_ARG;
   if (!bn_shape_ok(n, c)) return n == 0 ? DM_OK : DM_ERR_UNSUPPORTED;
   if (!grad_pooled || !argmax || !x || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta ||
       !workspace)
@@ -552,15 +552,24 @@ extern "C" int dm_bn_rows_max_backward(const float *grad_pooled, const unsigned 
   const int blocks = (int)((m + gpb - 1) / gpb);
   float *partial = (float *)workspace;
   bn_max_bwd_reduce_kernel<<<blocks, 256, 2 * 256 * 4 * sizeof(float), st>>>(
-      grad_pooled, argmax, x, m, ns, c, gamma, beta, save_mean, save_invstd, gpb, partial);
+      grad_pooled, argmax, x, m, ns, c, gamma, beta, save_mean, save_invstd, gpb, partial, ldg);
   DM_CHECK_LAUNCH();
   bn_bwd_finalize_kernel<<<c, 64, 0, st>>>(partial, blocks, c, grad_gamma, grad_beta);
   DM_CHECK_LAUNCH();
   const long long quads = n * c / 4;
   bn_max_bwd_apply_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, st>>>(
-      grad_pooled, argmax, x, m, ns, c, gamma, beta, save_mean, save_invstd, grad_gamma, grad_beta, grad_x);
+      grad_pooled, argmax, x, m, ns, c, gamma, beta, save_mean, save_invstd, grad_gamma, grad_beta, grad_x, ldg);
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+
+extern "C" int dm_bn_rows_max_backward(const float *grad_pooled, const unsigned char *argmax, const float *x,
+                                       long long m, int ns, int c, const float *gamma, const float *beta,
+                                       const float *save_mean, const float *save_invstd, float *grad_x,
+                                       float *grad_gamma, float *grad_beta, void *workspace,
+                                       size_t workspace_bytes, dm_stream_t stream) {
+  return dm_bn_rows_max_backward_ld(grad_pooled, c, argmax, x, m, ns, c, gamma, beta, save_mean, save_invstd, grad_x,
+                                    grad_gamma, grad_beta, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dm_bn_rows_eval(const float *x, long long n, int c, const float *gamma, const float *beta,

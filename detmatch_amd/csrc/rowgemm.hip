@@ -33,7 +33,7 @@ template <int NBW>
 __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                       float *__restrict__ Y, int R, int K, int N, int KP,
                                                       int ldy, int col0, float *__restrict__ st_partial,
-                                                      float *__restrict__ st_counts) {
+                                                      float *__restrict__ st_counts, int wt_ld) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int ld = KP + 4;                         // row stride of both operand tiles (floats)
   float *Ws = lds;                               // [NBW * 64][ld]   (row n: W[n][0..K), zero padded)
@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
   for (int e = tid; e < NBW * 64 * kq4; e += 256) {
     const int n = e / kq4, q = e - n * kq4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N) {
+    if (n < N && wt_ld > 0) {                    // W given transposed: element (n, k) at W[k * wt_ld + n] (dm_rowgemm_wt)
+      const float *src = W + (size_t)(4 * q) * wt_ld + n;
+      if (4 * q + 3 < K) v = make_float4(src[0], src[wt_ld], src[2 * (size_t)wt_ld], src[3 * (size_t)wt_ld]);
+    } else if (n < N) {
       const float *src = W + (size_t)n * K + 4 * q;
       if (4 * q + 3 < K) v = *(const float4 *)src;
       else if (4 * q < K) {                      // K % 4 == 0: never partial, kept for safety
@@ -180,7 +183,7 @@ int rowgemm_grid(int R, size_t smem) {
 
 template <int NBW>
 int launch(const float *X, const float *W, float *Y, int R, int K, int N, int ldy, int col0, hipStream_t st,
-           float *st_partial = nullptr, float *st_counts = nullptr) {
+           float *st_partial = nullptr, float *st_counts = nullptr, int wt_ld = 0) {
   const int KP = (K + 7) / 8 * 8;
   const size_t smem = rowgemm_smem(K, NBW);
   static bool attr = false;
@@ -191,7 +194,7 @@ int launch(const float *X, const float *W, float *Y, int R, int K, int N, int ld
   }
   if (smem > 160 * 1024) return DM_ERR_UNSUPPORTED;
   const int grid = rowgemm_grid(R, smem);
-  rowgemm_kernel<NBW><<<grid, 256, smem, st>>>(X, W, Y, R, K, N, KP, ldy, col0, st_partial, st_counts);
+  rowgemm_kernel<NBW><<<grid, 256, smem, st>>>(X, W, Y, R, K, N, KP, ldy, col0, st_partial, st_counts, wt_ld);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -232,6 +235,22 @@ extern "C" int dm_rowgemm_stats(const float *x, const float *w, float *y, long l
   if (n <= 64) return launch<1>(x, w, y, (int)rows, k, n, n, 0, st, partial, counts);
   if (n <= 128) return launch<2>(x, w, y, (int)rows, k, n, n, 0, st, partial, counts);
   return launch<3>(x, w, y, (int)rows, k, n, n, 0, st, partial, counts);
+}
+
+// y[:, col0:col0+n] = x (rows, k) . wt, wt (k, wt_ld) row-major with the n columns starting at wt: the INPUT gradient of
+// a linear layer straight from its stored (out, in) weight — x = dY, k = out, wt = weight + first live input column,
+// wt_ld = in — without a transposed copy of the weight per call
+extern "C" int dm_rowgemm_wt(const float *x, const float *wt, int wt_ld, float *y, long long rows, int k, int n,
+                             int ldy, int col0, dm_stream_t stream) {
+  if (rows < 0 || rows > 0x7fffffffLL / 256) return DM_ERR_INT32_RANGE;
+  if (!dm_rowgemm_supported(k, n) || (ldy & 3) || (col0 & 3) || col0 < 0 || ldy < col0 + n || wt_ld < n)
+    return DM_ERR_UNSUPPORTED;
+  if (rows == 0) return DM_OK;
+  if (!x || !wt || !y) return DM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 64) return launch<1>(x, wt, y, (int)rows, k, n, ldy, col0, st, nullptr, nullptr, wt_ld);
+  if (n <= 128) return launch<2>(x, wt, y, (int)rows, k, n, ldy, col0, st, nullptr, nullptr, wt_ld);
+  return launch<3>(x, wt, y, (int)rows, k, n, ldy, col0, st, nullptr, nullptr, wt_ld);
 }
 
 extern "C" int dm_rowgemm(const float *x, const float *w, float *y, long long rows, int k, int n,

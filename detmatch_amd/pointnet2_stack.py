@@ -218,6 +218,25 @@ class TallSkinnyLinear(Function):
         return y
 
     @staticmethod
+    def _rowgemm_dgrad(gy, w, dead):
+        """gx = gy @ w with the first `dead` columns written as zeros, read from the stored (out, in) weight
+        (csrc/rowgemm.hip: dm_rowgemm_wt) — no `w.t().contiguous()` copy per call; None if not taken."""
+        if not (gy.is_cuda and gy.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 2
+                and w.stride(1) == 1 and gy.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS
+                and os.environ.get('DM_ROWGEMM', '1') == '1'):
+            return None
+        L = _lib.lib()
+        r, k = gy.shape
+        n = w.shape[1] - dead
+        if not L.dm_rowgemm_supported(k, n) or dead % 4:
+            return None
+        gy = gy.contiguous()
+        gx = torch.empty((r, dead + n), dtype=torch.float32, device=gy.device)
+        _lib.check(L.dm_rowgemm_wt(_lib.ptr(gy), w.data_ptr() + 4 * dead, int(w.stride(0)), _lib.ptr(gx), r, k, n,
+                                   dead + n, dead, _lib.stream()), 'dm_rowgemm_wt')
+        return gx
+
+    @staticmethod
     def _rowgemm_stats(x, w):
         """_rowgemm that also reduces the column statistics of its output for the BatchNorm that follows
         (per-workgroup (mean, M2) partials from the output tile it already holds in LDS): -> y with the
@@ -260,7 +279,7 @@ class TallSkinnyLinear(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             d = ctx.dead_cols
-            gx = TallSkinnyLinear._rowgemm(gy, w.t()[d:], col0=d) if d else TallSkinnyLinear._rowgemm(gy, w.t())
+            gx = TallSkinnyLinear._rowgemm_dgrad(gy, w, d)
             if gx is None:
                 gx = gy @ w
         gw = None

@@ -337,6 +337,12 @@ int dm_bn_rows_max_backward(const float *grad_pooled, const unsigned char *argma
                             int ns, int c, const float *gamma, const float *beta, const float *save_mean,
                             const float *save_invstd, float *grad_x, float *grad_gamma, float *grad_beta,
                             void *workspace, size_t workspace_bytes, dm_stream_t stream);
+/* The same with grad_pooled rows `ldg` floats apart (ldg >= c, a multiple of 4, pointer 16-byte aligned): the pooled
+ * gradient of one grouper is a column block of the gradient of the concatenated features (torch.cat backward). */
+int dm_bn_rows_max_backward_ld(const float *grad_pooled, long long ldg, const unsigned char *argmax, const float *x,
+                               long long m, int ns, int c, const float *gamma, const float *beta,
+                               const float *save_mean, const float *save_invstd, float *grad_x, float *grad_gamma,
+                               float *grad_beta, void *workspace, size_t workspace_bytes, dm_stream_t stream);
 /* dm_bn_rows_forward / dm_bn_rows_max_forward with the column statistics already reduced to `blocks`
  * partials (layout (2, c, blocks): mean, M2) over counts[b] rows each (dm_rowgemm_stats): no pass over x for
  * the statistics. */
@@ -413,6 +419,11 @@ int dm_rowgemm_stats(const float *x, const float *w, float *y, long long rows, i
  * the input gradient of a first shared-MLP layer without the xyz / padding columns nobody differentiates. */
 int dm_rowgemm_strided(const float *x, const float *w, float *y, long long rows, int k, int n, int ldy,
                        int col0, dm_stream_t stream);
+/* The same with the weight given TRANSPOSED: y[:, col0:col0+n] = x (rows, k) . wt, wt (k, wt_ld) row-major, its n
+ * columns starting at `wt` — the input gradient of a linear layer from its stored (out, in) weight (x = dY, k = out,
+ * wt = weight + first live input column, wt_ld = in) without materialising weight^T per call (torch: `gy @ w`). */
+int dm_rowgemm_wt(const float *x, const float *wt, int wt_ld, float *y, long long rows, int k, int n, int ldy,
+                  int col0, dm_stream_t stream);
 
 /* Anchor-head box decoding: AnchorHeadTemplate.generate_predicted_boxes
  * (pcdet/models/dense_heads/anchor_head_template.py:225-272) = ResidualCoder.decode_torch

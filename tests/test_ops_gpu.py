@@ -526,6 +526,13 @@ def test_rowgemm_matches_float64_matmul(dev, rows, k, n):
                                         _lib.stream()), 'dm_rowgemm_strided')
         assert float(y2[:, :8].abs().max()) == 0.0
         assert torch.equal(y2[:, 8:], y)
+        # the transposed-weight entry (input gradient from the stored weight): wt (k, 4 + n) holds w^T behind 4 columns
+        wt = torch.randn(k, 4 + n, generator=g).to(dev)
+        wt[:, 4:] = w.t()
+        y3 = torch.full((rows, n + 8), float('nan'), device=dev)
+        _lib.check(L.dm_rowgemm_wt(_lib.ptr(x), wt.data_ptr() + 16, 4 + n, _lib.ptr(y3), rows, k, n, n + 8, 8,
+                                   _lib.stream()), 'dm_rowgemm_wt')
+        assert torch.equal(y3, y2)
 
 
 def test_tall_skinny_linear_autograd_through_rowgemm(dev):
@@ -592,6 +599,18 @@ def test_fused_bn_relu_maxpool_matches_two_step(dev, m, ns, c):
         ye = bn_relu_rows_max(x0, bn, ns)
         want = bn_relu_rows(x0, bn, relu=True).view(m, ns, c).max(dim=1)[0]
     assert torch.equal(ye, want)
+    # the pooled gradient as a column block of a wider matrix (the gradient of concatenated grouper outputs): read
+    # in place through its row pitch, bit-identical to the contiguous copy
+    wide = torch.randn(m, c + 36, device=dev)
+    wide[:, 4:4 + c] = gp
+    outs = []
+    for g_in in (gp, wide[:, 4:4 + c]):
+        bn2 = nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).to(dev)
+        x = x0.clone().requires_grad_(True)
+        bn_relu_rows_max(x, bn2, ns).backward(g_in)
+        outs.append((x.grad.clone(), bn2.weight.grad.clone(), bn2.bias.grad.clone()))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
 
 
 @pytest.mark.parametrize('counts', [([5000, 2300], [2048, 2048]), ([3000, 0, 1700], [253, 0, 300]),
