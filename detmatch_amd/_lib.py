@@ -5,6 +5,7 @@ fails loudly when the .so is missing, and every op raises when handed a tensor
 that is not on a HIP device.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -247,7 +248,9 @@ def workspace(nbytes, device, tag='default'):
     scratch memory."""
     if device.type == 'cuda':
         idx = device.index if device.index is not None else torch._C._cuda_getDevice()
-        key = (idx, torch._C._cuda_getCurrentRawStream(idx), tag)
+        # (+ the issuing thread: a backward pass issued by autograd's device thread while the main thread keeps
+        # issuing forward work on the SAME stream must not share multi-launch scratch — partials + reduce — with it)
+        key = (idx, torch._C._cuda_getCurrentRawStream(idx), tag, threading.get_ident())
     else:
         key = (-1, 0, tag)
     buf = _ws_cache.get(key)
