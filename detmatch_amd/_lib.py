@@ -77,6 +77,9 @@ SIGNATURES = {
     'dm_rowgemm_stats': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, vp, vp, vp]),
     'dm_rowgemm_strided': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, ci, ci, vp]),
     'dm_rowgemm_wt': (ci, [vp, vp, ci, vp, ctypes.c_longlong, ci, ci, ci, ci, vp]),
+    'dm_tall_wgrad_supported': (ci, [ci, ci]),
+    'dm_tall_wgrad_workspace_bytes': (sz, [ctypes.c_longlong, ci, ci]),
+    'dm_tall_wgrad': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, ci, vp, sz, vp]),
     'dm_anchor_decode': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, cf, cf, cf, vp, vp]),
     'dm_bn_rows_workspace_bytes': (sz, [ctypes.c_longlong, ci]),
     'dm_bn_rows_forward': (ci, [vp, ctypes.c_longlong, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, vp]),

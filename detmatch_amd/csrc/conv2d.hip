@@ -1858,6 +1858,167 @@ void dconv_wgrad9_kernel(const float *__restrict__ U, const float *__restrict__ 
   }
 }
 
+// ---- weight gradient of a tall-skinny linear layer: dW (N x K) = dY^T (N x R) . X (R x K) -------------------------
+// The shared 1 x 1 layers over grouped rows (pointnet2_modules.py:31-40): R = 65 k ... 885 k rows, N <= 64 outputs,
+// K <= 160 inputs — a reduction over rows that moves R * (N + K) * 4 bytes for 2 R N K flops (20-40 flop per byte):
+// memory-bound once the products run at the split-arithmetic rate.  The batched split-K BLAS call it replaces pays two
+// launches of >= 13 us each whatever the size and runs the large shapes on the fp32 matrix instruction.
+// A workgroup streams a contiguous range of rows in steps of 16: both operands are fetched as they lie in memory
+// ([row][channel], 16-byte pieces), split once into three bf16 planes in LDS, and read back transposed
+// (ds_read_tr16_b64) as in dconv_wgrad9_kernel; the (N / 32) x (K / 32) blocks of 32 x 32 outputs are dealt
+// round-robin to the four waves (<= 3 accumulators per wave), six products per block and step.  LDS rows have a
+// pitch of 64 or 192 bytes mod 256 — four consecutive rows then start in four different 64-byte quarters of the
+// bank row and a transposed read (4 rows x 2 x 32 bytes per half-wave) is conflict-free without a swizzle.
+// Rows are requested two steps ahead (one register set in flight, one being split).
+constexpr int TW_MAXK = 160, TW_MAXN = 64;
+
+__host__ __device__ inline int tw_pitch(int channels) {          // bytes per LDS row of one plane
+  int p = (channels * 2 + 63) / 64 * 64;
+  if ((p & 127) == 0) p += 64;
+  return p;
+}
+
+template <int MAXP>      // output blocks per wave: ceil((N / 32) * (K / 32) / 4)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void tall_wgrad_kernel(const float *__restrict__ U, const float *__restrict__ V, float *__restrict__ part,
+                       long long R, int N, int K, int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int up = tw_pitch(N), vp = tw_pitch(K);
+  const int u_plane = 16 * up, v_plane = 16 * vp;            // one plane of one stage
+  const int stage = 3 * (u_plane + v_plane);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long r_lo = (long long)blockIdx.x * rows_per_wg;
+  const long long r_hi = min(R, r_lo + rows_per_wg);
+  const int n4 = N / 4, q_row = (N + K) / 4;                 // float4 pieces per row: dY first, then X
+  const int pieces = 16 * q_row;
+
+  // the thread's (up to four) pieces of a step: row, source offset inside the step, LDS offset inside a stage
+  constexpr int PP = (16 * (TW_MAXN + TW_MAXK) / 4 + 255) / 256;      // 4
+  int p_row[PP], p_lds[PP];
+  long long p_src[PP];
+  bool p_isu[PP];
+#pragma unroll
+  for (int p = 0; p < PP; ++p) {
+    const int e = p * 256 + tid;
+    const int row = e / q_row, q = e - row * q_row;
+    p_row[p] = e < pieces ? row : -1;
+    p_isu[p] = q < n4;
+    p_src[p] = p_isu[p] ? (long long)row * N + 4 * q : (long long)row * K + 4 * (q - n4);
+    p_lds[p] = p_isu[p] ? row * up + 8 * q : 3 * u_plane + row * vp + 8 * (q - n4);
+  }
+  float4 rg[2][PP];
+  auto gload = [&](auto SET, long long r0) {                 // rows r0 .. r0 + 15 (clamped, masked at the store)
+    constexpr int S = decltype(SET)::value;
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const bool ok = p_row[p] >= 0 && r0 + p_row[p] < r_hi;
+      const float *src = p_isu[p] ? U + r0 * N : V + r0 * K;
+      rg[S][p] = *(const float4 *)(ok ? src + p_src[p] : (p_isu[p] ? U : V));
+    }
+  };
+  auto sstore = [&](auto SET, long long r0, int buf) {
+    constexpr int S = decltype(SET)::value;
+    unsigned char *base = lds + buf * stage;
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      if (p_row[p] < 0) continue;
+      const bool ok = r0 + p_row[p] < r_hi;
+      float4 a = rg[S][p];
+      a.x = ok ? a.x : 0.0f, a.y = ok ? a.y : 0.0f, a.z = ok ? a.z : 0.0f, a.w = ok ? a.w : 0.0f;
+      uint2 h, m, l;
+      split_bf16x3(a, &h, &m, &l);
+      unsigned char *dst = base + p_lds[p];
+      const int plane = p_isu[p] ? u_plane : v_plane;
+      *(uint2 *)dst = h, *(uint2 *)(dst + plane) = m, *(uint2 *)(dst + 2 * plane) = l;
+    }
+  };
+  // output blocks of this wave: pair index wave + 4 j -> (n block, k block)
+  // (a wave whose j-th pair does not exist repeats the last pair and drops the result: the product block stays free of
+  // branches — a conditional block of matrix instructions inside the loop makes the compiler copy accumulators)
+  const int nblk = (N + 31) / 32, kblk = (K + 31) / 32, pairs = nblk * kblk;
+  f32x16 acc[MAXP];
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+  // transposed fragment reads (see dconv_wgrad_bf16_kernel): lane 4q+p of a 16-lane group supplies row q, columns
+  // 4p..4p+3 of its 4 x 16 block; group = (8-row half, 16-channel half)
+  const int grp = lane >> 4, li = lane & 15, fq = li >> 2, fp = li & 3;
+  const int cb = grp & 1, fh = grp >> 1;
+  auto frag = [&](const unsigned char *plane_base, int pitch, int chan0) {
+    union { s16x4 s[2]; bf16x8 v; } u;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 8 * fh + 4 * rr + fq;
+      u.s[rr] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4 *)(plane_base + row * pitch + (chan0 + 16 * cb) * 2 + 8 * fp));
+    }
+    return u.v;
+  };
+  auto products = [&](int buf) {
+    const unsigned char *ub = lds + buf * stage, *vb = ub + 3 * u_plane;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int pi = min(wave + 4 * j, pairs - 1);
+      const int nb = pi % nblk, kb = pi / nblk;
+      bf16x8 af[3], bf[3];
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) {
+        af[sp] = frag(ub + sp * u_plane, up, nb * 32);
+        bf[sp] = frag(vb + sp * v_plane, vp, kb * 32);
+      }
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[j], 0, 0, 0);      // smallest terms first
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[j], 0, 0, 0);
+    }
+  };
+
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  const int steps = (int)((r_hi - r_lo + 15) / 16);
+  if (steps > 0) {
+    // the LDS rows beyond the channels a plane holds are never written: zero the stages once (fragments of the last,
+    // partial 32-channel block read them)
+    for (int e = tid; e < 2 * stage / 16; e += 256) ((uint4 *)lds)[e] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    gload(S0(), r_lo);
+    if (steps > 1) gload(S1(), r_lo + 16);
+    sstore(S0(), r_lo, 0);
+    __syncthreads();
+    int st = 0;
+    // two steps per trip: register set (st & 1) holds step st + 1 at the top of step st
+    for (; st + 2 <= steps; st += 2) {
+      if (st + 2 < steps) gload(S0(), r_lo + 16LL * (st + 2));
+      products(0);
+      sstore(S1(), r_lo + 16LL * (st + 1), 1);
+      __syncthreads();
+      if (st + 3 < steps) gload(S1(), r_lo + 16LL * (st + 3));
+      products(1);
+      if (st + 2 < steps) sstore(S0(), r_lo + 16LL * (st + 2), 0);
+      __syncthreads();
+    }
+    if (st < steps) products(0);
+  }
+  // accumulator block j -> part[wg][n][k] (rows n by register / lane half, columns k by lane)
+  float *dst = part + (size_t)blockIdx.x * N * K;
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) {
+    const int pi = wave + 4 * j;
+    if (pi >= pairs) continue;
+    const int nb = pi % nblk, kb = pi / nblk;
+    const int k = kb * 32 + lr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < N && k < K) dst[(size_t)n * K + k] = acc[j][r];
+    }
+  }
+}
+
 // out[u*su + v*sv + t*st] = scale_u[u] * sum_s part[s][t][u][v]   (v < Cv_out: drops channel padding)
 __global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(
     const float *__restrict__ part, float *__restrict__ out, const float *__restrict__ scale_u,
@@ -2399,6 +2560,52 @@ extern "C" int dm_dconv_wgrad(const float *U, const float *V, float *out, const 
   const long long total = (long long)g.T * g.Cu * g.Cv;
   dconv_wgrad_reduce_kernel<<<dm_ceil_div(total, 256), 256, 0, st>>>(
       part, out, scale_u, ns, g.T, g.Cu, g.Cv, Cv_out, su, sv, st_, accumulate);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+// dW (n, k) = dY^T . X over `rows` rows — the weight gradient of the tall-skinny linears (torch: a batched split-K
+// `bmm` + `sum`); fp32-class split arithmetic, bitwise reproducible (fixed row ranges, fixed-order reduce).
+static int tall_wgrad_wgs(long long rows) {
+  long long w = rows / 256;                      // >= 16 steps of 16 rows per workgroup
+  if (w > 1024) w = 1024;
+  if (w < 1) w = 1;
+  return (int)w;
+}
+
+extern "C" int dm_tall_wgrad_supported(int n, int k) {
+  return n >= 4 && n <= TW_MAXN && (n & 3) == 0 && k >= 4 && k <= TW_MAXK && (k & 3) == 0;
+}
+
+extern "C" size_t dm_tall_wgrad_workspace_bytes(long long rows, int n, int k) {
+  if (rows <= 0 || !dm_tall_wgrad_supported(n, k)) return 0;
+  return dm_align((size_t)tall_wgrad_wgs(rows) * n * k * sizeof(float));
+}
+
+extern "C" int dm_tall_wgrad(const float *dy, const float *x, float *dw, long long rows, int n, int k,
+                             int accumulate, void *workspace, size_t workspace_bytes, dm_stream_t stream) {
+  if (!dm_tall_wgrad_supported(n, k)) return DM_ERR_UNSUPPORTED;
+  if (rows < 0 || rows > 0x7fffffffLL * 8) return DM_ERR_INT32_RANGE;
+  if (!dy || !x || !dw) return DM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) {
+    if (!accumulate) DM_HIP(hipMemsetAsync(dw, 0, (size_t)n * k * sizeof(float), st));
+    return DM_OK;
+  }
+  if (!workspace || workspace_bytes < dm_tall_wgrad_workspace_bytes(rows, n, k)) return DM_ERR_WORKSPACE;
+  const int wgs = tall_wgrad_wgs(rows);
+  long long per = (rows + wgs - 1) / wgs;
+  per = (per + 15) / 16 * 16;
+  const int grid = (int)((rows + per - 1) / per);
+  const size_t smem = 2 * 3 * 16 * (size_t)(tw_pitch(n) + tw_pitch(k));
+  const int pairs = dm_ceil_div(n, 32) * dm_ceil_div(k, 32);
+  if (pairs <= 4) tall_wgrad_kernel<1><<<grid, 256, smem, st>>>(dy, x, (float *)workspace, rows, n, k, (int)per);
+  else if (pairs <= 8) tall_wgrad_kernel<2><<<grid, 256, smem, st>>>(dy, x, (float *)workspace, rows, n, k, (int)per);
+  else tall_wgrad_kernel<3><<<grid, 256, smem, st>>>(dy, x, (float *)workspace, rows, n, k, (int)per);
+  DM_CHECK_LAUNCH();
+  const long long total = (long long)n * k;
+  dconv_wgrad_reduce_kernel<<<dm_ceil_div(total, 256), 256, 0, st>>>((const float *)workspace, dw, nullptr, grid, 1, n, k, k,
+                                                                      k, 1, 1, accumulate);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -236,6 +236,28 @@ class TallSkinnyLinear(Function):
                                    dead + n, dead, _lib.stream()), 'dm_rowgemm_wt')
         return gx
 
+    # csrc/conv2d.hip's streaming weight-gradient kernel (dm_tall_wgrad): correct and reproducible, but on the shapes of
+    # the step it only ties the batched BLAS call (profiles/r04_tall_skinny_wgrad_blas_vs_own.txt: 250 vs 240 us on
+    # 884 736 x 132 x 64, 160 vs 98 us on 884 736 x 64 x 64, 24-49 vs 26-33 us on the small ones) — opt-in
+    OWN_WGRAD = os.environ.get('DM_TALL_WGRAD', '0') == '1'
+
+    @staticmethod
+    def _wgrad(gy, x):
+        """dW = gy^T x on csrc/conv2d.hip's streaming kernel (dm_tall_wgrad), or None if not taken."""
+        if not (gy.is_cuda and gy.dtype == torch.float32 and x.dtype == torch.float32 and x.shape[0] >= 4096):
+            return None
+        L = _lib.lib()
+        r, k = x.shape
+        n = gy.shape[1]
+        if not L.dm_tall_wgrad_supported(n, k):
+            return None
+        gy, x = gy.contiguous(), x.contiguous()
+        gw = torch.empty((n, k), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(int(L.dm_tall_wgrad_workspace_bytes(r, n, k)), x.device, 'tall_wgrad')
+        _lib.check(L.dm_tall_wgrad(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(gw), r, n, k, 0, _lib.ptr(ws), ws.numel(),
+                                   _lib.stream()), 'dm_tall_wgrad')
+        return gw
+
     @staticmethod
     def _rowgemm_stats(x, w):
         """_rowgemm that also reduces the column statistics of its output for the BatchNorm that follows
@@ -283,7 +305,9 @@ class TallSkinnyLinear(Function):
             if gx is None:
                 gx = gy @ w
         gw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and TallSkinnyLinear.OWN_WGRAD:
+            gw = TallSkinnyLinear._wgrad(gy, x)
+        if ctx.needs_input_grad[1] and gw is None:
             rows = x.shape[0]
             split = next((s for s in (256, 128, 64, 32, 16, 8) if rows % s == 0 and rows // s >= 2048), 1)
             if split > 1:

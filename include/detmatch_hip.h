@@ -425,6 +425,15 @@ int dm_rowgemm_strided(const float *x, const float *w, float *y, long long rows,
 int dm_rowgemm_wt(const float *x, const float *wt, int wt_ld, float *y, long long rows, int k, int n, int ldy,
                   int col0, dm_stream_t stream);
 
+/* dw (n, k) [+]= dy (rows, n)^T . x (rows, k): the WEIGHT gradient of the same tall-skinny layers (torch: `gy.t() @ x`, in
+ * the reference's autograd; here until round 4 a batched split-K BLAS call + sum).  n <= 64, k <= 160, multiples of 4;
+ * fp32-class split arithmetic (dm_dconv_set_math mode 2's six bf16 products, fp32 accumulate), fixed row ranges per
+ * workgroup and a fixed-order reduce: bitwise reproducible.  workspace: dm_tall_wgrad_workspace_bytes(rows, n, k). */
+int dm_tall_wgrad_supported(int n, int k);
+size_t dm_tall_wgrad_workspace_bytes(long long rows, int n, int k);
+int dm_tall_wgrad(const float *dy, const float *x, float *dw, long long rows, int n, int k, int accumulate,
+                  void *workspace, size_t workspace_bytes, dm_stream_t stream);
+
 /* Anchor-head box decoding: AnchorHeadTemplate.generate_predicted_boxes
  * (pcdet/models/dense_heads/anchor_head_template.py:225-272) = ResidualCoder.decode_torch
  * (pcdet/utils/box_coder_utils.py:43-76) + direction-bin correction (common_utils.limit_period).

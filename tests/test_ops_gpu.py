@@ -535,6 +535,36 @@ def test_rowgemm_matches_float64_matmul(dev, rows, k, n):
         assert torch.equal(y3, y2)
 
 
+@pytest.mark.parametrize('rows,k,n', [(70000, 132, 64), (65537, 64, 64), (40000, 36, 32), (33000, 16, 16),
+                                      (9000, 20, 16), (4100, 160, 64), (131072, 68, 64), (5000, 100, 48)])
+def test_tall_wgrad_matches_float64(dev, rows, k, n):
+    """dm_tall_wgrad (dW = dY^T X over 10^4..10^6 rows, csrc/conv2d.hip: split arithmetic, streaming row ranges)
+    against float64: maximum error within 4 fp32 ulps of the natural scale sum |dy||x| per sqrt(rows) accumulated
+    products (the bound of the dense convolutions' split arithmetic), bitwise reproducible, and `accumulate`."""
+    from detmatch_amd import _lib
+    g = torch.Generator().manual_seed(rows + 3 * k + n)
+    x = torch.randn(rows, k, generator=g).to(dev)
+    gy = torch.randn(rows, n, generator=g).to(dev)
+    L = _lib.lib()
+    assert L.dm_tall_wgrad_supported(n, k)
+    ws = torch.empty(int(L.dm_tall_wgrad_workspace_bytes(rows, n, k)), dtype=torch.uint8, device=dev)
+
+    def run(dst, acc):
+        _lib.check(L.dm_tall_wgrad(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(dst), rows, n, k, acc, _lib.ptr(ws), ws.numel(),
+                                   _lib.stream()), 'dm_tall_wgrad')
+    a = torch.full((n, k), float('nan'), device=dev)
+    b = torch.full((n, k), float('nan'), device=dev)
+    run(a, 0)
+    run(b, 0)
+    assert torch.equal(a, b)
+    want = gy.double().t() @ x.double()
+    scale = gy.double().abs().t() @ x.double().abs()
+    err = float(((a.double() - want).abs() / scale).max())
+    assert err <= 4 * 2.0 ** -24 * rows ** 0.5, err
+    run(b, 1)
+    torch.testing.assert_close(b, 2 * a, rtol=1e-6, atol=1e-6)
+
+
 def test_tall_skinny_linear_autograd_through_rowgemm(dev):
     """TallSkinnyLinear on the rowgemm path (threshold lowered) == the BLAS path: output, weight gradient,
     input gradient of the live columns; the dead leading columns get zeros."""

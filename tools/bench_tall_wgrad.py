@@ -1,6 +1,6 @@
 """Weight gradient of the tall-skinny linears (dW = dy^T x over 10^5..10^6 rows) of one DetMatch iteration:
-the shapes the step really issues, timed as (a) batched split-K BLAS + sum and (b) csrc/conv2d.hip's weight-gradient
-kernels (a 1-tap convolution over a 1 x R image).
+the shapes the step really issues, timed as (a) batched split-K BLAS + sum and (b) csrc/conv2d.hip's streaming
+kernel (dm_tall_wgrad).
     python tools/bench_tall_wgrad.py
 """
 import collections
@@ -61,8 +61,7 @@ def main():
         dw = torch.empty(cout, cin, device=dev)
 
         def own():
-            dense_conv._wgrad(gy, x, dw, None, [1, 1, rows, cout, cin, 1, rows, 1, 1, 1], [(0, 0)], cin, cin, 1, 1)
-            return dw
+            return p2.TallSkinnyLinear._wgrad(gy, x)
         ok = cin % 4 == 0 and cout % 4 == 0
         a = t(blas)
         b = t(own) if ok else float('nan')
