@@ -221,7 +221,9 @@ def require_device(*tensors):
 
 
 def ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device address of a tensor as a plain int (the argtypes convert it; wrapping it in a c_void_p object first costs
+    0.2 us more per argument, ~3 000 arguments per iteration), None for None."""
+    return None if t is None else t.data_ptr()
 
 
 def raw_stream():
@@ -231,7 +233,7 @@ def raw_stream():
 
 
 def stream():
-    return ctypes.c_void_p(raw_stream())
+    return raw_stream()
 
 
 def ints(v):
