@@ -163,6 +163,23 @@ SIGNATURES = {
     'dm_profile_count': (ci, []),
     'dm_profile_get': (ci, [ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
                             ctypes.POINTER(ctypes.c_ulonglong), c_f32_p]),
+    'dm_chain_fn_count': (ci, []),
+    'dm_chain_fn_index': (ci, [ctypes.c_char_p]),
+    'dm_chain_fn_name': (ctypes.c_char_p, [ci]),
+    'dm_chain_fn_signature': (ctypes.c_char_p, [ci]),
+    'dm_chain_run': (ci, [vp, ci, vp, ci, c_int_p]),
+    'dm_relu_mask_f32': (ci, [vp, vp, vp, ctypes.c_longlong, vp]),
+    'dm_add_mask_f32': (ci, [vp, vp, vp, vp, ctypes.c_longlong, vp]),
+    'dm_colsum_workspace_bytes': (sz, [ctypes.c_longlong, ci]),
+    'dm_colsum_f32': (ci, [vp, ctypes.c_longlong, ci, vp, ci, vp, sz, vp]),
+    'dm_resize_nearest_nhwc': (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    'dm_resize_nearest_nhwc_backward': (ci, [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
+    'dm_maxpool_nhwc': (ci, [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
+    'dm_subsample_nhwc_backward': (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
+    'dm_copy2d_f32': (ci, [vp, ctypes.c_longlong, vp, ctypes.c_longlong, ctypes.c_longlong, ci, vp]),
+    'dm_fill_bytes': (ci, [vp, ci, sz, vp]),
+    'dm_bn_fold_batch': (ci, [vp, ci, ci, vp]),
+    'dm_multi_add_f32': (ci, [vp, ci, ctypes.c_longlong, ci, vp]),
 }
 
 

@@ -1,0 +1,663 @@
+"""Builder of dense (NHWC) chains: convolution / BatchNorm / ReLU / resize / pool / concat sub-graphs as two op
+tables (forward, backward) behind ONE autograd node — host side of VERDICT r4 item 1 for the BEV backbone + anchor
+head convolutions (pcdet/models/backbones_2d/base_bev_backbone.py:38-112, anchor_head_single.py:20-37) and the
+2D trunk (mmdet ResNet-50 + FPN + RPNHead convolutions, configs/detmatch/001/detmatch/split_0.py:39-99).
+
+The builder is a build-time tape: `conv()`, `bn_relu()`, ... append the forward launches to `fwd` and remember how to
+differentiate themselves; `build()` walks the tape backwards and appends the mirror launches (ReLU masks, input
+gradients with the running gradient of a shared tensor added in the GEMM epilogue, weight / bias gradients) to `bwd`.
+Activations live in one arena per call (one `torch.empty`), gradients in another; packed weights, BatchNorm folds
+and concatenated head weights belong to the chain and are refreshed by one small program when the weights changed.
+Every launch is the same entry point with the same arguments as the op-by-op path (`dense_conv`, `bn_relu`): the
+results are bit-identical to it (tests/test_chain_gpu.py).
+"""
+import numpy as np
+import torch
+
+from . import _lib, bn_relu, dense_conv
+from .chain import DeviceTable, Layout, Program, S
+
+_PACK_DESC = np.dtype([('src', '<u8'), ('dst', '<u8'), ('scale_n', '<u8'), ('scale_k', '<u8'),
+                       ('sn', '<i8'), ('sk', '<i8'), ('st', '<i8'), ('S', '<i4'), ('N', '<i4'),
+                       ('K', '<i4'), ('Nsrc', '<i4'), ('Ksrc', '<i4'), ('pad', '<i4')])
+_FOLD_DESC = np.dtype([('gamma', '<u8'), ('beta', '<u8'), ('mean', '<u8'), ('var', '<u8'), ('scale', '<u8'),
+                       ('shift', '<u8'), ('eps', '<f4'), ('C', '<i4')])
+_AXPY_DESC = np.dtype([('dst', '<u8'), ('src', '<u8'), ('n', '<i8')])
+assert _PACK_DESC.itemsize == 80 and _FOLD_DESC.itemsize == 56 and _AXPY_DESC.itemsize == 24
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class Buf(object):
+    """An NHWC fp32 activation (n, h, w, c) at `ref` (slot + offset)."""
+    __slots__ = ('ref', 'n', 'h', 'w', 'c', 'rg', 'external')
+
+    def __init__(self, ref, n, h, w, c, rg, external=False):
+        self.ref, self.n, self.h, self.w, self.c, self.rg, self.external = ref, n, h, w, c, rg, external
+
+    @property
+    def rows(self):
+        return self.n * self.h * self.w
+
+    @property
+    def numel(self):
+        return self.rows * self.c
+
+    @property
+    def shape(self):
+        return (self.n, self.c, self.h, self.w)      # logical (N, C, H, W), memory NHWC
+
+
+class _Weights(object):
+    """Everything of a chain that is derived from parameters and changes only when they change: packed
+    convolution weights (+ bf16 planes), evaluation-mode BatchNorm folds, concatenated head weights.  One small
+    program (fold launch, concat launch, pack launch) refreshes all of it."""
+
+    def __init__(self, device):
+        self.device = device
+        self.fold_rows, self.cat_rows, self.pack_rows = [], [], []
+        self.keep = []
+        self.watch = []          # tensors whose version counters are checked per run (conv weights, folded statistics)
+        self.prog = None
+        self.stamp = None
+        self.max_fold_c, self.max_cat_n, self.max_pack = 1, 1, 1
+
+    def fold(self, bn):
+        """(scale, shift) buffers of an evaluation-mode BatchNorm / FrozenBN layer."""
+        c = bn.weight.shape[0]
+        scale = torch.empty(c, dtype=torch.float32, device=self.device)
+        shift = torch.empty_like(scale)
+        self.fold_rows.append((bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                               bn.running_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), float(bn.eps), c))
+        self.keep += [bn.weight, bn.bias, bn.running_mean, bn.running_var, scale, shift]
+        self.watch.append(bn.running_mean)
+        self.max_fold_c = max(self.max_fold_c, c)
+        return scale, shift
+
+    def cat(self, tensors, pad_to=None):
+        """Concatenation along dim 0 of parameters (head weights / biases), zero-padded to `pad_to` rows."""
+        tensors = [t.detach() for t in tensors]
+        rows = sum(t.shape[0] for t in tensors)
+        total = pad_to if pad_to is not None else rows
+        out = torch.zeros((total,) + tuple(tensors[0].shape[1:]), dtype=torch.float32, device=self.device)
+        per_row = out[0].numel() if out.dim() > 1 else 1
+        off = 0
+        for t in tensors:
+            assert t.is_contiguous()
+            self.cat_rows.append((out.data_ptr() + off * per_row * 4, t.data_ptr(), t.numel()))
+            self.max_cat_n = max(self.max_cat_n, t.numel())
+            off += t.shape[0]
+        self.keep += tensors + [out]
+        return out
+
+    def pack(self, src, S_, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None, planes=False):
+        """Packed [S][N][K] copy of `src` (dm_dconv_pack_batch row) -> (tensor, planes byte offset or None)."""
+        if planes:
+            nb = int(_lib.lib().dm_dconv_planes_bytes(S_, N, K))
+            dst = torch.empty(S_ * N * K + (nb + 3) // 4, dtype=torch.float32, device=self.device)
+        else:
+            dst = torch.empty(S_ * N * K, dtype=torch.float32, device=self.device)
+        self.pack_rows.append((src.data_ptr(), dst.data_ptr(), 0 if scale_n is None else scale_n.data_ptr(),
+                               0 if scale_k is None else scale_k.data_ptr(), sn, sk, st, S_, N, K, n_src, k_src,
+                               1 if planes else 0))
+        self.keep += [src, dst, scale_n, scale_k]
+        self.max_pack = max(self.max_pack, S_ * N * K)
+        return dst, (S_ * N * K * 4 if planes else None)
+
+    def finalize(self):
+        prog = Program('weights')
+        if self.fold_rows:
+            t = DeviceTable(np.array(self.fold_rows, dtype=_FOLD_DESC), self.device)
+            self.keep.append(t)
+            prog.call('dm_bn_fold_batch', t.dev, t.n, self.max_fold_c, Program.STREAM)
+        if self.cat_rows:
+            t = DeviceTable(np.array(self.cat_rows, dtype=_AXPY_DESC), self.device)
+            self.keep.append(t)
+            prog.call('dm_multi_add_f32', t.dev, t.n, self.max_cat_n, 1, Program.STREAM)
+        if self.pack_rows:
+            t = DeviceTable(np.array(self.pack_rows, dtype=_PACK_DESC), self.device)
+            self.keep.append(t)
+            prog.call('dm_dconv_pack_batch', t.dev, t.n, max(1, min(256, self.max_pack // 2048)), Program.STREAM)
+        self.prog = prog.finalize()
+
+    def _fingerprint(self):
+        v = 0
+        for t in self.watch:
+            v += t._version
+        return v
+
+    def refresh(self):
+        """Re-derive everything if a watched tensor changed (version counters) or somebody rewrote weights
+        through raw pointers since the last refresh (`dense_conv.weights_changed`: fused optimizer / EMA)."""
+        gen = dense_conv._GENERATION[0]
+        fp = self._fingerprint()
+        st = self.stamp
+        if st is not None and st[1] == fp and st[2] == dense_conv.LOAD_EPOCH[0]:
+            if st[0] == gen or not self.watch or not dense_conv._stale(st[0], self.watch[0].data_ptr()):
+                if st[0] != gen:
+                    self.stamp = (gen, fp, st[2])
+                return
+        self.prog.run([])
+        self.stamp = (gen, fp, dense_conv.LOAD_EPOCH[0])
+
+
+class DenseChainBuilder(object):
+
+    def __init__(self, name, device, training=True):
+        self.name, self.device, self.training = name, device, training
+        self.fwd = Program(name + '.fwd')
+        self.fa = self.fwd.layout('arena')
+        self.fws = self.fwd.slot('ws')
+        self.weights = _Weights(device)
+        self.inputs, self.outputs, self.out_diff = [], [], []
+        self.tape = []
+        self.params = []             # trainable parameters (or their virtual concatenations) that get a gradient
+        self.param_ids = {}
+        self.param_grad_refs, self.param_written = [], []
+        self.bn_modules = []         # training-mode BatchNorm layers (call counters)
+        self.math = _lib.lib().dm_dconv_get_math()
+
+    # ---- buffers ---------------------------------------------------------------------------------------------
+    def input(self, n, c, h, w, requires_grad):
+        ref = self.fwd.slot('in%d' % len(self.inputs))
+        b = Buf(ref, n, h, w, c, requires_grad, external=True)
+        self.inputs.append(b)
+        return b
+
+    def _new(self, n, h, w, c, rg):
+        return Buf(self.fa.floats(n, h, w, c), n, h, w, c, rg)
+
+    def output(self, buf, differentiable=True):
+        """differentiable=False: handed out as a plain value (nobody back-propagates through it)."""
+        self.outputs.append(buf)
+        self.out_diff.append(bool(differentiable) and buf.rg)
+        return buf
+
+    def _param(self, p, parts=None):
+        """Register a gradient target: a Parameter, or a virtual concatenation (tensor, [(param, row0, row1)])."""
+        if id(p) not in self.param_ids:
+            self.param_ids[id(p)] = len(self.params)
+            self.params.append((p, parts))
+            self.param_grad_refs.append(None)
+            self.param_written.append(False)
+        return self.param_ids[id(p)]
+
+    def _ws(self, prog, nbytes, slot):
+        if nbytes:
+            prog.need_workspace(nbytes)
+            return slot, int(nbytes)
+        return None, 0
+
+    # ---- forward emitters ------------------------------------------------------------------------------------
+    def _gemm(self, prog, ws_slot, x_ref, wp, planes_off, bias, residual, y_ref, geom, taps):
+        g, t, nbytes = dense_conv._plan('gemm', geom, taps)
+        ws, wb = self._ws(prog, nbytes, ws_slot)
+        prog.keep += [g, t]
+        prog.call('dm_dconv_gemm_planes', x_ref, wp, None if planes_off is None else wp.data_ptr() + planes_off,
+                  bias, residual, y_ref, g, t, ws, wb, Program.STREAM)
+
+    def _wants_planes(self, T, N, K, same):
+        return dense_conv.PLANES and same and 4 <= T <= 9 and K % 32 == 0 and N % 4 == 0 and N >= 64 and self.math == 2
+
+    def conv(self, x, weight, bias=None, stride=(1, 1), padding=(0, 0), relu=False, w_scale=None, residual=None,
+             weight_parts=None, bias_parts=None, bias_trainable=None):
+        """dense_conv._Conv2dFn: y = relu?(conv2d(x, weight * w_scale) + bias [+ residual]).  `weight` / `bias`:
+        Parameters, or chain-owned concatenations (`weight_parts` / `bias_parts` name the parameters behind them)."""
+        cout, cin, kh, kw = weight.shape
+        (sh, sw), (ph, pw) = stride, padding
+        c4 = _pad4(cin)
+        assert x.c == c4, 'chain input must carry %d channels' % c4
+        n, h, w = x.n, x.h, x.w
+        ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+        T = kh * kw
+        taps = [(a - ph, b - pw, a * kw + b) for a in range(kh) for b in range(kw)]
+        geom = [n, h, w, c4, ho, wo, cout, ho, wo, 0, 0, 1, 1, sh, sw, T, int(relu)]
+        same = sh == 1 and sw == 1 and ho == h and wo == w
+        wsrc = weight.detach()
+        wp, poff = self.weights.pack(wsrc, T, cout, c4, cout, cin, cin * T, T, 1, scale_n=w_scale,
+                                     planes=residual is None and self._wants_planes(T, cout, c4, same))
+        w_train = weight.requires_grad if weight_parts is None else any(p.requires_grad for p, _, _ in weight_parts)
+        if bias_trainable is None:
+            bias_trainable = bias is not None and (bias.requires_grad if bias_parts is None
+                                                   else any(p.requires_grad for p, _, _ in bias_parts))
+        self.weights.watch += [weight] if weight_parts is None else [p for p, _, _ in weight_parts]
+        y = self._new(n, ho, wo, cout, x.rg or w_train or bias_trainable)
+        if residual is not None:
+            assert (residual.n, residual.h, residual.w, residual.c) == (y.n, y.h, y.w, y.c)
+            y.rg = y.rg or residual.rg
+        bias_t = None if bias is None else bias.detach()
+        self._gemm(self.fwd, self.fws, x.ref, wp, poff, bias_t, None if residual is None else residual.ref, y.ref,
+                   geom, taps)
+        self.tape.append(('conv', dict(x=x, y=y, weight=weight, wsrc=wsrc, w_scale=w_scale, stride=(sh, sw),
+                                      padding=(ph, pw), relu=relu, residual=residual, w_train=w_train,
+                                      bias=bias if bias_trainable else None, weight_parts=weight_parts,
+                                      bias_parts=bias_parts, cin=cin)))
+        return y
+
+    def conv_transpose(self, x, weight, k):
+        """dense_conv._ConvTranspose2dFn (kernel == stride, no padding / bias)."""
+        cin, cout = weight.shape[0], weight.shape[1]
+        assert x.c == cin
+        n, h, w = x.n, x.h, x.w
+        T = k * k
+        wsrc = weight.detach()
+        wp, _ = self.weights.pack(wsrc, T, cout, cin, cout, cin, T, cout * T, 1)
+        self.weights.watch.append(weight)
+        y = self._new(n, h * k, w * k, cout, x.rg or weight.requires_grad)
+        for a in range(k):
+            for b in range(k):
+                self._gemm(self.fwd, self.fws, x.ref, wp, None, None, None, y.ref,
+                           [n, h, w, cin, h * k, w * k, cout, h, w, a, b, k, k, 1, 1, 1, 0], [(0, 0, a * k + b)])
+        self.tape.append(('convT', dict(x=x, y=y, weight=weight, wsrc=wsrc, k=k)))
+        return y
+
+    def bn_relu(self, x, bn, relu=True):
+        """Training-mode BatchNorm (+ ReLU) over the (N*H*W, C) rows: bn_relu._BNReLURows."""
+        L = _lib.lib()
+        c = x.c
+        assert bn.training and bn.track_running_stats and bn.momentum is not None
+        y = self._new(x.n, x.h, x.w, c, True)
+        mean, invstd = self.fa.floats(c), self.fa.floats(c)
+        ws, wb = self._ws(self.fwd, L.dm_bn_rows_workspace_bytes(x.rows, c), self.fws)
+        self.fwd.call('dm_bn_rows_forward', x.ref, x.rows, c, bn.weight.detach(), bn.bias.detach(), float(bn.eps),
+                      float(bn.momentum), bn.running_mean, bn.running_var, int(relu), y.ref, mean, invstd, ws, wb,
+                      Program.STREAM)
+        self.bn_modules.append(bn)
+        self.tape.append(('bn', dict(x=x, y=y, bn=bn, relu=relu, mean=mean, invstd=invstd)))
+        return y
+
+    def bn_eval(self, x, bn, relu=True):
+        """Evaluation-mode BatchNorm (+ ReLU) with the running statistics: bn_relu.bn_relu_rows' inference launch."""
+        y = self._new(x.n, x.h, x.w, x.c, False)
+        self.fwd.call('dm_bn_rows_eval', x.ref, x.rows, x.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                      bn.running_var, float(bn.eps), int(relu), y.ref, Program.STREAM)
+        return y
+
+    def maxpool(self, x, k, stride, pad):
+        ho, wo = (x.h + 2 * pad - k) // stride + 1, (x.w + 2 * pad - k) // stride + 1
+        y = self._new(x.n, ho, wo, x.c, x.rg)
+        self.fwd.call('dm_maxpool_nhwc', x.ref, x.n, x.h, x.w, x.c, k, stride, pad, y.ref, Program.STREAM)
+        self.tape.append(('maxpool', dict(x=x, y=y, k=k, stride=stride, pad=pad)))
+        return y
+
+    def resize_nearest(self, x, ho, wo):
+        y = self._new(x.n, ho, wo, x.c, x.rg)
+        self.fwd.call('dm_resize_nearest_nhwc', x.ref, x.n, x.h, x.w, x.c, ho, wo, y.ref, Program.STREAM)
+        self.tape.append(('resize', dict(x=x, y=y)))
+        return y
+
+    def concat(self, bufs):
+        """torch.cat(dim=1) of NHWC maps: column blocks of one wider map."""
+        n, h, w = bufs[0].n, bufs[0].h, bufs[0].w
+        c = sum(b.c for b in bufs)
+        y = self._new(n, h, w, c, any(b.rg for b in bufs))
+        off = 0
+        for b in bufs:
+            self.fwd.call('dm_copy2d_f32', b.ref, b.c, y.ref + off * 4, c, b.rows, b.c, Program.STREAM)
+            off += b.c
+        self.tape.append(('concat', dict(xs=list(bufs), y=y)))
+        return y
+
+    def split(self, x, widths):
+        """Column blocks of a map as separate dense maps (the anchor head's cls | box | dir predictions)."""
+        outs, off = [], 0
+        for wd in widths:
+            y = self._new(x.n, x.h, x.w, wd, x.rg)
+            self.fwd.call('dm_copy2d_f32', x.ref + off * 4, x.c, y.ref, wd, x.rows, wd, Program.STREAM)
+            outs.append(y)
+            off += wd
+        self.tape.append(('split', dict(x=x, ys=outs, widths=list(widths))))
+        return outs
+
+    # ---- backward generation ---------------------------------------------------------------------------------
+    def _build_backward(self):
+        bwd = self.bwd = Program(self.name + '.bwd')
+        self.bfa = bwd.slot('fwd_arena')             # the forward arena (saved activations), same offsets
+        ba = self.ba = bwd.layout('bwd_arena')
+        self.bws = bwd.slot('ws')
+        in_slots = [bwd.slot('in%d' % i) for i in range(len(self.inputs))]
+        gout_slots = [bwd.slot('gout%d' % i) for i in range(len(self.outputs))]
+        in_of = {id(b): s for b, s in zip(self.inputs, in_slots)}
+
+        def act(buf):       # a forward activation as the backward program sees it
+            return in_of[id(buf)] if buf.external else S(self.bfa.slot, buf.ref.off)
+
+        grads = {}          # id(buf) -> [ref, owned]
+
+        def add_grad(buf, ref, owned):
+            if not buf.rg:
+                return
+            cur = grads.get(id(buf))
+            if cur is None:
+                grads[id(buf)] = [ref, owned]
+                return
+            if cur[1]:
+                bwd.call('dm_add_mask_f32', cur[0], ref, None, cur[0], buf.numel, Program.STREAM)
+            else:
+                out = ba.floats(buf.numel)
+                bwd.call('dm_add_mask_f32', cur[0], ref, None, out, buf.numel, Program.STREAM)
+                grads[id(buf)] = [out, True]
+
+        for o, s, diff in zip(self.outputs, gout_slots, self.out_diff):
+            if diff:
+                add_grad(o, s, False)
+        # gradient regions of the parameters, in registration order
+
+        def pgrad(p):
+            i = self.param_ids[id(p)]
+            if self.param_grad_refs[i] is None:
+                self.param_grad_refs[i] = ba.floats(p.numel())
+            acc = self.param_written[i]
+            self.param_written[i] = True
+            return self.param_grad_refs[i], int(acc)
+
+        L = _lib.lib()
+        for kind, d in reversed(self.tape):
+            if kind == 'conv':
+                y = d['y']
+                if id(y) not in grads:
+                    continue
+                dy = grads[id(y)][0]
+                if d['relu']:
+                    m = ba.floats(y.numel)
+                    bwd.call('dm_relu_mask_f32', dy, act(y), m, y.numel, Program.STREAM)
+                    dy = m
+                if d['residual'] is not None:
+                    add_grad(d['residual'], dy, d['relu'])
+                x, weight = d['x'], d['weight']
+                cout, cin, kh, kw = weight.shape
+                (sh, sw), (ph, pw) = d['stride'], d['padding']
+                T, c4 = kh * kw, x.c
+                n, h, w, ho, wo = x.n, x.h, x.w, y.h, y.w
+                if x.rg:
+                    same = sh == 1 and sw == 1 and ho == h and wo == w
+                    wt, poff = self.weights.pack(d['wsrc'], T, c4, cout, cin, cout, T, cin * T, 1, scale_k=d['w_scale'],
+                                                 planes=self._wants_planes(T, c4, cout, same))
+                    dx = ba.floats(x.numel)
+                    if sh == 1 and sw == 1:
+                        taps = [(ph - a, pw - b, a * kw + b) for a in range(kh) for b in range(kw)]
+                        cur = grads.get(id(x))
+                        res = None
+                        if cur is not None and poff is None:
+                            # the gradient x already received from another consumer rides in the epilogue
+                            res = cur[0]
+                        self._gemm(bwd, self.bws, dy, wt, poff if res is None else None, None, res, dx,
+                                   [n, ho, wo, cout, h, w, c4, h, w, 0, 0, 1, 1, 1, 1, T, 0], taps)
+                        if res is not None:
+                            grads[id(x)] = [dx, True]
+                        else:
+                            add_grad(x, dx, True)
+                    else:
+                        classes = []
+                        for ry in range(sh):
+                            for rx in range(sw):
+                                taps = [((ry + ph - a) // sh, (rx + pw - b) // sw, a * kw + b)
+                                        for a in range(kh) for b in range(kw)
+                                        if (ry + ph - a) % sh == 0 and (rx + pw - b) % sw == 0]
+                                lh, lw = (h - ry + sh - 1) // sh, (w - rx + sw - 1) // sw
+                                classes.append((ry, rx, lh, lw, taps))
+                        if any(not c[4] for c in classes):
+                            bwd.call('dm_fill_bytes', dx, 0, x.numel * 4, Program.STREAM)
+                        for ry, rx, lh, lw, taps in classes:
+                            if taps and lh > 0 and lw > 0:
+                                self._gemm(bwd, self.bws, dy, wt, None, None, None, dx,
+                                           [n, ho, wo, cout, h, w, c4, lh, lw, ry, rx, sh, sw, 1, 1, len(taps), 0], taps)
+                        add_grad(x, dx, True)
+                if d['w_train']:
+                    target = weight
+                    self._param(target, d['weight_parts'])
+                    gref, acc = pgrad(target)
+                    g, t, nbytes = dense_conv._plan('wgrad', [n, ho, wo, cout, c4, h, w, sh, sw, T],
+                                                    [(a - ph, b - pw) for a in range(kh) for b in range(kw)])
+                    bwd.keep += [g, t]
+                    ws, wb = self._ws(bwd, nbytes, self.bws)
+                    bwd.call('dm_dconv_wgrad', dy, act(x), gref, d['w_scale'], g, t, d['cin'], d['cin'] * T, T, 1, acc,
+                             ws, wb, Program.STREAM)
+                if d['bias'] is not None:
+                    self._param(d['bias'], d['bias_parts'])
+                    gref, acc = pgrad(d['bias'])
+                    nb = L.dm_colsum_workspace_bytes(y.rows, cout)
+                    ws, wb = self._ws(bwd, nb, self.bws)
+                    bwd.call('dm_colsum_f32', dy, y.rows, cout, gref, acc, ws, wb, Program.STREAM)
+            elif kind == 'convT':
+                y, x, weight, k = d['y'], d['x'], d['weight'], d['k']
+                if id(y) not in grads:
+                    continue
+                dy = grads[id(y)][0]
+                cin, cout = weight.shape[0], weight.shape[1]
+                n, h, w = x.n, x.h, x.w
+                T = k * k
+                taps = [(a, b) for a in range(k) for b in range(k)]
+                if x.rg:
+                    wt, _ = self.weights.pack(d['wsrc'], T, cin, cout, cin, cout, cout * T, T, 1)
+                    dx = ba.floats(x.numel)
+                    self._gemm(bwd, self.bws, dy, wt, None, None, None, dx,
+                               [n, h * k, w * k, cout, h, w, cin, h, w, 0, 0, 1, 1, k, k, T, 0],
+                               [(a, b, a * k + b) for a, b in taps])
+                    add_grad(x, dx, True)
+                if weight.requires_grad:
+                    self._param(weight)
+                    gref, acc = pgrad(weight)
+                    g, t, nbytes = dense_conv._plan('wgrad', [n, h, w, cin, cout, h * k, w * k, k, k, T], taps)
+                    bwd.keep += [g, t]
+                    ws, wb = self._ws(bwd, nbytes, self.bws)
+                    bwd.call('dm_dconv_wgrad', act(x), dy, gref, None, g, t, cout, cout * T, T, 1, acc, ws, wb,
+                             Program.STREAM)
+            elif kind == 'bn':
+                y, x, bn = d['y'], d['x'], d['bn']
+                if id(y) not in grads:
+                    continue
+                dy = grads[id(y)][0]
+                c = x.c
+                gx = ba.floats(x.numel)
+                self._param(bn.weight)
+                self._param(bn.bias)
+                gg, acc_g = pgrad(bn.weight)
+                gb, acc_b = pgrad(bn.bias)
+                assert not acc_g and not acc_b, 'a BatchNorm layer is used once per chain'
+                ws, wb = self._ws(bwd, L.dm_bn_rows_workspace_bytes(x.rows, c), self.bws)
+                mean = S(self.bfa.slot, d['mean'].off)
+                invstd = S(self.bfa.slot, d['invstd'].off)
+                bwd.call('dm_bn_rows_backward', dy, act(x), x.rows, c, bn.weight.detach(), bn.bias.detach(), mean,
+                         invstd, int(d['relu']), gx, gg, gb, ws, wb, Program.STREAM)
+                add_grad(x, gx, True)
+            elif kind == 'maxpool':
+                if id(d['y']) in grads and d['x'].rg:
+                    if d['k'] != 1:
+                        raise NotImplementedError('max-pool backward with kernel > 1 is not on the chained path')
+                    x, y = d['x'], d['y']
+                    gx = ba.floats(x.numel)
+                    bwd.call('dm_subsample_nhwc_backward', grads[id(y)][0], x.n, x.h, x.w, x.c, d['stride'], gx,
+                             Program.STREAM)
+                    add_grad(x, gx, True)
+            elif kind == 'resize':
+                x, y = d['x'], d['y']
+                if id(y) in grads and x.rg:
+                    cur = grads.get(id(x))
+                    if cur is not None and cur[1]:
+                        bwd.call('dm_resize_nearest_nhwc_backward', grads[id(y)][0], x.n, x.h, x.w, x.c, y.h, y.w,
+                                 cur[0], 1, Program.STREAM)
+                    else:
+                        gx = ba.floats(x.numel)
+                        bwd.call('dm_resize_nearest_nhwc_backward', grads[id(y)][0], x.n, x.h, x.w, x.c, y.h, y.w,
+                                 gx, 0, Program.STREAM)
+                        add_grad(x, gx, True)
+            elif kind == 'concat':
+                y = d['y']
+                if id(y) not in grads:
+                    continue
+                dy, off = grads[id(y)][0], 0
+                for b in d['xs']:
+                    if b.rg:
+                        gx = ba.floats(b.numel)
+                        bwd.call('dm_copy2d_f32', dy + off * 4, y.c, gx, b.c, b.rows, b.c, Program.STREAM)
+                        add_grad(b, gx, True)
+                    off += b.c
+            elif kind == 'split':
+                x = d['x']
+                if not x.rg or not any(id(y) in grads for y in d['ys']):
+                    continue
+                gx = ba.floats(x.numel)
+                if sum(d['widths']) != x.c or not all(id(y) in grads for y in d['ys']):
+                    bwd.call('dm_fill_bytes', gx, 0, x.numel * 4, Program.STREAM)
+                off = 0
+                for y, wd in zip(d['ys'], d['widths']):
+                    if id(y) in grads:
+                        bwd.call('dm_copy2d_f32', grads[id(y)][0], wd, gx + off * 4, x.c, x.rows, wd, Program.STREAM)
+                    off += wd
+                add_grad(x, gx, True)
+            else:
+                raise AssertionError(kind)
+        self.input_grad_refs = [grads.get(id(b), [None])[0] if b.rg else None for b in self.inputs]
+
+    def build(self):
+        needs_bwd = self.training and any(self.out_diff)
+        if needs_bwd:
+            self._build_backward()
+            self.bwd.finalize()
+        else:
+            self.bwd = None
+        self.weights.finalize()
+        self.fwd.finalize()
+        return DenseChain(self)
+
+
+LOAD_HOOKED = set()
+
+
+def _watch_loads(modules):
+    """load_state_dict() of any of these modules invalidates every chain's derived weights."""
+    for m in modules:
+        if id(m) not in LOAD_HOOKED:
+            LOAD_HOOKED.add(id(m))
+            m.register_load_state_dict_post_hook(lambda *_: dense_conv.LOAD_EPOCH.__setitem__(0, dense_conv.LOAD_EPOCH[0] + 1))
+
+
+class DenseChain(object):
+    """A built chain: `__call__(*inputs)` -> output tensors (NCHW-shaped, NHWC memory), differentiable w.r.t. the
+    inputs that require grad and the trainable parameters it was built over."""
+
+    def __init__(self, b):
+        self.name, self.device = b.name, b.device
+        self.fwd, self.bwd, self.weights = b.fwd, b.bwd, b.weights
+        self.fwd_bytes = b.fa.size
+        self.inputs, self.outputs, self.out_diff = b.inputs, b.outputs, b.out_diff
+        self.bn_modules = b.bn_modules
+        self.params = [p for p, _ in b.params] if b.bwd is not None else []
+        self.param_parts = [parts for _, parts in b.params] if b.bwd is not None else []
+        if self.bwd is not None:
+            self.bwd_bytes = b.ba.size
+            self.param_grad_refs = b.param_grad_refs
+            self.input_grad_refs = b.input_grad_refs
+            # autograd inputs: the real Parameters behind the gradient targets
+            leaves, seen = [], set()
+            for p, parts in b.params:
+                for q in ([p] if parts is None else [q for q, _, _ in parts]):
+                    if q.requires_grad and id(q) not in seen:
+                        seen.add(id(q))
+                        leaves.append(q)
+            self.leaves = leaves
+        else:
+            self.leaves = []
+        self.out_shapes = [(o.n, o.h, o.w, o.c) for o in self.outputs]
+        self.first_ptr = self.weights.watch[0].data_ptr() if self.weights.watch else 0
+
+    def launches(self):
+        return len(self.fwd), (len(self.bwd) if self.bwd is not None else 0)
+
+    def valid(self):
+        """False once the parameters were re-homed (flat arenas, .to()): the tables hold raw addresses."""
+        return not self.weights.watch or self.weights.watch[0].data_ptr() == self.first_ptr
+
+    def _check_inputs(self, xs):
+        out = []
+        for x, b in zip(xs, self.inputs):
+            if not x.is_cuda:
+                raise _lib.DetMatchHipError('chains run on the MI355X only (got a %s tensor); there is no CPU path'
+                                            % x.device)
+            if tuple(x.shape) != b.shape:
+                raise ValueError('chain %s: input %s, built for %s' % (self.name, tuple(x.shape), b.shape))
+            out.append(dense_conv._cl(x))
+        return out
+
+    def forward_raw(self, xs):
+        """-> (output tensors, arena); xs: dense NHWC tensors."""
+        self.weights.refresh()
+        arena = torch.empty(self.fwd_bytes, dtype=torch.uint8, device=self.device)
+        ws = _lib.workspace(self.fwd.ws_bytes, self.device, 'chain') if self.fwd.ws_bytes else None
+        base = arena.data_ptr()
+        self.fwd.run([base, 0 if ws is None else ws.data_ptr()] + [x.data_ptr() for x in xs])
+        for bn in self.bn_modules:
+            if bn.num_batches_tracked is not None:
+                bn_relu._bump(bn)
+        f = arena.view(torch.float32)
+        outs = []
+        for o, (n, h, w, c) in zip(self.outputs, self.out_shapes):
+            off = o.ref.off // 4
+            outs.append(f[off:off + n * h * w * c].view(n, h, w, c).permute(0, 3, 1, 2))
+        return outs, arena
+
+    def backward_raw(self, arena, xs, gouts):
+        """-> (input gradients, gradients of `leaves`)."""
+        garena = torch.empty(self.bwd_bytes, dtype=torch.uint8, device=self.device)
+        ws = _lib.workspace(self.bwd.ws_bytes, self.device, 'chain') if self.bwd.ws_bytes else None
+        gs, gptr = [], []
+        for g, (n, h, w, c), diff in zip(gouts, self.out_shapes, self.out_diff):
+            if not diff:
+                gptr.append(0)
+                continue
+            if g is None:
+                g = torch.zeros((n, h, w, c), dtype=torch.float32, device=self.device).permute(0, 3, 1, 2)
+            g = dense_conv._cl(g)
+            gs.append(g)
+            gptr.append(g.data_ptr())
+        self.bwd.run([arena.data_ptr(), garena.data_ptr(), 0 if ws is None else ws.data_ptr()] +
+                     [x.data_ptr() for x in xs] + gptr)
+        f = garena.view(torch.float32)
+        gin = []
+        for b, ref in zip(self.inputs, self.input_grad_refs):
+            if ref is None:
+                gin.append(None)
+            else:
+                off = ref.off // 4
+                gin.append(f[off:off + b.numel].view(b.n, b.h, b.w, b.c).permute(0, 3, 1, 2))
+        by_leaf = {}
+        for p, parts, ref in zip(self.params, self.param_parts, self.param_grad_refs):
+            if ref is None:
+                continue
+            off = ref.off // 4
+            if parts is None:
+                by_leaf[id(p)] = f[off:off + p.numel()].view(p.shape)
+            else:
+                per_row = p[0].numel() if p.dim() > 1 else 1
+                for q, r0, r1 in parts:
+                    by_leaf[id(q)] = f[off + r0 * per_row:off + r1 * per_row].view(q.shape)
+        return gin, [by_leaf.get(id(q)) for q in self.leaves]
+
+    def __call__(self, *xs):
+        xs = self._check_inputs(xs)
+        if self.bwd is None or not torch.is_grad_enabled():
+            return self.forward_raw([x.detach() for x in xs])[0]
+        return _ChainFn.apply(self, len(xs), *(list(xs) + self.leaves))
+
+
+class _ChainFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, chain, n_in, *tensors):
+        xs = [t.detach() for t in tensors[:n_in]]
+        outs, arena = chain.forward_raw(xs)
+        ctx.chain, ctx.arena, ctx.xs = chain, arena, xs
+        nd = [o for o, diff in zip(outs, chain.out_diff) if not diff]
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        chain = ctx.chain
+        gin, gleaves = chain.backward_raw(ctx.arena, ctx.xs, gouts)
+        ctx.arena = ctx.xs = None
+        return (None, None) + tuple(gin) + tuple(gleaves)

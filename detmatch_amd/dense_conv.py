@@ -50,6 +50,11 @@ def set_math(mode):
     _lib.check(_lib.lib().dm_dconv_set_math(_MATH[mode]), 'dm_dconv_set_math')
 
 
+def get_math_code():
+    """The library's arithmetic code (includes the developer bits); chains are built per code."""
+    return _lib.lib().dm_dconv_get_math()
+
+
 def get_math():
     code = _lib.lib().dm_dconv_get_math()
     return [k for k, v in _MATH.items() if v == code][0]      # ('fp32_split_nopatch' reads back as 'fp32_split')
@@ -84,6 +89,7 @@ def weights_changed(ptr_lo=None, ptr_hi=None):
 
 
 _FLOOR = [0]        # entries packed before this generation are stale whatever the events say
+LOAD_EPOCH = [0]    # bumped by load_state_dict() of a module a chain was built over (dense_chain._watch_loads)
 
 
 def _stale(entry_gen, src_ptr):

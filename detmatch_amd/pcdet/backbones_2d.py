@@ -200,9 +200,92 @@ class BaseBEVBackbone(nn.Module):
             data_dict['spatial_features_%dx' % int(full / f.shape[2])] = f
         return True
 
+    # ---- the shape-static chain as ONE C-ABI call per pass (chain.py / dense_chain.py) -------------------------------
+    def _build_chain(self, x, train):
+        """Blocks + deblocks + concatenation + the anchor head's three 1x1 convolutions as one op table (forward) and
+        its mirror (backward).  train: BatchNorm with batch statistics (fused row kernels); otherwise the running
+        statistics folded into the convolutions exactly as `_Stage.__call__` does."""
+        from ..dense_chain import DenseChainBuilder, _watch_loads
+        head = self.fused_head
+        blocks, deblocks = self._plan()
+        b = DenseChainBuilder('bev_backbone+heads.%s' % ('train' if train else 'eval'), x.device, training=train)
+        n, c, h, w = x.shape
+        cur = b.input(n, c, h, w, bool(train and x.requires_grad))
+        branches, levels = [], []
+
+        def stage(st, t):
+            conv, bn = st.conv, st.bn
+            if isinstance(conv, nn.ConvTranspose2d):
+                k = int(conv.stride[0])
+                assert conv.bias is None and tuple(conv.kernel_size) == (k, k)
+                y = b.conv_transpose(t, conv.weight, k)
+                return b.bn_relu(y, bn) if train else b.bn_eval(y, bn)
+            assert conv.bias is None
+            if train:
+                return b.bn_relu(b.conv(t, conv.weight, None, tuple(conv.stride), tuple(st.padding)), bn)
+            s_, sh_ = b.weights.fold(bn)
+            return b.conv(t, conv.weight, sh_, tuple(conv.stride), tuple(st.padding), relu=True, w_scale=s_,
+                          bias_trainable=False)
+
+        for lvl, block in enumerate(blocks):
+            for st in block:
+                cur = stage(st, cur)
+            levels.append(cur)
+            branches.append(stage(deblocks[lvl][0], cur) if deblocks else cur)
+        out = branches[0] if len(branches) == 1 else b.concat(branches)
+        if len(deblocks) > len(blocks):
+            out = stage(deblocks[-1][0], out)
+        heads = [head.conv_cls, head.conv_box] + ([head.conv_dir_cls] if head.conv_dir_cls is not None else [])
+        widths = [m.out_channels for m in heads]
+        total = sum(widths) + (-sum(widths)) % 4
+        wparts, bparts, r = [], [], 0
+        for m in heads:
+            wparts.append((m.weight, r, r + m.out_channels))
+            bparts.append((m.bias, r, r + m.out_channels))
+            r += m.out_channels
+        wcat = b.weights.cat([m.weight for m in heads], pad_to=total)
+        bcat = b.weights.cat([m.bias for m in heads], pad_to=total)
+        y = b.conv(out, wcat, bcat, (1, 1), (0, 0), weight_parts=wparts, bias_parts=bparts)
+        for t in b.split(y, widths):
+            b.output(t)
+        b.output(out, differentiable=False)
+        for f in levels:
+            b.output(f, differentiable=False)
+        _watch_loads([self, head])
+        return b.build(), len(heads)
+
+    def _chained(self, data_dict, x):
+        from .. import chain as _chain
+        head = self.fused_head
+        if not _chain.ENABLED or head is None or not x.is_cuda or x.dtype != torch.float32:
+            return False
+        train = self.training and torch.is_grad_enabled() and head.training
+        if not train and (self.training or head.training or x.requires_grad or
+                          (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
+            return False
+        if any(isinstance(m, nn.BatchNorm2d) and not (m.track_running_stats and m.affine and m.momentum is not None)
+               for m in self.modules()):
+            return False
+        from .. import dense_conv
+        key = (bool(train), tuple(x.shape), dense_conv.get_math_code())
+        cache = self.__dict__.setdefault('_chains', {})
+        hit = cache.get(key)
+        if hit is None or not hit[0].valid():
+            if len(cache) > 8:
+                cache.clear()
+            hit = cache[key] = self._build_chain(x, train)
+        ch, n_heads = hit
+        outs = ch(x)
+        data_dict['dense_head_convs'] = tuple(t.permute(0, 2, 3, 1) for t in outs[:n_heads])
+        data_dict['spatial_features_2d'] = outs[n_heads]
+        full = x.shape[2]
+        for f in outs[n_heads + 1:]:
+            data_dict['spatial_features_%dx' % int(full / f.shape[2])] = f
+        return True
+
     def forward(self, data_dict):
         x = data_dict['spatial_features']
-        if self._graphed(data_dict, x):
+        if self._graphed(data_dict, x) or self._chained(data_dict, x):
             return data_dict
         out, levels = self._levels(x)
         for stride, f in levels:

@@ -943,6 +943,78 @@ int dm_profile_count(void);
 int dm_profile_get(int i, int *kind, int *a, int *b, int *c, int *rows, int *kvol,
                    unsigned long long *table, float *ms);
 
+/* ------------------------------------------------------------------------ */
+/* Chain-level issue (host-side launch interpreter)                          */
+/* ------------------------------------------------------------------------ */
+/* The reference issues its step one Python call -> one ATen / extension call -> one kernel at a time
+ * (e.g. pcdet/models/backbones_2d/base_bev_backbone.py:38-69: 15 conv + 15 BatchNorm + 15 ReLU module calls,
+ * each a pybind trip; mmdet ResNet-50 + FPN + RPNHead of configs/detmatch/001/detmatch/split_0.py:39-99:
+ * ~70 module calls; pcdet/ops/pointnet2/pointnet2_stack/pointnet2_modules.py:58-104).  A CHAIN replaces the
+ * per-kernel trips of such a shape-static sub-graph by ONE call: `ops_host` is a table of launches of THIS
+ * library's own entry points, argument k of op i = slots_host[slot[k]] + imm[k] (slot < 0: the immediate alone;
+ * float / double arguments travel as their bit patterns in the low 32 / all 64 bits).  What varies between
+ * calls (arena base addresses, the stream, data-dependent counts) sits in the slot table; the op table is built
+ * once per shape signature by the host layer.  dm_chain_run calls the entries in order on the calling thread and
+ * stops at the first non-zero return code (*failed_op_host = index of that op, -1 if none).  Same kernels, same
+ * order, same arguments as the op-by-op path — results are bit-identical to it.
+ *   dm_chain_fn_index      index of an entry point by name (-1: not launchable through a chain)
+ *   dm_chain_fn_signature  its argument classes, one letter each: p pointer, i int, l long long, z size_t,
+ *                          f float, d double (the host layer checks them against its own binding table) */
+#define DM_CHAIN_MAX_ARGS 32
+typedef struct dm_chain_op {
+  int32_t fn;
+  int32_t nargs;
+  int32_t slot[DM_CHAIN_MAX_ARGS];
+  int64_t imm[DM_CHAIN_MAX_ARGS];
+} dm_chain_op;
+int dm_chain_fn_count(void);
+int dm_chain_fn_index(const char *name);
+const char *dm_chain_fn_name(int fn);
+const char *dm_chain_fn_signature(int fn);
+int dm_chain_run(const dm_chain_op *ops_host, int n_ops, const long long *slots_host, int n_slots,
+                 int *failed_op_host);
+
+/* Element-wise / layout glue of the chained sub-graphs: what sat between this library's kernels as ATen launches
+ * in the op-by-op path, as entry points so that a sub-graph is one op table.  NHWC fp32, C % 4 == 0.
+ *   dm_relu_mask_f32   out = y > 0 ? grad : 0          (aten::threshold_backward behind F.relu, e.g.
+ *                      mmdet ResNet Bottleneck.forward / mmcv ConvModule activations)
+ *   dm_add_mask_f32    out = (a + b) [masked by y > 0]; b, y optional: the gradient of a residual block's input
+ *                      (shortcut + main branch, then the previous block's ReLU) in one pass
+ *   dm_colsum_f32      out[c] (+)= sum_r x[r][c]: the bias gradient of a convolution (aten::sum over N,H,W);
+ *                      two stages, fixed order.  C <= 1024
+ *   dm_resize_nearest_nhwc / _backward   F.interpolate(mode='nearest') to a given size and its gradient
+ *                      (mmdet FPN.forward top-down path, fpn.py:167-176 of mmdet 2.14); backward may accumulate
+ *   dm_maxpool_nhwc    F.max_pool2d(k, stride, pad): ResNet stem (3, 2, 1) and FPN's extra level (1, 2, 0)
+ *   dm_subsample_nhwc_backward   gradient of max_pool2d(kernel 1, stride s): zeros except the sampled pixels
+ *   dm_copy2d_f32      rows x cols floats between pitched matrices (torch.cat / channel slices of NHWC maps,
+ *                      base_bev_backbone.py:108 `torch.cat(ups, dim=1)`; 16-byte accesses when cols, pitches and
+ *                      addresses allow, scalar otherwise)
+ *   dm_fill_bytes      hipMemsetAsync
+ *   dm_bn_fold_batch   evaluation-mode BatchNorm as (scale, shift) for every layer of a table in one launch
+ *                      (rows of 56 bytes {gamma, beta, mean, var, scale_out, shift_out: pointers; float eps; int C}):
+ *                      scale = gamma * rsqrt(var + eps), shift = beta - mean * scale
+ *   dm_multi_add_f32   dst_i += src_i (assign != 0: dst_i = src_i) for a table of (dst, src, n: 24-byte rows) in
+ *                      one launch (gradient accumulation into the flat arena: torch._foreach_add_; the
+ *                      concatenated bias of the anchor head's three 1x1 convolutions: torch.cat) */
+int dm_relu_mask_f32(const float *grad, const float *y, float *out, long long n, dm_stream_t stream);
+int dm_add_mask_f32(const float *a, const float *b, const float *y, float *out, long long n, dm_stream_t stream);
+size_t dm_colsum_workspace_bytes(long long rows, int C);
+int dm_colsum_f32(const float *x, long long rows, int C, float *out, int accumulate, void *workspace,
+                  size_t workspace_bytes, dm_stream_t stream);
+int dm_resize_nearest_nhwc(const float *x, int B, int Hi, int Wi, int C, int Ho, int Wo, float *y,
+                           dm_stream_t stream);
+int dm_resize_nearest_nhwc_backward(const float *grad_y, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                    float *grad_x, int accumulate, dm_stream_t stream);
+int dm_maxpool_nhwc(const float *x, int B, int Hi, int Wi, int C, int k, int stride, int pad, float *y,
+                    dm_stream_t stream);
+int dm_subsample_nhwc_backward(const float *grad_y, int B, int Hi, int Wi, int C, int stride, float *grad_x,
+                               dm_stream_t stream);
+int dm_copy2d_f32(const float *src, long long src_pitch, float *dst, long long dst_pitch, long long rows, int cols,
+                  dm_stream_t stream);
+int dm_fill_bytes(void *dst, int byte_value, size_t nbytes, dm_stream_t stream);
+int dm_bn_fold_batch(const void *table_dev, int n_rows, int max_channels, dm_stream_t stream);
+int dm_multi_add_f32(const void *table_dev, int n_rows, long long max_n, int assign, dm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
