@@ -63,6 +63,17 @@ class _Weights(object):
         self.prog = None
         self.stamp = None
         self.max_fold_c, self.max_cat_n, self.max_pack = 1, 1, 1
+        self.mirrors = []        # (chain-owned tensor, getter of the tensor it mirrors)
+        self.mirror_key = None   # callable -> hashable: the mirrors are re-copied when it changes
+        self._mirror_stamp = object()
+
+    def mirror(self, getter):
+        """A chain-owned copy (stable address) of a tensor the host layer derives itself and may REPLACE by a new
+        tensor object (FrozenBN.scale_shift's cached affine map): re-copied whenever `mirror_key()` changes."""
+        src = getter()
+        own = torch.empty_like(src)
+        self.mirrors.append((own, getter))
+        return own
 
     def fold(self, bn):
         """(scale, shift) buffers of an evaluation-mode BatchNorm / FrozenBN layer."""
@@ -134,6 +145,13 @@ class _Weights(object):
         gen = dense_conv._GENERATION[0]
         fp = self._fingerprint()
         st = self.stamp
+        if self.mirrors:
+            mk = self.mirror_key() if self.mirror_key is not None else None
+            if mk != self._mirror_stamp:
+                with torch.no_grad():
+                    torch._foreach_copy_([o for o, _ in self.mirrors], [g() for _, g in self.mirrors])
+                self._mirror_stamp = mk
+                st = None
         if st is not None and st[1] == fp and st[2] == dense_conv.LOAD_EPOCH[0]:
             if st[0] == gen or not self.watch or not dense_conv._stale(st[0], self.watch[0].data_ptr()):
                 if st[0] != gen:

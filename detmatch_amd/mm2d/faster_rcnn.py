@@ -663,6 +663,105 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
     def extract_feat(self, img):
         return self.neck(self.backbone(img))
 
+    # ---- backbone + FPN + RPN convolutions as ONE C-ABI call per pass (chain.py / dense_chain.py) ------------------
+    def _build_trunk_chain(self, img, train):
+        """The op table of ResNet (frozen BatchNorm folded into the weight packs, shortcut sum + ReLU in the last
+        GEMM of a bottleneck), FPN (top-down sum in the lateral GEMM's epilogue) and the RPN head (3x3 + ReLU, then
+        objectness | deltas as one 1x1 GEMM per level), and — train — its mirror: mmdet ResNet / FPN / RPNHead
+        forward as configured at configs/detmatch/001/detmatch/split_0.py:39-99.  Outputs: the five pyramid maps,
+        then the five raw head maps (what `extract_feat` + `rpn_head` hand to prefetch_trunk / the inference path)."""
+        from ..dense_chain import DenseChainBuilder, _watch_loads
+        bb, neck, rpn = self.backbone, self.neck, self.rpn_head
+        b = DenseChainBuilder('faster_rcnn.trunk.%s' % ('train' if train else 'eval'), img.device, training=train)
+        n, _, h, w = img.shape
+        x = b.input(n, 4, h, w, False)
+
+        def cbn(t, conv, bn, relu, residual=None):
+            # the layer's own cached (scale, shift) tensors (FrozenBN.scale_shift: torch.rsqrt differs from the device
+            # rsqrtf in the last bit, and the chain must equal the op-by-op path bit for bit); they are constants
+            # until FrozenBN.GENERATION / a load_state_dict moves them: the chain keeps copies at stable addresses and
+            # re-copies them when either counter moves
+            s_ = b.weights.mirror(lambda bn=bn: bn.scale_shift()[0])
+            sh_ = b.weights.mirror(lambda bn=bn: bn.scale_shift()[1])
+            return b.conv(t, conv.weight, sh_, tuple(conv.stride), tuple(conv.padding), relu=relu, w_scale=s_,
+                          residual=residual, bias_trainable=False)
+
+        x = cbn(x, bb.conv1, bb.bn1, True)
+        x = b.maxpool(x, 3, 2, 1)
+        feats = []
+        for i, name in enumerate(bb.res_layers):
+            for blk in getattr(bb, name):
+                out = cbn(x, blk.conv1, blk.bn1, True)
+                out = cbn(out, blk.conv2, blk.bn2, True)
+                idt = x if blk.downsample is None else cbn(x, blk.downsample[0], blk.downsample[1], False)
+                x = cbn(out, blk.conv3, blk.bn3, True, residual=idt)
+            if i in bb.out_indices:
+                feats.append(x)
+        assert len(feats) == neck.num_ins
+
+        def plain(t, m, relu=False, residual=None):
+            return b.conv(t, m.weight, m.bias, tuple(m.stride), tuple(m.padding), relu=relu, residual=residual)
+
+        lat = [None] * len(feats)
+        lat[-1] = plain(feats[-1], neck.lateral_convs[-1].conv)
+        for i in range(len(feats) - 2, -1, -1):
+            up = b.resize_nearest(lat[i + 1], feats[i].h, feats[i].w)
+            lat[i] = plain(feats[i], neck.lateral_convs[i].conv, residual=up)
+        outs = [plain(t, c.conv) for c, t in zip(neck.fpn_convs, lat)]
+        for _ in range(neck.num_outs - len(outs)):
+            outs.append(b.maxpool(outs[-1], 1, 2, 0))
+        a = rpn.num_anchors
+        total = 5 * a + (-5 * a) % 4
+        wcat = b.weights.cat([rpn.rpn_cls.weight, rpn.rpn_reg.weight], pad_to=total)
+        bcat = b.weights.cat([rpn.rpn_cls.bias, rpn.rpn_reg.bias], pad_to=total)
+        wparts = [(rpn.rpn_cls.weight, 0, a), (rpn.rpn_reg.weight, a, 5 * a)]
+        bparts = [(rpn.rpn_cls.bias, 0, a), (rpn.rpn_reg.bias, a, 5 * a)]
+        raws = []
+        for t in outs:
+            t2 = plain(t, rpn.rpn_conv, relu=True)
+            raws.append(b.conv(t2, wcat, bcat, (1, 1), (0, 0), weight_parts=wparts, bias_parts=bparts))
+        for t in outs + raws:
+            b.output(t)
+        _watch_loads([self])
+        from .backbone import FrozenBN
+        b.weights.mirror_key = lambda: (FrozenBN.GENERATION, dense_conv.LOAD_EPOCH[0])
+        return b.build()
+
+    def _trunk_chain(self, img):
+        """-> (pyramid maps, raw RPN maps) through the chain, or None when it does not apply."""
+        from .. import chain as _chain
+        from .backbone import FrozenBN
+        if not _chain.ENABLED or not img.is_cuda or img.dtype != torch.float32 or img.shape[1] != 3:
+            return None
+        train = torch.is_grad_enabled() and not self._frozen()
+        if train and not self.training:
+            return None
+        if self.neck.num_outs < self.neck.num_ins or self.backbone.conv1.weight.requires_grad:
+            return None
+        key = (bool(train), tuple(img.shape), dense_conv.get_math_code())
+        cache = self.__dict__.setdefault('_trunk_chains', {})
+        ch = cache.get(key)
+        if ch is None or not ch.valid():
+            if len(cache) > 8:
+                cache.clear()
+            ch = cache[key] = self._build_trunk_chain(img, train)
+        x4 = dense_conv._pad_channels(dense_conv._cl(img.detach()), 4)
+        outs = ch(x4)
+        k = len(outs) // 2
+        return tuple(outs[:k]), list(outs[k:])
+
+    def _trunk(self, img):
+        """extract_feat + rpn_head -> (x, cls, reg, raw)."""
+        hit = self._trunk_chain(img)
+        a = self.rpn_head.num_anchors
+        if hit is not None:
+            x, raw = hit
+            self.rpn_head._raw_levels = raw
+            return x, [y[:, :a] for y in raw], [y[:, a:5 * a] for y in raw], raw
+        x = self.extract_feat(img)
+        cls, reg = self.rpn_head(x)
+        return x, cls, reg, self.rpn_head._raw_levels
+
     # ---- one trunk pass for several forward_train calls of an iteration (scheduling only) --------------------
     # The backbone's BatchNorm is frozen (eval), FPN and RPN have none: the samples of a batch are independent, so
     # backbone + FPN + RPN convolutions of the labeled and the unlabeled images of a DetMatch iteration can run as
@@ -690,9 +789,7 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
             n_feat = len(outs) // 2
             x, raw = tuple(outs[:n_feat]), outs[n_feat:]
         else:
-            x = self.extract_feat(batch)
-            self.rpn_head(x)
-            raw = self.rpn_head._raw_levels
+            x, _, _, raw = self._trunk(batch)
             outs = list(x) + list(raw)
         leaves = [t.detach().requires_grad_(True) for t in outs]
         spans, lo = {}, 0
@@ -737,8 +834,7 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
         if shared is not None:
             x, cls, reg = shared
         else:
-            x = self.extract_feat(img)
-            cls, reg = self.rpn_head(x)
+            x, cls, reg, _ = self._trunk(img)
         losses = self.rpn_head.loss(cls, reg, gt_bboxes, img_metas)
         proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg['rpn'] if self.test_cfg else None)
         proposals = self.rpn_head.get_bboxes([c.detach() for c in cls], [r.detach() for r in reg],
@@ -756,9 +852,7 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
         return hit[1]
 
     def _trunk_inference(self, img):
-        x = self.extract_feat(img)
-        cls, reg = self.rpn_head(x)
-        return x, cls, reg, self.rpn_head._raw_levels
+        return self._trunk(img)
 
     def simple_test_pre_nms(self, img, img_metas):
         """The body of SimpleTest_2D.forward (processors_2d.py:36-84)."""
@@ -771,8 +865,7 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
                 sec = self.__dict__['_trunk_section'] = StaticSection(self._trunk_inference, 'faster_rcnn.trunk')
             x, cls, reg, self.rpn_head._raw_levels = sec(img, frozen=frozen)
         else:
-            x = self.extract_feat(img)
-            cls, reg = self.rpn_head(x)
+            x, cls, reg, _ = self._trunk(img)
         proposals = self.rpn_head.get_bboxes(cls, reg, img_metas, self.test_cfg['rpn'])
         return self.roi_head.simple_test_pre_nms(x, proposals, img_metas)
 

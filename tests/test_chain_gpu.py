@@ -116,3 +116,68 @@ def test_chain_refuses_cpu_tensors():
     p = chain.Program('x')
     with pytest.raises(_lib.DetMatchHipError):
         p.call('dm_relu_mask_f32', torch.zeros(4), torch.zeros(4), torch.zeros(4), 4, chain.Program.STREAM)
+
+
+def _frcnn(dev):
+    from detmatch_amd import configs
+    from detmatch_amd.mm2d import FasterRCNN
+    torch.manual_seed(0)
+    cfg = configs.frcnn_kitti_model()
+    cfg.pop('type')
+    m = FasterRCNN(train_cfg=configs.frcnn_train_cfg(), test_cfg=configs.frcnn_test_cfg(), **cfg).to(dev)
+    with torch.no_grad():      # zero_init_residual zeroes bn3.weight: make every branch carry signal
+        for mod in m.backbone.modules():
+            if type(mod).__name__ == 'FrozenBN':
+                mod.weight.uniform_(0.5, 1.0)
+                mod.bias.uniform_(-0.1, 0.1)
+                mod.running_mean.uniform_(-0.1, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+        for p in list(m.rpn_head.parameters()) + list(m.neck.parameters()):
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)
+    return m
+
+
+def _trunk_run(m, img, train, enabled):
+    from detmatch_amd import chain
+    old = chain.ENABLED
+    chain.ENABLED = enabled
+    try:
+        m.train(train)
+        for p in m.parameters():
+            p.grad = None
+        with torch.set_grad_enabled(train):
+            x, cls, reg, raw = m._trunk(img)
+        out = dict(x=[t.detach().clone() for t in x], raw=[t.detach().clone() for t in raw])
+        if train:
+            g = torch.Generator(device='cpu').manual_seed(2)
+            loss = sum((t * torch.randn(t.shape, generator=g).to(t.device)).sum() for t in list(x) + list(raw))
+            loss.backward()
+            out['grads'] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        return out
+    finally:
+        chain.ENABLED = old
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_frcnn_trunk_chain_equals_op_by_op(dev, train):
+    m = _frcnn(dev)
+    if not train:
+        for p in m.parameters():
+            p.requires_grad_(False)
+    img = torch.randn(2, 3, 128, 192, device=dev) * 50
+    ref = _trunk_run(m, img, train, enabled=False)
+    got = _trunk_run(m, img, train, enabled=True)
+    assert m.__dict__.get('_trunk_chains'), 'the chain did not run'
+    ch = list(m.__dict__['_trunk_chains'].values())[0]
+    assert ch.launches()[0] >= 70
+    for i, (a, b) in enumerate(zip(got['x'] + got['raw'], ref['x'] + ref['raw'])):
+        _same(a, b, 'trunk output %d' % i)
+    if train:
+        assert set(got['grads']) == set(ref['grads']) and len(ref['grads']) > 40
+        for k, b in ref['grads'].items():
+            # tensors with three gradient contributions (a pyramid input feeds the lateral conv and both branches of
+            # the next stage) are summed in another order than autograd's: equal to fp32 rounding, not bit for bit
+            a = got['grads'][k]
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7, \
+                'grad %s: %g vs max %g' % (k, float((a - b).abs().max()), float(b.abs().max()))

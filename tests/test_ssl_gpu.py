@@ -540,8 +540,8 @@ def test_shared_student_2d_trunk_equals_separate_passes(dev, monkeypatch):
         monkeypatch.setenv('DM_SHARE_2D_TRUNK', share)
         monkeypatch.setenv('DM_LOOKAHEAD', '0')
         calls = []
-        orig = FasterRCNN.extract_feat
-        monkeypatch.setattr(FasterRCNN, 'extract_feat', lambda self, img, _o=orig: (calls.append((id(self), int(img.shape[0]))), _o(self, img))[1])
+        orig = FasterRCNN._trunk          # backbone + FPN + RPN convolutions (one chained call, or extract_feat + rpn_head)
+        monkeypatch.setattr(FasterRCNN, '_trunk', lambda self, img, _o=orig: (calls.append((id(self), int(img.shape[0]))), _o(self, img))[1])
         wl = DetMatchTrainWorkload(2, dev, seed=3)
         stu = wl.model.student.detector_2d
         w0 = stu.neck.lateral_convs[0].conv.weight.detach().clone()
@@ -554,7 +554,7 @@ def test_shared_student_2d_trunk_equals_separate_passes(dev, monkeypatch):
         assert mine == ([4, 4] if share == '1' else [2, 2, 2, 2]), mine
         res.append((logs, (stu.neck.lateral_convs[0].conv.weight.detach() - w0).clone(),
                     stu.backbone.layer3[0].conv2.weight.detach().clone()))
-        monkeypatch.setattr(FasterRCNN, 'extract_feat', orig)
+        monkeypatch.setattr(FasterRCNN, '_trunk', orig)
         del wl
     (la, da, wa), (lb, db, wb) = res
     # First iteration, same weights.  The trunk outputs agree up to the summation order of the split-K layers

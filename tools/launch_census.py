@@ -61,6 +61,7 @@ def main():
         wrap(d.model, 'post_processing', tag + '3d.post_processing')
     for tag, d in dets2d.items():
         wrap(d, 'extract_feat', tag + '2d.backbone+fpn')
+        wrap(d, '_trunk', tag + '2d.trunk(backbone+fpn+rpn)')
         wrap(d.rpn_head, 'forward', tag + '2d.rpn.forward')
         wrap(d.rpn_head, 'loss', tag + '2d.rpn.loss')
         wrap(d.rpn_head, 'get_bboxes', tag + '2d.rpn.get_bboxes')
