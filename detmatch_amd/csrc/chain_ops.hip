@@ -70,13 +70,23 @@ __global__ void colsum_partial_kernel(const float *__restrict__ x, long long row
   }
 }
 
+// 32 columns per workgroup, 8 lanes per column: lane l sums the partials p = l, l + 8, ... in order, then the eight
+// lane sums are added in lane order (a fixed tree: bitwise reproducible)
 __global__ void colsum_final_kernel(const float *__restrict__ partial, int n_part, int C, float *__restrict__ out,
                                     int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sh[8][32];
+  const int col = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + col;
   float s = 0.f;
-  for (int p = 0; p < n_part; ++p) s += partial[(long long)p * C + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < C)
+    for (int p = lane; p < n_part; p += 8) s += partial[(long long)p * C + c];
+  sh[lane][col] = s;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    float t = sh[0][col];
+    for (int l = 1; l < 8; ++l) t += sh[l][col];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // torch's 'nearest': src = min(floor(dst * (float)in / out), in - 1)
@@ -262,8 +272,8 @@ extern "C" int dm_add_mask_f32(const float *a, const float *b, const float *y, f
 }
 
 static int colsum_blocks(long long rows, int *rows_per_block) {
-  long long per = (rows + 1023) / 1024;
-  if (per < 64) per = 64;
+  long long per = (rows + 511) / 512;
+  if (per < 32) per = 32;
   *rows_per_block = (int)per;
   return (int)((rows + per - 1) / per);
 }
@@ -281,8 +291,8 @@ extern "C" int dm_colsum_f32(const float *x, long long rows, int C, float *out, 
   const int nb = colsum_blocks(rows, &per);
   colsum_partial_kernel<<<nb, kThreads, 0, (hipStream_t)stream>>>(x, rows, C, (float *)workspace, per);
   DM_CHECK_LAUNCH();
-  colsum_final_kernel<<<dm_ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>((const float *)workspace, nb, C, out,
-                                                                            accumulate);
+  colsum_final_kernel<<<dm_ceil_div(C, 32), 256, 0, (hipStream_t)stream>>>((const float *)workspace, nb, C, out,
+                                                                           accumulate);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -181,3 +181,87 @@ def test_frcnn_trunk_chain_equals_op_by_op(dev, train):
             a = got['grads'][k]
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7, \
                 'grad %s: %g vs max %g' % (k, float((a - b).abs().max()), float(b.abs().max()))
+
+
+# ---- the element-wise / layout entry points of csrc/chain_ops.hip against plain torch ---------------------------------
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def test_chain_ops_match_torch(dev):
+    import torch.nn.functional as F
+    from detmatch_amd import _lib
+    L = _lib.lib()
+    st = _lib.stream()
+    g = torch.Generator(device='cpu').manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    # relu mask / add + mask
+    a, b, y = rnd(5, 1028), rnd(5, 1028), rnd(5, 1028)
+    out = torch.empty_like(a)
+    _lib.check(L.dm_relu_mask_f32(a.data_ptr(), y.data_ptr(), out.data_ptr(), a.numel(), st), 'relu_mask')
+    assert torch.equal(out, torch.where(y > 0, a, torch.zeros_like(a)))
+    _lib.check(L.dm_add_mask_f32(a.data_ptr(), b.data_ptr(), y.data_ptr(), out.data_ptr(), a.numel(), st), 'add_mask')
+    assert torch.equal(out, torch.where(y > 0, a + b, torch.zeros_like(a)))
+    _lib.check(L.dm_add_mask_f32(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), a.numel(), st), 'add')
+    assert torch.equal(out, a + b)
+    # column sums (bias gradient): float64 reference, accumulate flag, run-to-run identical
+    for rows, c in ((70400, 72 + 0), (333, 256), (31, 4), (122880, 256)):
+        c = (c + 3) // 4 * 4
+        x = rnd(rows, c)
+        ws = torch.empty(L.dm_colsum_workspace_bytes(rows, c), dtype=torch.uint8, device=dev)
+        o1 = torch.full((c,), 7.0, device=dev)
+        _lib.check(L.dm_colsum_f32(x.data_ptr(), rows, c, o1.data_ptr(), 0, ws.data_ptr(), ws.numel(), st), 'colsum')
+        want = x.double().sum(0)
+        assert float((o1.double() - want).abs().max()) <= 2e-6 * float(x.abs().sum(0).max())
+        o2 = o1.clone()
+        _lib.check(L.dm_colsum_f32(x.data_ptr(), rows, c, o2.data_ptr(), 1, ws.data_ptr(), ws.numel(), st), 'colsum')
+        o3 = torch.empty_like(o1)
+        _lib.check(L.dm_colsum_f32(x.data_ptr(), rows, c, o3.data_ptr(), 0, ws.data_ptr(), ws.numel(), st), 'colsum')
+        assert torch.equal(o3, o1) and torch.allclose(o2, 2 * o1, rtol=1e-6)
+    # nearest resize and its gradient (exact 2x and a ragged size), max-pool, sub-sampling gradient
+    for (hi, wi), (ho, wo) in (((12, 39), (24, 78)), ((7, 5), (16, 13)), ((24, 78), (12, 39))):
+        x = rnd(2, 8, hi, wi)
+        xn = _nhwc(x)
+        yn = torch.empty(2, ho, wo, 8, device=dev)
+        _lib.check(L.dm_resize_nearest_nhwc(xn.data_ptr(), 2, hi, wi, 8, ho, wo, yn.data_ptr(), st), 'resize')
+        want = F.interpolate(x, size=(ho, wo), mode='nearest')
+        assert torch.equal(yn, _nhwc(want))
+        gy = rnd(2, 8, ho, wo)
+        xr = x.clone().requires_grad_(True)
+        F.interpolate(xr, size=(ho, wo), mode='nearest').backward(gy)
+        gx = torch.full((2, hi, wi, 8), 3.0, device=dev)
+        _lib.check(L.dm_resize_nearest_nhwc_backward(_nhwc(gy).data_ptr(), 2, hi, wi, 8, ho, wo, gx.data_ptr(), 0, st), 'rb')
+        assert torch.allclose(gx, _nhwc(xr.grad), rtol=1e-6, atol=1e-6)
+        _lib.check(L.dm_resize_nearest_nhwc_backward(_nhwc(gy).data_ptr(), 2, hi, wi, 8, ho, wo, gx.data_ptr(), 1, st), 'rb')
+        assert torch.allclose(gx, 2 * _nhwc(xr.grad), rtol=1e-6, atol=1e-6)
+    x = rnd(2, 8, 33, 47)
+    x[0, 0, 3, 3] = float('nan')
+    for k, s, p in ((3, 2, 1), (1, 2, 0), (2, 2, 0)):
+        want = F.max_pool2d(x, k, s, p)
+        yn = torch.empty(_nhwc(want).shape, device=dev)
+        _lib.check(L.dm_maxpool_nhwc(_nhwc(x).data_ptr(), 2, 33, 47, 8, k, s, p, yn.data_ptr(), st), 'maxpool')
+        assert torch.equal(torch.nan_to_num(yn, nan=123.0), torch.nan_to_num(_nhwc(want), nan=123.0))
+    xr = rnd(2, 8, 33, 47).requires_grad_(True)
+    yr = F.max_pool2d(xr, 1, 2)
+    gy = rnd(*yr.shape)
+    yr.backward(gy)
+    gx = torch.empty(2, 33, 47, 8, device=dev)
+    _lib.check(L.dm_subsample_nhwc_backward(_nhwc(gy).data_ptr(), 2, 33, 47, 8, 2, gx.data_ptr(), st), 'subsample')
+    assert torch.equal(gx, _nhwc(xr.grad))
+    # pitched copies: 16-byte path and the scalar path (18 | 42 | 12 column blocks)
+    src = rnd(1000, 72)
+    for off, wd in ((0, 18), (18, 42), (60, 12), (8, 64)):
+        dst = torch.zeros(1000, wd, device=dev)
+        _lib.check(L.dm_copy2d_f32(src.data_ptr() + off * 4, 72, dst.data_ptr(), wd, 1000, wd, st), 'copy2d')
+        assert torch.equal(dst, src[:, off:off + wd])
+    # multi-tensor add / assign
+    import numpy as np
+    from detmatch_amd.dense_chain import _AXPY_DESC
+    ds, ss = [rnd(n) for n in (5, 1000, 77)], [rnd(n) for n in (5, 1000, 77)]
+    want = [d + s_ for d, s_ in zip(ds, ss)]
+    rows = np.array([(d.data_ptr(), s_.data_ptr(), d.numel()) for d, s_ in zip(ds, ss)], dtype=_AXPY_DESC)
+    tab = torch.from_numpy(rows.view(np.uint8).copy()).to(dev)
+    _lib.check(L.dm_multi_add_f32(tab.data_ptr(), 3, 1000, 0, st), 'multi_add')
+    assert all(torch.equal(d, w) for d, w in zip(ds, want))
+    _lib.check(L.dm_multi_add_f32(tab.data_ptr(), 3, 1000, 1, st), 'multi_assign')
+    assert all(torch.equal(d, s_) for d, s_ in zip(ds, ss))
