@@ -63,6 +63,7 @@ class _Weights(object):
         self.prog = None
         self.stamp = None
         self.max_fold_c, self.max_cat_n, self.max_pack = 1, 1, 1
+        self.calls = []          # further launches of the refresh program: (entry name, args...)
         self.mirrors = []        # (chain-owned tensor, getter of the tensor it mirrors)
         self.mirror_key = None   # callable -> hashable: the mirrors are re-copied when it changes
         self._mirror_stamp = object()
@@ -131,6 +132,8 @@ class _Weights(object):
             t = DeviceTable(np.array(self.pack_rows, dtype=_PACK_DESC), self.device)
             self.keep.append(t)
             prog.call('dm_dconv_pack_batch', t.dev, t.n, max(1, min(256, self.max_pack // 2048)), Program.STREAM)
+        for c in self.calls:
+            prog.call(*c)
         self.prog = prog.finalize()
 
     def _fingerprint(self):

@@ -571,7 +571,7 @@ class SSL(nn.Module):
         unlabeled images).  Needs a driver that calls finish_deferred_backward() after the last backward pass
         (OptimizerHook does): `share_2d_trunk` is set by the callers that have one."""
         self._deferred = []
-        if not getattr(self, 'share_2d_trunk', False) or lane_mode not in (None, 'glue', 'serial') \
+        if not getattr(self, 'share_2d_trunk', False) or lane_mode not in (None, 'glue', 'serial', 'branches') \
                 or not torch.is_grad_enabled():
             return
         from .bbox_utils import mlvl_get, mlvl_getattr
@@ -588,8 +588,23 @@ class SSL(nn.Module):
                 det = mlvl_getattr(self, m.ssl_obj_attr)
                 if torch.is_tensor(img) and hasattr(det, 'prefetch_trunk'):
                     groups.setdefault(id(det), (det, []))[1].append(img)
+        lanes = getattr(self, '_lanes', None)
         for det, imgs in groups.values():
-            if len(imgs) >= 2 and det.prefetch_trunk(imgs):
+            if len(imgs) < 2:
+                continue
+            if lanes is not None and lane_mode == 'branches':
+                # the shared pass belongs to the 2D lane: the modules that consume its slices run there, and autograd
+                # replays its (deferred) backward on the stream of its forward — underneath the 3D backward
+                side = lanes.stream(1)
+                lanes.current = 1
+                try:
+                    with torch.cuda.stream(side):
+                        ok = det.prefetch_trunk(imgs)
+                finally:
+                    lanes.current = 0
+            else:
+                ok = det.prefetch_trunk(imgs)
+            if ok:
                 self._deferred.append(det)
 
     def finish_deferred_backward(self):
@@ -747,10 +762,10 @@ class SSL(nn.Module):
         # not queue behind it.  Measured 90.7 / 87.2 / 90.2 ms against 85.1 / 88.7 / 90.4 (same box, alternated): the wait
         # moves, the totals of host and device work do not change.
         trunk_late = _TRUNK_AFTER_TEACHER and torch.is_grad_enabled()
-        if not trunk_late:
-            self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
         if lanes is not None:
             lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
+        if not trunk_late:
+            self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
         unlab_modules = list(self.unlab_ssl_modules)
         if lanes is not None and (lanes.mode in ('glue', 'pairs') or getattr(self, 'lane_hoist', False)):
             # The teacher's inference passes read nothing but the raw unlabeled batch: issue them first, so

@@ -468,6 +468,24 @@ class StackSAModuleMSG(nn.Module):
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None,
                 empty_voxel_set_zeros=True):
         new_features_list = []
+        if self.row_layout and self.pool_method == 'max_pool' and features is not None and xyz.is_cuda:
+            # the whole call as one chained launch table behind one autograd node (sa_chain.py), when it applies
+            from . import chain as _chain
+            if _chain.ENABLED and fused_on():
+                train = self.mlps[0][1].training
+                key = (xyz_batch_cnt.numel(), new_xyz.shape[0], features.shape[1], train)
+                cache = self.__dict__.setdefault('_chains', {})
+                ch = cache.get(key)
+                if ch is None or (ch is not False and not ch.valid()):
+                    from .sa_chain import SAChain
+                    if len(cache) > 8:
+                        cache.clear()
+                    ch = cache[key] = SAChain(self, key[0], key[1], key[2], xyz.device, train) \
+                        if SAChain.applicable(self, key[1], key[2], train) else False
+                if ch is not False and (train or not (torch.is_grad_enabled() and (
+                        features.requires_grad or any(p.requires_grad for p in self.parameters())))):
+                    return new_xyz, ch(xyz, _i32(xyz_batch_cnt).contiguous(), new_xyz, _i32(new_xyz_batch_cnt).contiguous(),
+                                       features)
         if self.row_layout and self.pool_method == 'max_pool':
             # Row layout: a grouped reference is one contiguous row, the shared 1x1-conv MLP a GEMM
             # over (M*nsample, C) rows, BatchNorm2d a column reduction over the same M*nsample

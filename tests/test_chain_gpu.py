@@ -265,3 +265,67 @@ def test_chain_ops_match_torch(dev):
     assert all(torch.equal(d, w) for d, w in zip(ds, want))
     _lib.check(L.dm_multi_add_f32(tab.data_ptr(), 3, 1000, 1, st), 'multi_assign')
     assert all(torch.equal(d, s_) for d, s_ in zip(ds, ss))
+
+
+# ---- StackSAModuleMSG as one chained call (sa_chain.py) ----------------------------------------------------------------
+def _sa_run(sa, args, feats, train, enabled, own_wgrad):
+    from detmatch_amd import chain, pointnet2_stack as pn
+    old, old_w = chain.ENABLED, pn.TallSkinnyLinear.OWN_WGRAD
+    chain.ENABLED, pn.TallSkinnyLinear.OWN_WGRAD = enabled, own_wgrad
+    try:
+        sa.train(train)
+        for p in sa.parameters():
+            p.grad = None
+        f = feats.clone().requires_grad_(train)
+        with torch.set_grad_enabled(train):
+            _, out = sa(*args, features=f)
+        res = dict(out=out.detach().clone())
+        if train:
+            g = torch.Generator(device='cpu').manual_seed(4)
+            (out * torch.randn(out.shape, generator=g).to(out.device)).sum().backward()
+            res['gf'] = f.grad.clone()
+            res['grads'] = {n: p.grad.clone() for n, p in sa.named_parameters()}
+        res['state'] = {k: v.clone() for k, v in sa.state_dict().items()}
+        return res
+    finally:
+        chain.ENABLED, pn.TallSkinnyLinear.OWN_WGRAD = old, old_w
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_sa_module_chain_equals_op_by_op(dev, train):
+    from detmatch_amd import pointnet2_stack as pn
+    torch.manual_seed(5)
+    g = torch.Generator(device='cpu').manual_seed(6)
+    c, m_per, counts = 32, 1024, [5000, 3777]
+    sa = pn.StackSAModuleMSG(radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[c, 32, 32], [c, 32, 64]], use_xyz=True,
+                             pool_method='max_pool').to(dev)
+    with torch.no_grad():
+        for mod in sa.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5), mod.bias.uniform_(-0.2, 0.2)
+                mod.running_mean.uniform_(-0.1, 0.1), mod.running_var.uniform_(0.5, 2.0)
+    state = copy.deepcopy(sa.state_dict())
+    n = sum(counts)
+    xyz = (torch.rand(n, 3, generator=g) * torch.tensor([20.0, 20.0, 3.0])).to(dev)
+    feats = torch.randn(n, c, generator=g).to(dev)
+    new_xyz = torch.cat([xyz[:counts[0]][:m_per], xyz[counts[0]:][:m_per]]).contiguous() + 0.05
+    args = (xyz, torch.tensor(counts, dtype=torch.int32, device=dev), new_xyz,
+            torch.tensor([m_per, m_per], dtype=torch.int32, device=dev))
+    ref = _sa_run(sa, args, feats, train, enabled=False, own_wgrad=True)
+    sa.load_state_dict(state)
+    got = _sa_run(sa, args, feats, train, enabled=True, own_wgrad=True)
+    assert any(v is not False for v in sa.__dict__.get('_chains', {}).values()), 'the chain did not run'
+    _same(got['out'], ref['out'], 'pooled features')
+    for k in ref['state']:
+        _same(got['state'][k], ref['state'][k], 'state ' + k)
+    if train:
+        # (the scatter of the grouped rows' gradient accumulates with atomic adds: equal to rounding, run to run)
+        assert float((got['gf'] - ref['gf']).abs().max()) <= 1e-5 * float(ref['gf'].abs().max())
+        for k in ref['grads']:
+            _same(got['grads'][k], ref['grads'][k], 'grad ' + k)
+        # against the op-by-op default (weight gradients of the tall-skinny GEMMs on a batched BLAS call): fp32 rounding
+        sa.load_state_dict(state)
+        blas = _sa_run(sa, args, feats, train, enabled=False, own_wgrad=False)
+        for k in blas['grads']:
+            a, b = got['grads'][k], blas['grads'][k]
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, k
