@@ -113,11 +113,23 @@ def other_kernel_groups(wl):
     def fps(xyz, cnt, npoint):
         return timed('fps', float(xyz.shape[0]) * 12, f0, xyz, cnt, npoint)
     dense_conv._gemm, dense_conv._wgrad, pn2.furthest_point_sample_stack = gemm, wgrad, fps
+    # kernel-quality numbers: this ONE extra step is issued op by op (no chains: a chained launch cannot be bracketed
+    # from Python) and on one stream (a HIP-event pair around a launch would otherwise include the time its kernel
+    # waits for CUs held by another lane) — the same kernels with the same arguments as the timed steps
+    from detmatch_amd import chain
+    model = getattr(wl, 'model', None)
+    saved = (chain.ENABLED, getattr(model, 'two_lanes', None), getattr(model, 'lane_mode', None))
+    chain.ENABLED = False
+    if model is not None and saved[1] is not None:
+        model.two_lanes, model.lane_mode = False, 'glue'
     try:
         wl.step()
         torch.cuda.synchronize()
     finally:
         dense_conv._gemm, dense_conv._wgrad, pn2.furthest_point_sample_stack = g0, w0, f0
+        chain.ENABLED = saved[0]
+        if model is not None and saved[1] is not None:
+            model.two_lanes, model.lane_mode = saved[1], saved[2]
     out = {}
     for kind in ('gemm', 'wgrad'):
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs[kind])
@@ -135,7 +147,8 @@ def other_kernel_groups(wl):
                 frac_of_fp32_mfma_peak=round(fl / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), math=math,
                 peak_is='dense bf16 matrix peak / 6 (six bf16 products per fp32-class product)'
                 if peak not in (MFMA_F32_PEAK_TFLOPS, MFMA_BF16_PEAK_TFLOPS) else 'dense matrix peak of the instruction',
-                timing='HIP events around each launch (includes the launch gap of short kernels)')
+                timing='HIP events around each launch (includes the launch gap of short kernels), in one extra step '
+                       'issued op by op on one stream')
     if recs['fps']:
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs['fps'])
         by = sum(w for w, _, _ in recs['fps'])

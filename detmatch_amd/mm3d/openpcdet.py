@@ -162,7 +162,12 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
                            gt_bboxes_ignore=None):
         """openpcdet.py:79-160"""
         assert gt_bboxes_ignore is None
-        res = self._base_batch(points, img_metas)
+        return self.add_gt(self._base_batch(points, img_metas), points, gt_bboxes_3d, gt_labels_3d)
+
+    @torch.no_grad()
+    def add_gt(self, res, points, gt_bboxes_3d, gt_labels_3d):
+        """The ground-truth half of train_to_openpcdet (openpcdet.py:100-160): `gt_boxes` of a batch dict whose
+        label-independent part may already have been issued (PVRCNN.run_modules(until=...))."""
         dev = points[0].device
         trans = []
         for boxes, labels in zip(gt_bboxes_3d, gt_labels_3d):

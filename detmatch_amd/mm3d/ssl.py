@@ -24,6 +24,7 @@ def add_prefix(inputs, prefix):
 
 
 _TRUNK_AFTER_TEACHER = os.environ.get('DM_TRUNK_AFTER_TEACHER', '0') == '1'
+_ISSUE_EARLY = os.environ.get('DM_ISSUE_EARLY', '1') == '1'      # A/B switch of SSL modules' issue_early
 
 
 class _LaneDict(dict):
@@ -199,13 +200,13 @@ class _Lanes(object):
         for s in self.streams[1:]:
             s.wait_stream(self.main)
 
-    def run(self, module, ssl_obj, batch_dict):
+    def run(self, module, ssl_obj, batch_dict, method='forward'):
         lane = self.lane_of(module)
         self.current, self.pending = lane, []
         with torch.cuda.stream(self.stream(lane)):
             if self.rng is not None:
                 self.rng.enter(module)
-            out = module.forward(ssl_obj, batch_dict)
+            out = getattr(module, method)(ssl_obj, batch_dict)
             ev = torch.cuda.Event()
             ev.record(self.stream(lane))
         for tok in self.pending:
@@ -815,6 +816,17 @@ class SSL(nn.Module):
                 if hook is not None:      # e.g. FlatGradDDP.collect
                     hook()
             lab_dict['sup_losses'] = {k: v.detach() for k, v in sup.items()}
+        if getattr(self, 'issue_early', True) and _ISSUE_EARLY:
+            # Scheduling only: every pass of the unlabeled chain that can start before its inputs from the chain
+            # exist (teacher inference up to its read-back; the label-independent trunk of the student's pass) is
+            # issued now, in chain order, so that the read-backs further down find the device done.
+            for m in unlab_modules:
+                if hasattr(m, 'issue_early'):
+                    if lanes is not None:
+                        lanes.run(m, self, unlab_dict, method='issue_early')
+                    else:
+                        rng.enter(m)
+                        m.issue_early(self, unlab_dict)
         for m in schedule(unlab_modules):
             unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
         if lanes is not None:

@@ -76,6 +76,14 @@ def _threshold_pseudo(entries, score_thr, includes_bg, empty_boxes):
     return boxes, labels
 
 
+class _Early(object):
+    """Holder of a pass that was issued early (kept opaque: a stream-lane batch dict wraps plain dicts)."""
+    __slots__ = ('value',)
+
+    def __init__(self, value):
+        self.value = value
+
+
 # ------------------------------------------------------------------ 3D (OpenPCDet) modules
 @SSL_MODULES.register_module()
 class Opd_SimpleTest_3D(object):
@@ -107,11 +115,27 @@ class Opd_SimpleTest_3D(object):
             return detector.prepare_geometry_steps(cur['points'], cur['img_metas'], ws_tag)
         return None
 
+    def issue_early(self, ssl_obj, batch_dict):
+        """Scheduling only: the whole pass up to its read-back, issued before the host needs the result
+        (SSL.forward_train calls this for the modules of the unlabeled chain right after the labeled chain), so
+        that the read-back in forward() finds the device done instead of stalling the issue of everything else."""
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        model = getattr(detector, 'model', None)
+        if model is None or model.training or not hasattr(model, 'forward_issue'):
+            return
+        cur = mlvl_get(batch_dict, self.batch_dict_key)
+        batch = detector._base_batch(cur['points'], cur['img_metas'])
+        cur['_early.' + self.out_bboxes_key] = _Early(model.forward_issue(batch))
+
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
         cur = mlvl_get(batch_dict, self.batch_dict_key)
-        batch = detector._base_batch(cur['points'], cur['img_metas'])
-        pred_dicts, _ = detector.model(batch)
+        state = cur.pop('_early.' + self.out_bboxes_key, None) if isinstance(cur, dict) else None
+        if state is not None:
+            pred_dicts, _ = detector.model.forward_finish(state.value)
+        else:
+            batch = detector._base_batch(cur['points'], cur['img_metas'])
+            pred_dicts, _ = detector.model(batch)
         cur[self.out_bboxes_key] = _pred_dicts_to_tuples(pred_dicts)
         return batch_dict
 
@@ -151,6 +175,20 @@ class Opd_HardPseudoLabel_3D(object):
             return detector.prepare_geometry_steps(cur['points'], cur['img_metas'], ws_tag)
         return None
 
+    def issue_early(self, ssl_obj, batch_dict):
+        """Scheduling only: the label-independent part of the student's pass (voxel features, sparse backbone, BEV
+        backbone, key-point encoder — everything in front of the first target assignment) issued before the
+        pseudo-labels exist; forward() adds the labels and runs the rest.  Same kernels in the same order on the
+        same stream as the undivided pass."""
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        model = getattr(detector, 'model', None)
+        if model is None or not model.training or not hasattr(model, 'label_independent_until') \
+                or model.label_independent_until() is None:
+            return
+        cur = mlvl_get(batch_dict, self.target_batch_dict_key)
+        batch = detector._base_batch(cur['points'], cur['img_metas'])
+        cur['_early.trunk3d'] = _Early(model.run_modules(batch, until=model.label_independent_until()))
+
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
         cur = mlvl_get(batch_dict, self.target_batch_dict_key)
@@ -158,7 +196,11 @@ class Opd_HardPseudoLabel_3D(object):
             mlvl_get(batch_dict, self.target_bboxes_key), self.score_thr,
             self.cls_includes_bg_pred,
             lambda s: LiDARInstance3DBoxes(s.new_zeros((0, self.box_dim))))
-        batch = detector.train_to_openpcdet(cur['points'], cur['img_metas'], boxes, labels)
+        early = cur.pop('_early.trunk3d', None) if isinstance(cur, dict) else None
+        if early is not None:
+            batch = detector.add_gt(early.value, cur['points'], boxes, labels)
+        else:
+            batch = detector.train_to_openpcdet(cur['points'], cur['img_metas'], boxes, labels)
         batch = detector.model.run_modules(batch)
         loss, _, _ = detector.model.get_training_loss()
         batch_dict = _accumulate(ssl_obj, batch_dict, add_prefix(dict(loss=loss.mean()), self.name),
@@ -437,9 +479,16 @@ class SimpleTest_2D(object):
         self.batch_dict_key = batch_dict_key
         self.out_bboxes_key = out_bboxes_key
 
+    def issue_early(self, ssl_obj, batch_dict):
+        """Scheduling only (see Opd_SimpleTest_3D.issue_early): the pass has no read-back of its own — the NMS module
+        that consumes it has —, so issuing it early is running it early."""
+        self.forward(ssl_obj, batch_dict)
+
     def forward(self, ssl_obj, batch_dict):
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
         cur = mlvl_get(batch_dict, self.batch_dict_key)
+        if self.out_bboxes_key in cur:       # issued early
+            return batch_dict
         cur[self.out_bboxes_key] = detector.simple_test_pre_nms(cur['img'], cur['img_metas'])
         return batch_dict
 

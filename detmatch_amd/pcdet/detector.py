@@ -123,13 +123,24 @@ class PVRCNN(nn.Module):
                 mods = mods[:i] + [bev, pfe] + mods[i + 2:]
         return mods
 
-    def run_modules(self, batch_dict):
+    def run_modules(self, batch_dict, until=None):
         """The module chain.  `after_backbone_3d` (a one-shot callable set on the instance by the stream
         scheduler of SSL.forward_train, mode 'pairs') is called right after the sparse backbone has been
         issued: from there on the pass consists of many small kernels, underneath which the paired 2D
-        pass is issued on its own stream."""
+        pass is issued on its own stream.
+        `until`: stop in front of this module; the rest of the chain is remembered in the batch dict and runs when
+        run_modules is called on it again (SSL issues the label-independent part of a pass — everything in front
+        of the first module that reads `gt_boxes` — before the pseudo-labels exist)."""
         bb = getattr(self, 'backbone_3d', None)
-        for cur_module in self._order(batch_dict):
+        todo = batch_dict.pop('_pending_modules', None)
+        if todo is None:
+            todo = list(self._order(batch_dict))
+        while todo:
+            cur_module = todo[0]
+            if until is not None and cur_module is until:
+                batch_dict['_pending_modules'] = todo
+                return batch_dict
+            todo.pop(0)
             batch_dict = cur_module(batch_dict)
             if cur_module is bb:
                 hook = self.__dict__.pop('after_backbone_3d', None)
@@ -137,12 +148,25 @@ class PVRCNN(nn.Module):
                     hook(batch_dict)
         return batch_dict
 
+    def label_independent_until(self):
+        """The first module of the chain that reads the ground truth in training mode (target assignment)."""
+        return getattr(self, 'dense_head', None)
+
     def forward(self, batch_dict):
         batch_dict = self.run_modules(batch_dict)
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
             return {'loss': loss}, tb_dict, disp_dict
         return self.post_processing(batch_dict)
+
+    def forward_issue(self, batch_dict):
+        """Evaluation mode, everything up to the one read-back of post_processing; `forward_finish` completes it.
+        forward(batch) == forward_finish(forward_issue(batch))."""
+        assert not self.training
+        return self.post_processing_issue(self.run_modules(batch_dict))
+
+    def forward_finish(self, state):
+        return self.post_processing_finish(state)
 
     def get_training_loss(self):
         """pv_rcnn.py:24-32"""
@@ -153,6 +177,11 @@ class PVRCNN(nn.Module):
 
     def post_processing(self, batch_dict, no_nms=False):
         """detector3d_template.py:176-309 (MULTI_CLASSES_NMS False branch)."""
+        return self.post_processing_finish(self.post_processing_issue(batch_dict, no_nms))
+
+    def post_processing_issue(self, batch_dict, no_nms=False):
+        """Pass 1 of post_processing: everything that stays on the device; the survivor counts start their way to
+        the host (pinned buffer + event) without blocking."""
         cfg = self.model_cfg.POST_PROCESSING
         assert not cfg.NMS_CONFIG.MULTI_CLASSES_NMS
         batch_size = batch_dict['batch_size']
@@ -189,10 +218,31 @@ class PVRCNN(nn.Module):
                 sel, valid = all_sel[index], all_valid[index]
             staged.append((box_preds, src_box_preds, cls_preds, src_cls_preds, label_preds, sem_scores,
                            sem_scores_full, sel, valid))
-        # the ONE read-back of the call: how many boxes survive per sample (the reference returns
-        # variable-length tensors too, model_nms_utils.py:20)
+        counts = None
         if not no_nms:
-            keep_counts = all_valid.sum(dim=1).tolist()
+            dev_counts = all_valid.sum(dim=1)
+            if dev_counts.is_cuda:
+                host = torch.empty(dev_counts.shape, dtype=dev_counts.dtype, pin_memory=True)
+                host.copy_(dev_counts, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                counts = (host, ev)
+            else:
+                counts = (dev_counts, None)
+        return dict(staged=staged, counts=counts, no_nms=no_nms, batch_dict=batch_dict, recall_dict=recall_dict,
+                    pred_dicts=pred_dicts)
+
+    def post_processing_finish(self, state):
+        """Pass 2: the ONE read-back of the call — how many boxes survive per sample (the reference returns
+        variable-length tensors too, model_nms_utils.py:20) — and the variable-length records."""
+        cfg = self.model_cfg.POST_PROCESSING
+        staged, no_nms, batch_dict = state['staged'], state['no_nms'], state['batch_dict']
+        recall_dict, pred_dicts = state['recall_dict'], state['pred_dicts']
+        if not no_nms:
+            host, ev = state['counts']
+            if ev is not None:
+                ev.synchronize()
+            keep_counts = host.tolist()
         # pass 2: variable-length records
         for index, (box_preds, src_box_preds, cls_preds, src_cls_preds, label_preds, sem_scores,
                     sem_scores_full, sel, valid) in enumerate(staged):
