@@ -19,6 +19,7 @@ the only collective is the gradient all-reduce (RCCL) — weak scaling.
 import argparse
 import json
 import os
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream: detmatch_amd/__init__.py says why (before the runtime initialises)
 import sys
 import time
 
@@ -178,13 +179,19 @@ def trace_launches(wl):
     """One extra (untimed) step with the launch trace on: [(ci, co, rows, kvol, P)] per
     gather-GEMM launch in launch order, 'fwd' / 'dgrad' per launch, and [(ci, co, kvol, P, n_in,
     n_out)] per weight-gradient launch."""
+    from detmatch_amd import chain
     from detmatch_amd.spconv import ops as sp_ops
     sp_ops.LAUNCH_TRACE, sp_ops.LAUNCH_TRACE_DIR, sp_ops.LAUNCH_TRACE_W = [], [], []
+    # the trace lives in the op-by-op host path (it reads the pair count of every launch back): this one step is
+    # issued without chains — same launches, same order, same arguments as the chained steps of the timed region
+    saved = chain.ENABLED
+    chain.ENABLED = False
     try:
         wl.step()
         torch.cuda.synchronize()
         return list(sp_ops.LAUNCH_TRACE), list(sp_ops.LAUNCH_TRACE_DIR), list(sp_ops.LAUNCH_TRACE_W)
     finally:
+        chain.ENABLED = saved
         sp_ops.LAUNCH_TRACE = sp_ops.LAUNCH_TRACE_DIR = sp_ops.LAUNCH_TRACE_W = None
 
 

@@ -24,7 +24,31 @@ import torch
 from . import _lib
 
 ENABLED = os.environ.get('DM_CHAIN', '1') == '1'
+# families switched off individually (A/B, bisection): DM_CHAIN_OFF=bev,trunk2d,sa,sparse
+OFF = set(f for f in os.environ.get('DM_CHAIN_OFF', '').split(',') if f)
+
+
+EVAL_OFF = set(f for f in os.environ.get('DM_CHAIN_EVAL_OFF', '').split(',') if f)
+
+
+def on(family, train=True):
+    return ENABLED and family not in OFF and (train or family not in EVAL_OFF)
 MAX_ARGS = 32
+DEBUG_EVENTS = None
+if os.environ.get('DM_CHAIN_DEBUG'):
+    import collections
+    DEBUG_EVENTS = collections.deque(maxlen=40000)
+
+
+def debug_report():
+    """First incomplete op per stream (DM_CHAIN_DEBUG=1)."""
+    seen = {}
+    for name, i, op, stream, ev in DEBUG_EVENTS:
+        if stream in seen:
+            continue
+        if not ev.query():
+            seen[stream] = (name, i, op)
+    return seen
 
 
 class ChainOp(ctypes.Structure):
@@ -191,6 +215,17 @@ class Program(object):
         if len(values) != n - 1:
             raise ValueError('%s: %d slot values expected, got %d' % (self.name, n - 1, len(values)))
         v[1:n] = values
+        if DEBUG_EVENTS is not None:       # debugging aid: one op at a time with an event behind each
+            sz = ctypes.sizeof(ChainOp)
+            cur = torch.cuda.current_stream()
+            for i in range(len(self.ops)):
+                rc = self._run(self._table_ptr + i * sz, 1, self._values_ptr, n, self._failed)
+                if rc != 0:
+                    _lib.check(rc, 'chain %s, op %d (%s)' % (self.name, i, self.ops[i][2]))
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                DEBUG_EVENTS.append((self.name, i, self.ops[i][2], v[0], ev))
+            return
         rc = self._run(self._table_ptr, len(self.ops), self._values_ptr, n, self._failed)
         if rc != 0:
             i = self._failed.value

@@ -216,6 +216,10 @@ __global__ void copy2d_scalar_kernel(const float *__restrict__ src, long long sr
   }
 }
 
+__global__ void fill_kernel(uint4 *__restrict__ dst, uint4 v, long long n16) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = v;
+}
+
 struct BnFoldRow {   // one evaluation-mode BatchNorm layer (device pointers)
   const float *gamma, *beta, *mean, *var;
   float *scale, *shift;
@@ -357,6 +361,13 @@ extern "C" int dm_copy2d_f32(const float *src, long long src_pitch, float *dst, 
 extern "C" int dm_fill_bytes(void *dst, int byte_value, size_t nbytes, dm_stream_t stream) {
   if (nbytes == 0) return DM_OK;
   if (!dst) return DM_ERR_INVALID_ARG;
+  if (((uintptr_t)dst | nbytes) % 16 == 0) {      // an ordinary kernel on the caller's stream (no runtime blit path)
+    const unsigned w = (unsigned)(byte_value & 0xff) * 0x01010101u;
+    fill_kernel<<<grid_for((long long)(nbytes / 16)), kThreads, 0, (hipStream_t)stream>>>((uint4 *)dst, make_uint4(w, w, w, w),
+                                                                                         (long long)(nbytes / 16));
+    DM_CHECK_LAUNCH();
+    return DM_OK;
+  }
   DM_HIP(hipMemsetAsync(dst, byte_value, nbytes, (hipStream_t)stream));
   return DM_OK;
 }

@@ -731,9 +731,11 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
         """-> (pyramid maps, raw RPN maps) through the chain, or None when it does not apply."""
         from .. import chain as _chain
         from .backbone import FrozenBN
-        if not _chain.ENABLED or not img.is_cuda or img.dtype != torch.float32 or img.shape[1] != 3:
+        if not _chain.on('trunk2d') or not img.is_cuda or img.dtype != torch.float32 or img.shape[1] != 3:
             return None
         train = torch.is_grad_enabled() and not self._frozen()
+        if not _chain.on('trunk2d', train):
+            return None
         if train and not self.training:
             return None
         if self.neck.num_outs < self.neck.num_ins or self.backbone.conv1.weight.requires_grad:

@@ -115,11 +115,14 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
                                                      self.voxel_layer.max_num_points, max_voxels,
                                                      with_mean=True, sync=False)
         total = yield counts[len(pts):len(pts) + 1]
-        res = self._fill_base_batch(points, img_metas, v[:total], n[:total], c[:total], mean[:total])
+        res = self._fill_base_batch(points, img_metas, v[:total], n[:total], c[:total], mean[:total], fps=False)
         bb = getattr(self.model, 'backbone_3d', None)
         if bb is not None and hasattr(bb, 'build_rulebooks_steps'):
             res['indice_dict_prefetch'] = yield from bb.build_rulebooks_steps(
                 res['voxel_coords'], res['batch_size'], ws_tag=ws_tag)
+        # the key-point FPS (3 ms on two compute units) AFTER the rulebooks: it may share their stream, and the
+        # rulebooks' size read-backs must not queue behind it
+        self._launch_fps(res)
         stream = done = None
         if points[0].is_cuda:
             stream = torch.cuda.current_stream(points[0].device)
@@ -144,7 +147,12 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
         voxels, num_points, coors, mean = self.voxelize(points, with_mean=True)
         return self._fill_base_batch(points, img_metas, voxels, num_points, coors, mean)
 
-    def _fill_base_batch(self, points, img_metas, voxels, num_points, coors, mean):
+    def _launch_fps(self, res):
+        pfe = getattr(self.model, 'pfe', None)
+        if pfe is not None and hasattr(pfe, 'sample_keypoints_async'):
+            pfe.sample_keypoints_async(res)
+
+    def _fill_base_batch(self, points, img_metas, voxels, num_points, coors, mean, fps=True):
         res = dict(batch_size=len(points), voxels=voxels, voxel_num_points=num_points,
                    voxel_coords=coors, voxel_features=mean)
         res['points'] = torch.cat([F.pad(p.float(), (1, 0), mode='constant', value=k)
@@ -152,9 +160,8 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
         res['points_batch_cnt_host'] = [int(p.shape[0]) for p in points]
         if img_metas is not None:
             res['frame_id'] = np.array([m.get('sample_idx', i) for i, m in enumerate(img_metas)])
-        pfe = getattr(self.model, 'pfe', None)
-        if pfe is not None and hasattr(pfe, 'sample_keypoints_async'):
-            pfe.sample_keypoints_async(res)
+        if fps:
+            self._launch_fps(res)
         return res
 
     @torch.no_grad()

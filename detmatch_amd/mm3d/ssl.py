@@ -626,7 +626,7 @@ class SSL(nn.Module):
         if dev.type != 'cuda':
             return
         if getattr(self, '_geom_stream', None) is None:
-            self._geom_stream = torch.cuda.Stream(dev)
+            self._geom_stream = _lib.aux_stream(dev)      # shared with the key-point FPS (see _lib.aux_stream)
         dicts = (dict(stu=lab_stu, tea=data.get('lab_tea')), dict(stu=unlab_stu, tea=data.get('unlab_tea')))
         if ready is not None:
             self._geom_stream.wait_event(ready)

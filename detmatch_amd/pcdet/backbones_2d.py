@@ -257,7 +257,7 @@ class BaseBEVBackbone(nn.Module):
     def _chained(self, data_dict, x):
         from .. import chain as _chain
         head = self.fused_head
-        if not _chain.ENABLED or head is None or not x.is_cuda or x.dtype != torch.float32:
+        if not _chain.on('bev') or head is None or not x.is_cuda or x.dtype != torch.float32:
             return False
         train = self.training and torch.is_grad_enabled() and head.training
         if not train and (self.training or head.training or x.requires_grad or

@@ -131,8 +131,35 @@ class VoxelBackBone8x(nn.Module):
             indices, shape = indice_dict[m.indice_key][0], out_shape
         return indice_dict
 
+    def _chained(self, batch_dict, voxel_features, voxel_coords):
+        """The 12 layers as one chained call (sparse_chain.py), when it applies."""
+        from .. import chain as _chain
+        if not _chain.on('sparse') or not voxel_features.is_cuda or voxel_features.dtype != torch.float32 \
+                or voxel_features.shape[0] < 2:
+            return False
+        from ..sparse_chain import SparseBackboneChain
+        train = self.conv_input[1].training
+        if not train and torch.is_grad_enabled() and (voxel_features.requires_grad or
+                                                      any(p.requires_grad for p in self.parameters())):
+            return False
+        cache = self.__dict__.setdefault('_chains', {})
+        ch = cache.get(train)
+        if ch is None or (ch is not False and not ch.valid()):
+            ch = cache[train] = SparseBackboneChain(self, voxel_features.device, train) \
+                if SparseBackboneChain.applicable(self, train) else False
+        if ch is False:
+            return False
+        indice_dict = dict(batch_dict.pop('indice_dict_prefetch', None) or {})
+        x1, x2, x3, x4, out = ch(voxel_features, voxel_coords.int(), batch_dict['batch_size'], self.sparse_shape, indice_dict)
+        batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
+        batch_dict.update({'multi_scale_3d_features': {'x_conv1': x1, 'x_conv2': x2, 'x_conv3': x3, 'x_conv4': x4}})
+        batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
+        return True
+
     def forward(self, batch_dict):
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+        if self._chained(batch_dict, voxel_features, voxel_coords):
+            return batch_dict
         x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(),
                                     spatial_shape=self.sparse_shape,
                                     batch_size=batch_dict['batch_size'])

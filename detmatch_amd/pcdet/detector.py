@@ -218,17 +218,8 @@ class PVRCNN(nn.Module):
                 sel, valid = all_sel[index], all_valid[index]
             staged.append((box_preds, src_box_preds, cls_preds, src_cls_preds, label_preds, sem_scores,
                            sem_scores_full, sel, valid))
-        counts = None
-        if not no_nms:
-            dev_counts = all_valid.sum(dim=1)
-            if dev_counts.is_cuda:
-                host = torch.empty(dev_counts.shape, dtype=dev_counts.dtype, pin_memory=True)
-                host.copy_(dev_counts, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                counts = (host, ev)
-            else:
-                counts = (dev_counts, None)
+        # (the survivor counts stay on the device until post_processing_finish reads them back)
+        counts = all_valid.sum(dim=1) if not no_nms else None
         return dict(staged=staged, counts=counts, no_nms=no_nms, batch_dict=batch_dict, recall_dict=recall_dict,
                     pred_dicts=pred_dicts)
 
@@ -239,10 +230,7 @@ class PVRCNN(nn.Module):
         staged, no_nms, batch_dict = state['staged'], state['no_nms'], state['batch_dict']
         recall_dict, pred_dicts = state['recall_dict'], state['pred_dicts']
         if not no_nms:
-            host, ev = state['counts']
-            if ev is not None:
-                ev.synchronize()
-            keep_counts = host.tolist()
+            keep_counts = state['counts'].tolist()
         # pass 2: variable-length records
         for index, (box_preds, src_box_preds, cls_preds, src_cls_preds, label_preds, sem_scores,
                     sem_scores_full, sel, valid) in enumerate(staged):

@@ -187,8 +187,15 @@ class VoxelSetAbstraction(nn.Module):
         key = pts.device.index
         pool = VoxelSetAbstraction._side_streams.get(key)
         if pool is None:
-            pool = VoxelSetAbstraction._side_streams[key] = dict(
-                streams=[torch.cuda.Stream(device=pts.device) for _ in range(3)], next=0)
+            # (round 5: ONE side stream, shared with the geometry look-ahead — `_lib.aux_stream` says why; the FPS
+            # launches of an iteration are issued one iteration ahead, so running them one after the other costs
+            # nothing.  DM_FPS_STREAMS=3 restores the pool.)
+            import os
+            from .. import _lib
+            n = int(os.environ.get('DM_FPS_STREAMS', '1'))
+            streams = [_lib.aux_stream(pts.device)] if n <= 1 else \
+                [torch.cuda.Stream(device=pts.device) for _ in range(n)]
+            pool = VoxelSetAbstraction._side_streams[key] = dict(streams=streams, next=0)
         side = pool['streams'][pool['next'] % len(pool['streams'])]
         pool['next'] += 1
         main = torch.cuda.current_stream(pts.device)

@@ -282,7 +282,10 @@ class DetMatchTrainWorkload(object):
         # tails of small 3D kernels run underneath the 2D convolutions (70-77 ms against 81-87 ms in 'glue', same box).
         # The roofline kernel's duration in the bench line is the dispatch's own begin -> end time
         # (hipExtLaunchKernelGGL events, what rocprofv3 reports), co-scheduled or not.  DM_TWO_LANES=0: 'glue'.
-        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '1') == '1'
+        # (needs one hardware queue per stream: detmatch_amd/__init__.py sets GPU_MAX_HW_QUEUES when it is imported
+        # before the HIP runtime comes up; otherwise 'glue')
+        import detmatch_amd
+        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '1' if detmatch_amd.HW_QUEUES_OK else '0') == '1'
         mode = os.environ.get('DM_LANE_MODE', 'glue')
         self.model.lane_mode = None if (self.model.two_lanes or mode in ('serial', 'none', '0', '')) else mode
         self.model.lane_hoist = os.environ.get('DM_LANE_HOIST', '0') == '1'

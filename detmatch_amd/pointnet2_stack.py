@@ -471,8 +471,8 @@ class StackSAModuleMSG(nn.Module):
         if self.row_layout and self.pool_method == 'max_pool' and features is not None and xyz.is_cuda:
             # the whole call as one chained launch table behind one autograd node (sa_chain.py), when it applies
             from . import chain as _chain
-            if _chain.ENABLED and fused_on():
-                train = self.mlps[0][1].training
+            train = self.mlps[0][1].training
+            if _chain.on('sa', train) and fused_on():
                 key = (xyz_batch_cnt.numel(), new_xyz.shape[0], features.shape[1], train)
                 cache = self.__dict__.setdefault('_chains', {})
                 ch = cache.get(key)

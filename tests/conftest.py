@@ -1,4 +1,5 @@
 import os
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream: detmatch_amd/__init__.py says why (before the runtime initialises)
 import sys
 
 import pytest

@@ -329,3 +329,61 @@ def test_sa_module_chain_equals_op_by_op(dev, train):
         for k in blas['grads']:
             a, b = got['grads'][k], blas['grads'][k]
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, k
+
+
+# ---- VoxelBackBone8x as one chained call (sparse_chain.py) ---------------------------------------------------------------
+def _backbone_run(bb, vf, coords, train, enabled):
+    from detmatch_amd import chain
+    from detmatch_amd.spconv.ops import deferred_weight_grads
+    old = chain.ENABLED
+    chain.ENABLED = enabled
+    try:
+        bb.train(train)
+        for p in bb.parameters():
+            p.grad = None
+        with torch.set_grad_enabled(train):
+            d = bb(dict(voxel_features=vf, voxel_coords=coords, batch_size=2))
+        feats = [d['multi_scale_3d_features'][k] for k in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4')] + \
+            [d['encoded_spconv_tensor']]
+        res = dict(feats=[t.features.detach().clone() for t in feats], idx=[t.indices.clone() for t in feats],
+                   shapes=[list(t.spatial_shape) for t in feats])
+        if train:
+            g = torch.Generator(device='cpu').manual_seed(8)
+            loss = sum((t.features * torch.randn(t.features.shape, generator=g).to(vf.device)).sum() for t in feats)
+            with deferred_weight_grads():      # the batched weight-gradient launch of the op-by-op path
+                loss.backward()
+            res['grads'] = {n: p.grad.clone() for n, p in bb.named_parameters()}
+        res['state'] = {k: v.clone() for k, v in bb.state_dict().items()}
+        return res
+    finally:
+        chain.ENABLED = old
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_voxel_backbone_chain_equals_op_by_op(dev, train):
+    from detmatch_amd import synth, voxel
+    from detmatch_amd.pcdet.backbones_3d import VoxelBackBone8x
+    torch.manual_seed(1)
+    bb = VoxelBackBone8x({}, 4, [1408, 1600, 40]).to(dev)
+    with torch.no_grad():
+        for mod in bb.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.uniform_(0.5, 1.5), mod.bias.uniform_(-0.2, 0.2)
+                mod.running_mean.uniform_(-0.1, 0.1), mod.running_var.uniform_(0.5, 2.0)
+    state = copy.deepcopy(bb.state_dict())
+    pts = [torch.from_numpy(synth.lidar_frame(i)['points']).to(dev) for i in range(2)]
+    _, coords, _, mean, _ = voxel.voxelize_batch(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    ref = _backbone_run(bb, mean, coords, train, enabled=False)
+    bb.load_state_dict(state)
+    got = _backbone_run(bb, mean, coords, train, enabled=True)
+    assert bb.__dict__.get('_chains', {}).get(train) not in (None, False), 'the chain did not run'
+    assert got['shapes'] == ref['shapes']
+    for i, (a, b) in enumerate(zip(got['idx'], ref['idx'])):
+        assert torch.equal(a, b), 'indices of level %d' % i
+    for i, (a, b) in enumerate(zip(got['feats'], ref['feats'])):
+        _same(a, b, 'features of level %d' % i)
+    for k in ref['state']:
+        _same(got['state'][k], ref['state'][k], 'state ' + k)
+    if train:
+        for k in ref['grads']:
+            _same(got['grads'][k], ref['grads'][k], 'grad ' + k)
