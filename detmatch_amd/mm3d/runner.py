@@ -763,6 +763,9 @@ class EpochBasedRunner(_RunnerBase):
         self.call_hook('after_run')
 
 
+_ITER_SYNC = os.environ.get('DM_ITER_SYNC', '0') == '1'
+
+
 @RUNNERS.register_module()
 class IterBasedSSLRunner(_RunnerBase):
     """iter_based_ssl_runner.py:11-110: one labeled + one unlabeled batch per iteration, keys
@@ -799,6 +802,8 @@ class IterBasedSSLRunner(_RunnerBase):
         if self.lookahead and prefetch is not None and (self._max_iters is None or self.iter + 1 < self._max_iters):
             self._ahead = self._draw(lab_data_loader, unlab_data_loader)
         self.call_hook('before_train_iter')
+        if _ITER_SYNC and torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
         self._after_step(self.model.train_step(data_batch, self.optimizer, **kwargs))
         self.call_hook('after_train_iter')
         if self._ahead is not None:

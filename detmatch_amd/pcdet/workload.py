@@ -294,6 +294,13 @@ class DetMatchTrainWorkload(object):
         self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)
         self.runner.register_training_hooks(sched['lr_config'], sched['optimizer_config'],
                                             sched['custom_hooks'])
+        if self.model.two_lanes and 'DM_LOOKAHEAD' not in os.environ:
+            # Three lanes + the geometry of the NEXT iteration prepared on a side stream while this one still runs
+            # wedged the device about once per 200 iterations (round 5, profiles/r05_lane_hang_ab.txt: every queue
+            # waiting, no kernel running; never with the look-ahead off, with a stream synchronisation per iteration, or
+            # with the geometry on the main stream — 74-77 ms in all three against 70 when it does not hang).  With the
+            # lanes the geometry is prepared at the start of its own iteration instead.
+            self.runner.lookahead = False
         self.runner.call_hook('before_run')
         self.world = 1
         self.params = self.ddp.params
