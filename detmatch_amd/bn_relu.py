@@ -120,11 +120,8 @@ _PENDING = []
 _DEFER_ON = os.environ.get('DM_BN_DEFER', '1') == '1'
 
 
-CAPTURING = [False]     # graphs.TrainSection: inside a hipGraph capture the counter add is recorded with the rest
-
-
 def _bump(bn):
-    if _DEFER[0] and _DEFER_ON and not CAPTURING[0]:
+    if _DEFER[0] and _DEFER_ON:
         _PENDING.append(bn.num_batches_tracked)
     else:
         bn.num_batches_tracked.add_(1)

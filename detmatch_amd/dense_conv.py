@@ -198,37 +198,6 @@ def _refresh_stream(stream, device):
         e.ver = (gen, e.wref()._version, e.ver[2], e.ver[3])
 
 
-CAPTURING = [False]     # graphs.*Section: a hipGraph capture is running on this thread
-# Inside a capture the packed copy of a weight with constant scales is NOT recorded: the graph reads the cached
-# copy that belongs to the stream the graph will be replayed on (CAPTURE_STREAM), and a replay is preceded by
-# `ensure_fresh` — the one-launch refresh of that stream — so the graph holds the convolution kernels only (a recorded
-# pack per weight cost 0.6 ms of kernels per replay of the teacher's 2D trunk).  Weights with per-call scales
-# (evaluation-mode BatchNorm folds of a moving teacher) keep their recorded packs.
-CAPTURE_STREAM = [None]     # raw handle of the replay stream while a capture runs
-ALIAS_OF = {}               # id(alias parameter) -> the parameter it aliases (graphs.TrainSection records on aliases)
-CAPTURE_KEEP = []           # the packed copies a capture took from the cache: the section keeps them alive
-_FRESH = {}                 # stream -> generation its cached packs were last refreshed for
-
-
-def ensure_fresh(device, entries=()):
-    """Refresh the stale cached packs of the current stream (one launch, nothing if none is stale): called in
-    front of a graph replay, whose convolutions read the cached copies `entries` (CAPTURE_KEEP of its capture).
-    Raw-pointer rewrites announce themselves (`weights_changed` moves the generation); in-place torch updates
-    show in the parameter's version counter, checked for the graph's own entries."""
-    stream = _lib.raw_stream()
-    if stream not in _TABLES:
-        return
-    if _FRESH.get(stream) == _GENERATION[0]:
-        for e in entries:
-            w = e.wref()
-            if w is not None and e.ver[1] != w._version:
-                break
-        else:
-            return
-    _refresh_stream(stream, device)
-    _FRESH[stream] = _GENERATION[0]
-
-
 PLANES = os.environ.get('DM_DCONV_PLANES', '1') == '1'     # A/B: pre-split weight planes for the patch kernel
 
 
@@ -241,12 +210,8 @@ def _wants_planes(T, N, K, stride_one):
 def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None, planes=False):
     """[S][N][K] packed copy of `weight` (cached until the weight or a scale changes).  planes=True: the flat
     buffer also holds the pre-split bf16 planes behind the fp32 block (`dst.dm_planes` = their byte offset)."""
-    capturing = CAPTURING[0]
-    if capturing:
-        weight = ALIAS_OF.get(id(weight), weight)
-    shared = capturing and CAPTURE_STREAM[0] is not None and _constant(scale_n) and _constant(scale_k)
-    cacheable = isinstance(weight, nn.Parameter) and (not capturing or shared)     # temporaries may recycle an address
-    stream = CAPTURE_STREAM[0] if (capturing and cacheable) else _lib.raw_stream()
+    cacheable = isinstance(weight, nn.Parameter)     # temporaries may recycle an address
+    stream = _lib.raw_stream()
     if planes:
         tag = tag + 'P'
     key = (id(weight), weight.data_ptr(), tag, N, K, stream)
@@ -255,14 +220,12 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
     if hit is not None and hit.wref() is not weight:
         hit = None
     if hit is not None:
-        if capturing:
-            CAPTURE_KEEP.append(hit)
         if hit.ver == ver:
             return hit.dst
         if hit.ver[1:] == ver[1:] and hit.desc[0] == weight.data_ptr() and not _stale(hit.ver[0], hit.desc[0]):
             hit.ver = ver              # rewritten weights were somebody else's
             return hit.dst
-        if hit.batchable and hit.ver[2:] == ver[2:] and not capturing:      # (a capture must not record the refresh of everything)
+        if hit.batchable and hit.ver[2:] == ver[2:]:
             _refresh_stream(stream, weight.device)
             if hit.ver == ver:
                 return hit.dst
@@ -293,24 +256,11 @@ def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=
                   0 if scale_k is None else scale_k.data_ptr(), sn, sk, st, S, N, K, n_src, k_src,
                   1 if planes else 0, key)
         _PACK_CACHE[key] = e
-        if capturing:
-            CAPTURE_KEEP.append(e)
         if e.batchable:
             reg = _TABLES.setdefault(stream, {'entries': []})
             reg['entries'].append(e)
             reg.pop('tables', None)
     return dst
-
-
-def forget(weights):
-    """Drop the cached packed copies of these weights (their convolutions moved into a hipGraph that records
-    its own packs: the one-launch refresh of a stream must not keep re-packing copies nobody reads)."""
-    ids = {id(w) for w in weights}
-    for key in [k for k in _PACK_CACHE if k[0] in ids]:
-        del _PACK_CACHE[key]
-    for reg in _TABLES.values():
-        reg['entries'] = [e for e in reg['entries'] if e.wref() is not None and id(e.wref()) not in ids]
-        reg.pop('tables', None)
 
 
 _PLAN_BY_ID = {}

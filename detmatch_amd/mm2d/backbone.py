@@ -39,10 +39,6 @@ class FrozenBN(nn.Module):
         cached until one of the four tensors changes."""
         key = (FrozenBN.GENERATION, self.weight._version, self.bias._version,
                self.running_mean._version, self.running_var._version, self.weight.device)
-        if dense_conv.CAPTURING[0]:      # inside a hipGraph capture: recorded, so that a replay sees the current statistics
-            with torch.no_grad():
-                s = self.weight * torch.rsqrt(self.running_var + self.eps)
-                return s, self.bias - self.running_mean * s
         cached = getattr(self, '_affine', None)
         if cached is None or cached[0] != key:
             with torch.no_grad():

@@ -779,20 +779,8 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
                 or not self.training:
             return False
         batch = torch.cat([i for i in imgs], dim=0)
-        from .. import graphs
-        if graphs.TRAIN_ENABLED and batch.is_cuda:
-            # backbone + FPN + RPN convolutions, forward AND backward, as two hipGraphs behind one autograd node
-            sec = self.__dict__.get('_train_trunk_section')
-            if sec is None:
-                mods = (self.backbone, self.neck, self.rpn_head)
-                sec = self.__dict__['_train_trunk_section'] = graphs.TrainSection(
-                    self._trunk_train, mods, 'faster_rcnn.trunk.train')
-            outs = list(sec(batch))
-            n_feat = len(outs) // 2
-            x, raw = tuple(outs[:n_feat]), outs[n_feat:]
-        else:
-            x, _, _, raw = self._trunk(batch)
-            outs = list(x) + list(raw)
+        x, _, _, raw = self._trunk(batch)
+        outs = list(x) + list(raw)
         leaves = [t.detach().requires_grad_(True) for t in outs]
         spans, lo = {}, 0
         for i in imgs:
@@ -800,11 +788,6 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
             lo += i.shape[0]
         self._shared = dict(outs=outs, leaves=leaves, spans=spans, n_feat=len(x))
         return True
-
-    def _trunk_train(self, batch):
-        x = self.extract_feat(batch)
-        self.rpn_head(x)
-        return tuple(x) + tuple(self.rpn_head._raw_levels)
 
     def _shared_slices(self, img):
         sh = getattr(self, '_shared', None)
@@ -853,21 +836,9 @@ class FasterRCNN(DetectorStepMixin, nn.Module):
             hit = self.__dict__['_frozen_state'] = (sentinel.requires_grad, not any(p.requires_grad for p in trunk))
         return hit[1]
 
-    def _trunk_inference(self, img):
-        return self._trunk(img)
-
     def simple_test_pre_nms(self, img, img_metas):
         """The body of SimpleTest_2D.forward (processors_2d.py:36-84)."""
-        frozen = self._frozen()
-        if (frozen or not torch.is_grad_enabled()) and img.is_cuda:
-            # backbone + FPN + RPN convolutions: shape-static, replayed as one hipGraph (graphs.py)
-            sec = self.__dict__.get('_trunk_section')
-            if sec is None:
-                from ..graphs import StaticSection
-                sec = self.__dict__['_trunk_section'] = StaticSection(self._trunk_inference, 'faster_rcnn.trunk')
-            x, cls, reg, self.rpn_head._raw_levels = sec(img, frozen=frozen)
-        else:
-            x, cls, reg, _ = self._trunk(img)
+        x, cls, reg, _ = self._trunk(img)
         proposals = self.rpn_head.get_bboxes(cls, reg, img_metas, self.test_cfg['rpn'])
         return self.roi_head.simple_test_pre_nms(x, proposals, img_metas)
 

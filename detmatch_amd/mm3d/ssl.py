@@ -23,7 +23,6 @@ def add_prefix(inputs, prefix):
     return {'%s.%s' % (prefix, k): v for k, v in inputs.items()}
 
 
-_TRUNK_AFTER_TEACHER = os.environ.get('DM_TRUNK_AFTER_TEACHER', '0') == '1'
 _ISSUE_EARLY = os.environ.get('DM_ISSUE_EARLY', '1') == '1'      # A/B switch of SSL modules' issue_early
 
 
@@ -58,8 +57,7 @@ class _LaneDict(dict):
         ln = self._lanes
         if tok is not None and tok[0] != ln.current:
             if tok[1] is None:
-                # only possible for the 2D pass issued in the middle of its paired 3D pass (mode
-                # 'pairs'): the two must not exchange entries
+                # a producer that is still being issued: never with the modules run one after the other
                 raise RuntimeError('batch-dict entry %r is read on lane %d while lane %d is still '
                                    'producing it' % (k, ln.current, tok[0]))
             cur = torch.cuda.current_stream()
@@ -109,38 +107,6 @@ class _RngWindows(object):
             self.gen.set_offset(self.base + (len(self.index) + 1) * self.WINDOW)
 
 
-class _Pair(object):
-    """A 3D pass and the 2D pass issued from inside it (SSL.forward_train, lane mode 'pairs')."""
-
-    def __init__(self, m3, m2):
-        self.m3, self.m2 = m3, m2
-
-
-class _StreamGate(torch.autograd.Function):
-    """Identity whose backward makes the stream it runs on wait for another stream."""
-
-    @staticmethod
-    def forward(ctx, x, other):
-        ctx.other = other
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        torch.cuda.current_stream().wait_stream(ctx.other)
-        return g, None
-
-
-def _gate_backbone_outputs(batch, other):
-    """Every tensor through which gradient enters the sparse backbone (pcdet batch dict)."""
-    seen = []
-    for t in [batch.get('encoded_spconv_tensor')] + list((batch.get('multi_scale_3d_features') or {}).values()):
-        if t is None or any(t is u for u in seen):
-            continue
-        seen.append(t)
-        if isinstance(getattr(t, 'features', None), torch.Tensor) and t.features.requires_grad:
-            t.features = _StreamGate.apply(t.features, other)
-
-
 class _Lanes(object):
     """HIP streams for SSL.forward_train.  Lane 0 = the caller's stream: the student's 3D passes
     (stateful modules, strictly ordered) and the final aggregation; lane 1: the modules that run a 2D
@@ -173,8 +139,6 @@ class _Lanes(object):
         attr = getattr(module, 'ssl_obj_attr', None)
         if self.mode == 'glue':
             return 1 if attr is None else 0
-        if self.mode == 'pairs':
-            return 2 if attr is None else (1 if attr.endswith('detector_2d') else 0)
         if attr is None:
             return 2                       # glue
         if attr.endswith('detector_2d'):
@@ -212,51 +176,6 @@ class _Lanes(object):
         for tok in self.pending:
             tok[1] = ev
         self.current, self.pending = 0, []
-        return out
-
-    @staticmethod
-    def is_pair(m3, m2):
-        a3, a2 = str(getattr(m3, 'ssl_obj_attr', '')), str(getattr(m2, 'ssl_obj_attr', ''))
-        return a3.endswith('.detector_3d') and a2.endswith('.detector_2d') and \
-            a3.split('.')[0] == a2.split('.')[0]
-
-    def run_pair(self, m3, m2, ssl_obj, batch_dict):
-        """Mode 'pairs': a 3D pass and the 2D pass of the same network on the same batch exchange no
-        batch-dict entry.  The 3D pass is issued up to the end of its sparse backbone; at that point
-        (PVRCNN.run_modules hook) the WHOLE 2D pass is issued on lane 1, gated on the backbone's last
-        kernel; then the rest of the 3D pass — key-point encoder, heads, RoI head: hundreds of small
-        kernels that leave most CUs idle — is issued on lane 0 and runs underneath the 2D pass's
-        convolutions.  The sparse convolutions themselves never share the device: lane 0 waits for
-        lane 1 to drain before the backbone, and in the backward pass a gate in front of the backbone's
-        outputs waits for the 2D pass's backward (autograd issues nodes in reverse creation order: the
-        2D pass was recorded after the gates, so all of its backward is queued before they run)."""
-        from .ssl_modules import mlvl_getattr
-        model = mlvl_getattr(ssl_obj, m3.ssl_obj_attr).model
-        lane2d = self.stream(self.lane_of(m2))
-        done = []
-
-        def after_backbone(batch):
-            cur = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            lane2d.wait_event(ev)
-            if torch.is_grad_enabled():
-                _gate_backbone_outputs(batch, lane2d)
-            saved = (self.current, self.pending, self.rng.offset() if self.rng is not None else None)
-            self.run(m2, ssl_obj, batch_dict)
-            self.current, self.pending = saved[:2]
-            if self.rng is not None:
-                self.rng.restore(saved[2])
-            done.append(True)
-
-        model.after_backbone_3d = after_backbone
-        self.stream(self.lane_of(m3)).wait_stream(lane2d)
-        try:
-            out = self.run(m3, ssl_obj, batch_dict)
-        finally:
-            model.__dict__.pop('after_backbone_3d', None)
-        if not done:                      # the pass never reached a sparse backbone
-            out = self.run(m2, ssl_obj, out)
         return out
 
     def join(self, *values):
@@ -694,8 +613,6 @@ class SSL(nn.Module):
             return self._forward_train(lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs)
 
     def _forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
-        from .. import graphs
-        graphs.new_iteration()      # no forward of the previous iteration still waits for its backward
         if isinstance(unlab_stu, list):
             unlab_stu = self._collate(unlab_stu)
             unlab_tea = self._collate(unlab_tea)
@@ -724,24 +641,6 @@ class SSL(nn.Module):
 
         run = (lambda m, d: lanes.run(m, self, d)) if lanes is not None else run_serial
 
-        def schedule(mods):
-            """Modules in issue order; in mode 'pairs' a 3D pass directly followed by the 2D pass of the
-            same network becomes one item (see _Lanes.run_pair)."""
-            mods, out, i = list(mods), [], 0
-            while i < len(mods):
-                if lanes is not None and lanes.mode == 'pairs' and i + 1 < len(mods) and \
-                        lanes.is_pair(mods[i], mods[i + 1]):
-                    out.append(_Pair(mods[i], mods[i + 1]))
-                    i += 2
-                else:
-                    out.append(mods[i])
-                    i += 1
-            return out
-
-        def run(m, d, _run=run):
-            if isinstance(m, _Pair):
-                return lanes.run_pair(m.m3, m.m2, self, d)
-            return _run(m, d)
         # weight-independent geometry of every pass of the iteration, issued up front
         jobs = []
         for chain, d in ((self.lab_ssl_modules, lab_dict), (self.unlab_ssl_modules, unlab_dict)):
@@ -759,29 +658,19 @@ class SSL(nn.Module):
             # one device->host copy per round for all of them
             from ..spconv.ops import drive_steps_together
             drive_steps_together(jobs)
-        # Scheduling experiment (DM_TRUNK_AFTER_TEACHER=1, off by default): the student's shared 2D trunk pass (6-7 ms of
-        # convolutions nobody reads before the first supervised 2D module) issued AFTER the hoisted teacher passes, so
-        # that the teacher's first read-back (4.8 ms of host wait in tea.3d.post_processing, `r04_launch_census.txt`) does
-        # not queue behind it.  Measured 90.7 / 87.2 / 90.2 ms against 85.1 / 88.7 / 90.4 (same box, alternated): the wait
-        # moves, the totals of host and device work do not change.
-        trunk_late = _TRUNK_AFTER_TEACHER and torch.is_grad_enabled()
         if lanes is not None:
             lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
-        if not trunk_late:
-            self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
+        self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
         unlab_modules = list(self.unlab_ssl_modules)
-        if lanes is not None and (lanes.mode in ('glue', 'pairs') or getattr(self, 'lane_hoist', False)):
+        if lanes is not None and (lanes.mode == 'glue' or getattr(self, 'lane_hoist', False)):
             # The teacher's inference passes read nothing but the raw unlabeled batch: issue them first, so
             # that the glue that consumes them can run (on its side stream) while the main stream works
             # through the supervised passes and their early backward.  Values do not depend on the order:
             # the teacher is in eval mode and draws no random numbers.
             hoisted = [m for m in unlab_modules if getattr(m, 'hoistable', False) and
                        str(getattr(m, 'ssl_obj_attr', '')).startswith('teacher')]
-            if lanes.mode == 'pairs':      # 3D pass first: its 2D partner is issued from inside it
-                hoisted = sorted(hoisted, key=lambda m: not str(m.ssl_obj_attr).endswith('detector_3d'))
-            else:                          # read-back last
-                hoisted = sorted(hoisted, key=lambda m: getattr(m, 'has_readback', False))
-            for m in schedule(hoisted):
+            hoisted = sorted(hoisted, key=lambda m: getattr(m, 'has_readback', False))      # read-back last
+            for m in hoisted:
                 unlab_dict = run(m, unlab_dict)
             unlab_modules = [m for m in unlab_modules if m not in hoisted]
         early = lanes is None and getattr(self, 'early_backward', False) and torch.is_grad_enabled()
@@ -797,9 +686,7 @@ class SSL(nn.Module):
             for m in unlab_modules[:first_student]:
                 unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
             unlab_modules = unlab_modules[first_student:]
-        if trunk_late:
-            self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
-        for m in schedule(self.lab_ssl_modules):
+        for m in self.lab_ssl_modules:
             lab_dict = self._run_and_backprop(run, m, lab_dict, early, curr_ssl_weight)
         if lanes is not None:
             lanes.join(lab_dict['sup_losses'], lab_dict['ssl_losses'])
@@ -829,7 +716,7 @@ class SSL(nn.Module):
                     else:
                         rng.enter(m)
                         m.issue_early(self, unlab_dict)
-        for m in schedule(unlab_modules):
+        for m in unlab_modules:
             unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
         if lanes is not None:
             lanes.join(unlab_dict['ssl_losses'], lab_dict['ssl_losses'])

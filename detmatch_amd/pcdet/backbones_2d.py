@@ -145,7 +145,7 @@ class BaseBEVBackbone(nn.Module):
     def _levels(self, x):
         """-> (spatial_features_2d, [(stride, feature map) per block])"""
         blocks, deblocks = self._plan()
-        if not self.training and not dense_conv.CAPTURING[0]:
+        if not self.training:
             self.fold_eval_stages([st for blk in blocks for st in blk], x)
         full = x.shape[2]
         branches, levels = [], []
@@ -159,46 +159,11 @@ class BaseBEVBackbone(nn.Module):
             out = deblocks[-1][0](out)
         return out, levels
 
-    # ---- the shape-static chain as hipGraphs (graphs.py) --------------------------------------------------------
-    # `fused_head` (set by the detector: the anchor head that reads `spatial_features_2d`) rides along: its three
-    # 1x1 convolutions are the tail of the same chain, and nothing else differentiates through the 512-channel
-    # map — so the section hands out the head's raw predictions (differentiable) and the feature maps as plain
-    # values.
+    # `fused_head` (set by the detector: the anchor head that reads `spatial_features_2d`) rides along in the chained
+    # call below: its three 1x1 convolutions are the tail of the same chain, and nothing else differentiates through
+    # the 512-channel map — so the chain hands out the head's raw predictions (differentiable) and the feature maps as
+    # plain values.  (Round 4 ran this section as hipGraphs: replay was slower than eager issue on this runtime, §9.)
     fused_head = None
-
-    def _section_fn(self, x):
-        out, levels = self._levels(x)
-        heads = tuple(self.fused_head.conv_heads(out))
-        return heads + (out.detach(),) + tuple(f.detach() for _, f in levels)
-
-    def _graphed(self, data_dict, x):
-        from .. import graphs
-        head = self.fused_head
-        if head is None or not x.is_cuda:
-            return False
-        n_heads = 3 if head.conv_dir_cls is not None else 2
-        train = self.training and torch.is_grad_enabled()
-        if train and graphs.TRAIN_ENABLED and head.training:
-            sec = self.__dict__.get('_train_section')
-            if sec is None:
-                mods = [self, head.conv_cls, head.conv_box] + ([head.conv_dir_cls] if n_heads == 3 else [])
-                sec = self.__dict__['_train_section'] = graphs.TrainSection(
-                    self._section_fn, mods, 'bev_backbone+heads.train')
-            outs = sec(x)
-        elif graphs.ENABLED and not self.training and not head.training and not x.requires_grad and \
-                (not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters())):
-            sec = self.__dict__.get('_eval_section')
-            if sec is None:
-                sec = self.__dict__['_eval_section'] = graphs.StaticSection(self._section_fn, 'bev_backbone+heads.eval')
-            outs = sec(x, frozen=True)
-        else:
-            return False
-        data_dict['dense_head_convs'] = tuple(outs[:n_heads])
-        data_dict['spatial_features_2d'] = outs[n_heads]
-        full = x.shape[2]
-        for f in outs[n_heads + 1:]:
-            data_dict['spatial_features_%dx' % int(full / f.shape[2])] = f
-        return True
 
     # ---- the shape-static chain as ONE C-ABI call per pass (chain.py / dense_chain.py) -------------------------------
     def _build_chain(self, x, train):
@@ -285,7 +250,7 @@ class BaseBEVBackbone(nn.Module):
 
     def forward(self, data_dict):
         x = data_dict['spatial_features']
-        if self._graphed(data_dict, x) or self._chained(data_dict, x):
+        if self._chained(data_dict, x):
             return data_dict
         out, levels = self._levels(x)
         for stride, f in levels:

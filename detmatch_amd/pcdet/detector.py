@@ -124,14 +124,10 @@ class PVRCNN(nn.Module):
         return mods
 
     def run_modules(self, batch_dict, until=None):
-        """The module chain.  `after_backbone_3d` (a one-shot callable set on the instance by the stream
-        scheduler of SSL.forward_train, mode 'pairs') is called right after the sparse backbone has been
-        issued: from there on the pass consists of many small kernels, underneath which the paired 2D
-        pass is issued on its own stream.
+        """The module chain.
         `until`: stop in front of this module; the rest of the chain is remembered in the batch dict and runs when
         run_modules is called on it again (SSL issues the label-independent part of a pass — everything in front
         of the first module that reads `gt_boxes` — before the pseudo-labels exist)."""
-        bb = getattr(self, 'backbone_3d', None)
         todo = batch_dict.pop('_pending_modules', None)
         if todo is None:
             todo = list(self._order(batch_dict))
@@ -142,10 +138,6 @@ class PVRCNN(nn.Module):
                 return batch_dict
             todo.pop(0)
             batch_dict = cur_module(batch_dict)
-            if cur_module is bb:
-                hook = self.__dict__.pop('after_backbone_3d', None)
-                if hook is not None:
-                    hook(batch_dict)
         return batch_dict
 
     def label_independent_until(self):

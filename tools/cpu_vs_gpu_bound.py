@@ -52,13 +52,6 @@ def main():
     th1 = thread_cpu()
     rows = sorted(((c - th0.get(tid, (nm, 0.0))[1]) / n * 1e3, nm, tid) for tid, (nm, c) in th1.items())
     print('  CPU ms per step by thread: ' + ', '.join('%s[%d] %.1f' % (nm, tid, ms) for ms, nm, tid in rows[::-1] if ms >= 0.5))
-    from detmatch_amd import graphs
-    for ref in graphs._ALL_TRAIN_SECTIONS:
-        s = ref()
-        if s is not None and (s.captures or s.fallbacks):
-            print('  graph section %-28s captures %d  replays %d  backward replays %d  plain calls %d  host time in replays: fwd %.2f ms, bwd %.2f ms per step'
-                  % (s.name, s.captures, s.replays, s.bwd_replays, s.fallbacks, s.t_replay / (n + 5) * 1e3, s.t_replay_bwd / (n + 5) * 1e3))
-
 
 if __name__ == '__main__':
     main()
