@@ -561,11 +561,24 @@ def main():
                                global_batch=BATCH_PER_GPU * world,
                                parallelism='dp%d' % world),
                    roofline=roof)
+        ddp = getattr(wl, 'ddp', None)
+        if ddp is not None:
+            # multi-GPU readiness: how gradients are exchanged, and how many host cores a rank has
+            # to issue its iteration from (one Python thread + the autograd thread + the runtime's helper thread)
+            out['config']['grad_exchange'] = dict(mode=ddp.mode, collective=ddp.exchange, buckets=len(ddp.buckets),
+                                                  bucket_MiB=round(max(e - s_ for s_, e in ddp.buckets) * 4 / 2 ** 20, 1))
+        try:
+            out['config']['host_cores_per_rank'] = len(os.sched_getaffinity(0))
+        except AttributeError:
+            out['config']['host_cores_per_rank'] = os.cpu_count()
         model = getattr(wl, 'model', None)
         if model is not None and hasattr(model, 'lane_mode'):
             # how SSL.forward_train orders its modules over HIP streams (pcdet/workload.py)
             out['config']['stream_order'] = 'branches' if getattr(model, 'two_lanes', False) else \
                 (model.lane_mode or 'serial')
+            from detmatch_amd import chain
+            out['config']['issue'] = ('chained: one C-ABI call per static sub-graph (dm_chain_run)' if chain.ENABLED
+                                      else 'op by op') + ('' if not chain.OFF else ', families off: %s' % sorted(chain.OFF))
         # pseudo-label bookkeeping of the timed steps: proves the step exercises matching (NumPreds
         # metrics of the SSL chain, mean over the timed steps)
         lb = getattr(getattr(wl, 'runner', None), 'log_buffer', None) or {}

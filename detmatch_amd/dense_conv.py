@@ -33,6 +33,9 @@ _PACK_CACHE = {}
 _MATH = {'fp32_mfma': 0, 'bf16': 1, 'fp32_split': 2, 'fp32_split_nopatch': 18, 'fp32_split_tapwise_wgrad': 34}
 
 
+_MATH_CODE = [None]      # the library's arithmetic code, mirrored here (a ctypes query per convolution otherwise)
+
+
 def set_math(mode):
     """Arithmetic of the convolution GEMMs (forward, input gradient, weight gradient of the >= 128-channel layers):
       'fp32_split'  fp32-class: every operand is split into three bf16 numbers (together its 24 significand
@@ -48,11 +51,14 @@ def set_math(mode):
     if mode not in _MATH:
         raise ValueError("math mode must be one of 'fp32', %s" % sorted(_MATH))
     _lib.check(_lib.lib().dm_dconv_set_math(_MATH[mode]), 'dm_dconv_set_math')
+    _MATH_CODE[0] = _lib.lib().dm_dconv_get_math()
 
 
 def get_math_code():
-    """The library's arithmetic code (includes the developer bits); chains are built per code."""
-    return _lib.lib().dm_dconv_get_math()
+    """The library's arithmetic code; chains are built per code."""
+    if _MATH_CODE[0] is None:
+        _MATH_CODE[0] = _lib.lib().dm_dconv_get_math()
+    return _MATH_CODE[0]
 
 
 def get_math():
@@ -67,7 +73,12 @@ if FP32_DEFAULT not in _MATH:
     raise ValueError('DM_FP32_CONV must be one of %s' % sorted(_MATH))
 # The library starts in mode 0 (fp32_mfma); the default flavour is applied by a post-load hook, so importing
 # this module never loads (or needs) the .so and the mode is set whenever the library is first loaded.
-_lib.on_load(lambda l: _lib.check(l.dm_dconv_set_math(_MATH[FP32_DEFAULT]), 'dm_dconv_set_math'))
+def _apply_default(l):
+    _lib.check(l.dm_dconv_set_math(_MATH[FP32_DEFAULT]), 'dm_dconv_set_math')
+    _MATH_CODE[0] = l.dm_dconv_get_math()
+
+
+_lib.on_load(_apply_default)
 
 
 _EVENTS = []        # (generation after the event, ptr_lo, ptr_hi) of raw-pointer rewrites; None = everything
@@ -203,8 +214,9 @@ PLANES = os.environ.get('DM_DCONV_PLANES', '1') == '1'     # A/B: pre-split weig
 
 def _wants_planes(T, N, K, stride_one):
     """The layers dconv_patch_* takes in the split arithmetic (csrc/conv2d.hip: dm_dconv_gemm_planes)."""
-    return PLANES and stride_one and 4 <= T <= 9 and K % 32 == 0 and N % 4 == 0 and N >= 64 and \
-        _lib.lib().dm_dconv_get_math() == 2
+    if _MATH_CODE[0] is None:
+        _MATH_CODE[0] = _lib.lib().dm_dconv_get_math()
+    return PLANES and stride_one and 4 <= T <= 9 and K % 32 == 0 and N % 4 == 0 and N >= 64 and _MATH_CODE[0] == 2
 
 
 def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None, planes=False):
@@ -277,7 +289,9 @@ def _plan(kind, geom, taps):
         return hit[:3]
     key = (kind, tuple(geom), tuple(taps))
     hit = _PLAN_CACHE.get(key)
-    if hit is not None:
+    if hit is not None and any(geom is v[2] for v in _FWD_GEOM.values()):
+        # identity shortcut only for the cached forward geometries (lists that live as long as _FWD_GEOM): the
+        # backward / transposed paths build fresh lists per call, which would only churn this dict
         if len(_PLAN_BY_ID) > 8192:
             _PLAN_BY_ID.clear()
         _PLAN_BY_ID[fast] = hit + (geom, taps)

@@ -78,6 +78,36 @@ def broadcast(t, src, group=None):
     dist.broadcast(t, src, group=group)
 
 
+class _Chain2(object):
+    """Work handle of two dependent steps (reduce-scatter, then all-gather) done eagerly."""
+
+    def wait(self):
+        return True
+
+
+def reduce_scatter_then_all_gather(buf, shard, group=None):
+    """buf <- all-gather(reduce-scatter(buf)): the `rs_ag` exchange of one bucket.  RCCL: the two collectives,
+    asynchronous, on the process group's stream (the all-gather is ordered behind the reduce-scatter there).
+    gloo (CPU tests, and several ranks on one GPU): gloo has no reduce_scatter_tensor — every rank reduces the whole
+    bucket, keeps ITS shard (what a reduce-scatter leaves it with) and the shards are gathered back, so that the
+    shard arithmetic (bucket padding to a multiple of the world size, shard offsets, rank order) is exercised."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) != 'gloo':
+        dist.reduce_scatter_tensor(shard, buf, group=group, async_op=True)
+        return dist.all_gather_into_tensor(buf, shard, group=group, async_op=True)
+    rank = dist.get_rank(group)
+    n = shard.numel()
+    assert buf.numel() == n * world, 'bucket not padded to a multiple of the world size'
+    host = buf.detach().cpu() if buf.is_cuda else buf.detach().clone()
+    dist.all_reduce(host, group=group)
+    mine = host[rank * n:(rank + 1) * n].clone()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    shard.copy_(mine)
+    buf.copy_(torch.cat(parts))
+    return _Chain2()
+
+
 class FlatGradDDP(nn.Module):
 
     def __init__(self, module, params=None, bucket_bytes=64 << 20, process_group=None,
@@ -261,10 +291,8 @@ class FlatGradDDP(nn.Module):
             if self._shards is None:
                 self._shards = [torch.empty((e2 - s2) // self.world, dtype=torch.float32,
                                             device=self.flat.device) for s2, e2 in self.buckets]
-            sh = self._shards[b]
             # same stream of the process group: the all-gather runs after the reduce-scatter
-            dist.reduce_scatter_tensor(sh, buf, group=self.group, async_op=True)
-            self._pending.append(dist.all_gather_into_tensor(buf, sh, group=self.group, async_op=True))
+            self._pending.append(reduce_scatter_then_all_gather(buf, self._shards[b], self.group))
         else:
             self._pending.append(all_reduce(buf, group=self.group, async_op=True))
 

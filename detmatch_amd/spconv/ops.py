@@ -363,10 +363,13 @@ def _flush_weight_grads():
                 chunk = part[lo:lo + 16]
                 arr = (_lib.SpconvWgradJob * len(chunk))()
                 outs = []
+                # accumulate in place only if EVERY job of the chunk can (one flag per launch): otherwise each job
+                # gets a fresh buffer that is added afterwards (a job writing into its own .grad with accumulate = 0
+                # would lose the earlier pass and then be added to itself)
+                in_place = bool(accumulate) and all(j[1].grad is not None and j[1].grad.is_contiguous() for j in chunk)
                 for a, (feat, w, dy, pairs, num, _) in zip(arr, chunk):
-                    if accumulate:
-                        tgt = w.grad if w.grad.is_contiguous() else None
-                        out = tgt if tgt is not None else torch.empty_like(w)
+                    if in_place:
+                        tgt = out = w.grad
                     else:
                         tgt, out = None, torch.empty_like(w)
                     outs.append((w, out, tgt))
@@ -374,7 +377,7 @@ def _flush_weight_grads():
                     a.feat, a.out_grad, a.indice_pairs, a.indice_num = feat.data_ptr(), dy.data_ptr(), pairs.data_ptr(), num.data_ptr()
                     a.filt_grad = out.data_ptr()
                     a.pair_stride, a.kvol, a.cin, a.cout = int(stride), int(kvol), int(w.shape[-2]), int(w.shape[-1])
-                acc_all = bool(accumulate) and all(t is not None for _, _, t in outs)
+                acc_all = in_place
                 ws = _lib.workspace(L.dm_spconv_wgrad_batch_workspace_bytes(arr, len(chunk)), dev, 'wgrad_batch')
                 _lib.check(L.dm_spconv_wgrad_batch(arr, len(chunk), int(acc_all), _lib.ptr(ws), ws.numel(),
                                                    _lib.stream()), 'dm_spconv_wgrad_batch')

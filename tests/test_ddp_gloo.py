@@ -304,3 +304,69 @@ def test_hooks_mode_with_unfused_optimizer_and_unused_parameter():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == 'ok', 'rank %d: %s' % (rank, msg)
+
+
+def _worker_exchange(rank, world, port, q):
+    """The gradient arena after collect / all_reduce, collect / rs_ag and hooks / rs_ag on the SAME per-rank gradients:
+    bucket padding, shard offsets and the strictly ordered bucket issue of `hooks` give the same averaged gradients
+    (until round 5 `rs_ag` had only ever run on a one-rank RCCL group)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from detmatch_amd.mm3d.parallel import FlatGradDDP
+        results = {}
+        for mode, exchange in (('collect', 'all_reduce'), ('collect', 'rs_ag'), ('hooks', 'rs_ag'), ('hooks', 'all_reduce')):
+            torch.manual_seed(5)                   # same start on every rank and for every variant
+            net = _Net()
+            ddp = FlatGradDDP(net, bucket_bytes=200, mode=mode, exchange=exchange, broadcast=False)
+            assert len(ddp.buckets) > 2
+            for s_, e_ in ddp.buckets:            # every bucket cuts into `world` equal 16-byte aligned shards
+                assert (e_ - s_) % (4 * world) == 0
+            flats = []
+            for step in range(2):
+                torch.manual_seed(50 + 10 * step + rank)        # different data per rank
+                x = torch.randn(6, 8)
+                ddp.zero_grad()
+                if step == 1:                      # two backward passes accumulate, only the last one may exchange
+                    ddp.zero_grad(arm=False)
+                    ddp(x[:3]).square().mean().backward()
+                    ddp.collect()
+                    ddp.arm()
+                    ddp(x[3:]).square().mean().backward()
+                else:
+                    ddp(x).square().mean().backward()
+                ddp.finish()
+                flats.append(ddp.flat.clone())
+            results[(mode, exchange)] = flats
+            # liveness flags ride in the last bucket: summed over the ranks, every live parameter was seen by both
+            assert float(ddp.used.max()) == float(world) and bool(ddp.ever.any())
+        ref = results[('collect', 'all_reduce')]
+        for key, flats in results.items():
+            for a, b in zip(flats, ref):
+                assert torch.allclose(a, b, rtol=1e-6, atol=1e-8), key
+        # and every rank holds the same arena
+        for flats in results.values():
+            got = [torch.zeros_like(flats[-1]) for _ in range(world)]
+            dist.all_gather(got, flats[-1])
+            assert torch.equal(got[0], got[1])
+        q.put((rank, 'ok'))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rs_ag_and_hooks_equal_collect_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', 'rank %d: %s' % (rank, msg)
