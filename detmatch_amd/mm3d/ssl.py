@@ -641,6 +641,17 @@ class SSL(nn.Module):
 
         run = (lambda m, d: lanes.run(m, self, d)) if lanes is not None else run_serial
 
+        branches_first = lanes is not None and lanes.mode == 'branches' and _ISSUE_EARLY
+        if branches_first:
+            # Scheduling only ('branches'): what needs no 3D geometry — the student's shared 2D trunk and the
+            # teacher's 2D inference, both on the 2D lane — is issued BEFORE the geometry, whose size read-backs
+            # wait for the tail of the previous iteration on the main stream: the host issues these while it would
+            # otherwise idle there.
+            lanes.fork()
+            self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
+            for m in self.unlab_ssl_modules:
+                if getattr(m, 'early_before_geometry', False) and hasattr(m, 'issue_early'):
+                    lanes.run(m, self, unlab_dict, method='issue_early')
         # weight-independent geometry of every pass of the iteration, issued up front
         jobs = []
         for chain, d in ((self.lab_ssl_modules, lab_dict), (self.unlab_ssl_modules, unlab_dict)):
@@ -658,9 +669,10 @@ class SSL(nn.Module):
             # one device->host copy per round for all of them
             from ..spconv.ops import drive_steps_together
             drive_steps_together(jobs)
-        if lanes is not None:
-            lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
-        self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
+        if not branches_first:
+            if lanes is not None:
+                lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
+            self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
         unlab_modules = list(self.unlab_ssl_modules)
         if lanes is not None and (lanes.mode == 'glue' or getattr(self, 'lane_hoist', False)):
             # The teacher's inference passes read nothing but the raw unlabeled batch: issue them first, so

@@ -473,6 +473,7 @@ class SimpleTest_2D(object):
     (decoded boxes N x 4, softmax/sigmoid scores N x (C+1)), in the augmented image frame."""
 
     hoistable = True          # reads only the raw batch (see Opd_SimpleTest_3D)
+    early_before_geometry = True      # ... and no 3D geometry: SSL issues it while the geometry's read-backs are pending
 
     def __init__(self, ssl_obj_attr='teacher', batch_dict_key='tea', out_bboxes_key='2d_simple_test'):
         self.ssl_obj_attr = ssl_obj_attr
