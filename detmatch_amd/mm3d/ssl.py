@@ -24,6 +24,7 @@ def add_prefix(inputs, prefix):
 
 
 _ISSUE_EARLY = os.environ.get('DM_ISSUE_EARLY', '1') == '1'      # A/B switch of SSL modules' issue_early
+_EARLY_2D_BWD = os.environ.get('DM_EARLY_2D_BWD', '1') == '1'    # A/B switch of SSL._early_2d_backward
 
 
 class _LaneDict(dict):
@@ -130,6 +131,7 @@ class _Lanes(object):
         self.streams = [self.main] + pool
         self.current = 0
         self.pending = []
+        self.partial = {}             # lane -> event the main lane waits for in join() instead of the whole lane
         self.rng = None               # _RngWindows of the iteration
 
     def stream(self, lane):
@@ -180,8 +182,12 @@ class _Lanes(object):
 
     def join(self, *values):
         """Everything issued on the other lanes so far becomes visible to the main lane."""
-        for s in self.streams[1:]:
-            self.main.wait_stream(s)
+        for i, s in enumerate(self.streams[1:], 1):
+            ev = self.partial.get(i)
+            if ev is not None:
+                self.main.wait_event(ev)
+            else:
+                self.main.wait_stream(s)
         for v in values:
             self.record(v, self.main)
 
@@ -531,6 +537,42 @@ class SSL(nn.Module):
         for det in getattr(self, '_deferred', []):
             det.finish_deferred_backward()
         self._deferred = []
+        ev = self.__dict__.pop('_trunk_bwd_done', None)
+        if ev is not None:      # the trunk backward ran early on the 2D lane: whoever reads its gradients next waits for it
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _early_2d_backward(self, lanes, module, d, ssl_weight):
+        """'branches' only.  The student's 2D trunk receives gradient from the supervised 2D module (back-propagated
+        with the labeled chain) and from this one — the consistency loss reaches the 3D student only
+        (configs/detmatch/001/detmatch/split_0.py: its 2D side is the detached teacher).  So once this module has
+        run, its losses AND the deferred trunk backward can be issued on the 2D lane, underneath the rest of the
+        unlabeled chain, instead of behind the whole 3D backward at the end of the iteration (the 2D lane idled there
+        while the host issued the 3D backward: 26 ms of device time after the last forward kernel).  d(sum) = sum of d."""
+        side = lanes.stream(1)
+        before = dict(d['ssl_losses'])
+        d = lanes.run(module, self, d)
+        cur = self._collapse_losses(d['ssl_losses'])
+        picked = [(k, v) for k, v in cur.items() if (k not in before or before[k] is not v) and v.requires_grad]
+        if any(k in before for k, _ in picked):
+            return d
+        w = float(ssl_weight)
+        with torch.cuda.stream(side):
+            terms = []
+            for k, v in picked:
+                if 'loss' in k:
+                    terms.append(v if (w == 1.0 or '.metrics' in k or '.acc' in k) else v * w)
+                cur[k] = v.detach()
+            d['ssl_losses'] = cur
+            pre = torch.cuda.Event()
+            if terms:
+                sum(terms).backward()
+            pre.record(side)
+            self.finish_deferred_backward()
+            done = torch.cuda.Event()
+            done.record(side)
+        lanes.partial[1] = pre            # join(): the main lane needs the 2D lane up to here only ...
+        self._trunk_bwd_done = done       # ... the trunk's gradients are waited for where they are read
+        return d
 
     def prefetch_geometry(self, data, ready=None, tag='ahead'):
         """The weight-independent geometry (voxels, rulebooks, FPS key points) of every 3D pass of a FUTURE
@@ -728,8 +770,19 @@ class SSL(nn.Module):
                     else:
                         rng.enter(m)
                         m.issue_early(self, unlab_dict)
+        early_2d = lanes is not None and lanes.mode == 'branches' and _EARLY_2D_BWD and torch.is_grad_enabled() and \
+            getattr(self, '_deferred', None) and getattr(self, 'early_backward', False)
+        last_2d = None
+        if early_2d:
+            from .ssl_modules import HardPseudoLabel_2D
+            cands = [m for m in unlab_modules if isinstance(m, HardPseudoLabel_2D)]
+            users = [m for m in unlab_modules if str(getattr(m, 'ssl_obj_attr', '')).endswith('student.detector_2d')]
+            last_2d = cands[-1] if cands and users and users[-1] is cands[-1] else None
         for m in unlab_modules:
-            unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
+            if m is last_2d:
+                unlab_dict = self._early_2d_backward(lanes, m, unlab_dict, curr_ssl_weight)
+            else:
+                unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
         if lanes is not None:
             lanes.join(unlab_dict['ssl_losses'], lab_dict['ssl_losses'])
         losses = dict()

@@ -215,6 +215,32 @@ def test_lanes_do_not_change_gradients(dev, mode):
     assert rel < 2e-3, float(rel)
 
 
+def test_early_2d_backward_does_not_change_gradients(dev, monkeypatch):
+    """'branches' with the shared 2D trunk: the unlabeled 2D module's losses and the deferred trunk backward issued on
+    the 2D lane right after that module (SSL._early_2d_backward) give the same accumulated gradients and losses as
+    back-propagating everything at the end of the iteration; likewise the early issue of the unlabeled passes."""
+    from detmatch_amd.mm3d import ssl
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    out = []
+    for early in (True, False):
+        monkeypatch.setattr(ssl, '_EARLY_2D_BWD', early)
+        monkeypatch.setattr(ssl, '_ISSUE_EARLY', early)
+        wl = DetMatchTrainWorkload(2, dev)
+        assert wl.model.two_lanes and wl.model.share_2d_trunk
+        torch.manual_seed(321)       # one iteration: no feedback through updated weights
+        wl.step()
+        torch.cuda.synchronize()
+        out.append((wl.ddp.flat.clone(), {k: float(v) for k, v in wl.last_log.items()}))
+        del wl
+    (ga, la), (gb, lb) = out
+    assert torch.isfinite(ga).all() and ga.abs().sum() > 0
+    assert set(la) == set(lb)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    rel = (ga - gb).norm() / gb.norm()
+    assert rel < 2e-3, float(rel)
+
+
 def test_confthr_frcnn_iteration(dev):
     """2D-only SSL recipe (configs/detmatch/001/confthr_frcnn): teacher Faster R-CNN ->
     NMS(0.7) -> un-augment / re-augment -> hard pseudo labels for the student; two iterations."""
