@@ -85,6 +85,9 @@ def pmc_traffic(kernel):
     return None, None
 
 
+ISOLATED_RECS = []      # dm_profile records of the one-stream, op-by-op extra step (other_kernel_groups)
+
+
 def other_kernel_groups(wl):
     """One extra (untimed) step with HIP events around every dense-convolution launch and every FPS launch:
     the kernels that decide the step time, beside the sparse group BASELINE's metric names.
@@ -123,10 +126,14 @@ def other_kernel_groups(wl):
     chain.ENABLED = False
     if model is not None and saved[1] is not None:
         model.two_lanes, model.lane_mode = False, 'glue'
+    from detmatch_amd import _lib
+    _lib.lib().dm_profile_enable(1)        # the sparse gather-GEMMs of this step too: each kernel alone on the device
     try:
         wl.step()
         torch.cuda.synchronize()
     finally:
+        ISOLATED_RECS[:] = _lib.profile_records()
+        _lib.lib().dm_profile_enable(0)
         dense_conv._gemm, dense_conv._wgrad, pn2.furthest_point_sample_stack = g0, w0, f0
         chain.ENABLED = saved[0]
         if model is not None and saved[1] is not None:
@@ -547,6 +554,17 @@ def main():
                                              unit='GB/s', frac=round(g['bytes'] / sec / 1e9 / HBM_PEAK_GBS, 4),
                                              convention='SURVEY 8(d): P*(Cin+Cout)*4 + 8P + K*Cin*Cout*4 + N_out*Cout*4'),
                         all_spconv={k: rates(v) for k, v in by_dir.items()}, other_kernels=others)
+            # the same kernel with the device to itself (the extra one-stream step): in the timed region the three stream
+            # lanes co-schedule it with the 2D branch's convolutions, and its duration there includes the compute units
+            # it has to share — both are the dispatch's own begin -> end time (what rocprofv3 reports)
+            iso = [r for r in ISOLATED_RECS if r[0] == 0 and not r[3] and 'spconv_gr<%d,%d>' % (r[1], r[2]) == name]
+            if iso:
+                iso_us = sum(r[7] for r in iso) / len(iso) * 1e3
+                per = g['bytes'] / g['launches']
+                roof['alone_on_the_device'] = dict(avg_us=round(iso_us, 2), launches=len(iso),
+                                                   algorithmic_hbm_frac=round(per / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                   frac=round(g['flops'] / g['launches'] / (iso_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                                   note='one extra step issued op by op on ONE stream (no lanes)')
         # weak scaling: every rank steps through its own (2 labeled + 2 unlabeled) batch, so the
         # whole-job rate is world x steps / time (per-GPU-batch iterations per second, all ranks)
         out = dict(metric='train iters/sec', value=round(world * args.steps * 1.0 / dt, 3), unit='iters/sec',

@@ -127,7 +127,12 @@ class _Lanes(object):
         self.main = torch.cuda.current_stream(device)
         pool = _Lanes._side.get(device.index)
         if pool is None:
-            pool = _Lanes._side[device.index] = [torch.cuda.Stream(device=device) for _ in range(self.N - 1)]
+            # DM_LANE_PRIORITY (A/B): 'teacher' = the teacher-3D + glue lane on a high-priority stream, '3d' = that and
+            # nothing else differs (the student's 3D passes run on the caller's stream)
+            prio = os.environ.get('DM_LANE_PRIORITY', '')
+            pool = _Lanes._side[device.index] = [
+                torch.cuda.Stream(device=device),
+                torch.cuda.Stream(device=device, priority=-1 if prio in ('teacher', '3d') else 0)]
         self.streams = [self.main] + pool
         self.current = 0
         self.pending = []
