@@ -73,7 +73,7 @@ def pmc_traffic(kernel):
     """(HBM-side bytes per launch of `kernel`, the committed file they come from): rocprofv3 PMC passes of this
     same bench command (FETCH_SIZE and WRITE_SIZE in separate --pmc runs, gfx950 correction applied —
     tools/pmc_traffic.py, tools/collect_profiles.sh).  NOT measured in this run: the counters need the profiler."""
-    for name in ('r04_pmc_spconv.json', 'r03_pmc_spconv.json', 'r02_pmc_spconv.json', 'r01_pmc_spconv.json'):
+    for name in ('r05_pmc_spconv.json', 'r04_pmc_spconv.json', 'r03_pmc_spconv.json', 'r02_pmc_spconv.json', 'r01_pmc_spconv.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
