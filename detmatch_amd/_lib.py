@@ -163,6 +163,8 @@ SIGNATURES = {
     'dm_profile_count': (ci, []),
     'dm_profile_get': (ci, [ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
                             ctypes.POINTER(ctypes.c_ulonglong), c_f32_p]),
+    'dm_roi_decode_forward': (ci, [vp, vp, ci, vp, vp]),
+    'dm_roi_decode_backward': (ci, [vp, vp, vp, ci, vp, vp]),
     'dm_chain_fn_count': (ci, []),
     'dm_chain_fn_index': (ci, [ctypes.c_char_p]),
     'dm_chain_fn_name': (ctypes.c_char_p, [ci]),

@@ -46,7 +46,70 @@ __global__ __launch_bounds__(256) void anchor_decode_kernel(
   o[6] = r;
 }
 
+// RoI-head box decoding (roi_head_template.py:233-263): ResidualCoder.decode_torch against the RoI as a local anchor at
+// the origin, rotation of the decoded centre by the RoI's heading (common_utils.rotate_points_along_z), translation by
+// the RoI's centre — 20 element-wise / matmul / cat launches per pass in the tensor formulation, one here; and its
+// gradient w.r.t. the encodings (the RoIs are detached), which the consistency losses need.
+__global__ __launch_bounds__(256) void roi_decode_kernel(const float *__restrict__ enc, const float *__restrict__ rois,
+                                                          int n, float *__restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float *r = rois + (size_t)i * 7, *t = enc + (size_t)i * 7;
+  const float dx = r[3], dy = r[4], dz = r[5], ry = r[6];
+  const float diagonal = sqrtf(dx * dx + dy * dy);
+  const float xg = t[0] * diagonal, yg = t[1] * diagonal, zg = t[2] * dz;
+  const float c = cosf(ry), s = sinf(ry);
+  float *o = out + (size_t)i * 7;
+  o[0] = (xg * c - yg * s) + r[0];
+  o[1] = (xg * s + yg * c) + r[1];
+  o[2] = zg + r[2];
+  o[3] = expf(t[3]) * dx;
+  o[4] = expf(t[4]) * dy;
+  o[5] = expf(t[5]) * dz;
+  o[6] = t[6] + ry;
+}
+
+__global__ __launch_bounds__(256) void roi_decode_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ enc,
+                                                              const float *__restrict__ rois, int n,
+                                                              float *__restrict__ grad_enc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float *r = rois + (size_t)i * 7, *t = enc + (size_t)i * 7, *g = grad + (size_t)i * 7;
+  const float dx = r[3], dy = r[4], dz = r[5], ry = r[6];
+  const float diagonal = sqrtf(dx * dx + dy * dy);
+  const float c = cosf(ry), s = sinf(ry);
+  float *o = grad_enc + (size_t)i * 7;
+  o[0] = (g[0] * c + g[1] * s) * diagonal;
+  o[1] = (g[1] * c - g[0] * s) * diagonal;
+  o[2] = g[2] * dz;
+  o[3] = g[3] * (expf(t[3]) * dx);
+  o[4] = g[4] * (expf(t[4]) * dy);
+  o[5] = g[5] * (expf(t[5]) * dz);
+  o[6] = g[6];
+}
+
 }  // namespace
+
+extern "C" int dm_roi_decode_forward(const float *box_encodings, const float *rois, int n, float *boxes,
+                                     dm_stream_t stream) {
+  if (n < 0) return DM_ERR_INVALID_ARG;
+  if (n == 0) return DM_OK;
+  if (!box_encodings || !rois || !boxes) return DM_ERR_INVALID_ARG;
+  roi_decode_kernel<<<dm_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(box_encodings, rois, n, boxes);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_roi_decode_backward(const float *grad_boxes, const float *box_encodings, const float *rois, int n,
+                                      float *grad_encodings, dm_stream_t stream) {
+  if (n < 0) return DM_ERR_INVALID_ARG;
+  if (n == 0) return DM_OK;
+  if (!grad_boxes || !box_encodings || !rois || !grad_encodings) return DM_ERR_INVALID_ARG;
+  roi_decode_bwd_kernel<<<dm_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(grad_boxes, box_encodings, rois, n,
+                                                                             grad_encodings);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
 
 extern "C" int dm_anchor_decode(const float *box_encodings, const float *anchors, const float *dir_logits,
                                 long long n_total, int n_anchors, int n_dir_bins, float dir_offset,

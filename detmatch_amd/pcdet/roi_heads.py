@@ -252,6 +252,32 @@ class _FusedRcnnLoss(torch.autograd.Function):
         return d_cls.view(ctx.cls_shape), d_reg, None, None, None, None, None, None
 
 
+class _RoiDecode(torch.autograd.Function):
+    """dm_roi_decode_forward / _backward (csrc/box_decode.hip): generate_predicted_boxes' decode + rotate + translate in
+    one launch, gradient w.r.t. the refinements in one launch."""
+
+    @staticmethod
+    def forward(ctx, reg, rois):
+        reg = reg.contiguous()
+        rois = rois.detach().contiguous()
+        _lib.require_device(reg, rois)
+        n = int(reg.shape[0])
+        out = torch.empty((n, 7), dtype=torch.float32, device=reg.device)
+        _lib.check(_lib.lib().dm_roi_decode_forward(reg.data_ptr(), rois.data_ptr(), n, out.data_ptr(), _lib.raw_stream()),
+                   'dm_roi_decode_forward')
+        ctx.save_for_backward(reg, rois)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        reg, rois = ctx.saved_tensors
+        grad = grad.contiguous()
+        g = torch.empty_like(reg)
+        _lib.check(_lib.lib().dm_roi_decode_backward(grad.data_ptr(), reg.data_ptr(), rois.data_ptr(), int(reg.shape[0]),
+                                                     g.data_ptr(), _lib.raw_stream()), 'dm_roi_decode_backward')
+        return g, None
+
+
 class PVRCNNHead(nn.Module):
     """roi_head_template.py:11-263 + pvrcnn_head.py:8-201."""
 
@@ -419,6 +445,10 @@ class PVRCNNHead(nn.Module):
         """roi_head_template.py:233-263"""
         code_size = self.box_coder.code_size
         batch_cls_preds = cls_preds.view(batch_size, -1, cls_preds.shape[-1])
+        if fused_on() and box_preds.is_cuda and code_size == 7 and rois.shape[-1] == 7 and box_preds.dtype == torch.float32 \
+                and rois.dtype == torch.float32 and box_preds.numel() == rois.numel():
+            decoded = _RoiDecode.apply(box_preds.view(-1, 7), rois.view(-1, 7))
+            return batch_cls_preds, decoded.view(batch_size, -1, code_size)
         batch_box_preds = box_preds.view(batch_size, -1, code_size)
         roi_ry = rois[:, :, 6].view(-1)
         roi_xyz = rois[:, :, 0:3].view(-1, 3)

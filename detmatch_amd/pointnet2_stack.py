@@ -473,17 +473,24 @@ class StackSAModuleMSG(nn.Module):
             from . import chain as _chain
             train = self.mlps[0][1].training
             if _chain.on('sa', train) and fused_on():
-                key = (xyz_batch_cnt.numel(), new_xyz.shape[0], features.shape[1], train)
+                c_real = features.shape[1]
+                c_pad = (c_real + 3) // 4 * 4
+                fgrad = bool(features.requires_grad and torch.is_grad_enabled())
+                if c_pad != c_real and fgrad:
+                    c_pad = -1                         # padded features are plain values only (raw points)
+                key = (xyz_batch_cnt.numel(), new_xyz.shape[0], c_real, train, fgrad or c_pad == c_real)
                 cache = self.__dict__.setdefault('_chains', {})
                 ch = cache.get(key)
                 if ch is None or (ch is not False and not ch.valid()):
                     from .sa_chain import SAChain
                     if len(cache) > 8:
                         cache.clear()
-                    ch = cache[key] = SAChain(self, key[0], key[1], key[2], xyz.device, train) \
-                        if SAChain.applicable(self, key[1], key[2], train) else False
+                    ch = cache[key] = SAChain(self, key[0], key[1], c_pad, xyz.device, train, c_real=c_real, feat_grad=key[4]) \
+                        if c_pad > 0 and SAChain.applicable(self, key[1], c_pad, train, c_real) else False
                 if ch is not False and (train or not (torch.is_grad_enabled() and (
                         features.requires_grad or any(p.requires_grad for p in self.parameters())))):
+                    if c_pad != c_real:                # zero columns behind the real ones (their weights are zero too)
+                        features = F.pad(features, (0, c_pad - c_real))
                     return new_xyz, ch(xyz, _i32(xyz_batch_cnt).contiguous(), new_xyz, _i32(new_xyz_batch_cnt).contiguous(),
                                        features)
         if self.row_layout and self.pool_method == 'max_pool':

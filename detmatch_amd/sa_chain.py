@@ -26,9 +26,11 @@ def _bn_ok(bn, c):
 class SAChain(object):
 
     @staticmethod
-    def applicable(module, m, c_feat, train):
-        """The configurations the chain is built for (anything else keeps the op-by-op path)."""
+    def applicable(module, m, c_feat, train, c_real=None):
+        """The configurations the chain is built for (anything else keeps the op-by-op path).  c_real < c_feat: the
+        features were zero-padded to c_feat columns (raw points: one intensity column -> four)."""
         L = _lib.lib()
+        c_real = c_feat if c_real is None else c_real
         if len(module.groupers) != 2 or module.pool_method != 'max_pool' or not module.row_layout or c_feat % 4:
             return False
         for g, mlp in zip(module.groupers, module.mlps):
@@ -36,6 +38,8 @@ class SAChain(object):
                 return False
             mods = list(mlp)
             k = 4 + c_feat
+            if not mods or not isinstance(mods[0], nn.Conv2d) or mods[0].in_channels != 3 + c_real:
+                return False
             for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
                 if not isinstance(conv, nn.Conv2d) or not isinstance(bn, nn.BatchNorm2d) or not isinstance(act, nn.ReLU):
                     return False
@@ -46,10 +50,12 @@ class SAChain(object):
                 k = n
         return True
 
-    def __init__(self, module, batch, m, c_feat, device, train, name='sa'):
+    def __init__(self, module, batch, m, c_feat, device, train, name='sa', c_real=None, feat_grad=True):
         L = _lib.lib()
         self.module, self.train, self.device = module, train, device
         self.batch, self.m, self.c = batch, m, c_feat
+        self.c_real = c_feat if c_real is None else c_real
+        self.feat_grad = feat_grad      # False: nobody differentiates the features (raw points): no scatter of row gradients
         self.weights = W = _Weights(device)
         fwd = self.fwd = Program(name + '.fwd')
         fa = fwd.layout('arena')
@@ -82,10 +88,11 @@ class SAChain(object):
                 n = conv.out_channels
                 W.watch.append(conv.weight)
                 if li == 0:       # zero column for the padding float after xyz (pointnet2_stack._PadXyzColumn)
-                    w = torch.zeros((n, k), dtype=torch.float32, device=device)
-                    src = conv.weight.detach().view(n, k - 1)
-                    W.calls.append(('dm_copy2d_f32', src, k - 1, w, k, n, 3, ST))
-                    W.calls.append(('dm_copy2d_f32', src.data_ptr() + 12, k - 1, w.data_ptr() + 16, k, n, k - 4, ST))
+                    w = torch.zeros((n, k), dtype=torch.float32, device=device)      # (+ zero columns of padded features)
+                    ks = 3 + self.c_real
+                    src = conv.weight.detach().view(n, ks)
+                    W.calls.append(('dm_copy2d_f32', src, ks, w, k, n, 3, ST))
+                    W.calls.append(('dm_copy2d_f32', src.data_ptr() + 12, ks, w.data_ptr() + 16, k, n, self.c_real, ST))
                     W.keep += [src, w]
                 else:
                     w = conv.weight.detach().view(n, k)
@@ -178,22 +185,27 @@ class SAChain(object):
                 w_, wb = ws(L.dm_tall_wgrad_workspace_bytes(rows, n, k))
                 bwd.call('dm_tall_wgrad', gy, F(rec['x']), gw, rows, n, k, 0, w_, wb, ST)
                 if rec['first']:
-                    gwu = ba.floats(n, k - 1)
-                    bwd.call('dm_copy2d_f32', gw, k, gwu, k - 1, n, 3, ST)
-                    bwd.call('dm_copy2d_f32', gw + 16, k, gwu + 12, k - 1, n, k - 4, ST)
+                    ks = 3 + self.c_real
+                    gwu = ba.floats(n, ks)
+                    bwd.call('dm_copy2d_f32', gw, k, gwu, ks, n, 3, ST)
+                    bwd.call('dm_copy2d_f32', gw + 16, k, gwu + 12, ks, n, self.c_real, ST)
                     gw = gwu
-                    self.param_refs.append((gw, n * (k - 1)))
+                    self.param_refs.append((gw, n * ks))
                 else:
                     self.param_refs.append((gw, n * k))
                 self.params.append(conv.weight)
-                # input gradient
+                # input gradient (of the first layer only when somebody differentiates the features)
+                if rec['first'] and not self.feat_grad:
+                    continue
                 dead = 4 if rec['first'] else 0
                 g = ba.floats(rows, k)
                 bwd.call('dm_rowgemm_wt', gy, rec['w'].data_ptr() + 4 * dead, k, g, rows, n, k - dead, k, dead, ST)
-            rec0 = layers[0]
-            bwd.call('dm_group_rows_grad', batch, m, c_feat, n_src, rec0['ns'], width, 4, g, F(rec0['idx']), new_cnt,
-                     xyz_cnt, F(rec0['emp']), gfeat if gi == 0 else gfeat2, ST)
-        bwd.call('dm_add_mask_f32', gfeat, gfeat2, None, gfeat, nc_src, ST)
+            if self.feat_grad:
+                rec0 = layers[0]
+                bwd.call('dm_group_rows_grad', batch, m, c_feat, n_src, rec0['ns'], width, 4, g, F(rec0['idx']), new_cnt,
+                         xyz_cnt, F(rec0['emp']), gfeat if gi == 0 else gfeat2, ST)
+        if self.feat_grad:
+            bwd.call('dm_add_mask_f32', gfeat, gfeat2, None, gfeat, nc_src, ST)
         self.bwd_bytes = ba.size
         bwd.finalize()
 
@@ -217,14 +229,14 @@ class SAChain(object):
     def backward_raw(self, arena, xyz_cnt, new_cnt, n_src, gout):
         garena = torch.empty(self.bwd_bytes, dtype=torch.uint8, device=self.device)
         ws = _lib.workspace(self.bwd.ws_bytes, self.device, 'chain') if self.bwd.ws_bytes else None
-        gfeat = torch.empty((2, n_src, self.c), dtype=torch.float32, device=self.device)
+        gfeat = torch.empty((2, n_src if self.feat_grad else 1, self.c), dtype=torch.float32, device=self.device)
         gout = gout.contiguous()
         self.bwd.run([arena.data_ptr(), garena.data_ptr(), 0 if ws is None else ws.data_ptr(), xyz_cnt.data_ptr(),
                       new_cnt.data_ptr(), n_src, n_src * self.c, gout.data_ptr(), gfeat.data_ptr(),
                       gfeat.data_ptr() + 4 * n_src * self.c])
         f = garena.view(torch.float32)
         grads = [f[ref.off // 4:ref.off // 4 + numel].view(p.shape) for p, (ref, numel) in zip(self.params, self.param_refs)]
-        return gfeat[0], grads
+        return (gfeat[0] if self.feat_grad else None), grads
 
     def __call__(self, xyz, xyz_cnt, new_xyz, new_cnt, feat):
         for t in (xyz, xyz_cnt, new_xyz, new_cnt, feat):

@@ -943,6 +943,15 @@ int dm_profile_count(void);
 int dm_profile_get(int i, int *kind, int *a, int *b, int *c, int *rows, int *kvol,
                    unsigned long long *table, float *ms);
 
+/* RoI-head box decoding — RoIHeadTemplate.generate_predicted_boxes (pcdet/models/roi_heads/roi_head_template.py:233-263):
+ * ResidualCoder.decode_torch (pcdet/utils/box_coder_utils.py:43-76) of the (n, 7) refinements against each RoI taken as a
+ * local anchor at the origin, rotate_points_along_z (pcdet/utils/common_utils.py:34-56) of the decoded centre by the
+ * RoI's heading, translation by the RoI's centre: boxes (n, 7).  The backward gives the gradient w.r.t. the refinements
+ * (the RoIs are detached, roi_head_template.py:96-99) — the 2D <-> 3D consistency losses differentiate these boxes. */
+int dm_roi_decode_forward(const float *box_encodings, const float *rois, int n, float *boxes, dm_stream_t stream);
+int dm_roi_decode_backward(const float *grad_boxes, const float *box_encodings, const float *rois, int n,
+                           float *grad_encodings, dm_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* Chain-level issue (host-side launch interpreter)                          */
 /* ------------------------------------------------------------------------ */

@@ -387,3 +387,44 @@ def test_voxel_backbone_chain_equals_op_by_op(dev, train):
     if train:
         for k in ref['grads']:
             _same(got['grads'][k], ref['grads'][k], 'grad ' + k)
+
+
+def test_sa_module_chain_on_padded_raw_point_features(dev):
+    """The raw-points source of VoxelSetAbstraction has ONE feature column (intensity): the chain pads it to four (zero
+    columns meeting zero weight columns) so that the grouped rows are 16-byte aligned; the op-by-op path runs its 5-wide
+    first layer on BLAS — equal to fp32 rounding, parameters' gradients included; the features carry no gradient."""
+    from detmatch_amd import pointnet2_stack as pn
+    torch.manual_seed(9)
+    g = torch.Generator(device='cpu').manual_seed(10)
+    m_per, counts = 1024, [6000, 5000]
+    sa = pn.StackSAModuleMSG(radii=[0.4, 0.8], nsamples=[16, 16], mlps=[[1, 16, 16], [1, 16, 16]], use_xyz=True,
+                             pool_method='max_pool').to(dev)
+    state = copy.deepcopy(sa.state_dict())
+    n = sum(counts)
+    xyz = (torch.rand(n, 3, generator=g) * torch.tensor([10.0, 10.0, 2.0])).to(dev)
+    feats = torch.rand(n, 1, generator=g).to(dev)
+    new_xyz = torch.cat([xyz[:counts[0]][:m_per], xyz[counts[0]:][:m_per]]).contiguous() + 0.02
+    args = (xyz, torch.tensor(counts, dtype=torch.int32, device=dev), new_xyz,
+            torch.tensor([m_per, m_per], dtype=torch.int32, device=dev))
+
+    def run(enabled):
+        from detmatch_amd import chain
+        old = chain.ENABLED
+        chain.ENABLED = enabled
+        try:
+            sa.load_state_dict(state)
+            sa.train()
+            for p in sa.parameters():
+                p.grad = None
+            _, out = sa(*args, features=feats)
+            gg = torch.Generator(device='cpu').manual_seed(11)
+            (out * torch.randn(out.shape, generator=gg).to(dev)).sum().backward()
+            return out.detach().clone(), {k: p.grad.clone() for k, p in sa.named_parameters()}
+        finally:
+            chain.ENABLED = old
+    ref_out, ref_g = run(False)
+    got_out, got_g = run(True)
+    assert any(v is not False for v in sa.__dict__.get('_chains', {}).values()), 'the chain did not run'
+    assert float((got_out - ref_out).abs().max()) <= 1e-4 * float(ref_out.abs().max())
+    for k in ref_g:
+        assert float((got_g[k] - ref_g[k]).abs().max()) <= 1e-3 * float(ref_g[k].abs().max()) + 1e-6, k

@@ -258,3 +258,33 @@ def test_roi_target_kernel_against_reference_target_layer(dev, case):
         assert int((g_iou < 0.1).sum()) == int(S[k + 'smp_n_easy'][b])
         fg = src[g_iou >= 0.55]
         assert len(np.unique(fg)) == len(fg)                                   # foreground: without replacement
+
+
+def test_roi_decode_kernel_equals_tensor_formulation(dev):
+    """generate_predicted_boxes (roi_head_template.py:233-263) as one launch == decode_torch + rotate_points_along_z + shift,
+    values and the gradient w.r.t. the refinements (fp32 rounding: the tensor chain rotates through a batched matmul)."""
+    from detmatch_amd import fused
+    from detmatch_amd.pcdet import utils as U
+    from detmatch_amd.pcdet.roi_heads import _RoiDecode
+    g = torch.Generator(device='cpu').manual_seed(0)
+    n = 300
+    rois = torch.cat([torch.randn(n, 3, generator=g) * 20, torch.rand(n, 3, generator=g) * 4 + 0.5,
+                      (torch.rand(n, 1, generator=g) - 0.5) * 7], 1).to(dev)
+    reg0 = (torch.randn(n, 7, generator=g) * 0.3).to(dev)
+    go = torch.randn(n, 7, generator=g).to(dev)
+    coder = U.ResidualCoder()
+
+    def tensor_path(reg):
+        local = rois.clone()
+        local[:, 0:3] = 0
+        d = coder.decode_torch(reg.view(1, -1, 7), local.view(1, -1, 7)).view(-1, 7)
+        d = U.rotate_points_along_z(d.unsqueeze(1), rois[:, 6]).squeeze(1)
+        return torch.cat([d[:, 0:3] + rois[:, 0:3], d[:, 3:]], dim=-1)
+    ra = reg0.clone().requires_grad_(True)
+    want = tensor_path(ra)
+    want.backward(go)
+    rb = reg0.clone().requires_grad_(True)
+    got = _RoiDecode.apply(rb, rois)
+    got.backward(go)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((rb.grad - ra.grad).abs().max()) <= 2e-5 * float(ra.grad.abs().max())
