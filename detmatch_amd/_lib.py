@@ -163,6 +163,7 @@ SIGNATURES = {
     'dm_profile_count': (ci, []),
     'dm_profile_get': (ci, [ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
                             ctypes.POINTER(ctypes.c_ulonglong), c_f32_p]),
+    'dm_roi_grid_points': (ci, [vp, ci, ci, ci, vp, vp]),
     'dm_roi_decode_forward': (ci, [vp, vp, ci, vp, vp]),
     'dm_roi_decode_backward': (ci, [vp, vp, vp, ci, vp, vp]),
     'dm_chain_fn_count': (ci, []),

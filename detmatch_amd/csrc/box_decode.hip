@@ -88,7 +88,39 @@ __global__ __launch_bounds__(256) void roi_decode_bwd_kernel(const float *__rest
   o[6] = g[6];
 }
 
+// RoI grid points (pvrcnn_head.py:127-149): grid^3 points per RoI, ((i, j, k) + 0.5) / grid * size - size / 2 in the box
+// frame (k fastest), rotated by the heading, shifted to the centre.
+__global__ __launch_bounds__(256) void roi_grid_points_kernel(const float *__restrict__ rois, int n_rois, int roi_dim,
+                                                               int grid, float *__restrict__ out) {
+  const int g3 = grid * grid * grid;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_rois * g3) return;
+  const int r = (int)(i / g3), c = (int)(i % g3);
+  const float *b = rois + (size_t)r * roi_dim;
+  const int gi = c / (grid * grid), gj = (c / grid) % grid, gk = c % grid;
+  const float fg = (float)grid;
+  const float lx = ((float)gi + 0.5f) / fg * b[3] - b[3] / 2.0f;
+  const float ly = ((float)gj + 0.5f) / fg * b[4] - b[4] / 2.0f;
+  const float lz = ((float)gk + 0.5f) / fg * b[5] - b[5] / 2.0f;
+  const float cs = cosf(b[6]), sn = sinf(b[6]);
+  float *o = out + (size_t)i * 3;
+  o[0] = (lx * cs - ly * sn) + b[0];
+  o[1] = (lx * sn + ly * cs) + b[1];
+  o[2] = lz + b[2];
+}
+
 }  // namespace
+
+extern "C" int dm_roi_grid_points(const float *rois, int n_rois, int roi_dim, int grid, float *points,
+                                  dm_stream_t stream) {
+  if (n_rois < 0 || roi_dim < 7 || grid < 1 || grid > 32) return DM_ERR_INVALID_ARG;
+  if (n_rois == 0) return DM_OK;
+  if (!rois || !points) return DM_ERR_INVALID_ARG;
+  const long long total = (long long)n_rois * grid * grid * grid;
+  roi_grid_points_kernel<<<dm_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(rois, n_rois, roi_dim, grid, points);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
 
 extern "C" int dm_roi_decode_forward(const float *box_encodings, const float *rois, int n, float *boxes,
                                      dm_stream_t stream) {

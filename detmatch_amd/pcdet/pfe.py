@@ -271,4 +271,5 @@ class VoxelSetAbstraction(nn.Module):
         batch_dict['point_features'] = fc_rows(self.vsa_point_feature_fusion,
                                                point_features.view(-1, point_features.shape[-1]))
         batch_dict['point_coords'] = point_coords
+        batch_dict['point_batch_cnt'] = new_xyz_batch_cnt      # rows of point_coords per sample (the RoI head's ball queries)
         return batch_dict

@@ -400,10 +400,18 @@ class PVRCNNHead(nn.Module):
         point_coords = batch_dict['point_coords']
         point_features = batch_dict['point_features'] * batch_dict['point_cls_scores'].view(-1, 1)
         gs = self.model_cfg.ROI_GRID_POOL.GRID_SIZE
-        global_pts, _ = self.get_global_grid_points_of_roi(rois, grid_size=gs)
+        if fused_on() and rois.is_cuda and rois.dtype == torch.float32:
+            flat = rois.detach().reshape(-1, rois.shape[-1]).contiguous()
+            global_pts = torch.empty((flat.shape[0] * gs ** 3, 3), dtype=torch.float32, device=rois.device)
+            _lib.check(_lib.lib().dm_roi_grid_points(flat.data_ptr(), int(flat.shape[0]), int(flat.shape[1]), int(gs),
+                                                     global_pts.data_ptr(), _lib.raw_stream()), 'dm_roi_grid_points')
+        else:
+            global_pts, _ = self.get_global_grid_points_of_roi(rois, grid_size=gs)
         global_pts = global_pts.view(batch_size, -1, 3)
         xyz = point_coords[:, 1:4]
-        xyz_batch_cnt = batch_row_counts(point_coords[:, 0], batch_size)
+        xyz_batch_cnt = batch_dict.get('point_batch_cnt')      # set by the key-point encoder (rows per sample)
+        if xyz_batch_cnt is None or xyz_batch_cnt.numel() != batch_size:
+            xyz_batch_cnt = batch_row_counts(point_coords[:, 0], batch_size)
         new_xyz = global_pts.view(-1, 3)
         new_xyz_batch_cnt = torch.full((batch_size,), global_pts.shape[1], dtype=torch.int32,
                                        device=xyz.device)

@@ -949,6 +949,10 @@ int dm_profile_get(int i, int *kind, int *a, int *b, int *c, int *rows, int *kvo
  * RoI's heading, translation by the RoI's centre: boxes (n, 7).  The backward gives the gradient w.r.t. the refinements
  * (the RoIs are detached, roi_head_template.py:96-99) — the 2D <-> 3D consistency losses differentiate these boxes. */
 int dm_roi_decode_forward(const float *box_encodings, const float *rois, int n, float *boxes, dm_stream_t stream);
+/* PVRCNNHead.get_global_grid_points_of_roi (pcdet/models/roi_heads/pvrcnn_head.py:127-149): grid^3 points per RoI
+ * (rois (n, roi_dim >= 7) [x, y, z, dx, dy, dz, heading, ...]) -> points (n * grid^3, 3), point (i, j, k) of RoI r at row
+ * r * grid^3 + (i * grid + j) * grid + k. */
+int dm_roi_grid_points(const float *rois, int n_rois, int roi_dim, int grid, float *points, dm_stream_t stream);
 int dm_roi_decode_backward(const float *grad_boxes, const float *box_encodings, const float *rois, int n,
                            float *grad_encodings, dm_stream_t stream);
 

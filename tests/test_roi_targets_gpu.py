@@ -288,3 +288,18 @@ def test_roi_decode_kernel_equals_tensor_formulation(dev):
     got.backward(go)
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
     assert float((rb.grad - ra.grad).abs().max()) <= 2e-5 * float(ra.grad.abs().max())
+
+
+def test_roi_grid_points_kernel_equals_tensor_formulation(dev):
+    """dm_roi_grid_points == PVRCNNHead.get_global_grid_points_of_roi (pvrcnn_head.py:127-149) to fp32 rounding (the tensor
+    chain rotates through a batched matmul), same point order."""
+    from detmatch_amd import _lib
+    from detmatch_amd.pcdet.roi_heads import PVRCNNHead
+    g = torch.Generator(device='cpu').manual_seed(3)
+    n, gs = 77, 6
+    rois = torch.cat([torch.randn(n, 3, generator=g) * 30, torch.rand(n, 3, generator=g) * 5 + 0.3,
+                      (torch.rand(n, 1, generator=g) - 0.5) * 7], 1).to(dev)
+    want, _ = PVRCNNHead.get_global_grid_points_of_roi(PVRCNNHead, rois.view(1, n, 7), gs)
+    got = torch.empty((n * gs ** 3, 3), device=dev)
+    _lib.check(_lib.lib().dm_roi_grid_points(rois.data_ptr(), n, 7, gs, got.data_ptr(), _lib.stream()), 'grid')
+    assert float((got.view(n, -1, 3) - want).abs().max()) <= 1e-5 * float(want.abs().max())
