@@ -749,25 +749,6 @@ class SSL(nn.Module):
             lab_dict = self._run_and_backprop(run, m, lab_dict, early, curr_ssl_weight)
         if lanes is not None:
             lanes.join(lab_dict['sup_losses'], lab_dict['ssl_losses'])
-        issued_early = set()
-
-        def issue_early(pred):
-            # Scheduling only: every pass of the unlabeled chain that can start before its inputs from the chain
-            # exist (teacher inference up to its read-back; the label-independent trunk of the student's pass) is
-            # issued ahead, in chain order, so that the read-backs further down find the device done.
-            if not (getattr(self, 'issue_early', True) and _ISSUE_EARLY):
-                return
-            for m in unlab_modules:
-                if hasattr(m, 'issue_early') and id(m) not in issued_early and pred(m):
-                    issued_early.add(id(m))
-                    if lanes is not None:
-                        lanes.run(m, self, unlab_dict, method='issue_early')
-                    else:
-                        rng.enter(m)
-                        m.issue_early(self, unlab_dict)
-        # the teacher's passes BEFORE the supervised backward is issued (7 ms of host time the teacher lane can use),
-        # the student's trunk after it (it queues behind that backward on the main lane anyway)
-        issue_early(lambda m: str(getattr(m, 'ssl_obj_attr', '')).startswith('teacher'))
         if getattr(self, 'early_backward', False) and torch.is_grad_enabled():
             # Scheduling only: d(sum of losses) = sum of d(losses), so the supervised part can be
             # back-propagated now.  Its (GPU-bound) backward then runs underneath the host-bound
@@ -783,7 +764,17 @@ class SSL(nn.Module):
                 if hook is not None:      # e.g. FlatGradDDP.collect
                     hook()
             lab_dict['sup_losses'] = {k: v.detach() for k, v in sup.items()}
-        issue_early(lambda m: True)
+        if getattr(self, 'issue_early', True) and _ISSUE_EARLY:
+            # Scheduling only: every pass of the unlabeled chain that can start before its inputs from the chain
+            # exist (teacher inference up to its read-back; the label-independent trunk of the student's pass) is
+            # issued now, in chain order, so that the read-backs further down find the device done.
+            for m in unlab_modules:
+                if hasattr(m, 'issue_early'):
+                    if lanes is not None:
+                        lanes.run(m, self, unlab_dict, method='issue_early')
+                    else:
+                        rng.enter(m)
+                        m.issue_early(self, unlab_dict)
         early_2d = lanes is not None and lanes.mode == 'branches' and _EARLY_2D_BWD and torch.is_grad_enabled() and \
             getattr(self, '_deferred', None) and getattr(self, 'early_backward', False)
         last_2d = None
