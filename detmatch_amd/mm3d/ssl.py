@@ -783,27 +783,9 @@ class SSL(nn.Module):
             cands = [m for m in unlab_modules if isinstance(m, HardPseudoLabel_2D)]
             users = [m for m in unlab_modules if str(getattr(m, 'ssl_obj_attr', '')).endswith('student.detector_2d')]
             last_2d = cands[-1] if cands and users and users[-1] is cands[-1] else None
-        # Scheduling only ('branches'): a student 3D module directly followed by the last 2D module (which reads the
-        # teacher's pseudo-labels, not that module's boxes) leaves its read-back until the 2D module and its backward
-        # have been issued — the host issues them instead of waiting for the 3D heads on the device
-        deferred_3d = None
-        if last_2d is not None and _ISSUE_EARLY:
-            i2 = unlab_modules.index(last_2d)
-            prev = unlab_modules[i2 - 1] if i2 > 0 else None
-            if prev is not None and hasattr(prev, 'finish_readback') and \
-                    str(getattr(prev, 'out_bboxes_key', '')) not in str(getattr(last_2d, 'target_bboxes_key', '')):
-                deferred_3d = prev
         for m in unlab_modules:
-            if m is deferred_3d:
-                m.defer_readback = True
-                try:
-                    unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
-                finally:
-                    m.defer_readback = False
-            elif m is last_2d:
+            if m is last_2d:
                 unlab_dict = self._early_2d_backward(lanes, m, unlab_dict, curr_ssl_weight)
-                if deferred_3d is not None and '_pending' in deferred_3d.__dict__:
-                    unlab_dict = lanes.run(deferred_3d, self, unlab_dict, method='finish_readback')
             else:
                 unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
         if lanes is not None:

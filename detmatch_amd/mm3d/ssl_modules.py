@@ -206,21 +206,8 @@ class Opd_HardPseudoLabel_3D(object):
         batch_dict = _accumulate(ssl_obj, batch_dict, add_prefix(dict(loss=loss.mean()), self.name),
                                  prefer_sup=False)
         if self.out_bboxes_key is not None:
-            state = detector.model.post_processing_issue(batch, no_nms=self.no_nms)
-            if getattr(self, 'defer_readback', False) and not self.no_nms:
-                # Scheduling only (SSL.forward_train sets `defer_readback` for one call): the read-back of the survivor
-                # counts is left to finish_readback(), so that the caller can issue modules that do not read this
-                # module's boxes while the device works through the pass
-                self._pending = (detector, cur, state)
-                return batch_dict
-            pred_dicts, _ = detector.model.post_processing_finish(state)
+            pred_dicts, _ = detector.model.post_processing(batch, no_nms=self.no_nms)
             cur[self.out_bboxes_key] = _pred_dicts_to_tuples(pred_dicts)
-        return batch_dict
-
-    def finish_readback(self, ssl_obj, batch_dict):
-        detector, cur, state = self.__dict__.pop('_pending')
-        pred_dicts, _ = detector.model.post_processing_finish(state)
-        cur[self.out_bboxes_key] = _pred_dicts_to_tuples(pred_dicts)
         return batch_dict
 
 
