@@ -7,6 +7,7 @@ O=$R/gpurun_out/r05
 mkdir -p $O
 PARTS="${@:-trace pmc bench tools ab}"
 cd /tmp && export TMPDIR=/tmp
+export DM_BENCH_WATCHDOG=0     # profiled runs measure in-process (no child process from a process that holds the GPU)
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has trace; then
   # 1. kernel trace + stats of the default bench command
