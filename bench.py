@@ -406,16 +406,17 @@ def watched_single_gpu_run(args):
     if args.no_cpu_baseline:
         cmd.append('--no-cpu-baseline')
     limit = float(os.environ.get('DM_BENCH_WATCHDOG_S', '0')) or (240.0 + 1.0 * (args.steps + args.warmup))
+    first = float(os.environ.get('DM_BENCH_WATCHDOG_FIRST_S', '0')) or limit      # (tests shorten the first attempt)
     for attempt in (0, 1):
         env = dict(os.environ, DM_BENCH_CHILD='1')
         if attempt:
             env.update(DM_TWO_LANES='0', DM_BENCH_NOTE='first attempt (three stream lanes) did not finish within %d s and was '
                        'killed; this line is the one-lane order of round 4' % int(limit))
         try:
-            return subprocess.run(cmd, env=env, timeout=limit).returncode
+            return subprocess.run(cmd, env=env, timeout=limit if attempt else first).returncode
         except subprocess.TimeoutExpired:
-            print('bench.py: the measurement did not finish within %d s (attempt %d): killed' % (int(limit), attempt + 1),
-                  file=sys.stderr)
+            print('bench.py: the measurement did not finish within %d s (attempt %d): killed'
+                  % (int(limit if attempt else first), attempt + 1), file=sys.stderr)
     return 3
 
 
@@ -436,6 +437,8 @@ def main():
         # (never under a profiler: its preloaded library has initialised the GPU in THIS process, and a process that
         # holds the GPU must not start another program)
         sys.exit(watched_single_gpu_run(args))
+    if os.environ.get('DM_BENCH_FAKE_HANG') == '1' and os.environ.get('DM_TWO_LANES') != '0':
+        time.sleep(10 ** 6)      # test hook of the watchdog (tests/test_bench_launch.py): the first attempt never finishes
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

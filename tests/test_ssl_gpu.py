@@ -225,6 +225,7 @@ def test_early_2d_backward_does_not_change_gradients(dev, monkeypatch):
     for early in (True, False):
         monkeypatch.setattr(ssl, '_EARLY_2D_BWD', early)
         monkeypatch.setattr(ssl, '_ISSUE_EARLY', early)
+        monkeypatch.setenv('DM_TWO_LANES', '1')      # the bench default (tests/conftest.py runs everything else in one lane)
         wl = DetMatchTrainWorkload(2, dev)
         assert wl.model.two_lanes and wl.model.share_2d_trunk
         torch.manual_seed(321)       # one iteration: no feedback through updated weights
