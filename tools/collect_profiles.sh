@@ -47,8 +47,8 @@ fi
 if has ab; then
   # 3. round-5 A/Bs (same box, alternated)
   rm -f $O/ab_step_variants.txt
-  for i in 1 2; do
-    for v in "default:A=1" "no_early_2d_backward:DM_EARLY_2D_BWD=0" "op_by_op:DM_CHAIN=0" "one_lane_glue:DM_TWO_LANES=0" "op_by_op_one_lane(r4):DM_CHAIN=0 DM_TWO_LANES=0" "no_early_issue:DM_ISSUE_EARLY=0" "no_bev_chain:DM_CHAIN_OFF=bev" "no_trunk2d_chain:DM_CHAIN_OFF=trunk2d" "no_sa_chain:DM_CHAIN_OFF=sa" "no_sparse_chain:DM_CHAIN_OFF=sparse"; do
+  for i in ${AB_ROUNDS:-1 2}; do
+    for v in "default:A=1" "no_early_2d_backward:DM_EARLY_2D_BWD=0" "op_by_op:DM_CHAIN=0" "one_lane_glue:DM_TWO_LANES=0" "op_by_op_one_lane(r4):DM_CHAIN=0 DM_TWO_LANES=0" "no_early_issue:DM_ISSUE_EARLY=0" "no_trunk2d_chain:DM_CHAIN_OFF=trunk2d"; do
       n=${v%%:*}; e=${v#*:}
       env $e timeout 100 python3 bench.py --no-cpu-baseline --steps 30 --warmup 6 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-26s run $i  %.1f ms/step  roofline kernel %.1f us  order %s' % ('$n', d['ms_per_step'], r.get('avg_us') or 0, d['config'].get('stream_order')))" >> $O/ab_step_variants.txt || echo "$n run $i FAILED" >> $O/ab_step_variants.txt
     done
