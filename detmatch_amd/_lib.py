@@ -171,6 +171,8 @@ SIGNATURES = {
     'dm_chain_fn_name': (ctypes.c_char_p, [ci]),
     'dm_chain_fn_signature': (ctypes.c_char_p, [ci]),
     'dm_chain_run': (ci, [vp, ci, vp, ci, c_int_p]),
+    'dm_height_compress_forward': (ci, [vp, vp, ctypes.c_longlong, ci, ci, ci, ci, ci, vp, vp]),
+    'dm_height_compress_backward': (ci, [vp, vp, ctypes.c_longlong, ci, ci, ci, ci, vp, vp]),
     'dm_relu_mask_f32': (ci, [vp, vp, vp, ctypes.c_longlong, vp]),
     'dm_add_mask_f32': (ci, [vp, vp, vp, vp, ctypes.c_longlong, vp]),
     'dm_colsum_workspace_bytes': (sz, [ctypes.c_longlong, ci]),

@@ -254,7 +254,55 @@ __global__ void multi_add_kernel(const AxpyRow *__restrict__ rows, int n_rows, i
     row.dst[i] = assign ? row.src[i] : row.dst[i] + row.src[i];
 }
 
+// HeightCompression (height_compression.py:10-25) in NHWC: active voxel row i with coordinates [b, z, y, x] lands at
+// out[b][y][x][c * D + z] (the reference's .dense() -> view(B, C * D, H, W), channels_last memory).  The map is zeroed by
+// the caller; the gradient is the matching gather.
+__global__ void height_compress_kernel(const float *__restrict__ feat, const int4 *__restrict__ idx, long long n, int C,
+                                       int D, int H, int W, float *__restrict__ out) {
+  const long long total = n * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C;
+    const int c = (int)(i % C);
+    const int4 q = idx[r];      // b, z, y, x
+    out[((((long long)q.x * H + q.z) * W + q.w) * C + c) * D + q.y] = feat[i];
+  }
+}
+
+__global__ void height_compress_bwd_kernel(const float *__restrict__ gout, const int4 *__restrict__ idx, long long n, int C,
+                                           int D, int H, int W, float *__restrict__ gfeat) {
+  const long long total = n * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C;
+    const int c = (int)(i % C);
+    const int4 q = idx[r];
+    gfeat[i] = gout[((((long long)q.x * H + q.z) * W + q.w) * C + c) * D + q.y];
+  }
+}
+
 }  // namespace
+
+extern "C" int dm_height_compress_forward(const float *features, const int *indices, long long n, int C, int batch, int D,
+                                          int H, int W, float *out, dm_stream_t stream) {
+  if (n < 0 || C <= 0 || batch <= 0 || D <= 0 || H <= 0 || W <= 0 || !out) return DM_ERR_INVALID_ARG;
+  DM_HIP(hipMemsetAsync(out, 0, (size_t)batch * H * W * C * D * sizeof(float), (hipStream_t)stream));
+  if (n == 0) return DM_OK;
+  if (!features || !indices) return DM_ERR_INVALID_ARG;
+  height_compress_kernel<<<grid_for(n * C), kThreads, 0, (hipStream_t)stream>>>(features, (const int4 *)indices, n, C, D, H, W,
+                                                                                out);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_height_compress_backward(const float *grad_out, const int *indices, long long n, int C, int D, int H, int W,
+                                           float *grad_features, dm_stream_t stream) {
+  if (n < 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
+  if (n == 0) return DM_OK;
+  if (!grad_out || !indices || !grad_features) return DM_ERR_INVALID_ARG;
+  height_compress_bwd_kernel<<<grid_for(n * C), kThreads, 0, (hipStream_t)stream>>>(grad_out, (const int4 *)indices, n, C, D,
+                                                                                    H, W, grad_features);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
 
 extern "C" int dm_relu_mask_f32(const float *grad, const float *y, float *out, long long n, dm_stream_t stream) {
   if (n == 0) return DM_OK;

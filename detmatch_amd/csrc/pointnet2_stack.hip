@@ -780,107 +780,11 @@ struct FpsSamples {
 // (n <= 24576) stay in registers without spilling.
 constexpr int FPS_T = 512;
 
-template <int PPT>
-__global__ __launch_bounds__(FPS_T) void fps_kernel(FpsSamples smp, int m,
-                                                    const float *__restrict__ xyz,
-                                                    float *__restrict__ temp,
-                                                    int *__restrict__ idxs) {
-  __shared__ float s_d[8];
-  __shared__ int s_k[8];
-  __shared__ float s_pt[3];
-  const int b = blockIdx.x;
-  const int n = smp.off[b + 1] - smp.off[b];
-  const float *data = xyz + (size_t)smp.off[b] * 3;
-  float *tmp = temp + (size_t)smp.off[b];
-  int *out = idxs + (size_t)b * m;
-  if (n <= 0) return;
-  // the reference's block size for this n (sampling_gpu.cu:9-13) fixes the tie rule
-  int bs = 1;
-  while (bs * 2 <= n && bs < 1024) bs *= 2;
-  const int bs_mask = bs - 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float px[PPT], py[PPT], pz[PPT], pt[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    int k = tid + i * FPS_T;
-    bool ok = k < n;
-    px[i] = ok ? data[(size_t)k * 3 + 0] : 0.f;
-    py[i] = ok ? data[(size_t)k * 3 + 1] : 0.f;
-    pz[i] = ok ? data[(size_t)k * 3 + 2] : 0.f;
-    pt[i] = ok ? tmp[k] : -1.f;  // padding: min(d, -1) = -1 can never win (real d2 >= 0)
-  }
-  if (tid == 0) {
-    out[0] = 0;
-    s_pt[0] = data[0];
-    s_pt[1] = data[1];
-    s_pt[2] = data[2];
-  }
-  __syncthreads();
-  for (int j = 1; j < m; ++j) {
-    const float x1 = s_pt[0], y1 = s_pt[1], z1 = s_pt[2];
-    float best = -1.f;
-    int bslot = 0;  // slot i of the running best; its point index is tid + bslot * FPS_T
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      float d = dist2_fma(px[i] - x1, py[i] - y1, pz[i] - z1);
-      float d2 = fminf(d, pt[i]);
-      pt[i] = d2;
-      // strict '>' is the common path; exact ties (duplicated points) take the full rule
-      bool take = d2 > best;
-      if (d2 == best && d2 >= 0.f)
-        take = fps_better(d2, tid + i * FPS_T, best, tid + bslot * FPS_T, bs_mask);
-      best = take ? d2 : best;
-      bslot = take ? i : bslot;
-    }
-    int besti = tid + bslot * FPS_T;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      float od = __shfl_xor(best, off);
-      int ok = __shfl_xor(besti, off);
-      if (od >= 0.f && (best < 0.f || fps_better(od, ok, best, besti, bs_mask))) {
-        best = od;
-        besti = ok;
-      }
-    }
-    __syncthreads();  // previous round's s_pt / s_d readers are done
-    if (lane == 0) {
-      s_d[wave] = best;
-      s_k[wave] = besti;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      float d = lane < FPS_T / 64 ? s_d[lane] : -1.f;
-      int k = lane < FPS_T / 64 ? s_k[lane] : 0;
-#pragma unroll
-      for (int off = 4; off >= 1; off >>= 1) {
-        float od = __shfl_xor(d, off);
-        int ok = __shfl_xor(k, off);
-        if (od >= 0.f && (d < 0.f || fps_better(od, ok, d, k, bs_mask))) {
-          d = od;
-          k = ok;
-        }
-      }
-      if (lane == 0) {
-        out[j] = k;
-        s_pt[0] = data[(size_t)k * 3 + 0];
-        s_pt[1] = data[(size_t)k * 3 + 1];
-        s_pt[2] = data[(size_t)k * 3 + 2];
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    int k = tid + i * FPS_T;
-    if (k < n) tmp[k] = pt[i];
-  }
-}
-
 // ---- round 4: the same sampling with the per-round critical path cut to the arithmetic --------------------------
-// fps_kernel carries (distance, index) pairs through the scan (a compare + two selects per point), through twelve
-// ds_bpermute steps per wave and a second shuffle tree on wave 0, and fetches the winner's coordinates from global
-// memory behind three barriers: 3.3 us per round at KITTI size (20 k points), of which the arithmetic is a third.
-// Here a round reduces the VALUE only:
+// The kernel of rounds 1-3 (removed in round 5) carried (distance, index) pairs through the scan (a compare + two
+// selects per point), through twelve ds_bpermute steps per wave and a second shuffle tree on wave 0, and fetched the
+// winner's coordinates from global memory behind three barriers: 3.3 us per round at KITTI size (20 k points), of
+// which the arithmetic is a third.  Here a round reduces the VALUE only:
 //   * the scan updates two points per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: the same IEEE operations per
 //     element as dist2_fma) and keeps a running maximum with one v_max3 per pair: 4.5 instead of ~10 instructions
 //     per point;
@@ -890,8 +794,8 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsSamples smp, int m,
 //     their points it was and compete with the reference's tie rule as a 64-bit key through one LDS atomic min
 //     (normally one thread takes part) — second barrier; everybody reads the key and fetches the winner's
 //     coordinates with a wave-uniform (scalar) load.
-// Same total order as fps_kernel / the reference (larger distance; bit-reversed stride class; smaller index), so
-// the indices are bit-identical (tests/test_ops_gpu.py).
+// Same total order as the reference (larger distance; bit-reversed stride class; smaller index), so the indices are
+// the oracle's bit for bit (tests/test_ops_gpu.py).
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
 
 template <int CTRL, int ROW_MASK>
@@ -1081,7 +985,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_global(FpsSamples smp, int m,
 // A Waymo-sized frame (~200 k points -> 4096 key points) does not fit one workgroup's registers; the
 // single-workgroup fallback above streams all points from memory in every round (167 ms per call on
 // MI355X).  Here G workgroups own an interleaved share of the sample each (points and running minima
-// in registers, as in fps_kernel); per round every workgroup publishes its best candidate
+// in registers, as in fps_kernel2); per round every workgroup publishes its best candidate
 // (distance, index, coordinates) in a slot of the scratch buffer, tagged with the round number, and
 // reads everybody's slots back: a grid-wide exchange through L2 without atomics (release store of
 // the tag, acquire polls; slots double-buffered by round parity).  The winner is chosen with the
@@ -1430,10 +1334,11 @@ extern "C" int dm_voxel_centers(const int32_t *coords, int n, int batch, float v
   return DM_OK;
 }
 
-// tuning / test aid: 0 auto, 1 one workgroup per sample even for large clouds, 2 the pair-carrying one-workgroup kernel of rounds 1-3
+// tuning / test aid: 0 auto, 1 one workgroup per sample even for large clouds
 static int g_fps_variant = 0;
 
 extern "C" int dm_fps_set_variant(int v) {
+  if (v != 0 && v != 1) return DM_ERR_INVALID_ARG;
   g_fps_variant = v;
   return DM_OK;
 }
@@ -1441,7 +1346,7 @@ extern "C" int dm_fps_set_variant(int v) {
 static int fps_launch(const FpsSamples &smp, int batch, int max_n, int m, const float *xyz,
                       float *temp, int *idxs, hipStream_t st) {
   int ppt = dm_ceil_div(max_n, FPS_T);
-  if (g_fps_variant != 2 && ppt <= 48) {       // (variant 2: the round-1..3 kernel, for A/B and the equality test)
+  if (ppt <= 48) {
 #define DM_FPS2(P) fps_kernel2<P><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs)
     if (ppt <= 4) DM_FPS2(4);
     else if (ppt <= 8) DM_FPS2(8);
@@ -1454,14 +1359,7 @@ static int fps_launch(const FpsSamples &smp, int batch, int max_n, int m, const 
     DM_CHECK_LAUNCH();
     return DM_OK;
   }
-  if (ppt <= 4) fps_kernel<4><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
-  else if (ppt <= 8) fps_kernel<8><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
-  else if (ppt <= 16) fps_kernel<16><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
-  else if (ppt <= 24) fps_kernel<24><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
-  else if (ppt <= 32) fps_kernel<32><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
-  else if (ppt <= 40) fps_kernel<40><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
-  else if (ppt <= 48) fps_kernel<48><<<batch, FPS_T, 0, st>>>(smp, m, xyz, temp, idxs);
-  else {
+  {
     // large clouds: G workgroups per sample (see fps_kernel_multi).  The exchange slots live at the
     // start of each sample's `temp` range (n floats >= 2*G*8); all G * batch workgroups spin on each
     // other, so they are kept to a quarter of the chip's 512 slots of 1024 threads.

@@ -286,9 +286,8 @@ __global__ __launch_bounds__(256) void spconv_gg(const float *__restrict__ feat,
 }
 
 unsigned long long *g_debug_stamps = nullptr;
-int g_gg_variant = -1;  // -1 auto, 0 LDS-staged weights (spconv_gg), 1 register weights, 16-row tiles (spconv_gr),
-                        // 2 register weights, 32-row tiles (spconv_gr32: measured 5-15 % slower than gr, kept as an
-                        // experiment); auto = gr for cin >= 32, else gg
+int g_gg_variant = -1;  // -1 auto, 0 LDS-staged weights (spconv_gg), 1 register weights, 16-row tiles (spconv_gr);
+                        // auto = gr for cin >= 32, else gg
 
 // ---- main kernel, register-resident weights ----------------------------------
 // (Measured and dropped, round 2: EIGHT waves per tile for the layers with fewer than ~1 k tiles — each
@@ -451,172 +450,9 @@ __global__ __launch_bounds__(256) void spconv_gr(const float *__restrict__ feat,
   }
 }
 
-// ---- 32-row tiles on v_mfma_f32_32x32x2_f32 ---------------------------------------------------------
-// spconv_gr re-reads the (cin x cout) weights of an offset from L2 for every 16-row tile that uses it:
-// 16 KB of B against 4 KB of gathered A per (tile, offset) step at 64 -> 64, ~270 MB per launch, which
-// is what its waves wait for (the matrix pipe is busy ~41 % of the launch).  With rows packed by
-// neighbour mask a tile of 32 rows is nearly as full as one of 16, and the 32x32x2 MFMA uses every B
-// value for 32 rows: half the weight traffic per flop.  MEASURED (tools/bench_spconv_layers.py --variant 2):
-// 30.7 us against 29.0 us of spconv_gr on the 64 -> 64 layer, 22.5 against 19.5 us on the small ones —
-// the weight traffic is NOT what limits spconv_gr; fewer, fatter workgroups and the 8-way LDS meeting
-// cost more than the saved L2 reads.  Not selected by default (dm_spconv_set_variant(2)).
-// Workgroup = 8 waves = ONE tile of 32 output
-// rows; the tile's active offsets are dealt round-robin to the waves; a wave streams its offsets in
-// steps of 16 input channels (A: its row's 16 channels as 2 float4 per lane-half, B: 16 x COUT as
-// 2*NB float4 per lane, both one step ahead in registers), the eight partial tiles meet once in LDS
-// and are summed in wave order (bitwise reproducible).
-// Packed weights for this kernel: wp[k][kb][nb][h][n][j] = B_k[8 kb + 4 h + j][32 nb + n]
-// (lane = 32 h + n; the k order inside an 8-block is the same permutation for A and B).
-__global__ __launch_bounds__(256) void pack_weights32(const float *w, float *wp, int kvol, int ci, int co,
-                                                      int transpose_w, int flip_k) {
-  const int per_k = ci * co;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= kvol * per_k) return;
-  const int k = e / per_k, r = e % per_k;
-  const int j = r & 3, n = (r >> 2) & 31, h = (r >> 7) & 1;
-  const int nbs = co / 32;
-  const int nb = (r >> 8) % nbs, kb = (r >> 8) / nbs;
-  const int c = 8 * kb + 4 * h + j, col = 32 * nb + n;
-  const int kk = flip_k ? kvol - 1 - k : k;
-  wp[e] = transpose_w ? w[((size_t)kk * co + col) * ci + c] : w[((size_t)kk * ci + c) * co + col];
-}
-
-typedef float f32x16v __attribute__((ext_vector_type(16)));
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(512) void spconv_gr32(const float *__restrict__ feat, const float *__restrict__ wpack,
-                                                   const int32_t *__restrict__ nbr,
-                                                   const int32_t *__restrict__ perm, int n_out, int kvol,
-                                                   int cout_full, float *__restrict__ out,
-                                                   const int32_t *__restrict__ tile_order) {
-  constexpr int NB = COUT / 32;            // 32-column blocks per wave
-  constexpr int KB = CIN / 8;              // 8-deep k blocks per offset
-  constexpr int S = KB / 2;                // steps of 16 input channels
-  constexpr int LDP = COUT + 4;
-  __shared__ int32_t tbl[32][32];
-  __shared__ __attribute__((aligned(16))) float part[8][32][LDP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int row0 = (tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x) * 32;
-  const int nb_full = cout_full / 32;
-  const int nb0 = blockIdx.y * NB;
-  for (int e = tid; e < 32 * 32; e += 512) {
-    const int k = e >> 5, rr = e & 31;
-    const bool in = (k < kvol) && (row0 + rr < n_out);
-    tbl[k][rr] = in ? nbr[(size_t)k * n_out + row0 + rr] : -1;
-  }
-  __syncthreads();
-  // active offsets of the tile (every wave computes the same mask)
-  unsigned int active;
-  {
-    bool any = false;
-    if (lane < 32) {
-#pragma unroll 8
-      for (int rr = 0; rr < 32; ++rr) any |= tbl[lane][rr] >= 0;
-    }
-    active = (unsigned int)__ballot(any);
-  }
-  unsigned int mine = 0u;
-  {
-    int rank = 0;
-    for (unsigned int a = active; a; a &= a - 1u) {
-      if ((rank & 7) == wave) mine |= a & (0u - a);
-      ++rank;
-    }
-  }
-  f32x16v acc[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-
-  auto load_step = [&](int k, int s, f32x4 *w, f32x4 *a, unsigned int *ok) {
-    const int idx = tbl[k][r];
-    *ok = idx >= 0 ? 0xFFFFFFFFu : 0u;
-    const float *src = feat + (size_t)(idx >= 0 ? idx : 0) * CIN + 16 * s + 4 * h;
-    a[0] = *(const f32x4 *)(src);
-    a[1] = *(const f32x4 *)(src + 8);
-    const f32x4 *wk = (const f32x4 *)wpack + (size_t)k * (CIN * (size_t)cout_full / 4);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) w[t * NB + nb] = wk[((2 * s + t) * nb_full + nb0 + nb) * 64 + lane];
-  };
-  auto compute = [&](const f32x4 *w, const f32x4 *a, unsigned int ok) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float av = mask_bits(a[t][j], ok);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w[t * NB + nb][j], acc[nb], 0, 0, 0);
-      }
-  };
-  if (mine != 0u) {
-    const int n_steps = __popc(mine) * S;
-    unsigned int rest = mine;
-    int k = __ffs(rest) - 1, s = 0;
-    auto advance = [&]() {
-      if (s + 1 < S) {
-        ++s;
-      } else if (rest & (rest - 1u)) {
-        rest &= rest - 1u;
-        k = __ffs(rest) - 1;
-        s = 0;
-      }
-    };
-    f32x4 w0[2 * NB], w1[2 * NB], a0[2], a1[2];
-    unsigned int ok0, ok1;
-    load_step(k, s, w0, a0, &ok0);
-    int i = 0;
-    // pairs of steps as ONE straight-line loop body, the odd step behind the loop: with an exit between the two
-    // halves the accumulators of the two paths get different registers and are copied (through VGPRs) every turn.
-    // The last pair's second load re-reads the last step (advance() sticks there).
-    for (; i + 2 <= n_steps; i += 2) {
-      advance();
-      load_step(k, s, w1, a1, &ok1);
-      compute(w0, a0, ok0);
-      advance();
-      load_step(k, s, w0, a0, &ok0);
-      compute(w1, a1, ok1);
-    }
-    if (i < n_steps) compute(w0, a0, ok0);
-  }
-  // C layout of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) part[wave][(q & 3) + 8 * (q >> 2) + 4 * h][32 * nb + r] = acc[nb][q];
-  __syncthreads();
-  constexpr int F4_PER_ROW = COUT / 4;
-  for (int e = tid; e < 32 * F4_PER_ROW; e += 512) {
-    const int rr = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
-    const int prow = row0 + rr;
-    if (prow < n_out) {
-      f32x4 sum = *(const f32x4 *)&part[0][rr][4 * c4];
-#pragma unroll
-      for (int w = 1; w < 8; ++w) sum += *(const f32x4 *)&part[w][rr][4 * c4];
-      const int row = perm ? perm[prow] : prow;
-      *(f32x4 *)(out + (size_t)row * cout_full + blockIdx.y * COUT + 4 * c4) = sum;
-    }
-  }
-}
-
-template <int CIN, int COUT_FULL>
-int launch_gr32(const float *feat, const float *wpack, const int32_t *nbr, const int32_t *perm,
-                const int32_t *tile_order, int n_out, int kvol, float *out, hipStream_t st) {
-  constexpr int COUT = COUT_FULL > 64 ? 64 : COUT_FULL;
-  dim3 grid(dm_ceil_div(n_out, 32), COUT_FULL / COUT);
-  hipEvent_t e0, e1;
-  if (dm_prof_open(DM_PROF_SPCONV_GG, CIN, COUT_FULL, 0, n_out, kvol, nbr, &e0, &e1) >= 0)
-    hipExtLaunchKernelGGL((spconv_gr32<CIN, COUT>), grid, dim3(512), 0, st, e0, e1, 0, feat, wpack, nbr, perm, n_out,
-                          kvol, (int)COUT_FULL, out, tile_order);
-  else
-    spconv_gr32<CIN, COUT><<<grid, 512, 0, st>>>(feat, wpack, nbr, perm, n_out, kvol, COUT_FULL, out, tile_order);
-  DM_CHECK_LAUNCH();
-  return DM_OK;
-}
+// (Measured and dropped, round 3 / pruned round 5: 32-row tiles on v_mfma_f32_32x32x2_f32, eight waves per tile
+// sharing the offsets — half the weight traffic per flop, 30.7 against 29.0 us on the 64 -> 64 layer and 22.5 against
+// 19.5 us on the small ones: the weight traffic is not what limits spconv_gr.)
 
 template <int CIN, int COUT_FULL>
 int launch_gr(const float *feat, const float *wpack, const int32_t *nbr, const int32_t *perm,
@@ -1044,11 +880,6 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const int32_t *__restri
   }
 }
 
-// rows per tile of the register-weights gather-GEMM the launcher will pick (g_gg_variant)
-static int gr_tile_rows() { return g_gg_variant == 2 ? 32 : 16; }
-// (spconv16.hip launches 16-row tiles only: an order built for 32-row tiles must not reach it)
-int dm_spconv_tile_order_rows(void) { return gr_tile_rows(); }
-
 extern "C" size_t dm_spconv_tile_order_workspace_bytes(void) { return dm_align(66 * sizeof(int)); }
 
 extern "C" int dm_spconv_tile_order(const int32_t *nbr, int n_rows, int kvol, int32_t *order,
@@ -1060,17 +891,10 @@ extern "C" int dm_spconv_tile_order(const int32_t *nbr, int n_rows, int kvol, in
   if (workspace_bytes < dm_spconv_tile_order_workspace_bytes()) return DM_ERR_WORKSPACE;
   int *hist = (int *)workspace;
   DM_HIP(hipMemsetAsync(hist, 0, 66 * sizeof(int), st));
-  if (gr_tile_rows() == 32) {
-    const int n_tiles = dm_ceil_div(n_rows, 32);
-    tile_order_kernel<false, 32><<<dm_ceil_div(n_tiles, 4), 256, 0, st>>>(nbr, n_rows, kvol, n_tiles, hist, order);
-    DM_CHECK_LAUNCH();
-    tile_order_kernel<true, 32><<<dm_ceil_div(n_tiles, 4), 256, 0, st>>>(nbr, n_rows, kvol, n_tiles, hist, order);
-  } else {
-    const int n_tiles = dm_ceil_div(n_rows, 16);
-    tile_order_kernel<false, 16><<<dm_ceil_div(n_tiles, 4), 256, 0, st>>>(nbr, n_rows, kvol, n_tiles, hist, order);
-    DM_CHECK_LAUNCH();
-    tile_order_kernel<true, 16><<<dm_ceil_div(n_tiles, 4), 256, 0, st>>>(nbr, n_rows, kvol, n_tiles, hist, order);
-  }
+  const int n_tiles = dm_ceil_div(n_rows, 16);
+  tile_order_kernel<false, 16><<<dm_ceil_div(n_tiles, 4), 256, 0, st>>>(nbr, n_rows, kvol, n_tiles, hist, order);
+  DM_CHECK_LAUNCH();
+  tile_order_kernel<true, 16><<<dm_ceil_div(n_tiles, 4), 256, 0, st>>>(nbr, n_rows, kvol, n_tiles, hist, order);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -1153,6 +977,7 @@ extern "C" int dm_spconv_set_wgrad_chunk(int pairs) {
 }
 
 extern "C" int dm_spconv_set_variant(int v) {
+  if (v < -1 || v > 1) return DM_ERR_INVALID_ARG;
   g_gg_variant = v;
   return DM_OK;
 }
@@ -1164,9 +989,6 @@ extern "C" size_t dm_spconv_workspace_bytes(int kvol, int cin, int cout) {
 
 #define DM_GG_CASE(CI, CO)                                                              \
   if (ci == CI && co == CO) {                                                           \
-    if constexpr (CI >= 32 && (CO % 32) == 0) {                                         \
-      if (use_gr32) return launch_gr32<CI, CO>(feat, wp, nbr, row_perm, tile_order, n_rows_out, kvol, out, st); \
-    }                                                                                   \
     bool use_gr = g_gg_variant < 0 ? (CI >= 32) : (g_gg_variant >= 1);                  \
     if constexpr (CI >= 16) {                                                           \
       if (use_gr) return launch_gr<CI, CO>(feat, wp, nbr, row_perm, tile_order, n_rows_out, kvol, out, st); \
@@ -1193,14 +1015,7 @@ extern "C" int dm_spconv_gather_gemm(const float *feat, int n_rows_in, const flo
   int total = kvol * ci * co;
   // pack_weights indexes W as (kvol, ci, co) when !transpose_w and as
   // (kvol, co_w = co.., ) transposed otherwise: W is (kvol, cin, cout) = (kvol, co, ci)
-  // the 32-row kernel needs the tile order of 32-row tiles: only with an order built under the same
-  // variant (dm_spconv_tile_order / dm_spconv_pack_rows) or without one
-  const bool use_gr32 = gr_tile_rows() == 32 && ci >= 32 && (co % 32) == 0;
-  if (gr_tile_rows() == 32 && !use_gr32) tile_order = nullptr;   // the order was built for 32-row tiles
-  if (use_gr32)
-    pack_weights32<<<dm_ceil_div(total, 256), 256, 0, st>>>(filters, wp, kvol, ci, co, transpose_w, flip_k);
-  else
-    pack_weights<<<dm_ceil_div(total, 256), 256, 0, st>>>(filters, wp, kvol, ci, co, transpose_w, flip_k);
+  pack_weights<<<dm_ceil_div(total, 256), 256, 0, st>>>(filters, wp, kvol, ci, co, transpose_w, flip_k);
   DM_CHECK_LAUNCH();
   DM_GG_CASE(4, 16)
   DM_GG_CASE(16, 16)

@@ -24,7 +24,6 @@
 #include <hip/hip_ext.h>
 
 #include "dm_common.h"
-int dm_spconv_tile_order_rows(void);      // spconv.hip
 
 namespace {
 
@@ -328,9 +327,6 @@ extern "C" int dm_spconv_gather_gemm16(const void *feat, int n_rows_in, const vo
   if (n_rows_out == 0) return DM_OK;
   if (!filters || !nbr || !out || !workspace || (n_rows_in > 0 && !feat)) return DM_ERR_INVALID_ARG;
   if (workspace_bytes < dm_spconv16_workspace_bytes(kvol, cin, cout)) return DM_ERR_WORKSPACE;
-  // dm_spconv_tile_order / dm_spconv_pack_rows build orders of 32-row tiles under dm_spconv_set_variant(2); the
-  // kernels here walk 16-row tiles (ceil(n / 16) workgroups would read past such an order): launch in plain order
-  if (dm_spconv_tile_order_rows() != 16) tile_order = nullptr;
   switch (storage) {
     case DM_SP16_F32ROWS:
       return run16<float, float, __bf16, 1>(feat, filters, nbr, n_rows_out, kvol, cin, cout, transpose_w, flip_k, out,

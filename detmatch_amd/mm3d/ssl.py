@@ -127,12 +127,8 @@ class _Lanes(object):
         self.main = torch.cuda.current_stream(device)
         pool = _Lanes._side.get(device.index)
         if pool is None:
-            # DM_LANE_PRIORITY (A/B): 'teacher' = the teacher-3D + glue lane on a high-priority stream, '3d' = that and
-            # nothing else differs (the student's 3D passes run on the caller's stream)
-            prio = os.environ.get('DM_LANE_PRIORITY', '')
-            pool = _Lanes._side[device.index] = [
-                torch.cuda.Stream(device=device),
-                torch.cuda.Stream(device=device, priority=-1 if prio in ('teacher', '3d') else 0)]
+            # (a high-priority stream for the teacher-3D + glue lane measured no different: DESIGN.md §9)
+            pool = _Lanes._side[device.index] = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
         self.streams = [self.main] + pool
         self.current = 0
         self.pending = []
@@ -721,7 +717,7 @@ class SSL(nn.Module):
                 lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
             self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
         unlab_modules = list(self.unlab_ssl_modules)
-        if lanes is not None and (lanes.mode == 'glue' or getattr(self, 'lane_hoist', False)):
+        if lanes is not None and lanes.mode == 'glue':
             # The teacher's inference passes read nothing but the raw unlabeled batch: issue them first, so
             # that the glue that consumes them can run (on its side stream) while the main stream works
             # through the supervised passes and their early backward.  Values do not depend on the order:
@@ -734,17 +730,6 @@ class SSL(nn.Module):
             unlab_modules = [m for m in unlab_modules if m not in hoisted]
         early = lanes is None and getattr(self, 'early_backward', False) and torch.is_grad_enabled()
         curr_ssl_weight = self._get_curr_ssl_weight()
-        if lanes is None and getattr(self, 'hoist_teacher', False):
-            # Scheduling only: the unlabeled chain up to the first module that runs the student (teacher
-            # inference + the pseudo-label glue) reads nothing the labeled chain writes, draws no random
-            # numbers and runs the teacher in eval mode, so it may run FIRST.  Its read-backs (NMS counts,
-            # the Hungarian cost matrix) then wait for the teacher's own kernels only, instead of for the
-            # supervised passes' backward work queued in front of them.
-            first_student = next((i for i, m in enumerate(unlab_modules)
-                                  if str(getattr(m, 'ssl_obj_attr', '')).startswith('student')), 0)
-            for m in unlab_modules[:first_student]:
-                unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
-            unlab_modules = unlab_modules[first_student:]
         for m in self.lab_ssl_modules:
             lab_dict = self._run_and_backprop(run, m, lab_dict, early, curr_ssl_weight)
         if lanes is not None:

@@ -178,6 +178,33 @@ class VoxelBackBone8x(nn.Module):
         return batch_dict
 
 
+class _HeightCompressFn(torch.autograd.Function):
+    """dm_height_compress_forward / _backward (csrc/chain_ops.hip)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, batch, d, h, w):
+        from .. import _lib
+        features = features.contiguous()
+        n, c = features.shape
+        out = torch.empty((batch, h, w, c * d), dtype=torch.float32, device=features.device)
+        _lib.check(_lib.lib().dm_height_compress_forward(features.data_ptr(), indices.data_ptr(), n, c, batch, d, h, w,
+                                                         out.data_ptr(), _lib.raw_stream()), 'dm_height_compress_forward')
+        ctx.save_for_backward(indices)
+        ctx.geom = (n, c, d, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        from .. import _lib
+        (indices,) = ctx.saved_tensors
+        n, c, d, h, w = ctx.geom
+        grad = grad.contiguous()
+        g = torch.empty((n, c), dtype=torch.float32, device=grad.device)
+        _lib.check(_lib.lib().dm_height_compress_backward(grad.data_ptr(), indices.data_ptr(), n, c, d, h, w, g.data_ptr(),
+                                                          _lib.raw_stream()), 'dm_height_compress_backward')
+        return g, None, None, None, None, None
+
+
 class HeightCompression(nn.Module):
     """(B, C, D, H, W) dense scatter viewed as (B, C*D, H, W)."""
 
@@ -194,6 +221,13 @@ class HeightCompression(nn.Module):
         sp = batch_dict['encoded_spconv_tensor']
         d, h, w = (int(v) for v in sp.spatial_shape)
         c = sp.features.shape[1]
+        from ..fused import on as fused_on
+        if fused_on() and sp.features.is_cuda and sp.features.dtype == torch.float32 and sp.indices.dtype == torch.int32 \
+                and sp.indices.is_contiguous() and sp.indices.shape[1] == 4:
+            buf = _HeightCompressFn.apply(sp.features, sp.indices, int(sp.batch_size), d, h, w)
+            batch_dict['spatial_features'] = buf.permute(0, 3, 1, 2)
+            batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
+            return batch_dict
         idx = sp.indices.long()
         buf = sp.features.new_zeros((sp.batch_size, h, w, c, d))
         buf[idx[:, 0], idx[:, 2], idx[:, 3], :, idx[:, 1]] = sp.features      # (N, C) rows

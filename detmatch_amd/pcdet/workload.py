@@ -259,7 +259,6 @@ class DetMatchTrainWorkload(object):
             # (measured neutral on the step time, -190 launches: on by default) gradients of every early backward pass are folded into the flat arena by batched
             # multi-tensor adds and released, so autograd never accumulates tensor by tensor
             self.model.after_partial_backward = self.ddp.collect
-        self.model.hoist_teacher = os.environ.get('DM_HOIST_TEACHER', '0') == '1'   # measured: +2 ms (A/B 134.1 / 133.2 vs 131.0 / 132.5)
         # Stream lanes (ssl.py:_Lanes; data-flow edges of the batch dict become event waits).  Default
         # 'glue': every detector pass stays on the caller's stream, strictly ordered, the teacher's
         # inference is issued first and only the light pseudo-label glue with its host read-backs runs on
@@ -288,7 +287,6 @@ class DetMatchTrainWorkload(object):
         self.model.two_lanes = os.environ.get('DM_TWO_LANES', '1' if detmatch_amd.HW_QUEUES_OK else '0') == '1'
         mode = os.environ.get('DM_LANE_MODE', 'glue')
         self.model.lane_mode = None if (self.model.two_lanes or mode in ('serial', 'none', '0', '')) else mode
-        self.model.lane_hoist = os.environ.get('DM_LANE_HOIST', '0') == '1'
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
         self.n_fused = self.opt.enable_fused(self.ddp)
         self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)

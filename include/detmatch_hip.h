@@ -914,9 +914,8 @@ int dm_furthest_point_sampling_stack(int batch, const int *offsets_host, int m, 
 int dm_voxel_centers(const int32_t *coords, int n, int batch, float vx, float vy, float vz, float rx, float ry,
                      float rz, float *xyz, int32_t *counts, dm_stream_t stream);
 /* Test / tuning aid: 0 (default) clouds beyond one workgroup's registers (> 24576 points) are sampled by
- * several co-operating workgroups per sample (same indices); 1 forces one workgroup per sample; 2 takes the
- * one-workgroup kernel of rounds 1-3 (distance AND index carried through the reductions) instead of round 4's
- * value-only reduction with packed arithmetic (same indices). */
+ * several co-operating workgroups per sample (same indices); 1 forces one workgroup per sample.  Anything else:
+ * DM_ERR_INVALID_ARG. */
 int dm_fps_set_variant(int variant);
 /* Replaces roiaware_pool3d_cuda.points_in_boxes_gpu (roiaware_pool3d.cpp:98-129,
  * roiaware_pool3d_kernel.cu:313-360).  box_idx (batch, pts_num): first containing box or -1
@@ -935,7 +934,7 @@ int dm_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes
 int dm_profile_enable(int on); /* clears all records */
 /* diagnostic build aid: buf (device, 6 u64 per workgroup) or NULL to switch off */
 int dm_spconv_debug_stamps(void *buf);
-/* tuning aid: -1 auto, 0 LDS-staged-weights kernel, 1 register-weights kernel */
+/* tuning aid: -1 auto, 0 LDS-staged-weights kernel, 1 register-weights kernel; anything else DM_ERR_INVALID_ARG */
 int dm_spconv_set_variant(int v);
 /* Developer switch: pairs per weight-gradient workgroup (0 = heuristic; a multiple of 64). */
 int dm_spconv_set_wgrad_chunk(int pairs);
@@ -1009,6 +1008,14 @@ int dm_chain_run(const dm_chain_op *ops_host, int n_ops, const long long *slots_
  *   dm_multi_add_f32   dst_i += src_i (assign != 0: dst_i = src_i) for a table of (dst, src, n: 24-byte rows) in
  *                      one launch (gradient accumulation into the flat arena: torch._foreach_add_; the
  *                      concatenated bias of the anchor head's three 1x1 convolutions: torch.cat) */
+/* HeightCompression.forward (pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-25: `.dense()` -> (B, C, D, H, W)
+ * -> view (B, C * D, H, W)) written straight in NHWC: features (n, C) of the active voxels with indices (n, 4) int32
+ * [b, z, y, x] -> out (B, H, W, C * D) with channel c * D + z, zero elsewhere (zeroed by the callee); the backward
+ * gathers grad_features (n, C) from grad_out.  Replaces zeros + a 4-index index_put (and its autograd chain). */
+int dm_height_compress_forward(const float *features, const int *indices, long long n, int C, int batch, int D, int H,
+                               int W, float *out, dm_stream_t stream);
+int dm_height_compress_backward(const float *grad_out, const int *indices, long long n, int C, int D, int H, int W,
+                                float *grad_features, dm_stream_t stream);
 int dm_relu_mask_f32(const float *grad, const float *y, float *out, long long n, dm_stream_t stream);
 int dm_add_mask_f32(const float *a, const float *b, const float *y, float *out, long long n, dm_stream_t stream);
 size_t dm_colsum_workspace_bytes(long long rows, int C);

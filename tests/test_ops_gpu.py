@@ -218,27 +218,22 @@ def test_fps_reference_kat_and_ties(orc, dev):
     assert np.array_equal(got.cpu().numpy(), orc.furthest_point_sample(dup, 64))
 
 
-@pytest.mark.parametrize('n,m', [(700, 64), (5000, 512), (19940, 2048), (24000, 300)])
-def test_fps_value_only_reduction_equals_pair_carrying_kernel(dev, n, m):
-    """Round 4's one-workgroup kernel (packed distance arithmetic, value-only reductions, index recovered by an LDS
-    key minimum) against the kernel of rounds 1-3 that carries (distance, index) pairs: same indices bit for bit,
-    duplicated points (exact ties decided by the reference's stride-class rule) and ragged samples included."""
-    from detmatch_amd import _lib, pointnet2_stack as pn2
+@pytest.mark.parametrize('n,m', [(700, 64), (5000, 512), (24000, 300)])
+def test_fps_stack_ragged_with_duplicates_equals_oracle(orc, dev, n, m):
+    """The one-workgroup kernel (packed distance arithmetic, value-only reductions, index recovered by an LDS key
+    minimum) on ragged stacked samples with duplicated points (exact ties decided by the reference's stride-class
+    rule): the oracle's indices bit for bit, sample by sample."""
+    from detmatch_amd import pointnet2_stack as pn2
     g = torch.Generator().manual_seed(n + m)
     sizes = [n, n - 13]
     pts = [torch.rand(s_, 3, generator=g) * torch.tensor([70.0, 80.0, 4.0]) for s_ in sizes]
     pts[0][50:150] = pts[0][300:400]
     pts[1][:40] = pts[1][200:240]
     xyz = torch.cat(pts).to(dev).contiguous()
-    cnt = torch.tensor(sizes, dtype=torch.int32)
-    out = []
-    for variant in (0, 2):
-        _lib.lib().dm_fps_set_variant(variant)
-        try:
-            out.append(pn2.furthest_point_sample_stack(xyz, cnt, m).cpu())
-        finally:
-            _lib.lib().dm_fps_set_variant(0)
-    assert torch.equal(out[0], out[1])
+    got = pn2.furthest_point_sample_stack(xyz, torch.tensor(sizes, dtype=torch.int32), m).cpu().numpy()
+    for b, p in enumerate(pts):
+        want = orc.furthest_point_sample(p.numpy()[None], m)[0]
+        assert np.array_equal(got[b], want), b
 
 
 def test_points_in_boxes(orc, dev):

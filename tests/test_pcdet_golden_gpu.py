@@ -84,6 +84,37 @@ def test_height_compression_matches_reference_gpu(dev):
     assert sf.permute(0, 2, 3, 1).is_contiguous()            # NHWC memory, as the BEV convolutions read it
 
 
+def test_height_compression_kernels_equal_tensor_formulation_gpu(dev):
+    """dm_height_compress_forward / _backward against the zeros + index_put formulation (and its autograd gradient):
+    bit-exact, at the KITTI BEV shape, with an empty sample in the batch."""
+    from detmatch_amd import fused
+    from detmatch_amd.pcdet.backbones_3d import HeightCompression
+    from detmatch_amd.spconv.structure import SparseConvTensor
+    g = torch.Generator().manual_seed(5)
+    b, d, h, w, c, n = 3, 2, 200, 176, 128, 9000
+    cells = torch.randperm(2 * d * h * w, generator=g)[:n]          # samples 0 and 1 only: sample 2 stays empty
+    idx = torch.stack(torch.unravel_index(cells, (2, d, h, w)), 1).int().to(dev)
+    feat = torch.randn(n, c, generator=g).to(dev)
+    wgt = torch.randn(b, c * d, h, w, generator=g).to(dev)
+    res = []
+    for on in (True, False):
+        fused.ENABLED = on
+        try:
+            f = feat.clone().requires_grad_(True)
+            sp = SparseConvTensor(f, idx, [d, h, w], b)
+            sf = HeightCompression(ConfigDict(NUM_BEV_FEATURES=c * d))(
+                dict(encoded_spconv_tensor=sp, encoded_spconv_tensor_stride=8))['spatial_features']
+            (sf * wgt).sum().backward()
+            res.append((sf.detach().clone(), f.grad.clone()))
+        finally:
+            fused.ENABLED = True
+    assert res[0][0].shape == res[1][0].shape == (b, c * d, h, w)
+    assert res[0][0].permute(0, 2, 3, 1).is_contiguous()
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert float(res[0][0][2].abs().max()) == 0.0
+
+
 def test_tensor_utils_match_reference_gpu(dev):
     """Box coder, losses, box utilities, BEV interpolation on the device (tests/golden/pcdet_torch.npz)."""
     from detmatch_amd.pcdet import utils as U

@@ -134,30 +134,13 @@ def test_fp32_split_mode_matches_float64_better_than_the_fp32_instruction(dev, m
         assert errs['fp32_split'][i] <= 1.05 * errs['fp32_mfma'][i] + 1e-8, errs
 
 
-def test_16bit_kernels_ignore_a_32_row_tile_order(dev):
-    """dm_spconv_set_variant(2) makes dm_spconv_tile_order / dm_spconv_pack_rows build orders of 32-row tiles (the
-    fp32 32-row kernel's); the 16-bit kernels walk 16-row tiles and must not index such an order (half as many
-    entries as they have workgroups): under the variant the mixed-precision result equals the default variant's."""
-    from detmatch_amd import _lib, precision
-    from detmatch_amd.spconv import ops
-    rng = np.random.default_rng(9)
-    idx, rb = _scene(dev, rng, 9000, True)
-    x = torch.from_numpy(rng.standard_normal((rb.n_in, 64)).astype(np.float32)).to(dev)
-    w = torch.from_numpy((rng.standard_normal((3, 3, 3, 64, 64)) * 0.1).astype(np.float32)).to(dev)
+def test_pruned_spconv_variant_is_refused(dev):
+    """The 32-row-tile fp32 variant (dm_spconv_set_variant(2)) lost its A/B and was removed in round 5: the switch
+    refuses it instead of silently selecting something else."""
+    from detmatch_amd import _lib
     L = _lib.lib()
-    outs = []
     try:
-        for variant in (-1, 2):
-            _lib.check(L.dm_spconv_set_variant(variant), 'set_variant')
-            for attr in ('dm_packed', 'dm_tile_order'):          # per-table caches of the row packing / launch order
-                for t in (rb.nbr_out, rb.nbr_in):
-                    if hasattr(t, attr):
-                        delattr(t, attr)
-            with precision.mixed_precision():
-                y = ops.indice_conv(x, w, rb.indice_pairs, rb.indice_num, rb.n_out, False, True)
-            torch.cuda.synchronize()
-            outs.append(y.clone())
+        assert L.dm_spconv_set_variant(2) != 0
+        assert L.dm_spconv_set_variant(1) == 0
     finally:
         L.dm_spconv_set_variant(-1)
-    assert torch.isfinite(outs[1]).all()
-    assert torch.equal(outs[0], outs[1])
