@@ -15,9 +15,10 @@ if has trace; then
   f=$(find $O/kt -name "*kernel_trace.csv" | head -1)
   s=$(find $O/kt -name "*kernel_stats.csv" | head -1)
   cp $s $O/detmatch_bench_kernel_stats.csv
-  python3 $R/tools/steady_profile.py $f --marker ema_f32 --steps 8 --top 70 > $O/detmatch_step_steady.txt
-  python3 $R/tools/step_breakdown.py $f --steps 8 > $O/step_breakdown.txt
-  python3 $R/tools/dconv_calls.py $f > $O/dense_conv_launch_shapes.txt
+  python3 $R/tools/steady_profile.py $f --marker ema_f32 --steps 8 --skip-last 2 --top 70 > $O/detmatch_step_steady.txt
+  python3 $R/tools/step_breakdown.py $f --steps 8 --skip-last 2 > $O/step_breakdown.txt
+  python3 $R/tools/dconv_calls.py $f --skip-last 2 > $O/dense_conv_launch_shapes.txt
+  python3 $R/tools/aten_big_dispatches.py $f --marker ema_f32 --skip-last 2 --top 40 > $O/aten_big_dispatches.txt
   rm -rf $O/kt
 fi
 if has pmc; then

@@ -13,6 +13,10 @@ with open(sys.argv[1]) as fh:
                      int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1), int(r.get('Grid_Size_Y', 1) or 1)))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if 'ema_f32' in r[2]]
+if '--skip-last' in sys.argv:          # bench.py ends with two op-by-op measurement steps: leave them out
+    k = sys.argv.index('--skip-last')
+    marks = marks[:-int(sys.argv[k + 1])]
+    del sys.argv[k:k + 2]
 steps = 4
 pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else 'dconv')
 lo, hi = marks[-(steps + 1)], marks[-1]

@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--marker', required=True)
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--top', type=int, default=40)
+    ap.add_argument('--skip-last', type=int, default=0,
+                    help='iterations at the end of the trace to leave out (bench.py ends with two op-by-op measurement steps)')
     a = ap.parse_args()
     rows = []
     with open(a.csv) as fh:
@@ -29,6 +31,8 @@ def main():
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if re.search(a.marker, r[2])]
+    if a.skip_last:
+        marks = marks[:-a.skip_last]
     if len(marks) < a.steps + 1:
         sys.exit('only %d marker launches' % len(marks))
     lo, hi = marks[-(a.steps + 1)], marks[-1]

@@ -29,6 +29,8 @@ def main():
     ap.add_argument('csv')
     ap.add_argument('--marker', default='ema_f32')
     ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--skip-last', type=int, default=0,
+                    help='iterations at the end of the trace to leave out (bench.py ends with two op-by-op measurement steps)')
     a = ap.parse_args()
     rows = []
     with open(a.csv) as fh:
@@ -37,6 +39,8 @@ def main():
                          r.get('Queue_Id', '?'), r.get('Stream_Id', '?')))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if re.search(a.marker, r[2])]
+    if a.skip_last:
+        marks = marks[:-a.skip_last]
     steps = min(a.steps, len(marks) - 1)
     lo, hi = marks[-(steps + 1)], marks[-1]
     win = rows[lo:hi]
