@@ -139,8 +139,10 @@ class VoxelBackBone8x(nn.Module):
             return False
         from ..sparse_chain import SparseBackboneChain
         train = self.conv_input[1].training
-        if not train and torch.is_grad_enabled() and (voxel_features.requires_grad or
-                                                      any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (voxel_features.requires_grad or
+                                        (not train and any(p.requires_grad for p in self.parameters()))):
+            # the chain returns no gradient for the voxel features (MeanVFE has no parameters) and, in evaluation
+            # mode, none at all: whoever needs one takes the op-by-op path
             return False
         cache = self.__dict__.setdefault('_chains', {})
         ch = cache.get(train)
