@@ -420,6 +420,28 @@ def watched_single_gpu_run(args):
     return 3
 
 
+def start_stall_guard(limit_s, rank=0, what='bench.py'):
+    """Ranks started by a launcher (torchrun) have no parent of ours that could watch them (watched_single_gpu_run
+    covers the 1-GPU case): a thread ends the process with a diagnostic when no step has completed for `limit_s`
+    seconds, so that the intermittent device dead-lock of the stream lanes fails fast and says what to
+    do instead of hanging the whole job until somebody's timeout.  -> dict: set ['t'] = time.monotonic() after every
+    step, ['done'] = True at the end."""
+    import threading
+    state = dict(t=time.monotonic(), done=False)
+
+    def run():
+        while not state['done']:
+            time.sleep(min(5.0, max(0.05, limit_s / 4.0)))
+            if not state['done'] and time.monotonic() - state['t'] > limit_s:
+                sys.stderr.write('%s: rank %d completed no step for %.0f s - presumably the dead-lock of the three stream '
+                                 'lanes (DESIGN.md 6.R5); DM_TWO_LANES=0 runs the one-lane order, which never showed it\n'
+                                 % (what, rank, limit_s))
+                sys.stderr.flush()
+                os._exit(17)
+    threading.Thread(target=run, daemon=True, name='stall-guard').start()
+    return state
+
+
 def joined_world(dev, backend_is_device):
     """Number of ranks that actually joined the process group: all-reduce of ones."""
     one = torch.ones(1, dtype=torch.float32, device=dev if backend_is_device else 'cpu')
@@ -490,8 +512,13 @@ def main():
     if world > 1:
         wl.enable_ddp()
 
+    guard = None
+    if world > 1 and float(os.environ.get('DM_BENCH_STALL_S', '300')) > 0:
+        guard = start_stall_guard(float(os.environ.get('DM_BENCH_STALL_S', '300')), rank)
     for _ in range(args.warmup):
         wl.step()
+        if guard is not None:
+            guard['t'] = time.monotonic()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -500,11 +527,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
+        if guard is not None:
+            guard['t'] = time.monotonic()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if guard is not None:
+        guard['done'] = True
     recs = _lib.profile_records()
     _lib.lib().dm_profile_enable(0)
     sync_check = None

@@ -31,3 +31,19 @@ def test_world_size_mismatch_fails():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=e,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def test_stall_guard_ends_a_rank_that_makes_no_progress():
+    """Ranks under a launcher have no watching parent: bench.start_stall_guard ends the process (exit code 17, a
+    diagnostic naming the one-lane switch) when no step completes within the limit, and stays quiet otherwise."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "g = bench.start_stall_guard(0.4, rank=3); "
+            "[ (time.sleep(0.1), g.__setitem__('t', time.monotonic())) for _ in range(8) ]; "      # progress: no exit
+            "print('alive', flush=True); time.sleep(30)") % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 17, (r.returncode, r.stderr[-1000:])
+    assert 'alive' in r.stdout and 'rank 3' in r.stderr and 'DM_TWO_LANES=0' in r.stderr
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "g = bench.start_stall_guard(0.4); time.sleep(0.2); g['done'] = True; time.sleep(1.5); print('done')") % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'done' in r.stdout, (r.returncode, r.stderr[-1000:])
