@@ -3,10 +3,12 @@ import os as _os
 import sys as _sys
 
 # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The iteration uses the
-# default stream, two stream lanes (mm3d/ssl.py:_Lanes) and one side stream (_lib.aux_stream); with streams SHARING a
-# hardware queue the device dead-locked about once per 200 iterations (round 5: every queue waiting, no kernel
-# running; never with 5 or 6 queues, 107 instead of 70 ms per iteration with 8).  The variable is read when the
-# runtime initialises, so it is set here, at import — and the lanes are only the default when that was in time.
+# default stream, two stream lanes (mm3d/ssl.py:_Lanes) and one side stream (_lib.aux_stream) — plus RCCL's stream under
+# data parallelism: six queues give every stream its own.  Round 5 met an intermittent device dead-lock with streams
+# SHARING a hardware queue (every queue waiting, no kernel running); the first same-box A/B showed none with 5 or 6
+# queues, later boxes did while the geometry look-ahead still added streams — so this setting is a precaution, not the
+# cure (DESIGN.md 6.R5 has the bisection; 8 queues cost 107 instead of 70 ms per iteration).  The variable is read when
+# the runtime initialises, so it is set here, at import — and the lanes are only the default when that was in time.
 HW_QUEUES_OK = True
 if 'GPU_MAX_HW_QUEUES' in _os.environ:
     try:
