@@ -25,15 +25,13 @@ from . import _lib
 
 ENABLED = os.environ.get('DM_CHAIN', '1') == '1'
 MAX_ARGS = 32
-# families switched off individually (A/B, bisection): DM_CHAIN_OFF=bev,trunk2d,sa,sparse; DM_CHAIN_EVAL_OFF: only their
-# evaluation-mode (teacher) chains
+# families switched off individually (A/B, bisection): DM_CHAIN_OFF=bev,trunk2d,sa,sparse
 OFF = set(f for f in os.environ.get('DM_CHAIN_OFF', '').split(',') if f)
-EVAL_OFF = set(f for f in os.environ.get('DM_CHAIN_EVAL_OFF', '').split(',') if f)
 
 
 def on(family, train=True):
     """Is the chained issue of this family (in this mode) switched on?"""
-    return ENABLED and family not in OFF and (train or family not in EVAL_OFF)
+    return ENABLED and family not in OFF
 
 
 # debugging aid (DM_CHAIN_DEBUG=1): every op of every chain is run on its own with an event behind it, so that

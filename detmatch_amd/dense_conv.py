@@ -209,7 +209,7 @@ def _refresh_stream(stream, device):
         e.ver = (gen, e.wref()._version, e.ver[2], e.ver[3])
 
 
-PLANES = os.environ.get('DM_DCONV_PLANES', '1') == '1'     # A/B: pre-split weight planes for the patch kernel
+PLANES = True     # pre-split weight planes for the patch kernel (module switch of the A/B tools)
 
 
 def _wants_planes(T, N, K, stride_one):

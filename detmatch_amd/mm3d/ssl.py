@@ -589,8 +589,6 @@ class SSL(nn.Module):
             return
         if getattr(self, '_geom_stream', None) is None:
             self._geom_stream = _lib.aux_stream(dev)      # shared with the key-point FPS (see _lib.aux_stream)
-            if os.environ.get('DM_GEOM_ON_MAIN') == '1':
-                self._geom_stream = torch.cuda.current_stream(dev)
         dicts = (dict(stu=lab_stu, tea=data.get('lab_tea')), dict(stu=unlab_stu, tea=data.get('unlab_tea')))
         if ready is not None:
             self._geom_stream.wait_event(ready)

@@ -11,7 +11,6 @@ indexing, `tb_dict[...] = x.item()`): target assignment is a dense masked formul
 the padded GT tensor, so a training step issues no device->host copy here.  `tb_dict`
 values are detached 0-d tensors (call .item() on them outside the step if wanted).
 """
-import os
 
 import numpy as np
 import torch
@@ -514,8 +513,7 @@ class AnchorHeadSingle(nn.Module):
         """anchor_head_template.py:216-223.  On the GPU the three losses come from the fused kernel
         (csrc/anchor_loss.hip); `get_loss_torch` is the element-wise restatement of the reference (the one
         the reference-generated goldens pin, and the numerics reference of the kernel)."""
-        if fused_on() and self.forward_ret_dict['cls_preds'].is_cuda \
-                and os.environ.get('DM_ANCHOR_LOSS', 'fused') == 'fused':
+        if fused_on() and self.forward_ret_dict['cls_preds'].is_cuda:
             return self.get_loss_fused()
         return self.get_loss_torch()
 

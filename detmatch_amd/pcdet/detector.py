@@ -5,7 +5,6 @@ Module names (vfe, backbone_3d, map_to_bev_module, pfe, backbone_2d, dense_head,
 point_head, roi_head) and the `global_step` buffer follow the reference so that state
 dicts are interchangeable.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -116,7 +115,7 @@ class PVRCNN(nn.Module):
         change any value — it gives the FPS kernel (6.6 ms per pass) 8 ms of convolutions to hide behind
         instead of stalling the main stream right after the sparse backbone."""
         mods = self.module_list
-        if 'keypoints_async' in batch_dict and os.environ.get('DM_BEV_FIRST', '1') == '1':
+        if 'keypoints_async' in batch_dict:
             pfe, bev = getattr(self, 'pfe', None), getattr(self, 'backbone_2d', None)
             if pfe is not None and bev is not None and mods.index(bev) == mods.index(pfe) + 1:
                 i = mods.index(pfe)

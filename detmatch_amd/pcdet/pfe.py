@@ -189,13 +189,9 @@ class VoxelSetAbstraction(nn.Module):
         if pool is None:
             # (round 5: ONE side stream, shared with the geometry look-ahead — `_lib.aux_stream` says why; the FPS
             # launches of an iteration are issued one iteration ahead, so running them one after the other costs
-            # nothing.  DM_FPS_STREAMS=3 restores the pool.)
-            import os
+            # nothing; a pool of three streams was one of the conditions of the round-5 dead-lock.)
             from .. import _lib
-            n = int(os.environ.get('DM_FPS_STREAMS', '1'))
-            streams = [_lib.aux_stream(pts.device)] if n <= 1 else \
-                [torch.cuda.Stream(device=pts.device) for _ in range(n)]
-            pool = VoxelSetAbstraction._side_streams[key] = dict(streams=streams, next=0)
+            pool = VoxelSetAbstraction._side_streams[key] = dict(streams=[_lib.aux_stream(pts.device)], next=0)
         side = pool['streams'][pool['next'] % len(pool['streams'])]
         pool['next'] += 1
         main = torch.cuda.current_stream(pts.device)

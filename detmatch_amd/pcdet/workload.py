@@ -255,7 +255,7 @@ class DetMatchTrainWorkload(object):
         # one backbone + FPN + RPN pass for the student's labeled and unlabeled images (mm2d/faster_rcnn.py:
         # prefetch_trunk; the OptimizerHook of the runner finishes the deferred trunk backward)
         self.model.share_2d_trunk = os.environ.get('DM_SHARE_2D_TRUNK', '1') == '1'
-        if os.environ.get('DM_COLLECT_EARLY', '1') == '1' and self.ddp.mode == 'collect':
+        if self.ddp.mode == 'collect':
             # (measured neutral on the step time, -190 launches: on by default) gradients of every early backward pass are folded into the flat arena by batched
             # multi-tensor adds and released, so autograd never accumulates tensor by tensor
             self.model.after_partial_backward = self.ddp.collect

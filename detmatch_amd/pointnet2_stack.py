@@ -197,14 +197,16 @@ class TallSkinnyLinear(Function):
 
     # rows from which csrc/rowgemm.hip takes the forward / input-gradient GEMM (A/B of the DetMatch step:
     # 16 k rows 107.0 ms, 256 k rows 107.8 ms, BLAS only 109.5 ms; below ~16 k rows a launch is latency sized)
-    ROWGEMM_MIN_ROWS = int(os.environ.get('DM_ROWGEMM_MIN_ROWS', '16384'))
+    ROWGEMM_MIN_ROWS = 16384
+    ROWGEMM = True            # class switches of the A/B tools and equality tests
+    ROWGEMM_STATS = True
 
     @staticmethod
     def _rowgemm(x, w, col0=0):
         """x (R, K) . w (N, K)^T on csrc/rowgemm.hip (weights resident in LDS), or None if not taken.
         col0 > 0: the result has col0 leading zero columns (rows of col0 + N floats)."""
         if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
-                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and os.environ.get('DM_ROWGEMM', '1') == '1'):
+                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and TallSkinnyLinear.ROWGEMM):
             return None
         L = _lib.lib()
         r, k = x.shape
@@ -223,7 +225,7 @@ class TallSkinnyLinear(Function):
         (csrc/rowgemm.hip: dm_rowgemm_wt) — no `w.t().contiguous()` copy per call; None if not taken."""
         if not (gy.is_cuda and gy.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 2
                 and w.stride(1) == 1 and gy.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS
-                and os.environ.get('DM_ROWGEMM', '1') == '1'):
+                and TallSkinnyLinear.ROWGEMM):
             return None
         L = _lib.lib()
         r, k = gy.shape
@@ -239,7 +241,7 @@ class TallSkinnyLinear(Function):
     # csrc/conv2d.hip's streaming weight-gradient kernel (dm_tall_wgrad): correct and reproducible, but on the shapes of
     # the step it only ties the batched BLAS call (profiles/r04_tall_skinny_wgrad_blas_vs_own.txt: 250 vs 240 us on
     # 884 736 x 132 x 64, 160 vs 98 us on 884 736 x 64 x 64, 24-49 vs 26-33 us on the small ones) — opt-in
-    OWN_WGRAD = os.environ.get('DM_TALL_WGRAD', '0') == '1'
+    OWN_WGRAD = False
 
     @staticmethod
     def _wgrad(gy, x):
@@ -264,8 +266,8 @@ class TallSkinnyLinear(Function):
         (per-workgroup (mean, M2) partials from the output tile it already holds in LDS): -> y with the
         attribute `dm_bn_pre = (partial, counts, parts)`, or None if not taken."""
         if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
-                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and os.environ.get('DM_ROWGEMM', '1') == '1'
-                and os.environ.get('DM_ROWGEMM_STATS', '1') == '1'):
+                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and TallSkinnyLinear.ROWGEMM
+                and TallSkinnyLinear.ROWGEMM_STATS):
             return None
         L = _lib.lib()
         r, k = x.shape
@@ -498,7 +500,7 @@ class StackSAModuleMSG(nn.Module):
             # over (M*nsample, C) rows, BatchNorm2d a column reduction over the same M*nsample
             # elements per channel — the math of :72-83 without the (1, C, M, nsample) copies.
             found = [None] * len(self.groupers)
-            if len(self.groupers) == 2 and fused_on() and xyz.is_cuda and os.environ.get('DM_BALL_PAIR', '1') == '1':
+            if len(self.groupers) == 2 and fused_on() and xyz.is_cuda:
                 # both radii of the source in one scan of its points
                 ga, gb = self.groupers
                 found = ball_query_pair(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, xyz_batch_cnt,

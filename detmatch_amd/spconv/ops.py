@@ -205,7 +205,7 @@ def tile_order(nbr):
 TILE_ORDER_MIN_ROWS = 4096
 
 
-PACK_ROWS = os.environ.get('DM_SPCONV_PACK_ROWS', '1') == '1'
+PACK_ROWS = True       # (module switch of the equality tests and tools/spconv_pack_probe.py)
 
 
 def packed_rows(nbr):
@@ -302,7 +302,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
 # of the per-layer calls (same chunks, same fixed-order sums).  The drivers that own a backward pass wrap it
 # (SSL's early backward passes, OptimizerHook); a plain loss.backward() outside the context computes every weight
 # gradient inside the pass as before.
-WGRAD_BATCH = os.environ.get('DM_SPCONV_WGRAD_BATCH', '1') == '1'
+WGRAD_BATCH = True     # (module switch of the equality tests)
 _WGRAD_QUEUE = []
 _WGRAD_DEPTH = [0]
 WGRAD_BATCHES = [0]      # flushes so far (tests)
