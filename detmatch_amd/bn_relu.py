@@ -116,11 +116,8 @@ _DEFER = [False]
 _PENDING = []
 
 
-_DEFER_ON = True      # (module switch of the equality tests)
-
-
 def _bump(bn):
-    if _DEFER[0] and _DEFER_ON:
+    if _DEFER[0]:
         _PENDING.append(bn.num_batches_tracked)
     else:
         bn.num_batches_tracked.add_(1)

@@ -197,16 +197,14 @@ class TallSkinnyLinear(Function):
 
     # rows from which csrc/rowgemm.hip takes the forward / input-gradient GEMM (A/B of the DetMatch step:
     # 16 k rows 107.0 ms, 256 k rows 107.8 ms, BLAS only 109.5 ms; below ~16 k rows a launch is latency sized)
-    ROWGEMM_MIN_ROWS = 16384
-    ROWGEMM = True            # class switches of the A/B tools and equality tests
-    ROWGEMM_STATS = True
+    ROWGEMM_MIN_ROWS = 16384       # (class attribute: the equality tests and tools/bench_tall_skinny.py lower it)
 
     @staticmethod
     def _rowgemm(x, w, col0=0):
         """x (R, K) . w (N, K)^T on csrc/rowgemm.hip (weights resident in LDS), or None if not taken.
         col0 > 0: the result has col0 leading zero columns (rows of col0 + N floats)."""
         if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
-                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and TallSkinnyLinear.ROWGEMM):
+                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS):
             return None
         L = _lib.lib()
         r, k = x.shape
@@ -224,8 +222,7 @@ class TallSkinnyLinear(Function):
         """gx = gy @ w with the first `dead` columns written as zeros, read from the stored (out, in) weight
         (csrc/rowgemm.hip: dm_rowgemm_wt) — no `w.t().contiguous()` copy per call; None if not taken."""
         if not (gy.is_cuda and gy.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 2
-                and w.stride(1) == 1 and gy.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS
-                and TallSkinnyLinear.ROWGEMM):
+                and w.stride(1) == 1 and gy.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS):
             return None
         L = _lib.lib()
         r, k = gy.shape
@@ -266,8 +263,7 @@ class TallSkinnyLinear(Function):
         (per-workgroup (mean, M2) partials from the output tile it already holds in LDS): -> y with the
         attribute `dm_bn_pre = (partial, counts, parts)`, or None if not taken."""
         if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
-                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS and TallSkinnyLinear.ROWGEMM
-                and TallSkinnyLinear.ROWGEMM_STATS):
+                and x.shape[0] >= TallSkinnyLinear.ROWGEMM_MIN_ROWS):
             return None
         L = _lib.lib()
         r, k = x.shape
