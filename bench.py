@@ -395,28 +395,63 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def beat():
+    """Heartbeat of the measuring child process for watched_single_gpu_run (a no-op anywhere else)."""
+    path = os.environ.get('DM_BENCH_HEARTBEAT')
+    if path:
+        with open(path, 'a'):
+            os.utime(path, None)
+
+
 def watched_single_gpu_run(args):
     """`python bench.py` at one GPU: the measurement runs in a CHILD process under a watchdog.  Round 5 met an
     intermittent device dead-lock under the three stream lanes (profiles/r05_lane_hang_ab.txt: avoided, never
     understood); should a run ever wedge, the child is killed and the bench repeats ONCE in the one-lane order of
-    round 4 (`DM_TWO_LANES=0`) and says so in its line — a slower honest number instead of no number.  This process
-    never touches the GPU."""
+    round 4 (`DM_TWO_LANES=0`) and says so in its line — a slower honest number instead of no number.  The watchdog
+    goes by PROGRESS, not by total time: the child touches a heartbeat file after every step and phase (`beat`); it is
+    killed when the file is older than `DM_BENCH_WATCHDOG_S` (150 s) — or never appeared within 900 s: the first
+    `import torch` on a cold box takes minutes and must not be mistaken for a dead-lock.  This process never touches
+    the GPU."""
     import subprocess
+    import tempfile
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append('--no-cpu-baseline')
-    limit = float(os.environ.get('DM_BENCH_WATCHDOG_S', '0')) or (240.0 + 1.0 * (args.steps + args.warmup))
-    first = float(os.environ.get('DM_BENCH_WATCHDOG_FIRST_S', '0')) or limit      # (tests shorten the first attempt)
+    stall = float(os.environ.get('DM_BENCH_WATCHDOG_S', '0')) or 150.0
+    startup = max(900.0, stall)
+    first = float(os.environ.get('DM_BENCH_WATCHDOG_FIRST_S', '0'))      # (tests shorten the first attempt)
     for attempt in (0, 1):
-        env = dict(os.environ, DM_BENCH_CHILD='1')
+        fd, hb = tempfile.mkstemp(prefix='dm_bench_heartbeat_')
+        os.close(fd)
+        os.remove(hb)                 # it exists from the child's first beat on
+        env = dict(os.environ, DM_BENCH_CHILD='1', DM_BENCH_HEARTBEAT=hb)
+        lim_start, lim_stall = (first, first) if (attempt == 0 and first) else (startup, stall)
         if attempt:
-            env.update(DM_TWO_LANES='0', DM_BENCH_NOTE='first attempt (three stream lanes) did not finish within %d s and was '
-                       'killed; this line is the one-lane order of round 4' % int(limit))
+            env.update(DM_TWO_LANES='0', DM_BENCH_NOTE='first attempt (three stream lanes) made no progress for %d s and was '
+                       'killed; this line is the one-lane order of round 4' % int(first or stall))
+        proc = subprocess.Popen(cmd, env=env)
+        t0 = time.monotonic()
+        why = None
         try:
-            return subprocess.run(cmd, env=env, timeout=limit if attempt else first).returncode
-        except subprocess.TimeoutExpired:
-            print('bench.py: the measurement did not finish within %d s (attempt %d): killed'
-                  % (int(limit if attempt else first), attempt + 1), file=sys.stderr)
+            while why is None:
+                try:
+                    rc = proc.wait(timeout=0.5)
+                    return rc
+                except subprocess.TimeoutExpired:
+                    pass
+                try:
+                    idle = time.time() - os.path.getmtime(hb)
+                    if idle > lim_stall:
+                        why = 'no step or phase completed for %d s' % int(lim_stall)
+                except OSError:
+                    if time.monotonic() - t0 > lim_start:
+                        why = 'the workload did not start within %d s' % int(lim_start)
+            proc.kill()
+            proc.wait()
+        finally:
+            if os.path.exists(hb):
+                os.remove(hb)
+        print('bench.py: %s (attempt %d): killed' % (why, attempt + 1), file=sys.stderr)
     return 3
 
 
@@ -459,8 +494,11 @@ def main():
         # (never under a profiler: its preloaded library has initialised the GPU in THIS process, and a process that
         # holds the GPU must not start another program)
         sys.exit(watched_single_gpu_run(args))
-    if os.environ.get('DM_BENCH_FAKE_HANG') == '1' and os.environ.get('DM_TWO_LANES') != '0':
-        time.sleep(10 ** 6)      # test hook of the watchdog (tests/test_bench_launch.py): the first attempt never finishes
+    if os.environ.get('DM_BENCH_FAKE_HANG') in ('1', '2') and os.environ.get('DM_TWO_LANES') != '0':
+        # test hooks of the watchdog: the first attempt never starts ('1') / stops making progress after a heartbeat ('2')
+        if os.environ['DM_BENCH_FAKE_HANG'] == '2':
+            beat()
+        time.sleep(10 ** 6)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -515,8 +553,10 @@ def main():
     guard = None
     if world > 1 and float(os.environ.get('DM_BENCH_STALL_S', '300')) > 0:
         guard = start_stall_guard(float(os.environ.get('DM_BENCH_STALL_S', '300')), rank)
+    beat()
     for _ in range(args.warmup):
         wl.step()
+        beat()
         if guard is not None:
             guard['t'] = time.monotonic()
     torch.cuda.synchronize()
@@ -527,9 +567,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
+        beat()
         if guard is not None:
             guard['t'] = time.monotonic()
     torch.cuda.synchronize()
+    beat()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -557,7 +599,9 @@ def main():
     # one extra untimed step with the launch trace on — on EVERY rank (a step contains the gradient
     # and log all-reduces; a rank stepping alone would dead-lock the others)
     per_step, per_dir, per_w = trace_launches(wl)
+    beat()
     others = other_kernel_groups(wl)       # on every rank too (the step contains collectives)
+    beat()
     if rank == 0:
         # ---- roofline of the sparse-conv kernels (HIP events from the timed region) ----
         # the synthetic batch is the same every step, so launch j of a step always sees the same
@@ -675,7 +719,10 @@ def main():
         out['last_loss'] = float(wl.runner.outputs['loss'].detach()) if getattr(wl, 'runner', None) is not None and \
             getattr(wl.runner, 'outputs', None) else None
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(wl.frames, gpu_stage_pieces(wl.frames, dev))
+            beat()
+            pieces = gpu_stage_pieces(wl.frames, dev)
+            beat()
+            out['cpu_baseline'] = cpu_baseline(wl.frames, pieces)      # (bounded: 10-30 s of host work)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -47,3 +47,17 @@ def test_stall_guard_ends_a_rank_that_makes_no_progress():
             "g = bench.start_stall_guard(0.4); time.sleep(0.2); g['done'] = True; time.sleep(1.5); print('done')") % ROOT
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and 'done' in r.stdout, (r.returncode, r.stderr[-1000:])
+
+
+def test_watchdog_kills_a_child_without_progress_and_retries_in_one_lane():
+    """watched_single_gpu_run on CPU: a first attempt that never starts / stops beating is killed by the progress
+    watchdog; the second attempt runs with DM_TWO_LANES=0 (and ends at the 'needs a GPU' assertion here)."""
+    for fake, msg in (('1', 'did not start within'), ('2', 'no step or phase completed')):
+        env = dict(os.environ, DM_BENCH_FAKE_HANG=fake, DM_BENCH_WATCHDOG_FIRST_S='2')
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'DM_TWO_LANES', 'DM_BENCH_DRYRUN', 'DM_BENCH_CHILD'):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert msg in r.stderr and '(attempt 1): killed' in r.stderr, r.stderr[-1500:]
+        assert 'needs a GPU' in r.stderr and r.returncode != 0, (r.returncode, r.stderr[-1500:])
+        assert '(attempt 2)' not in r.stderr
