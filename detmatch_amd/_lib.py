@@ -266,6 +266,98 @@ def floats(v):
     return (ctypes.c_float * len(v))(*[float(x) for x in v])
 
 
+# ---- vendor BLAS: one GEMM at a time per process ------------------------------------------------------------------
+# Every fp32 GEMM torch hands to hipBLASLt on gfx950 is a Tensile STREAM-K kernel (`Cijk_..._SK3_...`): workgroups that
+# finish a partial tile publish it through flags in a workspace of the library handle and the owner of the tile spins in
+# `label_SK_Fixup` until they arrive.  Two such kernels in flight at the same time from one handle — two HIP streams of
+# one host thread — use the SAME flags: every recorded "three-lane device dead-lock" of round 5 was one of them (the
+# RoI head's 27 648 -> 256 FC) spinning for ever with the device 100 % busy (profiles/r06_deadlock_*.txt;
+# tools/streamk_two_streams_repro.py reproduces it with nothing but torch).  Rule of this package: a vendor GEMM is only
+# issued inside `blas_turn()`, which orders it behind the previous vendor GEMM of the process with an event edge when that
+# one went to another stream — in stream order nothing changes, across streams no two of them ever overlap.
+_BLAS_LOCK = threading.RLock()
+_BLAS_LAST = [None, 0]          # (event recorded behind the last vendor GEMM, raw handle of the stream it went to)
+_BLAS_RING = []                 # events are reused round-robin (a wait captures the record it was issued after)
+_BLAS_RING_POS = [0]
+BLAS_TURNS = [0, 0]             # turns taken, cross-stream edges inserted (census / tests)
+BLAS_TRACE = [False]            # tests: every turn is a `dm_blas_turn` range in torch's profiler (tests/test_blas_turn_gpu.py)
+
+
+class blas_turn(object):
+    """with blas_turn(): <torch GEMM(s) on the current stream>"""
+    __slots__ = ('cuda', 'rng')
+
+    def __enter__(self):
+        _BLAS_LOCK.acquire()
+        self.rng = None
+        if BLAS_TRACE[0]:
+            self.rng = torch.autograd.profiler.record_function('dm_blas_turn')
+            self.rng.__enter__()
+        self.cuda = torch.cuda.is_available()
+        if self.cuda:
+            ev, last_stream = _BLAS_LAST
+            if ev is not None and last_stream != raw_stream():
+                torch.cuda.current_stream().wait_event(ev)
+                BLAS_TURNS[1] += 1
+        BLAS_TURNS[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if self.cuda:
+                if len(_BLAS_RING) < 64:
+                    _BLAS_RING.append(torch.cuda.Event())
+                i = _BLAS_RING_POS[0] = (_BLAS_RING_POS[0] + 1) % 64
+                ev = _BLAS_RING[min(i, len(_BLAS_RING) - 1)]
+                ev.record()
+                _BLAS_LAST[0], _BLAS_LAST[1] = ev, raw_stream()
+        finally:
+            if self.rng is not None:
+                self.rng.__exit__(None, None, None)
+            _BLAS_LOCK.release()
+        return False
+
+
+class _BlasLinear(torch.autograd.Function):
+    """F.linear on the vendor library, forward AND backward inside a turn (autograd's own matmul backward would issue
+    its GEMMs from the engine's thread outside any turn)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        with blas_turn():
+            return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        g2, x2 = gy.reshape(-1, gy.shape[-1]), x.reshape(-1, x.shape[-1])
+        with blas_turn():
+            if ctx.needs_input_grad[0]:
+                gx = (g2 @ w).view(x.shape)
+            if ctx.needs_input_grad[1]:
+                gw = g2.t() @ x2
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(dim=0)
+        return gx, gw, gb
+
+
+def blas_linear(x, w, b=None):
+    """torch.nn.functional.linear(x, w, b) issued under the one-GEMM-at-a-time rule (see blas_turn)."""
+    if not torch.is_grad_enabled() or not (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        with blas_turn():
+            return torch.nn.functional.linear(x, w, b)
+    return _BlasLinear.apply(x, w, b)
+
+
+def blas_mm(a, b):
+    """a @ b (2-D, no autograd) under the rule."""
+    with blas_turn():
+        return torch.mm(a, b)
+
+
 _AUX = {}
 
 

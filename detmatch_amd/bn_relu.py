@@ -221,8 +221,9 @@ def bn_relu_rows(x, bn, relu=True):
 def _linear_rows(x, m):
     # (the RoI head's 27648 -> 256 layer was also tried as a split-K 1x1 convolution on conv2d.hip:
     # 290 us forward + backward against 212 us of the BLAS kernels torch picks — kept on BLAS)
+    # (vendor GEMM: only ever inside _lib.blas_turn — one Stream-K kernel at a time)
     w = m.weight
-    return F.linear(x, w.squeeze(-1) if w.dim() == 3 else w, m.bias)
+    return _lib.blas_linear(x, w.squeeze(-1) if w.dim() == 3 else w, m.bias)
 
 
 def fc_rows(seq, x):

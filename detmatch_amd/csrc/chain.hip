@@ -52,10 +52,13 @@ extern "C" int dm_chain_run(const dm_chain_op *ops_host, int n_ops, const long l
   const dm_chain_entry *t = dm_chain_table_(&n);
   if (failed_op_host) *failed_op_host = -1;
   if (n_ops < 0 || (n_ops > 0 && !ops_host) || (n_slots > 0 && !slots_host)) return DM_ERR_INVALID_ARG;
-  long long a[DM_CHAIN_MAX_ARGS];
+  long long a[DM_CHAIN_MAX_ARGS] = {0};
   for (int i = 0; i < n_ops; ++i) {
     const dm_chain_op &op = ops_host[i];
-    if (op.fn < 0 || op.fn >= n || op.nargs < 0 || op.nargs > DM_CHAIN_MAX_ARGS) {
+    // the trampoline of an entry reads exactly strlen(sig) arguments: an op with another count would hand it stale
+    // values of the previous op as pointers and sizes
+    if (op.fn < 0 || op.fn >= n || op.nargs < 0 || op.nargs > DM_CHAIN_MAX_ARGS ||
+        op.nargs != (int)strlen(t[op.fn].sig)) {
       if (failed_op_host) *failed_op_host = i;
       return DM_ERR_INVALID_ARG;
     }

@@ -60,6 +60,7 @@ class _Weights(object):
         self.fold_rows, self.cat_rows, self.pack_rows = [], [], []
         self.keep = []
         self.watch = []          # tensors whose version counters are checked per run (conv weights, folded statistics)
+        self._watch_ptrs = None
         self.prog = None
         self.stamp = None
         self.max_fold_c, self.max_cat_n, self.max_pack = 1, 1, 1
@@ -136,6 +137,13 @@ class _Weights(object):
             prog.call(*c)
         self.prog = prog.finalize()
 
+    def watch_ptrs(self):
+        """Ascending addresses of every watched tensor (the tables hold these raw addresses, so they are fixed for
+        the life of the chain: `DenseChain.valid()` drops the chain when a tensor is re-homed)."""
+        if self._watch_ptrs is None or len(self._watch_ptrs) != len(self.watch):
+            self._watch_ptrs = sorted(t.data_ptr() for t in self.watch)
+        return self._watch_ptrs
+
     def _fingerprint(self):
         v = 0
         for t in self.watch:
@@ -156,7 +164,7 @@ class _Weights(object):
                 self._mirror_stamp = mk
                 st = None
         if st is not None and st[1] == fp and st[2] == dense_conv.LOAD_EPOCH[0]:
-            if st[0] == gen or not self.watch or not dense_conv._stale(st[0], self.watch[0].data_ptr()):
+            if st[0] == gen or not self.watch or not dense_conv._stale_any(st[0], self.watch_ptrs()):
                 if st[0] != gen:
                     self.stamp = (gen, fp, st[2])
                 return
@@ -583,14 +591,14 @@ class DenseChain(object):
         else:
             self.leaves = []
         self.out_shapes = [(o.n, o.h, o.w, o.c) for o in self.outputs]
-        self.first_ptr = self.weights.watch[0].data_ptr() if self.weights.watch else 0
+        self.built_ptrs = tuple(t.data_ptr() for t in self.weights.watch)
 
     def launches(self):
         return len(self.fwd), (len(self.bwd) if self.bwd is not None else 0)
 
     def valid(self):
         """False once the parameters were re-homed (flat arenas, .to()): the tables hold raw addresses."""
-        return not self.weights.watch or self.weights.watch[0].data_ptr() == self.first_ptr
+        return tuple(t.data_ptr() for t in self.weights.watch) == self.built_ptrs
 
     def _check_inputs(self, xs):
         out = []

@@ -10,6 +10,7 @@ libdetmatch_hip.so; there is no MIOpen / cuDNN call and no CPU path: a CPU tenso
 stand-in for host tensors through `HOST_TENSOR_HOOK`; the stand-in lives in tests/_host_conv.py, the
 product, bench.py and smoke() never set the hook.)
 """
+import bisect
 import ctypes
 import os
 import weakref
@@ -110,6 +111,24 @@ def _stale(entry_gen, src_ptr):
         if gen <= entry_gen:
             break
         if lo is None or lo <= src_ptr < hi:
+            return True
+    return False
+
+
+def _stale_any(entry_gen, sorted_ptrs):
+    """_stale over SEVERAL source tensors (ascending addresses): True when any raw-pointer rewrite after
+    `entry_gen` covers at least one of them.  A chain's derived weights come from many parameters and buffers —
+    frozen ones among them, which the optimizer's byte ranges never cover — so asking about one tensor only is not
+    enough (the 2D trunk chain watched a frozen stem weight first and kept stale packed weights)."""
+    if entry_gen < _FLOOR[0]:
+        return True
+    for gen, lo, hi in reversed(_EVENTS):
+        if gen <= entry_gen:
+            break
+        if lo is None:
+            return True
+        i = bisect.bisect_left(sorted_ptrs, lo)
+        if i < len(sorted_ptrs) and sorted_ptrs[i] < hi:
             return True
     return False
 

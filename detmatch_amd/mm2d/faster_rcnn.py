@@ -479,9 +479,11 @@ class Shared2FCBBoxHead(nn.Module):
 
     def forward(self, x):
         x = x.flatten(1)
+        # (vendor GEMMs: only ever inside _lib.blas_turn — one Stream-K kernel at a time)
         for fc in self.shared_fcs:
-            x = F.relu(fc(x), inplace=True)
-        return self.fc_cls(x), self.fc_reg(x)
+            x = F.relu(_lib.blas_linear(x, fc.weight, fc.bias), inplace=True)
+        return _lib.blas_linear(x, self.fc_cls.weight, self.fc_cls.bias), \
+            _lib.blas_linear(x, self.fc_reg.weight, self.fc_reg.bias)
 
     def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, fused=None):
         """mmdet BBoxHead.loss: cls avg_factor = #(label_weights > 0); box loss over positives of

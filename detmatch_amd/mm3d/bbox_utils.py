@@ -195,8 +195,9 @@ def bbox_3d_to_bbox_2d(bboxes_3d, lidar2img, img_shape):
         return (torch.empty((0, 4), dtype=bboxes_3d.tensor.dtype, device=bboxes_3d.tensor.device),
                 torch.empty((0,), dtype=torch.bool, device=bboxes_3d.tensor.device))
     corners = bboxes_3d.corners.reshape(-1, 3)
-    hom = torch.cat([corners, corners.new_ones(size=(n * 8, 1))], dim=-1)
-    p = hom @ lidar2img.t()
+    # [corner, 1] @ lidar2img^T as three scaled columns + the translation column (no vendor GEMM for a 4-wide contraction)
+    p = corners[:, 0:1] * lidar2img[:, 0] + corners[:, 1:2] * lidar2img[:, 1] + corners[:, 2:3] * lidar2img[:, 2] \
+        + lidar2img[:, 3]
     depth = torch.clamp(p[:, 2], min=1e-5)     # clamp BEFORE the divide and the tests (:408)
     x = p[:, 0] / depth
     y = p[:, 1] / depth

@@ -12,27 +12,35 @@ def limit_period(val, offset=0.5, period=np.pi):
     return val - torch.floor(val / period + offset) * period
 
 
+def _planar_turn(u, v, angles):
+    """(u, v) -> (u cos + v sin, -u sin + v cos) with one angle per leading row; u, v (N, M), angles (N)."""
+    c, s = torch.cos(angles).unsqueeze(-1), torch.sin(angles).unsqueeze(-1)
+    return u * c + v * s, v * c - u * s
+
+
 def rotation_3d_in_axis(points, angles, axis=0):
-    """structures/utils.py:24-61: points (N, M, 3), angles (N)."""
-    rot_sin = torch.sin(angles)
-    rot_cos = torch.cos(angles)
-    ones = torch.ones_like(rot_cos)
-    zeros = torch.zeros_like(rot_cos)
-    if axis == 1:
-        rot_mat_T = torch.stack([torch.stack([rot_cos, zeros, -rot_sin]),
-                                 torch.stack([zeros, ones, zeros]),
-                                 torch.stack([rot_sin, zeros, rot_cos])])
-    elif axis == 2 or axis == -1:
-        rot_mat_T = torch.stack([torch.stack([rot_cos, -rot_sin, zeros]),
-                                 torch.stack([rot_sin, rot_cos, zeros]),
-                                 torch.stack([zeros, zeros, ones])])
+    """Same result as structures/utils.py:24-61 for points (N, M, 3), angles (N) — written as a planar turn of two
+    coordinate slices (no 3x3 matrices, no batched matrix product: a vendor GEMM per call for 8 corners per box is
+    what the reference pays).  The reference's conventions: axis 2 turns (x, y), axis 1 turns (x, z), and axis 0
+    ALSO moves the axes — (x, y, z) -> (z, x', y') — exactly as its matrix for that case does."""
+    x, y, z = points.unbind(-1)
+    if axis == 2 or axis == -1:
+        a, b = _planar_turn(x, y, angles)
+        out = (a, b, z)
+    elif axis == 1:
+        a, b = _planar_turn(x, z, angles)
+        out = (a, y, b)
     elif axis == 0:
-        rot_mat_T = torch.stack([torch.stack([zeros, rot_cos, -rot_sin]),
-                                 torch.stack([zeros, rot_sin, rot_cos]),
-                                 torch.stack([ones, zeros, zeros])])
+        a, b = _planar_turn(x, y, angles)
+        out = (z, a, b)
     else:
         raise ValueError('axis should in range [0, 1, 2], got %s' % axis)
-    return torch.einsum('aij,jka->aik', (points, rot_mat_T))
+    return torch.stack(out, dim=-1)
+
+
+def _rows_times_3x3(xyz, m):
+    """xyz (N, 3) @ m (3, 3) as three scaled row sums (no vendor GEMM for a 3-wide contraction)."""
+    return xyz[:, 0:1] * m[0] + xyz[:, 1:2] * m[1] + xyz[:, 2:3] * m[2]
 
 
 class LiDARInstance3DBoxes(object):
@@ -113,10 +121,10 @@ class LiDARInstance3DBoxes(object):
         else:
             rot_mat_T = angle.to(self.tensor)
             angle = torch.atan2(rot_mat_T[1, 0], rot_mat_T[0, 0])
-        self.tensor = torch.cat([self.tensor[:, :3] @ rot_mat_T, self.tensor[:, 3:6],
+        self.tensor = torch.cat([_rows_times_3x3(self.tensor[:, :3], rot_mat_T), self.tensor[:, 3:6],
                                  (self.tensor[:, 6] + angle).unsqueeze(-1), self.tensor[:, 7:]], -1)
         if points is not None:
-            points[:, :3] = points[:, :3] @ rot_mat_T
+            points[:, :3] = _rows_times_3x3(points[:, :3], rot_mat_T)
             return points, rot_mat_T
 
     def flip(self, bev_direction='horizontal', points=None):

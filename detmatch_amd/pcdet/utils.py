@@ -16,15 +16,12 @@ def limit_period(val, offset=0.5, period=np.pi):
 
 
 def rotate_points_along_z(points, angle):
-    """common_utils.py:34-56: points (B, N, 3+C), angle (B) — x' = x cos - y sin."""
-    cosa = torch.cos(angle)
-    sina = torch.sin(angle)
-    zeros = angle.new_zeros(points.shape[0])
-    ones = angle.new_ones(points.shape[0])
-    rot_matrix = torch.stack((cosa, sina, zeros, -sina, cosa, zeros, zeros, zeros, ones),
-                             dim=1).view(-1, 3, 3).float()
-    points_rot = torch.matmul(points[:, :, 0:3], rot_matrix)
-    return torch.cat((points_rot, points[:, :, 3:]), dim=-1)
+    """Same result as common_utils.py:34-56 for points (B, N, 3+C), angle (B): x' = x cos - y sin, y' = x sin + y cos,
+    everything else untouched — as a turn of the two coordinate slices (the reference builds B 3x3 matrices and calls a
+    batched matrix product)."""
+    c, s = torch.cos(angle).float().view(-1, 1), torch.sin(angle).float().view(-1, 1)
+    x, y = points[:, :, 0], points[:, :, 1]
+    return torch.cat((torch.stack((x * c - y * s, x * s + y * c), dim=-1), points[:, :, 2:]), dim=-1)
 
 
 def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):
@@ -57,17 +54,13 @@ def enlarge_box3d(boxes3d, extra_width=(0, 0, 0)):
 
 
 def boxes_iou_normal(boxes_a, boxes_b):
-    """box_utils.py:248-269: axis-aligned IoU of (N,4) x (M,4) [x1,y1,x2,y2]."""
-    x_min = torch.max(boxes_a[:, 0, None], boxes_b[None, :, 0])
-    x_max = torch.min(boxes_a[:, 2, None], boxes_b[None, :, 2])
-    y_min = torch.max(boxes_a[:, 1, None], boxes_b[None, :, 1])
-    y_max = torch.min(boxes_a[:, 3, None], boxes_b[None, :, 3])
-    x_len = torch.clamp_min(x_max - x_min, min=0)
-    y_len = torch.clamp_min(y_max - y_min, min=0)
-    area_a = (boxes_a[:, 2] - boxes_a[:, 0]) * (boxes_a[:, 3] - boxes_a[:, 1])
-    area_b = (boxes_b[:, 2] - boxes_b[:, 0]) * (boxes_b[:, 3] - boxes_b[:, 1])
-    inter = x_len * y_len
-    return inter / torch.clamp_min(area_a[:, None] + area_b[None, :] - inter, min=1e-6)
+    """Axis-aligned IoU of (N, 4) x (M, 4) [x1, y1, x2, y2] boxes, == box_utils.py:248-269: the overlap rectangle from
+    the broadcast corner max / min (both axes at once), union floored at 1e-6."""
+    a, b = boxes_a[:, None, :], boxes_b[None, :, :]
+    wh = (torch.min(a[..., 2:4], b[..., 2:4]) - torch.max(a[..., 0:2], b[..., 0:2])).clamp_min(0)
+    inter = wh[..., 0] * wh[..., 1]
+    area = lambda t: (t[..., 2] - t[..., 0]) * (t[..., 3] - t[..., 1])
+    return inter / (area(a) + area(b) - inter).clamp_min(1e-6)
 
 
 def boxes3d_lidar_to_aligned_bev_boxes(boxes3d):
@@ -93,34 +86,28 @@ class ResidualCoder(object):
         self.code_size = code_size
         self.encode_angle_by_sincos = False
 
+    @staticmethod
+    def _diag(anchors):
+        """length of the anchor's BEV diagonal, (.., 1)"""
+        return torch.sqrt(anchors[..., 3:4] ** 2 + anchors[..., 4:5] ** 2)
+
     def encode_torch(self, boxes, anchors):
-        # the reference clamps in place (:22-23); kept out-of-place here (same values)
-        anchors = torch.cat([anchors[:, :3], torch.clamp_min(anchors[:, 3:6], 1e-5), anchors[:, 6:]], -1)
-        boxes = torch.cat([boxes[:, :3], torch.clamp_min(boxes[:, 3:6], 1e-5), boxes[:, 6:]], -1)
-        xa, ya, za, dxa, dya, dza, ra, *cas = torch.split(anchors, 1, dim=-1)
-        xg, yg, zg, dxg, dyg, dzg, rg, *cgs = torch.split(boxes, 1, dim=-1)
-        diagonal = torch.sqrt(dxa ** 2 + dya ** 2)
-        xt = (xg - xa) / diagonal
-        yt = (yg - ya) / diagonal
-        zt = (zg - za) / dza
-        dxt = torch.log(dxg / dxa)
-        dyt = torch.log(dyg / dya)
-        dzt = torch.log(dzg / dza)
-        cts = [g - a for g, a in zip(cgs, cas)]
-        return torch.cat([xt, yt, zt, dxt, dyt, dzt, rg - ra, *cts], dim=-1)
+        """SECOND residuals (box_coder_utils.py:14-47), block-wise: centre offsets over (diag, diag, dz_a), log size
+        ratios, plain differences for the angle and any extra columns.  Sizes are floored at 1e-5 (the reference
+        clamps its inputs in place, :22-23; here the inputs are left alone)."""
+        size_a, size_g = anchors[..., 3:6].clamp_min(1e-5), boxes[..., 3:6].clamp_min(1e-5)
+        diag = torch.sqrt(size_a[..., 0:1] ** 2 + size_a[..., 1:2] ** 2)
+        scale = torch.cat([diag, diag, size_a[..., 2:3]], dim=-1)
+        return torch.cat([(boxes[..., 0:3] - anchors[..., 0:3]) / scale, torch.log(size_g / size_a),
+                          boxes[..., 6:] - anchors[..., 6:]], dim=-1)
 
     def decode_torch(self, box_encodings, anchors):
-        xa, ya, za, dxa, dya, dza, ra, *cas = torch.split(anchors, 1, dim=-1)
-        xt, yt, zt, dxt, dyt, dzt, rt, *cts = torch.split(box_encodings, 1, dim=-1)
-        diagonal = torch.sqrt(dxa ** 2 + dya ** 2)
-        xg = xt * diagonal + xa
-        yg = yt * diagonal + ya
-        zg = zt * dza + za
-        dxg = torch.exp(dxt) * dxa
-        dyg = torch.exp(dyt) * dya
-        dzg = torch.exp(dzt) * dza
-        cgs = [t + a for t, a in zip(cts, cas)]
-        return torch.cat([xg, yg, zg, dxg, dyg, dzg, rt + ra, *cgs], dim=-1)
+        """inverse of encode_torch (box_coder_utils.py:49-77): no flooring here, as in the reference"""
+        size_a = anchors[..., 3:6]
+        diag = self._diag(anchors)
+        scale = torch.cat([diag, diag, size_a[..., 2:3]], dim=-1)
+        return torch.cat([box_encodings[..., 0:3] * scale + anchors[..., 0:3], torch.exp(box_encodings[..., 3:6]) * size_a,
+                          box_encodings[..., 6:] + anchors[..., 6:]], dim=-1)
 
 
 # ---------------------------------------------------------------- loss_utils

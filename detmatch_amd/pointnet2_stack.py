@@ -291,7 +291,10 @@ class TallSkinnyLinear(Function):
         y = TallSkinnyLinear._rowgemm_stats(x, w) if bn_stats else None
         if y is None:
             y = TallSkinnyLinear._rowgemm(x, w)
-        return y if y is not None else x @ w.t()
+        if y is None:
+            with _lib.blas_turn():
+                y = x @ w.t()
+        return y
 
     @staticmethod
     def backward(ctx, gy):
@@ -301,18 +304,20 @@ class TallSkinnyLinear(Function):
             d = ctx.dead_cols
             gx = TallSkinnyLinear._rowgemm_dgrad(gy, w, d)
             if gx is None:
-                gx = gy @ w
+                with _lib.blas_turn():
+                    gx = gy @ w
         gw = None
         if ctx.needs_input_grad[1] and TallSkinnyLinear.OWN_WGRAD:
             gw = TallSkinnyLinear._wgrad(gy, x)
         if ctx.needs_input_grad[1] and gw is None:
             rows = x.shape[0]
             split = next((s for s in (256, 128, 64, 32, 16, 8) if rows % s == 0 and rows // s >= 2048), 1)
-            if split > 1:
-                gw = torch.bmm(gy.view(split, rows // split, -1).transpose(1, 2),
-                               x.view(split, rows // split, -1)).sum(dim=0)
-            else:
-                gw = gy.t() @ x
+            with _lib.blas_turn():
+                if split > 1:
+                    gw = torch.bmm(gy.view(split, rows // split, -1).transpose(1, 2),
+                                   x.view(split, rows // split, -1)).sum(dim=0)
+                else:
+                    gw = gy.t() @ x
         return gx, gw, None, None
 
 
@@ -417,7 +422,7 @@ def _shared_mlp_1x1(mlp, x):
             if mod.kernel_size != (1, 1) or mod.stride != (1, 1) or mod.groups != 1:
                 raise ValueError('shared MLPs are 1x1 convolutions')
             b, c, m, ns = x.shape
-            y = torch.matmul(mod.weight.view(mod.out_channels, c), x.reshape(b, c, m * ns))
+            y = _lib.blas_linear(x.reshape(b, c, m * ns).transpose(1, 2), mod.weight.view(mod.out_channels, c)).transpose(1, 2)
             if mod.bias is not None:
                 y = y + mod.bias.view(1, -1, 1)
             x = y.view(b, mod.out_channels, m, ns)

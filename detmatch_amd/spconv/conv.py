@@ -12,6 +12,7 @@ import math
 import torch
 from torch import nn
 
+from .. import _lib
 from . import functional as Fsp
 from . import ops
 from .modules import SparseModule
@@ -88,7 +89,7 @@ class SparseConvolution(SparseModule):
         if not isinstance(input, SparseConvTensor):
             raise TypeError('SparseConvolution expects a SparseConvTensor')
         if self.conv1x1:       # a pointwise layer touches no neighbours: one dense GEMM on the rows
-            rows = input.features @ self.weight.view(self.in_channels, self.out_channels)
+            rows = _lib.blas_linear(input.features, self.weight.view(self.in_channels, self.out_channels).t())
             ids, shape = input.indices, input.spatial_shape
         else:
             ids, pairs, num = self._rulebook(input)

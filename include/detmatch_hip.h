@@ -967,7 +967,8 @@ int dm_roi_decode_backward(const float *grad_boxes, const float *box_encodings, 
  * float / double arguments travel as their bit patterns in the low 32 / all 64 bits).  What varies between
  * calls (arena base addresses, the stream, data-dependent counts) sits in the slot table; the op table is built
  * once per shape signature by the host layer.  dm_chain_run calls the entries in order on the calling thread and
- * stops at the first non-zero return code (*failed_op_host = index of that op, -1 if none).  Same kernels, same
+ * stops at the first non-zero return code (*failed_op_host = index of that op, -1 if none); an op whose `nargs`
+ * differs from its entry's signature length is DM_ERR_INVALID_ARG before anything of it is called.  Same kernels, same
  * order, same arguments as the op-by-op path — results are bit-identical to it.
  *   dm_chain_fn_index      index of an entry point by name (-1: not launchable through a chain)
  *   dm_chain_fn_signature  its argument classes, one letter each: p pointer, i int, l long long, z size_t,

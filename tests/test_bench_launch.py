@@ -61,3 +61,33 @@ def test_watchdog_kills_a_child_without_progress_and_retries_in_one_lane():
         assert msg in r.stderr and '(attempt 1): killed' in r.stderr, r.stderr[-1500:]
         assert 'needs a GPU' in r.stderr and r.returncode != 0, (r.returncode, r.stderr[-1500:])
         assert '(attempt 2)' not in r.stderr
+
+
+def test_watchdog_parent_forwards_termination_to_its_child():
+    """`timeout N python bench.py` (SIGTERM to the parent) must not orphan the measuring child."""
+    import signal
+    import time
+    import psutil
+    env = dict(os.environ, DM_BENCH_FAKE_HANG='1')         # the child sleeps without ever beating
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'DM_TWO_LANES', 'DM_BENCH_DRYRUN', 'DM_BENCH_CHILD',
+              'DM_BENCH_WATCHDOG_FIRST_S'):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'],
+                         env=env, stderr=subprocess.PIPE, text=True)
+    try:
+        kids = []
+        for _ in range(200):
+            time.sleep(0.1)
+            kids = psutil.Process(p.pid).children(recursive=True)
+            if kids:
+                break
+        assert kids, 'the watchdog parent started no child'
+        p.send_signal(signal.SIGTERM)
+        rc = p.wait(timeout=30)
+        err = p.stderr.read()
+        assert rc == 128 + signal.SIGTERM and 'measuring child killed' in err, (rc, err[-500:])
+        gone, alive = psutil.wait_procs(kids, timeout=10)
+        assert not alive
+    finally:
+        if p.poll() is None:
+            p.kill()

@@ -1,0 +1,65 @@
+"""The one-vendor-GEMM-at-a-time rule on the GPU (two hipBLASLt Stream-K kernels of one process in flight
+at the same time dead-lock the device).  (1) The token orders GEMMs of different streams behind each other and the
+results are right.  (2) Census of the REAL iteration in the order that ships (three lanes): every aten GEMM of the
+step — forward, autograd thread included — is issued inside a turn."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+_GEMM_OPS = {'aten::mm', 'aten::addmm', 'aten::bmm', 'aten::baddbmm', 'aten::addbmm', 'aten::_scaled_mm'}
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    return torch.device('cuda', 0)
+
+
+def test_turns_serialise_gemms_across_streams(dev):
+    from detmatch_amd import _lib
+    torch.manual_seed(0)
+    x = [torch.randn(256, 27648, device=dev), torch.randn(200, 27648, device=dev)]
+    w = torch.randn(256, 27648, device=dev) * 0.01
+    ref = [F.linear(a, w) for a in x]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    edges0 = _lib.BLAS_TURNS[1]
+    for r in range(40):
+        ys = []
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                ys.append(_lib.blas_linear(x[i], w))
+        for s in streams:
+            s.synchronize()
+        for y, want in zip(ys, ref):
+            assert torch.allclose(y, want, rtol=1e-4, atol=1e-4)
+    assert _lib.BLAS_TURNS[1] - edges0 >= 79          # every GEMM but the first waited for its predecessor's event
+
+
+def test_every_gemm_of_the_shipped_iteration_is_inside_a_turn(dev, monkeypatch):
+    from torch.profiler import ProfilerActivity, profile
+    from detmatch_amd import _lib
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    monkeypatch.setenv('DM_TWO_LANES', '1')
+    wl = DetMatchTrainWorkload(2, dev)
+    assert wl.model.two_lanes
+    for _ in range(2):
+        wl.step()
+    torch.cuda.synchronize()
+    monkeypatch.setitem(_lib.BLAS_TRACE, 0, True)
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        wl.step()
+        torch.cuda.synchronize()
+    turns, gemms = {}, []
+    for e in prof.events():
+        if e.name == 'dm_blas_turn':
+            turns.setdefault(e.thread, []).append((e.time_range.start, e.time_range.end))
+        elif e.name in _GEMM_OPS:
+            gemms.append(e)
+    assert len(gemms) >= 40 and sum(len(v) for v in turns.values()) >= 40, (len(gemms), len(turns))
+    outside = [(e.name, e.thread, [tuple(s) for s in (e.input_shapes or [])]) for e in gemms
+               if not any(a <= e.time_range.start and e.time_range.end <= b for a, b in turns.get(e.thread, []))]
+    assert not outside, 'vendor GEMMs issued outside _lib.blas_turn(): %s' % outside[:8]

@@ -61,3 +61,64 @@ def test_float_bits():
     from detmatch_amd import chain
     assert chain.f32_bits(1.0) == 0x3f800000 and chain.f32_bits(-2.0) == 0xc0000000
     assert chain.f64_bits(1.0) == 0x3ff0000000000000
+
+
+def test_derived_weights_go_stale_when_any_watched_tensor_is_rewritten():
+    """the fused optimizer reports the byte range it rewrote; a chain whose FIRST watched tensor is
+    frozen (outside every such range) must still re-derive its packed weights when a later watched tensor is inside."""
+    import torch
+    from detmatch_amd import dense_chain, dense_conv
+
+    class _Prog(object):
+        runs = 0
+
+        def run(self, slots):
+            _Prog.runs += 1
+
+    arena = torch.zeros(64)
+    frozen, trained = torch.zeros(8), arena[16:32]            # frozen lives elsewhere, trained inside the arena
+    for order in ((frozen, trained), (trained, frozen)):
+        w = dense_chain._Weights(torch.device('cpu'))
+        w.watch += list(order)
+        w.prog = _Prog()
+        _Prog.runs = 0
+        w.refresh()
+        assert _Prog.runs == 1                                # first use derives
+        w.refresh()
+        assert _Prog.runs == 1                                # nothing changed
+        for i in range(5):                                    # five optimizer steps over the arena's bytes
+            dense_conv.weights_changed(arena.data_ptr(), arena.data_ptr() + 4 * arena.numel())
+            w.refresh()
+            assert _Prog.runs == 2 + i, order
+        # a rewrite somewhere else (the teacher's EMA range) leaves this chain alone
+        other = torch.zeros(32)
+        dense_conv.weights_changed(other.data_ptr(), other.data_ptr() + 4 * other.numel())
+        w.refresh()
+        assert _Prog.runs == 6
+        dense_conv.weights_changed()                          # "everything"
+        w.refresh()
+        assert _Prog.runs == 7
+    # the primitive: ranges are half-open, addresses ascending
+    g = dense_conv._GENERATION[0]
+    dense_conv.weights_changed(100, 200)
+    assert dense_conv._stale_any(g, [50, 150, 300]) and dense_conv._stale_any(g, [100])
+    assert not dense_conv._stale_any(g, [50, 200, 300]) and not dense_conv._stale_any(g, [])
+    assert not dense_conv._stale_any(dense_conv._GENERATION[0], [150])
+
+
+def test_chain_run_rejects_an_op_with_the_wrong_argument_count():
+    """The C-ABI is public: a hand-built table whose nargs is shorter than the entry's signature must not reach the
+    trampoline (it would read stale stack values as pointers)."""
+    from detmatch_amd import _lib, chain
+    L = _lib.lib()
+    idx, sig = chain._entry('dm_fill_bytes')
+    ops = (chain.ChainOp * 2)()
+    for o in ops:
+        o.fn, o.nargs = idx, len(sig)
+        for k in range(len(sig)):
+            o.slot[k], o.imm[k] = -1, 0                 # dst NULL, 0 bytes: DM_OK without a launch
+    failed = ctypes.c_int(-5)
+    assert L.dm_chain_run(ops, 2, None, 0, ctypes.byref(failed)) == 0 and failed.value == -1
+    ops[1].nargs = len(sig) - 1
+    rc = L.dm_chain_run(ops, 2, None, 0, ctypes.byref(failed))
+    assert rc != 0 and failed.value == 1
