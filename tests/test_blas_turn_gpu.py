@@ -49,10 +49,13 @@ def test_every_gemm_of_the_shipped_iteration_is_inside_a_turn(dev, monkeypatch):
     for _ in range(2):
         wl.step()
     torch.cuda.synchronize()
-    monkeypatch.setitem(_lib.BLAS_TRACE, 0, True)
-    with profile(activities=[ProfilerActivity.CPU]) as prof:
-        wl.step()
-        torch.cuda.synchronize()
+    _lib.BLAS_TRACE[0] = True
+    try:
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            wl.step()
+            torch.cuda.synchronize()
+    finally:
+        _lib.BLAS_TRACE[0] = False
     turns, gemms = {}, []
     for e in prof.events():
         if e.name == 'dm_blas_turn':
