@@ -1,23 +1,16 @@
 """DetMatch training step, MI355X-native."""
 import os as _os
-import sys as _sys
 
 # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The iteration uses the
 # default stream, two stream lanes (mm3d/ssl.py:_Lanes) and one side stream (_lib.aux_stream) — plus RCCL's stream under
-# data parallelism: six queues give every stream its own.  Round 5 met an intermittent device dead-lock with streams
-# SHARING a hardware queue (every queue waiting, no kernel running); the first same-box A/B showed none with 5 or 6
-# queues, later boxes did while the geometry look-ahead still added streams — so this setting is a precaution, not the
-# cure (DESIGN.md 6.R5 has the bisection; 8 queues cost 107 instead of 70 ms per iteration).  The variable is read when
-# the runtime initialises, so it is set here, at import — and the lanes are only the default when that was in time.
-HW_QUEUES_OK = True
-if 'GPU_MAX_HW_QUEUES' in _os.environ:
-    try:
-        HW_QUEUES_OK = int(_os.environ['GPU_MAX_HW_QUEUES']) >= 5
-    except ValueError:
-        HW_QUEUES_OK = False
-else:
-    _t = _sys.modules.get('torch')
-    if _t is not None and _t.cuda.is_initialized():
-        HW_QUEUES_OK = False          # too late: the runtime is up with its default
-    else:
-        _os.environ['GPU_MAX_HW_QUEUES'] = '6'
+# data parallelism; streams that share a hardware queue execute one behind the other, so the ENTRY POINTS
+# (bench.py, __graft_entry__.py, tests/conftest.py, tools/) ask for six queues before the runtime comes up.  The package
+# itself only reads the setting (importing a library must not rewrite the environment of its host process): with fewer
+# queues than streams the lanes still give the same results, only less overlap.  (Round 5 suspected the queue count
+# behind an intermittent dead-lock of the lanes; the cause was two vendor Stream-K GEMMs in flight at once —
+# DESIGN.md 6.R6 — and is handled in _lib.blas_turn, whatever the queue count.)
+try:
+    HW_QUEUES = int(_os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+except ValueError:
+    HW_QUEUES = 4
+HW_QUEUES_OK = HW_QUEUES >= 5

@@ -271,7 +271,7 @@ def floats(v):
 # finish a partial tile publish it through flags in a workspace of the library handle and the owner of the tile spins in
 # `label_SK_Fixup` until they arrive.  Two such kernels in flight at the same time from one handle — two HIP streams of
 # one host thread — use the SAME flags: every recorded "three-lane device dead-lock" of round 5 was one of them (the
-# RoI head's 27 648 -> 256 FC) spinning for ever with the device 100 % busy (profiles/r06_deadlock_*.txt;
+# RoI head's 27 648 -> 256 FC) spinning for ever with the device 100 % busy (profiles/r06_deadlock/, profiles/r06_lane_soak.txt;
 # tools/streamk_two_streams_repro.py reproduces it with nothing but torch).  Rule of this package: a vendor GEMM is only
 # issued inside `blas_turn()`, which orders it behind the previous vendor GEMM of the process with an event edge when that
 # one went to another stream — in stream order nothing changes, across streams no two of them ever overlap.

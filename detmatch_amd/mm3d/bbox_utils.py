@@ -361,6 +361,59 @@ def filter_by_nms_2d(bbox_list, nms_cfg, use_sigmoid_cls, return_indices=False):
     return res
 
 
+def filter_by_nms_2d_masked(entries, nms_cfg, use_sigmoid_cls):
+    """filter_by_nms_2d without a single device->host read: entries = [((boxes (n, 4), scores (n, C[+1])), keep | None)],
+    `keep` an optional bool mask over the n rows (rows a filter in front rejected).  -> [((boxes (K, 4), scores (K, .)),
+    valid (K,) bool)] with K = min(max_num, n * C) FIXED rows of which the first valid.sum() are, in order, exactly the
+    rows filter_by_nms_2d returns on the compacted list:
+      * the score threshold and `keep` do not select candidates, they push them behind every valid candidate in the
+        score order (stable sort of the same keys: valid candidates keep their relative order), where the greedy pass
+        can neither let them suppress a valid box nor keep one of them before the last valid survivor;
+      * the class offset of batched_nms is (max coordinate over the VALID candidates + 1), as on the compacted list;
+      * the greedy pass stops after max_num survivors (== dets[:max_num] of modified_multiclass_nms).
+    Needs nms_pre <= 0 (the configs' value) and max_num > 0."""
+    res = []
+    L = _lib.lib()
+    thr = float(nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr', 0.5)))
+    score_thr = nms_cfg.get('score_thr', None)
+    score_thr = 0 if score_thr is None else score_thr
+    max_num = int(nms_cfg.get('max_num', -1))
+    assert nms_cfg.get('nms_pre', -1) <= 0
+    for (bboxes, scores), keep_in in entries:
+        assert bboxes.shape[0] == scores.shape[0] and scores.dim() == 2
+        n = bboxes.shape[0]
+        c = scores.shape[1] if use_sigmoid_cls else scores.shape[1] - 1
+        assert bboxes.shape[1] in (4, 4 * c)          # class-agnostic or one box per class (modified_multiclass_nms :35-39)
+        if n == 0 or c == 0:
+            res.append(((bboxes, scores), None))
+            continue
+        dev = bboxes.device
+        flat_s = scores[:, :c].reshape(-1)                              # candidate (box, class) = box * c + class
+        valid = flat_s > score_thr
+        if keep_in is not None:
+            valid = valid & keep_in[:, None].expand(n, c).reshape(-1)
+        flat_b = bboxes.view(n, c, 4).reshape(-1, 4) if bboxes.shape[1] > 4 else bboxes[:, None, :].expand(n, c, 4).reshape(-1, 4)
+        labels = torch.arange(c, device=dev, dtype=bboxes.dtype).repeat(n)
+        neg = torch.full_like(flat_s, float('-inf'))
+        max_coord = torch.where(valid[:, None], flat_b, neg[:, None]).max()
+        key = torch.where(valid, flat_s, neg)
+        order = torch.sort(key, descending=True, stable=True)[1]
+        sorted_boxes = (flat_b + (labels * (max_coord + 1))[:, None])[order].contiguous().float()
+        m = n * c
+        k_rows = min(max_num, m) if max_num > 0 else m
+        keep = torch.empty((m,), dtype=torch.int64, device=dev)
+        num = torch.zeros((1,), dtype=torch.int32, device=dev)
+        ws = _lib.workspace(L.dm_nms_workspace_bytes(m), dev, 'nms')
+        _lib.check(L.dm_nms_2d(_lib.ptr(sorted_boxes), m, thr, k_rows if max_num > 0 else 0, _lib.ptr(keep), _lib.ptr(num),
+                               _lib.ptr(ws), ws.numel(), _lib.stream()), 'dm_nms_2d')
+        slot = torch.arange(k_rows, device=dev)
+        pos = torch.where(slot < num, keep[:k_rows], torch.zeros_like(slot))     # positions in the score order
+        ok = (slot < num) & (pos < valid.sum())                                  # (valid candidates come first in it)
+        cand = order.index_select(0, pos)
+        res.append(((take(flat_b, cand), take(scores, cand // c)), ok))
+    return res
+
+
 # ------------------------------------------------------------------ 3D multi-class NMS
 def xywhr2xyxyr(boxes_xywhr):
     """mmdet3d/core/bbox/structures/utils.py:62-82: BEV (cx, cy, w, h, r) -> (x1, y1, x2, y2, r)."""

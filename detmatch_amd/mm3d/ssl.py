@@ -155,6 +155,9 @@ class _Lanes(object):
                 value.record_stream(stream)
         elif hasattr(value, 'tensor') and isinstance(value.tensor, torch.Tensor):
             _Lanes.record(value.tensor, stream)
+        elif hasattr(value, 'full') and hasattr(value, 'keep'):      # ssl_modules.Masked: a lazily filtered entry
+            _Lanes.record(value.full, stream)
+            _Lanes.record(value.keep, stream)
         elif isinstance(value, (list, tuple)):
             for v in value:
                 _Lanes.record(v, stream)
@@ -173,6 +176,8 @@ class _Lanes(object):
         with torch.cuda.stream(self.stream(lane)):
             if self.rng is not None:
                 self.rng.enter(module)
+            if not getattr(module, 'takes_masked', False):
+                compact_masked(batch_dict)
             out = getattr(module, method)(ssl_obj, batch_dict)
             ev = torch.cuda.Event()
             ev.record(self.stream(lane))
@@ -191,6 +196,19 @@ class _Lanes(object):
                 self.main.wait_stream(s)
         for v in values:
             self.record(v, self.main)
+
+
+def compact_masked(d):
+    """Box lists as the reference's modules hand them to each other: every lazily filtered entry (ssl_modules.Masked)
+    of the (nested) batch dict compacted in place.  Run in front of a module that does not declare `takes_masked` — a
+    user's own SSL module sees plain (boxes, scores) tuples, whatever the built-in filters did before it."""
+    for k in list(d.keys()):
+        v = dict.__getitem__(d, k)             # (a look, not a read: no lane dependency for entries that hold no mask)
+        if isinstance(v, dict):
+            compact_masked(v)
+        elif isinstance(v, list) and any(hasattr(e, 'full') and hasattr(e, 'keep') for e in v):
+            v = d[k]                           # a read on this lane: waits for the producer's event
+            d[k] = [e.entry() if (hasattr(e, 'full') and hasattr(e, 'keep')) else e for e in v]
 
 
 class _Arena(object):
@@ -678,6 +696,8 @@ class SSL(nn.Module):
 
         def run_serial(m, d):
             rng.enter(m)
+            if not getattr(m, 'takes_masked', False):
+                compact_masked(d)
             return m.forward(self, d)
 
         run = (lambda m, d: lanes.run(m, self, d)) if lanes is not None else run_serial
@@ -707,9 +727,11 @@ class SSL(nn.Module):
                     m.prefetch(self, d)
         if jobs:
             # the passes' size read-backs (voxel count, N_out of the four strided rulebooks) in lockstep:
-            # one device->host copy per round for all of them
+            # one device->host copy per round for all of them; their key-point FPS as ONE launch behind the rulebooks
+            from ..pcdet.pfe import FpsBatch
             from ..spconv.ops import drive_steps_together
-            drive_steps_together(jobs)
+            with FpsBatch():
+                drive_steps_together(jobs)
         if not branches_first:
             if lanes is not None:
                 lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .bbox_utils import (apply_3d_transformation_bboxes, bbox_2d_transform, bbox_3d_to_bbox_2d,
-                         filter_by_nms_2d, mlvl_get, mlvl_getattr, mlvl_set, take, unaug_project_boxes)
+                         filter_by_nms_2d, filter_by_nms_2d_masked, mlvl_get, mlvl_getattr, mlvl_set, take, unaug_project_boxes)
 from ..devconst import const
 from ..fused import on as fused_on
 from .box3d import LiDARInstance3DBoxes
@@ -30,6 +30,39 @@ def _split(entry):
 
 def _join(boxes, rest, was_tuple):
     return (boxes,) + tuple(rest) if was_tuple else boxes
+
+
+class Masked(object):
+    """One sample's box-list entry — (boxes, scores, *extras) or bare boxes — whose rows count only where `keep` (a device
+    bool per row) says so: the output of a FILTER that has not been compacted.  Compaction (`nonzero` -> data-dependent
+    shape) is what makes the host wait for the device in the pseudo-label glue (the reference pays it per module and per
+    sample: processors_fusion.py:29-46, bbox_utils.py:286-347, processors_3d.py:140-150); the modules between a filter
+    and the Hungarian matching only map rows (augmentation replay) or filter again, and the matching reads its cost
+    matrix back to the host anyway — so the masks ride along and are resolved THERE, in the same read-back.
+    `entry()` compacts (one synchronising nonzero), for consumers that need true lengths."""
+    __slots__ = ('full', 'keep', '_entry')
+
+    def __init__(self, full, keep):
+        self.full, self.keep, self._entry = full, keep, None
+
+    def entry(self):
+        if self._entry is None:
+            ki = self.keep.nonzero(as_tuple=False).squeeze(1)
+            boxes, rest, tup = _split(self.full)
+            self._entry = _join(take(boxes, ki), [take(t, ki) for t in rest], tup)
+        return self._entry
+
+
+def plain(entries):
+    """A box list with every lazily filtered entry compacted (what the reference's modules hand each other)."""
+    if entries is None:
+        return None
+    return [e.entry() if isinstance(e, Masked) else e for e in entries]
+
+
+def _lazy(t):
+    """Filters stay lazy on the MI355X only (host tensors: compact at once, as the reference does)."""
+    return fused_on() and isinstance(t, torch.Tensor) and t.is_cuda
 
 
 def _lap_host(cost_host):
@@ -59,12 +92,20 @@ def _pred_dicts_to_tuples(pred_dicts):
     return res
 
 
-def _threshold_pseudo(entries, score_thr, includes_bg, empty_boxes):
+def _threshold_pseudo(entries, score_thr, includes_bg, empty_boxes, dense=False):
     """Hard pseudo labels: boxes whose max foreground score exceeds score_thr, label = argmax
     (consumers/openpcdet.py:139-158, consumers_2d.py:84-103).  Boolean indexing is the one
-    place the teacher path produces data-dependent shapes."""
+    place the teacher path produces data-dependent shapes.
+    dense=True (a consumer that takes padded ground truth: OpenPCDetDetector.add_gt turns rows whose label is out of
+    range into padding and moves them behind the valid rows, in order): boxes are NOT selected, rejected rows get the
+    label -1 — the same ground truth without the two synchronising selections per sample."""
     labels, boxes = [], []
-    for cur_boxes, cur_scores in entries:
+    for cur_boxes, cur_scores in plain(entries):
+        if dense and len(cur_scores) and _lazy(cur_scores):
+            top, lab = _fg_scores(cur_scores, includes_bg).max(dim=1)
+            labels.append(torch.where(top > score_thr, lab, torch.full_like(lab, -1)))
+            boxes.append(cur_boxes)
+            continue
         if len(cur_scores) == 0:
             labels.append(cur_scores.new_zeros((0,), dtype=torch.long))
             boxes.append(empty_boxes(cur_scores))
@@ -89,6 +130,7 @@ class _Early(object):
 class Opd_SimpleTest_3D(object):
     """consumers/openpcdet.py:15-95: run the detector in its CURRENT mode on [key]['points']
     and store un-thresholded (boxes, sigmoid class scores)."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     # scheduling hints for SSL.forward_train (lane mode 'glue'): reads only the raw batch -> may be
     # issued ahead of the labeled chain; ends with a host read-back (post_processing)
@@ -144,6 +186,7 @@ class Opd_SimpleTest_3D(object):
 class Opd_HardPseudoLabel_3D(object):
     """consumers/openpcdet.py:97-213: threshold teacher boxes into pseudo GT, run the student's
     training forward on them, and optionally keep the student's (no-NMS) boxes."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, score_thr, cls_includes_bg_pred=False, loss_detach_keys=[],
                  ssl_obj_attr='student', target_bboxes_key='tea.placeholder',
@@ -195,7 +238,8 @@ class Opd_HardPseudoLabel_3D(object):
         boxes, labels = _threshold_pseudo(
             mlvl_get(batch_dict, self.target_bboxes_key), self.score_thr,
             self.cls_includes_bg_pred,
-            lambda s: LiDARInstance3DBoxes(s.new_zeros((0, self.box_dim))))
+            lambda s: LiDARInstance3DBoxes(s.new_zeros((0, self.box_dim))),
+            dense=hasattr(detector, 'add_gt'))
         early = cur.pop('_early.trunk3d', None) if isinstance(cur, dict) else None
         if early is not None:
             batch = detector.add_gt(early.value, cur['points'], boxes, labels)
@@ -214,6 +258,7 @@ class Opd_HardPseudoLabel_3D(object):
 @SSL_MODULES.register_module()
 class Opd_Supervised_3D(object):
     """consumers/openpcdet.py:215-253"""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     # forward() adds losses and nothing else: no later module reads tensors of this pass's autograd
     # graph, so SSL.forward_train may back-propagate these losses as soon as they exist
@@ -260,9 +305,13 @@ class _MapBoxes(object):
         metas = mlvl_get(batch_dict, self.img_metas)
         out = []
         for entry, meta in zip(mlvl_get(batch_dict, self.in_bboxes_key), metas):
+            keep = None
+            if isinstance(entry, Masked):            # a row map: filtered-out rows are mapped too and stay filtered out
+                entry, keep = entry.full, entry.keep
             boxes, rest, tup = _split(entry)
             assert tup or isinstance(boxes, torch.Tensor)
-            out.append(_join(self._map(boxes, meta), rest, tup))
+            mapped = _join(self._map(boxes, meta), rest, tup)
+            out.append(mapped if keep is None else Masked(mapped, keep))
         mlvl_set(batch_dict, self.out_bboxes_key, out)
         return batch_dict
 
@@ -271,6 +320,7 @@ class _MapBoxes(object):
 class BboxesTransform_3D(_MapBoxes):
     """processors_3d.py:12-56: apply (reverse=False) or undo (reverse=True) the 3D augmentations
     recorded in img_metas (flip / rot / scale / trans, in transformation_3d_flow order)."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, reverse, img_metas, in_bboxes_key, out_bboxes_key):
         self.reverse, self.img_metas = reverse, img_metas
@@ -284,6 +334,7 @@ class BboxesTransform_3D(_MapBoxes):
 class BboxesTransform_2D(_MapBoxes):
     """processors_2d.py:128-187: 'forward' (reverse=False) maps original-image boxes into the
     augmented image (ori2new), reverse maps back."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, reverse, img_metas, in_bboxes_key, out_bboxes_key):
         self.reverse, self.img_metas = reverse, img_metas
@@ -297,12 +348,14 @@ class BboxesTransform_2D(_MapBoxes):
 @SSL_MODULES.register_module()
 class DetachBboxes(object):
     """processors_3d.py:59-78"""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, in_bboxes_key, out_bboxes_key):
         self.in_bboxes_key, self.out_bboxes_key = in_bboxes_key, out_bboxes_key
 
     def forward(self, ssl_obj, batch_dict):
-        out = [tuple(t.detach() for t in entry) for entry in mlvl_get(batch_dict, self.in_bboxes_key)]
+        out = [Masked(tuple(t.detach() for t in entry.full), entry.keep) if isinstance(entry, Masked)
+               else tuple(t.detach() for t in entry) for entry in mlvl_get(batch_dict, self.in_bboxes_key)]
         mlvl_set(batch_dict, self.out_bboxes_key, out)
         return batch_dict
 
@@ -311,6 +364,7 @@ class DetachBboxes(object):
 class Bboxes3DTo2D(object):
     """processors_3d.py:81-155: undo the 3D augs, project the 8 corners with lidar2img, take the
     clipped min/max box; optionally drop boxes that are invalid (behind the camera / empty)."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, img_metas='stu.img_metas', in_bboxes_key='stu.3d_bboxes_nms',
                  out_bboxes_key='stu.3d_bboxes_nms_2d_proj', filter_invalid=True):
@@ -321,13 +375,16 @@ class Bboxes3DTo2D(object):
     def forward(self, ssl_obj, batch_dict):
         metas = mlvl_get(batch_dict, self.img_metas)
         out = []
-        for entry, meta in zip(mlvl_get(batch_dict, self.in_bboxes_key), metas):
+        for entry, meta in zip(plain(mlvl_get(batch_dict, self.in_bboxes_key)), metas):
             boxes3d, rest, tup = _split(entry)
             if fused_on() and boxes3d.tensor.is_cuda and boxes3d.tensor.shape[1] == 7 and len(boxes3d.tensor):
                 boxes2d, valid = unaug_project_boxes(boxes3d, meta)       # two launches, fwd + bwd
             else:
                 boxes3d = apply_3d_transformation_bboxes(boxes3d, meta, reverse=True)
                 boxes2d, valid = bbox_3d_to_bbox_2d(boxes3d, meta['lidar2img'], meta['ori_shape'])
+            if self.filter_invalid and _lazy(boxes2d) and len(boxes2d):
+                out.append(Masked(_join(boxes2d, rest, tup), valid))       # resolved by the consumer (NMS / matching)
+                continue
             if self.filter_invalid:
                 vi = valid.nonzero(as_tuple=False).squeeze(1)      # one mask -> index conversion
                 boxes2d, rest = take(boxes2d, vi), [take(t, vi) for t in rest]
@@ -339,6 +396,7 @@ class Bboxes3DTo2D(object):
 @SSL_MODULES.register_module()
 class MaxScoreFilter(object):
     """processors_fusion.py:9-47"""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, cls_includes_bg_pred, score_thr, in_bboxes_key, out_bboxes_key):
         self.cls_includes_bg_pred = cls_includes_bg_pred
@@ -348,11 +406,19 @@ class MaxScoreFilter(object):
     def forward(self, ssl_obj, batch_dict):
         out = []
         for entry in mlvl_get(batch_dict, self.in_bboxes_key):
+            before = None
+            if isinstance(entry, Masked):
+                entry, before = entry.full, entry.keep
             scores = _fg_scores(entry[1], self.cls_includes_bg_pred)
             if len(scores) == 0:
                 keep = torch.zeros((0,), dtype=torch.bool, device=scores.device)
             else:
                 keep = scores.max(dim=1)[0] > self.score_thr
+            if before is not None:
+                keep = keep & before
+            if _lazy(scores) and len(scores):
+                out.append(Masked(tuple(entry), keep))
+                continue
             ki = keep.nonzero(as_tuple=False).squeeze(1)
             out.append(tuple(take(t, ki) for t in entry))
         mlvl_set(batch_dict, self.out_bboxes_key, out)
@@ -364,6 +430,7 @@ class FusionHungarianMatching(object):
     """processors_fusion.py:50-222: one-to-one match projected 3D boxes ('predictions') with 2D
     boxes ('GT') by cls + L1 + GIoU cost; matches dearer than cost_thr are dropped; outputs are
     index-aligned tuples.  Both score sets must be sigmoid probabilities."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, assigner_cfg, cost_thr, img_metas, cls_includes_bg_pred_3d,
                  cls_includes_bg_pred_2d, in_bboxes_3d_key, in_bboxes_2d_key, out_bboxes_3d_key,
@@ -450,15 +517,113 @@ class FusionHungarianMatching(object):
         idx3 = matched.nonzero(as_tuple=True)[0]
         return idx3, gt_inds[idx3] - 1, res.max_overlaps[idx3]
 
+    def _device_batch(self, e3s, e2s, metas, cfg):
+        """All samples of the batch with ONE device->host copy: per sample one launch builds the whole cost matrix over
+        the UNFILTERED rows (dm_fusion_match_cost), the matrices and the rows' filter masks come back together, the
+        host solves each LAP on the rows / columns its masks keep (the cost of a pair does not depend on the other
+        rows, so this is the matrix the compacted lists would give), applies the cost threshold, and one upload
+        carries every matched index pair.  -> [(idx3, idx2, cost)] per sample, indices into the unfiltered rows."""
+        from .. import _lib
+        L = _lib.lib()
+        w_cls, w_reg, w_iou, alpha, feps = cfg
+        parts, shapes = [], []
+        for e3, e2, meta in zip(e3s, e2s, metas):
+            k3 = k2 = None
+            if isinstance(e3, Masked):
+                e3, k3 = e3.full, e3.keep
+            if isinstance(e2, Masked):
+                e2, k2 = e2.full, e2.keep
+            s3 = _fg_scores(e3[1], self.cls_includes_bg_pred_3d).detach().float().contiguous()
+            s2 = _fg_scores(e2[1], self.cls_includes_bg_pred_2d).detach().float().contiguous()
+            boxes2d = e2[0].detach().float().contiguous()
+            n3, n2, c = int(s3.shape[0]), int(s2.shape[0]), int(s3.shape[1])
+            shapes.append((n3, n2, k3 is not None, k2 is not None))
+            if n3 == 0 or n2 == 0:
+                continue
+            img_h, img_w, _ = meta['ori_shape']
+            b3 = proj = m16 = None
+            if self.project_3d_to_2d:
+                b3 = e3[0].tensor.detach().float().contiguous()
+                m16 = _lib.floats(np.asarray(meta['lidar2img'].cpu() if torch.is_tensor(meta['lidar2img'])
+                                             else meta['lidar2img'], np.float32).reshape(-1))
+            else:
+                proj = e3[0].detach().float().contiguous()
+            cost = torch.empty((n3, n2), dtype=torch.float32, device=boxes2d.device)
+            _lib.check(L.dm_fusion_match_cost(
+                _lib.ptr(b3), _lib.ptr(proj), _lib.ptr(s3), n3, _lib.ptr(boxes2d), _lib.ptr(s2), n2, c, m16,
+                float(img_w), float(img_h), w_cls, w_reg, w_iou, alpha, feps, 1e-6, _lib.ptr(cost), None,
+                _lib.stream()), 'dm_fusion_match_cost')
+            parts.append(cost.view(-1))
+            if k3 is not None:
+                parts.append(k3.float())
+            if k2 is not None:
+                parts.append(k2.float())
+        dev = None
+        for e in list(e3s) + list(e2s):
+            t = (e.full if isinstance(e, Masked) else e)[1]
+            dev = t.device
+            break
+        host = torch.cat(parts).cpu().numpy() if parts else np.zeros((0,), np.float32)   # THE read-back of the module
+        pos, found = 0, []
+        for n3, n2, has3, has2 in shapes:
+            if n3 == 0 or n2 == 0:
+                found.append((np.zeros((0,), np.int64),) * 2 + (np.zeros((0,), np.float32),))
+                continue
+            cm = host[pos:pos + n3 * n2].reshape(n3, n2)
+            pos += n3 * n2
+            r = np.arange(n3)
+            if has3:
+                r = np.nonzero(host[pos:pos + n3] > 0.5)[0]
+                pos += n3
+            cc = np.arange(n2)
+            if has2:
+                cc = np.nonzero(host[pos:pos + n2] > 0.5)[0]
+                pos += n2
+            if len(r) == 0 or len(cc) == 0:
+                found.append((np.zeros((0,), np.int64),) * 2 + (np.zeros((0,), np.float32),))
+                continue
+            sub = np.ascontiguousarray(cm[np.ix_(r, cc)])
+            rows, cols = _lap_host(sub)
+            val = sub[rows, cols]
+            keep = np.ones(len(rows), bool) if self.cost_thr is None else ~(val > self.cost_thr)
+            found.append((r[rows[keep]].astype(np.int64), cc[cols[keep]].astype(np.int64), val[keep].astype(np.float32)))
+        # one upload for all samples: [idx3 | idx2] of every sample as int64, the matched costs as float32
+        flat_i = np.concatenate([np.concatenate([a, b]) for a, b, _ in found]) if found else np.zeros((0,), np.int64)
+        flat_c = np.concatenate([c for _, _, c in found]) if found else np.zeros((0,), np.float32)
+        di = torch.from_numpy(flat_i).to(dev, non_blocking=True)
+        dc = torch.from_numpy(flat_c).to(dev, non_blocking=True)
+        out, pi, pc = [], 0, 0
+        for a, b, c in found:
+            k = len(a)
+            out.append((di[pi:pi + k], di[pi + k:pi + 2 * k], dc[pc:pc + k]))
+            pi += 2 * k
+            pc += k
+        return out
+
     def forward(self, ssl_obj, batch_dict):
         metas = mlvl_get(batch_dict, self.img_metas)
+        e3s, e2s = mlvl_get(batch_dict, self.in_bboxes_3d_key), mlvl_get(batch_dict, self.in_bboxes_2d_key)
         out3, out2, costs = [], [], []
-        for e3, e2, meta in zip(mlvl_get(batch_dict, self.in_bboxes_3d_key),
-                                mlvl_get(batch_dict, self.in_bboxes_2d_key), metas):
-            i3, i2, c = self.match(e3, e2, meta)
-            out3.append(tuple(take(t, i3) for t in e3))
-            out2.append(tuple(take(t, i2) for t in e2))
-            costs.append(c)
+        cfg = self._device_costs() if fused_on() else None
+
+        def ok(e3, e2):
+            a = (e3.full if isinstance(e3, Masked) else e3)[1]
+            b = (e2.full if isinstance(e2, Masked) else e2)[1]
+            return a.is_cuda and len(a) <= 512 and len(b) <= 512 and a.dim() == 2 and \
+                _fg_scores(a, self.cls_includes_bg_pred_3d).shape[1] <= 8
+        if cfg is not None and len(e3s) and all(ok(a, b) for a, b in zip(e3s, e2s)):
+            for (i3, i2, c), e3, e2 in zip(self._device_batch(e3s, e2s, metas, cfg), e3s, e2s):
+                e3 = e3.full if isinstance(e3, Masked) else e3
+                e2 = e2.full if isinstance(e2, Masked) else e2
+                out3.append(tuple(take(t, i3) for t in e3))
+                out2.append(tuple(take(t, i2) for t in e2))
+                costs.append(c)
+        else:
+            for e3, e2, meta in zip(plain(e3s), plain(e2s), metas):
+                i3, i2, c = self.match(e3, e2, meta)
+                out3.append(tuple(take(t, i3) for t in e3))
+                out2.append(tuple(take(t, i2) for t in e2))
+                costs.append(c)
         mlvl_set(batch_dict, self.out_bboxes_3d_key, out3)
         mlvl_set(batch_dict, self.out_bboxes_2d_key, out2)
         if self.match_cost_key is not None:
@@ -471,6 +636,7 @@ class FusionHungarianMatching(object):
 class SimpleTest_2D(object):
     """processors_2d.py:11-86: Faster R-CNN test path up to (not including) NMS:
     (decoded boxes N x 4, softmax/sigmoid scores N x (C+1)), in the augmented image frame."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     hoistable = True          # reads only the raw batch (see Opd_SimpleTest_3D)
     early_before_geometry = True      # ... and no 3D geometry: SSL issues it while the geometry's read-backs are pending
@@ -497,6 +663,7 @@ class SimpleTest_2D(object):
 @SSL_MODULES.register_module()
 class BboxesNMS_2D(object):
     """processors_2d.py:89-125: per-class NMS that carries the FULL score vector of each kept box."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, nms_cfg, cls_includes_bg_pred, batch_dict_key='stu',
                  in_bboxes_key='3d_bboxes_nms_2d_proj',
@@ -508,14 +675,23 @@ class BboxesNMS_2D(object):
 
     def forward(self, ssl_obj, batch_dict):
         cur = mlvl_get(batch_dict, self.batch_dict_key)
-        cur[self.out_bboxes_key] = filter_by_nms_2d(cur[self.in_bboxes_key], self.nms_cfg,
-                                                    not self.cls_includes_bg_pred)
+        entries = cur[self.in_bboxes_key]
+        first = entries[0].full if entries and isinstance(entries[0], Masked) else (entries[0] if entries else None)
+        if first is not None and _lazy(first[1]) and self.nms_cfg.get('nms_pre', -1) <= 0:
+            # no compaction in front of the NMS (the score threshold and an incoming filter mask become "score below
+            # every valid one"), none behind it: max_num rows + a mask for the consumer (bbox_utils.filter_by_nms_2d_masked)
+            res = filter_by_nms_2d_masked([(e.full, e.keep) if isinstance(e, Masked) else (e, None) for e in entries],
+                                          self.nms_cfg, not self.cls_includes_bg_pred)
+            cur[self.out_bboxes_key] = [r if k is None else Masked(r, k) for r, k in res]
+            return batch_dict
+        cur[self.out_bboxes_key] = filter_by_nms_2d(plain(entries), self.nms_cfg, not self.cls_includes_bg_pred)
         return batch_dict
 
 
 @SSL_MODULES.register_module()
 class AverageBboxes_2D(object):
     """processors_2d.py:190-241: element-wise mean of two index-aligned box lists."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, cls_includes_bg_pred_1, cls_includes_bg_pred_2, in_bboxes_1_key,
                  in_bboxes_2_key, out_bboxes_key, out_score_type='averaged'):
@@ -527,8 +703,8 @@ class AverageBboxes_2D(object):
 
     def forward(self, ssl_obj, batch_dict):
         out = []
-        for e1, e2 in zip(mlvl_get(batch_dict, self.in_bboxes_1_key),
-                          mlvl_get(batch_dict, self.in_bboxes_2_key)):
+        for e1, e2 in zip(plain(mlvl_get(batch_dict, self.in_bboxes_1_key)),
+                          plain(mlvl_get(batch_dict, self.in_bboxes_2_key))):
             boxes = (e1[0] + e2[0]) / 2
             if self.out_score_type == 'averaged':
                 score = (_fg_scores(e1[1], self.cls_includes_bg_pred_1) +
@@ -547,6 +723,7 @@ class AverageBboxes_2D(object):
 @SSL_MODULES.register_module()
 class TwoStageSupervised_2D(object):
     """consumers_2d.py:8-52"""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     # forward() adds losses and nothing else: no later module reads tensors of this pass's autograd
     # graph, so SSL.forward_train may back-propagate these losses as soon as they exist
@@ -571,6 +748,7 @@ class TwoStageSupervised_2D(object):
 @SSL_MODULES.register_module()
 class HardPseudoLabel_2D(object):
     """consumers_2d.py:55-121"""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     # forward() adds losses and nothing else: no later module reads tensors of this pass's autograd
     # graph, so SSL.forward_train may back-propagate these losses as soon as they exist
@@ -645,6 +823,7 @@ class _FusedConsistencyLoss(torch.autograd.Function):
 class HungarianConsistency(object):
     """consumers_3d.py:11-117: box-level 2D<->3D consistency over index-aligned matched lists:
     class loss (MSE on probabilities or focal on logits), L1 on image-normalised boxes, GIoU."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, loss_cls_cfg=None, loss_iou_cfg=None, loss_l1_cfg=None,
                  loss_weights_cfg=dict(), in_bboxes_key='stu.3d_bboxes_nms_2d_proj',
@@ -671,8 +850,8 @@ class HungarianConsistency(object):
                 and self.loss_iou.eps == 1e-6)
 
     def forward(self, ssl_obj, batch_dict):
-        in_list = mlvl_get(batch_dict, self.in_bboxes_key)
-        tgt_list = mlvl_get(batch_dict, self.target_bboxes_key)
+        in_list = plain(mlvl_get(batch_dict, self.in_bboxes_key))
+        tgt_list = plain(mlvl_get(batch_dict, self.target_bboxes_key))
         metas = mlvl_get(batch_dict, self.target_img_metas_key)
         per_sample = dict()
         active = [(n, l) for n, l in (('cls_loss', self.loss_cls), ('l1_loss', self.loss_l1),
@@ -724,12 +903,13 @@ class HungarianConsistency(object):
 @SSL_MODULES.register_module()
 class NumPreds(object):
     """consumers/metrics.py:9-24: mean number of boxes per sample, logged as a metric."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, bboxes_key, out_name):
         self.bboxes_key, self.out_name = bboxes_key, out_name
 
     def forward(self, ssl_obj, batch_dict):
-        entries = mlvl_get(batch_dict, self.bboxes_key)
+        entries = plain(mlvl_get(batch_dict, self.bboxes_key))
         num = sum(e[0].shape[0] if isinstance(e, tuple) else e.shape[0] for e in entries) / len(entries)
         first = entries[0][0] if isinstance(entries[0], tuple) else entries[0]
         batch_dict['ssl_losses']['metrics.' + self.out_name] = torch.full(
@@ -741,6 +921,7 @@ class NumPreds(object):
 class Vis3D(object):
     """consumers/visualize.py: debugging output only — outside the hot path, kept
     as a pass-through so configs that list it still build."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
     def __init__(self, **kwargs):
         self.kwargs = kwargs
@@ -752,3 +933,4 @@ class Vis3D(object):
 @SSL_MODULES.register_module()
 class Vis2D_Kitti(Vis3D):
     """consumers/visualize.py (2D variant, confthr_frcnn recipe): pass-through, as Vis3D."""
+    takes_masked = True       # reads box lists through plain() / handles Masked entries itself

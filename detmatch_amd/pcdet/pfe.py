@@ -96,6 +96,21 @@ class _BevInterpolate(torch.autograd.Function):
         return gim.permute(0, 3, 1, 2), None, None
 
 
+class FpsBatch(object):
+    """with FpsBatch(): <prepare the geometry of several passes>  — their key-point FPS becomes one launch at exit."""
+
+    def __enter__(self):
+        self.outer = VoxelSetAbstraction._collect
+        VoxelSetAbstraction._collect = []
+        return self
+
+    def __exit__(self, *exc):
+        items, VoxelSetAbstraction._collect = VoxelSetAbstraction._collect, self.outer
+        if exc[0] is None and items:
+            VoxelSetAbstraction.flush_fps(items)
+        return False
+
+
 class VoxelSetAbstraction(nn.Module):
 
     def __init__(self, model_cfg, voxel_size, point_cloud_range, num_bev_features=None,
@@ -172,6 +187,7 @@ class VoxelSetAbstraction(nn.Module):
         return torch.cat(keypoints_list, dim=0)
 
     _side_streams = {}
+    _collect = None          # FpsBatch: [(module, batch dict)] of the passes whose FPS is to be ONE launch
 
     def sample_keypoints_async(self, batch_dict):
         """FPS depends only on the raw points, runs 2047 dependent rounds and occupies one CU per
@@ -179,6 +195,9 @@ class VoxelSetAbstraction(nn.Module):
         overlaps voxelisation + the sparse and BEV backbones; forward() joins on the event."""
         pts = batch_dict['points']
         if not pts.is_cuda:
+            return
+        if VoxelSetAbstraction._collect is not None:
+            VoxelSetAbstraction._collect.append((self, batch_dict))
             return
         # a small POOL of side streams, used round-robin: the three passes of a DetMatch iteration
         # (labeled student, teacher, unlabeled student) issue their FPS back to back at the step
@@ -201,6 +220,44 @@ class VoxelSetAbstraction(nn.Module):
             ev = torch.cuda.Event()
             ev.record(side)
         batch_dict['keypoints_async'] = (kp, ev)
+
+    @staticmethod
+    def flush_fps(items):
+        """The key points of SEVERAL passes (labeled student, teacher, unlabeled student of one DetMatch iteration) from
+        ONE launch: FPS is a chain of NUM_KEYPOINTS dependent rounds on one workgroup per sample (3.4 ms for 20 000 ->
+        2048 whatever else the device does), so three launches behind each other on the side stream deliver the last
+        pass's key points after 10 ms, one launch over all six samples after 3.4 — same indices per sample (each
+        workgroup sees its own sample only)."""
+        groups = {}
+        for mod, bd in items:
+            groups.setdefault((bd['points'].device, int(mod.model_cfg.NUM_KEYPOINTS)), []).append((mod, bd))
+        for (dev, num_kp), grp in groups.items():
+            if len(grp) == 1:
+                grp[0][0].sample_keypoints_async(grp[0][1])
+                continue
+            from .. import _lib
+            side = _lib.aux_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                xyz = torch.cat([bd['points'][:, 1:4] for _, bd in grp], dim=0).contiguous()
+                cnt = [int(c) for _, bd in grp for c in bd['points_batch_cnt_host']]
+                idx = pn2.furthest_point_sample_stack(xyz, cnt, num_kp).long()          # (sum of batch sizes, num_kp)
+                row, start, out = 0, 0, []
+                for mod, bd in grp:
+                    kps = []
+                    for n in bd['points_batch_cnt_host']:
+                        n = int(n)
+                        cur = idx[row]
+                        if n < num_kp:       # get_sampled_points: repeat-pad the n distinct picks
+                            cur = cur[:n].repeat(int(num_kp / n) + 1)[:num_kp]
+                        kps.append(xyz[start:start + n][cur].unsqueeze(dim=0))
+                        row += 1
+                        start += n
+                    out.append(torch.cat(kps, dim=0))
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for (mod, bd), kp in zip(grp, out):
+                bd['keypoints_async'] = (kp, ev)
 
     # ---- feature sources ---------------------------------------------------------------------
     def _branch_fns(self, batch_dict, keypoints, new_xyz, new_xyz_batch_cnt):

@@ -259,32 +259,20 @@ class DetMatchTrainWorkload(object):
             # (measured neutral on the step time, -190 launches: on by default) gradients of every early backward pass are folded into the flat arena by batched
             # multi-tensor adds and released, so autograd never accumulates tensor by tensor
             self.model.after_partial_backward = self.ddp.collect
-        # Stream lanes (ssl.py:_Lanes; data-flow edges of the batch dict become event waits).  Default
-        # 'glue': every detector pass stays on the caller's stream, strictly ordered, the teacher's
-        # inference is issued first and only the light pseudo-label glue with its host read-backs runs on
-        # a side stream underneath the supervised passes: -3.5 % step time (121.4 vs 125.9 ms, same box,
-        # alternated), heavy kernels never share the device, so the in-bench duration of the roofline
-        # kernel is unchanged (26.2-26.5 us) and agrees with the rocprofv3 trace.
-        # DM_LANE_MODE=pairs: 'glue' plus every 2D pass issued from inside its 3D partner right after the
-        # sparse backbone (ssl.py:_Lanes.run_pair), so that the 3D pass's long tail of small kernels runs
-        # underneath the 2D convolutions while the sparse convolutions keep the device to themselves
-        # (roofline kernel 26.6-27.3 us): 117.1-122.7 ms over five runs against 116.1-120.8 ms — inside the
-        # box-to-box noise, not the default.
-        # DM_TWO_LANES=1 ('branches': student 3D / 2D detectors / teacher 3D + glue on three streams) is
-        # -11 % (112.3 ms) but OPT-IN: co-scheduled kernels queue for CUs, a HIP-event pair around the
-        # roofline kernel then reads 34 us where the rocprofv3 trace of the same run reads 25 us — the
-        # "in-bench duration agrees with the rocprofv3 summary" contract of bench.py only holds when the
-        # heavy kernels run one at a time.  DM_LANE_MODE=serial: one stream.
-        # Same gradients and losses in all three orders (tests/test_ssl_gpu.py, tools/lane_stress.py).
-        # Round 5: with the static sub-graphs issued as chains (chain.py) the host no longer paces the iteration, and
-        # 'branches' became the default: 3D student / 2D detectors / teacher 3D + glue on three streams — the long
-        # tails of small 3D kernels run underneath the 2D convolutions (70-77 ms against 81-87 ms in 'glue', same box).
-        # The roofline kernel's duration in the bench line is the dispatch's own begin -> end time
-        # (hipExtLaunchKernelGGL events, what rocprofv3 reports), co-scheduled or not.  DM_TWO_LANES=0: 'glue'.
-        # (needs one hardware queue per stream: detmatch_amd/__init__.py sets GPU_MAX_HW_QUEUES when it is imported
-        # before the HIP runtime comes up; otherwise 'glue')
-        import detmatch_amd
-        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '1' if detmatch_amd.HW_QUEUES_OK else '0') == '1'
+        # Stream lanes (ssl.py:_Lanes; data-flow edges of the batch dict become event waits).
+        #   'branches' (DEFAULT, DM_TWO_LANES=1): student 3D / both 2D detectors / teacher 3D + glue on three HIP
+        #       streams, the static sub-graphs issued as chains (chain.py): the long tails of small 3D kernels run
+        #       underneath the 2D convolutions — 64-66 ms per iteration against 82 in 'glue' (round 5, same box).
+        #   'glue' (DM_TWO_LANES=0): every detector pass on the caller's stream, strictly ordered, only the pseudo-label
+        #       glue with its host read-backs on a side stream; DM_LANE_MODE=serial: one stream.
+        # Same gradients and losses in all orders (tests/test_ssl_gpu.py).  The "device dead-lock of the lanes" of
+        # round 5 was a vendor Stream-K GEMM of one lane spinning for ever next to a second one of another lane
+        # (DESIGN.md 6.R6); vendor GEMMs are issued one at a time since (_lib.blas_turn), and the order is the default
+        # at any world size — RCCL's stream included (profiles/r06_lane_soak.txt: 2 000 iterations, one rank, nccl).
+        # In the timed region a HIP-event pair around a kernel of one lane also contains the time the dispatch queues
+        # behind the other lanes' kernels; bench.py therefore takes the roofline kernel's duration from extra steps
+        # issued on one stream.
+        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '1') == '1'
         mode = os.environ.get('DM_LANE_MODE', 'glue')
         self.model.lane_mode = None if (self.model.two_lanes or mode in ('serial', 'none', '0', '')) else mode
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
@@ -293,11 +281,10 @@ class DetMatchTrainWorkload(object):
         self.runner.register_training_hooks(sched['lr_config'], sched['optimizer_config'],
                                             sched['custom_hooks'])
         if self.model.two_lanes and 'DM_LOOKAHEAD' not in os.environ:
-            # Three lanes + the geometry of the NEXT iteration prepared on a side stream while this one still runs
-            # wedged the device about once per 200 iterations (round 5, profiles/r05_lane_hang_ab.txt: every queue
-            # waiting, no kernel running; never with the look-ahead off, with a stream synchronisation per iteration, or
-            # with the geometry on the main stream — 74-77 ms in all three against 70 when it does not hang).  With the
-            # lanes the geometry is prepared at the start of its own iteration instead.
+            # With the lanes the geometry is prepared at the start of its own iteration: the early-issued 2D passes
+            # already fill the gap the look-ahead used to fill, and the look-ahead's extra side-stream work costs
+            # more than it hides (70.0 / 69.8 against 66.5 ms, profiles/r06_lane_soak.txt).  (Round 5 switched it off
+            # because it made the Stream-K dead-lock more frequent; it is safe now, just not faster.)
             self.runner.lookahead = False
         self.runner.call_hook('before_run')
         self.world = 1

@@ -11,13 +11,6 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 _GEMM_OPS = {'aten::mm', 'aten::addmm', 'aten::bmm', 'aten::baddbmm', 'aten::addbmm', 'aten::_scaled_mm'}
 
 
-@pytest.fixture(scope='module')
-def dev():
-    if not torch.cuda.is_available():
-        pytest.skip('needs the MI355X')
-    return torch.device('cuda', 0)
-
-
 def test_turns_serialise_gemms_across_streams(dev):
     from detmatch_amd import _lib
     torch.manual_seed(0)

@@ -3,6 +3,8 @@ the shapes the step really issues, timed as (a) batched split-K BLAS + sum and (
 kernel (dm_tall_wgrad).
     python tools/bench_tall_wgrad.py
 """
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import collections
 import os
 import sys

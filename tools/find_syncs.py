@@ -2,6 +2,8 @@
 
     python tools/find_syncs.py [detmatch|pvrcnn|confthr]
 """
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import collections
 import sys
 import traceback

@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import sys, torch
 sys.path.insert(0, '.')
 from detmatch_amd.pcdet.workload import DetMatchTrainWorkload

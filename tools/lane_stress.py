@@ -4,6 +4,8 @@ dependency shows up as garbage sooner or later).
 
     python tools/lane_stress.py [steps]
 """
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import math
 import os
 import sys

@@ -1,5 +1,7 @@
 """Run-to-run variability of the accumulated gradient after k iterations: serial vs serial, and
 serial vs two-lane execution (a race would show up as a much larger serial-vs-lanes difference)."""
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import sys
 
 import torch

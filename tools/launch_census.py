@@ -4,6 +4,8 @@ the optimizer; prints launches and device time per range (inclusive).
 
     python tools/launch_census.py [detmatch|pvrcnn|confthr] [kernel-name regex: count only those]
 """
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import collections
 import re
 import sys

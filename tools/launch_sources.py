@@ -4,6 +4,8 @@ node (backward thread), with the most frequent kernel of each source.
 
     python tools/launch_sources.py [top]
 """
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import collections
 import os
 import re

@@ -1,4 +1,6 @@
 """Top ATen ops of one training step by device time, grouped by input shapes (torch.profiler)."""
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import sys
 
 import torch

@@ -4,6 +4,8 @@ and everything autograd runs on the calling thread are covered (the device backw
 
     python tools/op_sites.py [top]
 """
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import collections
 import os
 import sys

@@ -5,6 +5,8 @@ means the device was waiting for the host there (host-bound), large means queued
 
     python tools/phase_timeline.py
 """
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
 import os
 import sys
 import time
