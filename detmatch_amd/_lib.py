@@ -42,6 +42,9 @@ SIGNATURES = {
                                     vp, sz, vp]),
     'dm_rulebook_conv_fill': (ci, [vp, ci, ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, ci,
                                    vp, vp, vp, vp, vp, vp, sz, vp]),
+    'dm_rulebook_subm_cap': (ci, [vp, vp, ci, ci, c_int_p, c_int_p, vp, vp, vp, vp, sz, vp]),
+    'dm_rulebook_conv_cap': (ci, [vp, vp, ci, ci, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, ci, vp, vp, vp, vp, vp,
+                                  vp, vp, sz, vp]),
     'dm_rulebook_set_mode': (ci, [ci]),
     'dm_pairs_to_table': (ci, [vp, vp, ci, ci, ci, vp, ci, vp]),
     'dm_spconv_workspace_bytes': (sz, [ci, ci, ci]),
@@ -344,8 +347,49 @@ class _BlasLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+# The raw handle of the MAIN lane of the iteration (mm3d/ssl.py:_Lanes sets it; None: no lanes).  Vendor GEMMs stay on
+# that lane: a turn orders a GEMM behind the previous one wherever that went, and behind the main lane's deep queue (the
+# host issues the student's backward 7-12 ms ahead of the device) a teacher-lane GEMM would wait for ALL of it — the
+# teacher's read-back moved from 27 to 35 ms into the iteration that way (profiles/r06_phase_timeline_token_only.txt).
+# FC layers issued on another lane therefore run on the library's own GEMM (csrc/conv2d.hip on (M, K, 1, 1) views:
+# forward within 0.7-1.3x of the vendor kernels, profiles/r05_fc_blas_vs_own.txt) and no turn ever inserts an edge.
+MAIN_STREAM = [None]
+OWN_LINEAR_CALLS = [0]
+
+
+def off_main_lane():
+    return MAIN_STREAM[0] is not None and torch.cuda.is_available() and raw_stream() != MAIN_STREAM[0]
+
+
+def own_linear(x, w, b=None):
+    """F.linear(x, w, b) on the library's GEMM (differentiable: dense_conv's autograd Function)."""
+    from . import dense_conv
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    m, k = x2.shape
+    n = w.shape[0]
+    OWN_LINEAR_CALLS[0] += 1
+    w4 = w.__dict__.get('_dm_view4') if isinstance(w, torch.nn.Parameter) else None
+    if w4 is None or w4.data_ptr() != w.data_ptr() or w4.shape[:2] != (n, k) or w4.requires_grad != w.requires_grad:
+        with torch.enable_grad():                  # (a view made under no_grad would never carry a gradient)
+            w4 = w.view(n, k, 1, 1)
+        if isinstance(w, torch.nn.Parameter):      # ONE view object per weight: the packed-weight cache is keyed by it
+            w4.dm_cacheable = True
+            w.__dict__['_dm_view4'] = w4
+    y = dense_conv.conv2d(x2.contiguous().view(m, k, 1, 1), w4, b)
+    return y.reshape(m, n).view(*shp[:-1], n)
+
+
+def _own_linear_takes(x, w):
+    return x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.numel() > 0 \
+        and w.dim() == 2 and w.is_contiguous()
+
+
 def blas_linear(x, w, b=None):
-    """torch.nn.functional.linear(x, w, b) issued under the one-GEMM-at-a-time rule (see blas_turn)."""
+    """torch.nn.functional.linear(x, w, b): on the main lane the vendor GEMM under the one-GEMM-at-a-time rule (see
+    blas_turn), on every other lane the library's own GEMM."""
+    if off_main_lane() and _own_linear_takes(x, w):
+        return own_linear(x, w, b)
     if not torch.is_grad_enabled() or not (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
         with blas_turn():
             return torch.nn.functional.linear(x, w, b)

@@ -65,10 +65,19 @@ __device__ __forceinline__ int block_excl_scan_flag(bool flag, int *total) {
   return base + pre;
 }
 
+// `n_dev` (capacity-sized builds, dm_rulebook_*_cap): the row count lives on the device, `n` is then the CAPACITY the
+// launch and the table strides are sized for; NULL: `n` is the count.
+__device__ __forceinline__ int rb_rows(int n, const int32_t *n_dev) {
+  if (!n_dev) return n;
+  const int v = *n_dev;
+  return v < n ? (v < 0 ? 0 : v) : n;
+}
+
 __global__ __launch_bounds__(256) void rb_insert_inputs(const int4 *indices, int n, RbGeom g,
                                                         uint32_t *hkeys, int32_t *hvals,
-                                                        int log2_size) {
+                                                        int log2_size, const int32_t *n_dev) {
   int i = blockIdx.x * 256 + threadIdx.x;
+  n = rb_rows(n, n_dev);
   if (i >= n) return;
   int4 c = indices[i];
   int fresh;
@@ -80,10 +89,13 @@ __global__ __launch_bounds__(256) void rb_insert_inputs(const int4 *indices, int
 __global__ __launch_bounds__(256) void rb_table_subm(const int4 *indices, int n, RbGeom g,
                                                      const uint32_t *hkeys, const int32_t *hvals,
                                                      int log2_size, int32_t *nbr, int32_t *chunk_cnt,
-                                                     int nchunks) {
+                                                     int nchunks, const int32_t *n_dev) {
   int o = blockIdx.x * 256 + threadIdx.x;
   int k = blockIdx.y;
   int v = -1;
+  const int cap = n;                       // table stride
+  n = rb_rows(n, n_dev);
+  if (o >= n && o < cap) nbr[(size_t)k * cap + o] = -1;      // rows of the capacity nobody owns
   if (o < n) {
     int4 c = indices[o];
     int kk[3];
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(256) void rb_table_subm(const int4 *indices, int n,
     int z = c.y + kk[0] - g.pad[0], y = c.z + kk[1] - g.pad[1], x = c.w + kk[2] - g.pad[2];
     if (z >= 0 && z < g.spatial[0] && y >= 0 && y < g.spatial[1] && x >= 0 && x < g.spatial[2])
       v = dm_hash_find(hkeys, hvals, log2_size, in_key(g, c.x, z, y, x));
-    nbr[(size_t)k * n + o] = v;
+    nbr[(size_t)k * cap + o] = v;
   }
   int total;
   block_excl_scan_flag(v >= 0, &total);
@@ -285,8 +297,9 @@ __global__ __launch_bounds__(256) void rb_pairs_to_table(const int32_t *pairs,
 // word, a segmented OR over each run of equal words leaves ONE atomicOr per run, and a word whose bits
 // are already seen set is skipped (a stale read only costs a redundant atomic).
 __global__ __launch_bounds__(256) void rb_bitmap_mark(const int4 *indices, int n, RbGeom g,
-                                                      uint32_t *bits) {
+                                                      uint32_t *bits, const int32_t *n_dev) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  n = rb_rows(n, n_dev);
   const int k = blockIdx.y;
   const int lane = threadIdx.x & 63;
   uint32_t word = 0xffffffffu, m = 0;
@@ -395,10 +408,13 @@ __global__ __launch_bounds__(256) void rb_bitmap_tables(const int4 *indices, int
                                                         const uint32_t *bits, const int32_t *word_pre,
                                                         const int32_t *blk_off, int32_t *nbr_in,
                                                         int32_t *nbr_out, int n_out,
-                                                        int32_t *chunk_cnt, int nchunks) {
+                                                        int32_t *chunk_cnt, int nchunks, const int32_t *n_dev) {
   int i = blockIdx.x * 256 + threadIdx.x;
   int k = blockIdx.y;
   int v = -1;
+  const int cap = n;                       // stride of nbr_in
+  n = rb_rows(n, n_dev);
+  if (i >= n && i < cap) nbr_in[(size_t)k * cap + i] = -1;
   if (i < n) {
     int4 c = indices[i];
     int kk[3], q[3];
@@ -410,7 +426,7 @@ __global__ __launch_bounds__(256) void rb_bitmap_tables(const int4 *indices, int
       if (v < n_out) nbr_out[(size_t)k * n_out + v] = i;
       else v = -1;                                 // n_out smaller than the count phase reported
     }
-    nbr_in[(size_t)k * n + i] = v;
+    nbr_in[(size_t)k * cap + i] = v;
   }
   int total;
   block_excl_scan_flag(v >= 0, &total);
@@ -562,10 +578,10 @@ extern "C" int dm_rulebook_subm(const int32_t *indices, int n, int batch,
   DM_HIP(hipMemsetAsync(w.ha_keys, 0xff, sizeof(uint32_t) << w.log2_a, st));
   int nb = dm_ceil_div(n, 256);
   rb_insert_inputs<<<nb, 256, 0, st>>>((const int4 *)indices, n, g, w.ha_keys, w.ha_vals,
-                                       w.log2_a);
+                                       w.log2_a, nullptr);
   DM_CHECK_LAUNCH();
   rb_table_subm<<<dim3(nb, g.kvol), 256, 0, st>>>((const int4 *)indices, n, g, w.ha_keys,
-                                                  w.ha_vals, w.log2_a, nbr_out, w.chunk_cnt, nb);
+                                                  w.ha_vals, w.log2_a, nbr_out, w.chunk_cnt, nb, nullptr);
   DM_CHECK_LAUNCH();
   return pairs_from_table(nbr_out, n, g.kvol, w.chunk_cnt, w.chunk_off, nb, indice_pairs, n,
                           indice_num, st);
@@ -595,7 +611,7 @@ extern "C" int dm_rulebook_conv_count(const int32_t *indices, int n, int batch,
     RbBitmap bm = carve_bitmap(w, g, batch, n);
     if (bm.fits) {
       DM_HIP(hipMemsetAsync(bm.bits, 0, bm.words * sizeof(uint32_t), st));
-      rb_bitmap_mark<<<dim3(nb, g.kvol), 256, 0, st>>>((const int4 *)indices, n, g, bm.bits);
+      rb_bitmap_mark<<<dim3(nb, g.kvol), 256, 0, st>>>((const int4 *)indices, n, g, bm.bits, nullptr);
       DM_CHECK_LAUNCH();
       rb_bitmap_scan<<<bm.nblk, 256, 0, st>>>(bm.bits, bm.word_pre, bm.blk_sum);
       DM_CHECK_LAUNCH();
@@ -609,7 +625,7 @@ extern "C" int dm_rulebook_conv_count(const int32_t *indices, int n, int batch,
   DM_HIP(hipMemsetAsync(w.hb_keys, 0xff, sizeof(uint32_t) << w.log2_b, st));
   DM_HIP(hipMemsetAsync(w.counter, 0, sizeof(int32_t), st));
   rb_insert_inputs<<<nb, 256, 0, st>>>((const int4 *)indices, n, g, w.ha_keys, w.ha_vals,
-                                       w.log2_a);
+                                       w.log2_a, nullptr);
   DM_CHECK_LAUNCH();
   rb_conv_candidates<<<dim3(nb, g.kvol), 256, 0, st>>>((const int4 *)indices, n, g, w.hb_keys,
                                                        w.log2_b, w.uniq, w.counter);
@@ -652,7 +668,7 @@ extern "C" int dm_rulebook_conv_fill(const int32_t *indices, int n, int batch,
                                                                 n_out, nbr_out, nbr_words, emit_blocks);
       DM_CHECK_LAUNCH();
       rb_bitmap_tables<<<dim3(nbi, g.kvol), 256, 0, st>>>((const int4 *)indices, n, g, bm.bits, bm.word_pre,
-                                                         bm.blk_off, nbr_in, nbr_out, n_out, w.chunk_cnt, nbi);
+                                                         bm.blk_off, nbr_in, nbr_out, n_out, w.chunk_cnt, nbi, nullptr);
       DM_CHECK_LAUNCH();
       return pairs_from_table(nbr_in, n, g.kvol, w.chunk_cnt, w.chunk_off, nbi, indice_pairs, n, indice_num, st, 1);
     }
@@ -678,6 +694,73 @@ extern "C" int dm_rulebook_conv_fill(const int32_t *indices, int n, int batch,
                                                       w.hb_vals, w.log2_b, nbr_in, w.chunk_cnt, nbi);
   DM_CHECK_LAUNCH();
   return pairs_from_table(nbr_in, n, g.kvol, w.chunk_cnt, w.chunk_off, nbi, indice_pairs, n, indice_num, st, 1);
+}
+
+// ---- capacity-sized builds: row counts stay on the device -----------------------------------------------------------
+// Same kernels, launched over the CAPACITY of the input; the count is read from `n_dev` by the kernels.  Every table has
+// the capacity as its row stride (nbr_out (kvol, cap_out), nbr_in / indice_pairs over cap_in); rows beyond the count are
+// -1 in the tables and untouched in out_ids.  A strided build writes *n_out_dev; should it exceed cap_out, the tables hold
+// the first cap_out outputs only and the caller (who reads the count when it chooses to) rebuilds that layer the
+// two-phase way.  Bitmap path only (DM_ERR_WORKSPACE when the bitmap does not fit: the caller falls back).
+extern "C" int dm_rulebook_subm_cap(const int32_t *indices, const int32_t *n_dev, int cap, int batch,
+                                    const int *spatial_shape_host, const int *ksize_host, int32_t *nbr_out,
+                                    int32_t *indice_pairs, int32_t *indice_num, void *workspace,
+                                    size_t workspace_bytes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (cap <= 0 || batch <= 0 || !indice_num || !n_dev || !indices || !nbr_out || !workspace) return DM_ERR_INVALID_ARG;
+  RbGeom g;
+  int one[3] = {1, 1, 1};
+  int pad[3] = {ksize_host[0] / 2, ksize_host[1] / 2, ksize_host[2] / 2};
+  int rc = make_geom(&g, batch, spatial_shape_host, spatial_shape_host, ksize_host, one, pad);
+  if (rc) return rc;
+  RbWorkspace w = carve(workspace, workspace_bytes, cap, g.kvol);
+  if (w.total > workspace_bytes) return DM_ERR_WORKSPACE;
+  DM_HIP(hipMemsetAsync(w.ha_keys, 0xff, sizeof(uint32_t) << w.log2_a, st));
+  int nb = dm_ceil_div(cap, 256);
+  rb_insert_inputs<<<nb, 256, 0, st>>>((const int4 *)indices, cap, g, w.ha_keys, w.ha_vals, w.log2_a, n_dev);
+  DM_CHECK_LAUNCH();
+  rb_table_subm<<<dim3(nb, g.kvol), 256, 0, st>>>((const int4 *)indices, cap, g, w.ha_keys, w.ha_vals, w.log2_a,
+                                                  nbr_out, w.chunk_cnt, nb, n_dev);
+  DM_CHECK_LAUNCH();
+  return pairs_from_table(nbr_out, cap, g.kvol, w.chunk_cnt, w.chunk_off, nb, indice_pairs, cap, indice_num, st);
+}
+
+extern "C" int dm_rulebook_conv_cap(const int32_t *indices, const int32_t *n_dev, int cap_in, int batch,
+                                    const int *spatial_shape_host, const int *out_shape_host,
+                                    const int *ksize_host, const int *stride_host, const int *padding_host,
+                                    int cap_out, int32_t *n_out_dev, int32_t *out_ids, int32_t *nbr_out,
+                                    int32_t *nbr_in, int32_t *indice_pairs, int32_t *indice_num,
+                                    void *workspace, size_t workspace_bytes, dm_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (cap_in <= 0 || cap_out <= 0 || batch <= 0 || !n_dev || !n_out_dev || !indices || !out_ids || !nbr_out ||
+      !nbr_in || !indice_num || !workspace)
+    return DM_ERR_INVALID_ARG;
+  RbGeom g;
+  int rc = make_geom(&g, batch, spatial_shape_host, out_shape_host, ksize_host, stride_host, padding_host);
+  if (rc) return rc;
+  RbWorkspace w = carve(workspace, workspace_bytes, cap_in, g.kvol);
+  if (w.total > workspace_bytes) return DM_ERR_WORKSPACE;
+  if (g_rb_mode == 1) return DM_ERR_WORKSPACE;
+  RbBitmap bm = carve_bitmap(w, g, batch, cap_in);
+  if (!bm.fits) return DM_ERR_WORKSPACE;
+  const int nbi = dm_ceil_div(cap_in, 256);
+  DM_HIP(hipMemsetAsync(bm.bits, 0, bm.words * sizeof(uint32_t), st));
+  rb_bitmap_mark<<<dim3(nbi, g.kvol), 256, 0, st>>>((const int4 *)indices, cap_in, g, bm.bits, n_dev);
+  DM_CHECK_LAUNCH();
+  rb_bitmap_scan<<<bm.nblk, 256, 0, st>>>(bm.bits, bm.word_pre, bm.blk_sum);
+  DM_CHECK_LAUNCH();
+  rb_scan_chunks<<<1, 256, 0, st>>>(bm.blk_sum, bm.nblk, bm.blk_off, n_out_dev);
+  DM_CHECK_LAUNCH();
+  const size_t nbr_words = (size_t)g.kvol * cap_out;
+  const int fill_blocks = (int)std::min<size_t>(2048, dm_ceil_div(nbr_words / 4 + 1, 256));
+  const int emit_blocks = (int)(bm.words / 64);
+  rb_bitmap_emit<<<emit_blocks + fill_blocks, 256, 0, st>>>(bm.bits, bm.word_pre, bm.blk_off, g, (int4 *)out_ids,
+                                                            cap_out, nbr_out, nbr_words, emit_blocks);
+  DM_CHECK_LAUNCH();
+  rb_bitmap_tables<<<dim3(nbi, g.kvol), 256, 0, st>>>((const int4 *)indices, cap_in, g, bm.bits, bm.word_pre,
+                                                     bm.blk_off, nbr_in, nbr_out, cap_out, w.chunk_cnt, nbi, n_dev);
+  DM_CHECK_LAUNCH();
+  return pairs_from_table(nbr_in, cap_in, g.kvol, w.chunk_cnt, w.chunk_off, nbi, indice_pairs, cap_in, indice_num, st, 1);
 }
 
 extern "C" int dm_rulebook_set_mode(int mode) {

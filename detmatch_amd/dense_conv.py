@@ -241,7 +241,8 @@ def _wants_planes(T, N, K, stride_one):
 def _pack(weight, tag, S, N, K, n_src, k_src, sn, sk, st, scale_n=None, scale_k=None, planes=False):
     """[S][N][K] packed copy of `weight` (cached until the weight or a scale changes).  planes=True: the flat
     buffer also holds the pre-split bf16 planes behind the fp32 block (`dst.dm_planes` = their byte offset)."""
-    cacheable = isinstance(weight, nn.Parameter)     # temporaries may recycle an address
+    # temporaries may recycle an address; `dm_cacheable`: a long-lived view of a Parameter (_lib.own_linear keeps one per FC weight)
+    cacheable = isinstance(weight, nn.Parameter) or getattr(weight, 'dm_cacheable', False)
     stream = _lib.raw_stream()
     if planes:
         tag = tag + 'P'

@@ -58,6 +58,11 @@ def pcdet_to_mm3d_boxes(pred_boxes):
     return LiDARInstance3DBoxes(b, origin=(0.5, 0.5, 0.5))
 
 
+# prepare_geometry_steps: the size read-backs of a pass (voxel count + N_out of the strided rulebooks) as ONE copy after
+# the whole chain has been issued at capacity (module attribute: the equality test switches it)
+DEFER_GEOMETRY_READBACKS = True
+
+
 @DETECTORS.register_module()
 class OpenPCDetDetector(DetectorStepMixin, nn.Module):
 
@@ -114,12 +119,30 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
                                                      self.voxel_layer.point_cloud_range,
                                                      self.voxel_layer.max_num_points, max_voxels,
                                                      with_mean=True, sync=False)
-        total = yield counts[len(pts):len(pts) + 1]
-        res = self._fill_base_batch(points, img_metas, v[:total], n[:total], c[:total], mean[:total], fps=False)
         bb = getattr(self.model, 'backbone_3d', None)
-        if bb is not None and hasattr(bb, 'build_rulebooks_steps'):
-            res['indice_dict_prefetch'] = yield from bb.build_rulebooks_steps(
-                res['voxel_coords'], res['batch_size'], ws_tag=ws_tag)
+        total_dev = counts[len(pts):len(pts) + 1]
+        deferred = None
+        if DEFER_GEOMETRY_READBACKS and bb is not None and hasattr(bb, 'build_rulebooks_deferred') and c.is_cuda:
+            # the voxelizer's count and N_out of every strided level stay on the device while the
+            # whole rulebook chain is issued at capacity (csrc/rulebook.hip: dm_rulebook_*_cap); ONE read-back returns
+            # them all (the reference: one per sample in the voxelizer, one per strided layer — spconv_ops.h:58-141)
+            deferred = bb.build_rulebooks_deferred(c, total_dev, len(pts), ws_tag=ws_tag)
+        if deferred is not None:
+            levels, n_out_devs = deferred
+            vals = yield torch.cat([total_dev] + n_out_devs)
+            vals = vals if isinstance(vals, list) else [vals]
+            total = vals[0]
+            res = self._fill_base_batch(points, img_metas, v[:total], n[:total], c[:total], mean[:total], fps=False)
+            indice_dict = bb.finish_rulebooks(levels, total, vals[1:])
+            if indice_dict is None:          # a level outgrew its capacity: the two-phase build, one read-back per level
+                indice_dict = yield from bb.build_rulebooks_steps(res['voxel_coords'], res['batch_size'], ws_tag=ws_tag)
+            res['indice_dict_prefetch'] = indice_dict
+        else:
+            total = yield total_dev
+            res = self._fill_base_batch(points, img_metas, v[:total], n[:total], c[:total], mean[:total], fps=False)
+            if bb is not None and hasattr(bb, 'build_rulebooks_steps'):
+                res['indice_dict_prefetch'] = yield from bb.build_rulebooks_steps(
+                    res['voxel_coords'], res['batch_size'], ws_tag=ws_tag)
         # the key-point FPS (3 ms on two compute units) AFTER the rulebooks: it may share their stream, and the
         # rulebooks' size read-backs must not queue behind it
         self._launch_fps(res)

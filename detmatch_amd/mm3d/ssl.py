@@ -125,6 +125,8 @@ class _Lanes(object):
         # all its host read-backs) runs on a side stream, underneath the supervised passes.
         self.mode = mode
         self.main = torch.cuda.current_stream(device)
+        from .. import _lib
+        _lib.MAIN_STREAM[0] = self.main.cuda_stream      # vendor GEMMs stay on this lane (_lib.blas_linear)
         pool = _Lanes._side.get(device.index)
         if pool is None:
             # (a high-priority stream for the teacher-3D + glue lane measured no different: DESIGN.md §9)

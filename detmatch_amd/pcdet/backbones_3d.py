@@ -131,6 +131,57 @@ class VoxelBackBone8x(nn.Module):
             indices, shape = indice_dict[m.indice_key][0], out_shape
         return indice_dict
 
+    def build_rulebooks_deferred(self, coords_cap, n_dev, batch_size, ws_tag='rulebook'):
+        """Every rulebook of the backbone issued WITHOUT a host value: `coords_cap` (cap, 4) voxel coordinates at the
+        voxelizer's capacity, `n_dev` its device count.  -> (levels, counts): levels = [(indice_key, CapRulebook,
+        input spatial shape)], counts = the device scalars N_out of the strided levels in order — the caller reads
+        them (with the voxel count) in ONE copy and calls finish_rulebooks.  None: the capacity-sized entries do not
+        apply (tiny clouds on huge grids: the occupancy bitmap does not fit) — use build_rulebooks_steps."""
+        from ..spconv import ops as sp_ops
+        from ..spconv.conv import SparseConvolution
+        levels, counts, seen = [], [], {}
+        indices, n_cur, cap_cur, shape = coords_cap, n_dev, int(coords_cap.shape[0]), list(self.sparse_shape)
+        first_cap = cap_cur
+        for m in self.modules():
+            if not isinstance(m, SparseConvolution) or m.conv1x1:
+                continue
+            if m.transposed:
+                return None
+            out_shape = shape if m.subm else sp_ops.get_conv_output_size(
+                shape, m.kernel_size, m.stride, m.padding, m.dilation)
+            if m.indice_key not in seen:
+                cap_out = None if m.subm else sp_ops.strided_capacity(cap_cur, m.kernel_size, m.stride, first_cap)
+                c = sp_ops.build_rulebook_cap(indices, n_cur, cap_cur, batch_size, shape, m.kernel_size, m.stride,
+                                              m.padding, m.dilation, m.subm, cap_out=cap_out, ws_tag=ws_tag)
+                if c is None:
+                    return None
+                seen[m.indice_key] = c
+                levels.append((m.indice_key, c, shape))
+                if not m.subm:
+                    counts.append(c.n_out_dev)
+            c = seen[m.indice_key]
+            indices, n_cur, cap_cur, shape = c.outids, c.n_out_dev, c.cap_out, out_shape
+        return levels, counts
+
+    @staticmethod
+    def finish_rulebooks(levels, n_voxels, n_outs):
+        """The host counts are here: exact-size rulebooks -> the indice_dict build_rulebooks_steps returns, or None when
+        a level outgrew its capacity."""
+        indice_dict, n_in, k = {}, int(n_voxels), 0
+        for key, c, shape in levels:
+            if c.subm:
+                n_out = n_in
+            else:
+                n_out = int(n_outs[k])
+                k += 1
+            rb = c.finish(n_in, n_out)
+            if rb is None:
+                return None
+            rb.indice_pairs.dm_tables = (rb.nbr_out, rb.nbr_in, rb.subm)
+            indice_dict[key] = (rb.outids, c.indices[:n_in], rb.indice_pairs, rb.indice_num, shape)
+            n_in = n_out
+        return indice_dict
+
     def _chained(self, batch_dict, voxel_features, voxel_coords):
         """The 12 layers as one chained call (sparse_chain.py), when it applies."""
         from .. import chain as _chain

@@ -42,7 +42,8 @@ def drive_steps(gen):
     try:
         ask = next(gen)
         while True:
-            ask = gen.send(int(ask.item()))
+            v = ask.reshape(-1).tolist()
+            ask = gen.send(int(v[0]) if len(v) == 1 else [int(x) for x in v])
     except StopIteration as stop:
         return stop.value
 
@@ -60,11 +61,14 @@ def drive_steps_together(gens):
             results[i] = stop.value
     while asks:
         order = sorted(asks)
-        vals = torch.cat([asks[i].reshape(1) for i in order]).tolist()
-        nxt = {}
-        for i, v in zip(order, vals):
+        flat = [asks[i].reshape(-1) for i in order]
+        vals = torch.cat(flat).tolist()            # (a generator may ask for several scalars at once: one tensor)
+        nxt, pos = {}, 0
+        for i, f in zip(order, flat):
+            v = [int(x) for x in vals[pos:pos + f.numel()]]
+            pos += f.numel()
             try:
-                nxt[i] = gens[i].send(int(v))
+                nxt[i] = gens[i].send(v[0] if len(v) == 1 else v)
             except StopIteration as stop:
                 results[i] = stop.value
         asks = nxt
@@ -130,6 +134,94 @@ def build_rulebook_steps(indices, batch_size, spatial_shape, ksize=3, stride=1, 
                                  _lib.ptr(rb.indice_num), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, 'dm_rulebook_conv_fill')
     return rb
+
+
+class CapRulebook(object):
+    """A rulebook issued over the CAPACITY of its input (dm_rulebook_subm_cap / dm_rulebook_conv_cap): every count is
+    still on the device.  `finish(n_in, n_out)` — once the caller has read the counts, all levels of all passes in one
+    copy — cuts it to the exact-size Rulebook the consumers take."""
+    __slots__ = ('subm', 'kvol', 'cap_in', 'cap_out', 'out_shape', 'indices', 'n_in_dev', 'n_out_dev', 'outids', 'nbr_out',
+                 'nbr_in', 'indice_pairs', 'indice_num', 'args')
+
+    def finish(self, n_in, n_out):
+        """-> Rulebook with exact-size tensors; None when the capacity was too small (n_out > cap_out: rebuild the
+        two-phase way)."""
+        if n_out > self.cap_out or n_in > self.cap_in:
+            return None
+        rb = Rulebook()
+        rb.subm, rb.kvol, rb.n_in, rb.n_out, rb.out_shape = self.subm, self.kvol, n_in, n_out, self.out_shape
+        rb.indice_num = self.indice_num
+        rb.outids = self.indices[:n_in] if self.subm else self.outids[:n_out]
+        rb.nbr_out = _cut_table(self.nbr_out, self.kvol, self.cap_in if self.subm else self.cap_out, n_out)
+        rb.nbr_in = None if self.subm else _cut_table(self.nbr_in, self.kvol, self.cap_in, n_in)
+        rb.indice_pairs = None if self.indice_pairs is None else \
+            _cut_table(self.indice_pairs, 2 * self.kvol, self.cap_in, n_in).view(self.kvol, 2, n_in)
+        return rb
+
+
+def _cut_table(table, rows, cap, n):
+    """The first n columns of a (rows, cap) int32 table as a dense (rows, n) one: one pitched copy (dm_copy2d_f32 moves
+    32-bit words, 16 bytes per lane when the pitches allow)."""
+    if n == cap:
+        return table.view(rows, cap)
+    out = torch.empty((rows, n), dtype=torch.int32, device=table.device)
+    if n > 0:
+        _lib.check(_lib.lib().dm_copy2d_f32(_lib.ptr(table), cap, _lib.ptr(out), n, rows, n, _lib.stream()), 'dm_copy2d_f32')
+    return out
+
+
+def strided_capacity(cap_in, ksize, stride, first_cap):
+    """Row capacity of a strided layer's output: an input touches at most prod(ceil(k / s)) outputs, but tables of
+    that size would be mostly padding (KITTI: 29 k -> 34 k -> 19 k -> 8 k -> 6 k rows) — twice the capacity of the
+    voxelizer bounds every level seen on LiDAR clouds, and a layer that still overflows is rebuilt two-phase
+    (CapRulebook.finish -> None)."""
+    worst = cap_in
+    for k, s_ in zip(ksize, stride):
+        worst *= -(-k // s_)
+    return int(min(worst, max(2 * first_cap, 4096)))
+
+
+def build_rulebook_cap(indices, n_dev, cap_in, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                       subm=False, with_pairs=True, cap_out=None, ws_tag='rulebook'):
+    """build_rulebook with every size on the device: `indices` (cap_in, 4) of which the first *n_dev rows count.
+    -> CapRulebook, or None when the capacity-sized entry does not apply (the caller builds two-phase)."""
+    ksize, stride, padding, dilation = (_norm(v, 3) for v in (ksize, stride, padding, dilation))
+    if indices.shape[1] != 4 or any(d != 1 for d in dilation) or cap_in <= 0:
+        return None
+    assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[0] >= cap_in
+    _lib.require_device(indices)
+    L = _lib.lib()
+    dev = indices.device
+    kvol = ksize[0] * ksize[1] * ksize[2]
+    spatial = [int(s) for s in spatial_shape]
+    c = CapRulebook()
+    c.subm, c.kvol, c.cap_in, c.indices, c.n_in_dev = bool(subm), kvol, int(cap_in), indices, n_dev
+    ws = _lib.workspace(L.dm_rulebook_workspace_bytes(cap_in, kvol), dev, ws_tag)
+    c.indice_num = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    c.indice_pairs = torch.empty((kvol, 2, cap_in), dtype=torch.int32, device=dev) if with_pairs else None
+    if subm:
+        c.out_shape, c.cap_out, c.n_out_dev, c.outids, c.nbr_in = spatial, int(cap_in), n_dev, indices, None
+        c.nbr_out = torch.empty((kvol, cap_in), dtype=torch.int32, device=dev)
+        rc = L.dm_rulebook_subm_cap(_lib.ptr(indices), _lib.ptr(n_dev), int(cap_in), int(batch_size), _lib.ints(spatial),
+                                    _lib.ints(ksize), _lib.ptr(c.nbr_out), _lib.ptr(c.indice_pairs), _lib.ptr(c.indice_num),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream())
+    else:
+        c.out_shape = get_conv_output_size(spatial, ksize, stride, padding, dilation)
+        c.cap_out = int(cap_out)
+        c.n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+        c.outids = torch.empty((c.cap_out, 4), dtype=torch.int32, device=dev)
+        c.nbr_out = torch.empty((kvol, c.cap_out), dtype=torch.int32, device=dev)
+        c.nbr_in = torch.empty((kvol, cap_in), dtype=torch.int32, device=dev)
+        rc = L.dm_rulebook_conv_cap(_lib.ptr(indices), _lib.ptr(n_dev), int(cap_in), int(batch_size), _lib.ints(spatial),
+                                    _lib.ints(c.out_shape), _lib.ints(ksize), _lib.ints(stride), _lib.ints(padding),
+                                    c.cap_out, _lib.ptr(c.n_out_dev), _lib.ptr(c.outids), _lib.ptr(c.nbr_out),
+                                    _lib.ptr(c.nbr_in), _lib.ptr(c.indice_pairs), _lib.ptr(c.indice_num), _lib.ptr(ws),
+                                    ws.numel(), _lib.stream())
+    if rc == 2:           # DM_ERR_WORKSPACE: the occupancy bitmap does not fit — not an error, the two-phase path takes it
+        return None
+    _lib.check(rc, 'dm_rulebook_%s_cap' % ('subm' if subm else 'conv'))
+    c.args = (batch_size, spatial, ksize, stride, padding, dilation, subm, with_pairs)
+    return c
 
 
 def get_indice_pairs_steps(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,

@@ -156,6 +156,31 @@ int dm_rulebook_conv_fill(const int32_t *indices, int n, int batch,
                           int32_t *indice_num /*(kvol)*/, void *workspace,
                           size_t workspace_bytes, dm_stream_t stream);
 
+/* Capacity-sized builds — SURVEY 8(b) B2: "ops whose output size is data-dependent ... must offer a device-resident
+ * count + capacity-bounded output so the caller can defer the read-back".  The reference reads numActOut back inside
+ * every strided layer (mmdet3d/ops/spconv/include/spconv/spconv_ops.h:58-141: `indiceNum.cpu()`, `outInds.slice(0, 0,
+ * numAct)`), four times per backbone pass, and the voxel count before the first one.  Here the row count of the INPUT
+ * is a device scalar too (`n_dev`: the voxelizer's device count, or the *n_out_dev of the previous layer) and `cap` /
+ * `cap_in` its capacity: launches and table strides are sized by the capacity, the kernels stop at the count.  Layout:
+ * nbr_out (kvol, cap_out), nbr_in (kvol, cap_in), indice_pairs (kvol, 2, cap_in), out_ids (cap_out, 4); rows beyond the
+ * count are -1 in the tables, unspecified in out_ids.  *n_out_dev > cap_out means the tables are truncated (the caller
+ * rebuilds that layer with dm_rulebook_conv_count / _fill).  The whole chain voxelize -> subm1 -> spconv2 -> ... of a
+ * pass can be issued without a host value; ONE read-back at the end returns every count (spconv/ops.py:
+ * build_rulebook_cap / finish_rulebook, pcdet/backbones_3d.py:build_rulebooks_deferred).  Results within the counts are
+ * bit-identical to the two-phase entries.  DM_ERR_WORKSPACE: the occupancy bitmap does not fit the workspace
+ * (dm_rulebook_workspace_bytes(cap_in, kvol)) — use the two-phase entries. */
+int dm_rulebook_subm_cap(const int32_t *indices /*(cap,4)*/, const int32_t *n_dev, int cap, int batch,
+                         const int *spatial_shape_host, const int *ksize_host, int32_t *nbr_out /*(kvol,cap)*/,
+                         int32_t *indice_pairs /*(kvol,2,cap) or NULL*/, int32_t *indice_num /*(kvol)*/,
+                         void *workspace, size_t workspace_bytes, dm_stream_t stream);
+int dm_rulebook_conv_cap(const int32_t *indices /*(cap_in,4)*/, const int32_t *n_dev, int cap_in, int batch,
+                         const int *spatial_shape_host, const int *out_shape_host, const int *ksize_host,
+                         const int *stride_host, const int *padding_host, int cap_out, int32_t *n_out_dev,
+                         int32_t *out_ids /*(cap_out,4)*/, int32_t *nbr_out /*(kvol,cap_out)*/,
+                         int32_t *nbr_in /*(kvol,cap_in)*/, int32_t *indice_pairs /*(kvol,2,cap_in) or NULL*/,
+                         int32_t *indice_num /*(kvol)*/, void *workspace, size_t workspace_bytes,
+                         dm_stream_t stream);
+
 /* Rebuild a gather table from reference-format pair lists (for callers that
  * hold a rulebook produced elsewhere).  side = 1: table[k][pairs[k][1][s]] =
  * pairs[k][0][s] (n_rows = n_out, forward); side = 0: the transpose. */

@@ -59,3 +59,36 @@ def test_every_gemm_of_the_shipped_iteration_is_inside_a_turn(dev, monkeypatch):
     outside = [(e.name, e.thread, [tuple(s) for s in (e.input_shapes or [])]) for e in gemms
                if not any(a <= e.time_range.start and e.time_range.end <= b for a, b in turns.get(e.thread, []))]
     assert not outside, 'vendor GEMMs issued outside _lib.blas_turn(): %s' % outside[:8]
+
+
+def test_off_main_lane_linear_is_the_own_gemm_and_matches(dev):
+    """_lib.blas_linear on a stream that is not the iteration's main lane: the library's GEMM (no vendor kernel, so no
+    turn edge), same values and gradients as F.linear to fp32-class accuracy."""
+    from detmatch_amd import _lib
+    torch.manual_seed(1)
+    side = torch.cuda.Stream()
+    old = _lib.MAIN_STREAM[0]
+    _lib.MAIN_STREAM[0] = torch.cuda.current_stream().cuda_stream
+    try:
+        for m, k, n, bias in ((200, 27648, 256, False), (256, 256, 7, True), (1024, 1024, 16, True), (300, 640, 128, False)):
+            x = torch.randn(m, k, device=dev, requires_grad=True)
+            w = torch.nn.Parameter(torch.randn(n, k, device=dev) / k ** 0.5)
+            b = torch.nn.Parameter(torch.randn(n, device=dev)) if bias else None
+            g = torch.randn(m, n, device=dev)
+            want = F.linear(x, w, b)
+            gw = torch.autograd.grad(want, [x, w] + ([b] if bias else []), g)
+            side.wait_stream(torch.cuda.current_stream())
+            calls, turns = _lib.OWN_LINEAR_CALLS[0], _lib.BLAS_TURNS[0]
+            with torch.cuda.stream(side):
+                got = _lib.blas_linear(x, w, b)
+                gg = torch.autograd.grad(got, [x, w] + ([b] if bias else []), g)
+                got2 = _lib.blas_linear(x, w, b)              # second call: packed weight from the cache
+            side.synchronize()
+            assert _lib.OWN_LINEAR_CALLS[0] == calls + 2 and _lib.BLAS_TURNS[0] == turns
+            assert got.shape == want.shape and torch.equal(got, got2)
+            scale = float(want.abs().max())
+            assert float((got - want).abs().max()) <= 2e-5 * scale
+            for a, c in zip(gg, gw):
+                assert float((a - c).abs().max()) <= 5e-5 * float(c.abs().max())
+    finally:
+        _lib.MAIN_STREAM[0] = old

@@ -129,6 +129,83 @@ def test_rulebook_bitmap_equals_hash_path_full_frame(dev):
     assert n_strided == 4
 
 
+def test_deferred_rulebooks_equal_two_phase(dev):
+    """voxelize -> subm1 -> spconv2 -> ... -> spconv_down2 of a KITTI-sized frame pair issued at CAPACITY
+    with every count on the device (dm_rulebook_subm_cap / dm_rulebook_conv_cap), counts read ONCE at the end: every
+    table, pair list and count identical to the two-phase builds (one read-back per strided level)."""
+    from detmatch_amd import synth, voxel
+    from detmatch_amd.pcdet.workload import BACKBONE_LAYERS
+    from detmatch_amd.spconv import ops
+    pts = [torch.from_numpy(synth.lidar_frame(s)['points']).to(dev) for s in range(2)]
+    v, coors, n, mean, counts = voxel.voxelize_batch(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000, sync=False)
+    assert coors.shape[0] == 32000
+    # capacity chain, no host value in between
+    idx, n_dev, cap, shape, seen, caps = coors, counts[2:3], 32000, [41, 1600, 1408], {}, []
+    for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
+        if key in seen:
+            continue
+        cap_out = None if subm else ops.strided_capacity(cap, ks, st, 32000)
+        c = ops.build_rulebook_cap(idx, n_dev, cap, 2, shape, ks, st, pd, 1, subm, cap_out=cap_out)
+        assert c is not None, key
+        seen[key] = c
+        caps.append((key, c, subm))
+        idx, n_dev, cap, shape = c.outids, c.n_out_dev, c.cap_out, c.out_shape
+    vals = torch.cat([counts[2:3]] + [c.n_out_dev for _, c, subm in caps if not subm]).tolist()      # THE read-back
+    assert len(vals) == 5
+    # two-phase reference
+    idx, shape, n_in, k = coors[:vals[0]], [41, 1600, 1408], vals[0], 1
+    for key, c, subm in caps:
+        want = ops.build_rulebook(idx, 2, shape, *[(ks, st, pd) for kk, sm, _, _, ks, st, pd in BACKBONE_LAYERS if kk == key][0],
+                                  1, subm)
+        n_out = n_in if subm else vals[k]
+        k += 0 if subm else 1
+        got = c.finish(n_in, n_out)
+        assert got is not None and got.n_out == want.n_out == n_out and got.out_shape == want.out_shape
+        for f in ('outids', 'nbr_out', 'indice_pairs', 'indice_num') + (() if subm else ('nbr_in',)):
+            a, b = getattr(got, f), getattr(want, f)
+            assert a.shape == b.shape and torch.equal(a, b), (key, f)
+        idx, shape, n_in = want.outids, want.out_shape, n_out
+    # a capacity that is too small is reported, not silently truncated
+    key, c, _ = [t for t in caps if not t[2]][0]
+    small = ops.build_rulebook_cap(coors, counts[2:3], 32000, 2, [41, 1600, 1408], [3, 3, 3], [2, 2, 2], [1, 1, 1], 1, False,
+                                   cap_out=1024)
+    assert small.finish(vals[0], int(small.n_out_dev.item())) is None
+
+
+def test_geometry_of_a_pass_needs_one_read_back(dev, monkeypatch):
+    """OpenPCDetDetector.prepare_geometry_steps: with the deferred builds the generator asks ONCE (voxel count + the four
+    N_out in one tensor); the batch it prepares equals the stepwise one (five asks)."""
+    from detmatch_amd.mm3d import openpcdet
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    wl = DetMatchTrainWorkload(2, dev)
+    det = wl.model.student.detector_3d
+    from detmatch_amd import synth
+    pts = [torch.from_numpy(synth.lidar_frame(s)['points']).to(dev) for s in range(2)]
+    out = []
+    for defer in (True, False):
+        monkeypatch.setattr(openpcdet, 'DEFER_GEOMETRY_READBACKS', defer)
+        det._geom_cache.clear()
+        gen, asks = det.prepare_geometry_steps(pts, None), 0
+        try:
+            ask = next(gen)
+            while True:
+                asks += 1
+                v = ask.reshape(-1).tolist()
+                ask = gen.send(v[0] if len(v) == 1 else v)
+        except StopIteration:
+            pass
+        out.append((asks, det._geom_cache[id(pts)][2]))
+    (a1, r1), (a2, r2) = out
+    assert a1 == 1 and a2 == 5
+    assert torch.equal(r1['voxel_coords'], r2['voxel_coords']) and torch.equal(r1['voxel_features'], r2['voxel_features'])
+    assert set(r1['indice_dict_prefetch']) == set(r2['indice_dict_prefetch'])
+    for key in r1['indice_dict_prefetch']:
+        (o1, i1, p1, n1, s1), (o2, i2, p2, n2, s2) = r1['indice_dict_prefetch'][key], r2['indice_dict_prefetch'][key]
+        assert torch.equal(o1, o2) and torch.equal(i1, i2) and torch.equal(p1, p2) and torch.equal(n1, n2) and s1 == s2
+        for t1, t2 in zip(p1.dm_tables[:2], p2.dm_tables[:2]):
+            assert (t1 is None and t2 is None) or torch.equal(t1, t2)
+
+
 @pytest.mark.parametrize('profile', ['kitti', 'waymo'])
 def test_strided_rulebook_properties_full_size(dev, profile):
     """Size-independent properties of the strided rulebooks at BASELINE's full frame sizes (KITTI B = 2, the
