@@ -1,5 +1,5 @@
 import os
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream: detmatch_amd/__init__.py says why (before the runtime initialises)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')   # the runtime's default, pinned: with RCCL initialised 5+ hardware queues cost +30 ms per iteration (detmatch_amd/__init__.py)
 import sys
 
 # The GPU tests run the iteration in the one-lane order ('glue') unless a test asks for the lanes itself: the three

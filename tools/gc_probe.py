@@ -1,7 +1,7 @@
 """How much of an iteration's host time is Python's cyclic garbage collector?  gc.callbacks around 10 iterations.
     python tools/gc_probe.py"""
 import os as _os
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')   # the runtime's default, pinned: with RCCL initialised 5+ hardware queues cost +30 ms per iteration (detmatch_amd/__init__.py)
 import gc
 import os
 import sys

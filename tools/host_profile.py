@@ -5,7 +5,7 @@ time (where the Python / launch overhead of the step goes; blocking read-backs s
     python tools/host_profile.py
 """
 import os as _os
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')   # the runtime's default, pinned: with RCCL initialised 5+ hardware queues cost +30 ms per iteration (detmatch_amd/__init__.py)
 import cProfile, pstats, sys, os, io
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import detmatch_amd, torch

@@ -1,7 +1,7 @@
 """Run-to-run variability of the accumulated gradient after k iterations: serial vs serial, and
 serial vs two-lane execution (a race would show up as a much larger serial-vs-lanes difference)."""
 import os as _os
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')   # the runtime's default, pinned: with RCCL initialised 5+ hardware queues cost +30 ms per iteration (detmatch_amd/__init__.py)
 import sys
 
 import torch

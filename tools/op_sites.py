@@ -5,7 +5,7 @@ and everything autograd runs on the calling thread are covered (the device backw
     python tools/op_sites.py [top]
 """
 import os as _os
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')   # the runtime's default, pinned: with RCCL initialised 5+ hardware queues cost +30 ms per iteration (detmatch_amd/__init__.py)
 import collections
 import os
 import sys

@@ -6,7 +6,7 @@ means the device was waiting for the host there (host-bound), large means queued
     python tools/phase_timeline.py
 """
 import os as _os
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')   # one hardware queue per HIP stream (detmatch_amd/__init__.py), before the runtime comes up
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')   # the runtime's default, pinned: with RCCL initialised 5+ hardware queues cost +30 ms per iteration (detmatch_amd/__init__.py)
 import os
 import sys
 import time
