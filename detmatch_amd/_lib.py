@@ -361,8 +361,9 @@ def off_main_lane():
     return MAIN_STREAM[0] is not None and torch.cuda.is_available() and raw_stream() != MAIN_STREAM[0]
 
 
-def own_linear(x, w, b=None):
-    """F.linear(x, w, b) on the library's GEMM (differentiable: dense_conv's autograd Function)."""
+def own_linear(x, w, b=None, relu=False):
+    """[relu](F.linear(x, w, b)) on the library's GEMM (differentiable: dense_conv's autograd Function; the ReLU rides in
+    the GEMM's epilogue)."""
     from . import dense_conv
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])
@@ -376,7 +377,7 @@ def own_linear(x, w, b=None):
         if isinstance(w, torch.nn.Parameter):      # ONE view object per weight: the packed-weight cache is keyed by it
             w4.dm_cacheable = True
             w.__dict__['_dm_view4'] = w4
-    y = dense_conv.conv2d(x2.contiguous().view(m, k, 1, 1), w4, b)
+    y = dense_conv.conv2d(x2.contiguous().view(m, k, 1, 1), w4, b, relu=relu)
     return y.reshape(m, n).view(*shp[:-1], n)
 
 
@@ -385,11 +386,13 @@ def _own_linear_takes(x, w):
         and w.dim() == 2 and w.is_contiguous()
 
 
-def blas_linear(x, w, b=None):
-    """torch.nn.functional.linear(x, w, b): on the main lane the vendor GEMM under the one-GEMM-at-a-time rule (see
-    blas_turn), on every other lane the library's own GEMM."""
+def blas_linear(x, w, b=None, relu=False):
+    """[relu](torch.nn.functional.linear(x, w, b)): on the main lane the vendor GEMM under the one-GEMM-at-a-time rule
+    (see blas_turn), on every other lane the library's own GEMM."""
     if off_main_lane() and _own_linear_takes(x, w):
-        return own_linear(x, w, b)
+        return own_linear(x, w, b, relu)
+    if relu:
+        return torch.relu_(blas_linear(x, w, b))
     if not torch.is_grad_enabled() or not (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
         with blas_turn():
             return torch.nn.functional.linear(x, w, b)

@@ -481,7 +481,7 @@ class Shared2FCBBoxHead(nn.Module):
         x = x.flatten(1)
         # (vendor GEMMs: only ever inside _lib.blas_turn — one Stream-K kernel at a time)
         for fc in self.shared_fcs:
-            x = F.relu(_lib.blas_linear(x, fc.weight, fc.bias), inplace=True)
+            x = _lib.blas_linear(x, fc.weight, fc.bias, relu=True)
         return _lib.blas_linear(x, self.fc_cls.weight, self.fc_cls.bias), \
             _lib.blas_linear(x, self.fc_reg.weight, self.fc_reg.bias)
 
