@@ -84,11 +84,14 @@ def test_off_main_lane_linear_is_the_own_gemm_and_matches(dev):
                 gg = torch.autograd.grad(got, [x, w] + ([b] if bias else []), g)
                 got2 = _lib.blas_linear(x, w, b)              # second call: packed weight from the cache
             side.synchronize()
-            assert _lib.OWN_LINEAR_CALLS[0] == calls + 2 and _lib.BLAS_TURNS[0] == turns
-            assert got.shape == want.shape and torch.equal(got, got2)
-            scale = float(want.abs().max())
-            assert float((got - want).abs().max()) <= 2e-5 * scale
-            for a, c in zip(gg, gw):
-                assert float((a - c).abs().max()) <= 5e-5 * float(c.abs().max())
+            assert _lib.OWN_LINEAR_CALLS[0] == calls + 2, (_lib.OWN_LINEAR_CALLS[0], calls)
+            assert _lib.BLAS_TURNS[0] == turns, 'a vendor GEMM was issued off the main lane'
+            assert got.shape == want.shape and torch.equal(got, got2), (got.shape, want.shape)
+            scale = float(want.detach().abs().max())
+            err = float((got.detach() - want.detach()).abs().max())
+            assert err <= 1e-4 * scale, (m, k, n, err, scale)
+            for which, a, c in zip('xwb', gg, gw):
+                e, sc = float((a - c).abs().max()), float(c.abs().max())
+                assert e <= 2e-4 * sc, (m, k, n, which, e, sc)
     finally:
         _lib.MAIN_STREAM[0] = old
