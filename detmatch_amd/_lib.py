@@ -382,8 +382,12 @@ def own_linear(x, w, b=None, relu=False):
 
 
 def _own_linear_takes(x, w):
-    return x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.numel() > 0 \
-        and w.dim() == 2 and w.is_contiguous()
+    if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.numel() > 0
+            and w.dim() == 2 and w.is_contiguous()):
+        return False
+    # the own backward reads gradient rows 16 bytes at a time: an output width that is not a multiple of 4 is fine in
+    # inference (the teacher's 1- and 7-wide RoI heads), with gradients it stays on the vendor kernel
+    return w.shape[0] % 4 == 0 or not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))
 
 
 def blas_linear(x, w, b=None, relu=False):

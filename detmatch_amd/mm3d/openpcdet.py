@@ -6,6 +6,7 @@ round trip (:132-145) and `coors[-1, 0].item()` (:92) are gone: batch size is le
 GT stays on the device.
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -60,7 +61,7 @@ def pcdet_to_mm3d_boxes(pred_boxes):
 
 # prepare_geometry_steps: the size read-backs of a pass (voxel count + N_out of the strided rulebooks) as ONE copy after
 # the whole chain has been issued at capacity (module attribute: the equality test switches it)
-DEFER_GEOMETRY_READBACKS = os.environ.get('DM_DEFER_GEOMETRY', '1') == '1'      # (round 6 A/B; the equality test switches the attribute)
+DEFER_GEOMETRY_READBACKS = True
 
 
 @DETECTORS.register_module()

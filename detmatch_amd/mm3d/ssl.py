@@ -27,7 +27,7 @@ def add_prefix(inputs, prefix):
 # attributes — the gradient-equality tests switch them (tests/test_ssl_gpu.py) — not environment switches.
 _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued before their chain inputs exist
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
-_2D_FIRST = os.environ.get('DM_2D_FIRST', '1') == '1'     # (round 6 A/B, see forward_train) the last 2D module in front of its 3D neighbour
+_2D_FIRST = False        # the last 2D module in front of its 3D neighbour: measured neutral (63.1 / 63.9 vs 63.3 / 63.7 ms, profiles/r06_ab_step_variants.txt): off
 
 
 class _LaneDict(dict):

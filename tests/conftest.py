@@ -2,10 +2,9 @@ import os
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')   # the runtime's default, pinned: with RCCL initialised 5+ hardware queues cost +30 ms per iteration (detmatch_amd/__init__.py)
 import sys
 
-# The GPU tests run the iteration in the one-lane order ('glue') unless a test asks for the lanes itself: the three
-# stream lanes of the bench default met an intermittent device dead-lock in round 5 (profiles/r05_lane_hang_ab.txt:
-# avoided, not understood), and a wedged test would take the whole run down.  The lane tests set the mode explicitly.
-os.environ.setdefault('DM_TWO_LANES', '0')
+# The GPU tests run the iteration in the order that SHIPS (three stream lanes, chains, early issue: the bench default)
+# unless a test sets another one itself.  (Round 5 ran them in the one-lane order because of an intermittent device
+# dead-lock of the lanes; its cause — two vendor Stream-K GEMMs in flight at once — is removed)
 
 import pytest
 

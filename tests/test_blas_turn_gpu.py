@@ -70,7 +70,7 @@ def test_off_main_lane_linear_is_the_own_gemm_and_matches(dev):
     old = _lib.MAIN_STREAM[0]
     _lib.MAIN_STREAM[0] = torch.cuda.current_stream().cuda_stream
     try:
-        for m, k, n, bias in ((200, 27648, 256, False), (256, 256, 7, True), (1024, 1024, 16, True), (300, 640, 128, False)):
+        for m, k, n, bias in ((200, 27648, 256, False), (256, 256, 8, True), (1024, 1024, 16, True), (300, 640, 128, False)):
             x = torch.randn(m, k, device=dev, requires_grad=True)
             w = torch.nn.Parameter(torch.randn(n, k, device=dev) / k ** 0.5)
             b = torch.nn.Parameter(torch.randn(n, device=dev)) if bias else None
@@ -93,5 +93,19 @@ def test_off_main_lane_linear_is_the_own_gemm_and_matches(dev):
             for which, a, c in zip('xwb', gg, gw):
                 e, sc = float((a - c).abs().max()), float(c.abs().max())
                 assert e <= 2e-4 * sc, (m, k, n, which, e, sc)
+        # inference with an output width that is not a multiple of 4 (the teacher's 7-wide box head): own GEMM;
+        # the same layer with gradients: vendor GEMM inside a turn
+        x = torch.randn(256, 256, device=dev)
+        w = torch.nn.Parameter(torch.randn(7, 256, device=dev) / 16)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            calls, turns = _lib.OWN_LINEAR_CALLS[0], _lib.BLAS_TURNS[0]
+            with torch.no_grad():
+                y = _lib.blas_linear(x, w)
+            assert _lib.OWN_LINEAR_CALLS[0] == calls + 1 and _lib.BLAS_TURNS[0] == turns
+            y2 = _lib.blas_linear(x, w)
+            assert _lib.BLAS_TURNS[0] == turns + 1 and y2.requires_grad
+        side.synchronize()
+        assert float((y - F.linear(x, w).detach()).abs().max()) <= 1e-4 * float(y.abs().max())
     finally:
         _lib.MAIN_STREAM[0] = old

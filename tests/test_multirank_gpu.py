@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('mode', ['collect', 'hooks'])
-def test_two_ranks_on_one_gpu_stay_in_sync(dev, mode):
-    # (one lane: two processes with three stream lanes each on ONE device is nobody's configuration, and more streams
-    # than hardware queues is where round 5 met its dead-lock)
+@pytest.mark.parametrize('mode,lanes', [('collect', '1'), ('hooks', '1'), ('collect', '0')])
+def test_two_ranks_on_one_gpu_stay_in_sync(dev, mode, lanes):
+    # lanes '1': the order that ships (three stream lanes per rank — round 5 ran this test in the one-lane order only:
+    # two processes with the lanes on one device dead-locked in a third of its runs, DESIGN.md 6.R6 says why)
     env = dict(os.environ, DM_FORCE_DEVICE='0', DM_DIST_BACKEND='gloo', DM_BENCH_CHECK_SYNC='1', DM_GRAD_MODE=mode,
-               DM_TWO_LANES='0')
+               DM_TWO_LANES=lanes)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
