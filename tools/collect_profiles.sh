@@ -1,9 +1,9 @@
 #!/bin/bash
-# Collects the round's judged artifacts on the GPU box into gpurun_out/r05/ (copied to profiles/ afterwards).
+# Collects the round's judged artifacts on the GPU box into gpurun_out/r06/ (copied to profiles/ afterwards).
 #   bash tools/collect_profiles.sh [part ...]     parts: trace pmc bench tools ab (default: all)
 # Every command runs under its own `timeout` (an intermittent device dead-lock cost this round 25 GPU-minutes once).
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05
+O=$R/gpurun_out/${DM_ROUND:-r06}
 mkdir -p $O
 PARTS="${@:-trace pmc bench tools ab}"
 cd /tmp && export TMPDIR=/tmp
@@ -49,7 +49,7 @@ if has ab; then
   # 3. round-5 A/Bs (same box, alternated)
   rm -f $O/ab_step_variants.txt
   for i in ${AB_ROUNDS:-1 2}; do
-    for v in "default:A=1" "no_early_2d_backward:DM_EARLY_2D_BWD=0" "op_by_op:DM_CHAIN=0" "one_lane_glue:DM_TWO_LANES=0" "op_by_op_one_lane(r4):DM_CHAIN=0 DM_TWO_LANES=0" "no_early_issue:DM_ISSUE_EARLY=0" "no_trunk2d_chain:DM_CHAIN_OFF=trunk2d"; do
+    for v in "default:A=1" "op_by_op:DM_CHAIN=0" "one_lane_glue:DM_TWO_LANES=0" "op_by_op_one_lane(r4):DM_CHAIN=0 DM_TWO_LANES=0" "no_trunk2d_chain:DM_CHAIN_OFF=trunk2d"; do
       n=${v%%:*}; e=${v#*:}
       env $e timeout 100 python3 bench.py --no-cpu-baseline --steps 30 --warmup 6 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-26s run $i  %.1f ms/step  roofline kernel %.1f us  order %s' % ('$n', d['ms_per_step'], r.get('avg_us') or 0, d['config'].get('stream_order')))" >> $O/ab_step_variants.txt || echo "$n run $i FAILED" >> $O/ab_step_variants.txt
     done
