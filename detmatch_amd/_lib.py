@@ -74,6 +74,8 @@ SIGNATURES = {
     'dm_consistency_loss_forward': (ci, [vp, vp, vp, vp, ci, ci, cf, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp]),
     'dm_consistency_loss_backward': (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp]),
     'dm_bbox2d_transform': (ci, [vp, ci, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp]),
+    'dm_fc_gemm_workspace_bytes': (sz, [ci, ci, ci]),
+    'dm_fc_gemm': (ci, [ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp]),
     'dm_rowgemm_supported': (ci, [ci, ci]),
     'dm_rowgemm': (ci, [vp, vp, vp, ctypes.c_longlong, ci, ci, vp]),
     'dm_rowgemm_parts': (ci, [ctypes.c_longlong, ci, ci]),
@@ -390,9 +392,78 @@ def _own_linear_takes(x, w):
     return w.shape[0] % 4 == 0 or not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))
 
 
+# ---- fully connected layers on the library's own exact-fp32 GEMM (csrc/fc_gemm.hip) -------------------------------------
+FC_GEMM = True            # module switch of the equality tests / tools/bench_fc.py (False: vendor GEMM inside a turn)
+FC_GEMM_CALLS = [0]
+
+
+def _fc_gemm(form, a, b, bias, out, m, n, k, lda, ldb, relu=False):
+    L = lib()
+    wsb = int(L.dm_fc_gemm_workspace_bytes(m, n, k))
+    ws = workspace(wsb, out.device, 'fc_gemm') if wsb else None
+    check(L.dm_fc_gemm(form, ptr(a), ptr(b), ptr(bias), ptr(out), m, n, k, lda, ldb, n, int(relu), ptr(ws),
+                       ws.numel() if ws is not None else 0, stream()), 'dm_fc_gemm')
+    FC_GEMM_CALLS[0] += 1
+    return out
+
+
+class _FcLinear(torch.autograd.Function):
+    """[relu](x w^T + b) for x (rows, in), w (out, in): forward, input gradient and weight gradient on dm_fc_gemm
+    (forms 0 / 1 / 2), the bias gradient as a column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x, w = x.detach().contiguous(), w.detach().contiguous()
+        m, k = x.shape
+        n = w.shape[0]
+        y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        _fc_gemm(0, x, w, None if b is None else b.detach(), y, m, n, k, k, k, relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.relu, ctx.has_bias = bool(relu), b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        m, k = x.shape
+        n = w.shape[0]
+        gy = gy.contiguous()
+        if ctx.relu:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _fc_gemm(1, gy, w, None, torch.empty_like(x), m, k, n, n, k)
+        if ctx.needs_input_grad[1]:
+            gw = _fc_gemm(2, gy, x, None, torch.empty_like(w), n, k, m, n, k)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=0)
+        return gx, gw, gb, None
+
+
+def _fc_takes(x, w, b):
+    return FC_GEMM and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 2 and \
+        x.numel() > 0 and (b is None or b.dtype == torch.float32)
+
+
+def fc_linear(x, w, b=None, relu=False):
+    """[relu](F.linear(x, w, b)) on csrc/fc_gemm.hip; x (..., in)."""
+    shp = x.shape
+    y = _FcLinear.apply(x.reshape(-1, shp[-1]), w, b, bool(relu))
+    return y.view(*shp[:-1], w.shape[0])
+
+
 def blas_linear(x, w, b=None, relu=False):
-    """[relu](torch.nn.functional.linear(x, w, b)): on the main lane the vendor GEMM under the one-GEMM-at-a-time rule
-    (see blas_turn), on every other lane the library's own GEMM."""
+    """[relu](torch.nn.functional.linear(x, w, b)) for the FC stacks of the step.  Main lane: the library's exact-fp32 FC
+    GEMM (csrc/fc_gemm.hip; `FC_GEMM = False`: the vendor GEMM under the one-GEMM-at-a-time rule, see blas_turn).  Other
+    lanes: the same, except that the one layer above 8 GFLOP (the 2D head's 12 544 -> 1 024 at 1 000-2 000 rows) takes the
+    library's convolution GEMM on (M, K, 1, 1) views (bf16-split arithmetic: faster on GEMMs of that size) — never a
+    vendor kernel, so no turn ever inserts a cross-lane edge."""
+    if _fc_takes(x, w, b):
+        rows = x.numel() // max(1, x.shape[-1])
+        big = 2.0 * rows * w.shape[0] * w.shape[1] > 8e9        # the 2D head's 12 544 -> 1 024 layer: 26-51 GFLOP
+        if not (big and _own_linear_takes(x, w)):
+            return fc_linear(x, w, b, relu)
+        return own_linear(x, w, b, relu)
     if off_main_lane() and _own_linear_takes(x, w):
         return own_linear(x, w, b, relu)
     if relu:

@@ -983,6 +983,19 @@ int dm_roi_decode_backward(const float *grad_boxes, const float *box_encodings, 
 /* ------------------------------------------------------------------------ */
 /* Chain-level issue (host-side launch interpreter)                          */
 /* ------------------------------------------------------------------------ */
+/* Fully connected layers (nn.Linear / Conv1d(kernel 1) of pcdet/models/roi_heads/pvrcnn_head.py:25-52,
+ * voxel_set_abstraction.py:107-111, point_head_template.py:34-47; the reference: cuBLAS through torch.nn.functional.linear
+ * and autograd's mm backward).  One exact-fp32 MFMA kernel, three operand forms, all row-major with leading dimensions:
+ *   form 0  C[M][N] = A[M][K] . B[N][K]^T [+ bias[N]] [ReLU]     forward            y  = x w^T + b
+ *   form 1  C[M][N] = A[M][K] . B[K][N]                          input gradient     gx = gy w
+ *   form 2  C[M][N] = A[K][M]^T . B[K][N]                        weight gradient    gw = gy^T x
+ * A long contraction over few output tiles is split along K; the partial products (workspace,
+ * dm_fc_gemm_workspace_bytes(M, N, K)) are summed in split order, so the result depends on the shapes only. */
+size_t dm_fc_gemm_workspace_bytes(int M, int N, int K);
+int dm_fc_gemm(int form, const float *A, const float *B, const float *bias /*or NULL*/, float *C, int M, int N, int K,
+               int lda, int ldb, int ldc, int relu, void *workspace, size_t workspace_bytes, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* The reference issues its step one Python call -> one ATen / extension call -> one kernel at a time
  * (e.g. pcdet/models/backbones_2d/base_bev_backbone.py:38-69: 15 conv + 15 BatchNorm + 15 ReLU module calls,
  * each a pybind trip; mmdet ResNet-50 + FPN + RPNHead of configs/detmatch/001/detmatch/split_0.py:39-99:

@@ -42,6 +42,7 @@ def test_every_gemm_of_the_shipped_iteration_is_inside_a_turn(dev, monkeypatch):
     for _ in range(2):
         wl.step()
     torch.cuda.synchronize()
+    fc0 = _lib.FC_GEMM_CALLS[0]
     _lib.BLAS_TRACE[0] = True
     try:
         with profile(activities=[ProfilerActivity.CPU]) as prof:
@@ -55,10 +56,13 @@ def test_every_gemm_of_the_shipped_iteration_is_inside_a_turn(dev, monkeypatch):
             turns.setdefault(e.thread, []).append((e.time_range.start, e.time_range.end))
         elif e.name in _GEMM_OPS:
             gemms.append(e)
-    assert len(gemms) >= 40 and sum(len(v) for v in turns.values()) >= 40, (len(gemms), len(turns))
+    # the FC stacks run on the library's own GEMMs (csrc/fc_gemm.hip, conv2d.hip): what is left for the vendor library
+    # is a handful of odd products at most — each of them inside a turn
+    assert len(gemms) <= 12 and sum(len(v) for v in turns.values()) >= len(gemms), (len(gemms), [e.name for e in gemms])
     outside = [(e.name, e.thread, [tuple(s) for s in (e.input_shapes or [])]) for e in gemms
                if not any(a <= e.time_range.start and e.time_range.end <= b for a, b in turns.get(e.thread, []))]
     assert not outside, 'vendor GEMMs issued outside _lib.blas_turn(): %s' % outside[:8]
+    assert _lib.FC_GEMM_CALLS[0] - fc0 >= 60            # forward + two gradients of the student's FC stacks, the teacher's forward
 
 
 def test_off_main_lane_linear_is_the_own_gemm_and_matches(dev):

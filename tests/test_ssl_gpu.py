@@ -625,8 +625,7 @@ def test_lookahead_geometry_is_scheduling_only(dev, monkeypatch):
 def test_shipped_order_soak_300_iterations(dev):
     """The configuration bench.py measures (three lanes, chains, early issue, shared 2D trunk, batched FPS, lazy glue),
     300 iterations in a row: finishes (round 5's reproducer of the lane dead-lock wedged within ~100-400), stays finite,
-    every vendor GEMM went through a turn and none of them needed a cross-lane edge (the other lanes' FCs run on the own
-    GEMM)."""
+    the FC stacks ran on the library's own GEMMs and no vendor GEMM ever needed a cross-lane edge."""
     import time
     from detmatch_amd import _lib
     from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
@@ -638,12 +637,12 @@ def test_shipped_order_soak_300_iterations(dev):
     for _ in range(3):
         wl.step()
     torch.cuda.synchronize()
-    turns, edges, own = _lib.BLAS_TURNS[0], _lib.BLAS_TURNS[1], _lib.OWN_LINEAR_CALLS[0]
+    edges, own = _lib.BLAS_TURNS[1], _lib.OWN_LINEAR_CALLS[0] + _lib.FC_GEMM_CALLS[0]
     t0 = time.time()
     for i in range(300):
         loss = wl.step()
     torch.cuda.synchronize()
     dt = time.time() - t0
     assert torch.isfinite(loss) and dt < 120, dt
-    assert _lib.BLAS_TURNS[0] - turns >= 300 * 20 and _lib.OWN_LINEAR_CALLS[0] - own >= 300 * 8
-    assert _lib.BLAS_TURNS[1] == edges, 'a vendor GEMM was issued on two lanes'
+    assert _lib.OWN_LINEAR_CALLS[0] + _lib.FC_GEMM_CALLS[0] - own >= 300 * 60
+    assert _lib.BLAS_TURNS[1] == edges, 'vendor GEMMs were issued on two lanes'

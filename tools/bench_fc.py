@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
-from detmatch_amd import dense_conv  # noqa: E402
+from detmatch_amd import _lib, dense_conv  # noqa: E402
 
 SHAPES = [('pvrcnn shared_fc 27648->256, 256 rois', 256, 27648, 256),
           ('pvrcnn shared_fc, teacher 200 rois', 200, 27648, 256),
@@ -37,7 +37,7 @@ def timed(fn, reps=20):
 
 def main():
     dev = torch.device('cuda', 0)
-    print('%-40s %6s | %22s | %22s | %22s' % ('layer', 'GFLOP', 'fwd  blas / own  us', 'dgrad blas / own us', 'wgrad blas / own us'))
+    print('%-40s %6s | %30s | %30s | %30s' % ('layer', 'GFLOP', 'fwd  blas / conv / fc_gemm  us', 'dgrad blas / conv / fc_gemm', 'wgrad blas / conv / fc_gemm'))
     for name, m, k, n in SHAPES:
         x = torch.randn(m, k, device=dev)
         w = torch.randn(n, k, device=dev) / k ** 0.5
@@ -63,8 +63,13 @@ def main():
         t_do = timed(lambda: own_bwd(True, False)) - t_f2
         t_wo = timed(lambda: own_bwd(False, True)) - t_f2
         gf = 2.0 * m * k * n / 1e9
-        print('%-40s %6.2f | %9.1f / %9.1f | %9.1f / %9.1f | %9.1f / %9.1f   err %.1e' % (
-            name, gf, t_fb, t_fo, t_db, t_do, t_wb, t_wo, err))
+        yb, gxb, gwb = torch.empty(m, n, device=dev), torch.empty(m, k, device=dev), torch.empty(n, k, device=dev)
+        t_ff = timed(lambda: _lib._fc_gemm(0, x, w, None, yb, m, n, k, k, k))
+        t_df = timed(lambda: _lib._fc_gemm(1, gy, w, None, gxb, m, k, n, n, k))
+        t_wf = timed(lambda: _lib._fc_gemm(2, gy, x, None, gwb, n, k, m, n, k))
+        err_f = float((yb - y_b).abs().max() / y_b.abs().max())
+        print('%-40s %6.2f | %8.1f / %8.1f / %8.1f | %8.1f / %8.1f / %8.1f | %8.1f / %8.1f / %8.1f   err conv %.1e fc %.1e' % (
+            name, gf, t_fb, t_fo, t_ff, t_db, t_do, t_df, t_wb, t_wo, t_wf, err, err_f))
 
 
 if __name__ == '__main__':
