@@ -393,7 +393,7 @@ def _own_linear_takes(x, w):
 
 
 # ---- fully connected layers on the library's own exact-fp32 GEMM (csrc/fc_gemm.hip) -------------------------------------
-FC_GEMM = True            # module switch of the equality tests / tools/bench_fc.py (False: vendor GEMM inside a turn)
+FC_GEMM = os.environ.get('DM_FC_GEMM', '1') == '1'      # (round 6 A/B; tests switch the attribute)
 FC_GEMM_CALLS = [0]
 
 
