@@ -252,6 +252,65 @@ def _oracle_stage(oracle, frames, rng_seed=0, timings=None):
     return T
 
 
+def _reference_stage(frames, threads):
+    """The same stage on the REFERENCE's own CPU kernels compiled in the build container (oracle/_ref: the unmodified
+    voxelizer; geometry.h + reordering.cc with torch::mm_out between gather and scatter under oracle/ref_spconv_driver.cc)
+    — present on the GPU box as prebuilt files only (nothing under /root/reference is read at run time).
+    -> per-piece seconds, or None when the prebuilt modules are not there / do not load."""
+    try:
+        from oracle import build_ref
+        ref = build_ref.load_ref(build_ref.SPCONV_NAME)
+        if ref is None or build_ref.load_ref(build_ref.NAME) is None:
+            return None
+    except Exception as e:      # optional: the port is the fallback baseline
+        sys.stderr.write('bench.py: oracle/_ref not usable (%s); cpu_baseline.kind = port\n' % (e,))
+        return None
+    from detmatch_amd import synth
+    from detmatch_amd.pcdet.workload import BACKBONE_LAYERS
+    from detmatch_amd.spconv.ops import get_conv_output_size
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        T = dict(voxelize=0.0, rulebook=0.0, conv_fwd=0.0, conv_bwd=0.0)
+        rng = np.random.default_rng(0)
+        t0 = time.perf_counter()
+        feats, coors = [], []
+        for b, f in enumerate(frames):
+            v, c, n = build_ref.ref_hard_voxelize(f['points'], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+            feats.append((v.sum(1) / np.maximum(n, 1)[:, None]).astype(np.float32))
+            coors.append(np.concatenate([np.full((len(n), 1), b, np.int32), c], 1))
+        T['voxelize'] = time.perf_counter() - t0
+        x = torch.from_numpy(np.concatenate(feats))
+        cur = torch.from_numpy(np.concatenate(coors).astype(np.int32))
+        shape, books, acts = [41, 1600, 1408], {}, []
+        for key, subm, cin, cout, ks, st, pd in BACKBONE_LAYERS:
+            osh = shape if subm else get_conv_output_size(shape, ks, st, pd, [1, 1, 1])
+            if key not in books:
+                t0 = time.perf_counter()
+                books[key] = ref.get_indice_pairs(cur, len(frames), osh, list(ks), list(st), list(pd), [1, 1, 1], bool(subm))
+                T['rulebook'] += time.perf_counter() - t0
+            o, p, n = books[key]
+            w = torch.from_numpy((rng.standard_normal((int(np.prod(ks)), cin, cout)) * 0.05).astype(np.float32)).view(
+                *ks, cin, cout)
+            t0 = time.perf_counter()
+            y = ref.indice_conv(x, w, p, n, o.shape[0], False, bool(subm))
+            T['conv_fwd'] += time.perf_counter() - t0
+            acts.append((x, w, p, n, bool(subm)))
+            x, cur, shape = torch.relu(y), o, osh
+        g = torch.ones_like(x)
+        t0 = time.perf_counter()
+        for xi, w, p, n, subm in reversed(acts):
+            g, _ = ref.indice_conv_backward(xi, w, g, p, n, False, subm)
+        T['conv_bwd'] = time.perf_counter() - t0
+        T['total'] = T['voxelize'] + T['rulebook'] + T['conv_fwd'] + T['conv_bwd']
+        return T
+    except Exception as e:
+        sys.stderr.write('bench.py: reference stage failed (%s); cpu_baseline.kind = port\n' % (e,))
+        return None
+    finally:
+        torch.set_num_threads(old)
+
+
 def cpu_baseline(frames, gpu_pieces=None):
     """The oracle (C restatement of the reference CPU path, oracle/dm_oracle.c) on the host cores of
     this box, per piece as BASELINE.md §4 asks: voxelize ms/frame, rulebooks ms, sparse conv forward /
@@ -297,6 +356,25 @@ def cpu_baseline(frames, gpu_pieces=None):
                pieces_1_thread=pieces,
                all_cores=dict(cores=cores, value=round(cores / dtn, 4),
                               note='%d independent copies of the stage in %.1f s' % (cores, dtn)))
+    # the reference's own CPU kernels, when their prebuilt modules travelled with the snapshot (oracle/_ref)
+    threads = min(os.cpu_count() or 1, 16)
+    r1 = _reference_stage(frames, 1)
+    if r1 is not None:
+        r1 = _reference_stage(frames, 1)           # second pass: the first touches the voxelizer's 360 MB grid
+        rn = _reference_stage(frames, threads)
+        ms = lambda T: dict(voxelize_ms_per_frame=round(T['voxelize'] / len(frames) * 1e3, 2), rulebooks_ms=round(T['rulebook'] * 1e3, 1),
+                            conv_fwd_ms=round(T['conv_fwd'] * 1e3, 1), conv_bwd_ms=round(T['conv_bwd'] * 1e3, 1))
+        out['port'] = dict(value=out['value'], cores=1, pieces_1_thread=out.pop('pieces_1_thread'), all_cores=out.pop('all_cores'),
+                           note=out.pop('note'))
+        out.update(value=round(1.0 / r1['total'], 4), cores=1, kind='reference',
+                   sample=out['sample'] + '; reference stage: 2 passes at 1 thread (second timed), 1 at %d threads' % threads,
+                   note='oracle/_ref: the reference\'s voxelization_cpu.cpp (unmodified) and geometry.h + reordering.cc with '
+                        'torch::mm_out (MKL) between gather and scatter, compiled in the build container; `port` = the C '
+                        'restatement (oracle/dm_oracle.c) on the same frames',
+                   pieces_1_thread=ms(r1))
+        if rn is not None:
+            out['all_threads'] = dict(threads=threads, value=round(1.0 / rn['total'], 4), pieces=ms(rn),
+                                      note='torch.set_num_threads(%d): the per-offset GEMMs are too small for MKL to scale' % threads)
     if gpu_pieces is not None:
         out['gpu_same_pieces'] = gpu_pieces
     return out

@@ -393,7 +393,8 @@ def _own_linear_takes(x, w):
 
 
 # ---- fully connected layers on the library's own exact-fp32 GEMM (csrc/fc_gemm.hip) -------------------------------------
-FC_GEMM = os.environ.get('DM_FC_GEMM', '1') == '1'      # (round 6 A/B; tests switch the attribute)
+FC_GEMM = True            # module switch of the equality tests / tools (False: vendor GEMM inside a turn on the main lane,
+                          # the convolution GEMM elsewhere): 60.6 / 60.7 against 63.4 / 63.7 ms per iteration, profiles/r06_fc_blas_vs_own.txt
 FC_GEMM_CALLS = [0]
 
 

@@ -11,8 +11,9 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 _GEMM_OPS = {'aten::mm', 'aten::addmm', 'aten::bmm', 'aten::baddbmm', 'aten::addbmm', 'aten::_scaled_mm'}
 
 
-def test_turns_serialise_gemms_across_streams(dev):
+def test_turns_serialise_gemms_across_streams(dev, monkeypatch):
     from detmatch_amd import _lib
+    monkeypatch.setattr(_lib, 'FC_GEMM', False)          # the VENDOR path of blas_linear (the default is the own FC GEMM)
     torch.manual_seed(0)
     x = [torch.randn(256, 27648, device=dev), torch.randn(200, 27648, device=dev)]
     w = torch.randn(256, 27648, device=dev) * 0.01
@@ -65,10 +66,11 @@ def test_every_gemm_of_the_shipped_iteration_is_inside_a_turn(dev, monkeypatch):
     assert _lib.FC_GEMM_CALLS[0] - fc0 >= 60            # forward + two gradients of the student's FC stacks, the teacher's forward
 
 
-def test_off_main_lane_linear_is_the_own_gemm_and_matches(dev):
-    """_lib.blas_linear on a stream that is not the iteration's main lane: the library's GEMM (no vendor kernel, so no
-    turn edge), same values and gradients as F.linear to fp32-class accuracy."""
+def test_off_main_lane_linear_is_the_own_gemm_and_matches(dev, monkeypatch):
+    """_lib.blas_linear on a stream that is not the iteration's main lane, with the FC GEMM switched off: the library's
+    convolution GEMM (no vendor kernel, so no turn edge), same values and gradients as F.linear to fp32-class accuracy."""
     from detmatch_amd import _lib
+    monkeypatch.setattr(_lib, 'FC_GEMM', False)
     torch.manual_seed(1)
     side = torch.cuda.Stream()
     old = _lib.MAIN_STREAM[0]
