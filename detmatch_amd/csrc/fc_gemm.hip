@@ -35,6 +35,7 @@ struct FcArgs {
   float *C;          // output, or the partial buffer [splits][M][N] when splits > 1
   int M, N, K, lda, ldb, ldc;
   int steps_per_split, relu, splits;
+  int tiles_m, tiles_n, per_xcd;
 };
 
 // One 64 x 32 operand tile, one float4 (4 consecutive elements of the operand's contiguous dimension) per thread pair.
@@ -114,9 +115,17 @@ __global__ __launch_bounds__(256) void fc_gemm_kernel(FcArgs a, int vec_a, int v
   __shared__ float Bs[FC_T * FC_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.y * FC_T, n0 = blockIdx.x * FC_T;
+  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the ids one XCD sees are
+  // L, L + 8, L + 16, ...; they are mapped to CONSECUTIVE logical tiles = (split, n tile, m tile) with m fastest — the
+  // workgroups that re-read the same B columns (skinny M: 4 m tiles) or the same K slice of both operands (split
+  // contraction: all tiles of a split) run next to each other on ONE XCD and hit in its L2 instead of going to HBM again.
+  const int logical = (int)(blockIdx.x % 8) * a.per_xcd + (int)(blockIdx.x / 8);
+  const int n_tiles = a.tiles_m * a.tiles_n;
+  if (logical >= n_tiles * a.splits) return;
+  const int split = logical / n_tiles, tile = logical - split * n_tiles;
+  const int m0 = (tile % a.tiles_m) * FC_T, n0 = (tile / a.tiles_m) * FC_T;
   const int steps = (a.K + FC_BK - 1) / FC_BK;
-  const int s_lo = blockIdx.z * a.steps_per_split;
+  const int s_lo = split * a.steps_per_split;
   const int s_hi = min(steps, s_lo + a.steps_per_split);
   f32x16 acc;
 #pragma unroll
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256) void fc_gemm_kernel(FcArgs a, int vec_a, int v
   if (col >= a.N) return;
   const bool direct = a.splits == 1;
   const float bv = (direct && a.bias) ? a.bias[col] : 0.f;
-  float *out = direct ? a.C : a.C + (size_t)blockIdx.z * a.M * a.N;
+  float *out = direct ? a.C : a.C + (size_t)split * a.M * a.N;
   const int ldo = direct ? a.ldc : a.N;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -218,7 +227,11 @@ extern "C" int dm_fc_gemm(int form, const float *A, const float *B, const float 
   }
   const int vec_a = (lda % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
   const int vec_b = (ldb % 4 == 0 && ((uintptr_t)B & 15) == 0) ? 1 : 0;
-  dim3 grid(dm_ceil_div(N, FC_T), dm_ceil_div(M, FC_T), a.splits);
+  a.tiles_m = dm_ceil_div(M, FC_T), a.tiles_n = dm_ceil_div(N, FC_T);
+  const long long total = (long long)a.tiles_m * a.tiles_n * a.splits;
+  if (total > 0x3fffffff) return DM_ERR_INVALID_ARG;
+  a.per_xcd = (int)((total + 7) / 8);
+  dim3 grid((unsigned)(a.per_xcd * 8), 1, 1);
   if (form == 0) fc_gemm_kernel<0><<<grid, 256, 0, st>>>(a, vec_a, vec_b);
   else if (form == 1) fc_gemm_kernel<1><<<grid, 256, 0, st>>>(a, vec_a, vec_b);
   else fc_gemm_kernel<2><<<grid, 256, 0, st>>>(a, vec_a, vec_b);
