@@ -18,6 +18,7 @@
 // the partial products go to a workspace and are summed in split order by a second kernel that also adds the bias and
 // applies the ReLU — the result is a function of the shapes only (no atomics).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/detmatch_hip.h"
 #include "dm_common.h"
@@ -26,9 +27,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int FC_T = 64;        // output tile (rows and columns)
-constexpr int FC_BK = 32;       // contraction step
-constexpr int FC_LD = FC_BK + 1;
+constexpr int FC_T = 64;        // output tile rows (columns: 64 * NB)
+constexpr int FC_DEFAULT_BK = 32;
+constexpr int FC_DEFAULT_NB_LARGE = 1;
 
 struct FcArgs {
   const float *A, *B, *bias;
@@ -38,30 +39,32 @@ struct FcArgs {
   int tiles_m, tiles_n, per_xcd;
 };
 
-// One 64 x 32 operand tile, one float4 (4 consecutive elements of the operand's contiguous dimension) per thread pair.
-// ROWS_ALONG_K = false: the operand is [row][k] in memory (k contiguous): thread -> (row = t / 8, k4 = t % 8).
-// ROWS_ALONG_K = true:  the operand is [k][row] in memory (row contiguous): thread -> (k = t / 16, r4 = t % 16), two per thread.
-template <bool ROWS_ALONG_K>
+// One 64 x BK operand tile in registers: BK / 16 float4 per thread (4 consecutive elements of the operand's contiguous
+// dimension each).
+// ROWS_ALONG_K = false: the operand is [row][k] in memory (k contiguous): float4 i -> (row = i / (BK / 4), k4 = i % (BK / 4)).
+// ROWS_ALONG_K = true:  the operand is [k][row] in memory (row contiguous): float4 i -> (k = i / 16, r4 = i % 16).
+template <int BK>
 struct TileRegs {
-  float4 v[ROWS_ALONG_K ? 2 : 2];
+  float4 v[BK / 16];
 };
 
-template <bool ROWS_ALONG_K>
-__device__ __forceinline__ void fetch_tile(TileRegs<ROWS_ALONG_K> &t, const float *P, int ld, int row0, int n_rows,
+template <bool ROWS_ALONG_K, int BK>
+__device__ __forceinline__ void fetch_tile(TileRegs<BK> &t, const float *P, int ld, int row0, int n_rows,
                                            int k0, int k_hi, int tid, bool vec) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < BK / 16; ++h) {
+    const int i = tid + 256 * h;
     int r, k;
     if (!ROWS_ALONG_K) {
-      r = (tid >> 3) + 32 * h;          // 64 rows, 8 float4 of k each
-      k = k0 + 4 * (tid & 7);
+      r = i / (BK / 4);
+      k = k0 + 4 * (i % (BK / 4));
     } else {
-      k = k0 + (tid >> 4) + 16 * h;     // 32 k-rows, 16 float4 of rows each
-      r = 4 * (tid & 15);
+      k = k0 + i / 16;
+      r = 4 * (i % 16);
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int row = row0 + r;
     if (!ROWS_ALONG_K) {
-      const int row = row0 + r;
       if (row < n_rows && k < k_hi) {
         const float *p = P + (size_t)row * ld + k;
         if (vec && k + 3 < k_hi) v = *(const float4 *)p;
@@ -73,7 +76,6 @@ __device__ __forceinline__ void fetch_tile(TileRegs<ROWS_ALONG_K> &t, const floa
         }
       }
     } else {
-      const int row = row0 + r;
       if (k < k_hi && row < n_rows) {
         const float *p = P + (size_t)k * ld + row;
         if (vec && row + 3 < n_rows) v = *(const float4 *)p;
@@ -89,82 +91,100 @@ __device__ __forceinline__ void fetch_tile(TileRegs<ROWS_ALONG_K> &t, const floa
   }
 }
 
-template <bool ROWS_ALONG_K>
-__device__ __forceinline__ void stage_tile(const TileRegs<ROWS_ALONG_K> &t, float *S, int tid) {
+template <bool ROWS_ALONG_K, int BK>
+__device__ __forceinline__ void stage_tile(const TileRegs<BK> &t, float *S, int tid) {
+  constexpr int LD = BK + 1;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < BK / 16; ++h) {
+    const int i = tid + 256 * h;
     const float4 v = t.v[h];
     if (!ROWS_ALONG_K) {
-      float *d = S + ((tid >> 3) + 32 * h) * FC_LD + 4 * (tid & 7);
+      float *d = S + (i / (BK / 4)) * LD + 4 * (i % (BK / 4));
       d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
     } else {
-      const int k = (tid >> 4) + 16 * h, r = 4 * (tid & 15);
-      S[(r + 0) * FC_LD + k] = v.x;
-      S[(r + 1) * FC_LD + k] = v.y;
-      S[(r + 2) * FC_LD + k] = v.z;
-      S[(r + 3) * FC_LD + k] = v.w;
+      const int k = i / 16, r = 4 * (i % 16);
+      S[(r + 0) * LD + k] = v.x;
+      S[(r + 1) * LD + k] = v.y;
+      S[(r + 2) * LD + k] = v.z;
+      S[(r + 3) * LD + k] = v.w;
     }
   }
 }
 
 // FORM 0: A [M][K], B [N][K];  FORM 1: A [M][K], B [K][N];  FORM 2: A [K][M], B [K][N]
-template <int FORM>
+// Workgroup tile 64 x (64 * NB): wave (wm, wn) owns rows wm * 32 .. + 32 and NB column blocks of 32 at
+// wn * 32 * NB (one A fragment feeds NB matrix instructions); the contraction walks BK at a time.
+template <int FORM, int BK, int NB>
 __global__ __launch_bounds__(256) void fc_gemm_kernel(FcArgs a, int vec_a, int vec_b) {
   constexpr bool A_T = FORM == 2, B_T = FORM != 0;
-  __shared__ float As[FC_T * FC_LD];
-  __shared__ float Bs[FC_T * FC_LD];
+  constexpr int LD = BK + 1;
+  extern __shared__ float fc_lds[];
+  float *As = fc_lds;                    // [64][LD]
+  float *Bs = fc_lds + FC_T * LD;        // [64 * NB][LD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
   // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the ids one XCD sees are
   // L, L + 8, L + 16, ...; they are mapped to CONSECUTIVE logical tiles = (split, n tile, m tile) with m fastest — the
   // workgroups that re-read the same B columns (skinny M: 4 m tiles) or the same K slice of both operands (split
-  // contraction: all tiles of a split) run next to each other on ONE XCD and hit in its L2 instead of going to HBM again.
+  // contraction: all tiles of a split) run next to each other on ONE XCD.  (Measured neutral on the shapes of the step:
+  // the re-reads already hit in the memory-side cache; kept because it costs nothing.)
   const int logical = (int)(blockIdx.x % 8) * a.per_xcd + (int)(blockIdx.x / 8);
   const int n_tiles = a.tiles_m * a.tiles_n;
   if (logical >= n_tiles * a.splits) return;
   const int split = logical / n_tiles, tile = logical - split * n_tiles;
-  const int m0 = (tile % a.tiles_m) * FC_T, n0 = (tile / a.tiles_m) * FC_T;
-  const int steps = (a.K + FC_BK - 1) / FC_BK;
+  const int m0 = (tile % a.tiles_m) * FC_T, n0 = (tile / a.tiles_m) * FC_T * NB;
+  const int steps = (a.K + BK - 1) / BK;
   const int s_lo = split * a.steps_per_split;
   const int s_hi = min(steps, s_lo + a.steps_per_split);
-  f32x16 acc;
+  f32x16 acc[NB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  TileRegs<A_T> ra;
-  TileRegs<B_T> rb;
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  TileRegs<BK> ra, rb[NB];
   if (s_lo < s_hi) {
-    fetch_tile<A_T>(ra, a.A, a.lda, m0, a.M, s_lo * FC_BK, a.K, tid, vec_a != 0);
-    fetch_tile<B_T>(rb, a.B, a.ldb, n0, a.N, s_lo * FC_BK, a.K, tid, vec_b != 0);
+    fetch_tile<A_T, BK>(ra, a.A, a.lda, m0, a.M, s_lo * BK, a.K, tid, vec_a != 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) fetch_tile<B_T, BK>(rb[b], a.B, a.ldb, n0 + 64 * b, a.N, s_lo * BK, a.K, tid, vec_b != 0);
   }
   for (int s = s_lo; s < s_hi; ++s) {
     __syncthreads();                               // the previous step's fragments have been read
-    stage_tile<A_T>(ra, As, tid);
-    stage_tile<B_T>(rb, Bs, tid);
+    stage_tile<A_T, BK>(ra, As, tid);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) stage_tile<B_T, BK>(rb[b], Bs + 64 * b * LD, tid);
     __syncthreads();
     if (s + 1 < s_hi) {                            // in flight under the MFMAs
-      fetch_tile<A_T>(ra, a.A, a.lda, m0, a.M, (s + 1) * FC_BK, a.K, tid, vec_a != 0);
-      fetch_tile<B_T>(rb, a.B, a.ldb, n0, a.N, (s + 1) * FC_BK, a.K, tid, vec_b != 0);
-    }
-    const float *pa = As + (wm * 32 + lr) * FC_LD + lh;
-    const float *pb = Bs + (wn * 32 + lr) * FC_LD + lh;
+      fetch_tile<A_T, BK>(ra, a.A, a.lda, m0, a.M, (s + 1) * BK, a.K, tid, vec_a != 0);
 #pragma unroll
-    for (int k = 0; k < FC_BK; k += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+      for (int b = 0; b < NB; ++b)
+        fetch_tile<B_T, BK>(rb[b], a.B, a.ldb, n0 + 64 * b, a.N, (s + 1) * BK, a.K, tid, vec_b != 0);
+    }
+    const float *pa = As + (wm * 32 + lr) * LD + lh;
+    const float *pb = Bs + (wn * 32 * NB + lr) * LD + lh;
+#pragma unroll
+    for (int k = 0; k < BK; k += 2) {
+      const float av = pa[k];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pb[b * 32 * LD + k], acc[b], 0, 0, 0);
+    }
   }
   // C layout of the 32 x 32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const int col = n0 + wn * 32 + lr;
-  if (col >= a.N) return;
   const bool direct = a.splits == 1;
-  const float bv = (direct && a.bias) ? a.bias[col] : 0.f;
   float *out = direct ? a.C : a.C + (size_t)split * a.M * a.N;
   const int ldo = direct ? a.ldc : a.N;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (row < a.M) {
-      float v = acc[r] + bv;
-      if (direct && a.relu) v = fmaxf(v, 0.f);
-      out[(size_t)row * ldo + col] = v;
+  for (int b = 0; b < NB; ++b) {
+    const int col = n0 + wn * 32 * NB + b * 32 + lr;
+    if (col >= a.N) continue;
+    const float bv = (direct && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < a.M) {
+        float v = acc[b][r] + bv;
+        if (direct && a.relu) v = fmaxf(v, 0.f);
+        out[(size_t)row * ldo + col] = v;
+      }
     }
   }
 }
@@ -184,22 +204,50 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float *__restrict_
 }
 
 // how the contraction is split: a function of the shape only
-int fc_splits(int M, int N, int K) {
-  const long long tiles = (long long)dm_ceil_div(M, FC_T) * dm_ceil_div(N, FC_T);
-  const int steps = dm_ceil_div(K, FC_BK);
-  if (tiles >= 256 || steps < 16) return 1;
+int fc_splits(int M, int N, int K, int bk, int nb) {
+  const long long tiles = (long long)dm_ceil_div(M, FC_T) * dm_ceil_div(N, FC_T * nb);
+  const int steps = dm_ceil_div(K, bk);
+  if (tiles >= 256 || steps * bk < 512) return 1;
   long long want = (512 + tiles - 1) / tiles;            // ~2 workgroups per compute unit
-  const int most = steps / 8 > 0 ? steps / 8 : 1;         // at least 8 steps (256 of K) per split
+  const int most = steps * bk / 256 > 0 ? steps * bk / 256 : 1;   // at least 256 of K per split
   if (want > most) want = most;
   if (want > 64) want = 64;
   return want < 1 ? 1 : (int)want;
+}
+
+// (contraction step, column blocks per wave) by shape; DM_FC_VARIANT=<bk><nb> (e.g. 642) forces one for tools/bench_fc.py
+void fc_variant(int M, int N, int K, int *bk, int *nb) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char *e = getenv("DM_FC_VARIANT");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced > 0) {
+    *bk = forced / 10 == 64 ? 64 : 32;
+    *nb = forced % 10 == 2 ? 2 : 1;
+    return;
+  }
+  *bk = FC_DEFAULT_BK;
+  *nb = (N >= 128 && (long long)dm_ceil_div(M, FC_T) * dm_ceil_div(N, 128) >= 128) ? FC_DEFAULT_NB_LARGE : 1;
+  (void)K;
+}
+
+template <int FORM>
+void fc_launch(const FcArgs &a, int bk, int nb, int vec_a, int vec_b, dim3 grid, hipStream_t st) {
+  const size_t lds = (size_t)FC_T * (1 + nb) * (bk + 1) * sizeof(float);
+  if (bk == 32 && nb == 1) fc_gemm_kernel<FORM, 32, 1><<<grid, 256, lds, st>>>(a, vec_a, vec_b);
+  else if (bk == 32 && nb == 2) fc_gemm_kernel<FORM, 32, 2><<<grid, 256, lds, st>>>(a, vec_a, vec_b);
+  else if (bk == 64 && nb == 1) fc_gemm_kernel<FORM, 64, 1><<<grid, 256, lds, st>>>(a, vec_a, vec_b);
+  else fc_gemm_kernel<FORM, 64, 2><<<grid, 256, lds, st>>>(a, vec_a, vec_b);
 }
 
 }  // namespace
 
 extern "C" size_t dm_fc_gemm_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int s = fc_splits(M, N, K);
+  int bk, nb;
+  fc_variant(M, N, K, &bk, &nb);
+  const int s = fc_splits(M, N, K, bk, nb);
   return s > 1 ? dm_align((size_t)s * M * N * sizeof(float)) : 0;
 }
 
@@ -214,8 +262,10 @@ extern "C" int dm_fc_gemm(int form, const float *A, const float *B, const float 
   if (K > 0 && (lda < min_lda || ldb < min_ldb)) return DM_ERR_INVALID_ARG;
   FcArgs a;
   a.A = A, a.B = B, a.bias = bias, a.M = M, a.N = N, a.K = K, a.lda = lda, a.ldb = ldb, a.ldc = ldc, a.relu = relu;
-  const int steps = dm_ceil_div(K > 0 ? K : 1, FC_BK);
-  a.splits = K > 0 ? fc_splits(M, N, K) : 1;
+  int bk, nb;
+  fc_variant(M, N, K, &bk, &nb);
+  const int steps = dm_ceil_div(K > 0 ? K : 1, bk);
+  a.splits = K > 0 ? fc_splits(M, N, K, bk, nb) : 1;
   a.steps_per_split = dm_ceil_div(steps, a.splits);
   a.splits = dm_ceil_div(steps, a.steps_per_split);       // no empty split
   if (K == 0) a.steps_per_split = 0;
@@ -227,14 +277,14 @@ extern "C" int dm_fc_gemm(int form, const float *A, const float *B, const float 
   }
   const int vec_a = (lda % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
   const int vec_b = (ldb % 4 == 0 && ((uintptr_t)B & 15) == 0) ? 1 : 0;
-  a.tiles_m = dm_ceil_div(M, FC_T), a.tiles_n = dm_ceil_div(N, FC_T);
+  a.tiles_m = dm_ceil_div(M, FC_T), a.tiles_n = dm_ceil_div(N, FC_T * nb);
   const long long total = (long long)a.tiles_m * a.tiles_n * a.splits;
   if (total > 0x3fffffff) return DM_ERR_INVALID_ARG;
   a.per_xcd = (int)((total + 7) / 8);
   dim3 grid((unsigned)(a.per_xcd * 8), 1, 1);
-  if (form == 0) fc_gemm_kernel<0><<<grid, 256, 0, st>>>(a, vec_a, vec_b);
-  else if (form == 1) fc_gemm_kernel<1><<<grid, 256, 0, st>>>(a, vec_a, vec_b);
-  else fc_gemm_kernel<2><<<grid, 256, 0, st>>>(a, vec_a, vec_b);
+  if (form == 0) fc_launch<0>(a, bk, nb, vec_a, vec_b, grid, st);
+  else if (form == 1) fc_launch<1>(a, bk, nb, vec_a, vec_b, grid, st);
+  else fc_launch<2>(a, bk, nb, vec_a, vec_b, grid, st);
   DM_CHECK_LAUNCH();
   if (a.splits > 1) {
     const long long mn = (long long)M * N;
