@@ -27,7 +27,7 @@ def add_prefix(inputs, prefix):
 # attributes — the gradient-equality tests switch them (tests/test_ssl_gpu.py) — not environment switches.
 _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued before their chain inputs exist
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
-_2D_FIRST = False        # the last 2D module in front of its 3D neighbour: measured neutral (63.1 / 63.9 vs 63.3 / 63.7 ms, profiles/r06_ab_step_variants.txt): off
+_2D_INSIDE_3D = os.environ.get('DM_2D_INSIDE_3D', '1') == '1'     # (round 6 A/B) the last 2D module between the issue and the read-back of its 3D neighbour
 
 
 class _LaneDict(dict):
@@ -793,20 +793,26 @@ class SSL(nn.Module):
             cands = [m for m in unlab_modules if isinstance(m, HardPseudoLabel_2D)]
             users = [m for m in unlab_modules if str(getattr(m, 'ssl_obj_attr', '')).endswith('student.detector_2d')]
             last_2d = cands[-1] if cands and users and users[-1] is cands[-1] else None
-        if last_2d is not None and _2D_FIRST:
+        split3d = None
+        if last_2d is not None and _2D_INSIDE_3D:
             # Scheduling only: the student's last 2D module (+ its losses and the deferred 2D trunk backward, all on the
-            # 2D lane) is issued IN FRONT of its 3D neighbour when it does not read that one's outputs — the main lane
-            # is still working through the early-issued 3D trunk then, and afterwards nothing stands between the 3D
-            # module's read-back and the consistency glue that gates the last backward.
+            # 2D lane) is issued between the ISSUE of its 3D neighbour and that neighbour's read-back when it does not read
+            # the neighbour's outputs — the host issues it while the device works through the 3D heads, and nothing stands
+            # between the read-back and the consistency glue that gates the last backward.
             from .ssl_modules import Opd_HardPseudoLabel_3D
             i = unlab_modules.index(last_2d)
             prev = unlab_modules[i - 1] if i > 0 else None
             if isinstance(prev, Opd_HardPseudoLabel_3D) and prev.out_bboxes_key is not None and \
                     not str(last_2d.target_bboxes_key).startswith(prev.target_batch_dict_key + '.' + prev.out_bboxes_key):
-                unlab_modules[i - 1], unlab_modules[i] = last_2d, prev
+                split3d = prev
         for m in unlab_modules:
-            if m is last_2d:
-                unlab_dict = self._early_2d_backward(lanes, m, unlab_dict, curr_ssl_weight)
+            if m is split3d:
+                unlab_dict = lanes.run(m, self, unlab_dict, method='forward_issue')
+                unlab_dict = self._early_2d_backward(lanes, last_2d, unlab_dict, curr_ssl_weight)
+                unlab_dict = lanes.run(m, self, unlab_dict, method='forward_finish')
+            elif m is last_2d:
+                if split3d is None:
+                    unlab_dict = self._early_2d_backward(lanes, m, unlab_dict, curr_ssl_weight)
             else:
                 unlab_dict = self._run_and_backprop(run, m, unlab_dict, early, curr_ssl_weight)
         if lanes is not None:

@@ -232,7 +232,11 @@ class Opd_HardPseudoLabel_3D(object):
         batch = detector._base_batch(cur['points'], cur['img_metas'])
         cur['_early.trunk3d'] = _Early(model.run_modules(batch, until=model.label_independent_until()))
 
-    def forward(self, ssl_obj, batch_dict):
+    def forward_issue(self, ssl_obj, batch_dict):
+        """forward() up to the read-back of the student's own boxes (`out_bboxes_key`): pseudo labels, the rest of the
+        pass, the losses, and the device half of post_processing.  SSL.forward_train issues the student's last 2D module
+        between this and forward_finish when the two are independent — the host then does not sit in the read-back while
+        the 2D lane has nothing queued."""
         detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
         cur = mlvl_get(batch_dict, self.target_batch_dict_key)
         boxes, labels = _threshold_pseudo(
@@ -250,9 +254,26 @@ class Opd_HardPseudoLabel_3D(object):
         batch_dict = _accumulate(ssl_obj, batch_dict, add_prefix(dict(loss=loss.mean()), self.name),
                                  prefer_sup=False)
         if self.out_bboxes_key is not None:
-            pred_dicts, _ = detector.model.post_processing(batch, no_nms=self.no_nms)
-            cur[self.out_bboxes_key] = _pred_dicts_to_tuples(pred_dicts)
+            if hasattr(detector.model, 'post_processing_issue'):
+                cur['_pending.' + self.out_bboxes_key] = _Early(('state', detector.model.post_processing_issue(
+                    batch, no_nms=self.no_nms)))
+            else:
+                cur['_pending.' + self.out_bboxes_key] = _Early(('done', detector.model.post_processing(
+                    batch, no_nms=self.no_nms)))
         return batch_dict
+
+    def forward_finish(self, ssl_obj, batch_dict):
+        if self.out_bboxes_key is None:
+            return batch_dict
+        detector = mlvl_getattr(ssl_obj, self.ssl_obj_attr)
+        cur = mlvl_get(batch_dict, self.target_batch_dict_key)
+        kind, value = cur.pop('_pending.' + self.out_bboxes_key).value
+        pred_dicts, _ = detector.model.post_processing_finish(value) if kind == 'state' else value
+        cur[self.out_bboxes_key] = _pred_dicts_to_tuples(pred_dicts)
+        return batch_dict
+
+    def forward(self, ssl_obj, batch_dict):
+        return self.forward_finish(ssl_obj, self.forward_issue(ssl_obj, batch_dict))
 
 
 @SSL_MODULES.register_module()
