@@ -510,7 +510,8 @@ def watched_single_gpu_run(args):
         os.close(fd)
         os.remove(hb)                 # it exists from the child's first beat on
         env = dict(os.environ, DM_BENCH_CHILD='1', DM_BENCH_HEARTBEAT=hb)
-        lim_start, lim_stall = (first, first) if (attempt == 0 and first) else (startup, stall)
+        # (test hook: the start limit stays generous — the child's `import torch` alone takes seconds on a busy host)
+        lim_start, lim_stall = (max(first * 5, 10.0), first) if (attempt == 0 and first) else (startup, stall)
         if attempt:
             env.update(DM_TWO_LANES='0', DM_BENCH_NOTE='first attempt (three stream lanes) made no progress for %d s and was '
                        'killed; this line is the one-lane order of round 4' % int(first or stall))

@@ -620,7 +620,8 @@ class _RunnerBase(object):
         self._epoch = 0
         self.mode = None
         self.outputs = None
-        self.log_buffer = dict()
+        self._lazy_logs = []
+        self._log_buffer = dict()
 
     iter = property(lambda self: self._iter)
     epoch = property(lambda self: self._epoch)
@@ -709,10 +710,29 @@ class _RunnerBase(object):
     def _after_step(self, outputs):
         if not isinstance(outputs, dict):
             raise TypeError('model.train_step() must return a dict')
-        if 'log_vars' in outputs:
-            for k, v in outputs['log_vars'].items():
-                self.log_buffer.setdefault(k, []).append(v)
         self.outputs = outputs
+        lv = outputs.get('log_vars')
+        if lv is not None and getattr(lv, '_pending', None) is not None:
+            self._lazy_logs.append(lv)           # values not computed yet (LazyLogVars): buffered when somebody reads
+        elif lv is not None:
+            buf = self._log_buffer
+            for k, v in lv.items():
+                buf.setdefault(k, []).append(v)
+
+    @property
+    def log_buffer(self):
+        """{key: [value per iteration]}; lazily parsed log_vars of finished iterations are folded in on access."""
+        if self._lazy_logs:
+            pending, self._lazy_logs = self._lazy_logs, []
+            for lv in pending:
+                for k, v in lv.items():
+                    self._log_buffer.setdefault(k, []).append(v)
+        return self._log_buffer
+
+    @log_buffer.setter
+    def log_buffer(self, value):
+        self._lazy_logs = []
+        self._log_buffer = value
 
 
 @RUNNERS.register_module()

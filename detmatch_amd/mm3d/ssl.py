@@ -27,7 +27,7 @@ def add_prefix(inputs, prefix):
 # attributes — the gradient-equality tests switch them (tests/test_ssl_gpu.py) — not environment switches.
 _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued before their chain inputs exist
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
-_2D_INSIDE_3D = os.environ.get('DM_2D_INSIDE_3D', '1') == '1'     # (round 6 A/B) the last 2D module between the issue and the read-back of its 3D neighbour
+_2D_INSIDE_3D = True      # the last 2D module between the issue and the read-back of its 3D neighbour: 60.2-60.5 against 61.4-62.0 ms (profiles/r06_ab_step_variants.txt)
 
 
 class _LaneDict(dict):
@@ -506,8 +506,11 @@ class SSL(nn.Module):
         vis = losses.pop('vis', dict())
         log_vars = losses.pop('log_vars', dict())
         loss, log_vars_ = self._parse_losses(losses)
-        log_vars.update(log_vars_)
-        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']), vis=vis)
+        # (ssl.py:249: log_vars.update(log_vars_) — the parsed values win; kept lazy: base_detector.LazyLogVars)
+        if log_vars:
+            merged = dict(log_vars)
+            log_vars_.update({k: v for k, v in merged.items() if k not in losses})
+        return dict(loss=loss, log_vars=log_vars_, num_samples=len(data['img_metas']), vis=vis)
 
     def forward(self, return_loss=True, **kwargs):
         if return_loss:
