@@ -481,6 +481,16 @@ def blas_mm(a, b):
         return torch.mm(a, b)
 
 
+# events behind gradient kernels that were issued on a side stream (dense_chain.SIDE_WGRAD): whoever reads the gradients
+# next (FlatGradDDP.collect / finish) makes its stream wait for them first
+PENDING_GRAD_EVENTS = []
+
+
+def wait_pending_grads():
+    while PENDING_GRAD_EVENTS:
+        torch.cuda.current_stream().wait_event(PENDING_GRAD_EVENTS.pop())
+
+
 _AUX = {}
 
 

@@ -543,8 +543,21 @@ class DenseChainBuilder(object):
 
     def build(self):
         needs_bwd = self.training and any(self.out_diff)
+        self.bwd_d = self.bwd_w = None
         if needs_bwd:
             self._build_backward()
+            # the same table in two halves (SIDE_WGRAD): everything on the gradient's way back to the inputs, and the
+            # weight / bias gradients — nothing of the first half reads what the second writes, and a layer's output
+            # gradient is final before the layer's own backward ops are emitted, so the second half may run after the
+            # whole first half, on another stream
+            w_ops = [op for op in self.bwd.ops if op[2] in _WGRAD_OPS]
+            if w_ops and len(w_ops) < len(self.bwd.ops):
+                self.bwd_d, self.bwd_w = Program(self.name + '.bwd_d'), Program(self.name + '.bwd_w')
+                for half, keep_w in ((self.bwd_d, False), (self.bwd_w, True)):
+                    half.slot_names = list(self.bwd.slot_names)
+                    half.ops = [op for op in self.bwd.ops if (op[2] in _WGRAD_OPS) == keep_w]
+                    half.keep, half.ws_bytes = self.bwd.keep, self.bwd.ws_bytes
+                    half.finalize()
             self.bwd.finalize()
         else:
             self.bwd = None
@@ -554,6 +567,12 @@ class DenseChainBuilder(object):
 
 
 LOAD_HOOKED = set()
+_WGRAD_OPS = ('dm_dconv_wgrad', 'dm_colsum_f32')
+# Weight-gradient half of a chain's backward on the side stream (_lib.aux_stream), underneath the rest of the backward
+# pass on the main lane.  Scheduling only.  Off unless the driver of the iteration switches it on (pcdet/workload.py: the
+# gradients are then read by FlatGradDDP.collect, which waits for _lib.PENDING_GRAD_EVENTS first; a caller that reads
+# `.grad` right after backward() must leave it off).
+SIDE_WGRAD = [False]
 
 
 def _watch_loads(modules):
@@ -571,6 +590,8 @@ class DenseChain(object):
     def __init__(self, b):
         self.name, self.device = b.name, b.device
         self.fwd, self.bwd, self.weights = b.fwd, b.bwd, b.weights
+        self.bwd_d, self.bwd_w = b.bwd_d, b.bwd_w
+        self.bws_index = b.bws.slot - 1 if b.bwd is not None else None      # position of the scratch pointer in the values
         self.fwd_bytes = b.fa.size
         self.inputs, self.outputs, self.out_diff = b.inputs, b.outputs, b.out_diff
         self.bn_modules = b.bn_modules
@@ -642,8 +663,26 @@ class DenseChain(object):
             g = dense_conv._cl(g)
             gs.append(g)
             gptr.append(g.data_ptr())
-        self.bwd.run([arena.data_ptr(), garena.data_ptr(), 0 if ws is None else ws.data_ptr()] +
-                     [x.data_ptr() for x in xs] + gptr)
+        vals = [arena.data_ptr(), garena.data_ptr(), 0 if ws is None else ws.data_ptr()] + [x.data_ptr() for x in xs] + gptr
+        if SIDE_WGRAD[0] and self.bwd_w is not None and not _lib.off_main_lane():
+            self.bwd_d.run(vals)
+            main = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side = _lib.aux_stream(self.device)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                ws2 = _lib.workspace(self.bwd.ws_bytes, self.device, 'chain') if self.bwd.ws_bytes else None
+                vals2 = list(vals)
+                vals2[self.bws_index] = 0 if ws2 is None else ws2.data_ptr()
+                self.bwd_w.run(vals2)
+                done = torch.cuda.Event()
+                done.record(side)
+            for t in [arena, garena] + list(xs) + gs:
+                t.record_stream(side)
+            _lib.PENDING_GRAD_EVENTS.append(done)
+        else:
+            self.bwd.run(vals)
         f = garena.view(torch.float32)
         gin = []
         for b, ref in zip(self.inputs, self.input_grad_refs):
