@@ -481,7 +481,7 @@ def blas_mm(a, b):
         return torch.mm(a, b)
 
 
-# events behind gradient kernels that were issued on a side stream (dense_chain.SIDE_WGRAD): whoever reads the gradients
+# events behind gradient kernels that were issued on a side stream (chain.SIDE_WGRAD): whoever reads the gradients
 # next (FlatGradDDP.collect / finish) makes its stream wait for them first
 PENDING_GRAD_EVENTS = []
 

@@ -235,6 +235,53 @@ class Program(object):
             _lib.check(rc, 'chain %s, op %d (%s)' % (self.name, i, what))
 
 
+# Weight-gradient half of a chain's backward on the side stream (_lib.aux_stream), underneath the rest of the backward pass
+# on the main lane.  Scheduling only.  Off unless the driver of the iteration switches it on for its length
+# (IterBasedSSLRunner.train: the gradients are then read by FlatGradDDP.collect, which waits for
+# _lib.PENDING_GRAD_EVENTS first); a caller that reads `.grad` right after backward() never sees it on.
+SIDE_WGRAD = [False]
+
+
+def split_program(prog, names):
+    """The table of `prog` (built, not necessarily finalized) in two halves sharing its slot layout: (ops NOT named in
+    `names`, ops named in `names`), both finalized — or (None, None) when one half would be empty.  The caller guarantees
+    that nothing of the first half reads what the second writes and that the second may run after the whole first."""
+    picked = [op for op in prog.ops if op[2] in names]
+    if not picked or len(picked) == len(prog.ops):
+        return None, None
+    halves = []
+    for tag, keep in (('.a', False), ('.b', True)):
+        half = Program(prog.name + tag)
+        half.slot_names = list(prog.slot_names)
+        half.ops = [op for op in prog.ops if (op[2] in names) == keep]
+        half.keep, half.ws_bytes = prog.keep, prog.ws_bytes
+        halves.append(half.finalize())
+    return halves[0], halves[1]
+
+
+def run_split(first, second, vals, ws_index, ws_bytes, device, tensors):
+    """`first` on the current stream, `second` behind it on the side stream with a scratch region of its own
+    (vals[ws_index]); `tensors`: everything the tables address (kept alive for the side stream).  The event behind the
+    second half goes to _lib.PENDING_GRAD_EVENTS."""
+    first.run(vals)
+    main = torch.cuda.current_stream(device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side = _lib.aux_stream(device)
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        ws2 = _lib.workspace(ws_bytes, device, 'chain') if ws_bytes else None
+        vals2 = list(vals)
+        vals2[ws_index] = 0 if ws2 is None else ws2.data_ptr()
+        second.run(vals2)
+        done = torch.cuda.Event()
+        done.record(side)
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    _lib.PENDING_GRAD_EVENTS.append(done)
+
+
 def workspace(prog, device):
     """The scratch region of a program run on the current stream / thread (None if it needs none)."""
     if not prog.ws_bytes:

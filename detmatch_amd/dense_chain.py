@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib, bn_relu, dense_conv
+from . import chain as _chain
 from .chain import DeviceTable, Layout, Program, S
 
 _PACK_DESC = np.dtype([('src', '<u8'), ('dst', '<u8'), ('scale_n', '<u8'), ('scale_k', '<u8'),
@@ -550,14 +551,8 @@ class DenseChainBuilder(object):
             # weight / bias gradients — nothing of the first half reads what the second writes, and a layer's output
             # gradient is final before the layer's own backward ops are emitted, so the second half may run after the
             # whole first half, on another stream
-            w_ops = [op for op in self.bwd.ops if op[2] in _WGRAD_OPS]
-            if w_ops and len(w_ops) < len(self.bwd.ops):
-                self.bwd_d, self.bwd_w = Program(self.name + '.bwd_d'), Program(self.name + '.bwd_w')
-                for half, keep_w in ((self.bwd_d, False), (self.bwd_w, True)):
-                    half.slot_names = list(self.bwd.slot_names)
-                    half.ops = [op for op in self.bwd.ops if (op[2] in _WGRAD_OPS) == keep_w]
-                    half.keep, half.ws_bytes = self.bwd.keep, self.bwd.ws_bytes
-                    half.finalize()
+            from .chain import split_program
+            self.bwd_d, self.bwd_w = split_program(self.bwd, _WGRAD_OPS)
             self.bwd.finalize()
         else:
             self.bwd = None
@@ -568,11 +563,6 @@ class DenseChainBuilder(object):
 
 LOAD_HOOKED = set()
 _WGRAD_OPS = ('dm_dconv_wgrad', 'dm_colsum_f32')
-# Weight-gradient half of a chain's backward on the side stream (_lib.aux_stream), underneath the rest of the backward
-# pass on the main lane.  Scheduling only.  Off unless the driver of the iteration switches it on (pcdet/workload.py: the
-# gradients are then read by FlatGradDDP.collect, which waits for _lib.PENDING_GRAD_EVENTS first; a caller that reads
-# `.grad` right after backward() must leave it off).
-SIDE_WGRAD = [False]
 
 
 def _watch_loads(modules):
@@ -664,23 +654,9 @@ class DenseChain(object):
             gs.append(g)
             gptr.append(g.data_ptr())
         vals = [arena.data_ptr(), garena.data_ptr(), 0 if ws is None else ws.data_ptr()] + [x.data_ptr() for x in xs] + gptr
-        if SIDE_WGRAD[0] and self.bwd_w is not None and not _lib.off_main_lane():
-            self.bwd_d.run(vals)
-            main = torch.cuda.current_stream(self.device)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            side = _lib.aux_stream(self.device)
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                ws2 = _lib.workspace(self.bwd.ws_bytes, self.device, 'chain') if self.bwd.ws_bytes else None
-                vals2 = list(vals)
-                vals2[self.bws_index] = 0 if ws2 is None else ws2.data_ptr()
-                self.bwd_w.run(vals2)
-                done = torch.cuda.Event()
-                done.record(side)
-            for t in [arena, garena] + list(xs) + gs:
-                t.record_stream(side)
-            _lib.PENDING_GRAD_EVENTS.append(done)
+        if _chain.SIDE_WGRAD[0] and self.bwd_w is not None and not _lib.off_main_lane():
+            _chain.run_split(self.bwd_d, self.bwd_w, vals, self.bws_index, self.bwd.ws_bytes, self.device,
+                             [arena, garena] + list(xs) + gs)
         else:
             self.bwd.run(vals)
         f = garena.view(torch.float32)

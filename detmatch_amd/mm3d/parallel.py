@@ -248,7 +248,7 @@ class FlatGradDDP(nn.Module):
         """collect mode: add the gradients autograd has produced so far into the arena (batched
         multi-tensor adds) and release them.  Call after every backward pass."""
         from .. import _lib
-        _lib.wait_pending_grads()          # weight gradients issued on the side stream (dense_chain.SIDE_WGRAD)
+        _lib.wait_pending_grads()          # weight gradients issued on the side stream (chain.SIDE_WGRAD)
         if self.mode != 'collect':
             return
         ps = [p for p in self.order if p.grad is not None and p.grad.data_ptr() != self._view[id(p)].data_ptr()]

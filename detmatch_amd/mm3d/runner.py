@@ -825,17 +825,17 @@ class IterBasedSSLRunner(_RunnerBase):
         if _ITER_SYNC and torch.cuda.is_available():
             torch.cuda.current_stream().synchronize()
         # weight-gradient halves of the chained backward passes on the side stream for the length of this iteration
-        # (dense_chain.SIDE_WGRAD; scheduling only): needs the lanes and a gradient arena that is filled by collect(),
+        # (chain.SIDE_WGRAD; scheduling only): needs the lanes and a gradient arena that is filled by collect(),
         # which waits for those kernels before it reads what they wrote
-        from .. import dense_chain
+        from .. import chain as _chain
         inner = _inner(self.model)
-        dense_chain.SIDE_WGRAD[0] = bool(getattr(inner, 'side_wgrad', False) and getattr(inner, 'two_lanes', False)
+        _chain.SIDE_WGRAD[0] = bool(getattr(inner, 'side_wgrad', False) and getattr(inner, 'two_lanes', False)
                                          and getattr(self.model, 'mode', None) == 'collect')
         try:
             self._after_step(self.model.train_step(data_batch, self.optimizer, **kwargs))
             self.call_hook('after_train_iter')
         finally:
-            dense_chain.SIDE_WGRAD[0] = False
+            _chain.SIDE_WGRAD[0] = False
         if self._ahead is not None:
             prefetch(self._ahead[0], self._ahead[1], tag='ahead%d_' % (self.iter & 1))
         self._inner_iter += 1

@@ -140,6 +140,7 @@ class SAChain(object):
         self.fwd_bytes = fa.size
         fwd.finalize()
         self.bwd = None
+        self.bwd_d = self.bwd_w = None
         if train:
             self._build_backward(width)
         W.finalize()
@@ -207,6 +208,10 @@ class SAChain(object):
         if self.feat_grad:
             bwd.call('dm_add_mask_f32', gfeat, gfeat2, None, gfeat, nc_src, ST)
         self.bwd_bytes = ba.size
+        # weight gradients (+ the two copies that unpad the first layer's) as a second half: chain.SIDE_WGRAD
+        from .chain import split_program
+        self.bwd_d, self.bwd_w = split_program(bwd, ('dm_tall_wgrad', 'dm_copy2d_f32'))
+        self.bws_index = bws.slot - 1
         bwd.finalize()
 
     def valid(self):
@@ -231,9 +236,15 @@ class SAChain(object):
         ws = _lib.workspace(self.bwd.ws_bytes, self.device, 'chain') if self.bwd.ws_bytes else None
         gfeat = torch.empty((2, n_src if self.feat_grad else 1, self.c), dtype=torch.float32, device=self.device)
         gout = gout.contiguous()
-        self.bwd.run([arena.data_ptr(), garena.data_ptr(), 0 if ws is None else ws.data_ptr(), xyz_cnt.data_ptr(),
-                      new_cnt.data_ptr(), n_src, n_src * self.c, gout.data_ptr(), gfeat.data_ptr(),
-                      gfeat.data_ptr() + 4 * n_src * self.c])
+        vals = [arena.data_ptr(), garena.data_ptr(), 0 if ws is None else ws.data_ptr(), xyz_cnt.data_ptr(),
+                new_cnt.data_ptr(), n_src, n_src * self.c, gout.data_ptr(), gfeat.data_ptr(),
+                gfeat.data_ptr() + 4 * n_src * self.c]
+        from . import chain as _chain
+        if _chain.SIDE_WGRAD[0] and self.bwd_w is not None and not _lib.off_main_lane():
+            _chain.run_split(self.bwd_d, self.bwd_w, vals, self.bws_index, self.bwd.ws_bytes, self.device,
+                             [arena, garena, gout, xyz_cnt, new_cnt])
+        else:
+            self.bwd.run(vals)
         f = garena.view(torch.float32)
         grads = [f[ref.off // 4:ref.off // 4 + numel].view(p.shape) for p, (ref, numel) in zip(self.params, self.param_refs)]
         return (gfeat[0] if self.feat_grad else None), grads

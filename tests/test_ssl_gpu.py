@@ -646,3 +646,28 @@ def test_shipped_order_soak_300_iterations(dev):
     assert torch.isfinite(loss) and dt < 120, dt
     assert _lib.OWN_LINEAR_CALLS[0] + _lib.FC_GEMM_CALLS[0] - own >= 300 * 60
     assert _lib.BLAS_TURNS[1] == edges, 'vendor GEMMs were issued on two lanes'
+
+
+def test_side_stream_weight_gradients_do_not_change_gradients(dev):
+    """chain.SIDE_WGRAD (the weight-gradient halves of the chained dense / set-abstraction backward passes on the side
+    stream, read by FlatGradDDP.collect behind their events): same accumulated gradient, same losses as with every
+    backward kernel on the main lane."""
+    from detmatch_amd import chain
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    out = []
+    for side in (True, False):
+        wl = DetMatchTrainWorkload(2, dev)
+        wl.model.side_wgrad = side
+        assert wl.model.two_lanes and wl.ddp.mode == 'collect'
+        torch.manual_seed(321)
+        wl.step()
+        torch.cuda.synchronize()
+        assert not chain.SIDE_WGRAD[0]               # only for the length of an iteration
+        out.append((wl.ddp.flat.clone(), {k: float(v) for k, v in wl.last_log.items()}))
+        del wl
+    (ga, la), (gb, lb) = out
+    assert torch.isfinite(ga).all() and ga.abs().sum() > 0
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    rel = (ga - gb).norm() / gb.norm()
+    assert rel < 2e-3, float(rel)
