@@ -6,6 +6,8 @@ point_head, roi_head) and the `global_step` buffer follow the reference so that 
 dicts are interchangeable.
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -23,6 +25,33 @@ _MODULES = {
     'AnchorHeadSingle': AnchorHeadSingle, 'PointHeadSimple': PointHeadSimple,
     'PVRCNNHead': PVRCNNHead,
 }
+
+
+# the key-point encoder (pfe) beside the BEV backbone on the side stream (PVRCNN.run_modules; module switch of the
+# equality test)
+PFE_SIDE = [os.environ.get('DM_PFE_SIDE', '1') == '1']
+_PFE_OUT = ('point_features', 'point_features_before_fusion', 'point_coords', 'point_batch_cnt')
+
+
+def _on_device(batch_dict):
+    p = batch_dict.get('points')
+    return torch.is_tensor(p) and p.is_cuda
+
+
+def _record_tree(value, stream):
+    """record_stream for every device tensor of a (nested) value that another stream is about to read"""
+    if torch.is_tensor(value):
+        if value.is_cuda:
+            value.record_stream(stream)
+    elif hasattr(value, 'features') and hasattr(value, 'indices'):      # SparseConvTensor
+        _record_tree(value.features, stream)
+        _record_tree(value.indices, stream)
+    elif isinstance(value, dict):
+        for v in value.values():
+            _record_tree(v, stream)
+    elif isinstance(value, (list, tuple)):
+        for v in value:
+            _record_tree(v, stream)
 
 
 class PVRCNN(nn.Module):
@@ -130,13 +159,52 @@ class PVRCNN(nn.Module):
         todo = batch_dict.pop('_pending_modules', None)
         if todo is None:
             todo = list(self._order(batch_dict))
+        pfe, bev, head = getattr(self, 'pfe', None), getattr(self, 'backbone_2d', None), getattr(self, 'dense_head', None)
         while todo:
             cur_module = todo[0]
             if until is not None and cur_module is until:
                 batch_dict['_pending_modules'] = todo
                 return batch_dict
             todo.pop(0)
+            if PFE_SIDE[0] and self.training and cur_module is bev and todo and todo[0] is pfe and _on_device(batch_dict):
+                # The key-point encoder reads the sparse features, the raw points and the BEV map that goes INTO the BEV
+                # backbone — nothing the backbone produces — and only the point / RoI heads read what it writes
+                # (pv_rcnn.py:9-22 runs them one after the other because a module list has no other order).  So the
+                # encoder runs on the side stream beside the backbone's convolutions, and — autograd runs a node's
+                # backward on the stream of its forward — its backward beside the backbone's.  Scheduling only.
+                todo.pop(0)
+                batch_dict = self._bev_and_pfe(bev, pfe, batch_dict)
+                continue
+            ev = batch_dict.get('_pfe_done') if cur_module is not head else None
+            if ev is not None:                       # first reader of the encoder's outputs on this stream
+                main = torch.cuda.current_stream()
+                main.wait_event(ev)
+                for k in _PFE_OUT:
+                    if torch.is_tensor(batch_dict.get(k)):
+                        batch_dict[k].record_stream(main)
+                del batch_dict['_pfe_done']
             batch_dict = cur_module(batch_dict)
+        return batch_dict
+
+    def _bev_and_pfe(self, bev, pfe, batch_dict):
+        from .. import _lib
+        dev = batch_dict['points'].device
+        main = torch.cuda.current_stream(dev)
+        side = _lib.aux_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        feats = {}
+        for k in ('spatial_features', 'points', 'voxel_coords'):
+            if torch.is_tensor(batch_dict.get(k)):
+                feats[k] = batch_dict[k]
+        batch_dict = bev(batch_dict)                 # one chained call: the main lane has its work first
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            _record_tree([feats, batch_dict.get('multi_scale_3d_features')], side)
+            batch_dict = pfe(batch_dict)
+            done = torch.cuda.Event()
+            done.record(side)
+        batch_dict['_pfe_done'] = done
         return batch_dict
 
     def label_independent_until(self):

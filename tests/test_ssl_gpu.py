@@ -671,3 +671,29 @@ def test_side_stream_weight_gradients_do_not_change_gradients(dev):
         assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
     rel = (ga - gb).norm() / gb.norm()
     assert rel < 2e-3, float(rel)
+
+
+def test_key_point_encoder_on_the_side_stream_does_not_change_gradients(dev):
+    """pcdet/detector.py:PFE_SIDE (the key-point encoder beside the BEV backbone, forward and backward): same accumulated
+    gradient and losses as the module list's own order."""
+    from detmatch_amd.pcdet import detector
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    out = []
+    saved = detector.PFE_SIDE[0]
+    try:
+        for side in (True, False):
+            detector.PFE_SIDE[0] = side
+            wl = DetMatchTrainWorkload(2, dev)
+            torch.manual_seed(321)
+            wl.step()
+            torch.cuda.synchronize()
+            out.append((wl.ddp.flat.clone(), {k: float(v) for k, v in wl.last_log.items()}))
+            del wl
+    finally:
+        detector.PFE_SIDE[0] = saved
+    (ga, la), (gb, lb) = out
+    assert torch.isfinite(ga).all() and ga.abs().sum() > 0
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    rel = (ga - gb).norm() / gb.norm()
+    assert rel < 2e-3, float(rel)
