@@ -654,7 +654,7 @@ class DenseChain(object):
             gs.append(g)
             gptr.append(g.data_ptr())
         vals = [arena.data_ptr(), garena.data_ptr(), 0 if ws is None else ws.data_ptr()] + [x.data_ptr() for x in xs] + gptr
-        if _chain.SIDE_WGRAD[0] and self.bwd_w is not None and not _lib.off_main_lane():
+        if _chain.SIDE_WGRAD[0] and self.bwd_w is not None and _lib.raw_stream() != _lib.aux_stream(self.device).cuda_stream:
             _chain.run_split(self.bwd_d, self.bwd_w, vals, self.bws_index, self.bwd.ws_bytes, self.device,
                              [arena, garena] + list(xs) + gs)
         else:

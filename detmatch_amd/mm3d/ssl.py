@@ -27,6 +27,7 @@ def add_prefix(inputs, prefix):
 # attributes — the gradient-equality tests switch them (tests/test_ssl_gpu.py) — not environment switches.
 _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued before their chain inputs exist
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
+_TRUNK_ON_2D_LANE = os.environ.get('DM_TRUNK_ON_2D_LANE', '1') == '1'     # (round 6 A/B, see forward_train)
 _2D_INSIDE_3D = True      # the last 2D module between the issue and the read-back of its 3D neighbour: 60.2-60.5 against 61.4-62.0 ms (profiles/r06_ab_step_variants.txt)
 
 
@@ -175,8 +176,8 @@ class _Lanes(object):
         for s in self.streams[1:]:
             s.wait_stream(self.main)
 
-    def run(self, module, ssl_obj, batch_dict, method='forward'):
-        lane = self.lane_of(module)
+    def run(self, module, ssl_obj, batch_dict, method='forward', lane=None):
+        lane = self.lane_of(module) if lane is None else lane
         self.current, self.pending = lane, []
         with torch.cuda.stream(self.stream(lane)):
             if self.rng is not None:
@@ -760,6 +761,10 @@ class SSL(nn.Module):
         curr_ssl_weight = self._get_curr_ssl_weight()
         for m in self.lab_ssl_modules:
             lab_dict = self._run_and_backprop(run, m, lab_dict, early, curr_ssl_weight)
+        lab_done = None
+        if lanes is not None:
+            lab_done = torch.cuda.Event()           # the labeled forward passes of the main lane are behind this
+            lab_done.record(lanes.main)
         if lanes is not None:
             lanes.join(lab_dict['sup_losses'], lab_dict['ssl_losses'])
         if getattr(self, 'early_backward', False) and torch.is_grad_enabled():
@@ -783,7 +788,16 @@ class SSL(nn.Module):
             # issued now, in chain order, so that the read-backs further down find the device done.
             for m in unlab_modules:
                 if hasattr(m, 'issue_early'):
-                    if lanes is not None:
+                    if lanes is not None and _TRUNK_ON_2D_LANE and lanes.mode == 'branches' and lab_done is not None and \
+                            getattr(m, 'trunk_may_change_lane', False):
+                        # Scheduling only: the label-independent trunk of the student's unlabeled 3D pass on the 2D lane
+                        # (idle between the labeled 2D pass and the pseudo-label 2D module), beside the supervised
+                        # backward on the main lane instead of behind it.  It reads the student's BatchNorm statistics
+                        # after the labeled forward (the event), as in the one-lane order; its backward runs where its
+                        # forward ran.
+                        lanes.stream(1).wait_event(lab_done)
+                        lanes.run(m, self, unlab_dict, method='issue_early', lane=1)
+                    elif lanes is not None:
                         lanes.run(m, self, unlab_dict, method='issue_early')
                     else:
                         rng.enter(m)

@@ -188,6 +188,8 @@ class Opd_HardPseudoLabel_3D(object):
     training forward on them, and optionally keep the student's (no-NMS) boxes."""
     takes_masked = True       # reads box lists through plain() / handles Masked entries itself
 
+    trunk_may_change_lane = True       # issue_early leaves an event behind its trunk: forward_issue may run on another stream
+
     def __init__(self, score_thr, cls_includes_bg_pred=False, loss_detach_keys=[],
                  ssl_obj_attr='student', target_bboxes_key='tea.placeholder',
                  target_batch_dict_key='stu', name='hard_pseudo_3d', weight=1,
@@ -230,7 +232,14 @@ class Opd_HardPseudoLabel_3D(object):
             return
         cur = mlvl_get(batch_dict, self.target_batch_dict_key)
         batch = detector._base_batch(cur['points'], cur['img_metas'])
-        cur['_early.trunk3d'] = _Early(model.run_modules(batch, until=model.label_independent_until()))
+        batch = model.run_modules(batch, until=model.label_independent_until())
+        where = None
+        if cur['points'][0].is_cuda:               # forward_issue may run on another stream (SSL: trunk on the 2D lane)
+            stream = torch.cuda.current_stream(cur['points'][0].device)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            where = (stream, ev)
+        cur['_early.trunk3d'] = _Early((batch, where))
 
     def forward_issue(self, ssl_obj, batch_dict):
         """forward() up to the read-back of the student's own boxes (`out_bboxes_key`): pseudo labels, the rest of the
@@ -246,7 +255,14 @@ class Opd_HardPseudoLabel_3D(object):
             dense=hasattr(detector, 'add_gt'))
         early = cur.pop('_early.trunk3d', None) if isinstance(cur, dict) else None
         if early is not None:
-            batch = detector.add_gt(early.value, cur['points'], boxes, labels)
+            trunk, where = early.value
+            if where is not None:
+                here = torch.cuda.current_stream(cur['points'][0].device)
+                if here != where[0]:               # issued on another lane: order it, keep the allocator informed
+                    from ..pcdet.detector import _record_tree
+                    here.wait_event(where[1])
+                    _record_tree({k: v for k, v in trunk.items() if k != '_pending_modules'}, here)
+            batch = detector.add_gt(trunk, cur['points'], boxes, labels)
         else:
             batch = detector.train_to_openpcdet(cur['points'], cur['img_metas'], boxes, labels)
         batch = detector.model.run_modules(batch)

@@ -240,7 +240,7 @@ class SAChain(object):
                 new_cnt.data_ptr(), n_src, n_src * self.c, gout.data_ptr(), gfeat.data_ptr(),
                 gfeat.data_ptr() + 4 * n_src * self.c]
         from . import chain as _chain
-        if _chain.SIDE_WGRAD[0] and self.bwd_w is not None and not _lib.off_main_lane():
+        if _chain.SIDE_WGRAD[0] and self.bwd_w is not None and _lib.raw_stream() != _lib.aux_stream(self.device).cuda_stream:
             _chain.run_split(self.bwd_d, self.bwd_w, vals, self.bws_index, self.bwd.ws_bytes, self.device,
                              [arena, garena, gout, xyz_cnt, new_cnt])
         else:
