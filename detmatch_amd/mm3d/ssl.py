@@ -27,7 +27,8 @@ def add_prefix(inputs, prefix):
 # attributes — the gradient-equality tests switch them (tests/test_ssl_gpu.py) — not environment switches.
 _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued before their chain inputs exist
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
-_TRUNK_ON_2D_LANE = os.environ.get('DM_TRUNK_ON_2D_LANE', '1') == '1'     # (round 6 A/B, see forward_train)
+_TRUNK_ON_2D_LANE = False     # the unlabeled 3D trunk on the 2D lane beside the supervised backward: measured WORSE (59.6 / 70.0 / 56.7 against
+                              # 55.2 / 60.0 / 56.4 ms: it delays the teacher, whose read-back gates the glue) — off, kept for the record
 _2D_INSIDE_3D = True      # the last 2D module between the issue and the read-back of its 3D neighbour: 60.2-60.5 against 61.4-62.0 ms (profiles/r06_ab_step_variants.txt)
 
 
