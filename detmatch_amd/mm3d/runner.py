@@ -75,6 +75,9 @@ class HybridOptimizer(torch.optim.Optimizer):
             if self.num_step_updated % k == 0:
                 if fused is not None and fused[i] is not None:
                     fused[i].step(getattr(self, 'grad_scale', None))
+                elif self._inert(i, o):
+                    continue         # no parameter of this member can ever hold a gradient (the recipe's 'teacher' SGD:
+                    #                  378 one-parameter groups that torch would walk for 1.4 ms to find nothing to do)
                 else:
                     ddp = getattr(self, '_ddp', None)
                     hidden = []
@@ -90,6 +93,16 @@ class HybridOptimizer(torch.optim.Optimizer):
                         p.grad = g
         self.grad_scale = None
         return loss
+
+    def _inert(self, i, o):
+        """True when no parameter of member i requires a gradient or holds one (torch's step() would skip them all)."""
+        cache = self.__dict__.setdefault('_inert_cache', {})
+        key = (i, sum(len(g['params']) for g in o.param_groups))
+        if cache.get('key%d' % i) != key:
+            cache['key%d' % i] = key
+            cache[i] = [p for g in o.param_groups for p in g['params']]
+        ps = cache[i]
+        return not any(p.requires_grad or p.grad is not None for p in ps)
 
     def enable_fused(self, ddp):
         """Route AdamW / SGD members whose parameters form one contiguous range of `ddp`'s flat
