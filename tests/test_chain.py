@@ -122,3 +122,24 @@ def test_chain_run_rejects_an_op_with_the_wrong_argument_count():
     ops[1].nargs = len(sig) - 1
     rc = L.dm_chain_run(ops, 2, None, 0, ctypes.byref(failed))
     assert rc != 0 and failed.value == 1
+
+
+def test_split_program_keeps_order_slots_and_shares_the_tables():
+    """chain.split_program: two halves of one op table (the weight-gradient half of a backward chain goes to the side
+    stream): every op lands in exactly one half, in its original order, both halves take the values of the full table."""
+    from detmatch_amd import chain
+    p = chain.Program('t')
+    a, n = p.slot('a'), p.slot('n')
+    p.call('dm_fill_bytes', a, 0, 0, chain.Program.STREAM)
+    p.call('dm_copy2d_f32', a, 4, a + 64, 4, n, 4, chain.Program.STREAM)
+    p.call('dm_fill_bytes', a + 8, 0, 0, chain.Program.STREAM)
+    p.call('dm_copy2d_f32', a + 128, 4, a + 192, 4, n, 4, chain.Program.STREAM)
+    first, second = chain.split_program(p, ('dm_copy2d_f32',))
+    assert [o[2] for o in first.ops] == ['dm_fill_bytes'] * 2 and [o[2] for o in second.ops] == ['dm_copy2d_f32'] * 2
+    assert first.ops[1][1][0] == (a.slot, 8) and second.ops[1][1][0] == (a.slot, 128)      # original order inside a half
+    assert first.slot_names == second.slot_names == p.slot_names
+    for half in (first, second):
+        half.run([4096, 0], stream=0)              # zero rows / zero bytes: no launch, DM_OK
+    assert chain.split_program(p, ('no_such_entry',)) == (None, None)
+    assert chain.split_program(p, ('dm_fill_bytes', 'dm_copy2d_f32')) == (None, None)
+    assert chain.SIDE_WGRAD == [False]               # only ever on for the length of an iteration (IterBasedSSLRunner.train)

@@ -478,3 +478,60 @@ def test_rng_windows_make_draws_independent_of_module_order():
     assert w.gen.off == 40 + 3 * W + 12
     w.finish()
     assert w.gen.off == 40 + 4 * W
+
+
+def test_lazy_log_vars_compute_on_first_read_only():
+    """base_detector._parse_losses: the loss comes back at once, the logged values are packed when somebody reads them
+    (the runner reads them after it has issued the backward pass)."""
+    from detmatch_amd.mm3d.base_detector import DetectorStepMixin, LazyLogVars
+
+    class _M(DetectorStepMixin):
+        pass
+    a = torch.tensor([1.0, 3.0], requires_grad=True)
+    losses = {'loss_a': a * 2, 'loss_b': [a.sum(), a.sum() * 0.5], 'acc': torch.tensor(0.25)}
+    loss, logs = _M()._parse_losses(losses)
+    assert isinstance(logs, LazyLogVars) and logs._pending is not None            # nothing packed yet
+    assert float(loss) == pytest.approx(4.0 + 6.0) and loss.requires_grad          # mean(2, 6) + (4 + 2)
+    logs.update({'extra': torch.tensor(7.0)})                                      # merged without forcing the values
+    assert logs._pending is not None
+    loss.backward()
+    assert torch.allclose(a.grad, torch.tensor([2.5, 2.5]))
+    assert float(logs['loss']) == pytest.approx(10.0) and logs._pending is None    # first read packs everything
+    assert float(logs['loss_a']) == pytest.approx(4.0) and float(logs['acc']) == 0.25 and float(logs['extra']) == 7.0
+    assert set(logs.keys()) == {'loss_a', 'loss_b', 'acc', 'loss', 'extra'} and len(logs) == 5
+    assert not logs['loss'].requires_grad
+
+
+def test_runner_buffers_lazy_logs_when_somebody_looks():
+    from detmatch_amd.mm3d.base_detector import LazyLogVars
+    from detmatch_amd.mm3d import runner as R
+    run = R.IterBasedSSLRunner.__new__(R.IterBasedSSLRunner)
+    run._lazy_logs, run._log_buffer = [], {}
+    for k in range(3):
+        lv = LazyLogVars({'loss_x': torch.tensor(float(k))}, torch.tensor(float(k)))
+        run._after_step(dict(loss=torch.tensor(0.0), log_vars=lv))
+        assert lv._pending is not None and len(run._lazy_logs) == k + 1           # not computed, not buffered yet
+    buf = run.log_buffer
+    assert [float(v) for v in buf['loss_x']] == [0.0, 1.0, 2.0] and not run._lazy_logs
+    run._after_step(dict(loss=torch.tensor(0.0), log_vars={'plain': torch.tensor(1.0)}))
+    assert 'plain' in run.log_buffer
+
+
+def test_hybrid_optimizer_skips_members_that_cannot_have_gradients():
+    """The recipe's 'teacher' SGD holds frozen parameters only: torch's step() would walk 378 one-parameter groups to
+    find nothing to do."""
+    from detmatch_amd.mm3d.runner import HybridOptimizer
+    w = torch.nn.Parameter(torch.ones(3))
+    frozen = [torch.nn.Parameter(torch.ones(2), requires_grad=False) for _ in range(4)]
+    o1 = torch.optim.SGD([w], lr=0.5)
+    o2 = torch.optim.SGD([dict(params=[p]) for p in frozen], lr=0.5)
+    calls = []
+    o2.step = lambda *a, **k: calls.append(1)
+    opt = HybridOptimizer.__new__(HybridOptimizer)
+    opt.optimizers, opt.step_intervals, opt.num_step_updated = [o1, o2], [1, 1], 0
+    w.grad = torch.ones(3)
+    opt.step()
+    assert torch.allclose(w.detach(), torch.full((3,), 0.5)) and not calls
+    frozen[0].grad = torch.ones(2)            # somebody handed it a gradient after all: torch decides
+    opt.step()
+    assert calls == [1]
