@@ -237,8 +237,10 @@ class TallSkinnyLinear(Function):
 
     # csrc/conv2d.hip's streaming weight-gradient kernel (dm_tall_wgrad): correct and reproducible, but on the shapes of
     # the step it only ties the batched BLAS call (profiles/r04_tall_skinny_wgrad_blas_vs_own.txt: 250 vs 240 us on
-    # 884 736 x 132 x 64, 160 vs 98 us on 884 736 x 64 x 64, 24-49 vs 26-33 us on the small ones) — opt-in
-    OWN_WGRAD = False
+    # 884 736 x 132 x 64, 160 vs 98 us on 884 736 x 64 x 64, 24-49 vs 26-33 us on the small ones).  Round 6: the default
+    # all the same — the chained path uses it anyway, and no vendor GEMM is left in the process (a Stream-K kernel of the
+    # vendor library next to a second one dead-locks the device); False: the split batched BLAS call, in a turn
+    OWN_WGRAD = True
 
     @staticmethod
     def _wgrad(gy, x):
