@@ -29,8 +29,9 @@ _MODULES = {
 
 # the key-point encoder (pfe) beside the BEV backbone on the side stream (PVRCNN.run_modules; module switch of the
 # equality test)
+# (training passes only: the teacher's encoder on the side stream as well measured 61.6 / 62.4 against 55.7 / 54.0 ms — it
+# queues in front of the student's work there)
 PFE_SIDE = [os.environ.get('DM_PFE_SIDE', '1') == '1']
-PFE_SIDE_EVAL = os.environ.get('DM_PFE_SIDE_EVAL', '0') == '1'      # (round 6 A/B) the teacher's encoder too
 _PFE_OUT = ('point_features', 'point_features_before_fusion', 'point_coords', 'point_batch_cnt')
 
 
@@ -167,8 +168,7 @@ class PVRCNN(nn.Module):
                 batch_dict['_pending_modules'] = todo
                 return batch_dict
             todo.pop(0)
-            if PFE_SIDE[0] and (self.training or PFE_SIDE_EVAL) and cur_module is bev and todo and todo[0] is pfe and \
-                    _on_device(batch_dict):
+            if PFE_SIDE[0] and self.training and cur_module is bev and todo and todo[0] is pfe and _on_device(batch_dict):
                 # The key-point encoder reads the sparse features, the raw points and the BEV map that goes INTO the BEV
                 # backbone — nothing the backbone produces — and only the point / RoI heads read what it writes
                 # (pv_rcnn.py:9-22 runs them one after the other because a module list has no other order).  So the
