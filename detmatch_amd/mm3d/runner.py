@@ -796,7 +796,6 @@ class EpochBasedRunner(_RunnerBase):
         self.call_hook('after_run')
 
 
-_ITER_SYNC = os.environ.get('DM_ITER_SYNC', '0') == '1'
 
 
 @RUNNERS.register_module()
@@ -835,8 +834,6 @@ class IterBasedSSLRunner(_RunnerBase):
         if self.lookahead and prefetch is not None and (self._max_iters is None or self.iter + 1 < self._max_iters):
             self._ahead = self._draw(lab_data_loader, unlab_data_loader)
         self.call_hook('before_train_iter')
-        if _ITER_SYNC and torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()
         # weight-gradient halves of the chained backward passes on the side stream for the length of this iteration
         # (chain.SIDE_WGRAD; scheduling only): needs the lanes and a gradient arena that is filled by collect(),
         # which waits for those kernels before it reads what they wrote

@@ -31,7 +31,7 @@ _MODULES = {
 # equality test)
 # (training passes only: the teacher's encoder on the side stream as well measured 61.6 / 62.4 against 55.7 / 54.0 ms — it
 # queues in front of the student's work there)
-PFE_SIDE = [os.environ.get('DM_PFE_SIDE', '1') == '1']
+PFE_SIDE = [True]
 _PFE_OUT = ('point_features', 'point_features_before_fusion', 'point_coords', 'point_batch_cnt')
 
 

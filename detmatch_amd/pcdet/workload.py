@@ -257,7 +257,7 @@ class DetMatchTrainWorkload(object):
         self.model.share_2d_trunk = os.environ.get('DM_SHARE_2D_TRUNK', '1') == '1'
         # weight-gradient halves of the chained backward passes on the side stream (scheduling only; the gradients are
         # read by ddp.collect, which waits for them) — with the lanes and the collect mode only
-        self.model.side_wgrad = os.environ.get('DM_SIDE_WGRAD', '1') == '1'      # (round 6 A/B; IterBasedSSLRunner.train applies it)
+        self.model.side_wgrad = True          # (IterBasedSSLRunner.train applies it for the length of an iteration; the equality test flips it)
         if self.ddp.mode == 'collect':
             # (measured neutral on the step time, -190 launches: on by default) gradients of every early backward pass are folded into the flat arena by batched
             # multi-tensor adds and released, so autograd never accumulates tensor by tensor
