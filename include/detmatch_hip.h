@@ -925,7 +925,16 @@ int dm_group_rows_grad(int batch, int m, int c, int n, int nsample, int row_widt
                        const int *features_batch_cnt, const unsigned char *empty_mask,
                        float *grad_features, dm_stream_t stream);
 /* Replaces furthest_point_sampling_wrapper (sampling_gpu.cu:25-189).  xyz (b,n,3),
- * temp (b,n) pre-filled with 1e10 by the caller, idxs (b,m). */
+ * temp (b,n) pre-filled with 1e10 by the caller, idxs (b,m).
+ * RESIDENCY REQUIREMENT of the large-cloud path (> 24 576 points per sample: G = min(64, 128 / batch) workgroups of
+ * 1 024 threads per sample exchange their round maxima through `temp` and SPIN on each other, csrc/pointnet2_stack.hip:
+ * fps_kernel_multi): all G workgroups of a sample must become resident.  They do whenever the device's other work
+ * retires — a spinning workgroup keeps its slot, the missing ones take the slots other kernels free — but NOT next to a
+ * second kernel that spins the same way (another large-cloud FPS launch on another stream, or a launch confined by a
+ * CU mask to fewer than G * batch workgroup slots): issue large-cloud FPS launches on ONE stream (the package does:
+ * _lib.aux_stream; the passes of an iteration are even one launch, pcdet/pfe.py:FpsBatch).  Clouds up to 24 576 points
+ * take one workgroup per sample and have no such requirement.  Exercised under the three stream lanes on the Waymo
+ * shape by tests/test_waymo_shape_gpu.py. */
 int dm_furthest_point_sampling(int batch, int n, int m, const float *xyz, float *temp, int *idxs,
                                dm_stream_t stream);
 /* Same, ragged: sample b owns points [offsets_host[b], offsets_host[b+1]) of the stacked
