@@ -74,6 +74,8 @@ SIGNATURES = {
     'dm_consistency_loss_forward': (ci, [vp, vp, vp, vp, ci, ci, cf, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp]),
     'dm_consistency_loss_backward': (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp]),
     'dm_bbox2d_transform': (ci, [vp, ci, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp]),
+    'dm_sort_rows_max': (ci, []),
+    'dm_sort_rows_f32': (ci, [vp, ci, ci, ctypes.c_longlong, ci, vp, vp, vp]),
     'dm_fc_gemm_workspace_bytes': (sz, [ci, ci, ci]),
     'dm_fc_gemm': (ci, [ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp]),
     'dm_rowgemm_supported': (ci, [ci, ci]),
@@ -390,6 +392,32 @@ def _own_linear_takes(x, w):
     # the own backward reads gradient rows 16 bytes at a time: an output width that is not a multiple of 4 is fine in
     # inference (the teacher's 1- and 7-wide RoI heads), with gradients it stays on the vendor kernel
     return w.shape[0] % 4 == 0 or not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))
+
+
+# ---- stable sort of short score rows (csrc/sort_rows.hip) -----------------------------------------------------------
+SORT_ROWS = True          # module switch of the equality test (False: torch.sort)
+SORT_ROWS_CALLS = [0]
+
+
+def sort_rows(keys, descending=True, dim=-1):
+    """torch.sort(keys, dim, descending, stable=True)[1] for float32 keys of up to 16 384 elements per row on the device
+    (one launch, one workgroup per row); anything else goes to torch.sort."""
+    if not (SORT_ROWS and keys.is_cuda and keys.dtype == torch.float32 and keys.dim() in (1, 2) and
+            dim in (-1, keys.dim() - 1) and 0 < keys.shape[-1] <= 16384 and keys.numel() > 0):
+        return torch.sort(keys, dim=dim, descending=descending, stable=True)[1]
+    k = keys.detach()
+    if k.stride(-1) != 1:
+        k = k.contiguous()
+    rows = 1 if k.dim() == 1 else k.shape[0]
+    n = k.shape[-1]
+    stride = n if k.dim() == 1 else k.stride(0)
+    if stride < n:
+        k = k.contiguous()
+        stride = n
+    idx = torch.empty(k.shape, dtype=torch.int64, device=k.device)
+    check(lib().dm_sort_rows_f32(ptr(k), rows, n, stride, int(bool(descending)), ptr(idx), None, stream()), 'dm_sort_rows_f32')
+    SORT_ROWS_CALLS[0] += 1
+    return idx
 
 
 # ---- fully connected layers on the library's own exact-fp32 GEMM (csrc/fc_gemm.hip) -------------------------------------

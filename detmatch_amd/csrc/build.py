@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libdetmatch_hip.so')
 SOURCES = ['voxelize.hip', 'rulebook.hip', 'spconv.hip', 'iou3d_nms.hip',
-           'pointnet2_stack.hip', 'points_in_boxes.hip', 'ssl_ops.hip', 'roi_align.hip', 'bn_relu.hip', 'augment.hip', 'kitti_eval.hip', 'anchor_loss.hip', 'misc.hip', 'conv2d.hip', 'anchor_assign.hip', 'roi_targets.hip', 'det2d_targets.hip', 'bev_interp.hip', 'ssl_match.hip', 'box_decode.hip', 'box_project.hip', 'consistency_loss.hip', 'rowgemm.hip', 'spconv16.hip', 'chain.hip', 'chain_tramp.hip', 'chain_ops.hip', 'fc_gemm.hip']
+           'pointnet2_stack.hip', 'points_in_boxes.hip', 'ssl_ops.hip', 'roi_align.hip', 'bn_relu.hip', 'augment.hip', 'kitti_eval.hip', 'anchor_loss.hip', 'misc.hip', 'conv2d.hip', 'anchor_assign.hip', 'roi_targets.hip', 'det2d_targets.hip', 'bev_interp.hip', 'ssl_match.hip', 'box_decode.hip', 'box_project.hip', 'consistency_loss.hip', 'rowgemm.hip', 'spconv16.hip', 'chain.hip', 'chain_tramp.hip', 'chain_ops.hip', 'fc_gemm.hip', 'sort_rows.hip']
 HEADERS = ['dm_common.h', 'box_geom.h', '../../include/detmatch_hip.h', 'chain_tramp.inc']
 # -ffp-contract=off: fused multiply-adds only where the source says fmaf(), so the
 # CPU oracle (same flag) and the device agree bit for bit on index-deciding math.

@@ -71,7 +71,7 @@ def _nms(fn_name, boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
     assert boxes.shape[1] == 7
     # stable: equal scores keep their original relative order (the reference's sort is
     # not stable, SURVEY K4 (i) — this build fixes the rule "lower index first")
-    order = torch.sort(scores, dim=0, descending=True, stable=True)[1]
+    order = _lib.sort_rows(scores, descending=True)
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
     b = boxes[order].contiguous().float()

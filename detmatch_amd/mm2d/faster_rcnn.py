@@ -145,7 +145,7 @@ def random_sample(assigned, num, pos_fraction, generator=None, keys=None):
 
 def nms_fixed(boxes, scores, iou_thr, max_num):
     """Greedy NMS on the device -> (idx (max_num) into boxes, ok (max_num) bool), score order."""
-    order = torch.sort(scores, descending=True, stable=True)[1]
+    order = _lib.sort_rows(scores, descending=True)
     b = boxes[order].contiguous().float()
     _lib.require_device(b)
     n = b.shape[0]
@@ -162,7 +162,7 @@ def nms_fixed(boxes, scores, iou_thr, max_num):
 
 def nms_fixed_batch(boxes, scores, iou_thr, max_num):
     """nms_fixed for B images of N candidates each in one launch chain -> (idx (B, max_num), ok (B, max_num))."""
-    order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
+    order = _lib.sort_rows(scores, descending=True)
     b = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4)).contiguous().float()
     _lib.require_device(b)
     bsz, n = b.shape[0], b.shape[1]

@@ -278,7 +278,7 @@ def nms_2d(boxes, scores, iou_threshold, max_num=-1):
     """mmcv.ops.nms on the device: -> (dets (k,5) sorted by score, keep indices (k,))."""
     if boxes.shape[0] == 0:
         return torch.cat([boxes, scores[:, None]], -1), boxes.new_zeros((0,), dtype=torch.long)
-    order = torch.sort(scores, descending=True, stable=True)[1]
+    order = _lib.sort_rows(scores, descending=True)
     b = boxes[order].contiguous().float()
     _lib.require_device(b)
     n = b.shape[0]
@@ -397,7 +397,7 @@ def filter_by_nms_2d_masked(entries, nms_cfg, use_sigmoid_cls):
         neg = torch.full_like(flat_s, float('-inf'))
         max_coord = torch.where(valid[:, None], flat_b, neg[:, None]).max()
         key = torch.where(valid, flat_s, neg)
-        order = torch.sort(key, descending=True, stable=True)[1]
+        order = _lib.sort_rows(key, descending=True)
         sorted_boxes = (flat_b + (labels * (max_coord + 1))[:, None])[order].contiguous().float()
         m = n * c
         k_rows = min(max_num, m) if max_num > 0 else m

@@ -43,7 +43,7 @@ def class_agnostic_nms_fixed_batch(box_scores, box_preds, nms_config, score_thre
         scores = torch.where(box_scores >= score_thresh, box_scores, box_scores.new_full((), -float('inf')))
     k = min(int(nms_config.NMS_PRE_MAXSIZE), n)
     top_scores, indices = torch.topk(scores, k=k, dim=1)
-    order = torch.sort(top_scores, dim=1, descending=True, stable=True)[1]
+    order = _lib.sort_rows(top_scores, descending=True)
     indices = torch.gather(indices, 1, order)                     # original index, NMS order
     boxes = torch.gather(box_preds[:, :, 0:7], 1, indices[:, :, None].expand(-1, -1, 7)).contiguous().float()
     L = _lib.lib()

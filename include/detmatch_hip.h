@@ -992,6 +992,16 @@ int dm_roi_decode_backward(const float *grad_boxes, const float *box_encodings, 
 /* ------------------------------------------------------------------------ */
 /* Chain-level issue (host-side launch interpreter)                          */
 /* ------------------------------------------------------------------------ */
+/* Stable sort of short rows of float keys: the score orders of the proposal layers and NMS wrappers
+ * (pcdet/models/model_utils/model_nms_utils.py:6-25, mmcv batched_nms / mmdet RPN `torch.sort(scores, descending=True)`;
+ * the reference: torch.sort -> a multi-launch library merge sort per call).  One launch, one workgroup per row, (key, index)
+ * pairs sorted in LDS: idx_out (rows, n) int64 = the permutation torch.sort(stable=True) returns (ties keep their original
+ * order; -0.0 == +0.0; a positive NaN is the largest key), keys_out (rows, n) optional.  n <= dm_sort_rows_max() (16 384). */
+int dm_sort_rows_max(void);
+int dm_sort_rows_f32(const float *keys, int rows, int n, long long key_stride, int descending, long long *idx_out,
+                     float *keys_out /*or NULL*/, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* Fully connected layers (nn.Linear / Conv1d(kernel 1) of pcdet/models/roi_heads/pvrcnn_head.py:25-52,
  * voxel_set_abstraction.py:107-111, point_head_template.py:34-47; the reference: cuBLAS through torch.nn.functional.linear
  * and autograd's mm backward).  One exact-fp32 MFMA kernel, three operand forms, all row-major with leading dimensions:
