@@ -585,7 +585,8 @@ class StandardRoIHead(nn.Module):
                 okk = torch.cat([pos_ok, neg_ok])
                 is_pos = torch.cat([pos_ok, torch.zeros_like(neg_ok)])
                 # compact to `num` rows, sampled ones first (positives before negatives)
-                front = torch.sort((~okk).long(), stable=True)[1][:num]
+                front = (_lib.sort_rows((~okk).float(), descending=False) if okk.is_cuda and okk.numel() else
+                         torch.sort((~okk).long(), stable=True)[1])[:num]
                 idx, okk, is_pos = idx[front], okk[front], is_pos[front]
                 b = boxes[idx]
                 if gt.shape[0] > 0:

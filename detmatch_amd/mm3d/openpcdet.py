@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 from torch.nn import functional as F
 
-from .. import voxel
+from .. import _lib, voxel
 from ..pcdet.config import ConfigDict
 from ..pcdet.detector import build_network
 from .base_detector import DetectorStepMixin
@@ -207,7 +207,8 @@ class OpenPCDetDetector(DetectorStepMixin, nn.Module):
             mask = (0 <= labels) & (labels < self.num_classes)
             # kept dense: out-of-range classes become all-zero rows (== padding) and are
             # moved behind the valid rows, like the boolean filter of :125-128
-            order = torch.sort((~mask).long(), stable=True)[1]
+            order = _lib.sort_rows((~mask).float(), descending=False) if mask.is_cuda and mask.numel() else \
+                torch.sort((~mask).long(), stable=True)[1]
             row = torch.cat([b, labels[:, None].float() + 1], dim=1) * mask[:, None].float()
             trans.append(row[order])
         # at least one (all-zero == padding) row: the dense target assigners treat it exactly
