@@ -512,10 +512,6 @@ def blas_mm(a, b):
 # events behind gradient kernels that were issued on a side stream (chain.SIDE_WGRAD): whoever reads the gradients
 # next (FlatGradDDP.collect / finish) makes its stream wait for them first
 PENDING_GRAD_EVENTS = []
-# where chain.run_split issues the weight-gradient halves: None = the side stream (_lib.aux_stream); SSL.forward_train points it
-# at the teacher lane for the LAST backward pass of the iteration (that lane is idle by then, while the side stream already
-# carries the key-point encoder's backward)
-WGRAD_STREAM = [None]
 
 
 def wait_pending_grads():

@@ -267,7 +267,7 @@ def run_split(first, second, vals, ws_index, ws_bytes, device, tensors):
     main = torch.cuda.current_stream(device)
     ready = torch.cuda.Event()
     ready.record(main)
-    side = _lib.WGRAD_STREAM[0] if _lib.WGRAD_STREAM[0] is not None else _lib.aux_stream(device)
+    side = _lib.aux_stream(device)
     side.wait_event(ready)
     with torch.cuda.stream(side):
         ws2 = _lib.workspace(ws_bytes, device, 'chain') if ws_bytes else None

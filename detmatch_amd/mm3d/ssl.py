@@ -29,7 +29,6 @@ _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued be
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
 _TRUNK_ON_2D_LANE = False     # the unlabeled 3D trunk on the 2D lane beside the supervised backward: measured WORSE (59.6 / 70.0 / 56.7 against
                               # 55.2 / 60.0 / 56.4 ms: it delays the teacher, whose read-back gates the glue) — off, kept for the record
-_WGRAD_ON_TEACHER_LANE = os.environ.get('DM_WGRAD_TEACHER_LANE', '1') == '1'     # (round 6 A/B, see the end of forward_train)
 _2D_INSIDE_3D = True      # the last 2D module between the issue and the read-back of its 3D neighbour: 60.2-60.5 against 61.4-62.0 ms (profiles/r06_ab_step_variants.txt)
 
 
@@ -683,7 +682,6 @@ class SSL(nn.Module):
             return self._forward_train(lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs)
 
     def _forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
-        _lib.WGRAD_STREAM[0] = None          # (set at the end of the previous iteration's forward_train)
         if isinstance(unlab_stu, list):
             unlab_stu = self._collate(unlab_stu)
             unlab_tea = self._collate(unlab_tea)
@@ -863,8 +861,6 @@ class SSL(nn.Module):
         flush_counters()
         with torch.no_grad():
             self._update_teacher()
-        if lanes is not None and lanes.mode == 'branches' and _WGRAD_ON_TEACHER_LANE:
-            _lib.WGRAD_STREAM[0] = lanes.stream(2)      # the last backward pass follows: the teacher lane is idle from here on
         self._lanes = None
         rng.finish()
         return losses
