@@ -837,6 +837,13 @@ def main():
             out['config']['stream_order'] = 'branches' if getattr(model, 'two_lanes', False) else \
                 (model.lane_mode or 'serial')
             from detmatch_amd import chain
+            from detmatch_amd.pcdet import detector as _det
+            side = []
+            if getattr(model, 'side_wgrad', False) and getattr(model, 'two_lanes', False) and getattr(getattr(wl, 'ddp', None), 'mode', None) == 'collect':
+                side.append('weight-gradient halves of the chained dense / set-abstraction backward passes')
+            if _det.PFE_SIDE[0]:
+                side.append('key-point encoder beside the BEV backbone (forward and backward)')
+            out['config']['side_stream'] = side + ['key-point FPS of all passes (one launch)']
             out['config']['issue'] = ('chained: one C-ABI call per static sub-graph (dm_chain_run)' if chain.ENABLED
                                       else 'op by op') + ('' if not chain.OFF else ', families off: %s' % sorted(chain.OFF))
         # pseudo-label bookkeeping of the timed steps: proves the step exercises matching (NumPreds
