@@ -809,6 +809,9 @@ class IterBasedSSLRunner(_RunnerBase):
     # side stream (SSL.prefetch_geometry) — the data-dependent size read-backs of the voxelizer / rulebooks
     # then overlap the tail of iteration i instead of idling the device at the step boundary.
     lookahead = os.environ.get('DM_LOOKAHEAD', '1') == '1'
+    # draw_ahead: only the DRAW one iteration ahead (no geometry on a side stream): the batch's `ready` event then sits in
+    # front of the previous iteration on the main stream, and the model's own early work can wait for it alone
+    draw_ahead = False
 
     @staticmethod
     def _draw(lab_data_loader, unlab_data_loader):
@@ -828,11 +831,16 @@ class IterBasedSSLRunner(_RunnerBase):
         self.mode = 'train'
         self._epoch = getattr(lab_data_loader, 'epoch', 0)
         ahead = getattr(self, '_ahead', None)
-        data_batch, _ = ahead if ahead is not None else self._draw(lab_data_loader, unlab_data_loader)
+        data_batch, ready = ahead if ahead is not None else self._draw(lab_data_loader, unlab_data_loader)
         self._ahead = None
         prefetch = getattr(_inner(self.model), 'prefetch_geometry', None)
-        if self.lookahead and prefetch is not None and (self._max_iters is None or self.iter + 1 < self._max_iters):
+        draw_ahead = self.lookahead or self.draw_ahead
+        if draw_ahead and prefetch is not None and (self._max_iters is None or self.iter + 1 < self._max_iters):
             self._ahead = self._draw(lab_data_loader, unlab_data_loader)
+        if ready is not None and prefetch is not None and ahead is not None:
+            # the batch existed before the previous iteration was issued: the model may start what reads nothing but the
+            # batch (geometry) and the EMA (teacher) without waiting for that iteration's tail (SSL._forward_train)
+            _inner(self.model)._data_ready = ready
         self.call_hook('before_train_iter')
         # weight-gradient halves of the chained backward passes on the side stream for the length of this iteration
         # (chain.SIDE_WGRAD; scheduling only): needs the lanes and a gradient arena that is filled by collect(),
@@ -846,7 +854,7 @@ class IterBasedSSLRunner(_RunnerBase):
             self.call_hook('after_train_iter')
         finally:
             _chain.SIDE_WGRAD[0] = False
-        if self._ahead is not None:
+        if self._ahead is not None and self.lookahead:
             prefetch(self._ahead[0], self._ahead[1], tag='ahead%d_' % (self.iter & 1))
         self._inner_iter += 1
         self._iter += 1

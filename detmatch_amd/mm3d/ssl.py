@@ -29,6 +29,9 @@ _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued be
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
 _TRUNK_ON_2D_LANE = False     # the unlabeled 3D trunk on the 2D lane beside the supervised backward: measured WORSE (59.6 / 70.0 / 56.7 against
                               # 55.2 / 60.0 / 56.4 ms: it delays the teacher, whose read-back gates the glue) — off, kept for the record
+_TEACHER_AHEAD = os.environ.get('DM_TEACHER_AHEAD', '1') == '1'   # the teacher's passes + all geometry wait for the EMA, not for the previous iteration's last backward
+_TEACHER_AHEAD_ALL = os.environ.get('DM_TEACHER_AHEAD_ALL', '0') == '1'   # ... the teacher's 3D pass too (else: its 2D pass only)
+_SUP_BWD_PER_LANE = os.environ.get('DM_SUP_BWD_PER_LANE', '0') == '1'   # supervised 2D losses back-propagated on the 2D lane
 _2D_INSIDE_3D = True      # the last 2D module between the issue and the read-back of its 3D neighbour: 60.2-60.5 against 61.4-62.0 ms (profiles/r06_ab_step_variants.txt)
 
 
@@ -675,6 +678,54 @@ class SSL(nn.Module):
                 hook()
         return d
 
+    def _sup_backward_on_lane(self, lanes, module, d, done):
+        """'branches' only.  A supervised 2D module's losses are back-propagated on the 2D lane right behind its forward
+        (heads only: the shared trunk's backward is deferred, _share_2d_trunk) instead of together with the 3D losses
+        on the main lane — whose supervised backward then starts when the 3D forward is done, not when the 2D lane
+        (teacher pass + shared trunk + this module: 19 ms) has caught up.  d(sum) = sum of d; the gradients are disjoint
+        from the 3D detector's.  `done`: gets the event behind the lane's backward (whoever reads gradients waits)."""
+        before = dict(d['sup_losses'])
+        d = lanes.run(module, self, d)
+        cur = d['sup_losses']
+        new = [(k, v) for k, v in cur.items() if k not in before or before[k] is not v]
+        if any(k in before for k, _ in new):
+            return d                   # summed into another module's key: left to the joint backward
+        side = lanes.stream(lanes.lane_of(module))
+        with torch.cuda.stream(side):
+            terms = []
+            for k, v in new:
+                v = self._collapse_losses({k: v})[k]
+                if 'loss' in k and v.requires_grad:
+                    terms.append(v)
+                cur[k] = v.detach()
+            if terms:
+                sum(terms).backward()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                done.append(ev)
+        return d
+
+    def _issue_geometry(self, lab_dict, unlab_dict):
+        """The weight-independent geometry of every pass of the iteration, issued up front on the current stream."""
+        jobs = []
+        for chain, d in ((self.lab_ssl_modules, lab_dict), (self.unlab_ssl_modules, unlab_dict)):
+            for m in chain:
+                steps = None
+                if hasattr(m, 'prefetch_steps') and getattr(m.prefetch, '__func__', None) is \
+                        getattr(type(m), 'prefetch', None):
+                    steps = m.prefetch_steps(self, d, 'rulebook%d' % len(jobs))
+                if steps is not None:
+                    jobs.append(steps)
+                elif hasattr(m, 'prefetch'):
+                    m.prefetch(self, d)
+        if jobs:
+            # the passes' size read-backs (voxel count, N_out of the four strided rulebooks) in lockstep:
+            # one device->host copy per round for all of them; their key-point FPS as ONE launch behind the rulebooks
+            from ..pcdet.pfe import FpsBatch
+            from ..spconv.ops import drive_steps_together
+            with FpsBatch():
+                drive_steps_together(jobs)
+
     def forward_train(self, lab_stu, lab_tea, unlab_stu, unlab_tea, *args, **kwargs):
         """ssl.py:255-350"""
         from ..bn_relu import deferred_counters
@@ -713,7 +764,35 @@ class SSL(nn.Module):
         run = (lambda m, d: lanes.run(m, self, d)) if lanes is not None else run_serial
 
         branches_first = lanes is not None and lanes.mode == 'branches' and _ISSUE_EARLY
-        if branches_first:
+        ahead = None
+        if branches_first and _TEACHER_AHEAD:
+            ema, ready = getattr(self, '_ema_done', None), self.__dict__.pop('_data_ready', None)
+            if ema is not None and ready is not None:
+                ahead = (ema, ready)
+        if ahead is not None:
+            # Scheduling only ('branches').  Of the previous iteration, the teacher reads the EMA only — which ran BEFORE
+            # that iteration's last backward pass (ssl.py:348) — and the geometry reads nothing but the batch.  So the 2D
+            # and the teacher lane do not wait for the main stream's tail (backward, clip, optimizer: 10+ ms of device
+            # time behind the host) but for the EMA's event and the batch's: the geometry of all passes (+ the key-point
+            # FPS) goes to the teacher lane, its ONE size read-back returns at once, and both teacher passes are issued
+            # and run underneath the student's last backward.  The student's passes wait for the optimizer as before.
+            from ..pcdet.pfe import VoxelSetAbstraction
+            for s in lanes.streams[1:]:
+                s.wait_event(ahead[0])
+                s.wait_event(ahead[1])
+            VoxelSetAbstraction.fps_stream = lanes.stream(2)
+            try:
+                with torch.cuda.stream(lanes.stream(2)):
+                    self._issue_geometry(lab_dict, unlab_dict)
+            finally:
+                VoxelSetAbstraction.fps_stream = None
+            for m in self.unlab_ssl_modules:
+                if hasattr(m, 'issue_early') and str(getattr(m, 'ssl_obj_attr', '')).startswith('teacher') and \
+                        (_TEACHER_AHEAD_ALL or getattr(m, 'early_before_geometry', False)):
+                    lanes.run(m, self, unlab_dict, method='issue_early')
+            lanes.fork()
+            self._share_2d_trunk(lab_dict, unlab_dict, lane_mode)
+        elif branches_first:
             # Scheduling only ('branches'): what needs no 3D geometry — the student's shared 2D trunk and the
             # teacher's 2D inference, both on the 2D lane — is issued BEFORE the geometry, whose size read-backs
             # wait for the tail of the previous iteration on the main stream: the host issues these while it would
@@ -723,25 +802,8 @@ class SSL(nn.Module):
             for m in self.unlab_ssl_modules:
                 if getattr(m, 'early_before_geometry', False) and hasattr(m, 'issue_early'):
                     lanes.run(m, self, unlab_dict, method='issue_early')
-        # weight-independent geometry of every pass of the iteration, issued up front
-        jobs = []
-        for chain, d in ((self.lab_ssl_modules, lab_dict), (self.unlab_ssl_modules, unlab_dict)):
-            for m in chain:
-                steps = None
-                if hasattr(m, 'prefetch_steps') and getattr(m.prefetch, '__func__', None) is \
-                        getattr(type(m), 'prefetch', None):
-                    steps = m.prefetch_steps(self, d, 'rulebook%d' % len(jobs))
-                if steps is not None:
-                    jobs.append(steps)
-                elif hasattr(m, 'prefetch'):
-                    m.prefetch(self, d)
-        if jobs:
-            # the passes' size read-backs (voxel count, N_out of the four strided rulebooks) in lockstep:
-            # one device->host copy per round for all of them; their key-point FPS as ONE launch behind the rulebooks
-            from ..pcdet.pfe import FpsBatch
-            from ..spconv.ops import drive_steps_together
-            with FpsBatch():
-                drive_steps_together(jobs)
+        if ahead is None:
+            self._issue_geometry(lab_dict, unlab_dict)
         if not branches_first:
             if lanes is not None:
                 lanes.fork()          # inputs, weights and the prefetched geometry live on the main stream
@@ -760,13 +822,19 @@ class SSL(nn.Module):
             unlab_modules = [m for m in unlab_modules if m not in hoisted]
         early = lanes is None and getattr(self, 'early_backward', False) and torch.is_grad_enabled()
         curr_ssl_weight = self._get_curr_ssl_weight()
+        sup_per_lane = lanes is not None and lanes.mode == 'branches' and _SUP_BWD_PER_LANE and torch.is_grad_enabled() \
+            and getattr(self, 'early_backward', False)
+        sup_2d_done = []
         for m in self.lab_ssl_modules:
-            lab_dict = self._run_and_backprop(run, m, lab_dict, early, curr_ssl_weight)
+            if sup_per_lane and lanes.lane_of(m) == 1:
+                lab_dict = self._sup_backward_on_lane(lanes, m, lab_dict, sup_2d_done)
+            else:
+                lab_dict = self._run_and_backprop(run, m, lab_dict, early, curr_ssl_weight)
         lab_done = None
         if lanes is not None:
             lab_done = torch.cuda.Event()           # the labeled forward passes of the main lane are behind this
             lab_done.record(lanes.main)
-        if lanes is not None:
+        if lanes is not None and not sup_2d_done:
             lanes.join(lab_dict['sup_losses'], lab_dict['ssl_losses'])
         if getattr(self, 'early_backward', False) and torch.is_grad_enabled():
             # Scheduling only: d(sum of losses) = sum of d(losses), so the supervised part can be
@@ -779,10 +847,14 @@ class SSL(nn.Module):
                 from ..spconv.ops import deferred_weight_grads
                 with deferred_weight_grads():
                     sum(terms).backward()
+                for ev in sup_2d_done:    # the hook reads every gradient that exists: the 2D lane's own backward included
+                    torch.cuda.current_stream().wait_event(ev)
                 hook = getattr(self, 'after_partial_backward', None)
                 if hook is not None:      # e.g. FlatGradDDP.collect
                     hook()
             lab_dict['sup_losses'] = {k: v.detach() for k, v in sup.items()}
+        if lanes is not None and sup_2d_done:
+            lanes.join(lab_dict['sup_losses'], lab_dict['ssl_losses'])
         if getattr(self, 'issue_early', True) and _ISSUE_EARLY:
             # Scheduling only: every pass of the unlabeled chain that can start before its inputs from the chain
             # exist (teacher inference up to its read-back; the label-independent trunk of the student's pass) is
@@ -861,6 +933,9 @@ class SSL(nn.Module):
         flush_counters()
         with torch.no_grad():
             self._update_teacher()
+        if dev.type == 'cuda':
+            self._ema_done = torch.cuda.Event()      # what the NEXT iteration's teacher passes wait for
+            self._ema_done.record()
         self._lanes = None
         rng.finish()
         return losses

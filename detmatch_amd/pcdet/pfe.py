@@ -187,6 +187,7 @@ class VoxelSetAbstraction(nn.Module):
         return torch.cat(keypoints_list, dim=0)
 
     _side_streams = {}
+    fps_stream = None        # SSL.forward_train (teacher ahead): the stream the key-point FPS is launched on instead of the side stream
     _collect = None          # FpsBatch: [(module, batch dict)] of the passes whose FPS is to be ONE launch
 
     def sample_keypoints_async(self, batch_dict):
@@ -213,6 +214,8 @@ class VoxelSetAbstraction(nn.Module):
             pool = VoxelSetAbstraction._side_streams[key] = dict(streams=[_lib.aux_stream(pts.device)], next=0)
         side = pool['streams'][pool['next'] % len(pool['streams'])]
         pool['next'] += 1
+        if VoxelSetAbstraction.fps_stream is not None:
+            side = VoxelSetAbstraction.fps_stream
         main = torch.cuda.current_stream(pts.device)
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
@@ -236,7 +239,7 @@ class VoxelSetAbstraction(nn.Module):
                 grp[0][0].sample_keypoints_async(grp[0][1])
                 continue
             from .. import _lib
-            side = _lib.aux_stream(dev)
+            side = VoxelSetAbstraction.fps_stream if VoxelSetAbstraction.fps_stream is not None else _lib.aux_stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side), torch.no_grad():
                 xyz = torch.cat([bd['points'][:, 1:4] for _, bd in grp], dim=0).contiguous()

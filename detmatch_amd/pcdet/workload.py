@@ -289,6 +289,7 @@ class DetMatchTrainWorkload(object):
             # more than it hides (70.0 / 69.8 against 66.5 ms, profiles/r06_lane_soak.txt).  (Round 5 switched it off
             # because it made the Stream-K dead-lock more frequent; it is safe now, just not faster.)
             self.runner.lookahead = False
+            self.runner.draw_ahead = True      # SSL._forward_train: teacher passes + geometry ahead of the previous iteration's tail
         self.runner.call_hook('before_run')
         self.world = 1
         self.params = self.ddp.params

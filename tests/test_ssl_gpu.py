@@ -697,3 +697,65 @@ def test_key_point_encoder_on_the_side_stream_does_not_change_gradients(dev):
         assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
     rel = (ga - gb).norm() / gb.norm()
     assert rel < 2e-3, float(rel)
+
+
+def _zero_lr(wl):
+    for h in wl.runner._hooks:
+        if getattr(h, 'base_lr', None):
+            h.base_lr = [0.0 for _ in h.base_lr]
+
+
+def test_teacher_ahead_of_the_previous_backward_is_scheduling_only(dev):
+    """ssl._TEACHER_AHEAD: from the second iteration on, the geometry of all passes and the teacher's 2D pass wait for the
+    previous iteration's EMA and the batch, not for its last backward / optimizer step — they run underneath that tail.
+    With the learning rate at zero the weights stay put, so iterations 2 and 3 must give the same losses with and without
+    (to the rounding of the atomics): anything the early work read too early, or wrote under a reader, would show."""
+    from detmatch_amd.mm3d import ssl
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    logs = {}
+    saved = ssl._TEACHER_AHEAD
+    try:
+        for ahead in (True, False):
+            ssl._TEACHER_AHEAD = ahead
+            wl = DetMatchTrainWorkload(2, dev, seed=5)
+            assert wl.runner.draw_ahead and wl.model.two_lanes
+            _zero_lr(wl)
+            out = []
+            for _ in range(4):
+                wl.step()
+                out.append({k: float(v) for k, v in wl.last_log.items()})
+            torch.cuda.synchronize()
+            assert (getattr(wl.model, '_ema_done', None) is not None)
+            logs[ahead] = out
+            del wl
+    finally:
+        ssl._TEACHER_AHEAD = saved
+    for it in range(4):
+        for k, v in logs[True][it].items():
+            assert v == pytest.approx(logs[False][it][k], rel=2e-4, abs=1e-6), (it, k)
+
+
+def test_supervised_2d_backward_on_its_lane_does_not_change_gradients(dev):
+    """ssl._SUP_BWD_PER_LANE (off by default: measured neutral): the supervised 2D losses back-propagated on the 2D lane
+    right behind their forward, the 3D ones on the main lane without waiting for the 2D lane — same accumulated gradient."""
+    from detmatch_amd.mm3d import ssl
+    from detmatch_amd.pcdet.workload import DetMatchTrainWorkload
+    out = []
+    saved = ssl._SUP_BWD_PER_LANE
+    try:
+        for per_lane in (True, False):
+            ssl._SUP_BWD_PER_LANE = per_lane
+            wl = DetMatchTrainWorkload(2, dev)
+            torch.manual_seed(321)
+            wl.step()
+            torch.cuda.synchronize()
+            out.append((wl.ddp.flat.clone(), {k: float(v) for k, v in wl.last_log.items()}))
+            del wl
+    finally:
+        ssl._SUP_BWD_PER_LANE = saved
+    (ga, la), (gb, lb) = out
+    assert torch.isfinite(ga).all() and ga.abs().sum() > 0
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    rel = (ga - gb).norm() / gb.norm()
+    assert rel < 2e-3, float(rel)

@@ -26,7 +26,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('csv')
     ap.add_argument('--marker', default='ema_f32')
-    ap.add_argument('--skip-last', type=int, default=3)
+    ap.add_argument('--skip-last', type=int, default=0)
+    ap.add_argument('--pick', type=int, default=-1)
     ap.add_argument('--gap', type=float, default=150.0)
     a = ap.parse_args()
     rows = []
@@ -35,8 +36,13 @@ def main():
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Stream_Id', '?')))
     rows.sort()
     opt = [i for i, r in enumerate(rows) if re.search(r'adamw', r[2])]
-    opt = opt[:-a.skip_last] if a.skip_last else opt
-    lo, hi = opt[-2] + 1, opt[-1] + 1            # one iteration: behind the previous optimizer step .. this optimizer step
+    # the timed region = the run of back-to-back iterations: take the interval of median length among the shortest half
+    gaps = sorted((rows[opt[i + 1]][0] - rows[opt[i]][0], i) for i in range(len(opt) - 1))
+    short = gaps[:max(1, len(gaps) // 2)]
+    pick = short[len(short) // 2][1] if a.pick < 0 else a.pick
+    print('optimizer-to-optimizer intervals (ms): ' + ' '.join('%.1f' % ((rows[opt[i + 1]][0] - rows[opt[i]][0]) / 1e6)
+                                                                for i in range(len(opt) - 1)) + '   -> picked #%d' % pick)
+    lo, hi = opt[pick] + 1, opt[pick + 1] + 1    # one iteration: behind the previous optimizer step .. this optimizer step
     # (the SGD step follows AdamW: extend to the next kernel that is not an optimizer kernel)
     while hi < len(rows) and re.search(r'sgd_|adamw', rows[hi][2]):
         hi += 1
