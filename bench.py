@@ -843,7 +843,15 @@ def main():
                 side.append('weight-gradient halves of the chained dense / set-abstraction backward passes')
             if _det.PFE_SIDE[0]:
                 side.append('key-point encoder beside the BEV backbone (forward and backward)')
-            out['config']['side_stream'] = side + ['key-point FPS of all passes (one launch)']
+            from detmatch_amd.mm3d import ssl as _ssl
+            ahead = bool(_ssl._TEACHER_AHEAD and getattr(model, 'two_lanes', False) and getattr(getattr(wl, 'runner', None), 'draw_ahead', False))
+            if not ahead:
+                side.append('key-point FPS of all passes (one launch)')
+            out['config']['side_stream'] = side
+            if ahead:
+                # SSL._forward_train: these wait for the previous iteration's EMA and the batch, not for its last backward
+                out['config']['ahead_of_previous_tail'] = ['voxelize + rulebooks + key-point FPS of all passes (teacher lane)',
+                                                           "teacher's 2D pass (2D lane)"]
             out['config']['issue'] = ('chained: one C-ABI call per static sub-graph (dm_chain_run)' if chain.ENABLED
                                       else 'op by op') + ('' if not chain.OFF else ', families off: %s' % sorted(chain.OFF))
         # pseudo-label bookkeeping of the timed steps: proves the step exercises matching (NumPreds

@@ -343,6 +343,7 @@ class SSL(nn.Module):
     # ---- state-dict fan-out (ssl.py:102-127) ------------------------------------
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
                               unexpected_keys, error_msgs):
+        self._ema_done = None          # the teacher is rewritten on the caller's stream: no early teacher pass in the next iteration
         loading_pretrained = not any('teacher' in k for k in state_dict.keys())
         if loading_pretrained:
             self.teacher.load_state_dict(state_dict)
@@ -368,6 +369,7 @@ class SSL(nn.Module):
         FlatGradDDP the student's trainable parameters come first, in gradient-arena order, and
         `ddp.flat_params` becomes that prefix of the student arena."""
         self._frozen_bn_differs = None
+        self._ema_done = None          # (the tensors are re-homed on the caller's stream)
         first = None
         if ddp is not None:
             name_of = {id(p): n for n, p in self.student.named_parameters()}

@@ -44,6 +44,7 @@ if has tools; then
   timeout 100 python3 tools/cpu_vs_gpu_bound.py 2>&1 | grep "detmatch:\|CPU ms" > $O/host_vs_device.txt
   DM_CHAIN=0 timeout 100 python3 tools/cpu_vs_gpu_bound.py 2>&1 | grep "detmatch:\|CPU ms" | sed "s/^/DM_CHAIN=0 /" >> $O/host_vs_device.txt
   timeout 100 python3 tools/find_syncs.py 2>&1 | grep -v "amdgpu.ids" > $O/host_syncs.txt
+  timeout 100 python3 tools/steady_timeline.py 7 2>&1 | grep -v "amdgpu.ids" > $O/steady_timeline.txt
 fi
 if has ab; then
   # 3. round-5 A/Bs (same box, alternated)
