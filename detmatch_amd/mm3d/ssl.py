@@ -29,7 +29,7 @@ _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued be
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
 _TRUNK_ON_2D_LANE = False     # the unlabeled 3D trunk on the 2D lane beside the supervised backward: measured WORSE (59.6 / 70.0 / 56.7 against
                               # 55.2 / 60.0 / 56.4 ms: it delays the teacher, whose read-back gates the glue) — off, kept for the record
-_TEACHER_AHEAD = os.environ.get('DM_TEACHER_AHEAD', '1') == '1'   # the teacher's passes + all geometry wait for the EMA, not for the previous iteration's last backward
+_TEACHER_AHEAD = os.environ.get('DM_TEACHER_AHEAD', '1') == '1'   # geometry + the teacher's 2D pass wait for the previous EMA (and the batch), not for the previous iteration's last backward
 _TEACHER_AHEAD_ALL = os.environ.get('DM_TEACHER_AHEAD_ALL', '0') == '1'   # ... the teacher's 3D pass too (else: its 2D pass only)
 _SUP_BWD_PER_LANE = os.environ.get('DM_SUP_BWD_PER_LANE', '0') == '1'   # supervised 2D losses back-propagated on the 2D lane
 _2D_INSIDE_3D = True      # the last 2D module between the issue and the read-back of its 3D neighbour: 60.2-60.5 against 61.4-62.0 ms (profiles/r06_ab_step_variants.txt)
@@ -767,8 +767,9 @@ class SSL(nn.Module):
 
         branches_first = lanes is not None and lanes.mode == 'branches' and _ISSUE_EARLY
         ahead = None
+        ready = self.__dict__.pop('_data_ready', None)      # (set by the runner for THIS iteration only)
         if branches_first and _TEACHER_AHEAD:
-            ema, ready = getattr(self, '_ema_done', None), self.__dict__.pop('_data_ready', None)
+            ema = getattr(self, '_ema_done', None)
             if ema is not None and ready is not None:
                 ahead = (ema, ready)
         if ahead is not None:
@@ -776,8 +777,10 @@ class SSL(nn.Module):
             # that iteration's last backward pass (ssl.py:348) — and the geometry reads nothing but the batch.  So the 2D
             # and the teacher lane do not wait for the main stream's tail (backward, clip, optimizer: 10+ ms of device
             # time behind the host) but for the EMA's event and the batch's: the geometry of all passes (+ the key-point
-            # FPS) goes to the teacher lane, its ONE size read-back returns at once, and both teacher passes are issued
-            # and run underneath the student's last backward.  The student's passes wait for the optimizer as before.
+            # FPS) goes to the teacher lane, its ONE size read-back returns at once, and the teacher's 2D pass is issued
+            # and runs underneath the student's last backward.  (The teacher's 3D pass stays in chain order: issued here
+            # too — _TEACHER_AHEAD_ALL — the host reaches the student's labeled pass 10 ms later and the main lane idles;
+            # measured 5 ms worse.)  The student's passes wait for the optimizer as before.
             from ..pcdet.pfe import VoxelSetAbstraction
             for s in lanes.streams[1:]:
                 s.wait_event(ahead[0])
