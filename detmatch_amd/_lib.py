@@ -523,11 +523,11 @@ _AUX = {}
 
 
 def aux_stream(device):
-    """THE side stream of a device for work that rides beside the iteration (key-point FPS, the geometry of the next
-    iteration).  One, on purpose: the runtime multiplexes HIP streams onto 4 hardware queues (GPU_MAX_HW_QUEUES), and
-    with the default stream and the two stream lanes of SSL.forward_train this is the fourth — round 5 measured a
-    device-side dead-lock (every queue waiting, no kernel running) once per ~200 iterations with seven streams sharing
-    the four queues, and 107 instead of 71 ms per iteration with GPU_MAX_HW_QUEUES=8."""
+    """THE side stream of a device for work that rides beside the iteration (the weight-gradient halves of the chained
+    backward passes, the key-point encoder beside the BEV backbone, the key-point FPS when it is not issued on the teacher
+    lane).  One, on purpose: the runtime multiplexes HIP streams onto 4 hardware queues (GPU_MAX_HW_QUEUES; more cost
+    30 ms per iteration once an RCCL communicator exists, profiles/r06_hw_queues_with_rccl.txt), and with the main stream and
+    the two stream lanes of SSL.forward_train this is the fourth."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     s = _AUX.get(idx)
     if s is None:
