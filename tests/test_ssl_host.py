@@ -535,3 +535,44 @@ def test_hybrid_optimizer_skips_members_that_cannot_have_gradients():
     frozen[0].grad = torch.ones(2)            # somebody handed it a gradient after all: torch decides
     opt.step()
     assert calls == [1]
+
+
+def test_runner_draws_one_batch_ahead_in_the_same_order_and_not_beyond_the_end():
+    """IterBasedSSLRunner.draw_ahead (what lets SSL._forward_train start the geometry / the teacher's 2D pass under the
+    previous iteration's tail): batch i + 1 is drawn before iteration i is issued — the model sees the same batches in
+    the same order as without, and nothing is drawn for an iteration that will not run."""
+    class Counting(list):
+        draws = 0
+
+        def __iter__(self):
+            for item in list.__iter__(self):
+                type(self).draws += 1
+                yield item
+
+    class Lab(Counting):
+        pass
+
+    class Unlab(Counting):
+        pass
+
+    seen = {}
+    for ahead in (False, True):
+        torch.manual_seed(0)
+        model = _Toy()
+        model.prefetch_geometry = lambda *a, **k: None
+        got = []
+        step = model.train_step
+        model.train_step = lambda data, optimizer=None, got=got, step=step: (got.append(float(data['lab_stu'][0, 0])),
+                                                                              step(data, optimizer))[1]
+        run = R.IterBasedSSLRunner(model, optimizer=R.build_optimizer(model, OPT_CFG), max_iters=5)
+        run.lookahead, run.draw_ahead = False, ahead
+        run.register_training_hooks(lr_config=dict(policy='step', step=[]), optimizer_config=dict(grad_clip=None))
+        Lab.draws = Unlab.draws = 0
+        lab = Lab(dict(stu=torch.full((4, 2), float(i)), img_metas=[0, 1]) for i in range(3))
+        unlab = Unlab(dict(stu=torch.full((4, 2), float(10 + i)), img_metas=[0, 1]) for i in range(4))
+        run.run([lab, unlab], [('train', 1)])
+        assert run.iter == 5
+        seen[ahead] = (got, Lab.draws, Unlab.draws)
+        assert not hasattr(model, '_data_ready') or not torch.cuda.is_available()
+    assert seen[True][0] == seen[False][0] == [0.0, 1.0, 2.0, 0.0, 1.0]
+    assert seen[True][1:] == seen[False][1:] == (5, 5)
