@@ -28,7 +28,8 @@ def add_prefix(inputs, prefix):
 _ISSUE_EARLY = True       # SSL modules' issue_early: unlabeled passes issued before their chain inputs exist
 _EARLY_2D_BWD = True      # SSL._early_2d_backward: unlabeled 2D losses + deferred 2D trunk backward right after the last 2D module
 _TRUNK_ON_2D_LANE = os.environ.get('DM_TRUNK_ON_2D_LANE', '0') == '1'     # the unlabeled 3D trunk on the 2D lane beside the supervised backward: measured WORSE (59.6 / 70.0 / 56.7 against
-                              # 55.2 / 60.0 / 56.4 ms: it delays the teacher, whose read-back gates the glue) — off, kept for the record
+                              # 55.2 / 60.0 / 56.4 ms: it delays the teacher, whose read-back gates the glue; no gain with the final order either,
+                              # profiles/r06_ab_step_variants.txt) — off, kept for the record
 _TEACHER_AHEAD = os.environ.get('DM_TEACHER_AHEAD', '1') == '1'   # geometry + the teacher's 2D pass wait for the previous EMA (and the batch), not for the previous iteration's last backward
 _TEACHER_AHEAD_ALL = os.environ.get('DM_TEACHER_AHEAD_ALL', '0') == '1'   # ... the teacher's 3D pass too (else: its 2D pass only)
 _SUP_BWD_PER_LANE = os.environ.get('DM_SUP_BWD_PER_LANE', '0') == '1'   # supervised 2D losses back-propagated on the 2D lane
