@@ -468,27 +468,12 @@ class SSL(nn.Module):
         return losses
 
     def _parse_losses(self, losses):
-        """mmdet BaseDetector._parse_losses: loss = sum of the entries whose key contains
-        'loss'.  The reference all-reduces every logged scalar separately (C2 in SURVEY §2.2);
-        here all of them travel in ONE packed all-reduce."""
-        log_vars = {}
-        for name, value in losses.items():
-            if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
-            elif isinstance(value, list):
-                log_vars[name] = sum(_l.mean() for _l in value)
-            else:
-                raise TypeError('%s is not a tensor or list of tensors' % name)
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
-        log_vars['loss'] = loss
-        keys = list(log_vars.keys())
-        packed = torch.stack([log_vars[k].detach().float() for k in keys])
-        if dist.is_available() and dist.is_initialized():
-            from .parallel import all_reduce
-            all_reduce(packed)
-            packed = packed / dist.get_world_size()
-        # kept on the device: the logger calls .item() when (and if) it prints
-        return loss, {k: packed[i] for i, k in enumerate(keys)}
+        """mmdet BaseDetector._parse_losses: loss = sum of the entries whose key contains 'loss'.  The reference
+        all-reduces every logged scalar separately (C2 in SURVEY §2.2); here the loss comes first and alone, and the
+        logged values travel in ONE packed all-reduce when somebody reads them (base_detector.LazyLogVars) — this
+        sits between the last glue module and the last backward pass, with the main lane idle."""
+        from .base_detector import DetectorStepMixin
+        return DetectorStepMixin._parse_losses(self, losses)
 
     # ---- step ------------------------------------------------------------------------------
     @staticmethod
