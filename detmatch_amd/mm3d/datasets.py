@@ -349,6 +349,8 @@ def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, t
         model.share_2d_trunk = True      # the OptimizerHook below finishes the deferred trunk backward
     optimizer = R.build_optimizer(model, cfg['optimizer'])
     ddp = FlatGradDDP(model, broadcast=distributed and world > 1) if dev.type == 'cuda' else model
+    from .schedule import apply_issue_order
+    apply_issue_order(model, ddp)        # the order bench.py measures: stream lanes, early backward passes, side stream
     if isinstance(ddp, FlatGradDDP) and hasattr(optimizer, 'enable_fused'):
         inner = ddp.module
         if hasattr(inner, 'build_arenas'):
@@ -362,6 +364,7 @@ def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, t
     runner = build_from_cfg(rcfg, RUNNERS, default_args=dict(
         model=ddp, optimizer=optimizer, work_dir=cfg.get('work_dir', None), logger=None, meta=meta))
     runner.timestamp = timestamp
+    apply_issue_order(model, ddp, runner)
     # ssl_train.py:100-105: cfg.fp16 -> Fp16OptimizerHook.  Here: the mixed-precision mode of the GEMM-shaped
     # kernels (bf16 multiplicands, fp32 accumulation / storage / master weights: detmatch_amd/precision.py);
     # bf16 has fp32's exponent range, so the hook's loss_scale is accepted and not needed

@@ -251,45 +251,14 @@ class DetMatchTrainWorkload(object):
         sched = configs.detmatch_schedule(batch_size, 1)
         self.ddp = FlatGradDDP(self.model, broadcast=False, mode=os.environ.get('DM_GRAD_MODE', 'collect'))
         self.opt = R.build_optimizer(self.model, sched['optimizer'])
-        self.model.early_backward = True
-        # one backbone + FPN + RPN pass for the student's labeled and unlabeled images (mm2d/faster_rcnn.py:
-        # prefetch_trunk; the OptimizerHook of the runner finishes the deferred trunk backward)
-        self.model.share_2d_trunk = os.environ.get('DM_SHARE_2D_TRUNK', '1') == '1'
-        # weight-gradient halves of the chained backward passes on the side stream (scheduling only; the gradients are
-        # read by ddp.collect, which waits for them) — with the lanes and the collect mode only
-        self.model.side_wgrad = True          # (IterBasedSSLRunner.train applies it for the length of an iteration; the equality test flips it)
-        if self.ddp.mode == 'collect':
-            # (measured neutral on the step time, -190 launches: on by default) gradients of every early backward pass are folded into the flat arena by batched
-            # multi-tensor adds and released, so autograd never accumulates tensor by tensor
-            self.model.after_partial_backward = self.ddp.collect
-        # Stream lanes (ssl.py:_Lanes; data-flow edges of the batch dict become event waits).
-        #   'branches' (DEFAULT, DM_TWO_LANES=1): student 3D / both 2D detectors / teacher 3D + glue on three HIP
-        #       streams, the static sub-graphs issued as chains (chain.py): the long tails of small 3D kernels run
-        #       underneath the 2D convolutions — 64-66 ms per iteration against 82 in 'glue' (round 5, same box).
-        #   'glue' (DM_TWO_LANES=0): every detector pass on the caller's stream, strictly ordered, only the pseudo-label
-        #       glue with its host read-backs on a side stream; DM_LANE_MODE=serial: one stream.
-        # Same gradients and losses in all orders (tests/test_ssl_gpu.py).  The "device dead-lock of the lanes" of
-        # round 5 was a vendor Stream-K GEMM of one lane spinning for ever next to a second one of another lane
-        # (DESIGN.md 6.R6); vendor GEMMs are issued one at a time since (_lib.blas_turn), and the order is the default
-        # at any world size — RCCL's stream included (profiles/r06_lane_soak.txt: 2 000 iterations, one rank, nccl).
-        # In the timed region a HIP-event pair around a kernel of one lane also contains the time the dispatch queues
-        # behind the other lanes' kernels; bench.py therefore takes the roofline kernel's duration from extra steps
-        # issued on one stream.
-        self.model.two_lanes = os.environ.get('DM_TWO_LANES', '1') == '1'
-        mode = os.environ.get('DM_LANE_MODE', 'glue')
-        self.model.lane_mode = None if (self.model.two_lanes or mode in ('serial', 'none', '0', '')) else mode
+        from ..mm3d.schedule import apply_issue_order
+        apply_issue_order(self.model, self.ddp)          # lanes, early backward passes, shared 2D trunk, side stream
         self.model.build_arenas(self.ddp)      # one layout for EMA, gradients and optimizer
         self.n_fused = self.opt.enable_fused(self.ddp)
         self.runner = R.IterBasedSSLRunner(self.ddp, optimizer=self.opt, max_iters=10 ** 9)
         self.runner.register_training_hooks(sched['lr_config'], sched['optimizer_config'],
                                             sched['custom_hooks'])
-        if self.model.two_lanes and 'DM_LOOKAHEAD' not in os.environ:
-            # With the lanes the geometry is prepared at the start of its own iteration: the early-issued 2D passes
-            # already fill the gap the look-ahead used to fill, and the look-ahead's extra side-stream work costs
-            # more than it hides (70.0 / 69.8 against 66.5 ms, profiles/r06_lane_soak.txt).  (Round 5 switched it off
-            # because it made the Stream-K dead-lock more frequent; it is safe now, just not faster.)
-            self.runner.lookahead = False
-            self.runner.draw_ahead = True      # SSL._forward_train: teacher passes + geometry ahead of the previous iteration's tail
+        apply_issue_order(self.model, self.ddp, self.runner)
         self.runner.call_hook('before_run')
         self.world = 1
         self.params = self.ddp.params
