@@ -815,6 +815,7 @@ class IterBasedSSLRunner(_RunnerBase):
 
     @staticmethod
     def _draw(lab_data_loader, unlab_data_loader):
+        epoch = getattr(lab_data_loader, 'epoch', 0)       # as IterBasedRunner.train reads it: BEFORE this batch is drawn
         lab = next(lab_data_loader)
         unlab = next(unlab_data_loader)
         data_batch = {'lab_%s' % k: v for k, v in lab.items()}
@@ -824,14 +825,13 @@ class IterBasedSSLRunner(_RunnerBase):
         if torch.cuda.is_available():
             ready = torch.cuda.Event()
             ready.record()
-        return data_batch, ready
+        return data_batch, ready, epoch
 
     def train(self, lab_data_loader, unlab_data_loader, **kwargs):
         _ensure_train_mode(self.model)
         self.mode = 'train'
-        self._epoch = getattr(lab_data_loader, 'epoch', 0)
         ahead = getattr(self, '_ahead', None)
-        data_batch, ready = ahead if ahead is not None else self._draw(lab_data_loader, unlab_data_loader)
+        data_batch, ready, self._epoch = ahead if ahead is not None else self._draw(lab_data_loader, unlab_data_loader)
         self._ahead = None
         prefetch = getattr(_inner(self.model), 'prefetch_geometry', None)
         draw_ahead = self.lookahead or self.draw_ahead

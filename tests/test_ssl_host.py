@@ -567,12 +567,20 @@ def test_runner_draws_one_batch_ahead_in_the_same_order_and_not_beyond_the_end()
         run = R.IterBasedSSLRunner(model, optimizer=R.build_optimizer(model, OPT_CFG), max_iters=5)
         run.lookahead, run.draw_ahead = False, ahead
         run.register_training_hooks(lr_config=dict(policy='step', step=[]), optimizer_config=dict(grad_clip=None))
+        epochs = []
+
+        class Spy(R.Hook):
+            def after_train_iter(self, runner):
+                epochs.append(runner.epoch)
+        run.register_hook(Spy())
         Lab.draws = Unlab.draws = 0
         lab = Lab(dict(stu=torch.full((4, 2), float(i)), img_metas=[0, 1]) for i in range(3))
         unlab = Unlab(dict(stu=torch.full((4, 2), float(10 + i)), img_metas=[0, 1]) for i in range(4))
         run.run([lab, unlab], [('train', 1)])
         assert run.iter == 5
-        seen[ahead] = (got, Lab.draws, Unlab.draws)
+        seen[ahead] = (got, Lab.draws, Unlab.draws, epochs)
         assert not hasattr(model, '_data_ready') or not torch.cuda.is_available()
     assert seen[True][0] == seen[False][0] == [0.0, 1.0, 2.0, 0.0, 1.0]
-    assert seen[True][1:] == seen[False][1:] == (5, 5)
+    assert seen[True][1:3] == seen[False][1:3] == (5, 5)
+    # runner.epoch is the labeled loader's epoch BEFORE the iteration's batch was drawn (IterBasedRunner.train), ahead or not
+    assert seen[True][3] == seen[False][3] == [0, 0, 0, 0, 1]
