@@ -584,3 +584,34 @@ def test_runner_draws_one_batch_ahead_in_the_same_order_and_not_beyond_the_end()
     assert seen[True][1:3] == seen[False][1:3] == (5, 5)
     # runner.epoch is the labeled loader's epoch BEFORE the iteration's batch was drawn (IterBasedRunner.train), ahead or not
     assert seen[True][3] == seen[False][3] == [0, 0, 0, 0, 1]
+
+
+def test_issue_order_is_decided_in_one_place(monkeypatch):
+    """mm3d/schedule.py: the config-driven entry and the bench workload call the same function; it leaves non-SSL models and
+    plain (non-FlatGradDDP) wrappers alone, and switches the look-ahead draw on only together with the lanes."""
+    from detmatch_amd.mm3d.parallel import FlatGradDDP
+    from detmatch_amd.mm3d.schedule import apply_issue_order
+
+    class Fake(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = nn.Linear(2, 2)
+
+        def _forward_train(self):
+            pass
+
+    plain = nn.Linear(2, 2)
+    assert apply_issue_order(plain, FlatGradDDP(plain, broadcast=False)) is False and not hasattr(plain, 'two_lanes')
+    m = Fake()
+    assert apply_issue_order(m, m) is False                     # not wrapped: one stream, one backward pass
+    for lanes in ('1', '0'):
+        monkeypatch.setenv('DM_TWO_LANES', lanes)
+        monkeypatch.delenv('DM_LOOKAHEAD', raising=False)
+        m = Fake()
+        ddp = FlatGradDDP(m, broadcast=False)
+        run = R.IterBasedSSLRunner(ddp, optimizer=torch.optim.SGD(m.parameters(), lr=0.1), max_iters=1)
+        before = run.lookahead
+        assert apply_issue_order(m, ddp) and apply_issue_order(m, ddp, run)
+        assert m.early_backward and m.side_wgrad and m.share_2d_trunk and m.after_partial_backward == ddp.collect
+        assert m.two_lanes == (lanes == '1') and m.lane_mode == (None if lanes == '1' else 'glue')
+        assert run.draw_ahead == (lanes == '1') and run.lookahead == (False if lanes == '1' else before)
