@@ -732,6 +732,15 @@ class _RunnerBase(object):
             for k, v in lv.items():
                 buf.setdefault(k, []).append(v)
 
+    def _settle_lazy_logs(self):
+        """With more than one rank the logged values are averaged by a collective when they are first read
+        (base_detector.LazyLogVars): every rank reads them here, at the same point of the iteration (behind the hooks, i.e.
+        behind the issued backward pass) — a reader that only exists on rank 0 (a logger, bench.py) must not be the one that
+        starts the all-reduce."""
+        import torch.distributed as dist
+        if self._lazy_logs and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.log_buffer
+
     @property
     def log_buffer(self):
         """{key: [value per iteration]}; lazily parsed log_vars of finished iterations are folded in on access."""
@@ -771,6 +780,7 @@ class EpochBasedRunner(_RunnerBase):
             self.call_hook('before_train_iter')
             self._after_step(self.model.train_step(data_batch, self.optimizer, **kwargs))
             self.call_hook('after_train_iter')
+            self._settle_lazy_logs()
             self._iter += 1
         self.call_hook('after_train_epoch')
         self.call_hook('after_epoch')
@@ -852,6 +862,7 @@ class IterBasedSSLRunner(_RunnerBase):
         try:
             self._after_step(self.model.train_step(data_batch, self.optimizer, **kwargs))
             self.call_hook('after_train_iter')
+            self._settle_lazy_logs()
         finally:
             _chain.SIDE_WGRAD[0] = False
         if self._ahead is not None and self.lookahead:
