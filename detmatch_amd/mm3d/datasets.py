@@ -322,6 +322,124 @@ def build_dataset(cfg, default_args=None):
 
 
 # --------------------------------------------------------------------------------------------
+# validation (ssl_train.py:119-140: build_dataset(cfg.data.val, test_mode=True) -> EvalHook)
+def compile_test_pipeline(decls):
+    """The test pipeline of configs/detmatch/001 (split_0.py:700-760): LoadImageFromFile, LoadPointsFromFile,
+    MultiScaleFlipAug3D(ONE img_scale, flip=False; identity GlobalRotScaleTrans, Resize(keep_ratio), RandomFlip3D,
+    PointsRangeFilter, Normalize, Pad, DefaultFormatBundle3D, Collect3D(points, img)) -> the arguments of KittiTestLoader.
+    Anything else (test-time augmentation: several scales, flips) is outside the DetMatch path and refused."""
+    names = _names(decls)
+    if names != ['LoadImageFromFile', 'LoadPointsFromFile', 'MultiScaleFlipAug3D']:
+        raise ValueError('test pipeline: %s' % names)
+    msfa = decls[2]
+    a = msfa.args
+    scale = a['img_scale']
+    if isinstance(scale, (list, tuple)) and scale and isinstance(scale[0], (list, tuple)):
+        if len(scale) != 1:
+            raise ValueError('test-time augmentation (several image scales) is outside the DetMatch path')
+        scale = scale[0]
+    if a.get('flip', False) or a.get('pts_scale_ratio', 1) != 1:
+        raise ValueError('test-time augmentation (flip / point scaling) is outside the DetMatch path')
+    inner = {t['type']: t for t in a['transforms']}
+    order = [t['type'] for t in a['transforms']]
+    want = ['GlobalRotScaleTrans', 'Resize', 'RandomFlip3D', 'PointsRangeFilter', 'Normalize', 'Pad',
+            'DefaultFormatBundle3D', 'Collect3D']
+    if order != want:
+        raise ValueError('test pipeline transforms: %s' % order)
+    g = inner['GlobalRotScaleTrans']
+    if list(g.get('rot_range', [0, 0])) != [0, 0] or list(g.get('scale_ratio_range', [1, 1])) != [1.0, 1.0] or \
+            any(float(v) != 0 for v in g.get('translation_std', [0, 0, 0])):
+        raise ValueError('test pipeline: GlobalRotScaleTrans must be the identity')
+    if not inner['Resize'].get('keep_ratio', False) or list(inner['Collect3D']['keys']) != ['points', 'img']:
+        raise ValueError('test pipeline: Resize(keep_ratio=True), Collect3D(points, img)')
+    n = inner['Normalize']
+    if n.get('to_rgb', True):
+        raise ValueError('Normalize: to_rgb=False (caffe-style backbone)')
+    load = decls[1].args
+    return dict(img_scale=tuple(int(v) for v in scale), point_cloud_range=list(inner['PointsRangeFilter']['point_cloud_range']),
+                img_mean=tuple(n['mean']), img_std=tuple(n['std']), size_divisor=int(inner['Pad'].get('size_divisor', 32)),
+                load_dim=int(load.get('load_dim', 4)), use_dim=load.get('use_dim', 4))
+
+
+class KittiTestLoader(object):
+    """The validation loader (mmdet build_dataloader(val_dataset, shuffle=False) + the test pipeline on the CPU workers,
+    ssl_train.py:121-131): frames in order, rank r of a distributed run takes every world-th one (DistributedSampler without
+    padding: every frame is evaluated once), each batch in the layout MultiScaleFlipAug3D + collate hand to forward_test —
+    one-element lists of (points list, img_metas list, stacked images)."""
+
+    def __init__(self, dataset, samples_per_gpu, device, rank=0, world_size=1):
+        import torch
+        from ..ts_ssl_dataset import ImageResizeFlipNormPad
+        self.dataset, self.bs, self.device = dataset, max(int(samples_per_gpu), 1), torch.device(device)
+        self.args = compile_test_pipeline(dataset.pipeline_decls)
+        self.image_tf = ImageResizeFlipNormPad([self.args['img_scale']], mean=self.args['img_mean'],
+                                               std=self.args['img_std'], size_divisor=self.args['size_divisor'])
+        self.indices = list(range(rank, len(dataset), world_size))
+
+    def __len__(self):
+        return (len(self.indices) + self.bs - 1) // self.bs
+
+    def _sample(self, i):
+        import numpy as np
+        import torch
+        from .box3d import LiDARInstance3DBoxes
+        ds, a = self.dataset, self.args
+        info = ds.get_data_info(i)
+        use = a['use_dim']
+        use = list(range(use)) if isinstance(use, int) else list(use)
+        pts = torch.from_numpy(np.ascontiguousarray(ds.load_points(i, a['load_dim'], a['load_dim'])[:, use])).to(self.device)
+        r = pts.new_tensor(a['point_cloud_range'])
+        keep = ((pts[:, :3] > r[:3]) & (pts[:, :3] < r[3:])).all(dim=1)        # PointsRangeFilter (in_range_3d: open box)
+        pts = pts[keep]
+        img = torch.from_numpy(ds.load_image(i)).to(self.device)
+        img, meta = self.image_tf(img, self.args['img_scale'], False)
+        meta.update(sample_idx=info['sample_idx'], lidar2img=info['lidar2img'], filename=info['img_info']['filename'],
+                    pts_filename=info['pts_filename'], box_type_3d=LiDARInstance3DBoxes, box_mode_3d=0,
+                    pcd_horizontal_flip=False, pcd_vertical_flip=False, pcd_scale_factor=1.0,
+                    pcd_rotation=torch.eye(3), pcd_trans=np.zeros(3, np.float32), transformation_3d_flow=['R', 'S', 'T'])
+        return pts, img, meta
+
+    def __iter__(self):
+        import torch
+        import torch.nn.functional as F
+        for b0 in range(0, len(self.indices), self.bs):
+            items = [self._sample(i) for i in self.indices[b0:b0 + self.bs]]
+            ph = max(int(it[1].shape[1]) for it in items)
+            pw = max(int(it[1].shape[2]) for it in items)           # collate pads a stacked DataContainer to the largest
+            imgs = torch.stack([F.pad(it[1], (0, pw - it[1].shape[2], 0, ph - it[1].shape[1])) for it in items])
+            yield dict(points=[[it[0] for it in items]], img_metas=[[it[2] for it in items]], img=[imgs])
+
+
+def single_gpu_test(model, data_loader):
+    """mmdet3d/apis/test.py single_gpu_test without the visualisation branch: model.eval(); one
+    `model(return_loss=False, rescale=True, **data)` per batch under no_grad; results concatenated."""
+    import torch
+    model.eval()
+    results = []
+    with torch.no_grad():
+        for data in data_loader:
+            results.extend(model(return_loss=False, rescale=True, **data))
+    return results
+
+
+def multi_gpu_test(model, data_loader):
+    """mmdet multi_gpu_test for KittiTestLoader's sharding (rank r holds frames r, r + world, ...): every rank tests its
+    share, the parts are gathered as objects and interleaved back into dataset order; rank 0 gets the list, the others None."""
+    import torch.distributed as dist
+    part = single_gpu_test(model, data_loader)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return part
+    from .parallel import all_gather_object
+    parts = all_gather_object(part)
+    if dist.get_rank() != 0:
+        return None
+    out = [None] * sum(len(p) for p in parts)
+    for r, p in enumerate(parts):
+        out[r::len(parts)] = p
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # training entry
 def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, timestamp=None, meta=None,
                        device='cuda', max_iters=None):
@@ -375,7 +493,14 @@ def train_ssl_detector(model, dataset, cfg, distributed=False, validate=False, t
                                    checkpoint_config=cfg.get('checkpoint_config', None),
                                    log_config=cfg.get('log_config', None))
     if validate:
-        raise NotImplementedError('validation hook: use SSL.simple_test + KittiDataset.evaluate')
+        # ssl_train.py:119-140: the validation set through its test pipeline, an (Dist)EvalHook behind the training hooks
+        val_cfg = dict(data['val'])
+        val_spg = int(val_cfg.pop('samples_per_gpu', 1))
+        val_dataset = build_dataset(val_cfg, dict(test_mode=True))
+        val_loader = KittiTestLoader(val_dataset, val_spg, dev, rank=rank, world_size=world)
+        eval_cfg = dict(cfg.get('evaluation', {}) or {})
+        eval_cfg['by_epoch'] = rcfg['type'] not in ('IterBasedRunner', 'IterBasedSSLRunner')
+        runner.register_hook(R.EvalHook(val_loader, **eval_cfg))
     # ssl_train.py:157-166
     if cfg.get('resume_from', None):
         runner.resume(cfg['resume_from'])

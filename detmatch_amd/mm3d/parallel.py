@@ -69,6 +69,13 @@ def all_reduce(t, group=None, async_op=False, op=None):
     return dist.all_reduce(t, group=group, async_op=async_op, **kw)
 
 
+def all_gather_object(obj, group=None):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (torch.distributed.all_gather_object; the validation results)."""
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
 def broadcast(t, src, group=None):
     if t.is_cuda and _host_staged(group):
         h = t.detach().cpu()

@@ -406,6 +406,45 @@ class OptimizerHook(Hook):
 
 
 @HOOKS.register_module()
+class EvalHook(Hook):
+    """mmdet EvalHook / DistEvalHook (mmdet/core/evaluation/eval_hooks.py) as ssl_train.py:132-140 registers them: every
+    `interval` iterations (epochs with by_epoch) run the validation loader through the model in eval mode, hand the results
+    to `dataset.evaluate(results, logger=..., **eval_kwargs)` on rank 0 and put the metrics into the log buffer.  The
+    loader shards the frames over the ranks itself (datasets.KittiTestLoader); the runner puts the model back into
+    training mode at the start of the next iteration."""
+
+    def __init__(self, dataloader, start=None, interval=1, by_epoch=True, save_best=None, rule=None, **eval_kwargs):
+        assert save_best is None, 'save_best is not part of the DetMatch recipes'
+        self.dataloader, self.start, self.interval, self.by_epoch = dataloader, start, int(interval), by_epoch
+        self.eval_kwargs = eval_kwargs
+        self.last = None          # metrics of the latest evaluation (rank 0)
+
+    def _due(self, n):
+        if self.start is not None and n < self.start:
+            return False
+        return n % self.interval == 0
+
+    def _evaluate(self, runner):
+        from .datasets import multi_gpu_test
+        results = multi_gpu_test(runner.model, self.dataloader)
+        if results is None:           # not rank 0
+            return
+        res = self.dataloader.dataset.evaluate(results, logger=getattr(runner, 'logger', None), **self.eval_kwargs)
+        self.last = dict(res)
+        buf = runner.log_buffer
+        for k, v in res.items():
+            buf.setdefault(k, []).append(torch.as_tensor(float(v)))
+
+    def after_train_iter(self, runner):
+        if not self.by_epoch and self._due(runner.iter + 1):
+            self._evaluate(runner)
+
+    def after_train_epoch(self, runner):
+        if self.by_epoch and self._due(runner.epoch + 1):
+            self._evaluate(runner)
+
+
+@HOOKS.register_module()
 class StepLrUpdaterHook(Hook):
     """mmcv LrUpdaterHook, policy='step' (by_epoch False) with warmup: regular lr =
     base * gamma^(#steps passed); during the first warmup_iters iterations

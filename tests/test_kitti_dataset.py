@@ -133,3 +133,44 @@ def test_inference_to_evaluation_end_to_end(ds):
         for k in ('2d.KITTI/Overall_2D_moderate', '3d.KITTI/Overall_3D_moderate', '3d.KITTI/Overall_BEV_easy',
                   '3d.KITTI/Pedestrian_3D_hard_strict'):
             assert np.isfinite(ap['%s.%s' % (who, k)]), (who, k, sorted(ap))
+
+
+def test_validation_loader_applies_the_test_pipeline():
+    """datasets.KittiTestLoader (cfg.data.val, ssl_train.py:121-131) on the CPU: frames in order, sharded by rank; one
+    image scale with keep_ratio, Normalize, Pad(32), PointsRangeFilter, the img_metas forward_test / simple_test read, and
+    the one-element-list layout of MultiScaleFlipAug3D.  Test-time augmentation is refused."""
+    from detmatch_amd import configs
+    from detmatch_amd.mm3d import register_all
+    from detmatch_amd.mm3d.datasets import KittiTestLoader, build_dataset, compile_test_pipeline
+    register_all()
+    info = os.path.join(ROOT, 'kitti_infos_train.pkl')
+    data = configs.detmatch_data(data_root=ROOT + '/', batch_size=2, lab_info=info, unlab_info=info, val_info=info)
+    ds = build_dataset(data['val'], dict(test_mode=True))
+    assert ds.test_mode
+    args = compile_test_pipeline(ds.pipeline_decls)
+    assert args['img_scale'] == (1280, 384) and args['size_divisor'] == 32 and args['point_cloud_range'][3] == 70.4
+    loader = KittiTestLoader(ds, 1, 'cpu')
+    batches = list(loader)
+    assert len(loader) == len(batches) == len(ds)
+    b = batches[0]
+    assert set(b) == {'points', 'img_metas', 'img'} and all(isinstance(v, list) and len(v) == 1 for v in b.values())
+    pts, meta, img = b['points'][0][0], b['img_metas'][0][0], b['img'][0]
+    raw = ds.load_image(0)
+    h, w = raw.shape[:2]
+    k = min(1280 / max(h, w), 384 / min(h, w))
+    nh, nw = int(h * k + 0.5), int(w * k + 0.5)
+    assert meta['ori_shape'] == (h, w, 3) and meta['img_shape'] == (nh, nw, 3) and not meta['flip']
+    assert img.shape == (1, 3, (nh + 31) // 32 * 32, (nw + 31) // 32 * 32) and meta['pad_shape'][:2] == tuple(img.shape[2:])
+    assert float(img[0, :, nh:, :].abs().max() if nh < img.shape[2] else 0.0) == 0.0            # Pad: zeros
+    r = args['point_cloud_range']
+    assert pts.shape[1] == 4 and bool(((pts[:, 0] > r[0]) & (pts[:, 0] < r[3]) & (pts[:, 1] > r[1]) & (pts[:, 1] < r[4])).all())
+    assert 0 < pts.shape[0] <= ds.load_points(0).shape[0]
+    assert meta['transformation_3d_flow'] == ['R', 'S', 'T'] and meta['sample_idx'] == ds.get_data_info(0)['sample_idx']
+    assert np.allclose(meta['lidar2img'], ds.get_data_info(0)['lidar2img'])
+    # rank 1 of 2 has nothing of a one-frame set; every frame is evaluated exactly once over the ranks
+    assert len(KittiTestLoader(ds, 1, 'cpu', rank=1, world_size=2)) == 0
+    bad = dict(data['val'])
+    bad['pipeline'] = [dict(t) for t in bad['pipeline']]
+    bad['pipeline'][2] = dict(bad['pipeline'][2], flip=True)
+    with pytest.raises(ValueError):
+        compile_test_pipeline(build_dataset(bad, dict(test_mode=True)).pipeline_decls)

@@ -117,8 +117,16 @@ def test_train_ssl_detector_from_config():
     model.teacher.load_state_dict(model.student.state_dict())
     datasets = [build_dataset(cfg['data']['train_lab']), build_dataset(cfg['data']['train_unlab'])]
     assert len(datasets[0]) == 100 * len(datasets[1]) and datasets[0].labeled and not datasets[1].labeled
-    run = train_ssl_detector(model, datasets, cfg, device='cuda:0')
+    # validate=True (ssl_train.py:119-140): cfg.data.val through its test pipeline, an EvalHook every `evaluation.interval`
+    # iterations -> KittiDataset.evaluate -> tea / stu x 2d / 3d KITTI metrics in the log buffer
+    cfg['data']['val'] = dict(cfg['data']['val'], ann_file=info)
+    cfg['evaluation'] = dict(interval=3)
+    run = train_ssl_detector(model, datasets, cfg, device='cuda:0', validate=True)
     assert run.iter == 3
+    ev = [h for h in run._hooks if type(h).__name__ == 'EvalHook']
+    assert len(ev) == 1 and not ev[0].by_epoch and ev[0].last is not None
+    for k in ('tea.3d.KITTI/Overall_3D_moderate', 'stu.2d.KITTI/Overall_2D_moderate', 'stu.3d.KITTI/Overall_BEV_easy'):
+        assert np.isfinite(ev[0].last[k]) and k in run.log_buffer, (k, sorted(ev[0].last))
     losses = [float(v) for v in run.log_buffer['loss']]
     assert all(np.isfinite(losses)), losses
     # the config-driven entry runs the issue order bench.py measures (mm3d/schedule.py): stream lanes, early backward
@@ -126,3 +134,4 @@ def test_train_ssl_detector_from_config():
     # teacher's 2D pass behind the previous EMA)
     assert model.two_lanes and model.early_backward and model.side_wgrad and model.share_2d_trunk
     assert run.draw_ahead and not run.lookahead and getattr(model, '_ema_done', None) is not None
+
