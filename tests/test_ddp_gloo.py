@@ -429,3 +429,53 @@ def test_lazy_log_vars_are_settled_on_every_rank_world2():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == 'ok', 'rank %d: %s' % (rank, msg)
+
+
+def _multi_test_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from detmatch_amd.mm3d.datasets import multi_gpu_test
+
+        class Loader(object):                     # KittiTestLoader's sharding: rank r holds frames r, r + world, ...
+            def __init__(self, n):
+                self.indices = list(range(rank, n, world))
+
+            def __iter__(self):
+                for i in self.indices:
+                    yield dict(frame=[i])
+
+        class Model(nn.Module):
+            def forward(self, return_loss=True, rescale=False, frame=None):
+                assert not return_loss and rescale and not self.training
+                return [dict(frame=f, rank=rank) for f in frame]
+
+        out = multi_gpu_test(Model(), Loader(7))
+        if rank == 0:
+            assert [r['frame'] for r in out] == list(range(7))             # dataset order again
+            assert [r['rank'] for r in out] == [0, 1, 0, 1, 0, 1, 0]
+        else:
+            assert out is None
+        q.put((rank, 'ok'))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_validation_results_are_gathered_in_dataset_order_world2():
+    """datasets.multi_gpu_test (mmdet multi_gpu_test for the rank-sharded validation loader): rank 0 evaluates the frames
+    in dataset order, the other ranks get None."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_multi_test_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', 'rank %d: %s' % (rank, msg)
