@@ -613,9 +613,58 @@ class _PassThroughHook(Hook):
         pass
 
 
-for _n in ('WandbVisHook', 'TextLoggerHook', 'TensorboardLoggerHook', 'WandbLoggerHook'):
+for _n in ('WandbVisHook', 'TensorboardLoggerHook', 'WandbLoggerHook'):
     # logging back-ends are outside the hot path: registered so configs build
     HOOKS.register_module(type(_n, (_PassThroughHook,), {}))
+
+
+@HOOKS.register_module()
+class TextLoggerHook(Hook):
+    """mmcv TextLoggerHook, the part a training run is watched through: every `interval` iterations rank 0 writes one line —
+    iteration, learning rate(s), seconds per iteration over the window, peak device memory, and the mean of every logged
+    value over the window (`log_config = dict(interval=50, hooks=[dict(type='TextLoggerHook')])`).  The values stay on the
+    device until here: one read-back per `interval` iterations.  File / json output and ETA are not reproduced."""
+
+    def __init__(self, by_epoch=True, interval=10, ignore_last=True, reset_flag=False, interval_exp_name=1000, **kwargs):
+        self.interval = int(interval)
+        self._t = None
+        self.lines = []            # what was written (rank 0), newest last; at most 100 kept
+
+    def before_run(self, runner):
+        self._t = time.time()
+
+    def after_train_iter(self, runner):
+        if (runner.iter + 1) % self.interval != 0:
+            return
+        runner._settle_lazy_logs()              # on EVERY rank: the collective behind the logged values (see there)
+        if not _is_rank0():
+            return
+        now = time.time()
+        dt = (now - (self._t or now)) / self.interval
+        self._t = now
+        parts = []
+        lrs = getattr(runner.optimizer, 'optimizers', [runner.optimizer])
+        parts.append('lr: ' + ' '.join('%.3e' % o.param_groups[0]['lr'] for o in lrs if getattr(o, 'param_groups', None)))
+        parts.append('time: %.3f' % dt)
+        if torch.cuda.is_available():
+            parts.append('memory: %d' % (torch.cuda.max_memory_allocated() // (1 << 20)))
+        buf = runner.log_buffer
+        keys = [k for k in buf if buf[k]]
+        if keys:
+            def scalar(v, dev):
+                v = v.detach() if torch.is_tensor(v) else torch.as_tensor(v)
+                return v.float().reshape(()).to(dev)
+            dev = next((v.device for k in keys for v in buf[k][-self.interval:] if torch.is_tensor(v) and v.is_cuda), 'cpu')
+            means = torch.stack([torch.stack([scalar(v, dev) for v in buf[k][-self.interval:]]).mean() for k in keys])
+            parts.extend('%s: %.4f' % (k, v) for k, v in zip(keys, means.tolist()))           # ONE read-back
+        total = getattr(runner, 'max_iters', None)
+        line = 'Iter [%d/%s]\t%s' % (runner.iter + 1, total if total is not None else '?', ', '.join(parts))
+        self.lines = (self.lines + [line])[-100:]
+        logger = getattr(runner, 'logger', None)
+        if logger is not None and hasattr(logger, 'info'):
+            logger.info(line)
+        else:
+            print(line, flush=True)
 
 
 class IterLoader(object):
@@ -680,10 +729,17 @@ class _RunnerBase(object):
     inner_iter = property(lambda self: self._inner_iter)
     max_iters = property(lambda self: self._max_iters)
 
-    def register_hook(self, hook):
+    def register_hook(self, hook, late=False):
+        """Hooks run in registration order; `late` ones (mmcv priority VERY_LOW: the loggers) stay behind every other hook,
+        whenever those are registered (an EvalHook added after register_training_hooks still runs in front of the logger)."""
         if isinstance(hook, dict):
             hook = build_from_cfg(hook, HOOKS)
-        self._hooks.append(hook)
+        n_late = getattr(self, '_n_late', 0)
+        if late:
+            self._hooks.append(hook)
+            self._n_late = n_late + 1
+        else:
+            self._hooks.insert(len(self._hooks) - n_late, hook)
 
     # ---- checkpoints (mmcv BaseRunner.save_checkpoint / load_checkpoint / resume; mmcv format:
     # dict(meta=dict(epoch, iter, ...), state_dict=..., optimizer=...), 'module.' prefix stripped)
@@ -731,8 +787,8 @@ class _RunnerBase(object):
     def register_training_hooks(self, lr_config=None, optimizer_config=None, custom_hooks=None,
                                 momentum_config=None, checkpoint_config=None, log_config=None, **ignored):
         """Order = mmcv priorities for this set: LR (VERY_HIGH) < momentum (HIGH) < optimizer
-        (ABOVE_NORMAL) < checkpoint (NORMAL) < custom (NORMAL).  log_config names logging back-ends, which
-        are pass-throughs here (outside the step); evaluation configs are not taken."""
+        (ABOVE_NORMAL) < checkpoint (NORMAL) < custom (NORMAL) < loggers (VERY_LOW, `late`).  Of the logging back-ends of
+        log_config only TextLoggerHook writes something (one line per interval); the others are pass-throughs."""
         if lr_config is not None:
             cfg = dict(lr_config)
             policy = cfg.pop('policy', 'step')
@@ -754,6 +810,11 @@ class _RunnerBase(object):
             self.register_hook(CheckpointHook(**cfg))
         for h in (custom_hooks or []):
             self.register_hook(h)
+        if log_config is not None:
+            for h in log_config.get('hooks', []):
+                cfg = dict(h)
+                cfg.setdefault('interval', log_config.get('interval', 10))
+                self.register_hook(build_from_cfg(cfg, HOOKS), late=True)
 
     def call_hook(self, name):
         for h in self._hooks:
@@ -771,23 +832,34 @@ class _RunnerBase(object):
             for k, v in lv.items():
                 buf.setdefault(k, []).append(v)
 
-    def _settle_lazy_logs(self):
-        """With more than one rank the logged values are averaged by a collective when they are first read
-        (base_detector.LazyLogVars): every rank reads them here, at the same point of the iteration (behind the hooks, i.e.
-        behind the issued backward pass) — a reader that only exists on rank 0 (a logger, bench.py) must not be the one that
-        starts the all-reduce."""
+    @staticmethod
+    def _several_ranks():
         import torch.distributed as dist
-        if self._lazy_logs and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self.log_buffer
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _fold(self, lazy):
+        for k, v in lazy.items():                # (first access computes the values: LazyLogVars._fill)
+            self._log_buffer.setdefault(k, []).append(v)
+
+    def _settle_lazy_logs(self):
+        """With more than one rank the logged values are averaged by a collective when they are computed
+        (base_detector.LazyLogVars._fill): every rank computes them HERE — the runner calls this behind the hooks of every
+        iteration (i.e. behind the issued backward pass), a hook that wants the current iteration's values calls it first, on
+        every rank (TextLoggerHook).  Reading `log_buffer` never starts that collective: a reader that only exists on rank 0
+        (the printing half of a logger, bench.py) would start it alone, or in another place of the collective order."""
+        if self._lazy_logs and self._several_ranks():
+            pending, self._lazy_logs = self._lazy_logs, []
+            for lv in pending:
+                self._fold(lv)
 
     @property
     def log_buffer(self):
-        """{key: [value per iteration]}; lazily parsed log_vars of finished iterations are folded in on access."""
-        if self._lazy_logs:
+        """{key: [value per iteration]}; lazily parsed log_vars of finished iterations are folded in on access — with one
+        rank.  With several ranks only `_settle_lazy_logs` folds them (see there)."""
+        if self._lazy_logs and not self._several_ranks():
             pending, self._lazy_logs = self._lazy_logs, []
             for lv in pending:
-                for k, v in lv.items():
-                    self._log_buffer.setdefault(k, []).append(v)
+                self._fold(lv)
         return self._log_buffer
 
     @log_buffer.setter

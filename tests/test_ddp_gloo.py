@@ -400,10 +400,22 @@ def _lazy_log_worker(rank, world, port, q):
                                         'student.detector_3d': dict(type='SGD', lr=0.01, step_interval=1)})
         run = R.IterBasedSSLRunner(model, optimizer=opt, max_iters=3)
         # no gradient clipping: the OptimizerHook then never reads the log buffer, nobody reads it on rank 1 at all
-        run.register_training_hooks(lr_config=dict(policy='step', step=[]), optimizer_config=dict(grad_clip=None))
+        run.register_training_hooks(lr_config=dict(policy='step', step=[]), optimizer_config=dict(grad_clip=None),
+                                    log_config=dict(interval=2, hooks=[dict(type='TextLoggerHook')]))
+
+        class Collective(R.Hook):                  # a hook with a collective of its own, registered AFTER the logger (EvalHook)
+            def after_train_iter(self, runner):
+                from detmatch_amd.mm3d.parallel import all_gather_object
+                assert all_gather_object(runner.iter) == [runner.iter] * world
+        run.register_hook(Collective())
+        assert [type(h).__name__ for h in run._hooks][-2:] == ['Collective', 'TextLoggerHook']      # loggers stay last
         lab = [dict(stu=torch.full((4, 2), float(rank + 1)), img_metas=[0, 1])]
         run.run([lab, lab], [('train', 1)])
         assert not run._lazy_logs                  # settled on every rank, every iteration (one all-reduce each)
+        logger = run._hooks[-1]
+        assert len(logger.lines) == (1 if rank == 0 else 0)          # iteration 2 of 3; only rank 0 writes
+        if rank == 0:
+            assert logger.lines[0].startswith('Iter [2/3]') and 'metrics.b: 1.5000' in logger.lines[0], logger.lines
         if rank == 0:                              # a reader that exists on one rank only (a logger, bench.py)
             vals = [float(v) for v in run.log_buffer['metrics.b']]
             assert vals == pytest.approx([1.5, 1.5, 1.5])          # mean of the ranks' 1.0 and 2.0

@@ -615,3 +615,23 @@ def test_issue_order_is_decided_in_one_place(monkeypatch):
         assert m.early_backward and m.side_wgrad and m.share_2d_trunk and m.after_partial_backward == ddp.collect
         assert m.two_lanes == (lanes == '1') and m.lane_mode == (None if lanes == '1' else 'glue')
         assert run.draw_ahead == (lanes == '1') and run.lookahead == (False if lanes == '1' else before)
+
+
+def test_text_logger_writes_one_line_per_interval(capsys):
+    """runner.TextLoggerHook from log_config (split_0.py: log_config = dict(interval=50, hooks=[TextLoggerHook, ...])): window
+    means of the logged values, the learning rates, behind every other hook."""
+    torch.manual_seed(0)
+    model = _Toy()
+    run = R.IterBasedSSLRunner(model, optimizer=R.build_optimizer(model, OPT_CFG), max_iters=4)
+    run.register_training_hooks(lr_config=dict(policy='step', step=[]), optimizer_config=dict(grad_clip=dict(max_norm=10, norm_type=2)),
+                                log_config=dict(interval=2, hooks=[dict(type='TextLoggerHook'), dict(type='WandbLoggerHook')]),
+                                custom_hooks=[dict(type='ModelIterEpochHook')])
+    lab = [dict(stu=torch.randn(4, 2), img_metas=[0, 1])] * 2
+    run.run([lab, lab], [('train', 1)])
+    names = [type(h).__name__ for h in run._hooks]
+    assert names[-2:] == ['TextLoggerHook', 'WandbLoggerHook'] and names.index('OptimizerHook') < names.index('TextLoggerHook')
+    lines = run._hooks[-2].lines
+    assert len(lines) == 2 and lines[0].startswith('Iter [2/4]') and lines[1].startswith('Iter [4/4]')
+    want = float(torch.stack([v.float() for v in run.log_buffer['loss'][2:4]]).mean())
+    assert 'loss: %.4f' % want in lines[1] and 'grad_norm: ' in lines[1] and 'lr: ' in lines[1] and 'time: ' in lines[1]
+    assert lines[1] in capsys.readouterr().out
