@@ -130,15 +130,40 @@ __global__ __launch_bounds__(256) void sgd_f32_kernel(float *__restrict__ p,
     first = (long long)f == step;
   }
   const int cnt = (int)(n - i < 4 ? n - i : 4);
-  for (int k = 0; k < cnt; ++k) {
-    const float pk = p[i + k];
-    float d = g[i + k] * gs + wd * pk;                       // grad.add(param, alpha=wd)
-    if (momentum != 0.0f) {
-      const float b = first ? d : buf[i + k] * momentum + d * (1.0f - dampening);
-      buf[i + k] = b;
+  const bool mom = momentum != 0.0f;
+  // whole 16-byte groups as float4 when the three arrays are 16-byte aligned (the arenas are): the scalar form of this
+  // kernel ran at half the bandwidth of adamw_f32_kernel (317 us for the 41 M parameters of the 2D student: 2.6 TB/s)
+  const bool vec = cnt == 4 && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)(mom ? buf : p)) & 15) == 0);
+  float pv[4], gv[4], bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    *(float4 *)pv = *(const float4 *)(p + i);
+    *(float4 *)gv = *(const float4 *)(g + i);
+    if (mom && !first) *(float4 *)bv = *(const float4 *)(buf + i);
+  } else {
+    for (int k = 0; k < cnt; ++k) {
+      pv[k] = p[i + k], gv[k] = g[i + k];
+      if (mom && !first) bv[k] = buf[i + k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float pk = pv[k];
+    float d = gv[k] * gs + wd * pk;                          // grad.add(param, alpha=wd)
+    if (mom) {
+      const float b = first ? d : bv[k] * momentum + d * (1.0f - dampening);
+      bv[k] = b;
       d = b;
     }
-    p[i + k] = pk - lr * d;
+    pv[k] = pk - lr * d;
+  }
+  if (vec) {
+    *(float4 *)(p + i) = *(float4 *)pv;
+    if (mom) *(float4 *)(buf + i) = *(float4 *)bv;
+  } else {
+    for (int k = 0; k < cnt; ++k) {
+      p[i + k] = pv[k];
+      if (mom) buf[i + k] = bv[k];
+    }
   }
 }
 
