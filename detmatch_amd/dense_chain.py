@@ -133,7 +133,7 @@ class _Weights(object):
         if self.pack_rows:
             t = DeviceTable(np.array(self.pack_rows, dtype=_PACK_DESC), self.device)
             self.keep.append(t)
-            prog.call('dm_dconv_pack_batch', t.dev, t.n, max(1, min(256, self.max_pack // 2048)), Program.STREAM)
+            prog.call('dm_dconv_pack_batch', t.dev, t.n, max(1, min(dense_conv.PACK_BLOCKS_CAP, self.max_pack // 2048)), Program.STREAM)
         for c in self.calls:
             prog.call(*c)
         self.prog = prog.finalize()

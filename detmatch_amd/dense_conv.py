@@ -172,6 +172,9 @@ class _Packed(object):
     __slots__ = ('ver', 'dst', 'src', 'wref', 'scale_n', 'scale_k', 'desc', 'batchable', 'stream')
 
 
+# workgroups per table row of dm_dconv_pack_batch (every row gets as many as the LARGEST one needs at 2 048 elements each, up to this)
+PACK_BLOCKS_CAP = int(os.environ.get('DM_PACK_BLOCKS_CAP', '1024'))    # 256: 207 us per launch, 1024: 176, 4096: 168 (profiles/r06_ab_step_variants.txt)
+
 # 80-byte rows of dm_dconv_pack_batch (csrc/conv2d.hip: DConvPackDesc)
 _DESC = None
 _TABLES = {}      # HIP stream -> {'entries': [...], 'table': device tensor or None}
@@ -220,7 +223,7 @@ def _refresh_stream(stream, device):
             rows = np.zeros(len(dirty), dtype=_desc_dtype())
             for i, e in enumerate(dirty):
                 rows[i] = e.desc[:-1]
-            blocks = max(1, min(256, max(e.dst.numel() for e in dirty) // 2048))
+            blocks = max(1, min(PACK_BLOCKS_CAP, max(e.dst.numel() for e in dirty) // 2048))
             hit = tables[sig] = (torch.from_numpy(rows.view(np.uint8)).to(device), blocks, list(dirty))
         _lib.check(_lib.lib().dm_dconv_pack_batch(hit[0].data_ptr(), len(dirty), hit[1], _lib.raw_stream()),
                    'dm_dconv_pack_batch')
