@@ -1272,8 +1272,13 @@ extern "C" int dm_group_rows_grad(int batch, int m, int c, int n, int nsample, i
     attr = true;
   }
   if (m >= 16384 && g_gp_grad_combine) {
-    int chunk = dm_ceil_div(m, 256);
-    chunk = chunk < 32 ? 32 : (chunk > 256 ? 256 : chunk);
+    // Queries per workgroup.  Round 6: ~4 096 workgroups instead of 256 (one per CU): a wave keeps four 512-byte rows in
+    // flight, so 1 024 waves hold 2 MB — the RoI-grid-pooling call (55 296 x 16 references of 128 floats) read its rows at
+    // 0.9-1.4 TB/s; with 14 queries per workgroup 149 instead of 513 us on a synthetic RoI geometry (3.0 TB/s,
+    // tools/bench_group_grad.py), more atomic rows per key point notwithstanding.  DM_GRG_WGS: A/B switch.
+    static const int target_wgs = [] { const char *e = getenv("DM_GRG_WGS"); const int v = e ? atoi(e) : 4096; return v < 1 ? 1 : v; }();
+    int chunk = dm_ceil_div(m, target_wgs);
+    chunk = chunk < 8 ? 8 : (chunk > 256 ? 256 : chunk);
     int n_slots = 1024;                       // open-addressing table of distinct source rows
     size_t lds = ((size_t)(3 * n_slots + 1) * 4 + (size_t)chunk * nsample * 4 + 15) & ~(size_t)15;
     if (chunk * nsample <= 65535 && lds <= 64 * 1024) {
